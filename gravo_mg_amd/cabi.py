@@ -1,0 +1,398 @@
+"""ctypes binding of the C-ABI in include/gravomg_hip.h (libgravomg_hip.so).
+
+This is the thinnest possible Python view of the boundary: numpy / scipy arrays in, numpy arrays out,
+every status code turned into an exception carrying gmg_last_error().  There is no CPU fallback: if the
+shared library is missing the import of :func:`lib` fails loudly, and every device entry point raises
+``GmgError`` (GMG_ERR_NO_DEVICE) on a box without a HIP device.
+
+Sparse matrices cross the boundary in the reference's own storage, CSC with int32 sorted indices
+(Eigen::SparseMatrix<double>; gravomg_bindings/src/cpp/core.cpp:4 and pybind11's sparse caster).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgravomg_hip.so")
+
+GMG_OK, GMG_ERR_INVALID, GMG_ERR_NO_DEVICE, GMG_ERR_HIP, GMG_ERR_STATE, GMG_ERR_NUMERIC, GMG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+SMOOTHER_MULTICOLOR_GS, SMOOTHER_JACOBI = 0, 1
+COARSE_HOST_LDLT, COARSE_DEVICE_INVERSE = 0, 1
+
+_STATUS_NAMES = {
+    -1: "GMG_ERR_INVALID", -2: "GMG_ERR_NO_DEVICE", -3: "GMG_ERR_HIP", -4: "GMG_ERR_STATE",
+    -5: "GMG_ERR_NUMERIC", -6: "GMG_ERR_UNSUPPORTED",
+}
+
+
+class GmgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class GmgConfig(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("smoother", C.c_int), ("jacobi_omega", C.c_double), ("pre_iters", C.c_int),
+        ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
+        ("row_align", C.c_int), ("host_threads", C.c_int), ("verbose", C.c_int),
+    ]
+
+
+class GmgHierarchyOptions(C.Structure):
+    _fields_ = [
+        ("ratio", C.c_double), ("lower_bound", C.c_int), ("check_voronoi", C.c_int), ("nested", C.c_int),
+        ("sampling", C.c_int), ("weighting", C.c_int),
+    ]
+
+
+_ip = C.POINTER(C.c_int)
+_dp = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes).  Must list every symbol include/gravomg_hip.h declares
+# (tests/test_cabi_symbols.py checks this table against the header).
+SIGNATURES = {
+    "gmg_config_default": (C.c_int, [C.POINTER(GmgConfig)]),
+    "gmg_create": (C.c_int, [C.POINTER(GmgConfig), C.POINTER(_vp)]),
+    "gmg_destroy": (None, [_vp]),
+    "gmg_last_error": (C.c_char_p, [_vp]),
+    "gmg_device_count": (C.c_int, []),
+    "gmg_set_num_levels": (C.c_int, [_vp, C.c_int]),
+    "gmg_set_prolongation": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _ip, _ip, _dp]),
+    "gmg_set_mass": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_set_system": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
+    "gmg_num_levels": (C.c_int, [_vp]),
+    "gmg_level_info": (C.c_int, [_vp, C.c_int, _ip, C.POINTER(C.c_int64), _ip, _ip]),
+    "gmg_get_level_operator": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
+    "gmg_get_level_ordering": (C.c_int, [_vp, C.c_int, _ip, _ip]),
+    "gmg_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "gmg_smooth": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int]),
+    "gmg_residual": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
+    "gmg_spmv": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp]),
+    "gmg_restrict": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp]),
+    "gmg_prolong_add": (C.c_int, [_vp, C.c_int, _dp, C.c_int, _dp]),
+    "gmg_coarse_solve": (C.c_int, [_vp, _dp, C.c_int, _dp]),
+    "gmg_residual_norm": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp]),
+    "gmg_vcycle": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "gmg_solve": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _ip, _dp, _dp]),
+    "gmg_load_problem": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "gmg_run_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "gmg_fetch_solution": (C.c_int, [_vp, _dp]),
+    "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
+    "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
+    "gmg_hierarchy_build": (C.c_int, [_dp, C.c_int, _ip, C.c_int, C.POINTER(GmgHierarchyOptions), C.POINTER(_vp)]),
+    "gmg_hierarchy_destroy": (None, [_vp]),
+    "gmg_hierarchy_num_levels": (C.c_int, [_vp]),
+    "gmg_hierarchy_level_shape": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
+    "gmg_hierarchy_get_prolongation": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
+    "gmg_hierarchy_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
+    "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libgravomg_hip.so (built in-tree by gravo_mg_amd/csrc/build.sh).  Fails loudly if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with gravo_mg_amd/csrc/build.sh (or __graft_entry__.build()). "
+                "gravo_mg_amd has no CPU fallback for the device path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def device_count() -> int:
+    return int(lib().gmg_device_count())
+
+
+def _f64(a, shape2d: bool = True) -> np.ndarray:
+    """Column-major (Fortran) float64 n x d view/copy of a vector or matrix."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a[:, None]
+    return np.asfortranarray(a)
+
+
+def _csc(m) -> sp.csc_matrix:
+    m = sp.csc_matrix(m)
+    if not m.has_sorted_indices:
+        m = m.copy()
+        m.sort_indices()
+    m.sum_duplicates()
+    if m.indptr.dtype != np.int32 or m.indices.dtype != np.int32:
+        if m.nnz >= 2**31:
+            raise ValueError("matrix too large for int32 indices")
+        m = sp.csc_matrix((m.data, m.indices.astype(np.int32), m.indptr.astype(np.int32)), shape=m.shape)
+    if m.data.dtype != np.float64:
+        m = m.astype(np.float64)
+    return m
+
+
+def _pi(a: np.ndarray):
+    return a.ctypes.data_as(_ip)
+
+
+def _pd(a: np.ndarray):
+    return a.ctypes.data_as(_dp)
+
+
+class Hierarchy:
+    """Graph-Voronoi prolongation hierarchy built on the host (gmg_hierarchy_build).
+
+    Mirrors what ``MGBS::MultigridSolver::buildHierarchy`` produces: ``U`` (list of scipy CSC matrices,
+    n_k x n_{k+1}) and the reference's ``hierarchyTiming`` keys."""
+
+    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0):
+        l = lib()
+        pos = np.ascontiguousarray(pos, dtype=np.float64)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        if pos.ndim != 2 or pos.shape[1] != 3 or neigh.ndim != 2 or neigh.shape[0] != pos.shape[0]:
+            raise ValueError("pos must be n x 3 and neigh n x K")
+        opt = GmgHierarchyOptions()
+        l.gmg_hierarchy_options_default(C.byref(opt))
+        opt.ratio, opt.lower_bound, opt.check_voronoi, opt.nested = float(ratio), int(lower_bound), int(bool(check_voronoi)), int(bool(nested))
+        opt.sampling, opt.weighting = int(sampling), int(weighting)
+        self._h = _vp()
+        rc = l.gmg_hierarchy_build(_pd(pos), pos.shape[0], _pi(neigh), neigh.shape[1], C.byref(opt), C.byref(self._h))
+        if rc:
+            raise GmgError(rc, "gmg_hierarchy_build failed (only Sampling.FASTDISK is supported)" if rc == GMG_ERR_UNSUPPORTED else "gmg_hierarchy_build failed")
+        self.U: List[sp.csc_matrix] = []
+        for k in range(l.gmg_hierarchy_num_levels(self._h)):
+            nf, nc, nnz = C.c_int(), C.c_int(), C.c_int()
+            l.gmg_hierarchy_level_shape(self._h, k, C.byref(nf), C.byref(nc), C.byref(nnz))
+            colptr = np.empty(nc.value + 1, np.int32); rowidx = np.empty(nnz.value, np.int32); val = np.empty(nnz.value, np.float64)
+            l.gmg_hierarchy_get_prolongation(self._h, k, _pi(colptr), _pi(rowidx), _pd(val))
+            self.U.append(sp.csc_matrix((val, rowidx, colptr), shape=(nf.value, nc.value)))
+
+    def timing(self, key: str) -> float:
+        out = C.c_double()
+        rc = lib().gmg_hierarchy_get_timing(self._h, key.encode(), C.byref(out))
+        if rc:
+            raise KeyError(key)
+        return out.value
+
+    TIMING_KEYS = ("n_vertices", "hierarchy", "sampling", "cluster", "next_neighborhood", "next_positions",
+                   "triangle_finding", "triangle_selection", "PDS", "levels")
+
+    def timings(self) -> dict:
+        return {k: self.timing(k) for k in self.TIMING_KEYS}
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().gmg_hierarchy_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Engine:
+    """One gmg_handle: device-resident hierarchy + V-cycle on one HIP stream."""
+
+    def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
+                 coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, device=0, verbose=False):
+        l = lib()
+        cfg = GmgConfig()
+        l.gmg_config_default(C.byref(cfg))
+        cfg.device, cfg.smoother, cfg.jacobi_omega = int(device), int(smoother), float(jacobi_omega)
+        cfg.pre_iters, cfg.post_iters, cfg.coarse_mode = int(pre_iters), int(post_iters), int(coarse_mode)
+        cfg.use_graph, cfg.sigma, cfg.row_align, cfg.verbose = int(bool(use_graph)), int(sigma), int(row_align), int(bool(verbose))
+        self._h = _vp()
+        rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
+        if rc:
+            raise GmgError(rc, "gmg_create failed (invalid configuration)")
+        self._n0 = None
+        self._sizes: List[int] = []
+
+    # -- plumbing
+    def _chk(self, rc: int):
+        if rc:
+            raise GmgError(rc, lib().gmg_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().gmg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- hierarchy input
+    def set_prolongations(self, U: Sequence):
+        l = lib()
+        self._chk(l.gmg_set_num_levels(self._h, len(U)))
+        self._sizes = []
+        for k, u in enumerate(U):
+            u = _csc(u)
+            self._chk(l.gmg_set_prolongation(self._h, k, u.shape[0], u.shape[1], _pi(u.indptr), _pi(u.indices), _pd(u.data)))
+            if k == 0:
+                self._sizes.append(u.shape[0])
+            self._sizes.append(u.shape[1])
+
+    def use_hierarchy(self, hier: Hierarchy):
+        self._chk(lib().gmg_use_hierarchy(self._h, hier._h))
+        self._sizes = [hier.U[0].shape[0]] + [u.shape[1] for u in hier.U] if hier.U else []
+
+    def set_mass(self, mass_diag):
+        m = np.ascontiguousarray(mass_diag, dtype=np.float64).ravel()
+        self._chk(lib().gmg_set_mass(self._h, m.shape[0], _pd(m)))
+
+    def set_system(self, lhs):
+        a = _csc(lhs)
+        if a.shape[0] != a.shape[1]:
+            raise ValueError("lhs must be square")
+        self._chk(lib().gmg_set_system(self._h, a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data)))
+        self._n0 = a.shape[0]
+
+    # -- introspection
+    @property
+    def num_levels(self) -> int:
+        return int(lib().gmg_num_levels(self._h))
+
+    def level_info(self, k: int) -> dict:
+        n, nnz, nc, npad = C.c_int(), C.c_int64(), C.c_int(), C.c_int()
+        self._chk(lib().gmg_level_info(self._h, k, C.byref(n), C.byref(nnz), C.byref(nc), C.byref(npad)))
+        return {"n": n.value, "nnz": nnz.value, "n_colors": nc.value, "n_pad": npad.value}
+
+    def level_operator(self, k: int) -> sp.csc_matrix:
+        info = self.level_info(k)
+        colptr = np.empty(info["n"] + 1, np.int32); rowidx = np.empty(info["nnz"], np.int32); val = np.empty(info["nnz"], np.float64)
+        self._chk(lib().gmg_get_level_operator(self._h, k, _pi(colptr), _pi(rowidx), _pd(val)))
+        return sp.csc_matrix((val, rowidx, colptr), shape=(info["n"], info["n"]))
+
+    def level_ordering(self, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        info = self.level_info(k)
+        new2old = np.empty(info["n_pad"], np.int32); cb = np.empty(info["n_colors"] + 1, np.int32)
+        self._chk(lib().gmg_get_level_ordering(self._h, k, _pi(new2old), _pi(cb)))
+        return new2old, cb
+
+    def timing(self, key: str) -> float:
+        out = C.c_double()
+        self._chk(lib().gmg_get_timing(self._h, key.encode(), C.byref(out)))
+        return out.value
+
+    # -- operators
+    def _level_n(self, k: int) -> int:
+        return self.level_info(k)["n"]
+
+    @staticmethod
+    def _shape_like(out: np.ndarray, ref) -> np.ndarray:
+        return out[:, 0].copy() if np.asarray(ref).ndim == 1 else out
+
+    def smooth(self, k, b, x, iters):
+        B, X = _f64(b), _f64(x).copy(order="F")
+        self._chk(lib().gmg_smooth(self._h, k, _pd(B), _pd(X), B.shape[1], int(iters)))
+        return self._shape_like(X, x)
+
+    def residual(self, k, b, x):
+        B, X = _f64(b), _f64(x)
+        R = np.empty_like(B, order="F")
+        self._chk(lib().gmg_residual(self._h, k, _pd(B), _pd(X), B.shape[1], _pd(R)))
+        return self._shape_like(R, x)
+
+    def spmv(self, k, x):
+        X = _f64(x)
+        Y = np.empty_like(X, order="F")
+        self._chk(lib().gmg_spmv(self._h, k, _pd(X), X.shape[1], _pd(Y)))
+        return self._shape_like(Y, x)
+
+    def restrict(self, k, r):
+        R = _f64(r)
+        RC = np.empty((self._level_n(k + 1), R.shape[1]), order="F")
+        self._chk(lib().gmg_restrict(self._h, k, _pd(R), R.shape[1], _pd(RC)))
+        return self._shape_like(RC, r)
+
+    def prolong_add(self, k, e, x):
+        E, X = _f64(e), _f64(x).copy(order="F")
+        self._chk(lib().gmg_prolong_add(self._h, k, _pd(E), E.shape[1], _pd(X)))
+        return self._shape_like(X, x)
+
+    def coarse_solve(self, rc):
+        R = _f64(rc)
+        E = np.empty_like(R, order="F")
+        self._chk(lib().gmg_coarse_solve(self._h, _pd(R), R.shape[1], _pd(E)))
+        return self._shape_like(E, rc)
+
+    def residual_norm(self, b, x, type=2) -> float:
+        B, X = _f64(b), _f64(x)
+        out = C.c_double()
+        self._chk(lib().gmg_residual_norm(self._h, _pd(B), _pd(X), B.shape[1], int(type), C.byref(out)))
+        return out.value
+
+    # -- hot path
+    def vcycle(self, b, x):
+        B, X = _f64(b), _f64(x).copy(order="F")
+        self._chk(lib().gmg_vcycle(self._h, _pd(B), _pd(X), B.shape[1]))
+        return self._shape_like(X, x)
+
+    def solve(self, rhs, x0=None, tol=1e-4, stop_type=2, max_iter=100):
+        """Returns (x, iterations, residue, convergence[(ms, residue), ...]).  x0 defaults to rhs
+        (gravomg_bindings/src/cpp/core.cpp:69)."""
+        B = _f64(rhs)
+        X = B.copy(order="F") if x0 is None else _f64(x0).copy(order="F")
+        iters, res = C.c_int(), C.c_double()
+        conv = np.zeros(2 * max(int(max_iter), 1))
+        self._chk(lib().gmg_solve(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
+                                  C.byref(iters), C.byref(res), _pd(conv)))
+        return self._shape_like(X, rhs), iters.value, res.value, conv[: 2 * iters.value].reshape(-1, 2)
+
+    def load_problem(self, b, x0):
+        B, X = _f64(b), _f64(x0)
+        self._chk(lib().gmg_load_problem(self._h, _pd(B), _pd(X), B.shape[1]))
+        self._loaded_shape = (B.shape[0], B.shape[1])
+
+    def run_cycles(self, n_cycles: int, stop_type: int = 2) -> np.ndarray:
+        res = np.zeros(max(int(n_cycles), 1))
+        self._chk(lib().gmg_run_cycles(self._h, int(n_cycles), int(stop_type), _pd(res)))
+        return res[: int(n_cycles)]
+
+    def fetch_solution(self) -> np.ndarray:
+        X = np.empty(self._loaded_shape, order="F")
+        self._chk(lib().gmg_fetch_solution(self._h, _pd(X)))
+        return X
+
+    # -- measurement
+    def bench_kernel(self, kind: int, k: int, d: int, reps: int) -> Tuple[float, int]:
+        ms, launches = C.c_double(), C.c_int()
+        self._chk(lib().gmg_bench_kernel(self._h, int(kind), int(k), int(d), int(reps), C.byref(ms), C.byref(launches)))
+        return ms.value, launches.value
+
+    def algorithmic_bytes(self, kind: int, k: int, d: int) -> float:
+        out = C.c_double()
+        self._chk(lib().gmg_algorithmic_bytes(self._h, int(kind), int(k), int(d), C.byref(out)))
+        return out.value
+
+
+def host_galerkin(A, U) -> sp.csc_matrix:
+    """Ac = U^T A U on the host (the product engine's RAP, exposed for parity tests)."""
+    a, u = _csc(A), _csc(U)
+    nc = u.shape[1]
+    colptr = np.zeros(nc + 1, np.int32)
+    rc = lib().gmg_host_galerkin(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), nc, _pi(u.indptr), _pi(u.indices), _pd(u.data),
+                                 _pi(colptr), None, None)
+    if rc:
+        raise GmgError(rc, "gmg_host_galerkin")
+    nnz = int(colptr[nc])
+    rowidx = np.empty(nnz, np.int32); val = np.empty(nnz, np.float64)
+    lib().gmg_host_galerkin(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), nc, _pi(u.indptr), _pi(u.indices), _pd(u.data),
+                            _pi(colptr), _pi(rowidx), _pd(val))
+    return sp.csc_matrix((val, rowidx, colptr), shape=(nc, nc))

@@ -1,0 +1,978 @@
+// engine.hip -- libgravomg_hip.so: device state, launch sequences and the C-ABI of include/gravomg_hip.h.
+//
+// One handle = one HIP device, one stream.  The hierarchy (all A_k as SELL-64 + diagonal, all U_k / U_k^T)
+// is uploaded once per system (gmg_set_system); a V-cycle is a fixed launch sequence on that stream
+// (smooth -> residual -> restrict ... coarse solve ... prolong-add -> smooth), captured into hipGraphs and
+// replayed.  The coarsest direct solve stays on the host (sparse LDL^T, host_ldlt.hpp) unless
+// GMG_COARSE_DEVICE_INVERSE is selected.
+//
+// Reference call sites this replaces: gravomg/src/multigrid_solver.cpp:1059-1088 (V-cycle),
+// :1194-1226 (smoother), :1228-1277 (norms), :1387-1419 (solve loop).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gravomg_hip.h"
+#include "host_hierarchy.hpp"
+#include "host_ldlt.hpp"
+#include "host_plan.hpp"
+#include "host_sparse.hpp"
+#include "kernels.hip.hpp"
+
+using namespace gmg;
+using clk = std::chrono::steady_clock;
+static inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+namespace {
+
+struct DevSell {
+    int n_slices = 0;
+    int64_t stored = 0, nnz_real = 0;
+    int64_t* slice_ptr = nullptr;
+    int* col = nullptr;
+    double* val = nullptr;
+    int* row_of = nullptr;
+};
+
+struct Level {
+    int n = 0, n_pad = 0;
+    LevelOrdering ord;
+    Compressed A;                 // natural numbering, host copy (Abar[k])
+    DevSell Aoff;                 // off-diagonal part, device numbering
+    double* diag = nullptr;       // n_pad
+    DevSell P, R;                 // U_k (rows: this level) and U_k^T (rows: next level); unused on level L
+    int* d_new2old = nullptr;
+    double *x = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;   // n_pad * dcap
+};
+
+}  // namespace
+
+struct gmg_hierarchy_s {
+    HierarchyResult res;
+};
+
+struct gmg_solver_s {
+    gmg_config cfg;
+    std::string err;
+    bool has_device = false;
+    hipStream_t stream = nullptr;
+    int L = -1;
+    std::vector<Compressed> U;
+    std::vector<char> U_set;
+    std::vector<double> mass;
+    std::vector<Level> lv;
+    SparseLDLT coarse;
+    bool system_ready = false;
+    int dcap = 0;
+    double *d_mass = nullptr, *d_minv = nullptr;
+    double* d_stage = nullptr; size_t stage_cap = 0;
+    double* d_partials = nullptr; int partial_blocks = 0;
+    double* d_norm = nullptr;
+    double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
+    double* h_norm = nullptr;
+    double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
+    std::vector<double> coarse_work;
+    std::map<std::string, double> timing;
+    std::map<int, hipGraphExec_t> graphs;
+    int loaded_d = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(gmg_handle h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail(h, GMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_DEVICE()                                                                     \
+    do {                                                                                  \
+        if (!h) return GMG_ERR_INVALID;                                                   \
+        if (!h->has_device) return fail(h, GMG_ERR_NO_DEVICE, "no usable HIP device (libgravomg_hip has no CPU fallback)"); \
+    } while (0)
+
+template <class T>
+int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
+void free_sell(DevSell& s) {
+    if (s.slice_ptr) (void)hipFree(s.slice_ptr);
+    if (s.col) (void)hipFree(s.col);
+    if (s.val) (void)hipFree(s.val);
+    if (s.row_of) (void)hipFree(s.row_of);
+    s = DevSell();
+}
+
+int upload_sell(gmg_handle h, DevSell& d, const SellHost& s) {
+    free_sell(d);
+    d.n_slices = s.n_slices; d.stored = s.stored(); d.nnz_real = s.nnz_real;
+    int rc;
+    if ((rc = upload(h, &d.slice_ptr, s.slice_ptr))) return rc;
+    if ((rc = upload(h, &d.col, s.col))) return rc;
+    if ((rc = upload(h, &d.val, s.val))) return rc;
+    if (!s.row_of.empty() && (rc = upload(h, &d.row_of, s.row_of))) return rc;
+    return GMG_OK;
+}
+
+void free_level(Level& l) {
+    free_sell(l.Aoff); free_sell(l.P); free_sell(l.R);
+    for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (l.d_new2old) { (void)hipFree(l.d_new2old); l.d_new2old = nullptr; }
+}
+
+void drop_graphs(gmg_handle h) {
+    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+void drop_system(gmg_handle h) {
+    drop_graphs(h);
+    for (auto& l : h->lv) free_level(l);
+    h->lv.clear();
+    h->system_ready = false;
+    h->dcap = 0;
+    h->loaded_d = 0;
+    if (h->d_mass) { (void)hipFree(h->d_mass); h->d_mass = nullptr; }
+    if (h->d_minv) { (void)hipFree(h->d_minv); h->d_minv = nullptr; }
+    if (h->d_ainv) { (void)hipFree(h->d_ainv); h->d_ainv = nullptr; }
+}
+
+inline int grid_for(int n_slices) {
+    int g = (n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
+    return (g + 7) / 8 * 8;    // multiple of 8 so the XCD swizzle is a bijection
+}
+
+// ---- launch helpers (all on h->stream; column chunks of <= 4) ----------------------------------------
+
+#define DISPATCH_D(dc, ...)              \
+    switch (dc) {                        \
+        case 1: { constexpr int D = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int D = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int D = 3; __VA_ARGS__; } break; \
+        default: { constexpr int D = 4; __VA_ARGS__; } break; \
+    }
+
+void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const int ld = l.n_pad;
+    for (int it = 0; it < iters; ++it)
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            for (int c = 0; c < l.ord.n_colors; ++c) {
+                int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
+                if (se <= sb) continue;
+                DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::gs_color<D>, dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                  l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
+                                                  l.x + (size_t)c0 * ld, ld, sb, se, 1));
+            }
+        }
+}
+
+void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const int ld = l.n_pad;
+    double* in = l.x; double* out = l.tmp;
+    for (int it = 0; it < iters; ++it) {
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::jacobi_sweep<D>, dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
+                                              in + (size_t)c0 * ld, out + (size_t)c0 * ld, ld, l.Aoff.n_slices, h->cfg.jacobi_omega, 1));
+        }
+        std::swap(in, out);
+    }
+    if (in != l.x) (void)hipMemcpyAsync(l.x, in, sizeof(double) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+}
+
+void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
+    if (iters <= 0) return;
+    if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps(h, l, d, iters);
+    else launch_gs_sweeps(h, l, d, iters);
+}
+
+// y = A x (mode 0) or y = b - A x (mode 1)
+void launch_spmv(gmg_handle h, Level& l, int d, int mode, const double* b, const double* x, double* y) {
+    const int ld = l.n_pad;
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        if (mode == 1) {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, b + (size_t)c0 * ld, x + (size_t)c0 * ld,
+                                              y + (size_t)c0 * ld, ld, l.Aoff.n_slices, 1));
+        } else {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 0>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, (const double*)nullptr, x + (size_t)c0 * ld,
+                                              y + (size_t)c0 * ld, ld, l.Aoff.n_slices, 1));
+        }
+    }
+}
+
+// coarse.b = U^T fine.r
+void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 0>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                          fine.R.slice_ptr, fine.R.col, fine.R.val, fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
+                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, fine.R.n_slices, 1));
+    }
+}
+
+// fine.x += U coarse.x
+void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                          fine.P.slice_ptr, fine.P.col, fine.P.val, (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
+                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, fine.P.n_slices, 1));
+    }
+}
+
+// sums of w r^2 / w b^2 per column -> h_norm[2*d] (after the caller synchronises the stream)
+int launch_norm(gmg_handle h, int d, int type) {
+    Level& l = h->lv[0];
+    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
+    const int nblk = (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+                                          l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
+                                          l.n_pad, l.Aoff.n_slices, h->d_partials));
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
+    }
+    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
+    return GMG_OK;
+}
+
+double norm_from_sums(const double* s, int d, int type) {
+    if (type == 3) {
+        double t = 0.0;
+        for (int c = 0; c < d; ++c) t += s[2 * c];
+        return std::sqrt(t);
+    }
+    double out = 0.0;
+    for (int c = 0; c < d; ++c) {
+        double v = type == 0 ? std::sqrt(s[2 * c]) / std::sqrt(s[2 * c + 1]) : std::sqrt(s[2 * c] / s[2 * c + 1]);
+        if (c == 0 || v > out) out = v;
+    }
+    return out;
+}
+
+int ensure_vectors(gmg_handle h, int d) {
+    if (d <= h->dcap) return GMG_OK;
+    drop_graphs(h);
+    for (auto& l : h->lv) {
+        for (double** p : {&l.x, &l.b, &l.r, &l.tmp}) {
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+            if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI) continue;
+            size_t bytes = sizeof(double) * (size_t)l.n_pad * d;
+            HIPCHK(hipMalloc((void**)p, bytes));
+            HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
+        }
+    }
+    Level& c = h->lv[h->L];
+    size_t need = (size_t)c.n_pad * d * 2;
+    if (need > h->pinned_cap) {
+        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+        HIPCHK(hipHostMalloc((void**)&h->h_pinned, sizeof(double) * need, hipHostMallocDefault));
+        h->pinned_cap = need;
+    }
+    if (h->h_norm) (void)hipHostFree(h->h_norm);
+    HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, hipHostMallocDefault));
+    if (h->d_norm) (void)hipFree(h->d_norm);
+    HIPCHK(hipMalloc((void**)&h->d_norm, sizeof(double) * 2 * d));
+    h->dcap = d;
+    h->loaded_d = 0;
+    return GMG_OK;
+}
+
+int ensure_stage(gmg_handle h, size_t n_doubles) {
+    if (n_doubles <= h->stage_cap) return GMG_OK;
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    HIPCHK(hipMalloc((void**)&h->d_stage, sizeof(double) * n_doubles));
+    h->stage_cap = n_doubles;
+    return GMG_OK;
+}
+
+// host natural n x d  ->  device numbering (level k) buffer
+int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
+    Level& l = h->lv[k];
+    int rc = ensure_stage(h, (size_t)l.n * d);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h->d_stage, src, sizeof(double) * (size_t)l.n * d, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(gmgk::permute_in, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.n, l.d_new2old, dst, l.n_pad, l.n_pad, d);
+    // the staging buffer is reused by the next call: order is guaranteed by the single stream
+    return GMG_OK;
+}
+
+int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
+    Level& l = h->lv[k];
+    int rc = ensure_stage(h, (size_t)l.n * d);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gmgk::permute_out, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, src, l.n_pad, l.n_pad, l.d_new2old, h->d_stage, l.n, d);
+    HIPCHK(hipMemcpyAsync(dst, h->d_stage, sizeof(double) * (size_t)l.n * d, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+// ---- V-cycle legs --------------------------------------------------------------------------------------
+
+void enqueue_down(gmg_handle h, int d) {
+    const int L = h->L;
+    for (int k = 0; k < L; ++k) {
+        Level& l = h->lv[k];
+        if (k > 0) (void)hipMemsetAsync(l.x, 0, sizeof(double) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
+        launch_smooth(h, l, d, h->cfg.pre_iters);                                                 // :1063
+        launch_spmv(h, l, d, 1, l.b, l.x, l.r);                                                   // :1066
+        launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b);                              // :1069
+    }
+}
+
+void enqueue_up(gmg_handle h, int d) {
+    for (int k = h->L - 1; k >= 0; --k) {
+        Level& l = h->lv[k];
+        launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);                           // :1082
+        launch_smooth(h, l, d, h->cfg.post_iters);                                                // :1085
+    }
+}
+
+void enqueue_coarse_device(gmg_handle h, int d) {
+    Level& c = h->lv[h->L];
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::dense_symv<D>, dim3((c.n + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock), dim3(gmgk::kBlock), 0,
+                                          h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad));
+    }
+}
+
+// Host coarsest solve (:1075): D2H rc, LDL^T back-substitution per column, H2D eps.
+int coarse_host_roundtrip(gmg_handle h, int d) {
+    Level& c = h->lv[h->L];
+    const size_t cnt = (size_t)c.n_pad * d;
+    double* rc = h->h_pinned;
+    double* e = h->h_pinned + cnt;
+    HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto t0 = clk::now();
+    std::memset(e, 0, sizeof(double) * cnt);
+    for (int col = 0; col < d; ++col) h->coarse.solve(rc + (size_t)col * c.n_pad, e + (size_t)col * c.n_pad, h->coarse_work.data());
+    h->timing["coarse_host_ms"] += ms_since(t0);
+    HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
+enum { G_DOWN = 1, G_UP = 2, G_FULL = 3 };
+
+template <class F>
+int run_graph(gmg_handle h, int key, F&& enqueue) {
+    if (!h->cfg.use_graph) { enqueue(); return GMG_OK; }
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        enqueue();
+        HIPCHK(hipStreamEndCapture(h->stream, &g));
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        it = h->graphs.emplace(key, ge).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, h->stream));
+    return GMG_OK;
+}
+
+// One V-cycle on the resident problem; with_norm >= 0 also enqueues the residual check of that type
+// (result in h_norm after the stream is synchronised by the caller).
+int vcycle_resident(gmg_handle h, int d, int norm_type) {
+    int rc;
+    const int nt = norm_type < 0 ? 9 : norm_type;
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
+        int err = GMG_OK;
+        rc = run_graph(h, G_FULL * 10000 + d * 10 + nt, [&] {
+            enqueue_down(h, d);
+            enqueue_coarse_device(h, d);
+            enqueue_up(h, d);
+            if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+        });
+        return rc ? rc : err;
+    }
+    if ((rc = run_graph(h, G_DOWN * 10000 + d * 10, [&] { enqueue_down(h, d); }))) return rc;
+    if ((rc = coarse_host_roundtrip(h, d))) return rc;
+    int err = GMG_OK;
+    rc = run_graph(h, G_UP * 10000 + d * 10 + nt, [&] {
+        enqueue_up(h, d);
+        if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+    });
+    return rc ? rc : err;
+}
+
+int check_level(gmg_handle h, int k, bool allow_coarsest) {
+    if (!h->system_ready) return fail(h, GMG_ERR_STATE, "no system set (call gmg_set_system first)");
+    if (k < 0 || k > h->L || (!allow_coarsest && k == h->L)) return fail(h, GMG_ERR_INVALID, "level index out of range");
+    return GMG_OK;
+}
+
+int check_norm_type(gmg_handle h, int type) {
+    if (type < 0 || type > 3) return fail(h, GMG_ERR_INVALID, "residual norm type must be 0..3");
+    if ((type == 1 || type == 2) && !h->d_mass) return fail(h, GMG_ERR_STATE, "mass matrix not set (gmg_set_mass) but an M-weighted norm was requested");
+    return GMG_OK;
+}
+
+}  // namespace
+
+// =========================================================================================================
+extern "C" {
+
+int gmg_config_default(gmg_config* cfg) {
+    if (!cfg) return GMG_ERR_INVALID;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0;
+    cfg->smoother = GMG_SMOOTHER_MULTICOLOR_GS;
+    cfg->jacobi_omega = 0.67;
+    cfg->pre_iters = 2;       // gravomg_bindings/src/gravomg/core.py:10
+    cfg->post_iters = 2;
+    cfg->coarse_mode = GMG_COARSE_HOST_LDLT;
+    cfg->use_graph = 1;
+    cfg->sigma = 1024;
+    cfg->row_align = 64;
+    cfg->host_threads = 0;
+    cfg->verbose = 0;
+    return GMG_OK;
+}
+
+int gmg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gmg_create(const gmg_config* cfg, gmg_handle* out) {
+    if (!out) return GMG_ERR_INVALID;
+    gmg_config c;
+    if (cfg) c = *cfg; else gmg_config_default(&c);
+    if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0) return GMG_ERR_INVALID;
+    gmg_handle h = new gmg_solver_s();
+    h->cfg = c;
+    if (h->cfg.host_threads <= 0) h->cfg.host_threads = hw_threads();
+    int ndev = gmg_device_count();
+    if (ndev > 0 && c.device >= 0 && c.device < ndev && hipSetDevice(c.device) == hipSuccess &&
+        hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess) {
+        h->has_device = true;
+        (void)hipEventCreate(&h->ev0);
+        (void)hipEventCreate(&h->ev1);
+    }
+    *out = h;
+    return GMG_OK;     // host-only entry points work without a device; device ones report GMG_ERR_NO_DEVICE
+}
+
+void gmg_destroy(gmg_handle h) {
+    if (!h) return;
+    if (h->has_device) {
+        (void)hipSetDevice(h->cfg.device);
+        (void)hipStreamSynchronize(h->stream);
+        drop_system(h);
+        for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)hipFree(*p);
+        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+        if (h->h_norm) (void)hipHostFree(h->h_norm);
+        if (h->ev0) (void)hipEventDestroy(h->ev0);
+        if (h->ev1) (void)hipEventDestroy(h->ev1);
+        (void)hipStreamDestroy(h->stream);
+    }
+    delete h;
+}
+
+const char* gmg_last_error(gmg_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int gmg_set_num_levels(gmg_handle h, int L) {
+    if (!h || L < 0 || L > 64) return h ? fail(h, GMG_ERR_INVALID, "invalid level count") : GMG_ERR_INVALID;
+    if (h->has_device) drop_system(h);
+    h->L = L;
+    h->U.assign(L, Compressed());
+    h->U_set.assign(L, 0);
+    return GMG_OK;
+}
+
+int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const int* colptr, const int* rowidx, const double* val) {
+    if (!h) return GMG_ERR_INVALID;
+    if (h->L < 0) return fail(h, GMG_ERR_STATE, "call gmg_set_num_levels first");
+    if (k < 0 || k >= h->L || n_fine <= 0 || n_coarse <= 0 || !colptr || !rowidx || !val) return fail(h, GMG_ERR_INVALID, "bad prolongation arguments");
+    for (int j = 0; j < n_coarse; ++j) if (colptr[j + 1] < colptr[j]) return fail(h, GMG_ERR_INVALID, "colptr not monotone");
+    for (int p = 0; p < colptr[n_coarse]; ++p) if (rowidx[p] < 0 || rowidx[p] >= n_fine) return fail(h, GMG_ERR_INVALID, "row index out of range in U");
+    if (h->has_device) drop_system(h);
+    h->U[k].assign(n_coarse, n_fine, colptr, rowidx, val);
+    h->U_set[k] = 1;
+    return GMG_OK;
+}
+
+int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
+    if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
+    h->mass.assign(mass_diag, mass_diag + n);
+    if (h->has_device && h->system_ready) {
+        // re-upload in device numbering
+        Level& l = h->lv[0];
+        if (l.n != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
+        std::vector<double> m(l.n_pad, 1.0), mi(l.n_pad, 1.0);
+        for (int r = 0; r < l.n_pad; ++r) if (l.ord.new2old[r] >= 0) { m[r] = h->mass[l.ord.new2old[r]]; mi[r] = 1.0 / m[r]; }
+        int rc;
+        if ((rc = upload(h, &h->d_mass, m))) return rc;
+        if ((rc = upload(h, &h->d_minv, mi))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return GMG_OK;
+}
+
+int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) {
+    NEED_DEVICE();
+    if (h->L <= 0) return fail(h, GMG_ERR_STATE, "hierarchy has no transfer levels (U is empty)");
+    for (int k = 0; k < h->L; ++k) if (!h->U_set[k]) return fail(h, GMG_ERR_STATE, "prolongation matrix missing for level " + std::to_string(k));
+    if (n <= 0 || !colptr || !rowidx || !val) return fail(h, GMG_ERR_INVALID, "bad system arguments");
+    if (h->U[0].n_inner != n) return fail(h, GMG_ERR_INVALID, "system size does not match U[0]");
+    for (int k = 0; k + 1 < h->L; ++k)
+        if (h->U[k].n_outer != h->U[k + 1].n_inner) return fail(h, GMG_ERR_INVALID, "U[k] / U[k+1] shapes do not chain");
+    for (int p = 0; p < colptr[n]; ++p) if (rowidx[p] < 0 || rowidx[p] >= n) return fail(h, GMG_ERR_INVALID, "index out of range in LHS");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    drop_system(h);
+    const int L = h->L;
+    h->lv.resize(L + 1);
+    // -- Galerkin products, multigrid_solver.cpp:1387-1392
+    auto t0 = clk::now();
+    h->lv[0].A.assign(n, n, colptr, rowidx, val);
+    for (int k = 1; k <= L; ++k) h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads);
+    h->timing["reduction"] = ms_since(t0);
+    // -- coarsest factorisation, :1401
+    t0 = clk::now();
+    if (!h->coarse.factor(h->lv[L].A)) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
+    h->coarse_work.assign(h->lv[L].A.n_outer, 0.0);
+    h->timing["coarsest_solve"] = ms_since(t0);
+    // -- device layout + upload
+    t0 = clk::now();
+    const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
+    for (int k = 0; k <= L; ++k) {
+        Level& l = h->lv[k];
+        l.n = l.A.n_outer;
+        l.ord = k < L ? make_ordering(l.A, mc, h->cfg.row_align, h->cfg.sigma) : identity_ordering(l.n);
+        l.n_pad = l.ord.n_pad;
+    }
+    for (int k = 0; k <= L; ++k) {
+        Level& l = h->lv[k];
+        int rc;
+        if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) return rc;
+        if (k == L) break;
+        SellHost sa; std::vector<double> dg; std::string e;
+        if (!build_operator_sell(l.A, l.ord, 0, sa, dg, e)) return fail(h, GMG_ERR_NUMERIC, "level " + std::to_string(k) + ": " + e);
+        if ((rc = upload_sell(h, l.Aoff, sa))) return rc;
+        if ((rc = upload(h, &l.diag, dg))) return rc;
+        Compressed Urows = transpose(h->U[k]);                                     // outer = fine rows
+        SellHost sp = build_transfer_sell(Urows, l.ord, h->lv[k + 1].ord, 0);
+        if ((rc = upload_sell(h, l.P, sp))) return rc;
+        SellHost sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, l.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0);   // outer = coarse rows
+        if ((rc = upload_sell(h, l.R, sr))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));      // host staging vectors die at scope end
+    }
+    {
+        Level& l0 = h->lv[0];
+        int nblk = (l0.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
+        if (nblk > h->partial_blocks) {
+            if (h->d_partials) (void)hipFree(h->d_partials);
+            HIPCHK(hipMalloc((void**)&h->d_partials, sizeof(double) * (size_t)nblk * 8));
+            h->partial_blocks = nblk;
+        }
+    }
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
+        // dense inverse of the coarsest operator, column by column through the host factor
+        const int nl = h->lv[L].n;
+        std::vector<double> inv((size_t)nl * nl);
+        parallel_ranges(nl, h->cfg.host_threads, [&](int lo, int hi, int) {
+            std::vector<double> e(nl, 0.0), w(nl);
+            for (int j = lo; j < hi; ++j) {
+                e[j] = 1.0;
+                h->coarse.solve(e.data(), inv.data() + (size_t)j * nl, w.data());
+                e[j] = 0.0;
+            }
+        });
+        int rc;
+        if ((rc = upload(h, &h->d_ainv, inv))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    h->system_ready = true;
+    if (!h->mass.empty()) {
+        if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
+        std::vector<double> keep = h->mass;
+        int rc = gmg_set_mass(h, n, keep.data());
+        if (rc) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->timing["upload"] = ms_since(t0);
+    h->timing["coarse_host_ms"] = 0.0;
+    return GMG_OK;
+}
+
+int gmg_num_levels(gmg_handle h) { return h ? h->L : GMG_ERR_INVALID; }
+
+int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int* n_pad) {
+    if (!h) return GMG_ERR_INVALID;
+    int rc = check_level(h, k, true);
+    if (rc) return rc;
+    Level& l = h->lv[k];
+    if (n) *n = l.n;
+    if (nnz) *nnz = l.A.nnz();
+    if (n_colors) *n_colors = l.ord.n_colors;
+    if (n_pad) *n_pad = l.n_pad;
+    return GMG_OK;
+}
+
+int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double* val) {
+    if (!h) return GMG_ERR_INVALID;
+    int rc = check_level(h, k, true);
+    if (rc) return rc;
+    const Compressed& A = h->lv[k].A;
+    if (colptr) std::memcpy(colptr, A.ptr.data(), sizeof(int) * (A.n_outer + 1));
+    if (rowidx) std::memcpy(rowidx, A.idx.data(), sizeof(int) * A.nnz());
+    if (val) std::memcpy(val, A.val.data(), sizeof(double) * A.nnz());
+    return GMG_OK;
+}
+
+int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin) {
+    if (!h) return GMG_ERR_INVALID;
+    int rc = check_level(h, k, true);
+    if (rc) return rc;
+    const LevelOrdering& o = h->lv[k].ord;
+    if (new2old) std::memcpy(new2old, o.new2old.data(), sizeof(int) * o.n_pad);
+    if (color_begin) std::memcpy(color_begin, o.color_begin.data(), sizeof(int) * (o.n_colors + 1));
+    return GMG_OK;
+}
+
+int gmg_get_timing(gmg_handle h, const char* key, double* out) {
+    if (!h || !key || !out) return GMG_ERR_INVALID;
+    auto it = h->timing.find(key);
+    if (it == h->timing.end()) return fail(h, GMG_ERR_INVALID, std::string("unknown timing key: ") + key);
+    *out = it->second;
+    return GMG_OK;
+}
+
+// ---- operators -------------------------------------------------------------------------------------------
+
+int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!b || !x || d <= 0 || iters < 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    if ((rc = to_device(h, k, b, d, l.b))) return rc;
+    if ((rc = to_device(h, k, x, d, l.x))) return rc;
+    launch_smooth(h, l, d, iters);
+    h->loaded_d = 0;
+    return to_host(h, k, l.x, d, x);
+}
+
+int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, double* r) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!b || !x || !r || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    if ((rc = to_device(h, k, b, d, l.b))) return rc;
+    if ((rc = to_device(h, k, x, d, l.x))) return rc;
+    launch_spmv(h, l, d, 1, l.b, l.x, l.r);
+    h->loaded_d = 0;
+    return to_host(h, k, l.r, d, r);
+}
+
+int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!x || !y || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    if ((rc = to_device(h, k, x, d, l.x))) return rc;
+    launch_spmv(h, l, d, 0, nullptr, l.x, l.r);
+    h->loaded_d = 0;
+    return to_host(h, k, l.r, d, y);
+}
+
+int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc_out) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!r || !rc_out || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    if ((rc = to_device(h, k, r, d, l.r))) return rc;
+    launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b);
+    h->loaded_d = 0;
+    return to_host(h, k + 1, h->lv[k + 1].b, d, rc_out);
+}
+
+int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!e || !x || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    if ((rc = to_device(h, k + 1, e, d, h->lv[k + 1].x))) return rc;
+    if ((rc = to_device(h, k, x, d, l.x))) return rc;
+    launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);
+    h->loaded_d = 0;
+    return to_host(h, k, l.x, d, x);
+}
+
+int gmg_coarse_solve(gmg_handle h, const double* rc_in, int d, double* e) {
+    NEED_DEVICE();
+    int rc = check_level(h, h->L, true);
+    if (rc) return rc;
+    if (!rc_in || !e || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& c = h->lv[h->L];
+    if ((rc = to_device(h, h->L, rc_in, d, c.b))) return rc;
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device(h, d);
+    else if ((rc = coarse_host_roundtrip(h, d))) return rc;
+    h->loaded_d = 0;
+    return to_host(h, h->L, c.x, d, e);
+}
+
+int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int type, double* out) {
+    NEED_DEVICE();
+    int rc = check_level(h, 0, false);
+    if (rc) return rc;
+    if (!b || !x || !out || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = check_norm_type(h, type))) return rc;
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[0];
+    if ((rc = to_device(h, 0, b, d, l.b))) return rc;
+    if ((rc = to_device(h, 0, x, d, l.x))) return rc;
+    if ((rc = launch_norm(h, d, type))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->loaded_d = 0;
+    *out = norm_from_sums(h->h_norm, d, type);
+    return GMG_OK;
+}
+
+// ---- resident problem: load / run / fetch ------------------------------------------------------------------
+
+int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) {
+    NEED_DEVICE();
+    int rc = check_level(h, 0, false);
+    if (rc) return rc;
+    if (!b || !x0 || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[0];
+    if ((rc = to_device(h, 0, b, d, l.b))) return rc;
+    if ((rc = to_device(h, 0, x0, d, l.x))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->loaded_d = d;
+    return GMG_OK;
+}
+
+int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) {
+    NEED_DEVICE();
+    if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
+    if (n_cycles < 0) return fail(h, GMG_ERR_INVALID, "bad cycle count");
+    int rc;
+    if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
+    const int d = h->loaded_d;
+    for (int i = 0; i < n_cycles; ++i) {
+        if ((rc = vcycle_resident(h, d, stop_type))) return rc;
+        if (stop_type >= 0) {
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (residues) residues[i] = norm_from_sums(h->h_norm, d, stop_type);
+        }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+int gmg_fetch_solution(gmg_handle h, double* x) {
+    NEED_DEVICE();
+    if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
+    if (!x) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    return to_host(h, 0, h->lv[0].x, h->loaded_d, x);
+}
+
+int gmg_vcycle(gmg_handle h, const double* b, double* x, int d) {
+    int rc = gmg_load_problem(h, b, x, d);
+    if (rc) return rc;
+    if ((rc = gmg_run_cycles(h, 1, -1, nullptr))) return rc;
+    return gmg_fetch_solution(h, x);
+}
+
+int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter, int* iters_out,
+              double* residue_out, double* conv) {
+    NEED_DEVICE();
+    int rc;
+    if ((rc = check_norm_type(h, stop_type))) return rc;
+    if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle (multigrid_solver.cpp:1411-1417)
+    auto t_all = clk::now();
+    if ((rc = gmg_load_problem(h, rhs, x, d))) return rc;
+    h->timing["coarse_host_ms"] = 0.0;
+    auto t0 = clk::now();
+    double residue = 0.0;
+    int it = 0;
+    do {
+        if ((rc = vcycle_resident(h, d, stop_type))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        residue = norm_from_sums(h->h_norm, d, stop_type);
+        if (conv) { conv[2 * it] = ms_since(t0); conv[2 * it + 1] = residue; }
+        ++it;
+        if (h->cfg.verbose) std::printf("%d,%f,%.14f \n", it, ms_since(t0), residue);
+    } while (residue > tol && it < max_iter);
+    h->timing["cycles"] = ms_since(t0);
+    if ((rc = gmg_fetch_solution(h, x))) return rc;
+    h->timing["iterations"] = it;
+    h->timing["residue"] = residue;
+    h->timing["solve_call"] = ms_since(t_all);
+    h->timing["solver_total"] = h->timing["reduction"] + h->timing["coarsest_solve"] + h->timing["upload"] + h->timing["solve_call"];
+    if (iters_out) *iters_out = it;
+    if (residue_out) *residue_out = residue;
+    return GMG_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------------------------------
+
+int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out) {
+    if (!h || !bytes_out) return GMG_ERR_INVALID;
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    const Level& l = h->lv[k];
+    const double s = 8.0, n = l.n, z = (double)l.A.nnz(), u = (double)h->U[k].nnz(), nc = h->lv[k + 1].n;
+    // matrix stream (value + int32 index) + row pointer + the dense vectors, each touched once
+    const double sweep = z * (s + 4) + 4 * (n + 1) + 3 * n * d * s;
+    switch (kind) {
+        case 0: case 1: *bytes_out = sweep; break;
+        case 2: *bytes_out = u * (s + 4) + 4 * (nc + 1) + n * d * s + nc * d * s; break;
+        case 3: *bytes_out = u * (s + 4) + 4 * (n + 1) + nc * d * s + 2 * n * d * s; break;
+        case 4: *bytes_out = sweep - n * d * s + n * s; break;       // reads x, b, M; writes nothing
+        default: return fail(h, GMG_ERR_INVALID, "unknown kernel kind");
+    }
+    return GMG_OK;
+}
+
+int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!ms_avg || reps <= 0 || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    int launches = 1;
+    auto body = [&]() {
+        switch (kind) {
+            case 0: launch_smooth(h, l, d, 1); launches = h->cfg.smoother == GMG_SMOOTHER_JACOBI ? 1 : l.ord.n_colors; break;
+            case 1: launch_spmv(h, l, d, 1, l.b, l.x, l.r); break;
+            case 2: launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b); break;
+            case 3: launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x); break;
+            case 4: (void)launch_norm(h, d, 0); launches = 2; break;
+            default: break;
+        }
+    };
+    if (kind < 0 || kind > 4) return fail(h, GMG_ERR_INVALID, "unknown kernel kind");
+    if (kind == 4 && k != 0) return fail(h, GMG_ERR_INVALID, "the norm kernel runs on level 0");
+    for (int i = 0; i < 3; ++i) body();
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) body();
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_avg = (double)ms / reps;
+    if (launches_out) *launches_out = launches;
+    h->loaded_d = 0;
+    return GMG_OK;
+}
+
+// ---- host-only: hierarchy -----------------------------------------------------------------------------------
+
+int gmg_hierarchy_options_default(gmg_hierarchy_options* o) {
+    if (!o) return GMG_ERR_INVALID;
+    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0;
+    return GMG_OK;
+}
+
+int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt, gmg_hierarchy* out) {
+    if (!pos || !neigh || n <= 0 || K <= 0 || !out) return GMG_ERR_INVALID;
+    gmg_hierarchy_options o;
+    if (opt) o = *opt; else gmg_hierarchy_options_default(&o);
+    if (o.sampling != 0) return GMG_ERR_UNSUPPORTED;      // only Sampling::FASTDISK (the default) is in scope
+    if (o.weighting < 0 || o.weighting > 2 || !(o.ratio > 0)) return GMG_ERR_INVALID;
+    for (size_t i = 0; i < (size_t)n * K; ++i) if (neigh[i] >= n) return GMG_ERR_INVALID;
+    HierarchyOptions ho;
+    ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting;
+    gmg_hierarchy hh = new gmg_hierarchy_s();
+    hh->res = HierarchyBuilder::build(pos, n, neigh, K, ho);
+    *out = hh;
+    return GMG_OK;
+}
+
+void gmg_hierarchy_destroy(gmg_hierarchy hh) { delete hh; }
+
+int gmg_hierarchy_num_levels(gmg_hierarchy hh) { return hh ? (int)hh->res.U.size() : GMG_ERR_INVALID; }
+
+int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coarse, int* nnz) {
+    if (!hh || k < 0 || k >= (int)hh->res.U.size()) return GMG_ERR_INVALID;
+    const Compressed& u = hh->res.U[k];
+    if (n_fine) *n_fine = u.n_inner;
+    if (n_coarse) *n_coarse = u.n_outer;
+    if (nnz) *nnz = u.nnz();
+    return GMG_OK;
+}
+
+int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val) {
+    if (!hh || k < 0 || k >= (int)hh->res.U.size()) return GMG_ERR_INVALID;
+    const Compressed& u = hh->res.U[k];
+    if (colptr) std::memcpy(colptr, u.ptr.data(), sizeof(int) * (u.n_outer + 1));
+    if (rowidx) std::memcpy(rowidx, u.idx.data(), sizeof(int) * u.nnz());
+    if (val) std::memcpy(val, u.val.data(), sizeof(double) * u.nnz());
+    return GMG_OK;
+}
+
+int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out) {
+    if (!hh || !key || !out) return GMG_ERR_INVALID;
+    auto it = hh->res.timing.find(key);
+    if (it == hh->res.timing.end()) return GMG_ERR_INVALID;
+    *out = it->second;
+    return GMG_OK;
+}
+
+int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) {
+    if (!h || !hh) return GMG_ERR_INVALID;
+    int rc = gmg_set_num_levels(h, (int)hh->res.U.size());
+    if (rc) return rc;
+    for (int k = 0; k < (int)hh->res.U.size(); ++k) {
+        const Compressed& u = hh->res.U[k];
+        if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
+    }
+    return GMG_OK;
+}
+
+int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const double* a_val, int n_coarse, const int* u_colptr,
+                      const int* u_rowidx, const double* u_val, int* c_colptr, int* c_rowidx, double* c_val) {
+    if (n <= 0 || n_coarse <= 0 || !a_colptr || !a_rowidx || !a_val || !u_colptr || !u_rowidx || !u_val || !c_colptr) return GMG_ERR_INVALID;
+    Compressed A, U;
+    A.assign(n, n, a_colptr, a_rowidx, a_val);
+    U.assign(n_coarse, n, u_colptr, u_rowidx, u_val);
+    Compressed C = galerkin_rap(A, U, hw_threads());
+    std::memcpy(c_colptr, C.ptr.data(), sizeof(int) * (n_coarse + 1));
+    if (c_rowidx) std::memcpy(c_rowidx, C.idx.data(), sizeof(int) * C.nnz());
+    if (c_val) std::memcpy(c_val, C.val.data(), sizeof(double) * C.nnz());
+    return GMG_OK;
+}
+
+}  // extern "C"

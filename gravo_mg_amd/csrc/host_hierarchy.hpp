@@ -1,0 +1,388 @@
+// host_hierarchy.hpp -- Graph-Voronoi prolongation hierarchy (host, sequential graph algorithm).
+//
+// Restates, with its own data structures, what the reference's constructor does on its default path:
+//   MGBS::MultigridSolver::buildHierarchy / constructProlongation
+//       gravomg/src/multigrid_solver.cpp:43-60, 62-469
+//   computeAverageEdgeLength     :695-711
+//   fastDiskSample               :975-1013
+//   constructDijkstraWithCluster :1015-1056
+//   inTriangle                   :471-507
+//   inverseDistanceWeights       :515-526,  uniformWeights :509-513
+// Supported options: Sampling::FASTDISK only; Weighting::{BARYCENTRIC, UNIFORM, INVDIST}; nested;
+// check_voronoi.  The other samplers / SIG06 / SIG21 / ablation hierarchies are paper baselines and are
+// out of scope; they are rejected with GMG_ERR_UNSUPPORTED upstream.
+//
+// Behavioural details that are kept on purpose (SURVEY.md A.2/A.3 and the lines cited inline):
+//   * a level is accepted only if the sample set has >= lower_bound points, at most 10 levels (:103,:156);
+//   * the coarse neighbour table keeps the point itself in column 0 and at most maxNeigh-1 neighbours (:196-205);
+//   * the first containing triangle wins (:343-349, the `break`), the first non-negative "inside edge" in
+//     ascending key order wins (:375-383), edge distances are stored as float (std::map<int,float>, :336).
+#pragma once
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+#include <map>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "host_sparse.hpp"
+
+namespace gmg {
+
+struct HierarchyOptions {
+    double ratio = 8.0;          // gravomg_bindings/src/gravomg/core.py:10
+    int lower_bound = 1000;
+    bool check_voronoi = true;
+    bool nested = false;
+    int weighting = 0;           // 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST (multigrid_solver.h:48-52)
+};
+
+struct HierarchyResult {
+    std::vector<Compressed> U;               // U[k]: n_k x n_{k+1}, CSC (outer = coarse columns)
+    std::vector<int> dof;                    // n_0, n_1, ..., n_L
+    std::vector<std::vector<int>> samples;   // per level: fine index of each coarse sample
+    std::map<std::string, double> timing;    // the reference's hierarchyTiming keys
+    // per level counts of prolongation row kinds: triangle / edge / fallback / single
+    std::vector<std::array<int, 4>> row_kinds;
+};
+
+namespace detail {
+struct V3 { double x, y, z; };
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+inline V3 normalized(V3 a) { double z = dot(a, a); return z > 0 ? (1.0 / std::sqrt(z)) * a : a; }
+struct HeapItem { int v; double dist; bool operator>(const HeapItem& o) const { return dist > o.dist; } };
+}  // namespace detail
+
+class HierarchyBuilder {
+    using V3 = detail::V3;
+public:
+    // pos: n x 3 row-major; neigh: n x K row-major, rows padded with -1 (scanned left to right).
+    static HierarchyResult build(const double* pos, int n, const int* neigh, int K, const HierarchyOptions& opt) {
+        using clk = std::chrono::steady_clock;
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        HierarchyResult R;
+        auto t_all = clk::now();
+        for (const char* key : {"PDS", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection"}) R.timing[key] = 0.0;
+        R.timing["n_vertices"] = n;
+        std::vector<V3> P(n);
+        for (int i = 0; i < n; ++i) P[i] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+        std::vector<int> NB(neigh, neigh + (size_t)n * K);
+        int nbK = K;
+        R.dof.push_back(n);
+        int level = 0;
+        while ((int)P.size() > opt.lower_bound && level < 10) {                      // :103
+            const int nf = (int)P.size();
+            const double radius = std::cbrt(opt.ratio) * average_edge_length(P, NB, nbK);   // :104
+            std::vector<double> D(nf, std::numeric_limits<double>::max());
+            std::vector<int> nearest(nf, 0);
+            auto t0 = clk::now();
+            std::vector<int> sample = fast_disk_sample(P, NB, nbK, radius, D, nearest);     // :128
+            if ((int)sample.size() < opt.lower_bound) break;                                // :156-159
+            const int nc = (int)sample.size();
+            auto t1 = clk::now();
+            R.timing["sampling"] += ms(t0, t1);
+            voronoi_dijkstra(P, sample, NB, nbK, D, nearest);                               // :170
+            auto t2 = clk::now();
+            R.timing["cluster"] += ms(t1, t2);
+
+            // coarse adjacency: clusters that touch through a fine edge (:178-187); sorted unique lists
+            std::vector<std::vector<int>> cadj(nc);
+            for (int f = 0; f < nf; ++f)
+                for (int j = 0; j < nbK; ++j) {
+                    int g = NB[(size_t)f * nbK + j];
+                    if (g < 0) break;
+                    if (nearest[f] != nearest[g]) cadj[nearest[f]].push_back(nearest[g]);
+                }
+            int max_nb = 0;
+            for (auto& a : cadj) {
+                std::sort(a.begin(), a.end());
+                a.erase(std::unique(a.begin(), a.end()), a.end());
+                max_nb = std::max(max_nb, (int)a.size());
+            }
+            // homogeneous table for the next level (:196-205): self first, then at most max_nb-1 neighbours
+            std::vector<int> NBc((size_t)nc * std::max(max_nb, 1), -1);
+            const int Kc = std::max(max_nb, 1);
+            if (max_nb > 0)
+                for (int i = 0; i < nc; ++i) {
+                    NBc[(size_t)i * Kc] = i;
+                    int cnt = 1;
+                    for (int node : cadj[i]) {
+                        if (node == i) continue;
+                        if (cnt >= max_nb) break;
+                        NBc[(size_t)i * Kc + cnt++] = node;
+                    }
+                }
+            auto t3 = clk::now();
+            R.timing["next_neighborhood"] += ms(t2, t3);
+
+            // coarse positions (:216-240)
+            std::vector<V3> Pc(nc, V3{0, 0, 0});
+            if (opt.nested) {
+                for (int c = 0; c < nc; ++c) Pc[c] = P[sample[c]];
+            } else {
+                std::vector<int> csize(nc, 0);
+                for (int f = 0; f < nf; ++f) { Pc[nearest[f]] = Pc[nearest[f]] + P[f]; ++csize[nearest[f]]; }
+                for (int c = 0; c < nc; ++c) {
+                    if (csize[c] == 1) {
+                        V3 s = P[sample[c]];
+                        for (int nb : cadj[c]) s = s + P[sample[nb]];
+                        Pc[c] = (1.0 / (cadj[c].size() + 1.0)) * s;
+                    } else {
+                        Pc[c] = (1.0 / csize[c]) * Pc[c];
+                    }
+                }
+            }
+            auto t4 = clk::now();
+            R.timing["next_positions"] += ms(t3, t4);
+
+            // candidate triangles from mutually adjacent Voronoi cells (:247-281)
+            std::vector<std::array<int, 3>> tris;
+            std::vector<V3> tri_normal;
+            std::vector<std::vector<int>> tris_of(nc);
+            for (int c = 0; c < nc; ++c) {
+                const auto& a = cadj[c];
+                for (size_t i2 = 0; i2 < a.size(); ++i2) {
+                    int v2 = a[i2];
+                    if (v2 < c) continue;
+                    for (size_t i3 = i2 + 1; i3 < a.size(); ++i3) {
+                        int v3 = a[i3];
+                        if (v3 < c) continue;
+                        if (!opt.check_voronoi || std::binary_search(cadj[v2].begin(), cadj[v2].end(), v3)) {
+                            int t = (int)tris.size();
+                            tris.push_back({c, v2, v3});
+                            tri_normal.push_back(detail::normalized(detail::cross(Pc[v2] - Pc[c], Pc[v3] - Pc[c])));
+                            tris_of[c].push_back(t); tris_of[v2].push_back(t); tris_of[v3].push_back(t);
+                        }
+                    }
+                }
+            }
+            auto t5 = clk::now();
+            R.timing["triangle_finding"] += ms(t4, t5);
+
+            // per fine point: pick coarse parents and weights (:291-452)
+            std::vector<int> trow; std::vector<int> tcol; std::vector<double> tval;
+            trow.reserve((size_t)nf * 3); tcol.reserve((size_t)nf * 3); tval.reserve((size_t)nf * 3);
+            auto emit = [&](int f, int c, double w) { trow.push_back(f); tcol.push_back(c); tval.push_back(w); };
+            std::array<int, 4> kinds{0, 0, 0, 0};
+            std::map<int, float> inside_edge;
+            for (int f = 0; f < nf; ++f) {
+                const V3 p = P[f];
+                const int c = nearest[f];
+                const V3 pc = Pc[c];
+                if (opt.nested && sample[c] == f) { emit(f, c, 1.0); continue; }
+                if (cadj[c].empty()) { emit(f, c, 1.0); ++kinds[3]; continue; }
+                if (cadj[c].size() == 1) {
+                    int nb = cadj[c][0];
+                    emit_edge(f, c, nb, p, pc, Pc, opt.weighting, emit);
+                    ++kinds[3];
+                    continue;
+                }
+                inside_edge.clear();
+                bool found = false;
+                std::array<int, 3> best{0, 0, 0};
+                double bary[3] = {0, 0, 0};
+                for (int t : tris_of[c]) {
+                    std::array<int, 3> tri = tris[t];
+                    while (tri[0] != c) std::rotate(tri.begin(), tri.begin() + 1, tri.end());
+                    double b[3];
+                    double dist = in_triangle(p, tri, tri_normal[t], Pc, b, inside_edge);
+                    if (dist >= 0.0) { found = true; best = tri; bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2]; break; }
+                }
+                if (found) {
+                    ++kinds[0];
+                    double w[3];
+                    if (opt.weighting == 0) { w[0] = bary[0]; w[1] = bary[1]; w[2] = bary[2]; }
+                    else if (opt.weighting == 1) { w[0] = w[1] = w[2] = 1.0 / 3; }
+                    else inv_dist_weights(Pc, p, best.data(), 3, w);
+                    for (int j = 0; j < 3; ++j) emit(f, best[j], w[j]);
+                    continue;
+                }
+                int edge_to = -1;
+                for (const auto& kv : inside_edge)
+                    if (kv.second >= 0.f) { edge_to = kv.first; break; }              // :375-383
+                if (edge_to >= 0) {
+                    ++kinds[1];
+                    emit_edge(f, c, edge_to, p, pc, Pc, opt.weighting, emit);
+                    continue;
+                }
+                // closest three (:415-435): the cell itself + its two nearest table neighbours, inverse distance
+                ++kinds[2];
+                std::vector<std::pair<double, int>> cand;
+                for (int j = 0; j < Kc; ++j) {
+                    int nb = NBc[(size_t)c * Kc + j];
+                    if (nb < 0 || nb == c) continue;
+                    cand.emplace_back(detail::norm(p - Pc[nb]), nb);
+                }
+                std::sort(cand.begin(), cand.end());
+                int from[3] = {c, -1, -1};
+                int cnt = 1;
+                for (size_t j = 0; j < cand.size() && cnt < 3; ++j) from[cnt++] = cand[j].second;
+                double w[3];
+                inv_dist_weights(Pc, p, from, cnt, w);
+                for (int j = 0; j < cnt; ++j) emit(f, from[j], w[j]);
+            }
+            auto t6 = clk::now();
+            R.timing["triangle_selection"] += ms(t5, t6);
+            R.row_kinds.push_back(kinds);
+
+            R.U.push_back(from_triplets(nf, nc, trow, tcol, tval));
+            R.samples.push_back(std::move(sample));
+            R.dof.push_back(nc);
+            P.swap(Pc);
+            NB.swap(NBc);
+            nbK = Kc;
+            ++level;
+        }
+        R.timing["levels"] = (double)R.U.size();
+        R.timing["hierarchy"] = ms(t_all, clk::now());
+        return R;
+    }
+
+private:
+    static double average_edge_length(const std::vector<V3>& P, const std::vector<int>& NB, int K) {   // :695-711
+        double sum = 0.0; long cnt = 0;
+        const int n = (int)P.size();
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < K; ++j) {
+                int g = NB[(size_t)i * K + j];
+                if (g < 0) continue;
+                double d = detail::norm(P[i] - P[g]);
+                if (d > 0) { sum += d; ++cnt; }
+            }
+        return sum / (double)cnt;
+    }
+
+    // :975-1013  greedy disk sampling over the one- and two-ring, first come first served in index order
+    static std::vector<int> fast_disk_sample(const std::vector<V3>& P, const std::vector<int>& NB, int K, double radius,
+                                             std::vector<double>& D, std::vector<int>& nearest) {
+        const int n = (int)P.size();
+        std::vector<char> visited(n, 0);
+        std::vector<int> sel;
+        for (int i = 0; i < n; ++i) {
+            if (visited[i]) continue;
+            const int sidx = (int)sel.size();
+            sel.push_back(i);
+            nearest[i] = sidx;
+            for (int j = 0; j < K; ++j) {
+                int g = NB[(size_t)i * K + j];
+                if (g < 0) break;
+                double d1 = detail::norm(P[i] - P[g]);
+                if (!(d1 < radius)) continue;
+                visited[g] = 1;
+                if (d1 < D[g]) { D[g] = d1; nearest[g] = sidx; }
+                for (int j2 = 0; j2 < K; ++j2) {
+                    int g2 = NB[(size_t)g * K + j2];
+                    if (g2 < 0) break;
+                    double d2 = d1 + detail::norm(P[g] - P[g2]);
+                    if (d2 < radius) {
+                        visited[g2] = 1;
+                        if (d2 < D[g2]) { D[g2] = d2; nearest[g2] = sidx; }
+                    }
+                }
+            }
+        }
+        return sel;
+    }
+
+    // :1015-1056  multi-source Dijkstra; D/nearest arrive pre-seeded by the sampler and are only ever lowered
+    static void voronoi_dijkstra(const std::vector<V3>& P, const std::vector<int>& src, const std::vector<int>& NB, int K,
+                                 std::vector<double>& D, std::vector<int>& nearest) {
+        std::priority_queue<detail::HeapItem, std::vector<detail::HeapItem>, std::greater<detail::HeapItem>> heap;
+        for (int i = 0; i < (int)src.size(); ++i) {
+            D[src[i]] = 0.0;
+            heap.push({src[i], 0.0});
+            nearest[src[i]] = i;
+        }
+        while (!heap.empty()) {
+            detail::HeapItem it = heap.top();
+            const int owner = nearest[it.v];
+            heap.pop();
+            for (int j = 0; j < K; ++j) {
+                int g = NB[(size_t)it.v * K + j];
+                if (g < 0) continue;
+                double cand = it.dist + detail::norm(P[g] - P[it.v]);
+                if (cand < D[g]) { D[g] = cand; heap.push({g, cand}); nearest[g] = owner; }
+            }
+        }
+    }
+
+    // :471-507  barycentric test of the projection of p onto the triangle's plane; returns |distance to plane|
+    // when inside, -1 otherwise, and records the "inside edge" bookkeeping.
+    static double in_triangle(V3 p, const std::array<int, 3>& tri, V3 nrm, const std::vector<V3>& pos, double bary[3],
+                              std::map<int, float>& inside_edge) {
+        const V3 v1 = pos[tri[0]], v2 = pos[tri[1]], v3 = pos[tri[2]];
+        const V3 v1p = p - v1, e12 = v2 - v1, e13 = v3 - v1;
+        const double plane_dist = detail::dot(p - v1, nrm);
+        const V3 q = p - plane_dist * nrm;
+        const double area2 = detail::dot(detail::cross(v2 - v1, v3 - v1), nrm);
+        bary[0] = detail::dot(detail::cross(v3 - v2, q - v2), nrm) / area2;
+        bary[1] = detail::dot(detail::cross(v1 - v3, q - v3), nrm) / area2;
+        bary[2] = 1.0 - bary[0] - bary[1];
+        if (!inside_edge.count(tri[1])) inside_edge[tri[1]] = (float)detail::norm(v1p - detail::dot(v1p, e12) * e12);
+        if (!inside_edge.count(tri[2])) inside_edge[tri[2]] = (float)detail::norm(v1p - detail::dot(v1p, e13) * e13);
+        if (bary[0] < 0. || bary[1] < 0.) inside_edge[tri[1]] = -1.f;
+        if (bary[0] < 0. || bary[2] < 0.) inside_edge[tri[2]] = -1.f;
+        if (bary[0] >= 0. && bary[1] >= 0. && bary[2] >= 0.) return std::fabs(plane_dist);
+        return -1.0;
+    }
+
+    static void inv_dist_weights(const std::vector<V3>& pos, V3 p, const int* ids, int cnt, double* w) {   // :515-526
+        double s = 0.0;
+        for (int j = 0; j < cnt; ++j) { w[j] = 1.0 / std::max(1e-8, detail::norm(p - pos[ids[j]])); s += w[j]; }
+        for (int j = 0; j < cnt; ++j) w[j] /= s;
+    }
+
+    // two-parent rows (:308-331 and :386-411): clamp the projection parameter onto the segment
+    template <class Emit>
+    static void emit_edge(int f, int c, int other, V3 p, V3 pc, const std::vector<V3>& Pc, int weighting, Emit& emit) {
+        double w1, w2;
+        if (weighting == 0) {
+            V3 e = Pc[other] - pc;
+            double len = std::max(detail::norm(e), 1e-8);
+            w2 = detail::dot(p - pc, detail::normalized(e)) / len;
+            w2 = std::min(std::max(w2, 0.), 1.);
+            w1 = 1. - w2;
+        } else if (weighting == 1) {
+            w1 = w2 = 0.5;
+        } else {
+            int ids[2] = {c, other};
+            double w[2];
+            inv_dist_weights(Pc, p, ids, 2, w);
+            w1 = w[0]; w2 = w[1];
+        }
+        emit(f, c, w1);
+        emit(f, other, w2);
+    }
+
+    // Eigen's setFromTriplets semantics: duplicates are summed, explicit zeros are kept, inner indices sorted.
+    static Compressed from_triplets(int nrows, int ncols, const std::vector<int>& r, const std::vector<int>& c, const std::vector<double>& v) {
+        Compressed M;
+        M.n_outer = ncols; M.n_inner = nrows;
+        std::vector<int> cnt((size_t)ncols + 1, 0);
+        for (int cc : c) cnt[cc + 1]++;
+        for (int j = 0; j < ncols; ++j) cnt[j + 1] += cnt[j];
+        std::vector<int> ri(r.size()); std::vector<double> vv(r.size());
+        std::vector<int> next(cnt.begin(), cnt.end() - 1);
+        for (size_t t = 0; t < r.size(); ++t) { int q = next[c[t]]++; ri[q] = r[t]; vv[q] = v[t]; }   // rows arrive ascending
+        M.ptr.assign((size_t)ncols + 1, 0);
+        for (int j = 0; j < ncols; ++j) {
+            int lo = cnt[j], hi = cnt[j + 1];
+            int last = -1;
+            for (int q = lo; q < hi; ++q) {
+                if (ri[q] == last) { M.val.back() += vv[q]; continue; }
+                M.idx.push_back(ri[q]); M.val.push_back(vv[q]); last = ri[q];
+            }
+            M.ptr[j + 1] = (int)M.idx.size();
+        }
+        return M;
+    }
+};
+
+}  // namespace gmg

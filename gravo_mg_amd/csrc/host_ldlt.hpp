@@ -1,0 +1,155 @@
+// host_ldlt.hpp -- sparse LDL^T for the coarsest level, kept on the host as the north star asks.
+//
+// Replaces the reference's `Eigen::SimplicialLDLT<Eigen::SparseMatrix<double>> coarsestSolver`
+// (gravomg/include/gravomg/multigrid_solver.h:145; factor at gravomg/src/multigrid_solver.cpp:1401,
+// back-substitution once per V-cycle at :1075).  Eigen is a third-party dependency that is not
+// present; this is an independent implementation of the same mathematical object: a fill-reducing
+// symmetric permutation (minimum degree on the explicit elimination graph -- the coarsest level has
+// 1 000 ... ~8 000 unknowns) followed by an up-looking sparse LDL^T driven by the
+// elimination tree.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <iterator>
+#include <vector>
+
+#include "host_sparse.hpp"
+
+namespace gmg {
+
+class SparseLDLT {
+public:
+    int n = 0;
+    bool ok = false;
+    std::vector<int> perm;       // new -> old
+    std::vector<int> Lp, Li;     // strictly lower unit factor, by columns
+    std::vector<double> Lx, D;
+
+    // A: symmetric, compressed, sorted indices, full (both triangles) storage.
+    bool factor(const Compressed& A) {
+        n = A.n_outer;
+        ok = false;
+        min_degree(A);
+        std::vector<int> inv(n);
+        for (int i = 0; i < n; ++i) inv[perm[i]] = i;
+        // Upper triangle (incl. diagonal) of C = P A P^T, by columns, unsorted rows are fine.
+        std::vector<int> Cp(n + 1, 0), Ci;
+        std::vector<double> Cx;
+        for (int k = 0; k < n; ++k) {
+            int old = perm[k];
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p)
+                if (inv[A.idx[p]] <= k) Cp[k + 1]++;
+        }
+        for (int k = 0; k < n; ++k) Cp[k + 1] += Cp[k];
+        Ci.resize(Cp[n]); Cx.resize(Cp[n]);
+        for (int k = 0; k < n; ++k) {
+            int q = Cp[k], old = perm[k];
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+                int i = inv[A.idx[p]];
+                if (i <= k) { Ci[q] = i; Cx[q] = A.val[p]; ++q; }
+            }
+        }
+        // symbolic: elimination tree + column counts of L
+        std::vector<int> parent(n, -1), flag(n, -1), lnz(n, 0);
+        for (int k = 0; k < n; ++k) {
+            flag[k] = k;
+            for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
+                int i = Ci[p];
+                while (i < k && flag[i] != k) {
+                    if (parent[i] < 0) parent[i] = k;
+                    lnz[i]++;
+                    flag[i] = k;
+                    i = parent[i];
+                }
+            }
+        }
+        Lp.assign(n + 1, 0);
+        for (int k = 0; k < n; ++k) Lp[k + 1] = Lp[k] + lnz[k];
+        Li.assign(Lp[n], 0); Lx.assign(Lp[n], 0.0); D.assign(n, 0.0);
+        // numeric, up-looking: row k of L is the solution of a sparse triangular system
+        std::vector<double> y(n, 0.0);
+        std::vector<int> pattern(n), fill(n, 0);
+        std::fill(flag.begin(), flag.end(), -1);
+        for (int k = 0; k < n; ++k) {
+            int top = n;
+            flag[k] = k;
+            for (int p = Cp[k]; p < Cp[k + 1]; ++p) {
+                int i = Ci[p];
+                y[i] += Cx[p];
+                int len = 0;
+                while (i < k && flag[i] != k) { pattern[len++] = i; flag[i] = k; i = parent[i]; }
+                while (len > 0) pattern[--top] = pattern[--len];
+            }
+            double dk = y[k];
+            y[k] = 0.0;
+            for (; top < n; ++top) {
+                int i = pattern[top];
+                double yi = y[i];
+                y[i] = 0.0;
+                int pend = Lp[i] + fill[i];
+                for (int p = Lp[i]; p < pend; ++p) y[Li[p]] -= Lx[p] * yi;
+                double lki = yi / D[i];
+                dk -= lki * yi;
+                Li[pend] = k; Lx[pend] = lki;
+                fill[i]++;
+            }
+            if (dk == 0.0 || !std::isfinite(dk)) return false;
+            D[k] = dk;
+        }
+        ok = true;
+        return true;
+    }
+
+    // x = A^{-1} b for one column; work must hold n doubles.
+    void solve(const double* b, double* x, double* work) const {
+        double* y = work;
+        for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+        for (int j = 0; j < n; ++j) {
+            double yj = y[j];
+            for (int p = Lp[j]; p < Lp[j + 1]; ++p) y[Li[p]] -= Lx[p] * yj;
+        }
+        for (int j = 0; j < n; ++j) y[j] /= D[j];
+        for (int j = n - 1; j >= 0; --j) {
+            double s = y[j];
+            for (int p = Lp[j]; p < Lp[j + 1]; ++p) s -= Lx[p] * y[Li[p]];
+            y[j] = s;
+        }
+        for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
+    }
+
+    long factor_nnz() const { return (long)Lp.empty() ? 0 : Lp[n]; }
+
+private:
+    // Minimum-degree ordering on the explicit elimination graph (adequate for n <~ 10^4).
+    void min_degree(const Compressed& A) {
+        std::vector<std::vector<int>> adj(n);
+        for (int j = 0; j < n; ++j) {
+            for (int p = A.ptr[j]; p < A.ptr[j + 1]; ++p)
+                if (A.idx[p] != j) adj[j].push_back(A.idx[p]);
+            std::sort(adj[j].begin(), adj[j].end());
+            adj[j].erase(std::unique(adj[j].begin(), adj[j].end()), adj[j].end());
+        }
+        std::vector<char> done(n, 0);
+        perm.resize(n);
+        std::vector<int> merged;
+        for (int step = 0; step < n; ++step) {
+            int v = -1; size_t best = ~(size_t)0;
+            for (int j = 0; j < n; ++j)
+                if (!done[j] && adj[j].size() < best) { best = adj[j].size(); v = j; }
+            done[v] = 1;
+            perm[step] = v;
+            const std::vector<int>& nv = adj[v];
+            for (int u : nv) {
+                // adj[u] = (adj[u] U nv) \ {u, v}
+                merged.clear();
+                std::set_union(adj[u].begin(), adj[u].end(), nv.begin(), nv.end(), std::back_inserter(merged));
+                std::vector<int>& au = adj[u];
+                au.clear();
+                for (int w : merged) if (w != u && w != v) au.push_back(w);
+            }
+            adj[v].clear(); adj[v].shrink_to_fit();
+        }
+    }
+};
+
+}  // namespace gmg

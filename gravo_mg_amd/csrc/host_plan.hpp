@@ -1,0 +1,231 @@
+// host_plan.hpp -- turns the host hierarchy (A_k, U_k in compressed storage) into the device layout.
+//
+// Device layout (DESIGN.md "Data layout in HBM"):
+//   * every level gets its own DEVICE NUMBERING: rows grouped by colour (multicolour Gauss-Seidel),
+//     inside a colour kept in mesh order except for a stable sort by row length inside windows of
+//     `sigma` rows (keeps SELL padding small without destroying locality), each colour class padded
+//     to a multiple of `row_align` rows (64 = one wavefront; 64*P when P ranks split every colour);
+//   * matrices are SELL-64: slices of 64 rows, one row per lane, entries stored j-major inside a
+//     slice so that a wavefront's loads of col[]/val[] are contiguous (256 B / 512 B per j);
+//   * A_k is stored WITHOUT its diagonal; the diagonal is a dense vector (the reference fetches it with
+//     coeffRef(k,k), gravomg/src/multigrid_solver.cpp:1207);
+//   * U_k (<= 3 entries per row, multigrid_solver.cpp:371-373,413-414) is stored twice: SELL of U for
+//     x += U e, and SELL of U^T (rows sorted by length inside windows, output row in `row_of`) for
+//     rc = U^T r.  U^T as CSR is exactly the reference's CSC storage of U.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "host_sparse.hpp"
+
+namespace gmg {
+
+constexpr int kSlice = 64;
+
+struct LevelOrdering {
+    int n = 0;                        // real unknowns
+    int n_pad = 0;                    // device vector length (multiple of 64)
+    int n_colors = 0;
+    std::vector<int> color_begin;     // n_colors + 1, in device rows (multiples of row_align)
+    std::vector<int> new2old;         // n_pad, -1 for padding rows
+    std::vector<int> old2new;         // n
+};
+
+struct SellHost {
+    int n_rows_pad = 0;               // rows covered by slices (multiple of 64)
+    int n_cols = 0;
+    int n_slices = 0;
+    int64_t nnz_real = 0;
+    std::vector<int64_t> slice_ptr;   // n_slices + 1, element offsets (multiples of 64)
+    std::vector<int> col;
+    std::vector<double> val;
+    std::vector<int> row_of;          // empty => slice row r is device row r; else output row (or -1)
+    int64_t stored() const { return slice_ptr.empty() ? 0 : slice_ptr[n_slices]; }
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Greedy first-fit colouring in natural order (4 colours on a valence-6 mesh,
+// 13-18 on Galerkin levels).  A is symmetric; self-loops ignored.
+inline int greedy_coloring(const Compressed& A, std::vector<int>& color) {
+    const int n = A.n_outer;
+    color.assign(n, -1);
+    std::vector<int> forbid;
+    int ncol = 0;
+    for (int i = 0; i < n; ++i) {
+        forbid.assign((size_t)ncol + 1, 0);
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+            int j = A.idx[p];
+            if (j != i && color[j] >= 0) forbid[color[j]] = 1;
+        }
+        int c = 0;
+        while (c < ncol && forbid[c]) ++c;
+        color[i] = c;
+        if (c == ncol) ++ncol;
+    }
+    return ncol;
+}
+
+// multicolor = false -> a single "colour" holding every row (Jacobi-type smoothers, coarsest level).
+inline LevelOrdering make_ordering(const Compressed& A, bool multicolor, int row_align, int sigma) {
+    LevelOrdering o;
+    const int n = A.n_outer;
+    o.n = n;
+    std::vector<int> color;
+    if (multicolor) o.n_colors = greedy_coloring(A, color);
+    else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
+    std::vector<int> count(o.n_colors, 0);
+    for (int i = 0; i < n; ++i) count[color[i]]++;
+    o.color_begin.assign(o.n_colors + 1, 0);
+    for (int c = 0; c < o.n_colors; ++c) o.color_begin[c + 1] = o.color_begin[c] + round_up(count[c], row_align);
+    o.n_pad = o.n_colors ? o.color_begin[o.n_colors] : 0;
+    if (o.n_pad == 0) o.n_pad = row_align;
+    o.new2old.assign(o.n_pad, -1);
+    o.old2new.assign(n, -1);
+    std::vector<int> fill(o.color_begin.begin(), o.color_begin.end() - (o.n_colors ? 1 : 0));
+    for (int i = 0; i < n; ++i) o.new2old[fill[color[i]]++] = i;
+    if (sigma > 0) {
+        for (int c = 0; c < o.n_colors; ++c) {
+            int lo = o.color_begin[c], hi = lo + count[c];
+            for (int w = lo; w < hi; w += sigma) {
+                int we = std::min(hi, w + sigma);
+                std::stable_sort(o.new2old.begin() + w, o.new2old.begin() + we, [&](int a, int b) {
+                    return (A.ptr[a + 1] - A.ptr[a]) > (A.ptr[b + 1] - A.ptr[b]);
+                });
+            }
+        }
+    }
+    for (int r = 0; r < o.n_pad; ++r)
+        if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
+    return o;
+}
+
+inline LevelOrdering identity_ordering(int n) {
+    LevelOrdering o;
+    o.n = n; o.n_pad = round_up(std::max(n, 1), kSlice); o.n_colors = 1;
+    o.color_begin = {0, o.n_pad};
+    o.new2old.assign(o.n_pad, -1);
+    o.old2new.resize(n);
+    for (int i = 0; i < n; ++i) { o.new2old[i] = i; o.old2new[i] = i; }
+    return o;
+}
+
+// Rows given as (ptr, idx, val) in DEVICE numbering for n_rows_pad rows -> SELL-64.
+// If sort_sigma > 0 the rows are re-sorted by length inside windows and row_of records the output row.
+inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const std::vector<int64_t>& ptr,
+                            const std::vector<int>& idx, const std::vector<double>& val, int sort_sigma) {
+    SellHost s;
+    s.n_rows_pad = n_rows_pad; s.n_cols = n_cols; s.n_slices = n_rows_pad / kSlice;
+    s.nnz_real = ptr[n_rows_pad];
+    std::vector<int> order(n_rows_pad);
+    std::iota(order.begin(), order.end(), 0);
+    if (sort_sigma > 0) {
+        for (int w = 0; w < n_rows_pad; w += sort_sigma) {
+            int we = std::min(n_rows_pad, w + sort_sigma);
+            std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) {
+                return (ptr[a + 1] - ptr[a]) > (ptr[b + 1] - ptr[b]);
+            });
+        }
+        s.row_of = order;
+    }
+    s.slice_ptr.assign((size_t)s.n_slices + 1, 0);
+    for (int sl = 0; sl < s.n_slices; ++sl) {
+        int64_t w = 0;
+        for (int l = 0; l < kSlice; ++l) {
+            int r = order[sl * kSlice + l];
+            w = std::max<int64_t>(w, ptr[r + 1] - ptr[r]);
+        }
+        s.slice_ptr[sl + 1] = s.slice_ptr[sl] + w * kSlice;
+    }
+    s.col.assign((size_t)s.stored(), 0);
+    s.val.assign((size_t)s.stored(), 0.0);
+    parallel_ranges(s.n_slices, hw_threads(), [&](int lo, int hi, int) {
+        for (int sl = lo; sl < hi; ++sl) {
+            int64_t base = s.slice_ptr[sl];
+            int64_t w = (s.slice_ptr[sl + 1] - base) / kSlice;
+            for (int l = 0; l < kSlice; ++l) {
+                int r = order[sl * kSlice + l];
+                int64_t len = ptr[r + 1] - ptr[r];
+                for (int64_t j = 0; j < w; ++j) {
+                    int64_t q = base + j * kSlice + l;
+                    if (j < len) { s.col[q] = idx[ptr[r] + j]; s.val[q] = val[ptr[r] + j]; }
+                    else { s.col[q] = 0; s.val[q] = 0.0; }   // padding: 0 * x[0]
+                }
+            }
+        }
+    });
+    return s;
+}
+
+// A (symmetric, natural numbering) -> off-diagonal SELL + diagonal, in the level's device numbering.
+// Returns false (and sets err) if a real row has no / a zero diagonal entry.
+inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int sigma_unused, SellHost& out,
+                                std::vector<double>& diag, std::string& err) {
+    (void)sigma_unused;
+    const int np = o.n_pad;
+    std::vector<int64_t> ptr((size_t)np + 1, 0);
+    diag.assign(np, 1.0);
+    for (int r = 0; r < np; ++r) {
+        int old = o.new2old[r];
+        int64_t len = 0;
+        if (old >= 0) {
+            bool has = false;
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+                if (A.idx[p] == old) { has = true; diag[r] = A.val[p]; }
+                else ++len;
+            }
+            if (!has || diag[r] == 0.0) { err = "system matrix has a missing or zero diagonal entry at row " + std::to_string(old); return false; }
+        }
+        ptr[r + 1] = ptr[r] + len;
+    }
+    std::vector<int> idx((size_t)ptr[np]);
+    std::vector<double> val((size_t)ptr[np]);
+    parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
+        std::vector<std::pair<int, double>> row;
+        for (int r = lo; r < hi; ++r) {
+            int old = o.new2old[r];
+            if (old < 0) continue;
+            row.clear();
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p)
+                if (A.idx[p] != old) row.emplace_back(o.old2new[A.idx[p]], A.val[p]);
+            std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            int64_t q = ptr[r];
+            for (auto& e : row) { idx[q] = e.first; val[q] = e.second; ++q; }
+        }
+    });
+    out = csr_to_sell(np, np, ptr, idx, val, 0);
+    return true;
+}
+
+// Generic: rows of `Mrows` (compressed, outer = rows in natural numbering of the row space) mapped into
+// device numbering of the row space (orow) and column space (ocol).
+inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering& orow, const LevelOrdering& ocol,
+                                    int sort_sigma) {
+    const int np = orow.n_pad;
+    std::vector<int64_t> ptr((size_t)np + 1, 0);
+    for (int r = 0; r < np; ++r) {
+        int old = orow.new2old[r];
+        ptr[r + 1] = ptr[r] + (old >= 0 ? Mrows.ptr[old + 1] - Mrows.ptr[old] : 0);
+    }
+    std::vector<int> idx((size_t)ptr[np]);
+    std::vector<double> val((size_t)ptr[np]);
+    parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
+        std::vector<std::pair<int, double>> row;
+        for (int r = lo; r < hi; ++r) {
+            int old = orow.new2old[r];
+            if (old < 0) continue;
+            row.clear();
+            for (int p = Mrows.ptr[old]; p < Mrows.ptr[old + 1]; ++p)
+                row.emplace_back(ocol.old2new[Mrows.idx[p]], Mrows.val[p]);
+            std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            int64_t q = ptr[r];
+            for (auto& e : row) { idx[q] = e.first; val[q] = e.second; ++q; }
+        }
+    });
+    return csr_to_sell(np, ocol.n_pad, ptr, idx, val, sort_sigma);
+}
+
+}  // namespace gmg

@@ -1,0 +1,244 @@
+// kernels.hip.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the V-cycle hot path.
+//
+// All sparse operators are SELL-64 (host_plan.hpp): one slice = 64 rows = one wavefront, one row per
+// lane, entries j-major inside the slice.  A wave's j-th load of col[] is 256 contiguous bytes and of
+// val[] 512 contiguous bytes (perfectly coalesced streams); the only irregular access is the gather of
+// x[col].  Each lane accumulates its row sequentially in stored (ascending device column) order, so the
+// result is deterministic and independent of the launch geometry.  These are HBM-bound irregular sparse
+// contractions (0.17-0.25 flop/byte): no MFMA, no LDS -- the slice pointer is wave-uniform (scalar
+// loads), x lives in L2 / Infinity Cache (24 MB at 3 M unknowns), matrices stream once per launch.
+//
+// Dense multi-vectors: column-major, leading dimension ld (= padded level size), D columns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmgk {
+
+constexpr int kBlock = 256;          // 4 wavefronts
+constexpr int kWavesPerBlock = kBlock / 64;
+
+// Slice handled by this wave.  With xcd_swizzle the grid is re-mapped so that each XCD (block b runs on
+// XCD b % 8, MI355X_MICROARCH.md "Workgroup dispatch") walks one contiguous eighth of the slice range:
+// neighbouring slices gather neighbouring x entries, which then hit the same per-XCD L2.
+__device__ __forceinline__ int wave_slice(int n_slices_total, int xcd_swizzle) {
+    int nblk = gridDim.x;
+    int b = blockIdx.x;
+    if (xcd_swizzle && (nblk & 7) == 0) b = (b & 7) * (nblk >> 3) + (b >> 3);
+    int w = b * kWavesPerBlock + (threadIdx.x >> 6);
+    (void)n_slices_total;
+    return __builtin_amdgcn_readfirstlane(w);
+}
+
+// acc[c] = sum_j val[j] * x[col[j] + c*ld] over this lane's row of slice s.
+template <int D>
+__device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                        const double* __restrict__ val, const double* x, int ld, int s, int lane,
+                                        double (&acc)[D]) {
+    const int64_t p0 = slice_ptr[s];
+    const int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+    const int* cp = col + p0 + lane;
+    const double* vp = val + p0 + lane;
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < w; ++j) {
+        const int cj = cp[(int64_t)j * 64];
+        const double vj = vp[(int64_t)j * 64];
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] += vj * x[cj + (int64_t)c * ld];
+    }
+}
+
+// One colour of a multicolour Gauss-Seidel sweep: rows [slice_begin*64, slice_end*64).
+//   x_i <- (b_i - sum_{j != i} a_ij x_j) / a_ii          (gravomg/src/multigrid_solver.cpp:1200-1208)
+// Rows of one colour do not couple, so the parallel update equals the reference's sequential sweep in
+// the colour-permuted ordering.
+template <int D>
+__global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                   const double* __restrict__ val, const double* __restrict__ diag,
+                                                   const double* __restrict__ b, double* x, int ld, int slice_begin,
+                                                   int slice_end, int xcd_swizzle) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
+    if (s >= slice_end) return;
+    const int lane = threadIdx.x & 63;
+    const int row = s * 64 + lane;
+    double acc[D];
+    row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    const double dg = diag[row];
+#pragma unroll
+    for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
+}
+
+// Weighted Jacobi sweep: x_out = x_in + omega * (b - A x_in) / diag.
+template <int D>
+__global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                       const double* __restrict__ val, const double* __restrict__ diag,
+                                                       const double* __restrict__ b, const double* __restrict__ x_in,
+                                                       double* __restrict__ x_out, int ld, int n_slices, double omega,
+                                                       int xcd_swizzle) {
+    const int s = wave_slice(n_slices, xcd_swizzle);
+    if (s >= n_slices) return;
+    const int lane = threadIdx.x & 63;
+    const int row = s * 64 + lane;
+    double acc[D];
+    row_dot<D>(slice_ptr, col, val, x_in, ld, s, lane, acc);
+    const double dg = diag[row];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double xi = x_in[row + (int64_t)c * ld];
+        x_out[row + (int64_t)c * ld] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
+    }
+}
+
+// MODE 0: y = A x      MODE 1: y = b - A x   (gravomg/src/multigrid_solver.cpp:1066)
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                    const double* __restrict__ val, const double* __restrict__ diag,
+                                                    const double* __restrict__ b, const double* __restrict__ x,
+                                                    double* __restrict__ y, int ld, int n_slices, int xcd_swizzle) {
+    const int s = wave_slice(n_slices, xcd_swizzle);
+    if (s >= n_slices) return;
+    const int lane = threadIdx.x & 63;
+    const int row = s * 64 + lane;
+    double acc[D];
+    row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    const double dg = diag[row];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double ax = acc[c] + dg * x[row + (int64_t)c * ld];
+        y[row + (int64_t)c * ld] = MODE == 1 ? b[row + (int64_t)c * ld] - ax : ax;
+    }
+}
+
+// Transfer operators.  ADD = 0: y[out_row] = sum val * x[col]   (restriction rc = U^T r, :1069)
+//                       ADD = 1: y[out_row] += sum val * x[col]  (prolongation x += U e, :1082)
+// row_of (may be null) maps the slice row to the output row (-1 = none); ldx/ldy are the leading
+// dimensions of the source / destination level.
+template <int D, int ADD>
+__global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                   const double* __restrict__ val, const int* __restrict__ row_of,
+                                                   const double* __restrict__ x, int ldx, double* __restrict__ y, int ldy,
+                                                   int n_slices, int xcd_swizzle) {
+    const int s = wave_slice(n_slices, xcd_swizzle);
+    if (s >= n_slices) return;
+    const int lane = threadIdx.x & 63;
+    double acc[D];
+    row_dot<D>(slice_ptr, col, val, x, ldx, s, lane, acc);
+    const int row = row_of ? row_of[s * 64 + lane] : s * 64 + lane;
+    if (row < 0) return;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        if (ADD) y[row + (int64_t)c * ldy] += acc[c];
+        else y[row + (int64_t)c * ldy] = acc[c];
+    }
+}
+
+// Residual norms (gravomg/src/multigrid_solver.cpp:1228-1277): per block, partial sums of
+// w_i r_i^2 and w_i b_i^2 for r = A x - b and w = weight ? weight[i] : 1.
+// partials layout: [block][2*D].  Reduced by reduce_partials (deterministic order).
+template <int D>
+__global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                                 const double* __restrict__ val, const double* __restrict__ diag,
+                                                                 const double* __restrict__ b, const double* __restrict__ x,
+                                                                 const double* __restrict__ weight, int ld, int n_slices,
+                                                                 double* __restrict__ partials) {
+    __shared__ double red[kWavesPerBlock][2 * D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = blockIdx.x * kWavesPerBlock + wave;
+    double sums[2 * D];
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
+    if (s < n_slices) {
+        const int row = s * 64 + lane;
+        double acc[D];
+        row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        const double dg = diag[row];
+        const double w = weight ? weight[row] : 1.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double bi = b[row + (int64_t)c * ld];
+            const double r = acc[c] + dg * x[row + (int64_t)c * ld] - bi;
+            sums[2 * c] = (r * w) * r;
+            sums[2 * c + 1] = (bi * w) * bi;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) {
+        double v = sums[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        double v = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) v += red[w2][threadIdx.x];
+        partials[(int64_t)blockIdx.x * (2 * D) + threadIdx.x] = v;
+    }
+}
+
+// out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of 256 threads, fixed order.
+__global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
+                                                          double* __restrict__ out) {
+    __shared__ double red[kBlock];
+    for (int c = 0; c < ncomp; ++c) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += partials[(int64_t)i * ncomp + c];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = kBlock / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = red[0];
+        __syncthreads();
+    }
+}
+
+// Natural (host) numbering <-> device numbering.  src natural: column-major n x D.
+__global__ void permute_in(const double* __restrict__ src, int n, const int* __restrict__ new2old, double* __restrict__ dst,
+                           int ld, int n_pad, int D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    const int old = new2old[r];
+    for (int c = 0; c < D; ++c) dst[r + (int64_t)c * ld] = old >= 0 ? src[old + (int64_t)c * n] : 0.0;
+}
+
+__global__ void permute_out(const double* __restrict__ src, int ld, int n_pad, const int* __restrict__ new2old,
+                            double* __restrict__ dst, int n, int D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    const int old = new2old[r];
+    if (old < 0) return;
+    for (int c = 0; c < D; ++c) dst[old + (int64_t)c * n] = src[r + (int64_t)c * ld];
+}
+
+// Coarsest level, GMG_COARSE_DEVICE_INVERSE: e = Ainv * rc, Ainv dense symmetric n x n (ld = n), one wave
+// per row, lanes stride the row (coalesced), wave reduction.  x/y leading dimension ldv.
+template <int D>
+__global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ Ainv, int n, const double* __restrict__ x,
+                                                     double* __restrict__ y, int ldv) {
+    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    double acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    const double* a = Ainv + (int64_t)row * n;
+    for (int j = lane; j < n; j += 64) {
+        const double v = a[j];
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] += v * x[j + (int64_t)c * ldv];
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double v = acc[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) y[row + (int64_t)c * ldv] = v;
+    }
+}
+
+}  // namespace gmgk

@@ -1,0 +1,178 @@
+/*
+ * gravomg_hip.h -- C-ABI of libgravomg_hip.so: the MI355X (gfx950) engine for the Gravo MG
+ * multigrid V-cycle hot path.
+ *
+ * The reference (rubenwiersma/gravo_mg) has no FFI seam for this path: MGBS::MultigridSolver::solve
+ * calls Eigen expression templates inline.  This header IS the seam a
+ * maintainer would put directly under `multiGridVCycleGS` / `solve`; each entry point names the
+ * reference code it replaces (paths relative to the reference repository root).  INTEGRATION.md shows
+ * the binding a reference maintainer would add (C++ member functions of MGBS::MultigridSolver and the
+ * pybind11 shim).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every call returns a gmg_status (0 = ok, < 0 = error);
+ *     gmg_last_error(h) returns a human-readable message for the last failing call on that handle.
+ *   - sparse matrices are passed exactly as Eigen::SparseMatrix<double> stores them: CSC, int32
+ *     indices, sorted inner indices (`colptr[ncols+1]`, `rowidx[nnz]`, `val[nnz]`).  System matrices
+ *     must be symmetric (the reference's Gauss-Seidel depends on it, multigrid_solver.cpp:1200-1208).
+ *   - dense multi-vectors are column-major n x d (Eigen::MatrixXd): column c starts at ptr + c*n.
+ *   - host pointers are borrowed for the duration of the call only; device memory, the HIP stream and
+ *     the captured hipGraphs are owned by the handle.  A handle is not thread-safe.
+ *   - all device entry points fail with GMG_ERR_NO_DEVICE when no HIP device is usable; there is no
+ *     CPU fallback behind this interface.
+ */
+#ifndef GRAVOMG_HIP_H
+#define GRAVOMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gmg_solver_s* gmg_handle;
+typedef struct gmg_hierarchy_s* gmg_hierarchy;
+
+typedef enum {
+    GMG_OK = 0,
+    GMG_ERR_INVALID = -1,      /* bad argument / shape */
+    GMG_ERR_NO_DEVICE = -2,    /* no usable HIP device */
+    GMG_ERR_HIP = -3,          /* a HIP runtime call failed */
+    GMG_ERR_STATE = -4,        /* call order: hierarchy / system not set */
+    GMG_ERR_NUMERIC = -5,      /* zero/missing diagonal, singular coarsest operator */
+    GMG_ERR_UNSUPPORTED = -6   /* option outside the hot-path scope (F/W-cycle, SIG06, ...) */
+} gmg_status;
+
+enum { GMG_SMOOTHER_MULTICOLOR_GS = 0, GMG_SMOOTHER_JACOBI = 1 };
+enum { GMG_COARSE_HOST_LDLT = 0, GMG_COARSE_DEVICE_INVERSE = 1 };
+
+typedef struct {
+    int device;            /* HIP device ordinal */
+    int smoother;          /* GMG_SMOOTHER_*: multicolour Gauss-Seidel (default) or weighted Jacobi */
+    double jacobi_omega;   /* damping for GMG_SMOOTHER_JACOBI (default 0.67) */
+    int pre_iters;         /* MultigridSolver::preIters  (gravomg_bindings/src/cpp/core.cpp:55) */
+    int post_iters;        /* MultigridSolver::postIters (core.cpp:56) */
+    int coarse_mode;       /* GMG_COARSE_*: where the coarsest direct solve is applied (default host) */
+    int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs (default 1) */
+    int sigma;             /* SELL sorting window in rows (multiple of 64; 0 = no sorting; default 1024) */
+    int row_align;         /* colour classes padded to this many rows (multiple of 64; default 64) */
+    int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
+    int verbose;
+} gmg_config;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+int gmg_config_default(gmg_config* cfg);
+/* Replaces the construction of the solver state the pybind shim owns
+ * (gravomg_bindings/src/cpp/core.cpp:27,138). */
+int gmg_create(const gmg_config* cfg, gmg_handle* out);
+void gmg_destroy(gmg_handle h);
+const char* gmg_last_error(gmg_handle h);
+/* Number of usable HIP devices (0 on a CPU-only box); never fails. */
+int gmg_device_count(void);
+
+/* ---- hierarchy input ------------------------------------------------------------------------ */
+/* Declare how many transfer levels follow (L = U.size()).  Drops any previous hierarchy/system. */
+int gmg_set_num_levels(gmg_handle h, int L);
+/* U[k], n_k x n_{k+1}, CSC.  Replaces the `U` member / set_prolongation_matrices
+ * (gravomg/include/gravomg/multigrid_solver.h:106, gravomg_bindings/src/cpp/core.cpp:86-88). */
+int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const int* colptr, const int* rowidx, const double* val);
+/* Lumped mass diagonal M (n_0 entries) used by the residual norms, multigrid_solver.h:96-97. */
+int gmg_set_mass(gmg_handle h, int n, const double* mass_diag);
+/* LHS for the next solves.  Performs what solve() does before its loop (multigrid_solver.cpp:1387-1401):
+ * Galerkin products Abar[k] = U[k-1]^T Abar[k-1] U[k-1], coarsest LDL^T factorisation, plus the device
+ * layout (colouring, SELL) and the upload.  Timings land in "reduction", "coarsest_solve", "upload". */
+int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val);
+
+/* ---- introspection -------------------------------------------------------------------------- */
+int gmg_num_levels(gmg_handle h);                       /* L, or < 0 */
+/* n_k, nnz(A_k), number of colours, padded device length of level k (0 <= k <= L). */
+int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int* n_pad);
+/* Copy out A_k (CSC).  k = 0 is the LHS, k >= 1 the Galerkin operators (the reference's Abar[k]). */
+int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double* val);
+/* Device numbering of level k: new2old[n_pad] (-1 = padding row), color_begin[n_colors+1]. */
+int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin);
+/* Named timers in ms, same keys as the reference's solverTiming (multigrid_solver.cpp:1394,1403,1445-1448):
+ * "reduction", "coarsest_solve", "cycles", "solver_total", "iterations", "residue"; plus "upload",
+ * "coarse_host_ms" (host back-substitutions inside the cycles). */
+int gmg_get_timing(gmg_handle h, const char* key, double* out);
+
+/* ---- operators (host in / host out; natural numbering).  Used by the parity tests -------------- */
+/* `iters` smoothing sweeps on level k: replaces GaussSeidelSmoother, multigrid_solver.cpp:1194-1226. */
+int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters);
+/* r = b - A_k x : multigrid_solver.cpp:1066. */
+int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, double* r);
+/* y = A_k x. */
+int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y);
+/* rc = U_k^T r : multigrid_solver.cpp:1069. */
+int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc);
+/* x += U_k e : multigrid_solver.cpp:1082. */
+int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x);
+/* e = A_L^{-1} rc with the configured coarse solver: multigrid_solver.cpp:1075. */
+int gmg_coarse_solve(gmg_handle h, const double* rc, int d, double* e);
+/* residualCheck(A_0, b, x, type), multigrid_solver.cpp:1228-1277 (types 0..3). */
+int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int type, double* out);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+/* One V-cycle on level 0, x updated in place: multiGridVCycleGS, multigrid_solver.cpp:1059-1088. */
+int gmg_vcycle(gmg_handle h, const double* b, double* x, int d);
+/* The MG branch of solve(), multigrid_solver.cpp:1408-1419: do { V-cycle; residualCheck } while
+ * (residue > tol && it < max_iter).  x arrives holding the initial guess (the binding passes x0 = rhs,
+ * gravomg_bindings/src/cpp/core.cpp:69).  conv (optional) receives (elapsed_ms, residue) pairs and must
+ * hold 2*max_iter doubles. */
+int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter,
+              int* iters_out, double* residue_out, double* conv);
+
+/* ---- resident problem (device-resident b / x; what gmg_solve and bench.py are built from) ---------- */
+/* Upload rhs and the initial guess (natural numbering, n_0 x d) and keep them resident. */
+int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d);
+/* Run n_cycles V-cycles on the resident problem.  stop_type >= 0: each cycle is followed by the residual
+ * check of that type exactly as the solve loop does (residues[i] receives it; residues may be NULL);
+ * stop_type < 0: cycles only.  Returns after the stream has drained. */
+int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
+/* Download the resident iterate (natural numbering). */
+int gmg_fetch_solution(gmg_handle h, double* x);
+
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:
+ * kind 0 = full smoothing sweep (all colours), 1 = residual r=b-Ax, 2 = restrict, 3 = prolong_add,
+ * 4 = residual-norm kernels.  The repetitions are enqueued back to back between two events (the way the
+ * V-cycle issues them); launches_out = kernel launches per repetition (colours for the sweep). */
+int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out);
+/* Algorithmic (compulsory) bytes of the same unit of work, SURVEY.md 8(d). */
+int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out);
+
+/* ---- host-only: hierarchy construction (no device needed) ----------------------------------- */
+typedef struct {
+    double ratio;          /* core.py:10 ratio=8.0 */
+    int lower_bound;       /* lower_bound=1000 */
+    int check_voronoi;     /* 1 */
+    int nested;            /* 0 */
+    int sampling;          /* Sampling enum (multigrid_solver.h:40-46); only 0 = FASTDISK is supported */
+    int weighting;         /* Weighting enum (multigrid_solver.h:48-52): 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST */
+} gmg_hierarchy_options;
+
+int gmg_hierarchy_options_default(gmg_hierarchy_options* o);
+/* Replaces MGBS::MultigridSolver::buildHierarchy / constructProlongation
+ * (gravomg/src/multigrid_solver.cpp:43-60, 62-469).  pos: n x 3 row-major; neigh: n x K row-major,
+ * padded with -1 (gravomg_bindings/src/cpp/core.cpp:15-18). */
+int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt,
+                        gmg_hierarchy* out);
+void gmg_hierarchy_destroy(gmg_hierarchy hh);
+int gmg_hierarchy_num_levels(gmg_hierarchy hh);                            /* U.size() */
+int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coarse, int* nnz);
+int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val);
+/* hierarchyTiming keys of the reference (multigrid_solver.cpp:21,57,90-97). */
+int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out);
+/* Convenience: feed every U_k of a built hierarchy into a solver handle. */
+int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
+
+/* Host-only Galerkin product Ac = U^T A U (CSC in / CSC out, caller sizes the output with the first call:
+ * pass colptr_out only to get nnz in colptr_out[n_coarse]).  Exposed for the RAP parity tests. */
+int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const double* a_val,
+                      int n_coarse, const int* u_colptr, const int* u_rowidx, const double* u_val,
+                      int* c_colptr, int* c_rowidx, double* c_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAVOMG_HIP_H */

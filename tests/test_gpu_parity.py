@@ -1,0 +1,201 @@
+"""GPU parity: every hot-path operator, the V-cycle and the solve loop of libgravomg_hip.so (through the
+C-ABI) against the CPU restatement in oracle/ on the same seeded inputs.
+
+Tolerances (fp64, stated per test):
+  * operators (SpMV, residual, restriction, prolongation, norms): <= 1e-13 relative (only the order of a
+    handful of additions differs from the oracle);
+  * multicolour Gauss-Seidel == the reference's lexicographic Gauss-Seidel applied to the colour-permuted
+    system P A P^T: <= 1e-12 relative against the oracle run on P A P^T;
+  * V-cycle / solve with the GPU smoother are a DIFFERENT (equally valid) iteration from natural-order GS:
+    parity is on the converged solution -- both reach the reference's stopping test (M-norm <= tol) and the
+    two solutions agree to ||dx||_M/||x||_M <= 20*tol; iteration counts are reported, equal +-2.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+@pytest.fixture(scope="module", params=["poisson-d1", "smoothing-d3", "pointcloud", "random-order"])
+def setup(request, cabi):
+    if request.param == "poisson-d1":
+        P = problems.torus_problem(48, 40, "poisson", 60)
+    elif request.param == "smoothing-d3":
+        P = problems.torus_problem(40, 36, "smoothing", 60)
+    elif request.param == "pointcloud":
+        P = problems.pointcloud_problem(3000)
+    else:
+        P = problems.torus_problem(48, 40, "poisson", 60, order="random")
+    assert cabi.device_count() > 0, "gpu tests need a HIP device"
+    eng = cabi.Engine()
+    eng.set_prolongations(P.U)
+    eng.set_mass(P.mass)
+    eng.set_system(P.lhs)
+    return P, eng
+
+
+def test_levels_and_galerkin(setup, oracle):
+    P, eng = setup
+    O = oracle.Hierarchy(P.U, P.mass)
+    O.set_system(P.lhs)
+    assert eng.num_levels == len(P.U) >= 1
+    for k in range(len(P.U) + 1):
+        A, Ao = eng.level_operator(k), O.level_operator(k)
+        assert A.shape == Ao.shape
+        assert (A != 0).nnz <= Ao.nnz
+        assert abs(A - Ao).max() <= 1e-13 * abs(Ao).max()
+
+
+def test_spmv_residual(setup, oracle):
+    P, eng = setup
+    rng = np.random.default_rng(0)
+    for k in range(len(P.U)):
+        A = eng.level_operator(k)
+        for d in (1, 3):
+            x = rng.standard_normal((A.shape[0], d)); b = rng.standard_normal((A.shape[0], d))
+            assert rel(eng.spmv(k, x), A @ x) <= 1e-13
+            assert rel(eng.residual(k, b, x), oracle.residual(A, b, x)) <= 1e-13
+
+
+def test_transfers(setup, oracle):
+    P, eng = setup
+    rng = np.random.default_rng(1)
+    for k, U in enumerate(P.U):
+        for d in (1, 3):
+            r = rng.standard_normal((U.shape[0], d)); e = rng.standard_normal((U.shape[1], d)); x = rng.standard_normal((U.shape[0], d))
+            assert rel(eng.restrict(k, r), oracle.restrict(U, r)) <= 1e-13
+            assert rel(eng.prolong_add(k, e, x), oracle.prolong_add(U, e, x)) <= 1e-13
+
+
+def test_multicolor_gs_is_reference_gs_on_permuted_system(setup, oracle):
+    P, eng = setup
+    rng = np.random.default_rng(2)
+    for k in range(len(P.U)):
+        A = eng.level_operator(k)
+        new2old, color_begin = eng.level_ordering(k)
+        Ap, order = problems.permuted_system(A, new2old)
+        # colouring is proper: no edge inside a colour class
+        colour_of = np.empty(A.shape[0], int)
+        for c in range(len(color_begin) - 1):
+            rows = new2old[color_begin[c]:color_begin[c + 1]]
+            colour_of[rows[rows >= 0]] = c
+        coo = sp.coo_matrix(A)
+        off = coo.row != coo.col
+        assert np.all(colour_of[coo.row[off]] != colour_of[coo.col[off]])
+        for d in (1, 3):
+            b = rng.standard_normal((A.shape[0], d)); x = rng.standard_normal((A.shape[0], d))
+            for iters in (1, 2):
+                got = eng.smooth(k, b, x, iters)
+                want_p = oracle.gauss_seidel(Ap, b[order], x[order], iters)
+                want = np.empty_like(want_p); want[order] = want_p
+                assert rel(got, want) <= 1e-12
+
+
+def test_norms(setup, oracle):
+    P, eng = setup
+    rng = np.random.default_rng(3)
+    d = P.rhs.shape[1]
+    x = rng.standard_normal((P.n, d))
+    for t in (0, 1, 2, 3):
+        got = eng.residual_norm(P.rhs, x, t)
+        want = oracle.residual_check(P.lhs, P.mass, P.rhs, x, t)
+        assert abs(got - want) <= 1e-12 * abs(want)
+
+
+def test_coarse_solve(setup, oracle):
+    P, eng = setup
+    AL = eng.level_operator(len(P.U))
+    rng = np.random.default_rng(4)
+    rc = rng.standard_normal((AL.shape[0], 3))
+    e = eng.coarse_solve(rc)
+    assert rel(AL @ e, rc) <= 1e-9
+
+
+def test_vcycle_matches_oracle_with_same_ordering(setup, oracle):
+    """One V-cycle where the oracle is given the device's colour ordering on every level: same algebra,
+    only floating-point summation order differs."""
+    P, eng = setup
+    L = len(P.U)
+    orders = []
+    for k in range(L):
+        n2o, _ = eng.level_ordering(k)
+        orders.append(n2o[n2o >= 0])
+    orders.append(np.arange(P.U[-1].shape[1]))
+    Up = [sp.csc_matrix(P.U[k].tocsr()[orders[k]][:, orders[k + 1]]) for k in range(L)]
+    lhs_p = sp.csc_matrix(P.lhs.tocsr()[orders[0]][:, orders[0]])
+    O = oracle.Hierarchy(Up, P.mass[orders[0]])
+    O.set_system(lhs_p)
+    x0 = P.rhs.copy()
+    got = eng.vcycle(P.rhs, x0)
+    want_p = O.vcycle(P.rhs[orders[0]], x0[orders[0]])
+    want = np.empty_like(want_p); want[orders[0]] = want_p
+    assert rel(got, want) <= 1e-10
+
+
+def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
+    P, eng = setup
+    tol = 1e-4
+    x, it, res, conv = eng.solve(P.rhs, tol=tol, stop_type=2, max_iter=100)
+    assert res <= tol and it < 100 and conv.shape == (it, 2)
+    assert abs(oracle.residual_check(P.lhs, P.mass, P.rhs, x, 2) - res) <= 1e-9 * res + 1e-15
+    O = oracle.Hierarchy(P.U, P.mass)
+    O.set_system(P.lhs)
+    xo, ito, reso, _ = O.solve(P.rhs, tol=tol)
+    assert reso <= tol
+    assert abs(it - ito) <= 2, (it, ito)
+    m = P.mass[:, None] if x.ndim == 2 else P.mass
+    dx = np.sqrt((m * (x - xo) ** 2).sum()) / np.sqrt((m * xo ** 2).sum())
+    assert dx <= 20 * tol
+    # tight solve: both converge to the same fixed point
+    x2, it2, res2, _ = eng.solve(P.rhs, tol=1e-10, max_iter=100)
+    xo2, _, reso2, _ = O.solve(P.rhs, tol=1e-10)
+    assert res2 <= 1e-10 and reso2 <= 1e-10
+    dx2 = np.sqrt((m * (x2 - xo2) ** 2).sum()) / np.sqrt((m * xo2 ** 2).sum())
+    assert dx2 <= 1e-6
+
+
+@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "no_graph"])
+def test_engine_variants(cabi, oracle, variant):
+    P = problems.torus_problem(48, 40, "poisson", 60)
+    kw = {"jacobi": dict(smoother=cabi.SMOOTHER_JACOBI), "device_coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
+          "no_graph": dict(use_graph=False)}[variant]
+    eng = cabi.Engine(**kw)
+    eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    x, it, res, _ = eng.solve(P.rhs, tol=1e-8, max_iter=200)
+    assert res <= 1e-8
+    ref = cabi.Engine()
+    ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(P.lhs)
+    xr, itr, resr, _ = ref.solve(P.rhs, tol=1e-8, max_iter=200)
+    assert rel(x, xr) <= 1e-5
+    if variant != "jacobi":
+        assert it == itr
+        assert rel(x, xr) <= 1e-9
+    if variant == "jacobi":
+        # weighted Jacobi sweep == x + w D^-1 (b - A x), checked against the oracle's residual
+        A = eng.level_operator(0)
+        rng = np.random.default_rng(5)
+        b = rng.standard_normal(A.shape[0]); x0 = rng.standard_normal(A.shape[0])
+        want = x0 + 0.67 * oracle.residual(A, b, x0) / A.diagonal()
+        assert rel(eng.smooth(0, b, x0, 1), want) <= 1e-13
+
+
+def test_errors_are_loud(cabi):
+    eng = cabi.Engine()
+    with pytest.raises(cabi.GmgError):
+        eng.set_system(sp.identity(10, format="csc"))           # no hierarchy
+    P = problems.torus_problem(48, 40, "poisson", 60)
+    eng.set_prolongations(P.U)
+    bad = P.lhs.tolil(); bad[5, 5] = 0.0
+    with pytest.raises(cabi.GmgError) as ei:
+        bad = sp.csc_matrix(bad); bad.eliminate_zeros(); eng.set_system(bad)
+    assert ei.value.code == cabi.GMG_ERR_NUMERIC
+    eng.set_system(P.lhs)
+    with pytest.raises(cabi.GmgError):
+        eng.residual_norm(P.rhs, P.rhs, 2)                       # mass not set
