@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- the Gravo MG V-cycle hot path on MI355X: V-cycle wall time + solve-to-1e-4 iterations on a
+~3 M-vertex mesh Poisson problem (BASELINE.json metric), with the fine-level kernel's HBM roofline and the
+1-core CPU restatement timed beside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--n1 1732 --n2 1732]
+
+A "step" is ONE V-cycle followed by the residual check, exactly one trip of the reference's solve loop
+(gravomg/src/multigrid_solver.cpp:1411-1417), on device-resident data.  Workload:
+jittered torus 1732 x 1732 = 2 999 824 vertices, cotangent Laplacian, lhs = 1e-6*M + S, rhs = M*y,
+y ~ N(0,1) seed 42, d = 1, x0 = rhs, ratio 8, lower_bound 1000, 2+2 smoothing sweeps, M-norm stop at 1e-4.
+
+For N > 1 the driver launches this file under torch.distributed.run; the finest level is row-partitioned
+and the ranks exchange their slices of x with an RCCL all-gather between colour sweeps
+(gravo_mg_amd/dist.py).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(n1, n2, order="natural"):
+    from gravo_mg_amd import cabi, meshgen
+    t = time.perf_counter()
+    V, F = meshgen.torus_mesh(n1, n2, order=order)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    log(f"[bench] mesh + Laplacian: n={V.shape[0]} nnz={S.nnz} ({time.perf_counter() - t:.1f}s)")
+    t = time.perf_counter()
+    H = cabi.Hierarchy(V, neigh, ratio=8.0, lower_bound=1000)
+    log(f"[bench] hierarchy: dof={[H.U[0].shape[0]] + [u.shape[1] for u in H.U]} ({time.perf_counter() - t:.1f}s)")
+    lhs, rhs = meshgen.poisson_system(S, mass, tau=1e-6, seed=42, d=1)
+    return H, mass, lhs, rhs
+
+
+def load_pmc_traffic(workload):
+    """HBM bytes per fine-level launch from the committed rocprofv3 --pmc summary (profiles/), if one matches."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            j = json.load(f)
+        if j.get("workload") == workload:
+            return j.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(H, mass, lhs, rhs, cycles):
+    """The oracle (line-by-line CPU restatement, 1 thread as the reference pins omp_set_num_threads(1),
+    multigrid_solver.cpp:86-87) on the SAME workload: Galerkin setup + `cycles` V-cycles with residual check."""
+    from oracle import oracle
+    oracle.build()
+    O = oracle.Hierarchy(H.U, mass)
+    t = time.perf_counter()
+    O.set_system(lhs)
+    setup_s = time.perf_counter() - t
+    t = time.perf_counter()
+    x, it, res, conv = O.solve(rhs, tol=0.0, stop_type=2, max_iter=cycles)     # tol 0 => exactly `cycles` trips
+    cyc_s = time.perf_counter() - t
+    return {
+        "value": 1e3 * cyc_s / it, "unit": "ms per V-cycle (incl. residual check)", "cores": 1, "kind": "port",
+        "sample": f"{it} V-cycles + residual checks of the full {lhs.shape[0]}-vertex workload (x0=rhs) after the Galerkin setup",
+        "setup_ms": {"reduction": O.timing["reduction"], "coarsest_solve": O.timing["coarsest_solve"], "total": 1e3 * setup_s},
+        "residues": [float(r) for r in conv[:, 1]],
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n1", type=int, default=1732)
+    ap.add_argument("--n2", type=int, default=1732)
+    ap.add_argument("--order", default="natural", choices=["natural", "random"])
+    ap.add_argument("--cpu-cycles", type=int, default=3, help="V-cycles timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--coarse", default="host", choices=["host", "device"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kernel-reps", type=int, default=50)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:
+        from gravo_mg_amd import dist_bench
+        return dist_bench.main(args)
+
+    import torch
+    from gravo_mg_amd import cabi
+
+    assert torch.cuda.is_available() and cabi.device_count() > 0, "bench.py needs a HIP device (no CPU fallback)"
+    workload = f"torus{args.n1}x{args.n2}-poisson-tau1e-6-d1-{args.order}"
+    H, mass, lhs, rhs = build_workload(args.n1, args.n2, args.order)
+    n0 = lhs.shape[0]
+
+    eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT,
+                      use_graph=not args.no_graph)
+    eng.use_hierarchy(H)
+    eng.set_mass(mass)
+    t = time.perf_counter()
+    eng.set_system(lhs)
+    setup_ms = 1e3 * (time.perf_counter() - t)
+    levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
+    log(f"[bench] set_system {setup_ms:.0f} ms (reduction {eng.timing('reduction'):.0f}, coarsest {eng.timing('coarsest_solve'):.0f}, "
+        f"upload {eng.timing('upload'):.0f}); levels {levels}")
+
+    # ---- timed region: K V-cycles (+ residual check each) on resident data ------------------------------
+    eng.load_problem(rhs, rhs)                       # x0 = rhs (gravomg_bindings/src/cpp/core.cpp:69)
+    eng.run_cycles(args.warmup, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    residues = eng.run_cycles(args.steps, 2)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ms_per_step = 1e3 * (t1 - t0) / args.steps
+
+    # ---- solve-to-tolerance (fresh start), the other half of the metric ----------------------------------
+    t = time.perf_counter()
+    x, iters, res, conv = eng.solve(rhs, tol=1e-4, stop_type=2, max_iter=100)
+    solve_ms = 1e3 * (time.perf_counter() - t)
+    timing = {k: eng.timing(k) for k in ("reduction", "coarsest_solve", "upload", "cycles", "solve_call", "solver_total", "coarse_host_ms")}
+
+    # ---- roofline of the dominant kernel: fine-level Gauss-Seidel colour launches (gs_color<1,1>) --------
+    sweep_ms, launches = eng.bench_kernel(0, 0, 1, args.kernel_reps)
+    sweep_bytes = eng.algorithmic_bytes(0, 0, 1)
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+    kern = {}
+    for name, kind in (("residual", 1), ("restrict", 2), ("prolong_add", 3), ("norm", 4)):
+        ms, _ = eng.bench_kernel(kind, 0, 1, args.kernel_reps)
+        by = eng.algorithmic_bytes(kind, 0, 1)
+        kern[name] = {"ms": ms, "GBps": by / (ms * 1e-3) / 1e9}
+    roofline = {
+        "bound": "hbm", "kernel": "gmgk::gs_color<1,1> (fine-level multicolour Gauss-Seidel, one launch per colour)",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": load_pmc_traffic(workload),
+        "launch_ms": sweep_ms / launches, "launches_per_sweep": launches,
+        "algorithmic_bytes_per_launch": sweep_bytes / launches,
+        "other_fine_kernels": kern,
+    }
+
+    cpu = cpu_baseline(H, mass, lhs, rhs, args.cpu_cycles) if args.cpu_cycles > 0 else None
+
+    out = {
+        "metric": "V-cycle wall time (ms per V-cycle incl. residual check) + solve-to-1e-4 iterations, 3M-vertex Poisson",
+        "value": ms_per_step, "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
+                   "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": not args.no_graph,
+                   "tolerance": 1e-4, "stopping_criteria": 2},
+        "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms, "solver_timing_ms": timing,
+        "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
+        "timed_residues_tail": [float(r) for r in residues[-3:]],
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    if cpu:
+        out["speedup_vs_cpu_per_cycle"] = cpu["value"] / ms_per_step
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -171,15 +171,22 @@ inline int grid_for(int n_slices) {
 
 void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
+    const bool fine = &l == &h->lv[0];
     for (int it = 0; it < iters; ++it)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             for (int c = 0; c < l.ord.n_colors; ++c) {
                 int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
                 if (se <= sb) continue;
-                DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::gs_color<D>, dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                  l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
-                                                  l.x + (size_t)c0 * ld, ld, sb, se, 1));
+                if (fine) {
+                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                      l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
+                                                      l.x + (size_t)c0 * ld, ld, sb, se, 1));
+                } else {
+                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                      l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
+                                                      l.x + (size_t)c0 * ld, ld, sb, se, 1));
+                }
             }
         }
 }

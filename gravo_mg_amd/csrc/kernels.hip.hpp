@@ -53,8 +53,9 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
 // One colour of a multicolour Gauss-Seidel sweep: rows [slice_begin*64, slice_end*64).
 //   x_i <- (b_i - sum_{j != i} a_ij x_j) / a_ii          (gravomg/src/multigrid_solver.cpp:1200-1208)
 // Rows of one colour do not couple, so the parallel update equals the reference's sequential sweep in
-// the colour-permuted ordering.
-template <int D>
+// the colour-permuted ordering.  FINE tags the level-0 instantiation so that profilers report the dominant
+// (fine-level) launches under their own kernel name.
+template <int D, int FINE>
 __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const double* __restrict__ val, const double* __restrict__ diag,
                                                    const double* __restrict__ b, double* x, int ld, int slice_begin,

@@ -86,7 +86,7 @@ def cotan_laplacian(V, F):
     area = face_area(V, F)
     mass = np.zeros(n)
     for a in range(3):
-        np.add.at(mass, F[:, a], area / 3.0)
+        mass += np.bincount(F[:, a], weights=area / 3.0, minlength=n)
     return S, mass
 
 
