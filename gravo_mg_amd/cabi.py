@@ -40,7 +40,8 @@ class GmgConfig(C.Structure):
     _fields_ = [
         ("device", C.c_int), ("smoother", C.c_int), ("jacobi_omega", C.c_double), ("pre_iters", C.c_int),
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
-        ("row_align", C.c_int), ("host_threads", C.c_int), ("verbose", C.c_int),
+        ("row_align", C.c_int), ("block_rows", C.c_int), ("block_from_level", C.c_int), ("host_threads", C.c_int),
+        ("verbose", C.c_int),
     ]
 
 
@@ -71,6 +72,7 @@ SIGNATURES = {
     "gmg_level_info": (C.c_int, [_vp, C.c_int, _ip, C.POINTER(C.c_int64), _ip, _ip]),
     "gmg_get_level_operator": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gmg_get_level_ordering": (C.c_int, [_vp, C.c_int, _ip, _ip]),
+    "gmg_get_level_blocks": (C.c_int, [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
     "gmg_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_smooth": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int]),
     "gmg_residual": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
@@ -206,13 +208,15 @@ class Engine:
     """One gmg_handle: device-resident hierarchy + V-cycle on one HIP stream."""
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
-                 coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, device=0, verbose=False):
+                 coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, block_rows=1024, block_from_level=1,
+                 device=0, verbose=False):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
         cfg.device, cfg.smoother, cfg.jacobi_omega = int(device), int(smoother), float(jacobi_omega)
         cfg.pre_iters, cfg.post_iters, cfg.coarse_mode = int(pre_iters), int(post_iters), int(coarse_mode)
         cfg.use_graph, cfg.sigma, cfg.row_align, cfg.verbose = int(bool(use_graph)), int(sigma), int(row_align), int(bool(verbose))
+        cfg.block_rows, cfg.block_from_level = int(block_rows), int(block_from_level)
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -284,6 +288,16 @@ class Engine:
         new2old = np.empty(info["n_pad"], np.int32); cb = np.empty(info["n_colors"] + 1, np.int32)
         self._chk(lib().gmg_get_level_ordering(self._h, k, _pi(new2old), _pi(cb)))
         return new2old, cb
+
+    def level_blocks(self, k: int):
+        """(blk_begin[n_blocks+1], row_color[n_pad]) of a blocked level, or None for a colour-major level."""
+        nb = C.c_int()
+        self._chk(lib().gmg_get_level_blocks(self._h, k, C.byref(nb), None, None))
+        if nb.value == 0:
+            return None
+        bb = np.empty(nb.value + 1, np.int32); rc = np.empty(self.level_info(k)["n_pad"], np.uint8)
+        self._chk(lib().gmg_get_level_blocks(self._h, k, C.byref(nb), _pi(bb), rc.ctypes.data_as(C.POINTER(C.c_ubyte))))
+        return bb, rc
 
     def timing(self, key: str) -> float:
         out = C.c_double()

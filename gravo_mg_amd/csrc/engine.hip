@@ -47,6 +47,11 @@ struct Level {
     DevSell Aoff;                 // off-diagonal part, device numbering
     double* diag = nullptr;       // n_pad
     DevSell P, R;                 // U_k (rows: this level) and U_k^T (rows: next level); unused on level L
+    // blocked levels (block-hybrid Gauss-Seidel): in-block part (16-bit local columns) + off-block part
+    DevSell Ain, Aout;
+    unsigned short* ain_col16 = nullptr;
+    int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
+    unsigned char* d_row_color = nullptr;
     int* d_new2old = nullptr;
     double *x = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;   // n_pad * dcap
 };
@@ -132,7 +137,11 @@ int upload_sell(gmg_handle h, DevSell& d, const SellHost& s) {
 }
 
 void free_level(Level& l) {
-    free_sell(l.Aoff); free_sell(l.P); free_sell(l.R);
+    free_sell(l.Aoff); free_sell(l.P); free_sell(l.R); free_sell(l.Ain); free_sell(l.Aout);
+    if (l.ain_col16) { (void)hipFree(l.ain_col16); l.ain_col16 = nullptr; }
+    if (l.d_blk_begin) { (void)hipFree(l.d_blk_begin); l.d_blk_begin = nullptr; }
+    if (l.d_blk_ncolors) { (void)hipFree(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
+    if (l.d_row_color) { (void)hipFree(l.d_row_color); l.d_row_color = nullptr; }
     for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (l.d_new2old) { (void)hipFree(l.d_new2old); l.d_new2old = nullptr; }
 }
@@ -206,9 +215,28 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
     if (in != l.x) (void)hipMemcpyAsync(l.x, in, sizeof(double) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
 }
 
+// block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
+void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const int ld = l.n_pad;
+    const int nb = l.ord.n_blocks();
+    double* in = l.x; double* out = l.tmp;
+    for (int it = 0; it < iters; ++it) {
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<D, 32>), dim3(nb), dim3(gmgk::kBlockRows), 0, h->stream, l.d_blk_begin,
+                                              l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
+                                              l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                              out + (size_t)c0 * ld, ld));
+        }
+        std::swap(in, out);
+    }
+    if (in != l.x) (void)hipMemcpyAsync(l.x, in, sizeof(double) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+}
+
 void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
     if (iters <= 0) return;
     if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps(h, l, d, iters);
+    else if (l.ord.blocked) launch_block_sweeps(h, l, d, iters);
     else launch_gs_sweeps(h, l, d, iters);
 }
 
@@ -285,7 +313,7 @@ int ensure_vectors(gmg_handle h, int d) {
     for (auto& l : h->lv) {
         for (double** p : {&l.x, &l.b, &l.r, &l.tmp}) {
             if (*p) { (void)hipFree(*p); *p = nullptr; }
-            if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI) continue;
+            if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
             size_t bytes = sizeof(double) * (size_t)l.n_pad * d;
             HIPCHK(hipMalloc((void**)p, bytes));
             HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
@@ -456,6 +484,8 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->use_graph = 1;
     cfg->sigma = 1024;
     cfg->row_align = 64;
+    cfg->block_rows = 1024;
+    cfg->block_from_level = 1;
     cfg->host_threads = 0;
     cfg->verbose = 0;
     return GMG_OK;
@@ -471,7 +501,8 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
     if (!out) return GMG_ERR_INVALID;
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
-    if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0) return GMG_ERR_INVALID;
+    if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
+        c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
     if (h->cfg.host_threads <= 0) h->cfg.host_threads = hw_threads();
@@ -571,7 +602,11 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     for (int k = 0; k <= L; ++k) {
         Level& l = h->lv[k];
         l.n = l.A.n_outer;
-        l.ord = k < L ? make_ordering(l.A, mc, h->cfg.row_align, h->cfg.sigma) : identity_ordering(l.n);
+        const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
+        if (k == L) l.ord = identity_ordering(l.n);
+        else if (blocked) l.ord = make_block_ordering(l.A, h->cfg.block_rows);
+        else l.ord = make_ordering(l.A, mc, h->cfg.row_align, h->cfg.sigma);
+        if (l.ord.n_colors > 255) return fail(h, GMG_ERR_UNSUPPORTED, "more than 255 colours on level " + std::to_string(k));
         l.n_pad = l.ord.n_pad;
     }
     for (int k = 0; k <= L; ++k) {
@@ -583,6 +618,18 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if (!build_operator_sell(l.A, l.ord, 0, sa, dg, e)) return fail(h, GMG_ERR_NUMERIC, "level " + std::to_string(k) + ": " + e);
         if ((rc = upload_sell(h, l.Aoff, sa))) return rc;
         if ((rc = upload(h, &l.diag, dg))) return rc;
+        SellHost sin, sout;
+        std::vector<unsigned short> c16;
+        if (l.ord.blocked) {
+            build_operator_sell_split(l.A, l.ord, sin, sout);
+            c16.assign(sin.col.begin(), sin.col.end());
+            if ((rc = upload_sell(h, l.Ain, sin))) return rc;
+            if ((rc = upload_sell(h, l.Aout, sout))) return rc;
+            if ((rc = upload(h, &l.ain_col16, c16))) return rc;
+            if ((rc = upload(h, &l.d_blk_begin, l.ord.blk_begin))) return rc;
+            if ((rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors))) return rc;
+            if ((rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
+        }
         Compressed Urows = transpose(h->U[k]);                                     // outer = fine rows
         SellHost sp = build_transfer_sell(Urows, l.ord, h->lv[k + 1].ord, 0);
         if ((rc = upload_sell(h, l.P, sp))) return rc;
@@ -660,6 +707,17 @@ int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin) 
     const LevelOrdering& o = h->lv[k].ord;
     if (new2old) std::memcpy(new2old, o.new2old.data(), sizeof(int) * o.n_pad);
     if (color_begin) std::memcpy(color_begin, o.color_begin.data(), sizeof(int) * (o.n_colors + 1));
+    return GMG_OK;
+}
+
+int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, unsigned char* row_color) {
+    if (!h) return GMG_ERR_INVALID;
+    int rc = check_level(h, k, true);
+    if (rc) return rc;
+    const LevelOrdering& o = h->lv[k].ord;
+    if (n_blocks) *n_blocks = o.blocked ? o.n_blocks() : 0;
+    if (o.blocked && blk_begin) std::memcpy(blk_begin, o.blk_begin.data(), sizeof(int) * o.blk_begin.size());
+    if (o.blocked && row_color) std::memcpy(row_color, o.row_color.data(), o.row_color.size());
     return GMG_OK;
 }
 
@@ -881,7 +939,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     int launches = 1;
     auto body = [&]() {
         switch (kind) {
-            case 0: launch_smooth(h, l, d, 1); launches = h->cfg.smoother == GMG_SMOOTHER_JACOBI ? 1 : l.ord.n_colors; break;
+            case 0: launch_smooth(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors; break;
             case 1: launch_spmv(h, l, d, 1, l.b, l.x, l.r); break;
             case 2: launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b); break;
             case 3: launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x); break;

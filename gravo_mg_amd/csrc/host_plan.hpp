@@ -32,6 +32,13 @@ struct LevelOrdering {
     std::vector<int> color_begin;     // n_colors + 1, in device rows (multiples of row_align)
     std::vector<int> new2old;         // n_pad, -1 for padding rows
     std::vector<int> old2new;         // n
+    // "blocked" levels (block-hybrid Gauss-Seidel, one launch per sweep): rows grouped into compact
+    // blocks of <= block_rows rows, colour-sorted inside a block, each block padded to 64 rows.
+    bool blocked = false;
+    std::vector<int> blk_begin;       // n_blocks + 1, device rows (multiples of 64)
+    std::vector<int> blk_ncolors;     // n_blocks
+    std::vector<unsigned char> row_color;   // n_pad, colour of a row inside its block (padding rows: 0)
+    int n_blocks() const { return blk_begin.empty() ? 0 : (int)blk_begin.size() - 1; }
 };
 
 struct SellHost {
@@ -98,6 +105,88 @@ inline LevelOrdering make_ordering(const Compressed& A, bool multicolor, int row
             }
         }
     }
+    for (int r = 0; r < o.n_pad; ++r)
+        if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
+    return o;
+}
+
+// Block ordering for the block-hybrid smoother.  Blocks are grown breadth-first over the matrix graph
+// from seeds taken on the frontier of what is already assigned, so they are compact patches whatever the
+// input vertex order is (a contiguous range of a row-major mesh ordering would be a thin strip with nearly
+// every edge cut).  Inside a block: greedy colouring of the in-block subgraph in BFS order, rows sorted by
+// colour.  Every block is padded to a multiple of 64 rows so SELL slices never straddle blocks.
+inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
+    LevelOrdering o;
+    const int n = A.n_outer;
+    o.n = n;
+    o.blocked = true;
+    std::vector<int> block_of(n, -1);
+    std::vector<int> members, queue, cand;
+    std::vector<int> color(n, -1);
+    std::vector<char> forbid;
+    size_t cand_head = 0;
+    int scan = 0;
+    o.blk_begin.push_back(0);
+    std::vector<int> order_tmp;
+    while (true) {
+        int seed = -1;
+        while (cand_head < cand.size()) {
+            int c = cand[cand_head++];
+            if (block_of[c] < 0) { seed = c; break; }
+        }
+        if (seed < 0) {
+            while (scan < n && block_of[scan] >= 0) ++scan;
+            if (scan >= n) break;
+            seed = scan;
+        }
+        const int b = o.n_blocks();
+        members.clear(); queue.clear();
+        block_of[seed] = b; members.push_back(seed); queue.push_back(seed);
+        size_t head = 0;
+        while (head < queue.size() && (int)members.size() < block_rows) {
+            int v = queue[head++];
+            for (int p = A.ptr[v]; p < A.ptr[v + 1] && (int)members.size() < block_rows; ++p) {
+                int w = A.idx[p];
+                if (block_of[w] < 0) { block_of[w] = b; members.push_back(w); queue.push_back(w); }
+            }
+        }
+        // unassigned neighbours of the unexpanded tail become seed candidates for the next blocks
+        for (size_t q = head; q < queue.size(); ++q) {
+            int v = queue[q];
+            for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p)
+                if (block_of[A.idx[p]] < 0) cand.push_back(A.idx[p]);
+        }
+        // in-block greedy colouring (BFS order)
+        int ncol = 0;
+        for (int v : members) {
+            forbid.assign((size_t)ncol + 1, 0);
+            for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) {
+                int w = A.idx[p];
+                if (w != v && block_of[w] == b && color[w] >= 0) forbid[color[w]] = 1;
+            }
+            int c = 0;
+            while (c < ncol && forbid[c]) ++c;
+            color[v] = c;
+            if (c == ncol) ++ncol;
+        }
+        std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return color[x] < color[y]; });
+        const int begin = o.blk_begin.back();
+        const int padded = round_up((int)members.size(), kSlice);
+        order_tmp.clear();
+        o.new2old.resize((size_t)begin + padded, -1);
+        o.row_color.resize((size_t)begin + padded, 0);
+        for (size_t i = 0; i < members.size(); ++i) {
+            o.new2old[begin + i] = members[i];
+            o.row_color[begin + i] = (unsigned char)std::min(color[members[i]], 255);
+        }
+        o.blk_begin.push_back(begin + padded);
+        o.blk_ncolors.push_back(ncol);
+        o.n_colors = std::max(o.n_colors, ncol);
+    }
+    o.n_pad = o.blk_begin.back();
+    if (o.n_pad == 0) { o.n_pad = kSlice; o.new2old.assign(kSlice, -1); o.row_color.assign(kSlice, 0); }
+    o.color_begin = {0, o.n_pad};      // not colour-major: a single range
+    o.old2new.assign(n, -1);
     for (int r = 0; r < o.n_pad; ++r)
         if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
     return o;
@@ -198,6 +287,49 @@ inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int
     });
     out = csr_to_sell(np, np, ptr, idx, val, 0);
     return true;
+}
+
+// Blocked level: split the off-diagonal part of A into the entries that stay inside the row's block
+// (`in`: column = device row MINUS the block's first row, < 65536, for the LDS-resident sweep) and the
+// entries that leave it (`out`: device column; applied to the previous iterate, Jacobi-style).
+inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& o, SellHost& in, SellHost& out) {
+    const int np = o.n_pad;
+    std::vector<int> blk_of_row(np, 0);
+    for (int b = 0; b < o.n_blocks(); ++b)
+        for (int r = o.blk_begin[b]; r < o.blk_begin[b + 1]; ++r) blk_of_row[r] = b;
+    std::vector<int64_t> pin((size_t)np + 1, 0), pout((size_t)np + 1, 0);
+    for (int r = 0; r < np; ++r) {
+        int old = o.new2old[r];
+        int64_t li = 0, lo = 0;
+        if (old >= 0)
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+                if (A.idx[p] == old) continue;
+                if (blk_of_row[o.old2new[A.idx[p]]] == blk_of_row[r]) ++li; else ++lo;
+            }
+        pin[r + 1] = pin[r] + li;
+        pout[r + 1] = pout[r] + lo;
+    }
+    std::vector<int> iin((size_t)pin[np]), iout((size_t)pout[np]);
+    std::vector<double> vin((size_t)pin[np]), vout((size_t)pout[np]);
+    parallel_ranges(np, hw_threads(), [&](int lo_, int hi_, int) {
+        std::vector<std::pair<int, double>> row;
+        for (int r = lo_; r < hi_; ++r) {
+            int old = o.new2old[r];
+            if (old < 0) continue;
+            row.clear();
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p)
+                if (A.idx[p] != old) row.emplace_back(o.old2new[A.idx[p]], A.val[p]);
+            std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            int64_t qi = pin[r], qo = pout[r];
+            const int base = o.blk_begin[blk_of_row[r]];
+            for (auto& e : row) {
+                if (blk_of_row[e.first] == blk_of_row[r]) { iin[qi] = e.first - base; vin[qi] = e.second; ++qi; }
+                else { iout[qo] = e.first; vout[qo] = e.second; ++qo; }
+            }
+        }
+    });
+    in = csr_to_sell(np, np, pin, iin, vin, 0);
+    out = csr_to_sell(np, np, pout, iout, vout, 0);
 }
 
 // Generic: rows of `Mrows` (compressed, outer = rows in natural numbering of the row space) mapped into

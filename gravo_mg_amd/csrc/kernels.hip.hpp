@@ -71,6 +71,87 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
     for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
 }
 
+// Block-hybrid Gauss-Seidel sweep, ONE launch per sweep (coarse levels, where a launch per colour is
+// latency-bound: 13-18 colours on the Galerkin operators).
+//   * one workgroup (up to 1024 rows = 16 wavefronts) per compact block of rows (host_plan.hpp);
+//   * couplings that leave the block use the PREVIOUS iterate x_in (Jacobi between blocks) and are summed
+//     up front by all lanes at once -- their gathers are independent of the in-block ordering;
+//   * the block's own x lives in LDS; in-block couplings are applied colour by colour (exact multicolour
+//     Gauss-Seidel inside the block) with __syncthreads() between colours.  Each lane keeps its row's
+//     in-block entries (16-bit local column + value) in registers, loaded before the colour loop, so a
+//     colour step is LDS gathers + FMAs only;
+//   * x_out != x_in (double buffer): other blocks read x_in while this one writes, so the result is
+//     deterministic.
+// In matrix form one sweep is x_out = x_in + T^{-1} (b - A x_in), T = D + strict-lower(A restricted to the
+// block diagonal, device order); tests/test_gpu_parity.py checks exactly that.
+constexpr int kBlockRows = 1024;
+template <int D, int WIN>
+__global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
+                                                       const unsigned char* __restrict__ row_color,
+                                                       const int64_t* __restrict__ in_ptr, const unsigned short* __restrict__ in_col,
+                                                       const double* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
+                                                       const int* __restrict__ out_col, const double* __restrict__ out_val,
+                                                       const double* __restrict__ diag, const double* __restrict__ b,
+                                                       const double* __restrict__ x_in, double* __restrict__ x_out, int ld) {
+    __shared__ double xs[D][kBlockRows];
+    const int blk = blockIdx.x;
+    const int r0 = blk_begin[blk];
+    const int nrows = blk_begin[blk + 1] - r0;            // multiple of 64
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool active = wave * 64 < nrows;                 // wave-uniform
+    const int row = r0 + t;
+    double rhs[D], dg = 1.0;
+    int mycolor = -1, w = 0;
+    int64_t p0 = 0;
+    double v[WIN];
+    unsigned short ci[WIN];
+    if (active) {
+        const int s = (r0 >> 6) + wave;
+#pragma unroll
+        for (int c = 0; c < D; ++c) xs[c][t] = x_in[row + (int64_t)c * ld];
+        p0 = in_ptr[s];
+        w = (int)((in_ptr[s + 1] - p0) >> 6);
+#pragma unroll
+        for (int j = 0; j < WIN; ++j)
+            if (j < w) { v[j] = in_val[p0 + (int64_t)j * 64 + lane]; ci[j] = in_col[p0 + (int64_t)j * 64 + lane]; }
+        double acc[D];
+        row_dot<D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+#pragma unroll
+        for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
+        dg = diag[row];
+        mycolor = row_color[row];
+    }
+    __syncthreads();
+    const int nc = blk_ncolors[blk];
+    for (int col = 0; col < nc; ++col) {
+        if (mycolor == col) {
+            double s_[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] = 0.0;
+#pragma unroll
+            for (int j = 0; j < WIN; ++j)
+                if (j < w) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) s_[c] += v[j] * xs[c][ci[j]];
+                }
+            for (int j = WIN; j < w; ++j) {                 // rows longer than the register window (rare)
+                const double vj = in_val[p0 + (int64_t)j * 64 + lane];
+                const int cj = in_col[p0 + (int64_t)j * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < D; ++c) s_[c] += vj * xs[c][cj];
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) xs[c][t] = (rhs[c] - s_[c]) / dg;
+        }
+        __syncthreads();
+    }
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c][t];
+    }
+}
+
 // Weighted Jacobi sweep: x_out = x_in + omega * (b - A x_in) / diag.
 template <int D>
 __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,

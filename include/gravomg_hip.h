@@ -56,6 +56,9 @@ typedef struct {
     int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs (default 1) */
     int sigma;             /* SELL sorting window in rows (multiple of 64; 0 = no sorting; default 1024) */
     int row_align;         /* colour classes padded to this many rows (multiple of 64; default 64) */
+    int block_rows;        /* block-hybrid Gauss-Seidel: rows per block (multiple of 64, <= 1024; 0 = off; default 1024) */
+    int block_from_level;  /* levels >= this use the block-hybrid sweep (one launch per sweep); default 1:
+                              level 0 keeps the exact multicolour sweep, the launch-bound coarse levels are blocked */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
 } gmg_config;
@@ -91,6 +94,9 @@ int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int
 int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double* val);
 /* Device numbering of level k: new2old[n_pad] (-1 = padding row), color_begin[n_colors+1]. */
 int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin);
+/* Blocked levels (block-hybrid Gauss-Seidel): *n_blocks (0 if the level is colour-major), blk_begin[n_blocks+1]
+ * (device rows) and row_color[n_pad] (colour of a row inside its block).  Output pointers may be NULL. */
+int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, unsigned char* row_color);
 /* Named timers in ms, same keys as the reference's solverTiming (multigrid_solver.cpp:1394,1403,1445-1448):
  * "reduction", "coarsest_solve", "cycles", "solver_total", "iterations", "residue"; plus "upload",
  * "coarse_host_ms" (host back-substitutions inside the cycles). */

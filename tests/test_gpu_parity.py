@@ -26,15 +26,26 @@ def rel(a, b):
 @pytest.fixture(scope="module", params=["poisson-d1", "smoothing-d3", "pointcloud", "random-order"])
 def setup(request, cabi):
     if request.param == "poisson-d1":
-        P = problems.torus_problem(48, 40, "poisson", 60)
+        P = problems.torus_problem(96, 80, "poisson", 30)          # 7680 -> ~1250 -> ~200 -> ~33: L = 3
     elif request.param == "smoothing-d3":
-        P = problems.torus_problem(40, 36, "smoothing", 60)
+        P = problems.torus_problem(64, 60, "smoothing", 60)        # L = 2, d = 3
     elif request.param == "pointcloud":
         P = problems.pointcloud_problem(3000)
     else:
         P = problems.torus_problem(48, 40, "poisson", 60, order="random")
     assert cabi.device_count() > 0, "gpu tests need a HIP device"
     eng = cabi.Engine()
+    eng.set_prolongations(P.U)
+    eng.set_mass(P.mass)
+    eng.set_system(P.lhs)
+    return P, eng
+
+
+@pytest.fixture(scope="module")
+def setup_exact(setup, cabi):
+    """Same problem, exact (global) multicolour Gauss-Seidel on EVERY level (block_rows=0)."""
+    P, _ = setup
+    eng = cabi.Engine(block_rows=0)
     eng.set_prolongations(P.U)
     eng.set_mass(P.mass)
     eng.set_system(P.lhs)
@@ -74,8 +85,50 @@ def test_transfers(setup, oracle):
             assert rel(eng.prolong_add(k, e, x), oracle.prolong_add(U, e, x)) <= 1e-13
 
 
-def test_multicolor_gs_is_reference_gs_on_permuted_system(setup, oracle):
+def test_block_hybrid_sweep_matches_matrix_form(setup, oracle):
+    """Blocked levels (default: every level >= 1): one sweep == x + T^-1 (b - A x) with
+    T = D + strict-lower(A restricted to the block diagonal) in device order: Jacobi between blocks, exact
+    Gauss-Seidel inside a block.  The residual comes from the oracle, T^-1 from scipy."""
+    import scipy.sparse.linalg as spla
     P, eng = setup
+    rng = np.random.default_rng(7)
+    checked = 0
+    for k in range(len(P.U)):
+        blocks = eng.level_blocks(k)
+        if blocks is None:
+            assert k == 0
+            continue
+        checked += 1
+        blk_begin, row_color = blocks
+        A = eng.level_operator(k)
+        new2old, _ = eng.level_ordering(k)
+        assert np.all(np.diff(blk_begin) % 64 == 0) and np.all(np.diff(blk_begin) <= 1024) and blk_begin[-1] == len(new2old)
+        real = new2old >= 0
+        blk_of_dev = np.repeat(np.arange(len(blk_begin) - 1), np.diff(blk_begin))
+        order = new2old[real]; blk = blk_of_dev[real]; col = row_color[real]
+        Ap = A.tocsr()[order][:, order].tocoo()
+        same = blk[Ap.row] == blk[Ap.col]
+        off = Ap.row != Ap.col
+        # proper colouring inside every block, rows colour-sorted inside a block
+        assert np.all(col[Ap.row[same & off]] != col[Ap.col[same & off]])
+        assert np.all((np.diff(col) >= 0) | (np.diff(blk) != 0))
+        keep = same & (Ap.col <= Ap.row)
+        T = sp.csr_matrix((Ap.data[keep], (Ap.row[keep], Ap.col[keep])), shape=Ap.shape)
+        for d in (1, 3):
+            b = rng.standard_normal((A.shape[0], d)); x = rng.standard_normal((A.shape[0], d))
+            want = x.copy()
+            for iters in (1, 2, 3):
+                r = oracle.residual(A, b, want)
+                step = np.empty_like(want)
+                step[order] = spla.spsolve_triangular(T, r[order], lower=True)
+                want = want + step
+                got = eng.smooth(k, b, x, iters)
+                assert rel(got, want) <= 1e-12
+    assert checked == len(P.U) - 1
+
+
+def test_multicolor_gs_is_reference_gs_on_permuted_system(setup_exact, oracle):
+    P, eng = setup_exact
     rng = np.random.default_rng(2)
     for k in range(len(P.U)):
         A = eng.level_operator(k)
@@ -124,10 +177,10 @@ def test_coarse_solve(setup, oracle):
     assert np.linalg.norm(AL @ (e - eo)) <= 1e-11 * (spla.norm(AL) * np.linalg.norm(eo))
 
 
-def test_vcycle_matches_oracle_with_same_ordering(setup, oracle):
-    """One V-cycle where the oracle is given the device's colour ordering on every level: same algebra,
-    only floating-point summation order differs."""
-    P, eng = setup
+def test_vcycle_matches_oracle_with_same_ordering(setup_exact, oracle):
+    """One V-cycle (exact multicolour GS on every level) where the oracle is given the device's colour
+    ordering on every level: same algebra, only floating-point summation order differs."""
+    P, eng = setup_exact
     L = len(P.U)
     orders = []
     for k in range(L):
@@ -174,11 +227,12 @@ def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
     assert dx2 <= 100 * tight
 
 
-@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "no_graph"])
+@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "no_graph", "exact_gs", "blocked_all", "small_blocks"])
 def test_engine_variants(cabi, oracle, variant):
     P = problems.torus_problem(48, 40, "poisson", 60)
     kw = {"jacobi": dict(smoother=cabi.SMOOTHER_JACOBI), "device_coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
-          "no_graph": dict(use_graph=False)}[variant]
+          "no_graph": dict(use_graph=False), "exact_gs": dict(block_rows=0), "blocked_all": dict(block_from_level=0),
+          "small_blocks": dict(block_rows=128)}[variant]
     eng = cabi.Engine(**kw)
     eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
     x, it, res, _ = eng.solve(P.rhs, tol=1e-6, max_iter=200)
@@ -187,7 +241,9 @@ def test_engine_variants(cabi, oracle, variant):
     ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(P.lhs)
     xr, itr, resr, _ = ref.solve(P.rhs, tol=1e-6, max_iter=200)
     assert rel(x, xr) <= 1e-5
-    if variant != "jacobi":
+    if variant in ("exact_gs", "blocked_all", "small_blocks"):
+        assert abs(it - itr) <= 2
+    elif variant != "jacobi":
         assert it == itr
         assert rel(x, xr) <= 1e-6      # ||x||/||b|| ~ 1e8 on this Poisson system
     if variant == "jacobi":
