@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--coarse", default="host", choices=["host", "device"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--kernel-reps", type=int, default=50)
+    ap.add_argument("--block-rows", type=int, default=None, help="block-hybrid GS rows per block (engine default if unset)")
+    ap.add_argument("--block-from-level", type=int, default=None)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,8 +110,13 @@ def main():
     H, mass, lhs, rhs = build_workload(args.n1, args.n2, args.order)
     n0 = lhs.shape[0]
 
+    kw = {}
+    if args.block_rows is not None:
+        kw["block_rows"] = args.block_rows
+    if args.block_from_level is not None:
+        kw["block_from_level"] = args.block_from_level
     eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT,
-                      use_graph=not args.no_graph)
+                      use_graph=not args.no_graph, **kw)
     eng.use_hierarchy(H)
     eng.set_mass(mass)
     t = time.perf_counter()

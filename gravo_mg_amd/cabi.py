@@ -97,6 +97,9 @@ SIGNATURES = {
     "gmg_hierarchy_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
     "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
+    "gmg_host_plan_level": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _ip, _ip,
+                                      C.POINTER(C.c_ubyte)]),
+    "gmg_host_ldlt_solve": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int64)]),
 }
 
 _lib = None
@@ -208,7 +211,7 @@ class Engine:
     """One gmg_handle: device-resident hierarchy + V-cycle on one HIP stream."""
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
-                 coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, block_rows=1024, block_from_level=1,
+                 coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, block_rows=256, block_from_level=1,
                  device=0, verbose=False):
         l = lib()
         cfg = GmgConfig()
@@ -410,3 +413,39 @@ def host_galerkin(A, U) -> sp.csc_matrix:
     lib().gmg_host_galerkin(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), nc, _pi(u.indptr), _pi(u.indices), _pd(u.data),
                             _pi(colptr), _pi(rowidx), _pd(val))
     return sp.csc_matrix((val, rowidx, colptr), shape=(nc, nc))
+
+
+def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024) -> dict:
+    """Device layout of one level computed on the host (no GPU needed): ordering, colours / blocks, SELL
+    padding statistics.  mode 0 = colour-major (exact multicolour GS), 1 = block ordering (block-hybrid GS)."""
+    a = _csc(A)
+    n = a.shape[0]
+    cap = n + 64 * (n // 64 + 2) if mode == 1 else n + 64 * 256
+    info = (C.c_int64 * 6)()
+    new2old = np.empty(cap, np.int32); color_begin = np.zeros(257, np.int32)
+    blk_begin = np.zeros(n // 64 + 3, np.int32); row_color = np.zeros(cap, np.uint8)
+    rc = lib().gmg_host_plan_level(n, _pi(a.indptr), _pi(a.indices), _pd(a.data), int(mode), int(block_rows), int(sigma), info,
+                                   _pi(new2old), _pi(color_begin), _pi(blk_begin), row_color.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    if rc:
+        raise GmgError(rc, "gmg_host_plan_level")
+    n_pad, n_colors, n_blocks = int(info[0]), int(info[1]), int(info[2])
+    out = {"n_pad": n_pad, "n_colors": n_colors, "n_blocks": n_blocks, "sell_stored": int(info[3]), "offdiag_nnz": int(info[4]),
+           "new2old": new2old[:n_pad].copy()}
+    if mode == 1:
+        out["blk_begin"] = blk_begin[: n_blocks + 1].copy()
+        out["row_color"] = row_color[:n_pad].copy()
+    else:
+        out["color_begin"] = color_begin[: n_colors + 1].copy()
+    return out
+
+
+def host_ldlt_solve(A, b):
+    """x = A^-1 b with the product's coarsest-level solver (host sparse LDL^T); returns (x, nnz(L))."""
+    a = _csc(A)
+    B = _f64(b)
+    X = np.empty_like(B, order="F")
+    nnz = C.c_int64()
+    rc = lib().gmg_host_ldlt_solve(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), _pd(B), B.shape[1], _pd(X), C.byref(nnz))
+    if rc:
+        raise GmgError(rc, "gmg_host_ldlt_solve (zero pivot?)")
+    return (X[:, 0].copy() if np.asarray(b).ndim == 1 else X), nnz.value

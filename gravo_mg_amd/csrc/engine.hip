@@ -163,6 +163,8 @@ void drop_system(gmg_handle h) {
     if (h->d_ainv) { (void)hipFree(h->d_ainv); h->d_ainv = nullptr; }
 }
 
+constexpr int kNormBlocks = 2048;      // residual-norm partial sums: 8 blocks per CU, grid-stride
+
 inline int grid_for(int n_slices) {
     int g = (n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
     return (g + 7) / 8 * 8;    // multiple of 8 so the XCD swizzle is a bijection
@@ -223,7 +225,7 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
     for (int it = 0; it < iters; ++it) {
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<D, 32>), dim3(nb), dim3(gmgk::kBlockRows), 0, h->stream, l.d_blk_begin,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
                                               l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
                                               l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
                                               out + (size_t)c0 * ld, ld));
@@ -281,7 +283,7 @@ void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const d
 int launch_norm(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
+    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
@@ -484,7 +486,7 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->use_graph = 1;
     cfg->sigma = 1024;
     cfg->row_align = 64;
-    cfg->block_rows = 1024;
+    cfg->block_rows = 256;
     cfg->block_from_level = 1;
     cfg->host_threads = 0;
     cfg->verbose = 0;
@@ -638,8 +640,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         HIPCHK(hipStreamSynchronize(h->stream));      // host staging vectors die at scope end
     }
     {
-        Level& l0 = h->lv[0];
-        int nblk = (l0.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
+        int nblk = kNormBlocks;
         if (nblk > h->partial_blocks) {
             if (h->d_partials) (void)hipFree(h->d_partials);
             HIPCHK(hipMalloc((void**)&h->d_partials, sizeof(double) * (size_t)nblk * 8));
@@ -957,7 +958,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     HIPCHK(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    *ms_avg = (double)ms / reps;
+    *ms_avg = (double)ms / reps / (kind == 0 ? 2 : 1);     // kind 0 enqueues two sweeps per repetition (ping-pong buffers)
     if (launches_out) *launches_out = launches;
     h->loaded_d = 0;
     return GMG_OK;
@@ -1037,6 +1038,37 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
     std::memcpy(c_colptr, C.ptr.data(), sizeof(int) * (n_coarse + 1));
     if (c_rowidx) std::memcpy(c_rowidx, C.idx.data(), sizeof(int) * C.nnz());
     if (c_val) std::memcpy(c_val, C.val.data(), sizeof(double) * C.nnz());
+    return GMG_OK;
+}
+
+int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma, int64_t* info,
+                        int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color) {
+    if (n <= 0 || !colptr || !rowidx || !val || mode < 0 || mode > 1) return GMG_ERR_INVALID;
+    if (mode == 1 && (block_rows <= 0 || block_rows > gmgk::kBlockRows || block_rows % 64)) return GMG_ERR_INVALID;
+    if (sigma < 0 || sigma % 64) return GMG_ERR_INVALID;
+    Compressed A;
+    A.assign(n, n, colptr, rowidx, val);
+    LevelOrdering o = mode == 1 ? make_block_ordering(A, block_rows) : make_ordering(A, true, 64, sigma);
+    if (o.n_colors > 256) return GMG_ERR_UNSUPPORTED;
+    SellHost sa; std::vector<double> dg; std::string e;
+    if (!build_operator_sell(A, o, 0, sa, dg, e)) return GMG_ERR_NUMERIC;
+    if (info) { info[0] = o.n_pad; info[1] = o.n_colors; info[2] = o.n_blocks(); info[3] = sa.stored(); info[4] = sa.nnz_real; info[5] = 0; }
+    if (new2old) std::memcpy(new2old, o.new2old.data(), sizeof(int) * o.n_pad);
+    if (color_begin && !o.blocked) std::memcpy(color_begin, o.color_begin.data(), sizeof(int) * (o.n_colors + 1));
+    if (blk_begin && o.blocked) std::memcpy(blk_begin, o.blk_begin.data(), sizeof(int) * o.blk_begin.size());
+    if (row_color && o.blocked) std::memcpy(row_color, o.row_color.data(), o.row_color.size());
+    return GMG_OK;
+}
+
+int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x, int64_t* factor_nnz) {
+    if (n <= 0 || !colptr || !rowidx || !val || !b || !x || d <= 0) return GMG_ERR_INVALID;
+    Compressed A;
+    A.assign(n, n, colptr, rowidx, val);
+    SparseLDLT f;
+    if (!f.factor(A)) return GMG_ERR_NUMERIC;
+    std::vector<double> w(n);
+    for (int c = 0; c < d; ++c) f.solve(b + (size_t)c * n, x + (size_t)c * n, w.data());
+    if (factor_nnz) *factor_nnz = f.factor_nnz();
     return GMG_OK;
 }
 

@@ -104,8 +104,18 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     double rhs[D], dg = 1.0;
     int mycolor = -1, w = 0;
     int64_t p0 = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) rhs[c] = 0.0;
+    // In-block entries of this lane's row, zero-padded to WIN so the colour loop can run unconditional
+    // chunks of CH entries (CH independent LDS gathers in flight instead of one wait per entry).  The 16-bit
+    // local columns are packed two per register.
+    constexpr int CH = D == 1 ? 8 : 4;
     double v[WIN];
-    unsigned short ci[WIN];
+    unsigned cpk[WIN / 2];
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) v[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < WIN / 2; ++j) cpk[j] = 0u;
     if (active) {
         const int s = (r0 >> 6) + wave;
 #pragma unroll
@@ -113,13 +123,20 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
         p0 = in_ptr[s];
         w = (int)((in_ptr[s + 1] - p0) >> 6);
 #pragma unroll
-        for (int j = 0; j < WIN; ++j)
-            if (j < w) { v[j] = in_val[p0 + (int64_t)j * 64 + lane]; ci[j] = in_col[p0 + (int64_t)j * 64 + lane]; }
+        for (int j0 = 0; j0 < WIN; j0 += 8)
+            if (j0 < w) {
+#pragma unroll
+                for (int j = j0; j < j0 + 8; ++j)
+                    if (j < w) {
+                        v[j] = in_val[p0 + (int64_t)j * 64 + lane];
+                        cpk[j >> 1] |= (unsigned)in_col[p0 + (int64_t)j * 64 + lane] << ((j & 1) * 16);
+                    }
+            }
         double acc[D];
         row_dot<D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
 #pragma unroll
         for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
-        dg = diag[row];
+        dg = 1.0 / diag[row];      // reciprocal once, outside the sequential colour loop
         mycolor = row_color[row];
     }
     __syncthreads();
@@ -130,10 +147,19 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
 #pragma unroll
             for (int c = 0; c < D; ++c) s_[c] = 0.0;
 #pragma unroll
-            for (int j = 0; j < WIN; ++j)
-                if (j < w) {
+            for (int j0 = 0; j0 < WIN; j0 += CH)
+                if (j0 < w) {
+                    double xv[CH][D];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) s_[c] += v[j] * xs[c][ci[j]];
+                    for (int j = 0; j < CH; ++j) {
+                        const int cj = (cpk[(j0 + j) >> 1] >> (((j0 + j) & 1) * 16)) & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < D; ++c) xv[j][c] = xs[c][cj];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
                 }
             for (int j = WIN; j < w; ++j) {                 // rows longer than the register window (rare)
                 const double vj = in_val[p0 + (int64_t)j * 64 + lane];
@@ -142,7 +168,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
                 for (int c = 0; c < D; ++c) s_[c] += vj * xs[c][cj];
             }
 #pragma unroll
-            for (int c = 0; c < D; ++c) xs[c][t] = (rhs[c] - s_[c]) / dg;
+            for (int c = 0; c < D; ++c) xs[c][t] = (rhs[c] - s_[c]) * dg;
         }
         __syncthreads();
     }
@@ -227,11 +253,11 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
                                                                  double* __restrict__ partials) {
     __shared__ double red[kWavesPerBlock][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int s = blockIdx.x * kWavesPerBlock + wave;
     double sums[2 * D];
 #pragma unroll
     for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
-    if (s < n_slices) {
+    // fixed-size grid, each wave strides over the slices: few partials, fixed summation order
+    for (int s = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave); s < n_slices; s += gridDim.x * kWavesPerBlock) {
         const int row = s * 64 + lane;
         double acc[D];
         row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
@@ -241,8 +267,8 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
         for (int c = 0; c < D; ++c) {
             const double bi = b[row + (int64_t)c * ld];
             const double r = acc[c] + dg * x[row + (int64_t)c * ld] - bi;
-            sums[2 * c] = (r * w) * r;
-            sums[2 * c + 1] = (bi * w) * bi;
+            sums[2 * c] += (r * w) * r;
+            sums[2 * c + 1] += (bi * w) * bi;
         }
     }
 #pragma unroll

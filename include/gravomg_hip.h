@@ -56,7 +56,7 @@ typedef struct {
     int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs (default 1) */
     int sigma;             /* SELL sorting window in rows (multiple of 64; 0 = no sorting; default 1024) */
     int row_align;         /* colour classes padded to this many rows (multiple of 64; default 64) */
-    int block_rows;        /* block-hybrid Gauss-Seidel: rows per block (multiple of 64, <= 1024; 0 = off; default 1024) */
+    int block_rows;        /* block-hybrid Gauss-Seidel: rows per block (multiple of 64, <= 1024; 0 = off; default 256) */
     int block_from_level;  /* levels >= this use the block-hybrid sweep (one launch per sweep); default 1:
                               level 0 keeps the exact multicolour sweep, the launch-bound coarse levels are blocked */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
@@ -177,6 +177,19 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
 int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const double* a_val,
                       int n_coarse, const int* u_colptr, const int* u_rowidx, const double* u_val,
                       int* c_colptr, int* c_rowidx, double* c_val);
+
+/* Host-only view of the device layout planner (colouring / block growing / SELL-64), for CPU tests of the
+ * host logic.  mode 0: colour-major ordering (exact multicolour Gauss-Seidel), mode 1: block ordering
+ * (block-hybrid Gauss-Seidel, `block_rows` rows per block).  info[0..5] = n_pad, n_colors, n_blocks,
+ * stored SELL entries (off-diagonal), real off-diagonal entries, 0.  new2old must hold n + 64*(n/64 + 2)
+ * ints if mode 1 and n + 64*256 if mode 0 (only n_pad are written); color_begin 257 ints; blk_begin
+ * n/64 + 3 ints; row_color like new2old (bytes).  Output pointers may be NULL. */
+int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma,
+                        int64_t* info, int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color);
+/* Host-only: x = A^{-1} b with the coarsest-level solver (minimum-degree + sparse LDL^T, host_ldlt.hpp),
+ * b/x column-major n x d.  Returns GMG_ERR_NUMERIC on a zero pivot.  factor_nnz (optional) = nnz(L). */
+int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x,
+                        int64_t* factor_nnz);
 
 #ifdef __cplusplus
 }

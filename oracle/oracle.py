@@ -155,7 +155,7 @@ class Hierarchy:
 
     def solve(self, rhs, x0=None, tol=1e-4, stop_type=2, max_iter=100):
         B = _f(rhs); X = B.copy(order="F") if x0 is None else _f(x0).copy(order="F")
-        conv = np.zeros(2 * max_iter); res = C.c_double()
+        conv = np.zeros(2 * max(int(max_iter), 1)); res = C.c_double()      # do-while: >= 1 cycle
         it = lib().orc_solve(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter), _pd(conv), C.byref(res))
         self.timing["cycles"] = float(conv[2 * (it - 1)])
         self.timing["iterations"] = it

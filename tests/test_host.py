@@ -1,0 +1,246 @@
+"""Host-side logic of libgravomg_hip.so that needs no GPU: the hierarchy builder, the Galerkin product, the
+device-layout planner, the coarsest-level LDL^T, the C-ABI surface and its error behaviour on a box without
+a HIP device.  CPU only."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from tests import problems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------- C-ABI surface
+def test_library_exports_every_declared_symbol(cabi):
+    """Every function include/gravomg_hip.h declares is exported by the built library and typed in cabi.SIGNATURES."""
+    hdr = open(os.path.join(ROOT, "include", "gravomg_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gmg_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 40
+    lib = C.CDLL(cabi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(cabi.SIGNATURES), (declared ^ set(cabi.SIGNATURES))
+
+
+def test_config_defaults_follow_reference_python_defaults(cabi):
+    cfg = cabi.GmgConfig()
+    assert cabi.lib().gmg_config_default(C.byref(cfg)) == 0
+    # gravomg_bindings/src/gravomg/core.py:10  pre_iters=2, post_iters=2
+    assert (cfg.pre_iters, cfg.post_iters) == (2, 2)
+    assert cfg.smoother == cabi.SMOOTHER_MULTICOLOR_GS and cfg.coarse_mode == cabi.COARSE_HOST_LDLT
+    opt = cabi.GmgHierarchyOptions()
+    assert cabi.lib().gmg_hierarchy_options_default(C.byref(opt)) == 0
+    assert (opt.ratio, opt.lower_bound, opt.check_voronoi, opt.nested, opt.sampling, opt.weighting) == (8.0, 1000, 1, 0, 0, 0)
+
+
+def test_invalid_config_rejected(cabi):
+    for kw in (dict(sigma=100), dict(row_align=32), dict(block_rows=2048), dict(block_rows=100), dict(pre_iters=-1)):
+        with pytest.raises(cabi.GmgError):
+            cabi.Engine(**kw)
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu(cabi):
+    """No CPU fallback behind the C-ABI: on a box without a HIP device every device call is GMG_ERR_NO_DEVICE."""
+    if cabi.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    P = problems.torus_problem(24, 20, "poisson", 20)
+    eng = cabi.Engine()
+    eng.set_prolongations(P.U)          # host-side state is accepted ...
+    eng.set_mass(P.mass)
+    with pytest.raises(cabi.GmgError) as ei:
+        eng.set_system(P.lhs)           # ... anything that needs the device is refused
+    assert ei.value.code == cabi.GMG_ERR_NO_DEVICE and "no CPU fallback" in str(ei.value)
+    for call in (lambda: eng.vcycle(P.rhs, P.rhs), lambda: eng.solve(P.rhs), lambda: eng.smooth(0, P.rhs, P.rhs, 1),
+                 lambda: eng.residual_norm(P.rhs, P.rhs), lambda: eng.load_problem(P.rhs, P.rhs), lambda: eng.run_cycles(1)):
+        with pytest.raises(cabi.GmgError) as ei:
+            call()
+        assert ei.value.code == cabi.GMG_ERR_NO_DEVICE
+
+
+def test_argument_validation(cabi):
+    P = problems.torus_problem(24, 20, "poisson", 20)
+    eng = cabi.Engine()
+    l = cabi.lib()
+    u = sp.csc_matrix(P.U[0])
+    # prolongation before the level count is a state error
+    rc = l.gmg_set_prolongation(eng._h, 0, u.shape[0], u.shape[1], cabi._pi(u.indptr), cabi._pi(u.indices), cabi._pd(u.data))
+    assert rc == cabi.GMG_ERR_STATE
+    assert l.gmg_set_num_levels(eng._h, 1) == 0
+    bad = u.indices.copy(); bad[0] = u.shape[0] + 5
+    assert l.gmg_set_prolongation(eng._h, 0, u.shape[0], u.shape[1], cabi._pi(u.indptr), cabi._pi(bad), cabi._pd(u.data)) == cabi.GMG_ERR_INVALID
+    assert l.gmg_set_prolongation(eng._h, 3, u.shape[0], u.shape[1], cabi._pi(u.indptr), cabi._pi(u.indices), cabi._pd(u.data)) == cabi.GMG_ERR_INVALID
+    assert b"" != l.gmg_last_error(eng._h)
+    out = C.c_double()
+    assert l.gmg_get_timing(eng._h, b"no_such_key", C.byref(out)) == cabi.GMG_ERR_INVALID
+
+
+# ---------------------------------------------------------------------------------------------- hierarchy builder
+@pytest.mark.parametrize("kind", ["torus", "torus-random", "pointcloud"])
+def test_hierarchy_properties(cabi, kind):
+    """Properties the reference's constructProlongation guarantees (multigrid_solver.cpp:62-469):
+    <= 3 parents per row, barycentric weights in [0,1] summing to 1, every accepted level >= lower_bound, chained shapes."""
+    from gravo_mg_amd import meshgen
+    lb = 40
+    if kind == "pointcloud":
+        pos = meshgen.torus_points(4000, noise=0.002)
+        S, _ = meshgen.knn_graph_laplacian(pos, 8)
+    else:
+        pos, F = meshgen.torus_mesh(72, 60, order="random" if kind == "torus-random" else "natural")
+        S, _ = meshgen.cotan_laplacian(pos, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    H = cabi.Hierarchy(pos, neigh, lower_bound=lb)
+    assert len(H.U) >= 2
+    n = pos.shape[0]
+    for k, U in enumerate(H.U):
+        assert U.shape[0] == n and lb <= U.shape[1] < n
+        n = U.shape[1]
+        per_row = np.diff(sp.csr_matrix(U).indptr)
+        assert per_row.min() >= 1 and per_row.max() <= 3
+        assert U.data.min() >= -1e-12 and U.data.max() <= 1 + 1e-12
+        np.testing.assert_allclose(np.asarray(U.sum(axis=1)).ravel(), 1.0, atol=1e-12)
+        assert np.all(np.diff(U.indptr) >= 1)                       # every coarse point has children
+        assert U.has_sorted_indices
+    # coarsening factor of FASTDISK with ratio 8 sits around 6
+    assert 3.0 <= pos.shape[0] / H.U[0].shape[1] <= 12.0
+    # deterministic
+    H2 = cabi.Hierarchy(pos, neigh, lower_bound=lb)
+    for a, b in zip(H.U, H2.U):
+        assert (a != b).nnz == 0
+    t = H.timings()
+    assert t["n_vertices"] == pos.shape[0] and t["levels"] == len(H.U) and t["hierarchy"] > 0
+
+
+def test_hierarchy_options(cabi):
+    from gravo_mg_amd import meshgen
+    pos, F = meshgen.torus_mesh(48, 40)
+    S, _ = meshgen.cotan_laplacian(pos, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    base = cabi.Hierarchy(pos, neigh, lower_bound=40)
+    # lower_bound larger than the first sample set -> no levels at all (the reference then has U.size() == 0)
+    assert len(cabi.Hierarchy(pos, neigh, lower_bound=1000).U) == 0
+    # nested: sample points interpolate themselves with weight 1 (multigrid_solver.cpp:297-300)
+    nested = cabi.Hierarchy(pos, neigh, lower_bound=40, nested=True)
+    U0 = sp.csr_matrix(nested.U[0])
+    assert (np.diff(U0.indptr) == 1).sum() >= U0.shape[1]
+    # uniform / inverse-distance weighting keep the sparsity pattern of the barycentric default
+    for w in (1, 2):
+        alt = cabi.Hierarchy(pos, neigh, lower_bound=40, weighting=w)
+        assert alt.U[0].shape == base.U[0].shape
+        np.testing.assert_allclose(np.asarray(alt.U[0].sum(axis=1)).ravel(), 1.0, atol=1e-12)
+    # UNIFORM: 1/3 (triangle) or 1/2 (edge) everywhere except the "closest three" fallback rows, which use
+    # inverse-distance weights under every scheme (multigrid_solver.cpp:415-435)
+    uni = cabi.Hierarchy(pos, neigh, lower_bound=40, weighting=1)
+    w = np.round(uni.U[0].data, 12)
+    assert np.isin(w, [round(1 / 3, 12), 0.5, 1.0]).mean() >= 0.9
+    # larger ratio -> larger sampling radius -> fewer coarse points
+    assert cabi.Hierarchy(pos, neigh, lower_bound=10, ratio=27.0).U[0].shape[1] < base.U[0].shape[1]
+    # out-of-scope samplers are rejected, not silently replaced
+    with pytest.raises(cabi.GmgError) as ei:
+        cabi.Hierarchy(pos, neigh, lower_bound=40, sampling=1)
+    assert ei.value.code == cabi.GMG_ERR_UNSUPPORTED
+
+
+# ---------------------------------------------------------------------------------------------- Galerkin product
+@pytest.mark.parametrize("kind", ["poisson", "bilaplacian", "pointcloud"])
+def test_host_galerkin_matches_scipy(cabi, kind):
+    P = problems.pointcloud_problem(3000) if kind == "pointcloud" else problems.torus_problem(48, 40, kind, 40)
+    A = sp.csc_matrix(P.lhs)
+    for U in P.U:
+        want = sp.csc_matrix(U.T @ A @ U)
+        got = cabi.host_galerkin(A, U)
+        assert got.shape == want.shape and got.has_sorted_indices
+        assert abs(got - want).max() <= 1e-13 * abs(want).max()
+        assert abs(got - got.T).max() <= 1e-13 * abs(want).max()
+        # pattern == exact symbolic product (explicit zeros from cancellation are kept, like Eigen's product)
+        Uo, Ao = sp.csc_matrix(U, copy=True), sp.csc_matrix(A, copy=True)
+        Uo.data[:] = 1.0; Ao.data[:] = 1.0                  # scipy drops exact-zero sums, so count with ones
+        assert got.nnz == sp.csc_matrix(Uo.T @ Ao @ Uo).nnz
+        A = want
+
+
+# ---------------------------------------------------------------------------------------------- layout planner
+@pytest.mark.parametrize("order", ["natural", "random"])
+def test_colour_major_ordering(cabi, order):
+    P = problems.torus_problem(48, 40, "poisson", 40, order=order)
+    As = [sp.csc_matrix(P.lhs), sp.csc_matrix(P.U[0].T @ P.lhs @ P.U[0])]
+    for A in As:
+        n = A.shape[0]
+        plan = cabi.host_plan_level(A, mode=0)
+        new2old, cb = plan["new2old"], plan["color_begin"]
+        real = new2old[new2old >= 0]
+        assert sorted(real) == list(range(n))                                 # a permutation of the rows
+        assert plan["n_pad"] % 64 == 0 and np.all(cb % 64 == 0) and cb[-1] == plan["n_pad"]
+        colour = np.empty(n, int)
+        for c in range(plan["n_colors"]):
+            rows = new2old[cb[c]:cb[c + 1]]
+            colour[rows[rows >= 0]] = c
+        coo = sp.coo_matrix(A); off = coo.row != coo.col
+        assert np.all(colour[coo.row[off]] != colour[coo.col[off]])          # proper colouring
+        assert plan["offdiag_nnz"] == A.nnz - n
+        assert plan["sell_stored"] >= plan["offdiag_nnz"] and plan["sell_stored"] % 64 == 0
+    # valence-6 mesh: 7-point rows, a handful of colours, little SELL padding (4 colours)
+    plan = cabi.host_plan_level(As[0], mode=0)
+    assert plan["n_colors"] <= 8 and plan["sell_stored"] <= 1.25 * plan["offdiag_nnz"]
+
+
+@pytest.mark.parametrize("order", ["natural", "random"])
+def test_block_ordering_is_compact_and_properly_coloured(cabi, order):
+    P = problems.torus_problem(72, 60, "poisson", 40, order=order)
+    A = sp.csc_matrix(P.U[0].T @ P.lhs @ P.U[0])
+    n = A.shape[0]
+    for rows in (128, 256):
+        plan = cabi.host_plan_level(A, mode=1, block_rows=rows)
+        new2old, bb, rc = plan["new2old"], plan["blk_begin"], plan["row_color"]
+        assert sorted(new2old[new2old >= 0]) == list(range(n))
+        assert np.all(np.diff(bb) % 64 == 0) and np.all(np.diff(bb) <= rows) and bb[-1] == plan["n_pad"]
+        blk_dev = np.repeat(np.arange(plan["n_blocks"]), np.diff(bb))
+        real = new2old >= 0
+        blk = np.empty(n, int); col = np.empty(n, int)
+        blk[new2old[real]] = blk_dev[real]; col[new2old[real]] = rc[real]
+        coo = sp.coo_matrix(A); off = coo.row != coo.col
+        same = blk[coo.row] == blk[coo.col]
+        assert np.all(col[coo.row[same & off]] != col[coo.col[same & off]])      # proper inside every block
+        # compact blocks: most couplings stay inside a block even when the input order is random
+        assert same[off].mean() >= 0.6, same[off].mean()
+        # colours ascend inside a block
+        d_blk = np.diff(blk_dev[real]); d_col = np.diff(rc[real].astype(int))
+        assert np.all((d_col >= 0) | (d_blk != 0))
+
+
+def test_missing_diagonal_is_a_numeric_error(cabi):
+    A = sp.csc_matrix(np.array([[2.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 1.0, 2.0]]))
+    A.eliminate_zeros()
+    with pytest.raises(cabi.GmgError) as ei:
+        cabi.host_plan_level(A, mode=0)
+    assert ei.value.code == cabi.GMG_ERR_NUMERIC
+
+
+# ---------------------------------------------------------------------------------------------- coarsest solver
+def test_host_ldlt(cabi):
+    P = problems.torus_problem(72, 60, "poisson", 40)
+    A = sp.csc_matrix(P.lhs)
+    for U in P.U:
+        A = sp.csc_matrix(U.T @ A @ U)
+    assert 40 <= A.shape[0] <= 400
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal((A.shape[0], 3))
+    x, nnzL = cabi.host_ldlt_solve(A, b)
+    assert np.linalg.norm(A @ x - b) <= 1e-11 * (spla.norm(A) * np.linalg.norm(x))
+    assert 0 < nnzL < A.shape[0] * (A.shape[0] - 1) // 2
+    # a well-conditioned SPD system to full accuracy, and 1-D right-hand sides keep their shape
+    B = sp.csc_matrix(problems.torus_problem(40, 36, "smoothing", 60).lhs)
+    y = rng.standard_normal(B.shape[0])
+    z, nnzB = cabi.host_ldlt_solve(B, y)
+    assert z.shape == y.shape and np.linalg.norm(B @ z - y) <= 1e-12 * np.linalg.norm(y)
+    assert nnzB < 40 * B.shape[0]                       # fill-reducing ordering: far from dense
+    # singular matrix -> loud numeric error, no garbage
+    Z = sp.csc_matrix(np.array([[1.0, 1.0], [1.0, 1.0]]))
+    with pytest.raises(cabi.GmgError) as ei:
+        cabi.host_ldlt_solve(Z, np.ones(2))
+    assert ei.value.code == cabi.GMG_ERR_NUMERIC
