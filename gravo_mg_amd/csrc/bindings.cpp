@@ -1,0 +1,223 @@
+// bindings.cpp -- pybind11 module `gravomg_bindings`: the reference's Python-facing class, same constructor
+// signature (22 positional arguments) and method list as gravomg_bindings/src/cpp/core.cpp:13-180, implemented
+// over MGBS::MultigridSolver (multigrid_solver.h) -> C-ABI -> HIP kernels.
+//
+// pybind11's Eigen casters are not usable (no Eigen), so scipy sparse matrices are unpacked by hand the way
+// pybind11/eigen/matrix.h does it (obj -> csc_matrix -> indptr / indices / data) and numpy arrays are taken
+// column-major (forcecast), i.e. all arguments are copied in and results copied out, like upstream.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+
+#include "multigrid_solver.h"
+
+namespace py = pybind11;
+using DenseIn = py::array_t<double, py::array::f_style | py::array::forcecast>;
+using IntIn = py::array_t<int, py::array::c_style | py::array::forcecast>;
+
+namespace {
+
+MGBS::MatrixXd to_dense(const DenseIn& a) {
+    if (a.ndim() != 1 && a.ndim() != 2) throw std::invalid_argument("expected a 1-D or 2-D float array");
+    MGBS::MatrixXd m((int)a.shape(0), a.ndim() == 2 ? (int)a.shape(1) : 1);
+    std::memcpy(m.data.data(), a.data(), sizeof(double) * m.data.size());
+    return m;
+}
+
+py::array_t<double> from_dense(const MGBS::MatrixXd& m) {
+    py::array_t<double, py::array::f_style> out({(py::ssize_t)m.rows(), (py::ssize_t)m.cols()});
+    std::memcpy(out.mutable_data(), m.data.data(), sizeof(double) * m.data.size());
+    return std::move(out);
+}
+
+MGBS::SparseMatrix to_sparse(const py::object& obj) {
+    py::object sp = py::module_::import("scipy.sparse");
+    py::object csc = sp.attr("csc_matrix")(obj);
+    csc.attr("sum_duplicates")();
+    csc.attr("sort_indices")();
+    auto shape = csc.attr("shape").cast<std::pair<py::ssize_t, py::ssize_t>>();
+    auto indptr = csc.attr("indptr").cast<py::array_t<int, py::array::forcecast>>();
+    auto indices = csc.attr("indices").cast<py::array_t<int, py::array::forcecast>>();
+    auto data = csc.attr("data").cast<py::array_t<double, py::array::forcecast>>();
+    MGBS::SparseMatrix m;
+    m.rows_ = (int)shape.first; m.cols_ = (int)shape.second;
+    m.outer.assign(indptr.data(), indptr.data() + indptr.size());
+    m.inner.assign(indices.data(), indices.data() + indices.size());
+    m.values.assign(data.data(), data.data() + data.size());
+    return m;
+}
+
+py::object from_sparse(const MGBS::SparseMatrix& m) {
+    py::object sp = py::module_::import("scipy.sparse");
+    py::array_t<double> data(m.values.size(), m.values.data());
+    py::array_t<int> indices(m.inner.size(), m.inner.data());
+    py::array_t<int> indptr(m.outer.size(), m.outer.data());
+    return sp.attr("csc_matrix")(py::make_tuple(data, indices, indptr), py::arg("shape") = py::make_tuple(m.rows(), m.cols()));
+}
+
+MGBS::MatrixXi to_int(const IntIn& a) {
+    if (a.ndim() != 2) throw std::invalid_argument("neighbors must be an n x K integer array");
+    MGBS::MatrixXi m;
+    m.rows_ = (int)a.shape(0); m.cols_ = (int)a.shape(1);
+    m.data.assign(a.data(), a.data() + a.size());
+    return m;
+}
+
+}  // namespace
+
+class MultigridSolver {
+public:
+    // Same argument list as gravomg_bindings/src/cpp/core.cpp:20-26.
+    MultigridSolver(DenseIn positions, IntIn neighbors, py::object mass, double ratio, int low_bound, int cycle_type, double tolerance,
+                    int stopping_criteria, int pre_iters, int post_iters, int max_iter, bool check_voronoi, bool nested,
+                    Sampling sampling_strategy, Weighting weighting, bool sig06, DenseIn normals, bool verbose, bool debug, bool ablation,
+                    int ablation_num_points, bool ablation_random) {
+        MGBS::MatrixXd V = to_dense(positions);
+        MGBS::MatrixXi N = to_int(neighbors);
+        MGBS::SparseMatrix M = to_sparse(mass);
+        if (V.cols() != 3 || N.rows() != V.rows() || M.rows() != V.rows()) throw std::invalid_argument("positions must be n x 3, neighbors n x K, mass n x n");
+        solver.reset(new MGBS::MultigridSolver(V, N, M));
+        solver->checkVoronoi = check_voronoi;
+        solver->nested = nested;
+        solver->samplingStrategy = sampling_strategy;
+        solver->weightingScheme = weighting;
+        solver->maxIter = max_iter;
+        solver->sig06 = sig06;
+        solver->ablation = ablation;
+        solver->ablationNumPoints = ablation_num_points;
+        solver->ablationRandom = ablation_random;
+        solver->normals = to_dense(normals);
+        solver->verbose = verbose;
+        solver->debug = debug;
+        solver->ratio = ratio;
+        solver->lowBound = low_bound;
+        solver->buildHierarchy();
+        if (solver->U.empty() && *solver->lastError()) throw std::runtime_error(solver->lastError());
+        solver->cycleType = cycle_type;
+        solver->accuracy = tolerance;
+        solver->stoppingCriteria = stopping_criteria;
+        solver->preIters = pre_iters;
+        solver->postIters = post_iters;
+        solver->isSmootherGaussSeidel = true;
+    }
+
+    void construct_sig21_hierarchy(py::object) { throw std::runtime_error("the SIG21 comparison hierarchy is out of scope of the MI355X hot-path build"); }
+    void toggle_hierarchy(Hierarchy hierarchy) {
+        if (hierarchy != OURS) throw std::runtime_error("only Hierarchy.OURS is available in the MI355X hot-path build");
+    }
+
+    // core.cpp:68-72: x0 = rhs
+    py::array_t<double> solve(py::object lhs, DenseIn rhs) {
+        MGBS::SparseMatrix A = to_sparse(lhs);
+        MGBS::MatrixXd b = to_dense(rhs);
+        if (A.rows() != A.cols() || A.rows() != b.rows()) throw std::invalid_argument("lhs must be n x n and rhs n x d");
+        MGBS::MatrixXd x = b;
+        solver->clearError();
+        solver->solve(A, b, x, 2);
+        check();
+        return from_dense(x);
+    }
+
+    py::array_t<double> direct_solve(py::object lhs, DenseIn rhs, bool pardiso) {
+        MGBS::SparseMatrix A = to_sparse(lhs);
+        MGBS::MatrixXd b = to_dense(rhs);
+        MGBS::MatrixXd x = b;
+        solver->clearError();
+        solver->solve(A, b, x, pardiso ? 1 : 0);
+        check();
+        return from_dense(x);
+    }
+
+    py::list prolongation_matrices() {
+        py::list out;
+        for (const auto& u : solver->U) out.append(from_sparse(u));
+        return out;
+    }
+
+    void set_prolongation_matrices(py::list U) {
+        std::vector<MGBS::SparseMatrix> v;
+        for (auto item : U) v.push_back(to_sparse(py::reinterpret_borrow<py::object>(item)));
+        solver->U = v;
+    }
+
+    std::vector<std::vector<int>> sampling_indices() { return solver->samples; }
+    py::list level_points() { return py::list(); }        // debug-only data upstream (filled only when debug=True)
+    py::list level_edges() { return py::list(); }
+    py::list notrimap() { return py::list(); }
+    py::list all_triangles() { return py::list(); }
+    py::list coarse_normals() { return py::list(); }
+    py::list nearest_source() { return py::list(); }
+
+    void write_hierarchy_timing(std::string experiment, std::string file, bool write_headers) { MGBS::writeTiming(solver->hierarchyTiming, experiment, file, write_headers); }
+    void write_solver_timing(std::string experiment, std::string file, bool write_headers) { MGBS::writeTiming(solver->solverTiming, experiment, file, write_headers); }
+    void write_convergence(std::string file) { MGBS::writeConvergence(solver->convergence, file); }
+
+    double residual(py::object lhs, DenseIn rhs, DenseIn solution, int type = 2) {
+        MGBS::SparseMatrix A = to_sparse(lhs);
+        solver->clearError();
+        double r = solver->residualCheck(A, to_dense(rhs), to_dense(solution), type);
+        check();
+        return r;
+    }
+
+    // extras (not upstream): timers as dicts, engine knobs
+    std::map<std::string, double> solver_timing() { return solver->solverTiming; }
+    std::map<std::string, double> hierarchy_timing() { return solver->hierarchyTiming; }
+    std::vector<std::tuple<double, double>> convergence() { return solver->convergence; }
+    void set_engine_option(const std::string& key, double value) {
+        gmg_config& c = solver->engineConfig;
+        if (key == "smoother") c.smoother = (int)value;
+        else if (key == "jacobi_omega") c.jacobi_omega = value;
+        else if (key == "coarse_mode") c.coarse_mode = (int)value;
+        else if (key == "use_graph") c.use_graph = (int)value;
+        else if (key == "block_rows") c.block_rows = (int)value;
+        else if (key == "block_from_level") c.block_from_level = (int)value;
+        else if (key == "device") c.device = (int)value;
+        else throw std::invalid_argument("unknown engine option: " + key);
+    }
+
+private:
+    // The reference reports problems with printed messages only; the drop-in additionally raises, so that a missing
+    // GPU / an unsupported option can never pass silently.
+    void check() {
+        std::string now = solver->lastError();
+        if (!now.empty()) throw std::runtime_error(now);
+    }
+    std::unique_ptr<MGBS::MultigridSolver> solver;
+};
+
+PYBIND11_MODULE(gravomg_bindings, m) {
+    m.doc() = "Multigrid solver bindings (MI355X-native V-cycle hot path)";
+
+    py::enum_<Hierarchy>(m, "Hierarchy").value("OURS", OURS).value("SIG21", SIG21);
+    py::enum_<Sampling>(m, "Sampling").value("FASTDISK", FASTDISK).value("POISSONDISK", POISSONDISK).value("FPS", FPS).value("RANDOM", RANDOM).value("MIS", MIS);
+    py::enum_<Weighting>(m, "Weighting").value("BARYCENTRIC", BARYCENTRIC).value("UNIFORM", UNIFORM).value("INVDIST", INVDIST);
+
+    py::class_<MultigridSolver>(m, "MultigridSolver")
+        .def(py::init<DenseIn, IntIn, py::object, double, int, int, double, int, int, int, int, bool, bool, Sampling, Weighting, bool, DenseIn, bool, bool, bool, int, bool>())
+        .def("construct_sig21_hierarchy", &MultigridSolver::construct_sig21_hierarchy, py::arg("F"))
+        .def("toggle_hierarchy", &MultigridSolver::toggle_hierarchy, py::arg("hierarchy"))
+        .def("solve", &MultigridSolver::solve, py::arg("lhs"), py::arg("rhs"))
+        .def("direct_solve", &MultigridSolver::direct_solve, py::arg("lhs"), py::arg("rhs"), py::arg("pardiso"))
+        .def("prolongation_matrices", &MultigridSolver::prolongation_matrices)
+        .def("set_prolongation_matrices", &MultigridSolver::set_prolongation_matrices, py::arg("U"))
+        .def("sampling_indices", &MultigridSolver::sampling_indices)
+        .def("level_points", &MultigridSolver::level_points)
+        .def("level_edges", &MultigridSolver::level_edges)
+        .def("notrimap", &MultigridSolver::notrimap)
+        .def("all_triangles", &MultigridSolver::all_triangles)
+        .def("coarse_normals", &MultigridSolver::coarse_normals)
+        .def("nearest_source", &MultigridSolver::nearest_source)
+        .def("write_hierarchy_timing", &MultigridSolver::write_hierarchy_timing, py::arg("experiment"), py::arg("file"), py::arg("write_headers"))
+        .def("write_solver_timing", &MultigridSolver::write_solver_timing, py::arg("experiment"), py::arg("file"), py::arg("write_headers"))
+        .def("write_convergence", &MultigridSolver::write_convergence, py::arg("file"))
+        .def("residual", &MultigridSolver::residual, py::arg("lhs"), py::arg("rhs"), py::arg("solution"), py::arg("type") = 2)
+        .def("solver_timing", &MultigridSolver::solver_timing)
+        .def("hierarchy_timing", &MultigridSolver::hierarchy_timing)
+        .def("convergence", &MultigridSolver::convergence)
+        .def("set_engine_option", &MultigridSolver::set_engine_option, py::arg("key"), py::arg("value"));
+}

@@ -1,0 +1,211 @@
+// multigrid_solver.cpp -- MGBS::MultigridSolver over the C-ABI of libgravomg_hip.so (see multigrid_solver.h).
+#include "multigrid_solver.h"
+
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+
+namespace MGBS {
+
+namespace {
+bool configEqual(const gmg_config& a, const gmg_config& b) { return std::memcmp(&a, &b, sizeof(gmg_config)) == 0; }
+}  // namespace
+
+MultigridSolver::MultigridSolver(MatrixXd& V_, MatrixXi& neigh_, SparseMatrix& M_) : V(V_), neigh(neigh_), M(M_) {
+    hierarchyTiming["n_vertices"] = V.rows();               // multigrid_solver.cpp:21
+    gmg_config_default(&engineConfig);
+    std::memset(&createdWith_, 0, sizeof(createdWith_));
+}
+
+MultigridSolver::~MultigridSolver() {
+    if (engine_) gmg_destroy(engine_);
+}
+
+const char* MultigridSolver::lastError() const { return err_.c_str(); }
+
+// multigrid_solver.cpp:43-60.  Only the default FASTDISK hierarchy is in scope; SIG06 / ablation hierarchies and the
+// other samplers are paper baselines and are refused loudly.
+void MultigridSolver::buildHierarchy() {
+    if (sig06 || ablation) {
+        err_ = "SIG06 / ablation hierarchies are out of scope of the MI355X hot-path build";
+        std::cout << "ERROR! " << err_ << std::endl;
+        U.clear();
+        return;
+    }
+    gmg_hierarchy_options opt;
+    gmg_hierarchy_options_default(&opt);
+    opt.ratio = ratio; opt.lower_bound = lowBound; opt.check_voronoi = checkVoronoi; opt.nested = nested;
+    opt.sampling = (int)samplingStrategy; opt.weighting = (int)weightingScheme;
+    // positions: column-major n x 3 -> row-major
+    const int n = V.rows();
+    std::vector<double> pos((size_t)n * 3);
+    for (int i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) pos[(size_t)i * 3 + c] = V(i, c);
+    gmg_hierarchy hh = nullptr;
+    int rc = gmg_hierarchy_build(pos.data(), n, neigh.data.data(), neigh.cols(), &opt, &hh);
+    if (rc != GMG_OK) {
+        err_ = rc == GMG_ERR_UNSUPPORTED ? "only Sampling::FASTDISK is supported by the MI355X hot-path build" : "gmg_hierarchy_build failed";
+        std::cout << "ERROR! " << err_ << std::endl;
+        U.clear();
+        return;
+    }
+    const int L = gmg_hierarchy_num_levels(hh);
+    U.assign(L, SparseMatrix());
+    DoF.clear();
+    DoF.push_back(n);
+    for (int k = 0; k < L; ++k) {
+        int nf, nc, nnz;
+        gmg_hierarchy_level_shape(hh, k, &nf, &nc, &nnz);
+        SparseMatrix& u = U[k];
+        u.rows_ = nf; u.cols_ = nc;
+        u.outer.resize(nc + 1); u.inner.resize(nnz); u.values.resize(nnz);
+        gmg_hierarchy_get_prolongation(hh, k, u.outer.data(), u.inner.data(), u.values.data());
+        DoF.push_back(nc);
+    }
+    for (const char* key : {"hierarchy", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection", "PDS", "levels"}) {
+        double v = 0;
+        if (gmg_hierarchy_get_timing(hh, key, &v) == GMG_OK) hierarchyTiming[key] = v;
+    }
+    gmg_hierarchy_destroy(hh);
+}
+
+int MultigridSolver::ensureEngine() {
+    gmg_config want = engineConfig;
+    want.pre_iters = preIters; want.post_iters = postIters; want.verbose = 0;
+    if (engine_ && !configEqual(want, createdWith_)) { gmg_destroy(engine_); engine_ = nullptr; }
+    if (!engine_) {
+        int rc = gmg_create(&want, &engine_);
+        if (rc != GMG_OK) { engine_ = nullptr; err_ = "gmg_create failed (invalid engine configuration)"; return rc; }
+        createdWith_ = want;
+        uploadedU_.clear();
+        systemReady_ = false;
+    }
+    return GMG_OK;
+}
+
+int MultigridSolver::ensureSystem(const SparseMatrix& LHS) {
+    int rc = ensureEngine();
+    if (rc) return rc;
+    bool sameU = uploadedU_.size() == U.size();
+    for (size_t k = 0; sameU && k < U.size(); ++k) sameU = uploadedU_[k].sameAs(U[k]);
+    if (!sameU) {
+        if ((rc = gmg_set_num_levels(engine_, (int)U.size()))) { err_ = gmg_last_error(engine_); return rc; }
+        for (size_t k = 0; k < U.size(); ++k)
+            if ((rc = gmg_set_prolongation(engine_, (int)k, U[k].rows(), U[k].cols(), U[k].outer.data(), U[k].inner.data(), U[k].values.data()))) {
+                err_ = gmg_last_error(engine_);
+                return rc;
+            }
+        uploadedU_ = U;
+        systemReady_ = false;
+    }
+    if (!systemReady_ || !uploadedLHS_.sameAs(LHS)) {
+        // mass diagonal for the M / M^-1 norms (multigrid_solver.cpp:1248-1264)
+        std::vector<double> md(M.cols(), 0.0);
+        for (int j = 0; j < M.cols(); ++j)
+            for (int p = M.outer[j]; p < M.outer[j + 1]; ++p) if (M.inner[p] == j) md[j] = M.values[p];
+        if ((rc = gmg_set_mass(engine_, (int)md.size(), md.data()))) { err_ = gmg_last_error(engine_); return rc; }
+        if ((rc = gmg_set_system(engine_, LHS.rows(), LHS.outer.data(), LHS.inner.data(), LHS.values.data()))) { err_ = gmg_last_error(engine_); systemReady_ = false; return rc; }
+        uploadedLHS_ = LHS;
+        systemReady_ = true;
+    }
+    return GMG_OK;
+}
+
+// multigrid_solver.cpp:1059-1088.  A and k other than (the current LHS, 0) would need their own upload; the solve loop
+// only ever calls it with (LHS, ..., 0), which is what this supports.  Returns 0.0 like the reference.
+double MultigridSolver::multiGridVCycleGS(SparseMatrix& A, MatrixXd& b, MatrixXd& x, int k, bool) {
+    if (k != 0) { err_ = "multiGridVCycleGS: only the top-level call (k = 0) is exposed"; std::cout << "ERROR! " << err_ << std::endl; return 0.0; }
+    if (ensureSystem(A) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return 0.0; }
+    if (gmg_vcycle(engine_, b.data.data(), x.data.data(), b.cols()) != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; }
+    return 0.0;
+}
+
+// multigrid_solver.cpp:1194-1226 (tol / isDebug unused there as well).  Runs the engine's level-0 smoother:
+// multicolour Gauss-Seidel, i.e. the reference sweep in a colour-permuted order.
+void MultigridSolver::GaussSeidelSmoother(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int maxIter_, double, bool) {
+    if (ensureSystem(LHS) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return; }
+    if (gmg_smooth(engine_, 0, rhs.data.data(), x.data.data(), rhs.cols(), maxIter_) != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; }
+}
+
+// multigrid_solver.cpp:1228-1277
+double MultigridSolver::residualCheck(const SparseMatrix& A, const MatrixXd& b, const MatrixXd& x, int type) {
+    double out = std::numeric_limits<double>::quiet_NaN();
+    if (ensureSystem(A) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return out; }
+    if (gmg_residual_norm(engine_, b.data.data(), x.data.data(), b.cols(), type, &out) != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; }
+    return out;
+}
+
+// multigrid_solver.cpp:1279-1485
+void MultigridSolver::solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int solverType) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    convergence.reserve(maxIter);                                        // :1283 (never cleared upstream either)
+    if (solverType == 0) {
+        // direct LDL^T on the host (the reference's SimplicialLLT/LDLT comparison branch, :1287-1320)
+        if (verbose) std::cout << "Solve the linear system using direct solver";
+        auto t0 = clk::now();
+        int64_t nnzL = 0;
+        std::vector<double> out(x.data.size());
+        int rc = gmg_host_ldlt_solve(LHS.rows(), LHS.outer.data(), LHS.inner.data(), LHS.values.data(), rhs.data.data(), rhs.cols(), out.data(), &nnzL);
+        if (rc != GMG_OK) { err_ = "direct solve failed (zero pivot)"; std::cout << "ERROR! " << err_ << std::endl; return; }
+        x.data = out;
+        solverTiming["direct_total"] = ms(t0);
+        return;
+    }
+    if (solverType == 1) { std::cout << "Pardiso is not available in this build" << std::endl; return; }   // :1364
+    if (solverType != 2) return;
+    if (verbose) std::cout << "Solve the linear system using OUR Multigrid solver \n";
+    if (!isSmootherGaussSeidel) return;                                   // :1380
+    if (cycleType != 0) {                                                 // F-/W-cycles index U out of range upstream
+        err_ = "only cycle_type = 0 (V-cycle) is supported";
+        std::cout << "ERROR! " << err_ << std::endl;
+        return;
+    }
+    if (U.empty()) { err_ = "the hierarchy has no levels (mesh smaller than lower_bound?)"; std::cout << "ERROR! " << err_ << std::endl; return; }
+    auto t_total = clk::now();
+    if (verbose) std::cout << "Reducing system" << std::endl;
+    if (ensureSystem(LHS) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return; }
+    for (const char* key : {"reduction", "coarsest_solve"}) { double v = 0; if (gmg_get_timing(engine_, key, &v) == GMG_OK) solverTiming[key] = v; }
+    if (verbose) std::cout << "V-CYCLE \n";
+    std::vector<double> conv(2 * (size_t)std::max(maxIter, 1));
+    int iters = 0;
+    double residue = std::numeric_limits<double>::max();
+    int rc = gmg_solve(engine_, rhs.data.data(), x.data.data(), rhs.cols(), accuracy, stoppingCriteria, maxIter, &iters, &residue, conv.data());
+    if (rc != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
+    for (int i = 0; i < iters; ++i) {
+        convergence.push_back({conv[2 * i], conv[2 * i + 1]});          // :1414
+        if (verbose) printf("%d,%f,%.14f \n", i + 1, conv[2 * i], conv[2 * i + 1]);
+    }
+    double cyc = 0;
+    gmg_get_timing(engine_, "cycles", &cyc);
+    solverTiming["cycles"] = cyc;                                         // :1445-1448
+    solverTiming["solver_total"] = ms(t_total);
+    solverTiming["iterations"] = iters * 1.0;
+    solverTiming["residue"] = residue;
+}
+
+// gravomg/src/utility.cpp:106-131: header row "experiment,<keys...>" (map order), then one row per call
+void writeTiming(const std::map<std::string, double>& timing, const std::string& experiment, const std::string& filename, const bool& writeHeaders) {
+    std::ofstream f;
+    if (writeHeaders) f.open(filename.c_str()); else f.open(filename.c_str(), std::ios_base::app);
+    if (!f.is_open()) { std::cout << "Unable to open timing file: " << filename << std::endl; return; }
+    if (writeHeaders) {
+        f << "experiment";
+        for (auto const& t : timing) f << ',' << t.first;
+        f << "\n";
+    }
+    f << experiment;
+    for (auto const& t : timing) f << ',' << t.second;
+    f << "\n";
+}
+
+// gravomg/src/utility.cpp:133-149
+void writeConvergence(const std::vector<std::tuple<double, double>>& convergence, const std::string& filename) {
+    std::ofstream f(filename.c_str());
+    if (!f.is_open()) { std::cout << "Unable to open convergence file: " << filename << std::endl; return; }
+    f << "time,residue\n";
+    for (auto const& it : convergence) f << std::get<0>(it) << ',' << std::get<1>(it) << "\n";
+}
+
+}  // namespace MGBS

@@ -1,0 +1,132 @@
+// multigrid_solver.h -- host-side mirror of the reference's C++ interface on the V-cycle path.
+//
+// Same class name, namespace, public method names, argument meaning and public tunables as
+// gravomg/include/gravomg/multigrid_solver.h:54-170 (MGBS::MultigridSolver), so the pybind11 shim
+// (bindings.cpp, mirroring gravomg_bindings/src/cpp/core.cpp) and a C++ caller read the same.  Eigen is not
+// available, so the matrix types are minimal stand-ins with Eigen's storage conventions:
+//   MGBS::SparseMatrix  == Eigen::SparseMatrix<double>  (CSC, int32, sorted inner indices)
+//   MGBS::MatrixXd      == Eigen::MatrixXd              (column-major n x d)
+//   MGBS::MatrixXi      == Eigen::MatrixXi, but ROW-major here (numpy's default; only `neigh` uses it)
+// All numerics of the hot path run in libgravomg_hip.so through include/gravomg_hip.h.
+#ifndef GRAVOMG_AMD_MULTIGRID_SOLVER_H
+#define GRAVOMG_AMD_MULTIGRID_SOLVER_H
+
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/gravomg_hip.h"
+
+/* Enums of the reference, gravomg/include/gravomg/multigrid_solver.h:35-52 */
+enum Hierarchy { OURS = 0, SIG21 = 1 };
+enum Sampling { FASTDISK = 0, POISSONDISK = 1, FPS = 2, RANDOM = 3, MIS = 4 };
+enum Weighting { BARYCENTRIC = 0, UNIFORM = 1, INVDIST = 2 };
+
+namespace MGBS {
+
+struct SparseMatrix {
+    int rows_ = 0, cols_ = 0;
+    std::vector<int> outer;      // cols_+1
+    std::vector<int> inner;      // nnz
+    std::vector<double> values;  // nnz
+    int rows() const { return rows_; }
+    int cols() const { return cols_; }
+    int nonZeros() const { return outer.empty() ? 0 : outer[cols_]; }
+    bool sameAs(const SparseMatrix& o) const { return rows_ == o.rows_ && cols_ == o.cols_ && outer == o.outer && inner == o.inner && values == o.values; }
+};
+
+struct MatrixXd {
+    int rows_ = 0, cols_ = 0;
+    std::vector<double> data;    // column-major
+    MatrixXd() {}
+    MatrixXd(int r, int c) : rows_(r), cols_(c), data((size_t)r * c, 0.0) {}
+    int rows() const { return rows_; }
+    int cols() const { return cols_; }
+    double& operator()(int i, int j) { return data[(size_t)j * rows_ + i]; }
+    double operator()(int i, int j) const { return data[(size_t)j * rows_ + i]; }
+};
+
+struct MatrixXi {
+    int rows_ = 0, cols_ = 0;
+    std::vector<int> data;       // row-major
+    int rows() const { return rows_; }
+    int cols() const { return cols_; }
+};
+
+class MultigridSolver {
+public:
+    // gravomg/include/gravomg/multigrid_solver.h:58; M is the (diagonal) mass matrix
+    MultigridSolver(MatrixXd& V, MatrixXi& neigh, SparseMatrix& M);
+    ~MultigridSolver();
+    MultigridSolver(const MultigridSolver&) = delete;
+    MultigridSolver& operator=(const MultigridSolver&) = delete;
+
+    /* Hierarchy-related methods (multigrid_solver.cpp:43-60) */
+    void buildHierarchy();
+
+    /* Multigrid solver pieces, same names as multigrid_solver.h:77-83 */
+    double multiGridVCycleGS(SparseMatrix& A, MatrixXd& b, MatrixXd& x, int k, bool isDebug = true);
+    void GaussSeidelSmoother(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int maxIter, double tol, bool isDebug = true);
+    double residualCheck(const SparseMatrix& A, const MatrixXd& b, const MatrixXd& x, int type);
+
+    /* Core solver function (multigrid_solver.h:90): solverType 2 = multigrid (the hot path), 0 = direct LDL^T,
+       1 = Pardiso (not available: message, as an upstream build without MKL prints). */
+    void solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int solverType = 2);
+
+    /* Data, same names as the reference's public members */
+    MatrixXd V;
+    MatrixXd normals;
+    MatrixXi neigh;
+    SparseMatrix M;
+    std::vector<size_t> DoF;
+    std::vector<SparseMatrix> U;                 // prolongation operators (what the solver sees)
+    std::vector<std::vector<int>> samples;
+    int cycleType = 0;                           // 0: V-cycle (1 F / 2 W are rejected: broken upstream)
+    bool isSmootherGaussSeidel = false;          // set by the shim (core.cpp:57); solve() does nothing without it
+    bool sig06 = false;
+    bool checkVoronoi = true;
+    bool nested = false;
+    int stoppingCriteria = 0;                    // multigrid_solver.h:131
+    int maxIter = 50;
+    int lowBound = 1000;
+    double ratio = 8;
+    Sampling samplingStrategy = FASTDISK;
+    Weighting weightingScheme = BARYCENTRIC;
+    int preIters = 2;
+    int postIters = 2;
+    double accuracy = 5e-4;                      // multigrid_solver.h:144
+    bool verbose = true;
+    bool debug = false;
+    bool ablation = false;
+    int ablationNumPoints = 3;
+    bool ablationRandom = false;
+
+    /* Logging and timing (multigrid_solver.h:157-159) */
+    std::map<std::string, double> hierarchyTiming;
+    std::map<std::string, double> solverTiming;
+    std::vector<std::tuple<double, double>> convergence;
+
+    /* MI355X engine knobs (not in the reference) */
+    gmg_config engineConfig;
+    const char* lastError() const;
+    void clearError() { err_.clear(); }
+
+private:
+    int ensureEngine();
+    int ensureSystem(const SparseMatrix& LHS);
+    gmg_handle engine_ = nullptr;
+    std::vector<SparseMatrix> uploadedU_;
+    SparseMatrix uploadedLHS_;
+    bool systemReady_ = false;
+    gmg_config createdWith_;
+    std::string err_;
+};
+
+/* gravomg/src/utility.cpp:106-149, same CSV layout */
+void writeTiming(const std::map<std::string, double>& timing, const std::string& experiment, const std::string& filename, const bool& writeHeaders = false);
+void writeConvergence(const std::vector<std::tuple<double, double>>& convergence, const std::string& filename);
+
+}  // namespace MGBS
+
+#endif

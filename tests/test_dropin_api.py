@@ -1,0 +1,138 @@
+"""The drop-in surface: `import gravomg` / `gravomg_bindings` from gravo_mg_amd/dropin/ with the reference's names,
+signatures and defaults (gravomg_bindings/src/gravomg/core.py:7-147, gravomg_bindings/src/cpp/core.cpp:142-180).
+CPU part: import, signature, helpers vs captured reference outputs, loud failure without a GPU.
+GPU part (-m gpu): the reference's own call pattern (demos/smoothing.py:35-52, experiments/python/comparisons.py:167-174)."""
+import inspect
+import os
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DROPIN = os.path.join(ROOT, "gravo_mg_amd", "dropin")
+
+
+@pytest.fixture(scope="module")
+def gravomg(cabi):
+    import glob
+    if not glob.glob(os.path.join(DROPIN, "gravomg_bindings*.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    if DROPIN not in sys.path:
+        sys.path.insert(0, DROPIN)
+    import gravomg as g
+    return g
+
+
+def _problem():
+    from gravo_mg_amd import meshgen
+    V, F = meshgen.torus_mesh(48, 40)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    return V, F, S, sp.diags(mass).tocsr(), mass
+
+
+def test_api_surface_matches_reference(gravomg):
+    sig = inspect.signature(gravomg.MultigridSolver.__init__)
+    want = [("pos", inspect._empty), ("neigh", inspect._empty), ("mass", inspect._empty), ("ratio", 8.0), ("lower_bound", 1000),
+            ("cycle_type", 0), ("tolerance", 1e-4), ("stopping_criteria", 2), ("pre_iters", 2), ("post_iters", 2), ("max_iter", 100),
+            ("check_voronoi", True), ("nested", False), ("sampling_strategy", gravomg.Sampling.FASTDISK),
+            ("weighting", gravomg.Weighting.BARYCENTRIC), ("sig06", False), ("normals", None), ("verbose", False), ("debug", False),
+            ("ablation", False), ("ablation_num_points", 3), ("ablation_random", False)]
+    got = [(n, p.default) for n, p in list(sig.parameters.items())[1:]]
+    assert got == want
+    for name in ("solve", "direct_solve", "residual", "set_prolongation_matrices", "prolongation_matrices", "write_solver_timing",
+                 "write_hierarchy_timing", "write_convergence", "construct_sig21_hierarchy", "toggle_hierarchy", "sampling_indices",
+                 "level_points", "level_edges", "notrimap", "all_triangles", "coarse_normals", "nearest_source"):
+        assert hasattr(gravomg.MultigridSolver, name), name
+    assert [e.name for e in gravomg.Sampling.__members__.values()] == ["FASTDISK", "POISSONDISK", "FPS", "RANDOM", "MIS"]
+    assert [e.name for e in gravomg.Weighting.__members__.values()] == ["BARYCENTRIC", "UNIFORM", "INVDIST"]
+    assert [e.name for e in gravomg.Hierarchy.__members__.values()] == ["OURS", "SIG21"]
+    for fn in ("neighbors_from_stiffness", "neighbors_from_faces", "knn_undirected", "normalize_area", "normalize_bounding_box"):
+        assert callable(getattr(gravomg, fn))
+
+
+def test_util_matches_captured_reference_outputs(gravomg):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "util_neigh.npz"))
+    n = z["V"].shape[0]
+    S = sp.csc_matrix((z["S_data"], z["S_indices"], z["S_indptr"]), shape=(n, n))
+    for fmt in ("csc", "csr"):
+        assert np.array_equal(gravomg.neighbors_from_stiffness(S.asformat(fmt)), z["neigh_from_stiffness"])
+    assert np.array_equal(gravomg.neighbors_from_faces(z["F"]), z["neigh_from_faces"])
+    np.testing.assert_allclose(gravomg.normalize_area(z["V"] * 3.7 + 1.0, z["F"]), z["normalize_area"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(gravomg.normalize_bounding_box(z["P"]), z["normalize_bounding_box"], rtol=1e-13, atol=1e-15)
+    kn = gravomg.knn_undirected(z["P"], 3)
+    assert kn.dtype == np.int32 and kn.shape[0] == z["P"].shape[0]
+    for i, row in enumerate(kn):                                   # symmetric, self excluded
+        for j in row[row >= 0]:
+            assert i != j and i in kn[j]
+
+
+def test_construction_and_hierarchy_without_gpu(gravomg, tmp_path):
+    """Hierarchy construction is host-side: works on a CPU box; the solve itself must refuse loudly there."""
+    V, F, S, M, mass = _problem()
+    neigh = gravomg.neighbors_from_stiffness(S)
+    solver = gravomg.MultigridSolver(V, neigh, M, lower_bound=40)
+    U = solver.prolongation_matrices
+    assert len(U) >= 2 and all(sp.issparse(u) for u in U) and U[0].shape[0] == V.shape[0]
+    f = tmp_path / "hier.csv"
+    solver.write_hierarchy_timing("torus", str(f), True)
+    head, row = f.read_text().strip().split("\n")
+    assert head.split(",")[0] == "experiment" and {"hierarchy", "n_vertices", "levels", "sampling", "cluster"} <= set(head.split(","))
+    assert row.split(",")[0] == "torus" and len(row.split(",")) == len(head.split(","))
+    with pytest.raises(RuntimeError):
+        gravomg.MultigridSolver(V, neigh, M, lower_bound=40, sampling_strategy=gravomg.Sampling.MIS)
+    with pytest.raises(RuntimeError):
+        gravomg.MultigridSolver(V, neigh, M, lower_bound=40, sig06=True)
+    from gravo_mg_amd import cabi
+    if cabi.device_count() == 0:
+        lhs = (M + 1e-3 * S).tocsr()
+        with pytest.raises(RuntimeError, match="no usable HIP device"):
+            solver.solve(lhs, M @ V)
+
+
+@pytest.mark.gpu
+def test_reference_call_pattern_smoothing_and_poisson(gravomg, oracle, tmp_path):
+    V, F, S, M, mass = _problem()
+    neigh = gravomg.neighbors_from_stiffness(S)
+    solver = gravomg.MultigridSolver(V, neigh, M, verbose=False, ratio=8, lower_bound=40, tolerance=1e-4, max_iter=100,
+                                     sampling_strategy=gravomg.Sampling.FASTDISK)
+    # demos/smoothing.py:43-52
+    lhs = (M + 0.001 * S).tocsr()
+    rhs = M @ V
+    x = solver.solve(lhs, rhs)
+    assert x.shape == (V.shape[0], 3) and x.flags.f_contiguous
+    res = solver.residual(lhs, rhs, x)
+    assert res <= 1e-4
+    assert abs(res - oracle.residual_check(lhs, mass, rhs, x, 2)) <= 1e-3 * res + 1e-9
+    t = solver.solver_timing
+    assert {"reduction", "coarsest_solve", "cycles", "solver_total", "iterations", "residue"} <= set(t)
+    assert t["iterations"] >= 1 and t["residue"] <= 1e-4 and t["solver_total"] >= t["cycles"] > 0
+    # same answer as the CPU restatement of the reference given the same hierarchy
+    O = oracle.Hierarchy(solver.prolongation_matrices, mass)
+    O.set_system(lhs)
+    xo, ito, reso, _ = O.solve(rhs, tol=1e-4)
+    assert abs(t["iterations"] - ito) <= 2
+    assert np.sqrt((mass[:, None] * (x - xo) ** 2).sum() / (mass[:, None] * xo ** 2).sum()) <= 2e-3
+    # experiments/python/comparisons.py:75-96,167-174: Poisson, rhs = M y, CSV writers
+    lhs_p = (M * 1e-6 + S).tocsr()
+    y = np.random.default_rng(42).standard_normal((V.shape[0], 1))
+    xp = solver.solve(lhs_p, M @ y)
+    assert solver.residual(lhs_p, M @ y, xp) <= 1e-4
+    f1, f2 = tmp_path / "solver.csv", tmp_path / "conv.csv"
+    solver.write_solver_timing("torus", str(f1), True)
+    solver.write_solver_timing("torus", str(f1), False)
+    lines = f1.read_text().strip().split("\n")
+    assert lines[0].startswith("experiment,") and len(lines) == 3 and "iterations" in lines[0] and "solver_total" in lines[0]
+    solver.write_convergence(str(f2))
+    conv = f2.read_text().strip().split("\n")
+    assert conv[0] == "time,residue" and len(conv) - 1 == len(solver.convergence)
+    # injected hierarchy + other norms + unsupported options
+    solver.set_prolongation_matrices(solver.prolongation_matrices[:1])
+    x1 = solver.solve(lhs, rhs)
+    assert solver.residual(lhs, rhs, x1, 0) <= 1e-3
+    with pytest.raises(RuntimeError):
+        gravomg.MultigridSolver(V, neigh, M, lower_bound=40, cycle_type=1).solve(lhs, rhs)
+    xd = solver.direct_solve(lhs, rhs)
+    assert np.linalg.norm(lhs @ xd - rhs) <= 1e-10 * np.linalg.norm(rhs)
