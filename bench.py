@@ -95,10 +95,11 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--block-rows", type=int, default=None, help="block-hybrid GS rows per block (engine default if unset)")
     ap.add_argument("--block-from-level", type=int, default=None)
+    ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    if world > 1 or args.gpus > 1 or args.force_dist:
         from gravo_mg_amd import dist_bench
         return dist_bench.main(args)
 

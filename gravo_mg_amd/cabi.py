@@ -86,6 +86,14 @@ SIGNATURES = {
     "gmg_load_problem": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "gmg_run_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "gmg_fetch_solution": (C.c_int, [_vp, _dp]),
+    "gmg_set_stream": (C.c_int, [_vp, _vp]),
+    "gmg_dist_setup": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "gmg_dist_bind": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "gmg_dist_smooth_color": (C.c_int, [_vp, C.c_int]),
+    "gmg_dist_residual_own": (C.c_int, [_vp]),
+    "gmg_dist_coarse_cycle": (C.c_int, [_vp]),
+    "gmg_dist_prolong_own": (C.c_int, [_vp]),
+    "gmg_dist_norm_partial": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
@@ -226,6 +234,7 @@ class Engine:
             raise GmgError(rc, "gmg_create failed (invalid configuration)")
         self._n0 = None
         self._sizes: List[int] = []
+        self.pre_iters, self.post_iters = int(pre_iters), int(post_iters)
 
     # -- plumbing
     def _chk(self, rc: int):
@@ -398,6 +407,34 @@ class Engine:
         self._chk(lib().gmg_algorithmic_bytes(self._h, int(kind), int(k), int(d), C.byref(out)))
         return out.value
 
+    # -- multi-GPU steps (device pointers / stream handles are plain integers)
+    def set_stream(self, stream_handle: int):
+        self._chk(lib().gmg_set_stream(self._h, _vp(stream_handle) if stream_handle else None))
+
+    def dist_setup(self, rank: int, world: int):
+        self._chk(lib().gmg_dist_setup(self._h, int(rank), int(world)))
+
+    def dist_bind(self, x_ptr: int, b_ptr: int, r_ptr: int, d: int):
+        self._chk(lib().gmg_dist_bind(self._h, _vp(x_ptr), _vp(b_ptr), _vp(r_ptr), int(d)))
+        self._loaded_shape = (self.level_info(0)["n"], int(d))
+
+    def dist_smooth_color(self, c: int):
+        self._chk(lib().gmg_dist_smooth_color(self._h, int(c)))
+
+    def dist_residual_own(self):
+        self._chk(lib().gmg_dist_residual_own(self._h))
+
+    def dist_coarse_cycle(self):
+        self._chk(lib().gmg_dist_coarse_cycle(self._h))
+
+    def dist_prolong_own(self):
+        self._chk(lib().gmg_dist_prolong_own(self._h))
+
+    def dist_norm_partial(self, type: int, d: int) -> np.ndarray:
+        sums = np.zeros(2 * d)
+        self._chk(lib().gmg_dist_norm_partial(self._h, int(type), _pd(sums)))
+        return sums
+
 
 def host_galerkin(A, U) -> sp.csc_matrix:
     """Ac = U^T A U on the host (the product engine's RAP, exposed for parity tests)."""
@@ -415,12 +452,15 @@ def host_galerkin(A, U) -> sp.csc_matrix:
     return sp.csc_matrix((val, rowidx, colptr), shape=(nc, nc))
 
 
-def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024) -> dict:
+def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024, row_align: int = 64) -> dict:
     """Device layout of one level computed on the host (no GPU needed): ordering, colours / blocks, SELL
-    padding statistics.  mode 0 = colour-major (exact multicolour GS), 1 = block ordering (block-hybrid GS)."""
+    padding statistics.  mode 0 = colour-major (exact multicolour GS; colour classes padded to `row_align` rows),
+    1 = block ordering (block-hybrid GS, `block_rows` rows per block)."""
     a = _csc(A)
     n = a.shape[0]
-    cap = n + 64 * (n // 64 + 2) if mode == 1 else n + 64 * 256
+    if mode == 0:
+        block_rows = row_align
+    cap = n + 64 * (n // 64 + 2) if mode == 1 else n + row_align * 256
     info = (C.c_int64 * 6)()
     new2old = np.empty(cap, np.int32); color_begin = np.zeros(257, np.int32)
     blk_begin = np.zeros(n // 64 + 3, np.int32); row_color = np.zeros(cap, np.uint8)

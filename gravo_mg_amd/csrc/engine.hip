@@ -87,6 +87,12 @@ struct gmg_solver_s {
     std::map<int, hipGraphExec_t> graphs;
     int loaded_d = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // multi-GPU (one process per GPU): this rank's share of level 0, externally owned level-0 vectors
+    hipStream_t own_stream = nullptr;
+    int rank = 0, world = 1;
+    bool dist_ready = false;
+    double *own_x0 = nullptr, *own_b0 = nullptr, *own_r0 = nullptr;   // engine-owned buffers parked while external ones are bound
+    bool bound = false;
 };
 
 namespace {
@@ -151,8 +157,15 @@ void drop_graphs(gmg_handle h) {
     h->graphs.clear();
 }
 
+void unbind_level0(gmg_handle h) {
+    if (h->bound && !h->lv.empty()) { h->lv[0].x = h->own_x0; h->lv[0].b = h->own_b0; h->lv[0].r = h->own_r0; }
+    h->bound = false; h->own_x0 = h->own_b0 = h->own_r0 = nullptr;
+}
+
 void drop_system(gmg_handle h) {
     drop_graphs(h);
+    unbind_level0(h);
+    h->dist_ready = false;
     for (auto& l : h->lv) free_level(l);
     h->lv.clear();
     h->system_ready = false;
@@ -250,11 +263,11 @@ void launch_spmv(gmg_handle h, Level& l, int d, int mode, const double* b, const
         if (mode == 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, b + (size_t)c0 * ld, x + (size_t)c0 * ld,
-                                              y + (size_t)c0 * ld, ld, l.Aoff.n_slices, 1));
+                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
         } else {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 0>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, (const double*)nullptr, x + (size_t)c0 * ld,
-                                              y + (size_t)c0 * ld, ld, l.Aoff.n_slices, 1));
+                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
         }
     }
 }
@@ -265,7 +278,7 @@ void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const doub
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 0>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                           fine.R.slice_ptr, fine.R.col, fine.R.val, fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
-                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, fine.R.n_slices, 1));
+                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1));
     }
 }
 
@@ -275,7 +288,7 @@ void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const d
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                           fine.P.slice_ptr, fine.P.col, fine.P.val, (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
-                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, fine.P.n_slices, 1));
+                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1));
     }
 }
 
@@ -288,7 +301,7 @@ int launch_norm(gmg_handle h, int d, int type) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                           l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
-                                          l.n_pad, l.Aoff.n_slices, h->d_partials));
+                                          l.n_pad, 0, l.Aoff.n_slices, h->d_partials));
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
     }
     HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
@@ -312,6 +325,7 @@ double norm_from_sums(const double* s, int d, int type) {
 int ensure_vectors(gmg_handle h, int d) {
     if (d <= h->dcap) return GMG_OK;
     drop_graphs(h);
+    unbind_level0(h);
     for (auto& l : h->lv) {
         for (double** p : {&l.x, &l.b, &l.r, &l.tmp}) {
             if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -368,9 +382,9 @@ int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
 
 // ---- V-cycle legs --------------------------------------------------------------------------------------
 
-void enqueue_down(gmg_handle h, int d) {
+void enqueue_down(gmg_handle h, int d, int k0 = 0) {
     const int L = h->L;
-    for (int k = 0; k < L; ++k) {
+    for (int k = k0; k < L; ++k) {
         Level& l = h->lv[k];
         if (k > 0) (void)hipMemsetAsync(l.x, 0, sizeof(double) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
         launch_smooth(h, l, d, h->cfg.pre_iters);                                                 // :1063
@@ -379,8 +393,8 @@ void enqueue_down(gmg_handle h, int d) {
     }
 }
 
-void enqueue_up(gmg_handle h, int d) {
-    for (int k = h->L - 1; k >= 0; --k) {
+void enqueue_up(gmg_handle h, int d, int k0 = 0) {
+    for (int k = h->L - 1; k >= k0; --k) {
         Level& l = h->lv[k];
         launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);                           // :1082
         launch_smooth(h, l, d, h->cfg.post_iters);                                                // :1085
@@ -512,6 +526,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
     if (ndev > 0 && c.device >= 0 && c.device < ndev && hipSetDevice(c.device) == hipSuccess &&
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess) {
         h->has_device = true;
+        h->own_stream = h->stream;
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
     }
@@ -530,7 +545,7 @@ void gmg_destroy(gmg_handle h) {
         if (h->h_norm) (void)hipHostFree(h->h_norm);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
-        (void)hipStreamDestroy(h->stream);
+        (void)hipStreamDestroy(h->own_stream);
     }
     delete h;
 }
@@ -910,6 +925,164 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     return GMG_OK;
 }
 
+// ---- multi-GPU: one process per GPU, level 0 row-partitioned per colour, levels >= 1 replicated ---------------
+// The caller (gravo_mg_amd/dist.py) owns the level-0 vectors and performs the exchanges (RCCL all-gather of the
+// colour segment of x after every colour); these entry points only launch this rank's share of the work.
+
+int gmg_set_stream(gmg_handle h, void* hip_stream) {
+    NEED_DEVICE();
+    HIPCHK(hipStreamSynchronize(h->stream));
+    drop_graphs(h);
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return GMG_OK;
+}
+
+int gmg_dist_setup(gmg_handle h, int rank, int world) {
+    NEED_DEVICE();
+    int rc = check_level(h, 0, false);
+    if (rc) return rc;
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, GMG_ERR_INVALID, "bad rank / world size");
+    const LevelOrdering& o = h->lv[0].ord;
+    if (o.blocked || h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the colour-major multicolour ordering on level 0");
+    for (int c = 0; c < o.n_colors; ++c)
+        if ((o.color_begin[c + 1] - o.color_begin[c]) % (64 * world)) return fail(h, GMG_ERR_STATE, "colour classes are not aligned to 64*world rows: create the handle with row_align = 64*world");
+    h->rank = rank; h->world = world; h->dist_ready = true;
+    return GMG_OK;
+}
+
+int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d) {
+    NEED_DEVICE();
+    if (!h->dist_ready) return fail(h, GMG_ERR_STATE, "call gmg_dist_setup first");
+    if (!x0 || !b0 || !r0 || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    int rc = ensure_vectors(h, d);
+    if (rc) return rc;
+    drop_graphs(h);
+    Level& l = h->lv[0];
+    if (!h->bound) { h->own_x0 = l.x; h->own_b0 = l.b; h->own_r0 = l.r; }
+    l.x = x0; l.b = b0; l.r = r0;
+    h->bound = true;
+    h->loaded_d = d;
+    return GMG_OK;
+}
+
+namespace {
+inline void own_range(gmg_handle h, int c, int& sb, int& se) {
+    const LevelOrdering& o = h->lv[0].ord;
+    const int chunk = (o.color_begin[c + 1] - o.color_begin[c]) / 64 / h->world;
+    sb = o.color_begin[c] / 64 + h->rank * chunk;
+    se = sb + chunk;
+}
+int dist_ready(gmg_handle h) {
+    if (!h->dist_ready || !h->bound || h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "distributed state not set (gmg_dist_setup + gmg_dist_bind)");
+    return GMG_OK;
+}
+}  // namespace
+
+// One colour of one Gauss-Seidel sweep on this rank's rows of level 0.
+int gmg_dist_smooth_color(gmg_handle h, int c) {
+    NEED_DEVICE();
+    int rc = dist_ready(h);
+    if (rc) return rc;
+    Level& l = h->lv[0];
+    if (c < 0 || c >= l.ord.n_colors) return fail(h, GMG_ERR_INVALID, "colour out of range");
+    int sb, se;
+    own_range(h, c, sb, se);
+    const int d = h->loaded_d, ld = l.n_pad;
+    if (se > sb)
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+                                              l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1));
+        }
+    return GMG_OK;
+}
+
+// r0[own rows] = b0 - A x0
+int gmg_dist_residual_own(gmg_handle h) {
+    NEED_DEVICE();
+    int rc = dist_ready(h);
+    if (rc) return rc;
+    Level& l = h->lv[0];
+    const int d = h->loaded_d, ld = l.n_pad;
+    for (int c = 0; c < l.ord.n_colors; ++c) {
+        int sb, se;
+        own_range(h, c, sb, se);
+        if (se <= sb) continue;
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+                                              l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, l.r + (size_t)c0 * ld, ld,
+                                              sb, se, 1));
+        }
+    }
+    return GMG_OK;
+}
+
+// Replicated coarse part: b1 = U0^T r0 (needs the complete r0), levels 1..L-1 down, coarsest solve, back up to level 1.
+int gmg_dist_coarse_cycle(gmg_handle h) {
+    NEED_DEVICE();
+    int rc = dist_ready(h);
+    if (rc) return rc;
+    const int d = h->loaded_d;
+    launch_restrict(h, h->lv[0], h->lv[1], d, h->lv[0].r, h->lv[1].b);
+    enqueue_down(h, d, 1);
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device(h, d);
+    else if ((rc = coarse_host_roundtrip(h, d))) return rc;
+    enqueue_up(h, d, 1);
+    return GMG_OK;
+}
+
+// x0[own rows] += U0 x1
+int gmg_dist_prolong_own(gmg_handle h) {
+    NEED_DEVICE();
+    int rc = dist_ready(h);
+    if (rc) return rc;
+    Level& l = h->lv[0];
+    Level& cl = h->lv[1];
+    const int d = h->loaded_d;
+    for (int c = 0; c < l.ord.n_colors; ++c) {
+        int sb, se;
+        own_range(h, c, sb, se);
+        if (se <= sb) continue;
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.P.slice_ptr, l.P.col,
+                                              l.P.val, (const int*)nullptr, cl.x + (size_t)c0 * cl.n_pad, cl.n_pad, l.x + (size_t)c0 * l.n_pad, l.n_pad,
+                                              sb, se, 1));
+        }
+    }
+    return GMG_OK;
+}
+
+// sums[2*c] / sums[2*c+1] = this rank's share of sum w r^2 / sum w b^2 for column c (host output; synchronises).
+int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) {
+    NEED_DEVICE();
+    int rc = dist_ready(h);
+    if (rc) return rc;
+    if (!sums) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = check_norm_type(h, type))) return rc;
+    Level& l = h->lv[0];
+    const int d = h->loaded_d;
+    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
+    const int nc = l.ord.n_colors;
+    const int nblk = std::max(1, kNormBlocks / std::max(nc, 1));
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        for (int c = 0; c < nc; ++c) {
+            int sb, se;
+            own_range(h, c, sb, se);
+            DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
+                                              l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, sb, se,
+                                              h->d_partials + (size_t)c * nblk * 2 * dc));
+        }
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0);
+    }
+    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::memcpy(sums, h->h_norm, sizeof(double) * 2 * d);
+    return GMG_OK;
+}
+
 // ---- measurement --------------------------------------------------------------------------------------------
 
 int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out) {
@@ -1048,7 +1221,7 @@ int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const doubl
     if (sigma < 0 || sigma % 64) return GMG_ERR_INVALID;
     Compressed A;
     A.assign(n, n, colptr, rowidx, val);
-    LevelOrdering o = mode == 1 ? make_block_ordering(A, block_rows) : make_ordering(A, true, 64, sigma);
+    LevelOrdering o = mode == 1 ? make_block_ordering(A, block_rows) : make_ordering(A, true, (block_rows > 0 && block_rows % 64 == 0) ? block_rows : 64, sigma);
     if (o.n_colors > 256) return GMG_ERR_UNSUPPORTED;
     SellHost sa; std::vector<double> dg; std::string e;
     if (!build_operator_sell(A, o, 0, sa, dg, e)) return GMG_ERR_NUMERIC;

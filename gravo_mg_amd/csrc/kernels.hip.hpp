@@ -204,9 +204,10 @@ template <int D, int MODE>
 __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                     const double* __restrict__ val, const double* __restrict__ diag,
                                                     const double* __restrict__ b, const double* __restrict__ x,
-                                                    double* __restrict__ y, int ld, int n_slices, int xcd_swizzle) {
-    const int s = wave_slice(n_slices, xcd_swizzle);
-    if (s >= n_slices) return;
+                                                    double* __restrict__ y, int ld, int slice_begin, int slice_end,
+                                                    int xcd_swizzle) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
+    if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     double acc[D];
@@ -227,9 +228,9 @@ template <int D, int ADD>
 __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const double* __restrict__ val, const int* __restrict__ row_of,
                                                    const double* __restrict__ x, int ldx, double* __restrict__ y, int ldy,
-                                                   int n_slices, int xcd_swizzle) {
-    const int s = wave_slice(n_slices, xcd_swizzle);
-    if (s >= n_slices) return;
+                                                   int slice_begin, int slice_end, int xcd_swizzle) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
+    if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     double acc[D];
     row_dot<D>(slice_ptr, col, val, x, ldx, s, lane, acc);
@@ -249,15 +250,16 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                                  const double* __restrict__ val, const double* __restrict__ diag,
                                                                  const double* __restrict__ b, const double* __restrict__ x,
-                                                                 const double* __restrict__ weight, int ld, int n_slices,
-                                                                 double* __restrict__ partials) {
+                                                                 const double* __restrict__ weight, int ld, int slice_begin,
+                                                                 int slice_end, double* __restrict__ partials) {
     __shared__ double red[kWavesPerBlock][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double sums[2 * D];
 #pragma unroll
     for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
     // fixed-size grid, each wave strides over the slices: few partials, fixed summation order
-    for (int s = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave); s < n_slices; s += gridDim.x * kWavesPerBlock) {
+    for (int s = slice_begin + __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave); s < slice_end;
+         s += gridDim.x * kWavesPerBlock) {
         const int row = s * 64 + lane;
         double acc[D];
         row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);

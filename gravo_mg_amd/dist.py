@@ -1,0 +1,160 @@
+"""Multi-GPU V-cycle: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI).
+
+Partition (BASELINE.json north_star): 1-D row split of the finest level.  The device numbering
+of level 0 is colour-major; every colour class is padded to 64*P rows and cut into P equal contiguous pieces,
+rank p owns piece p of every colour.  Levels >= 1 are small (<= n_0/6) and are REPLICATED: every rank runs them
+redundantly, which needs no communication at all.
+
+Exchange steps per V-cycle (each an in-place all-gather of one colour's segment of a level-0 vector; a rank's
+input is its own piece of the output buffer):
+    after every colour of every Gauss-Seidel sweep ......... x  (the next colour reads it)
+    after the residual ..................................... r  (the replicated restriction needs all of it)
+    after the prolongation ................................. x
+plus one all-reduce of 2*d doubles per residual check.  Because the colours are GLOBAL, the distributed sweep is
+the same multicolour Gauss-Seidel as on one GPU: results are independent of P up to the summation order of the
+norm.  (A halo-only exchange would move O(sqrt(n/P)) instead of n/(C*P) values per step -- the collective count,
+i.e. the latency, stays the same; at 3 M vertices the path is latency-bound either way)
+
+The local work is done by a *backend*: `EngineBackend` launches this rank's share on its GPU through the C-ABI
+(gmg_dist_* in include/gravomg_hip.h).  tests/test_dist_gloo.py plugs in a numpy backend to check the
+orchestration (partition arithmetic, order of exchanges) with the gloo backend on CPU.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class DistVCycle:
+    """V-cycle + residual check + solve loop over `world` ranks.  `backend` provides the local steps and the
+    level-0 vectors x, b, r as flat torch tensors of length d * n_pad (column-major)."""
+
+    def __init__(self, backend, group=None):
+        self.be = backend
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.color_begin = [int(v) for v in backend.color_begin]
+        self.n_pad = int(backend.n_pad)
+        self.d = int(backend.d)
+        self.n_colors = len(self.color_begin) - 1
+        for c in range(self.n_colors):
+            assert (self.color_begin[c + 1] - self.color_begin[c]) % (64 * self.world) == 0, "colour classes must be 64*world aligned"
+        self.n_collectives = 0
+
+    # -- exchange ------------------------------------------------------------------------------------------
+    def _allgather_color(self, buf: torch.Tensor, c: int):
+        if self.world == 1:
+            return
+        lo, hi = self.color_begin[c], self.color_begin[c + 1]
+        piece = (hi - lo) // self.world
+        if piece == 0:
+            return
+        for col in range(self.d):
+            seg = buf[col * self.n_pad + lo: col * self.n_pad + hi]
+            mine = seg[self.rank * piece: (self.rank + 1) * piece]
+            try:
+                dist.all_gather_into_tensor(seg, mine, group=self.group)
+            except (RuntimeError, NotImplementedError):          # backends without the flat variant (old gloo)
+                dist.all_gather(list(seg.chunk(self.world)), mine.clone(), group=self.group)
+            self.n_collectives += 1
+
+    def _allgather_all(self, buf: torch.Tensor):
+        for c in range(self.n_colors):
+            self._allgather_color(buf, c)
+
+    # -- the cycle (gravomg/src/multigrid_solver.cpp:1059-1088) ----------------------------------------------
+    def smooth(self, iters: int):
+        for _ in range(iters):
+            for c in range(self.n_colors):
+                self.be.smooth_color(c)
+                self._allgather_color(self.be.x, c)
+
+    def vcycle(self):
+        with self.be.stream_context():              # kernels and collectives ordered on the backend's stream
+            self.smooth(self.be.pre_iters)              # :1063
+            self.be.residual_own()                      # :1066
+            self._allgather_all(self.be.r)
+            self.be.coarse_cycle()                      # :1069-1079 (replicated)
+            self.be.prolong_own()                       # :1082
+            self._allgather_all(self.be.x)
+            self.smooth(self.be.post_iters)             # :1085
+
+    # -- residualCheck (:1228-1277) ---------------------------------------------------------------------------
+    def residual_norm(self, type: int = 2) -> float:
+        sums = torch.as_tensor(np.asarray(self.be.norm_partial(type), dtype=np.float64))
+        if self.world > 1:
+            with self.be.stream_context():
+                t = sums.to(self.be.x.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                sums = t.cpu()
+            self.n_collectives += 1
+        s = sums.numpy()
+        if type == 3:
+            return math.sqrt(float(s[0::2].sum()))
+        vals = [(math.sqrt(s[2 * c]) / math.sqrt(s[2 * c + 1])) if type == 0 else math.sqrt(s[2 * c] / s[2 * c + 1]) for c in range(self.d)]
+        return max(vals)
+
+    # -- solve loop (:1408-1419) --------------------------------------------------------------------------------
+    def solve(self, tol: float = 1e-4, stop_type: int = 2, max_iter: int = 100):
+        it, residues = 0, []
+        while True:
+            self.vcycle()
+            res = self.residual_norm(stop_type)
+            residues.append(res)
+            it += 1
+            if not (res > tol and it < max_iter):
+                break
+        return it, res, residues
+
+
+class EngineBackend:
+    """This rank's share of level 0 + the replicated coarse levels on one MI355X, through the C-ABI.
+    All launches and the RCCL collectives are ordered on one dedicated torch stream."""
+
+    def __init__(self, engine, d: int, rank: int, world: int, device: Optional[torch.device] = None):
+        self.eng = engine
+        self.d = int(d)
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        info = engine.level_info(0)
+        self.n_pad = info["n_pad"]
+        _, cb = engine.level_ordering(0)
+        self.color_begin = [int(v) for v in cb]
+        self.pre_iters, self.post_iters = engine.pre_iters, engine.post_iters
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.x = torch.zeros(self.n_pad * self.d, dtype=torch.float64, device=self.device)
+        self.b = torch.zeros_like(self.x)
+        self.r = torch.zeros_like(self.x)
+        torch.cuda.synchronize(self.device)
+        engine.set_stream(self.stream.cuda_stream)
+        engine.dist_setup(rank, world)
+        engine.dist_bind(self.x.data_ptr(), self.b.data_ptr(), self.r.data_ptr(), self.d)
+
+    def stream_context(self):
+        return torch.cuda.stream(self.stream)
+
+    def load(self, b_host, x0_host):
+        """Host rhs / initial guess (natural numbering, n x d) -> the bound device vectors (every rank loads all rows)."""
+        self.eng.load_problem(b_host, x0_host)
+
+    def fetch(self):
+        return self.eng.fetch_solution()
+
+    def smooth_color(self, c):
+        self.eng.dist_smooth_color(c)
+
+    def residual_own(self):
+        self.eng.dist_residual_own()
+
+    def coarse_cycle(self):
+        self.eng.dist_coarse_cycle()
+
+    def prolong_own(self):
+        self.eng.dist_prolong_own()
+
+    def norm_partial(self, type):
+        return self.eng.dist_norm_partial(type, self.d)

@@ -1,0 +1,89 @@
+"""bench.py --gpus N (N > 1): the same 3 M-vertex Poisson V-cycle, finest level row-partitioned over N ranks
+(gravo_mg_amd/dist.py).  Launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N --steps K --warmup W`; also works with N = 1 (WORLD_SIZE=1) to exercise the distributed code path on one GPU.
+Timing: W untimed cycles, barrier + synchronize, K V-cycles each followed by the residual check, synchronize +
+barrier, MAX over ranks.  Rank 0 prints ONE JSON line."""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+
+def main(args):
+    import torch
+    import torch.distributed as dist
+
+    from gravo_mg_amd import cabi
+    from gravo_mg_amd.dist import DistVCycle, EngineBackend
+
+    import bench as single
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus or args.gpus <= 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    workload = f"torus{args.n1}x{args.n2}-poisson-tau1e-6-d1-{args.order}"
+    H, mass, lhs, rhs = single.build_workload(args.n1, args.n2, args.order)      # deterministic: every rank builds the same
+    eng = cabi.Engine(device=local, row_align=64 * world, use_graph=False,
+                      coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT)
+    eng.use_hierarchy(H)
+    eng.set_mass(mass)
+    eng.set_system(lhs)
+    levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
+    be = EngineBackend(eng, 1, rank, world, torch.device("cuda", local))
+    dv = DistVCycle(be)
+
+    def run(k):
+        out = []
+        for _ in range(k):
+            dv.vcycle()
+            out.append(dv.residual_norm(2))
+        return out
+
+    be.load(rhs, rhs)
+    run(args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    residues = run(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t1 = time.perf_counter()
+    tmax = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    ms_per_step = 1e3 * float(tmax.item()) / args.steps
+    colls = dv.n_collectives
+
+    be.load(rhs, rhs)
+    t = time.perf_counter()
+    iters, res, hist = dv.solve(1e-4, 2, 100)
+    torch.cuda.synchronize()
+    solve_ms = 1e3 * (time.perf_counter() - t)
+
+    if rank == 0:
+        n0 = lhs.shape[0]
+        out = {
+            "metric": "V-cycle wall time (ms per V-cycle incl. residual check) + solve-to-1e-4 iterations, 3M-vertex Poisson",
+            "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
+                       "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": False,
+                       "partition": f"level 0 rows split {world}-way per colour, levels >= 1 replicated, RCCL all-gather of x per colour",
+                       "tolerance": 1e-4, "stopping_criteria": 2},
+            "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms,
+            "collectives_per_cycle": colls / max(args.steps + args.warmup, 1),
+            "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
+            "timed_residues_tail": [float(r) for r in residues[-3:]],
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()

@@ -138,6 +138,29 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
 /* Download the resident iterate (natural numbering). */
 int gmg_fetch_solution(gmg_handle h, double* x);
 
+/* ---- multi-GPU: one process per GPU ---------------------------------------------------------- */
+/* The finest level is split by rows: every colour class (padded to 64*world rows: create the handle with
+ * row_align = 64*world) is cut into `world` equal contiguous pieces and rank p owns piece p of each colour.
+ * Levels >= 1 are replicated on every rank.  The caller owns the level-0 vectors (device memory, device
+ * numbering, n_pad_0 x d column-major) and exchanges them between the steps below (gravo_mg_amd/dist.py: RCCL
+ * all-gather of a colour's segment of x after each colour, all-reduce of the norm sums); because the colours are
+ * global the result does not depend on the number of ranks. */
+/* Run all launches on this HIP stream (e.g. torch's current stream) instead of the handle's own; NULL restores it. */
+int gmg_set_stream(gmg_handle h, void* hip_stream);
+int gmg_dist_setup(gmg_handle h, int rank, int world);
+/* Use caller-owned device buffers as level-0 x, b, r (until the next gmg_set_system / a larger d). */
+int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d);
+/* Colour c of one Gauss-Seidel sweep on this rank's rows (multigrid_solver.cpp:1194-1226, row-partitioned). */
+int gmg_dist_smooth_color(gmg_handle h, int c);
+/* r0[own rows] = b0 - A x0 (:1066). */
+int gmg_dist_residual_own(gmg_handle h);
+/* Replicated coarse part of the V-cycle: U0^T r0 (complete r0 required), levels 1..L-1, coarsest solve (:1069-1079). */
+int gmg_dist_coarse_cycle(gmg_handle h);
+/* x0[own rows] += U0 x1 (:1082). */
+int gmg_dist_prolong_own(gmg_handle h);
+/* This rank's share of the residual-norm sums: sums[2c] = sum w r^2, sums[2c+1] = sum w b^2 for rhs column c. */
+int gmg_dist_norm_partial(gmg_handle h, int type, double* sums);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:
  * kind 0 = full smoothing sweep (all colours), 1 = residual r=b-Ax, 2 = restrict, 3 = prolong_add,
@@ -180,9 +203,10 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
 
 /* Host-only view of the device layout planner (colouring / block growing / SELL-64), for CPU tests of the
  * host logic.  mode 0: colour-major ordering (exact multicolour Gauss-Seidel), mode 1: block ordering
- * (block-hybrid Gauss-Seidel, `block_rows` rows per block).  info[0..5] = n_pad, n_colors, n_blocks,
+ * (block-hybrid Gauss-Seidel, `block_rows` rows per block).  In mode 0 `block_rows` is the colour-class
+ * alignment (the config's row_align; 0 = 64).  info[0..5] = n_pad, n_colors, n_blocks,
  * stored SELL entries (off-diagonal), real off-diagonal entries, 0.  new2old must hold n + 64*(n/64 + 2)
- * ints if mode 1 and n + 64*256 if mode 0 (only n_pad are written); color_begin 257 ints; blk_begin
+ * ints if mode 1 and n + row_align*256 if mode 0 (only n_pad are written); color_begin 257 ints; blk_begin
  * n/64 + 3 ints; row_color like new2old (bytes).  Output pointers may be NULL. */
 int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma,
                         int64_t* info, int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color);
