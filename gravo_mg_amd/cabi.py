@@ -113,6 +113,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1 with the same SONAMEs as
+    /opt/rocm.  Whichever copy is loaded first serves the whole process, and torch reports "No HIP GPUs are
+    available" if the system copy got in first.  bench.py, dist.py and the tests use torch in the same process for
+    streams and torch.distributed, so make torch's copy the process-wide one -- without importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def lib() -> C.CDLL:
     """Load libgravomg_hip.so (built in-tree by gravo_mg_amd/csrc/build.sh).  Fails loudly if absent."""
     global _lib
@@ -121,6 +143,7 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with gravo_mg_amd/csrc/build.sh (or __graft_entry__.build()). "
                 "gravo_mg_amd has no CPU fallback for the device path.")
+        _preload_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)

@@ -123,6 +123,15 @@ int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
     return GMG_OK;
 }
 
+template <class T>
+int upload(gmg_handle h, T** dst, const RawVec<T>& src) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
 void free_sell(DevSell& s) {
     if (s.slice_ptr) (void)hipFree(s.slice_ptr);
     if (s.col) (void)hipFree(s.col);
@@ -615,44 +624,71 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     h->timing["coarsest_solve"] = ms_since(t0);
     // -- device layout + upload
     t0 = clk::now();
+    auto lap = [&](const char* key, clk::time_point& t) { h->timing[key] += ms_since(t); t = clk::now(); };
+    for (const char* key : {"setup_ordering", "setup_sell", "setup_h2d", "setup_transpose", "setup_sell_P", "setup_sell_R", "setup_sell_A"}) h->timing[key] = 0.0;
+    auto tl = clk::now();
     const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
+    {
+        // the per-level orderings are independent of each other: one host thread per level
+        std::vector<std::thread> pool;
+        for (int k = 0; k <= L; ++k) {
+            Level& l = h->lv[k];
+            l.n = l.A.n_outer;
+            const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
+            pool.emplace_back([&l, k, L, blocked, mc, h] {
+                if (k == L) l.ord = identity_ordering(l.n);
+                else if (blocked) l.ord = make_block_ordering(l.A, h->cfg.block_rows);
+                else l.ord = make_ordering(l.A, mc, h->cfg.row_align, h->cfg.sigma);
+            });
+        }
+        for (auto& th : pool) th.join();
+    }
     for (int k = 0; k <= L; ++k) {
         Level& l = h->lv[k];
-        l.n = l.A.n_outer;
-        const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
-        if (k == L) l.ord = identity_ordering(l.n);
-        else if (blocked) l.ord = make_block_ordering(l.A, h->cfg.block_rows);
-        else l.ord = make_ordering(l.A, mc, h->cfg.row_align, h->cfg.sigma);
         if (l.ord.n_colors > 255) return fail(h, GMG_ERR_UNSUPPORTED, "more than 255 colours on level " + std::to_string(k));
         l.n_pad = l.ord.n_pad;
     }
+    lap("setup_ordering", tl);
     for (int k = 0; k <= L; ++k) {
         Level& l = h->lv[k];
         int rc;
         if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) return rc;
         if (k == L) break;
         SellHost sa; std::vector<double> dg; std::string e;
+        auto ta = clk::now();
         if (!build_operator_sell(l.A, l.ord, 0, sa, dg, e)) return fail(h, GMG_ERR_NUMERIC, "level " + std::to_string(k) + ": " + e);
+        lap("setup_sell_A", ta);
+        lap("setup_sell", tl);
         if ((rc = upload_sell(h, l.Aoff, sa))) return rc;
         if ((rc = upload(h, &l.diag, dg))) return rc;
+        lap("setup_h2d", tl);
         SellHost sin, sout;
         std::vector<unsigned short> c16;
         if (l.ord.blocked) {
             build_operator_sell_split(l.A, l.ord, sin, sout);
-            c16.assign(sin.col.begin(), sin.col.end());
+            c16.resize(sin.col.size());
+            parallel_ranges((int)sin.col.size(), h->cfg.host_threads, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) c16[i] = (unsigned short)sin.col[i]; });
+            lap("setup_sell", tl);
             if ((rc = upload_sell(h, l.Ain, sin))) return rc;
             if ((rc = upload_sell(h, l.Aout, sout))) return rc;
             if ((rc = upload(h, &l.ain_col16, c16))) return rc;
             if ((rc = upload(h, &l.d_blk_begin, l.ord.blk_begin))) return rc;
             if ((rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors))) return rc;
             if ((rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
+            lap("setup_h2d", tl);
         }
-        Compressed Urows = transpose(h->U[k]);                                     // outer = fine rows
+        auto tt = clk::now();
+        Compressed Urows = transpose_parallel(h->U[k]);                            // outer = fine rows
+        lap("setup_transpose", tt);
         SellHost sp = build_transfer_sell(Urows, l.ord, h->lv[k + 1].ord, 0);
-        if ((rc = upload_sell(h, l.P, sp))) return rc;
+        lap("setup_sell_P", tt);
         SellHost sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, l.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0);   // outer = coarse rows
+        lap("setup_sell_R", tt);
+        lap("setup_sell", tl);
+        if ((rc = upload_sell(h, l.P, sp))) return rc;
         if ((rc = upload_sell(h, l.R, sr))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));      // host staging vectors die at scope end
+        lap("setup_h2d", tl);
     }
     {
         int nblk = kNormBlocks;

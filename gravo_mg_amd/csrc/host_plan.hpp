@@ -12,18 +12,61 @@
 //   * U_k (<= 3 entries per row, multigrid_solver.cpp:371-373,413-414) is stored twice: SELL of U for
 //     x += U e, and SELL of U^T (rows sorted by length inside windows, output row in `row_of`) for
 //     rc = U^T r.  U^T as CSR is exactly the reference's CSC storage of U.
+// Everything here runs once per system on the host; the passes over rows are threaded (parallel_ranges) and the
+// large arrays are left uninitialised until their single parallel fill.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <vector>
+
+#include <stdlib.h>
+#include <sys/mman.h>
 
 #include "host_sparse.hpp"
 
 namespace gmg {
 
 constexpr int kSlice = 64;
+
+// Plain array without value-initialisation (std::vector zero-fills: ~100 ms per 200 MB on one core).  Large arrays are
+// 2 MiB-aligned and marked MADV_HUGEPAGE: the staging buffers of one 3 M-vertex level are ~0.5 GB of fresh memory, and
+// with 4 KiB pages 128 threads first-touching them serialise on the page-fault path.
+template <class T>
+struct RawVec {
+    T* p = nullptr;
+    size_t n = 0;
+    RawVec() {}
+    RawVec(const RawVec&) = delete;
+    RawVec& operator=(const RawVec&) = delete;
+    RawVec(RawVec&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    RawVec& operator=(RawVec&& o) noexcept { if (this != &o) { std::free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~RawVec() { std::free(p); }
+    void resize(size_t m) {
+        std::free(p);
+        p = nullptr; n = m;
+        const size_t bytes = std::max<size_t>(m, 1) * sizeof(T);
+        if (bytes >= (size_t)4 << 20) {
+            void* q = nullptr;
+            const size_t rounded = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+            if (posix_memalign(&q, (size_t)2 << 20, rounded) == 0) {
+                (void)madvise(q, rounded, MADV_HUGEPAGE);
+                p = (T*)q;
+                return;
+            }
+        }
+        p = (T*)std::malloc(bytes);
+    }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
 
 struct LevelOrdering {
     int n = 0;                        // real unknowns
@@ -47,8 +90,8 @@ struct SellHost {
     int n_slices = 0;
     int64_t nnz_real = 0;
     std::vector<int64_t> slice_ptr;   // n_slices + 1, element offsets (multiples of 64)
-    std::vector<int> col;
-    std::vector<double> val;
+    RawVec<int> col;
+    RawVec<double> val;
     std::vector<int> row_of;          // empty => slice row r is device row r; else output row (or -1)
     int64_t stored() const { return slice_ptr.empty() ? 0 : slice_ptr[n_slices]; }
 };
@@ -201,52 +244,75 @@ inline LevelOrdering identity_ordering(int n) {
     for (int i = 0; i < n; ++i) { o.new2old[i] = i; o.old2new[i] = i; }
     return o;
 }
+// Row-wise staging of a matrix in DEVICE numbering: ptr (prefix sums of row lengths), then (idx, val) sorted by column.
+struct RowStage {
+    std::vector<int64_t> ptr;
+    RawVec<int> idx;
+    RawVec<double> val;
+};
 
-// Rows given as (ptr, idx, val) in DEVICE numbering for n_rows_pad rows -> SELL-64.
-// If sort_sigma > 0 the rows are re-sorted by length inside windows and row_of records the output row.
-inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const std::vector<int64_t>& ptr,
-                            const std::vector<int>& idx, const std::vector<double>& val, int sort_sigma) {
+// lengths[r] for r < np computed in parallel by `len_of(r)`, then one sequential prefix sum.
+template <class LenFn>
+inline void stage_lengths(int np, RowStage& st, LenFn&& len_of) {
+    st.ptr.assign((size_t)np + 1, 0);
+    parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
+        for (int r = lo; r < hi; ++r) st.ptr[r + 1] = len_of(r);
+    });
+    for (int r = 0; r < np; ++r) st.ptr[r + 1] += st.ptr[r];
+    st.idx.resize((size_t)st.ptr[np]);
+    st.val.resize((size_t)st.ptr[np]);
+}
+
+// Staged rows -> SELL-64.  If sort_sigma > 0 the rows are re-sorted by length inside windows and row_of records
+// the output row.
+inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const RowStage& st, int sort_sigma) {
+    const std::vector<int64_t>& ptr = st.ptr;
     SellHost s;
     s.n_rows_pad = n_rows_pad; s.n_cols = n_cols; s.n_slices = n_rows_pad / kSlice;
     s.nnz_real = ptr[n_rows_pad];
-    std::vector<int> order(n_rows_pad);
-    std::iota(order.begin(), order.end(), 0);
-    if (sort_sigma > 0) {
-        for (int w = 0; w < n_rows_pad; w += sort_sigma) {
-            int we = std::min(n_rows_pad, w + sort_sigma);
-            std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) {
-                return (ptr[a + 1] - ptr[a]) > (ptr[b + 1] - ptr[b]);
-            });
-        }
+    std::vector<int> order;
+    const bool sorted = sort_sigma > 0;
+    if (sorted) {
+        order.resize(n_rows_pad);
+        const int nwin = (n_rows_pad + sort_sigma - 1) / sort_sigma;
+        parallel_ranges(nwin, hw_threads(), [&](int lo, int hi, int) {
+            for (int wi = lo; wi < hi; ++wi) {
+                int w = wi * sort_sigma, we = std::min(n_rows_pad, w + sort_sigma);
+                std::iota(order.begin() + w, order.begin() + we, w);
+                std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) { return (ptr[a + 1] - ptr[a]) > (ptr[b + 1] - ptr[b]); });
+            }
+        });
         s.row_of = order;
     }
+    auto row_at = [&](int i) { return sorted ? order[i] : i; };
     s.slice_ptr.assign((size_t)s.n_slices + 1, 0);
-    for (int sl = 0; sl < s.n_slices; ++sl) {
-        int64_t w = 0;
-        for (int l = 0; l < kSlice; ++l) {
-            int r = order[sl * kSlice + l];
-            w = std::max<int64_t>(w, ptr[r + 1] - ptr[r]);
-        }
-        s.slice_ptr[sl + 1] = s.slice_ptr[sl] + w * kSlice;
-    }
-    s.col.assign((size_t)s.stored(), 0);
-    s.val.assign((size_t)s.stored(), 0.0);
     parallel_ranges(s.n_slices, hw_threads(), [&](int lo, int hi, int) {
         for (int sl = lo; sl < hi; ++sl) {
-            int64_t base = s.slice_ptr[sl];
-            int64_t w = (s.slice_ptr[sl + 1] - base) / kSlice;
+            int64_t w = 0;
+            for (int l = 0; l < kSlice; ++l) { int r = row_at(sl * kSlice + l); w = std::max<int64_t>(w, ptr[r + 1] - ptr[r]); }
+            s.slice_ptr[sl + 1] = w * kSlice;
+        }
+    });
+    for (int sl = 0; sl < s.n_slices; ++sl) s.slice_ptr[sl + 1] += s.slice_ptr[sl];
+    s.col.resize((size_t)s.stored());
+    s.val.resize((size_t)s.stored());
+    parallel_ranges(s.n_slices, hw_threads(), [&](int lo, int hi, int) {
+        for (int sl = lo; sl < hi; ++sl) {
+            const int64_t base = s.slice_ptr[sl];
+            const int64_t w = (s.slice_ptr[sl + 1] - base) / kSlice;
             for (int l = 0; l < kSlice; ++l) {
-                int r = order[sl * kSlice + l];
-                int64_t len = ptr[r + 1] - ptr[r];
-                for (int64_t j = 0; j < w; ++j) {
-                    int64_t q = base + j * kSlice + l;
-                    if (j < len) { s.col[q] = idx[ptr[r] + j]; s.val[q] = val[ptr[r] + j]; }
-                    else { s.col[q] = 0; s.val[q] = 0.0; }   // padding: 0 * x[0]
-                }
+                const int r = row_at(sl * kSlice + l);
+                const int64_t len = ptr[r + 1] - ptr[r], p0 = ptr[r];
+                for (int64_t j = 0; j < len; ++j) { s.col[base + j * kSlice + l] = st.idx[p0 + j]; s.val[base + j * kSlice + l] = st.val[p0 + j]; }
+                for (int64_t j = len; j < w; ++j) { s.col[base + j * kSlice + l] = 0; s.val[base + j * kSlice + l] = 0.0; }   // padding: 0 * x[0]
             }
         }
     });
     return s;
+}
+
+inline void sort_row(std::vector<std::pair<int, double>>& row) {
+    std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
 }
 
 // A (symmetric, natural numbering) -> off-diagonal SELL + diagonal, in the level's device numbering.
@@ -255,23 +321,22 @@ inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int
                                 std::vector<double>& diag, std::string& err) {
     (void)sigma_unused;
     const int np = o.n_pad;
-    std::vector<int64_t> ptr((size_t)np + 1, 0);
     diag.assign(np, 1.0);
-    for (int r = 0; r < np; ++r) {
+    std::atomic<int> bad_row{-1};
+    RowStage st;
+    stage_lengths(np, st, [&](int r) -> int64_t {
         int old = o.new2old[r];
+        if (old < 0) return 0;
         int64_t len = 0;
-        if (old >= 0) {
-            bool has = false;
-            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
-                if (A.idx[p] == old) { has = true; diag[r] = A.val[p]; }
-                else ++len;
-            }
-            if (!has || diag[r] == 0.0) { err = "system matrix has a missing or zero diagonal entry at row " + std::to_string(old); return false; }
+        bool has = false;
+        for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+            if (A.idx[p] == old) { has = true; diag[r] = A.val[p]; }
+            else ++len;
         }
-        ptr[r + 1] = ptr[r] + len;
-    }
-    std::vector<int> idx((size_t)ptr[np]);
-    std::vector<double> val((size_t)ptr[np]);
+        if (!has || diag[r] == 0.0) bad_row.store(old);
+        return len;
+    });
+    if (bad_row.load() >= 0) { err = "system matrix has a missing or zero diagonal entry at row " + std::to_string(bad_row.load()); return false; }
     parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
         std::vector<std::pair<int, double>> row;
         for (int r = lo; r < hi; ++r) {
@@ -280,12 +345,12 @@ inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int
             row.clear();
             for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p)
                 if (A.idx[p] != old) row.emplace_back(o.old2new[A.idx[p]], A.val[p]);
-            std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
-            int64_t q = ptr[r];
-            for (auto& e : row) { idx[q] = e.first; val[q] = e.second; ++q; }
+            sort_row(row);
+            int64_t q = st.ptr[r];
+            for (auto& e : row) { st.idx[q] = e.first; st.val[q] = e.second; ++q; }
         }
     });
-    out = csr_to_sell(np, np, ptr, idx, val, 0);
+    out = csr_to_sell(np, np, st, 0);
     return true;
 }
 
@@ -297,20 +362,19 @@ inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& 
     std::vector<int> blk_of_row(np, 0);
     for (int b = 0; b < o.n_blocks(); ++b)
         for (int r = o.blk_begin[b]; r < o.blk_begin[b + 1]; ++r) blk_of_row[r] = b;
-    std::vector<int64_t> pin((size_t)np + 1, 0), pout((size_t)np + 1, 0);
-    for (int r = 0; r < np; ++r) {
+    RowStage sin, sout;
+    auto count = [&](int r, bool inside) -> int64_t {
         int old = o.new2old[r];
-        int64_t li = 0, lo = 0;
-        if (old >= 0)
-            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
-                if (A.idx[p] == old) continue;
-                if (blk_of_row[o.old2new[A.idx[p]]] == blk_of_row[r]) ++li; else ++lo;
-            }
-        pin[r + 1] = pin[r] + li;
-        pout[r + 1] = pout[r] + lo;
-    }
-    std::vector<int> iin((size_t)pin[np]), iout((size_t)pout[np]);
-    std::vector<double> vin((size_t)pin[np]), vout((size_t)pout[np]);
+        if (old < 0) return 0;
+        int64_t len = 0;
+        for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+            if (A.idx[p] == old) continue;
+            if ((blk_of_row[o.old2new[A.idx[p]]] == blk_of_row[r]) == inside) ++len;
+        }
+        return len;
+    };
+    stage_lengths(np, sin, [&](int r) { return count(r, true); });
+    stage_lengths(np, sout, [&](int r) { return count(r, false); });
     parallel_ranges(np, hw_threads(), [&](int lo_, int hi_, int) {
         std::vector<std::pair<int, double>> row;
         for (int r = lo_; r < hi_; ++r) {
@@ -319,17 +383,17 @@ inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& 
             row.clear();
             for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p)
                 if (A.idx[p] != old) row.emplace_back(o.old2new[A.idx[p]], A.val[p]);
-            std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
-            int64_t qi = pin[r], qo = pout[r];
+            sort_row(row);
+            int64_t qi = sin.ptr[r], qo = sout.ptr[r];
             const int base = o.blk_begin[blk_of_row[r]];
             for (auto& e : row) {
-                if (blk_of_row[e.first] == blk_of_row[r]) { iin[qi] = e.first - base; vin[qi] = e.second; ++qi; }
-                else { iout[qo] = e.first; vout[qo] = e.second; ++qo; }
+                if (blk_of_row[e.first] == blk_of_row[r]) { sin.idx[qi] = e.first - base; sin.val[qi] = e.second; ++qi; }
+                else { sout.idx[qo] = e.first; sout.val[qo] = e.second; ++qo; }
             }
         }
     });
-    in = csr_to_sell(np, np, pin, iin, vin, 0);
-    out = csr_to_sell(np, np, pout, iout, vout, 0);
+    in = csr_to_sell(np, np, sin, 0);
+    out = csr_to_sell(np, np, sout, 0);
 }
 
 // Generic: rows of `Mrows` (compressed, outer = rows in natural numbering of the row space) mapped into
@@ -337,13 +401,11 @@ inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& 
 inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering& orow, const LevelOrdering& ocol,
                                     int sort_sigma) {
     const int np = orow.n_pad;
-    std::vector<int64_t> ptr((size_t)np + 1, 0);
-    for (int r = 0; r < np; ++r) {
+    RowStage st;
+    stage_lengths(np, st, [&](int r) -> int64_t {
         int old = orow.new2old[r];
-        ptr[r + 1] = ptr[r] + (old >= 0 ? Mrows.ptr[old + 1] - Mrows.ptr[old] : 0);
-    }
-    std::vector<int> idx((size_t)ptr[np]);
-    std::vector<double> val((size_t)ptr[np]);
+        return old >= 0 ? Mrows.ptr[old + 1] - Mrows.ptr[old] : 0;
+    });
     parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
         std::vector<std::pair<int, double>> row;
         for (int r = lo; r < hi; ++r) {
@@ -352,12 +414,38 @@ inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering
             row.clear();
             for (int p = Mrows.ptr[old]; p < Mrows.ptr[old + 1]; ++p)
                 row.emplace_back(ocol.old2new[Mrows.idx[p]], Mrows.val[p]);
-            std::sort(row.begin(), row.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
-            int64_t q = ptr[r];
-            for (auto& e : row) { idx[q] = e.first; val[q] = e.second; ++q; }
+            sort_row(row);
+            int64_t q = st.ptr[r];
+            for (auto& e : row) { st.idx[q] = e.first; st.val[q] = e.second; ++q; }
         }
     });
-    return csr_to_sell(np, ocol.n_pad, ptr, idx, val, sort_sigma);
+    return csr_to_sell(np, ocol.n_pad, st, sort_sigma);
+}
+
+// Rows of U (fine-row major) from its CSC storage, threaded: per-row counts with atomics, prefix sum, scatter.
+// Entry order inside a row is arbitrary (the builders above sort every row by device column anyway).
+inline Compressed transpose_parallel(const Compressed& a) {
+    Compressed t;
+    t.n_outer = a.n_inner; t.n_inner = a.n_outer;
+    const int nnz = a.nnz();
+    std::unique_ptr<std::atomic<int>[]> cnt(new std::atomic<int>[(size_t)a.n_inner + 1]);
+    parallel_ranges(a.n_inner + 1, hw_threads(), [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) cnt[i].store(0, std::memory_order_relaxed); });
+    parallel_ranges(a.n_outer, hw_threads(), [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j)
+            for (int p = a.ptr[j]; p < a.ptr[j + 1]; ++p) cnt[a.idx[p]].fetch_add(1, std::memory_order_relaxed);
+    });
+    t.ptr.assign((size_t)a.n_inner + 1, 0);
+    for (int i = 0; i < a.n_inner; ++i) t.ptr[i + 1] = t.ptr[i] + cnt[i].load(std::memory_order_relaxed);
+    parallel_ranges(a.n_inner, hw_threads(), [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) cnt[i].store(t.ptr[i], std::memory_order_relaxed); });
+    t.idx.resize(nnz); t.val.resize(nnz);
+    parallel_ranges(a.n_outer, hw_threads(), [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j)
+            for (int p = a.ptr[j]; p < a.ptr[j + 1]; ++p) {
+                int q = cnt[a.idx[p]].fetch_add(1, std::memory_order_relaxed);
+                t.idx[q] = j; t.val[q] = a.val[p];
+            }
+    });
+    return t;
 }
 
 }  // namespace gmg

@@ -33,7 +33,7 @@ struct Compressed {
 inline int hw_threads() {
     unsigned t = std::thread::hardware_concurrency();
     if (t == 0) t = 1;
-    return (int)std::min(t, 64u);
+    return (int)std::min(t, 128u);
 }
 
 template <class F>

@@ -12,8 +12,29 @@ Differences a user can observe, all deliberate (SURVEY.md A
 import numpy as np
 from scipy.sparse import csr_matrix
 
-import gravomg_bindings
-from gravomg_bindings import Hierarchy, Sampling, Weighting
+def _preload_torch_hip_runtime():
+    # torch-ROCm wheels bundle libamdhip64 / libhsa-runtime64 with the system SONAMEs; whichever copy loads first serves
+    # the whole process and torch fails if it is not its own.  Make torch's copy (if torch is installed) the one in use.
+    import ctypes, importlib.util, os
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
+_preload_torch_hip_runtime()
+
+import gravomg_bindings  # noqa: E402
+from gravomg_bindings import Hierarchy, Sampling, Weighting  # noqa: E402
 
 
 class MultigridSolver(object):
