@@ -30,23 +30,49 @@ __device__ __forceinline__ int wave_slice(int n_slices_total, int xcd_swizzle) {
     return __builtin_amdgcn_readfirstlane(w);
 }
 
-// acc[c] = sum_j val[j] * x[col[j] + c*ld] over this lane's row of slice s.
-template <int D>
+// W entries of this lane's row, all loads issued before the first use: W column loads + W value loads in flight,
+// then W*D gathers in flight, then the FMAs in stored order (the accumulation order is that of a plain loop).
+template <int D, int W>
+__device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const double* __restrict__ vp, const double* x, int ld,
+                                              double (&acc)[D]) {
+    int c[W];
+    double v[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { c[j] = cp[j * 64]; v[j] = vp[j * 64]; }
+    double xv[W][D];
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[j][d] = x[c[j] + (int64_t)d * ld];
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] += v[j] * xv[j][d];
+}
+
+// acc[c] = sum_j val[j] * x[col[j] + c*ld] over this lane's row of slice s.  The slice width is wave-uniform, so
+// the dispatch on it is a scalar branch: full groups of 8, then one width-specialised tail (no serialized
+// remainder loop -- with 6-7 entries per mesh row and 3 per prolongation row the tail IS the row).
+template <int D, int G = 8>
 __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                         const double* __restrict__ val, const double* x, int ld, int s, int lane,
                                         double (&acc)[D]) {
     const int64_t p0 = slice_ptr[s];
-    const int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+    int w = (int)((slice_ptr[s + 1] - p0) >> 6);
     const int* cp = col + p0 + lane;
     const double* vp = val + p0 + lane;
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
-#pragma unroll 4
-    for (int j = 0; j < w; ++j) {
-        const int cj = cp[(int64_t)j * 64];
-        const double vj = vp[(int64_t)j * 64];
-#pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] += vj * x[cj + (int64_t)c * ld];
+    for (; w >= G; w -= G, cp += G * 64, vp += G * 64) row_dot_group<D, G>(cp, vp, x, ld, acc);
+    switch (w) {                                                   // w < G here
+        case 1: row_dot_group<D, 1>(cp, vp, x, ld, acc); break;
+        case 2: row_dot_group<D, 2>(cp, vp, x, ld, acc); break;
+        case 3: row_dot_group<D, 3>(cp, vp, x, ld, acc); break;
+        case 4: if (G > 4) row_dot_group<D, 4>(cp, vp, x, ld, acc); break;
+        case 5: if (G > 4) row_dot_group<D, 5>(cp, vp, x, ld, acc); break;
+        case 6: if (G > 4) row_dot_group<D, 6>(cp, vp, x, ld, acc); break;
+        case 7: if (G > 4) row_dot_group<D, 7>(cp, vp, x, ld, acc); break;
+        default: break;
     }
 }
 
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
                     }
             }
         double acc[D];
-        row_dot<D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+        row_dot<D, (D == 1 ? 8 : 4)>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
 #pragma unroll
         for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
         dg = 1.0 / diag[row];      // reciprocal once, outside the sequential colour loop
