@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--block-rows", type=int, default=None, help="block-hybrid GS rows per block (engine default if unset)")
     ap.add_argument("--block-from-level", type=int, default=None)
+    ap.add_argument("--block-lanes", type=int, default=None)
     ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
@@ -116,6 +117,8 @@ def main():
         kw["block_rows"] = args.block_rows
     if args.block_from_level is not None:
         kw["block_from_level"] = args.block_from_level
+    if args.block_lanes is not None:
+        kw["block_lanes"] = args.block_lanes
     eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT,
                       use_graph=not args.no_graph, **kw)
     eng.use_hierarchy(H)

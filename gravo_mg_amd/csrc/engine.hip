@@ -33,6 +33,7 @@ namespace {
 
 struct DevSell {
     int n_slices = 0;
+    int lpr = 1;                  // lanes per row of the SELL layout (1 or 4)
     int64_t stored = 0, nnz_real = 0;
     int64_t* slice_ptr = nullptr;
     int* col = nullptr;
@@ -142,7 +143,7 @@ void free_sell(DevSell& s) {
 
 int upload_sell(gmg_handle h, DevSell& d, const SellHost& s) {
     free_sell(d);
-    d.n_slices = s.n_slices; d.stored = s.stored(); d.nnz_real = s.nnz_real;
+    d.n_slices = s.n_slices; d.stored = s.stored(); d.nnz_real = s.nnz_real; d.lpr = s.lpr;
     int rc;
     if ((rc = upload(h, &d.slice_ptr, s.slice_ptr))) return rc;
     if ((rc = upload(h, &d.col, s.col))) return rc;
@@ -185,6 +186,7 @@ void drop_system(gmg_handle h) {
     if (h->d_ainv) { (void)hipFree(h->d_ainv); h->d_ainv = nullptr; }
 }
 
+constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
 constexpr int kNormBlocks = 2048;      // residual-norm partial sums: 8 blocks per CU, grid-stride
 
 inline int grid_for(int n_slices) {
@@ -247,10 +249,17 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
     for (int it = 0; it < iters; ++it) {
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                              l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
-                                              l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
-                                              out + (size_t)c0 * ld, ld));
+            if (l.Ain.lpr == 4) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
+                                                  l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                                  out + (size_t)c0 * ld, ld));
+            } else {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
+                                                  l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                                  out + (size_t)c0 * ld, ld));
+            }
         }
         std::swap(in, out);
     }
@@ -265,37 +274,47 @@ void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
 }
 
 // y = A x (mode 0) or y = b - A x (mode 1)
-void launch_spmv(gmg_handle h, Level& l, int d, int mode, const double* b, const double* x, double* y) {
+template <int LPR>
+void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const double* b, const double* x, double* y) {
     const int ld = l.n_pad;
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         if (mode == 1) {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, b + (size_t)c0 * ld, x + (size_t)c0 * ld,
                                               y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
         } else {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 0>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 0, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, (const double*)nullptr, x + (size_t)c0 * ld,
                                               y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
         }
     }
 }
+void launch_spmv(gmg_handle h, Level& l, int d, int mode, const double* b, const double* x, double* y) {
+    if (l.Aoff.lpr == 4) launch_spmv_lpr<4>(h, l, d, mode, b, x, y);
+    else launch_spmv_lpr<1>(h, l, d, mode, b, x, y);
+}
 
 // coarse.b = U^T fine.r
-void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
+template <int LPR>
+void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 0>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 0, LPR>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                           fine.R.slice_ptr, fine.R.col, fine.R.val, fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
                                           dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1));
     }
 }
+void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
+    if (fine.R.lpr == 4) launch_restrict_lpr<4>(h, fine, coarse, d, src, dst);
+    else launch_restrict_lpr<1>(h, fine, coarse, d, src, dst);
+}
 
-// fine.x += U coarse.x
+// fine.x += U coarse.x   (U has <= 3 entries per row: always one lane per row)
 void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                           fine.P.slice_ptr, fine.P.col, fine.P.val, (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
                                           coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1));
     }
@@ -509,8 +528,9 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->use_graph = 1;
     cfg->sigma = 1024;
     cfg->row_align = 64;
-    cfg->block_rows = 256;
+    cfg->block_rows = 64;
     cfg->block_from_level = 1;
+    cfg->block_lanes = 0;
     cfg->host_threads = 0;
     cfg->verbose = 0;
     return GMG_OK;
@@ -527,7 +547,8 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0) return GMG_ERR_INVALID;
+        c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 ||
+        (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
     if (h->cfg.host_threads <= 0) h->cfg.host_threads = hw_threads();
@@ -656,7 +677,12 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if (k == L) break;
         SellHost sa; std::vector<double> dg; std::string e;
         auto ta = clk::now();
-        if (!build_operator_sell(l.A, l.ord, 0, sa, dg, e)) return fail(h, GMG_ERR_NUMERIC, "level " + std::to_string(k) + ": " + e);
+        // lanes per row on a blocked level: the quad layout pays where the level is latency-bound (few wavefronts);
+        // a big level is throughput-bound and keeps one lane per row (single-wave blocks, no cross-wave barriers)
+        const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
+        // (level 0 always keeps one lane per row: the residual-norm kernels read its operator in that layout)
+        const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
+        if (!build_operator_sell(l.A, l.ord, lpr, sa, dg, e)) return fail(h, GMG_ERR_NUMERIC, "level " + std::to_string(k) + ": " + e);
         lap("setup_sell_A", ta);
         lap("setup_sell", tl);
         if ((rc = upload_sell(h, l.Aoff, sa))) return rc;
@@ -665,7 +691,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         SellHost sin, sout;
         std::vector<unsigned short> c16;
         if (l.ord.blocked) {
-            build_operator_sell_split(l.A, l.ord, sin, sout);
+            build_operator_sell_split(l.A, l.ord, sin, sout, lpr);
             c16.resize(sin.col.size());
             parallel_ranges((int)sin.col.size(), h->cfg.host_threads, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) c16[i] = (unsigned short)sin.col[i]; });
             lap("setup_sell", tl);
@@ -682,7 +708,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         lap("setup_transpose", tt);
         SellHost sp = build_transfer_sell(Urows, l.ord, h->lv[k + 1].ord, 0);
         lap("setup_sell_P", tt);
-        SellHost sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, l.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0);   // outer = coarse rows
+        SellHost sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, l.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0, h->cfg.block_lanes == 1 ? 1 : 4);   // outer = coarse rows (~18 entries each)
         lap("setup_sell_R", tt);
         lap("setup_sell", tl);
         if ((rc = upload_sell(h, l.P, sp))) return rc;
@@ -1046,7 +1072,7 @@ int gmg_dist_residual_own(gmg_handle h) {
         if (se <= sb) continue;
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                               l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, l.r + (size_t)c0 * ld, ld,
                                               sb, se, 1));
         }
@@ -1082,7 +1108,7 @@ int gmg_dist_prolong_own(gmg_handle h) {
         if (se <= sb) continue;
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.P.slice_ptr, l.P.col,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.P.slice_ptr, l.P.col,
                                               l.P.val, (const int*)nullptr, cl.x + (size_t)c0 * cl.n_pad, cl.n_pad, l.x + (size_t)c0 * l.n_pad, l.n_pad,
                                               sb, se, 1));
         }

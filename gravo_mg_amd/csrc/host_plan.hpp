@@ -88,6 +88,7 @@ struct SellHost {
     int n_rows_pad = 0;               // rows covered by slices (multiple of 64)
     int n_cols = 0;
     int n_slices = 0;
+    int lpr = 1;                      // lanes per row: 1 (64 rows per slice) or 4 (16 rows per slice)
     int64_t nnz_real = 0;
     std::vector<int64_t> slice_ptr;   // n_slices + 1, element offsets (multiples of 64)
     RawVec<int> col;
@@ -264,11 +265,15 @@ inline void stage_lengths(int np, RowStage& st, LenFn&& len_of) {
 }
 
 // Staged rows -> SELL-64.  If sort_sigma > 0 the rows are re-sorted by length inside windows and row_of records
-// the output row.
-inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const RowStage& st, int sort_sigma) {
+// the output row.  lpr = lanes per row: 1 (one row per lane, 64 rows per slice) or 4 ("quad" layout for the
+// latency-bound coarse levels: 16 rows per slice, entry e of a row goes to sub-lane e % 4 at depth e / 4, the
+// kernel adds the four partial sums with two cross-lane steps -> 4x shorter dependency chains, 4x more waves).
+inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const RowStage& st, int sort_sigma, int lpr = 1) {
     const std::vector<int64_t>& ptr = st.ptr;
+    const int rps = kSlice / lpr;                 // rows per slice
     SellHost s;
-    s.n_rows_pad = n_rows_pad; s.n_cols = n_cols; s.n_slices = n_rows_pad / kSlice;
+    s.lpr = lpr;
+    s.n_rows_pad = n_rows_pad; s.n_cols = n_cols; s.n_slices = n_rows_pad / rps;
     s.nnz_real = ptr[n_rows_pad];
     std::vector<int> order;
     const bool sorted = sort_sigma > 0;
@@ -289,7 +294,7 @@ inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const RowStage& st, int 
     parallel_ranges(s.n_slices, hw_threads(), [&](int lo, int hi, int) {
         for (int sl = lo; sl < hi; ++sl) {
             int64_t w = 0;
-            for (int l = 0; l < kSlice; ++l) { int r = row_at(sl * kSlice + l); w = std::max<int64_t>(w, ptr[r + 1] - ptr[r]); }
+            for (int l = 0; l < rps; ++l) { int r = row_at(sl * rps + l); w = std::max<int64_t>(w, (ptr[r + 1] - ptr[r] + lpr - 1) / lpr); }
             s.slice_ptr[sl + 1] = w * kSlice;
         }
     });
@@ -300,11 +305,14 @@ inline SellHost csr_to_sell(int n_rows_pad, int n_cols, const RowStage& st, int 
         for (int sl = lo; sl < hi; ++sl) {
             const int64_t base = s.slice_ptr[sl];
             const int64_t w = (s.slice_ptr[sl + 1] - base) / kSlice;
-            for (int l = 0; l < kSlice; ++l) {
-                const int r = row_at(sl * kSlice + l);
+            for (int l = 0; l < rps; ++l) {
+                const int r = row_at(sl * rps + l);
                 const int64_t len = ptr[r + 1] - ptr[r], p0 = ptr[r];
-                for (int64_t j = 0; j < len; ++j) { s.col[base + j * kSlice + l] = st.idx[p0 + j]; s.val[base + j * kSlice + l] = st.val[p0 + j]; }
-                for (int64_t j = len; j < w; ++j) { s.col[base + j * kSlice + l] = 0; s.val[base + j * kSlice + l] = 0.0; }   // padding: 0 * x[0]
+                for (int64_t e = 0; e < w * lpr; ++e) {
+                    const int64_t q = base + (e / lpr) * kSlice + l * lpr + (e % lpr);
+                    if (e < len) { s.col[q] = st.idx[p0 + e]; s.val[q] = st.val[p0 + e]; }
+                    else { s.col[q] = 0; s.val[q] = 0.0; }                     // padding: 0 * x[0]
+                }
             }
         }
     });
@@ -317,9 +325,9 @@ inline void sort_row(std::vector<std::pair<int, double>>& row) {
 
 // A (symmetric, natural numbering) -> off-diagonal SELL + diagonal, in the level's device numbering.
 // Returns false (and sets err) if a real row has no / a zero diagonal entry.
-inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int sigma_unused, SellHost& out,
+inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int lpr, SellHost& out,
                                 std::vector<double>& diag, std::string& err) {
-    (void)sigma_unused;
+    if (lpr != 4) lpr = 1;
     const int np = o.n_pad;
     diag.assign(np, 1.0);
     std::atomic<int> bad_row{-1};
@@ -350,14 +358,14 @@ inline bool build_operator_sell(const Compressed& A, const LevelOrdering& o, int
             for (auto& e : row) { st.idx[q] = e.first; st.val[q] = e.second; ++q; }
         }
     });
-    out = csr_to_sell(np, np, st, 0);
+    out = csr_to_sell(np, np, st, 0, lpr);
     return true;
 }
 
 // Blocked level: split the off-diagonal part of A into the entries that stay inside the row's block
 // (`in`: column = device row MINUS the block's first row, < 65536, for the LDS-resident sweep) and the
 // entries that leave it (`out`: device column; applied to the previous iterate, Jacobi-style).
-inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& o, SellHost& in, SellHost& out) {
+inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& o, SellHost& in, SellHost& out, int lpr = 1) {
     const int np = o.n_pad;
     std::vector<int> blk_of_row(np, 0);
     for (int b = 0; b < o.n_blocks(); ++b)
@@ -392,14 +400,14 @@ inline void build_operator_sell_split(const Compressed& A, const LevelOrdering& 
             }
         }
     });
-    in = csr_to_sell(np, np, sin, 0);
-    out = csr_to_sell(np, np, sout, 0);
+    in = csr_to_sell(np, np, sin, 0, lpr);
+    out = csr_to_sell(np, np, sout, 0, lpr);
 }
 
 // Generic: rows of `Mrows` (compressed, outer = rows in natural numbering of the row space) mapped into
 // device numbering of the row space (orow) and column space (ocol).
 inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering& orow, const LevelOrdering& ocol,
-                                    int sort_sigma) {
+                                    int sort_sigma, int lpr = 1) {
     const int np = orow.n_pad;
     RowStage st;
     stage_lengths(np, st, [&](int r) -> int64_t {
@@ -419,7 +427,7 @@ inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering
             for (auto& e : row) { st.idx[q] = e.first; st.val[q] = e.second; ++q; }
         }
     });
-    return csr_to_sell(np, ocol.n_pad, st, sort_sigma);
+    return csr_to_sell(np, ocol.n_pad, st, sort_sigma, lpr);
 }
 
 // Rows of U (fine-row major) from its CSC storage, threaded: per-row counts with atomics, prefix sum, scatter.

@@ -38,7 +38,7 @@ __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const 
     int c[W];
     double v[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) { c[j] = cp[j * 64]; v[j] = vp[j * 64]; }
+    for (int j = 0; j < W; ++j) { c[j] = __builtin_nontemporal_load(cp + j * 64); v[j] = __builtin_nontemporal_load(vp + j * 64); }
     double xv[W][D];
 #pragma unroll
     for (int j = 0; j < W; ++j)
@@ -73,6 +73,16 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
         case 6: if (G > 4) row_dot_group<D, 6>(cp, vp, x, ld, acc); break;
         case 7: if (G > 4) row_dot_group<D, 7>(cp, vp, x, ld, acc); break;
         default: break;
+    }
+}
+
+// Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
+template <int D>
+__device__ __forceinline__ void quad_reduce(double (&acc)[D]) {
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        acc[c] += __shfl_xor(acc[c], 1, 64);
+        acc[c] += __shfl_xor(acc[c], 2, 64);
     }
 }
 
@@ -204,6 +214,100 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     }
 }
 
+// The same sweep on the QUAD layout (4 lanes per row; blocks of <= 256 rows = 1024 threads).  A colour step is the
+// critical path of the coarse levels -- 13-16 of them run back to back with one or two wavefronts active -- so the
+// row is spread over four lanes: each lane keeps <= WQ in-block entries in registers, gathers them from LDS in one
+// batch, and the quad adds its four partial sums with two cross-lane steps.  Same mathematics as gs_block.
+constexpr int kQuadBlockRows = 256;
+template <int D, int WQ>
+__global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
+                                                        const unsigned char* __restrict__ row_color,
+                                                        const int64_t* __restrict__ in_ptr, const unsigned short* __restrict__ in_col,
+                                                        const double* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
+                                                        const int* __restrict__ out_col, const double* __restrict__ out_val,
+                                                        const double* __restrict__ diag, const double* __restrict__ b,
+                                                        const double* __restrict__ x_in, double* __restrict__ x_out, int ld) {
+    __shared__ double xs[D][kQuadBlockRows];
+    const int blk = blockIdx.x;
+    const int r0 = blk_begin[blk];
+    const int nrows = blk_begin[blk + 1] - r0;            // multiple of 64, <= 256
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool active = wave * 16 < nrows;                 // wave-uniform: a wave covers 16 rows
+    const int lrow = t >> 2;
+    const int row = r0 + lrow;
+    const bool writer = (t & 3) == 0;
+    double rhs[D], dg = 1.0;
+    int mycolor = -1, w = 0;
+    int64_t p0 = 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) rhs[c] = 0.0;
+    double v[WQ];
+    unsigned cpk[WQ / 2];
+#pragma unroll
+    for (int j = 0; j < WQ; ++j) v[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < WQ / 2; ++j) cpk[j] = 0u;
+    if (active) {
+        const int s = (r0 >> 4) + wave;
+        if (writer) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) xs[c][lrow] = x_in[row + (int64_t)c * ld];
+        }
+        p0 = in_ptr[s];
+        w = (int)((in_ptr[s + 1] - p0) >> 6);
+#pragma unroll
+        for (int j = 0; j < WQ; ++j)
+            if (j < w) {
+                v[j] = __builtin_nontemporal_load(in_val + p0 + (int64_t)j * 64 + lane);
+                cpk[j >> 1] |= (unsigned)__builtin_nontemporal_load(in_col + p0 + (int64_t)j * 64 + lane) << ((j & 1) * 16);
+            }
+        double acc[D];
+        row_dot<D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+        quad_reduce<D>(acc);
+#pragma unroll
+        for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
+        dg = 1.0 / diag[row];
+        mycolor = row_color[row];
+    }
+    __syncthreads();
+    const int nc = blk_ncolors[blk];
+    for (int col = 0; col < nc; ++col) {
+        if (mycolor == col) {
+            double s_[D];
+            double xv[WQ][D];
+#pragma unroll
+            for (int j = 0; j < WQ; ++j) {
+                const int cj = (cpk[j >> 1] >> ((j & 1) * 16)) & 0xffff;
+#pragma unroll
+                for (int c = 0; c < D; ++c) xv[j][c] = xs[c][cj];
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] = 0.0;
+#pragma unroll
+            for (int j = 0; j < WQ; ++j)
+#pragma unroll
+                for (int c = 0; c < D; ++c) s_[c] += v[j] * xv[j][c];
+            for (int j = WQ; j < w; ++j) {                  // rows with more than 4*WQ in-block entries (rare)
+                const double vj = in_val[p0 + (int64_t)j * 64 + lane];
+                const int cj = in_col[p0 + (int64_t)j * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < D; ++c) s_[c] += vj * xs[c][cj];
+            }
+            quad_reduce<D>(s_);
+            if (writer) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) xs[c][lrow] = (rhs[c] - s_[c]) * dg;
+            }
+        }
+        __syncthreads();
+    }
+    if (active && writer) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c][lrow];
+    }
+}
+
 // Weighted Jacobi sweep: x_out = x_in + omega * (b - A x_in) / diag.
 template <int D>
 __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
@@ -226,7 +330,8 @@ __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict
 }
 
 // MODE 0: y = A x      MODE 1: y = b - A x   (gravomg/src/multigrid_solver.cpp:1066)
-template <int D, int MODE>
+// LPR = lanes per row of the SELL layout (1, or 4 on the coarse levels): slices then hold 64 / LPR rows.
+template <int D, int MODE, int LPR>
 __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                     const double* __restrict__ val, const double* __restrict__ diag,
                                                     const double* __restrict__ b, const double* __restrict__ x,
@@ -235,9 +340,10 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
-    const int row = s * 64 + lane;
+    const int row = s * (64 / LPR) + lane / LPR;
     double acc[D];
     row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    if (LPR == 4) { quad_reduce<D>(acc); if (lane & 3) return; }
     const double dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -249,8 +355,8 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
 // Transfer operators.  ADD = 0: y[out_row] = sum val * x[col]   (restriction rc = U^T r, :1069)
 //                       ADD = 1: y[out_row] += sum val * x[col]  (prolongation x += U e, :1082)
 // row_of (may be null) maps the slice row to the output row (-1 = none); ldx/ldy are the leading
-// dimensions of the source / destination level.
-template <int D, int ADD>
+// dimensions of the source / destination level.  LPR as in spmv_full.
+template <int D, int ADD, int LPR>
 __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const double* __restrict__ val, const int* __restrict__ row_of,
                                                    const double* __restrict__ x, int ldx, double* __restrict__ y, int ldy,
@@ -260,7 +366,9 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
     const int lane = threadIdx.x & 63;
     double acc[D];
     row_dot<D>(slice_ptr, col, val, x, ldx, s, lane, acc);
-    const int row = row_of ? row_of[s * 64 + lane] : s * 64 + lane;
+    if (LPR == 4) { quad_reduce<D>(acc); if (lane & 3) return; }
+    const int srow = s * (64 / LPR) + lane / LPR;
+    const int row = row_of ? row_of[srow] : srow;
     if (row < 0) return;
 #pragma unroll
     for (int c = 0; c < D; ++c) {

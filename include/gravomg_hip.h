@@ -56,7 +56,11 @@ typedef struct {
     int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs (default 1) */
     int sigma;             /* SELL sorting window in rows (multiple of 64; 0 = no sorting; default 1024) */
     int row_align;         /* colour classes padded to this many rows (multiple of 64; default 64) */
-    int block_rows;        /* block-hybrid Gauss-Seidel: rows per block (multiple of 64, <= 1024; 0 = off; default 256) */
+    int block_rows;        /* block-hybrid Gauss-Seidel: rows per block (multiple of 64, <= 1024, <= 256 unless
+                              block_lanes = 1; 0 = off; default 64 = one wavefront per block) */
+    int block_lanes;       /* SELL lanes per row on the blocked levels and in the restriction: 1, 4 ("quad" layout: 16 rows
+                              per wavefront) or 0 = automatic (default): 4 on levels with < 262144 rows (latency-bound),
+                              1 on larger ones (throughput-bound) */
     int block_from_level;  /* levels >= this use the block-hybrid sweep (one launch per sweep); default 1:
                               level 0 keeps the exact multicolour sweep, the launch-bound coarse levels are blocked */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */

@@ -227,12 +227,12 @@ def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
     assert dx2 <= 100 * tight
 
 
-@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "no_graph", "exact_gs", "blocked_all", "small_blocks"])
+@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "no_graph", "exact_gs", "blocked_all", "small_blocks", "lane_per_row_blocks"])
 def test_engine_variants(cabi, oracle, variant):
     P = problems.torus_problem(48, 40, "poisson", 60)
     kw = {"jacobi": dict(smoother=cabi.SMOOTHER_JACOBI), "device_coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
           "no_graph": dict(use_graph=False), "exact_gs": dict(block_rows=0), "blocked_all": dict(block_from_level=0),
-          "small_blocks": dict(block_rows=128)}[variant]
+          "small_blocks": dict(block_rows=128), "lane_per_row_blocks": dict(block_lanes=1, block_rows=1024)}[variant]
     eng = cabi.Engine(**kw)
     eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
     x, it, res, _ = eng.solve(P.rhs, tol=1e-6, max_iter=200)
@@ -241,7 +241,7 @@ def test_engine_variants(cabi, oracle, variant):
     ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(P.lhs)
     xr, itr, resr, _ = ref.solve(P.rhs, tol=1e-6, max_iter=200)
     assert rel(x, xr) <= 1e-5
-    if variant in ("exact_gs", "blocked_all", "small_blocks"):
+    if variant in ("exact_gs", "blocked_all", "small_blocks", "lane_per_row_blocks"):
         assert abs(it - itr) <= 2
     elif variant != "jacobi":
         assert it == itr
