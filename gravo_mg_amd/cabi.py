@@ -41,7 +41,7 @@ class GmgConfig(C.Structure):
         ("device", C.c_int), ("smoother", C.c_int), ("jacobi_omega", C.c_double), ("pre_iters", C.c_int),
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
-        ("host_threads", C.c_int),
+        ("device_setup", C.c_int), ("host_threads", C.c_int),
         ("verbose", C.c_int),
     ]
 
@@ -74,6 +74,8 @@ SIGNATURES = {
     "gmg_get_level_operator": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gmg_get_level_ordering": (C.c_int, [_vp, C.c_int, _ip, _ip]),
     "gmg_get_level_blocks": (C.c_int, [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
+    "gmg_debug_sell_info": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "gmg_debug_sell_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _dp, _ip, _dp]),
     "gmg_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_smooth": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int]),
     "gmg_residual": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
@@ -244,7 +246,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device=0, verbose=False):
+                 device_setup=True, device=0, verbose=False):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -252,6 +254,7 @@ class Engine:
         cfg.pre_iters, cfg.post_iters, cfg.coarse_mode = int(pre_iters), int(post_iters), int(coarse_mode)
         cfg.use_graph, cfg.sigma, cfg.row_align, cfg.verbose = int(bool(use_graph)), int(sigma), int(row_align), int(bool(verbose))
         cfg.block_rows, cfg.block_from_level, cfg.block_lanes = int(block_rows), int(block_from_level), int(block_lanes)
+        cfg.device_setup = int(bool(device_setup))
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -334,6 +337,18 @@ class Engine:
         bb = np.empty(nb.value + 1, np.int32); rc = np.empty(self.level_info(k)["n_pad"], np.uint8)
         self._chk(lib().gmg_get_level_blocks(self._h, k, C.byref(nb), _pi(bb), rc.ctypes.data_as(C.POINTER(C.c_ubyte))))
         return bb, rc
+
+    def debug_sell(self, k: int, which: int) -> dict:
+        """Device-resident SELL layout (0 A, 1 A_in, 2 A_out, 3 P, 4 R) copied back, for layout parity tests."""
+        info = (C.c_int64 * 4)()
+        self._chk(lib().gmg_debug_sell_info(self._h, int(k), int(which), info))
+        ns, lpr, stored, has_row_of = (int(v) for v in info)
+        sp_ = np.zeros(ns + 1, np.int64); col = np.zeros(stored, np.int32); val = np.zeros(stored)
+        row_of = np.zeros(ns * (64 // lpr), np.int32) if has_row_of else None
+        diag = np.zeros(self.level_info(k)["n_pad"]) if which == 0 else None
+        self._chk(lib().gmg_debug_sell_copy(self._h, int(k), int(which), sp_.ctypes.data_as(C.POINTER(C.c_int64)), _pi(col), _pd(val),
+                                            _pi(row_of) if has_row_of else None, _pd(diag) if diag is not None else None))
+        return {"n_slices": ns, "lpr": lpr, "slice_ptr": sp_, "col": col, "val": val, "row_of": row_of, "diag": diag}
 
     def timing(self, key: str) -> float:
         out = C.c_double()

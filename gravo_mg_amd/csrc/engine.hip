@@ -12,6 +12,8 @@
 
 #include <chrono>
 #include <cmath>
+#include <functional>
+#include <future>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -24,6 +26,7 @@
 #include "host_plan.hpp"
 #include "host_sparse.hpp"
 #include "kernels.hip.hpp"
+#include "setup_kernels.hip.hpp"
 
 using namespace gmg;
 using clk = std::chrono::steady_clock;
@@ -187,6 +190,149 @@ void drop_system(gmg_handle h) {
 }
 
 constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
+
+// ---- device-side layout construction (setup_kernels.hip.hpp) ------------------------------------------------
+struct DevCsr {
+    int n_outer = 0;
+    int *ptr = nullptr, *idx = nullptr;
+    double* val = nullptr;
+};
+
+void free_csr(DevCsr& m) {
+    if (m.ptr) (void)hipFree(m.ptr);
+    if (m.idx) (void)hipFree(m.idx);
+    if (m.val) (void)hipFree(m.val);
+    m = DevCsr();
+}
+
+int upload_csr(gmg_handle h, DevCsr& d, const Compressed& m) {
+    free_csr(d);
+    d.n_outer = m.n_outer;
+    int rc;
+    if ((rc = upload(h, &d.ptr, m.ptr)) || (rc = upload(h, &d.idx, m.idx)) || (rc = upload(h, &d.val, m.val))) return rc;
+    return GMG_OK;
+}
+
+template <class T>
+struct DevTmp {                       // scratch device array freed at scope exit
+    T* p = nullptr;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    int alloc(gmg_handle h, size_t n) { HIPCHK(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return GMG_OK; }
+};
+
+// Builds one SELL matrix on the device.  pbeg/pend/idx/val: source rows (natural numbering); f: row/column maps and
+// filter; d_order: optional slice-position -> device-row map (uploaded by the caller; also stored as row_of);
+// col16: write 16-bit columns into *col16_out (in-block part of a blocked level) instead of out.col.
+int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pend, const int* idx, const double* val, gmgs::RowFilter f,
+                      const int* d_order, int n_rows_pad, int lpr, unsigned short** col16_out, double* d_diag, int* d_err) {
+    free_sell(out);
+    const int rps = 64 / lpr;
+    out.lpr = lpr;
+    out.n_slices = n_rows_pad / rps;
+    DevTmp<int> len;
+    DevTmp<int64_t> widths;
+    int rc;
+    if ((rc = len.alloc(h, n_rows_pad)) || (rc = widths.alloc(h, out.n_slices))) return rc;
+    hipLaunchKernelGGL(gmgs::row_lengths, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, f, d_order, n_rows_pad, len.p, d_err);
+    hipLaunchKernelGGL(gmgs::slice_widths, dim3((out.n_slices + 255) / 256), dim3(256), 0, h->stream, len.p, lpr, out.n_slices, widths.p);
+    std::vector<int64_t> sp((size_t)out.n_slices + 1, 0);
+    HIPCHK(hipMemcpyAsync(sp.data() + 1, widths.p, sizeof(int64_t) * out.n_slices, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < out.n_slices; ++i) sp[i + 1] += sp[i];
+    out.stored = sp[out.n_slices];
+    if ((rc = upload(h, &out.slice_ptr, sp))) return rc;
+    HIPCHK(hipMalloc((void**)&out.val, std::max<int64_t>(out.stored, 1) * sizeof(double)));
+    if (col16_out) {
+        if (*col16_out) { (void)hipFree(*col16_out); *col16_out = nullptr; }
+        HIPCHK(hipMalloc((void**)col16_out, std::max<int64_t>(out.stored, 1) * sizeof(unsigned short)));
+        hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
+                           n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
+    } else {
+        HIPCHK(hipMalloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
+        hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
+                           out.slice_ptr, out.col, out.val, d_diag, d_err);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));      // sp (host) is read by the async upload
+    return GMG_OK;
+}
+
+// Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device.  Returns 1 when the
+// device builder cannot take the input (a row longer than gmgs::kMaxRow, a prolongation row with more than 3 entries):
+// the caller then falls back to the host planner.
+int device_layout_level(gmg_handle h, int k, int* d_err) {
+    const int L = h->L;
+    Level& l = h->lv[k];
+    int rc;
+    DevCsr dA;
+    DevTmp<int> d_old2new, d_blk_of_row;
+    if ((rc = upload_csr(h, dA, l.A))) return rc;
+    if ((rc = upload(h, &d_old2new.p, l.ord.old2new))) { free_csr(dA); return rc; }
+    gmgs::RowFilter f{l.d_new2old, d_old2new.p, nullptr, nullptr, 0, 1};
+    const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
+    const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
+    HIPCHK(hipMalloc((void**)&l.diag, sizeof(double) * l.n_pad));
+    if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) { free_csr(dA); return rc; }
+    l.Aoff.nnz_real = l.A.nnz() - l.n;
+    if (l.ord.blocked) {
+        std::vector<int> blk_of_row(l.n_pad, 0);
+        for (int b = 0; b < l.ord.n_blocks(); ++b)
+            for (int r = l.ord.blk_begin[b]; r < l.ord.blk_begin[b + 1]; ++r) blk_of_row[r] = b;
+        if ((rc = upload(h, &d_blk_of_row.p, blk_of_row)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
+            (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) { free_csr(dA); return rc; }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        gmgs::RowFilter fin{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
+        gmgs::RowFilter fout{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
+        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err)) ||
+            (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) { free_csr(dA); return rc; }
+    }
+    free_csr(dA);
+    if (k == L) return GMG_OK;
+    // ---- transfers k <-> k+1
+    Level& c = h->lv[k + 1];
+    DevCsr dU;
+    DevTmp<int> d_old2new_c, d_order, d_cnt, d_ecol, d_pbeg, d_pend;
+    DevTmp<double> d_eval;
+    if ((rc = upload_csr(h, dU, h->U[k])) || (rc = upload(h, &d_old2new_c.p, c.ord.old2new))) { free_csr(dU); return rc; }
+    // restriction: rows = coarse points (columns of the CSC U), sorted by length inside windows like the host planner
+    {
+        const Compressed& U = h->U[k];
+        const int np = c.n_pad, sigma = h->cfg.sigma;
+        std::vector<int> order(np);
+        auto len_of = [&](int r) { int old = c.ord.new2old[r]; return old >= 0 ? U.ptr[old + 1] - U.ptr[old] : 0; };
+        if (sigma > 0) {
+            const int nwin = (np + sigma - 1) / sigma;
+            parallel_ranges(nwin, h->cfg.host_threads, [&](int lo, int hi, int) {
+                for (int wi = lo; wi < hi; ++wi) {
+                    int w = wi * sigma, we = std::min(np, w + sigma);
+                    std::iota(order.begin() + w, order.begin() + we, w);
+                    std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) { return len_of(a) > len_of(b); });
+                }
+            });
+            if ((rc = upload(h, &d_order.p, order))) { free_csr(dU); return rc; }
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        gmgs::RowFilter fr{c.d_new2old, d_old2new.p, nullptr, nullptr, 0, 0};
+        const int lpr_r = h->cfg.block_lanes == 1 ? 1 : 4;
+        if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) { free_csr(dU); return rc; }
+        l.R.nnz_real = U.nnz();
+        if (sigma > 0) { l.R.row_of = d_order.p; d_order.p = nullptr; }     // the order array becomes the output-row map
+    }
+    // prolongation: rows = fine points; U is stored by coarse column, so first regroup it by fine row (<= 3 per row)
+    {
+        const int nf = l.n;
+        if ((rc = d_cnt.alloc(h, nf)) || (rc = d_ecol.alloc(h, (size_t)nf * 3)) || (rc = d_eval.alloc(h, (size_t)nf * 3)) || (rc = d_pbeg.alloc(h, nf)) ||
+            (rc = d_pend.alloc(h, nf))) { free_csr(dU); return rc; }
+        HIPCHK(hipMemsetAsync(d_cnt.p, 0, sizeof(int) * nf, h->stream));
+        hipLaunchKernelGGL(gmgs::ell3_from_csc, dim3((c.n + 255) / 256), dim3(256), 0, h->stream, dU.ptr, dU.idx, dU.val, c.n, d_cnt.p, d_ecol.p, d_eval.p, d_err);
+        hipLaunchKernelGGL(gmgs::ell3_ptr, dim3((nf + 255) / 256), dim3(256), 0, h->stream, d_cnt.p, nf, d_pbeg.p, d_pend.p);
+        gmgs::RowFilter fp{l.d_new2old, d_old2new_c.p, nullptr, nullptr, 0, 0};
+        if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, d_ecol.p, d_eval.p, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) { free_csr(dU); return rc; }
+        l.P.nnz_real = h->U[k].nnz();
+    }
+    free_csr(dU);
+    return GMG_OK;
+}
+
 constexpr int kNormBlocks = 2048;      // residual-norm partial sums: 8 blocks per CU, grid-stride
 
 inline int grid_for(int n_slices) {
@@ -531,6 +677,7 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->block_rows = 64;
     cfg->block_from_level = 1;
     cfg->block_lanes = 0;
+    cfg->device_setup = 1;
     cfg->host_threads = 0;
     cfg->verbose = 0;
     return GMG_OK;
@@ -633,89 +780,181 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     drop_system(h);
     const int L = h->L;
     h->lv.resize(L + 1);
-    // -- Galerkin products, multigrid_solver.cpp:1387-1392
-    auto t0 = clk::now();
-    h->lv[0].A.assign(n, n, colptr, rowidx, val);
-    for (int k = 1; k <= L; ++k) h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads);
-    h->timing["reduction"] = ms_since(t0);
-    // -- coarsest factorisation, :1401
-    t0 = clk::now();
-    if (!h->coarse.factor(h->lv[L].A)) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
-    h->coarse_work.assign(h->lv[L].A.n_outer, 0.0);
-    h->timing["coarsest_solve"] = ms_since(t0);
-    // -- device layout + upload
-    t0 = clk::now();
-    auto lap = [&](const char* key, clk::time_point& t) { h->timing[key] += ms_since(t); t = clk::now(); };
-    for (const char* key : {"setup_ordering", "setup_sell", "setup_h2d", "setup_transpose", "setup_sell_P", "setup_sell_R", "setup_sell_A"}) h->timing[key] = 0.0;
-    auto tl = clk::now();
+    // Host setup as a small task graph (everything below the RAP chain is independent per level):
+    //   main thread : A_1 .. A_L by Galerkin products (multigrid_solver.cpp:1387-1392)
+    //   per level k : device ordering of level k as soon as A_k exists, then its operator layout (SELL)
+    //   level L     : LDL^T factorisation of A_L (:1401) (+ dense inverse for GMG_COARSE_DEVICE_INVERSE)
+    //   per level k : transfer layouts P_k, R_k once the orderings of levels k and k+1 exist
+    // The uploads follow on the calling thread once their inputs are ready.
+    auto t_all = clk::now();
     const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
-    {
-        // the per-level orderings are independent of each other: one host thread per level
-        std::vector<std::thread> pool;
-        for (int k = 0; k <= L; ++k) {
-            Level& l = h->lv[k];
-            l.n = l.A.n_outer;
+    bool device_setup = h->cfg.device_setup != 0;
+    struct LevelStage {
+        SellHost sa, sin, sout, sp, sr;
+        std::vector<double> dg;
+        std::vector<unsigned short> c16;
+        std::string err;
+        bool ok = true;
+        double ms_order = 0, ms_sell = 0;
+    };
+    std::vector<LevelStage> stage(L + 1);
+    std::vector<std::shared_future<void>> ord_done(L + 1);
+    std::vector<std::future<void>> op_done(L), tr_done(L);
+    std::future<bool> factor_done;
+    std::vector<double> inv;        // dense A_L^{-1} (device coarse mode)
+    double ms_factor = 0;
+    h->lv[0].A.assign(n, n, colptr, rowidx, val);
+    std::function<void(int)> spawn_level_ops;
+    auto spawn_level = [&](int k) {
+        Level& l = h->lv[k];
+        l.n = l.A.n_outer;
+        ord_done[k] = std::async(std::launch::async, [&, k] {
+            auto t = clk::now();
+            Level& lk = h->lv[k];
             const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
-            pool.emplace_back([&l, k, L, blocked, mc, h] {
-                if (k == L) l.ord = identity_ordering(l.n);
-                else if (blocked) l.ord = make_block_ordering(l.A, h->cfg.block_rows);
-                else l.ord = make_ordering(l.A, mc, h->cfg.row_align, h->cfg.sigma);
+            if (k == L) lk.ord = identity_ordering(lk.n);
+            else if (blocked) lk.ord = make_block_ordering(lk.A, h->cfg.block_rows);
+            else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
+            lk.n_pad = lk.ord.n_pad;
+            stage[k].ms_order = ms_since(t);
+        }).share();
+        if (k == L || device_setup) return;
+        spawn_level_ops(k);
+    };
+    spawn_level_ops = [&](int k) {
+        op_done[k] = std::async(std::launch::async, [&, k] {
+            ord_done[k].wait();
+            auto t = clk::now();
+            Level& lk = h->lv[k];
+            LevelStage& st = stage[k];
+            // lanes per row on a blocked level: the quad layout pays where the level is latency-bound (few wavefronts);
+            // a big level is throughput-bound and keeps one lane per row (single-wave blocks, no cross-wave barriers).
+            // Level 0 always keeps one lane per row: the residual-norm kernels read its operator in that layout.
+            const int lanes_auto = lk.n < kQuadLevelRows ? 4 : 1;
+            const int lpr = (lk.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
+            if (lk.ord.n_colors > 255) { st.ok = false; st.err = "more than 255 colours"; return; }
+            if (!build_operator_sell(lk.A, lk.ord, lpr, st.sa, st.dg, st.err)) { st.ok = false; return; }
+            if (lk.ord.blocked) {
+                build_operator_sell_split(lk.A, lk.ord, st.sin, st.sout, lpr);
+                st.c16.resize(st.sin.col.size());
+                parallel_ranges((int)st.sin.col.size(), h->cfg.host_threads, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) st.c16[i] = (unsigned short)st.sin.col[i]; });
+            }
+            st.ms_sell += ms_since(t);
+        });
+    };
+    auto spawn_transfer = [&](int k) {
+        if (device_setup) return;
+        tr_done[k] = std::async(std::launch::async, [&, k] {
+            ord_done[k].wait();
+            ord_done[k + 1].wait();
+            auto t = clk::now();
+            Level& lk = h->lv[k];
+            Compressed Urows = transpose_parallel(h->U[k]);                            // outer = fine rows
+            stage[k].sp = build_transfer_sell(Urows, lk.ord, h->lv[k + 1].ord, 0);
+            stage[k].sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, lk.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0,
+                                              h->cfg.block_lanes == 1 ? 1 : 4);       // outer = coarse rows (~18 entries each)
+            stage[k].ms_sell += ms_since(t);
+        });
+    };
+    auto t0 = clk::now();
+    spawn_level(0);
+    for (int k = 1; k <= L; ++k) {
+        h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads);
+        spawn_level(k);
+        spawn_transfer(k - 1);
+    }
+    h->timing["reduction"] = ms_since(t0);
+    factor_done = std::async(std::launch::async, [&] {
+        auto t = clk::now();
+        bool ok = h->coarse.factor(h->lv[L].A);
+        if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
+            const int nl = h->lv[L].A.n_outer;
+            inv.resize((size_t)nl * nl);
+            parallel_ranges(nl, h->cfg.host_threads, [&](int lo, int hi, int) {
+                std::vector<double> e(nl, 0.0), w(nl);
+                for (int j = lo; j < hi; ++j) {
+                    e[j] = 1.0;
+                    h->coarse.solve(e.data(), inv.data() + (size_t)j * nl, w.data());
+                    e[j] = 0.0;
+                }
             });
         }
-        for (auto& th : pool) th.join();
+        ms_factor = ms_since(t);
+        return ok;
+    });
+    auto tl = clk::now();
+    double ms_h2d = 0;
+    int rc_all = GMG_OK;
+    std::string err_all;
+    if (device_setup) {
+        // -- layouts built on the device from the raw matrices + orderings (setup_kernels.hip.hpp)
+        DevTmp<int> d_err;
+        int herr = 0;
+        if ((rc_all = d_err.alloc(h, 1)) == GMG_OK) {
+            (void)hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream);
+            for (int k = 0; k <= L && rc_all == GMG_OK; ++k) {
+                ord_done[k].wait();
+                if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); break; }
+                rc_all = upload(h, &h->lv[k].d_new2old, h->lv[k].ord.new2old);
+            }
+            for (int k = 0; k < L && rc_all == GMG_OK; ++k) rc_all = device_layout_level(h, k, d_err.p);
+            if (rc_all == GMG_OK) {
+                (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+                (void)hipStreamSynchronize(h->stream);
+                if (herr == 2) { rc_all = GMG_ERR_NUMERIC; err_all = "system matrix has a missing or zero diagonal entry"; }
+                else if (herr != 0) {
+                    // rows too long for the device builder: redo the layout with the host planner
+                    device_setup = false;
+                    for (int k = 0; k <= L; ++k) { if (k < L) { spawn_level_ops(k); } }
+                    for (int k = 0; k < L; ++k) spawn_transfer(k);
+                }
+            }
+        }
+        ms_h2d = ms_since(tl);
     }
-    for (int k = 0; k <= L; ++k) {
-        Level& l = h->lv[k];
-        if (l.ord.n_colors > 255) return fail(h, GMG_ERR_UNSUPPORTED, "more than 255 colours on level " + std::to_string(k));
-        l.n_pad = l.ord.n_pad;
-    }
-    lap("setup_ordering", tl);
-    for (int k = 0; k <= L; ++k) {
+    // -- host-planned layouts: uploads in the order the stages complete (level 0 first: the largest, ready early)
+    for (int k = 0; k <= L && rc_all == GMG_OK && !device_setup; ++k) {
         Level& l = h->lv[k];
         int rc;
-        if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) return rc;
+        ord_done[k].wait();
+        auto tu = clk::now();
+        if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) { rc_all = rc; break; }
+        ms_h2d += ms_since(tu);
         if (k == L) break;
-        SellHost sa; std::vector<double> dg; std::string e;
-        auto ta = clk::now();
-        // lanes per row on a blocked level: the quad layout pays where the level is latency-bound (few wavefronts);
-        // a big level is throughput-bound and keeps one lane per row (single-wave blocks, no cross-wave barriers)
-        const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
-        // (level 0 always keeps one lane per row: the residual-norm kernels read its operator in that layout)
-        const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
-        if (!build_operator_sell(l.A, l.ord, lpr, sa, dg, e)) return fail(h, GMG_ERR_NUMERIC, "level " + std::to_string(k) + ": " + e);
-        lap("setup_sell_A", ta);
-        lap("setup_sell", tl);
-        if ((rc = upload_sell(h, l.Aoff, sa))) return rc;
-        if ((rc = upload(h, &l.diag, dg))) return rc;
-        lap("setup_h2d", tl);
-        SellHost sin, sout;
-        std::vector<unsigned short> c16;
+        op_done[k].get();
+        LevelStage& st = stage[k];
+        if (!st.ok) { rc_all = GMG_ERR_NUMERIC; err_all = "level " + std::to_string(k) + ": " + st.err; break; }
+        tu = clk::now();
+        if ((rc = upload_sell(h, l.Aoff, st.sa)) || (rc = upload(h, &l.diag, st.dg))) { rc_all = rc; break; }
         if (l.ord.blocked) {
-            build_operator_sell_split(l.A, l.ord, sin, sout, lpr);
-            c16.resize(sin.col.size());
-            parallel_ranges((int)sin.col.size(), h->cfg.host_threads, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) c16[i] = (unsigned short)sin.col[i]; });
-            lap("setup_sell", tl);
-            if ((rc = upload_sell(h, l.Ain, sin))) return rc;
-            if ((rc = upload_sell(h, l.Aout, sout))) return rc;
-            if ((rc = upload(h, &l.ain_col16, c16))) return rc;
-            if ((rc = upload(h, &l.d_blk_begin, l.ord.blk_begin))) return rc;
-            if ((rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors))) return rc;
-            if ((rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
-            lap("setup_h2d", tl);
+            if ((rc = upload_sell(h, l.Ain, st.sin)) || (rc = upload_sell(h, l.Aout, st.sout)) || (rc = upload(h, &l.ain_col16, st.c16)) ||
+                (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) || (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) ||
+                (rc = upload(h, &l.d_row_color, l.ord.row_color))) { rc_all = rc; break; }
         }
-        auto tt = clk::now();
-        Compressed Urows = transpose_parallel(h->U[k]);                            // outer = fine rows
-        lap("setup_transpose", tt);
-        SellHost sp = build_transfer_sell(Urows, l.ord, h->lv[k + 1].ord, 0);
-        lap("setup_sell_P", tt);
-        SellHost sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, l.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0, h->cfg.block_lanes == 1 ? 1 : 4);   // outer = coarse rows (~18 entries each)
-        lap("setup_sell_R", tt);
-        lap("setup_sell", tl);
-        if ((rc = upload_sell(h, l.P, sp))) return rc;
-        if ((rc = upload_sell(h, l.R, sr))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));      // host staging vectors die at scope end
-        lap("setup_h2d", tl);
+        ms_h2d += ms_since(tu);
     }
+    for (int k = 0; k < L && rc_all == GMG_OK && !device_setup; ++k) {
+        Level& l = h->lv[k];
+        int rc;
+        tr_done[k].get();
+        auto tu = clk::now();
+        if ((rc = upload_sell(h, l.P, stage[k].sp)) || (rc = upload_sell(h, l.R, stage[k].sr))) { rc_all = rc; break; }
+        ms_h2d += ms_since(tu);
+    }
+    {   // never leave with tasks still referencing this frame
+        for (int k = 0; k <= L; ++k) if (ord_done[k].valid()) ord_done[k].wait();
+        for (int k = 0; k < L; ++k) { if (op_done[k].valid()) op_done[k].wait(); if (tr_done[k].valid()) tr_done[k].wait(); }
+    }
+    const bool factor_ok = factor_done.get();
+    (void)hipStreamSynchronize(h->stream);      // staged host arrays die at scope end
+    if (rc_all != GMG_OK) return err_all.empty() ? rc_all : fail(h, rc_all, err_all);
+    if (!factor_ok) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
+    h->coarse_work.assign(h->lv[L].A.n_outer, 0.0);
+    h->timing["coarsest_solve"] = ms_factor;
+    h->timing["setup_ordering"] = 0.0; h->timing["setup_sell"] = 0.0;
+    for (int k = 0; k <= L; ++k) { h->timing["setup_ordering"] = std::max(h->timing["setup_ordering"], stage[k].ms_order); h->timing["setup_sell"] = std::max(h->timing["setup_sell"], stage[k].ms_sell); }
+    h->timing["setup_h2d"] = ms_h2d;
+    (void)tl;
     {
         int nblk = kNormBlocks;
         if (nblk > h->partial_blocks) {
@@ -725,17 +964,6 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         }
     }
     if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
-        // dense inverse of the coarsest operator, column by column through the host factor
-        const int nl = h->lv[L].n;
-        std::vector<double> inv((size_t)nl * nl);
-        parallel_ranges(nl, h->cfg.host_threads, [&](int lo, int hi, int) {
-            std::vector<double> e(nl, 0.0), w(nl);
-            for (int j = lo; j < hi; ++j) {
-                e[j] = 1.0;
-                h->coarse.solve(e.data(), inv.data() + (size_t)j * nl, w.data());
-                e[j] = 0.0;
-            }
-        });
         int rc;
         if ((rc = upload(h, &h->d_ainv, inv))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -748,7 +976,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
-    h->timing["upload"] = ms_since(t0);
+    h->timing["upload"] = ms_since(t_all) - h->timing["reduction"];      // everything of the setup that is not the RAP chain
     h->timing["coarse_host_ms"] = 0.0;
     return GMG_OK;
 }
@@ -784,7 +1012,9 @@ int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin) 
     if (rc) return rc;
     const LevelOrdering& o = h->lv[k].ord;
     if (new2old) std::memcpy(new2old, o.new2old.data(), sizeof(int) * o.n_pad);
-    if (color_begin) std::memcpy(color_begin, o.color_begin.data(), sizeof(int) * (o.n_colors + 1));
+    if (color_begin) {      // colour-major levels: n_colors + 1 entries; blocked levels: {0, n_pad} (one range)
+        for (int c = 0; c <= o.n_colors; ++c) color_begin[c] = c < (int)o.color_begin.size() ? o.color_begin[c] : o.n_pad;
+    }
     return GMG_OK;
 }
 
@@ -796,6 +1026,44 @@ int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, uns
     if (n_blocks) *n_blocks = o.blocked ? o.n_blocks() : 0;
     if (o.blocked && blk_begin) std::memcpy(blk_begin, o.blk_begin.data(), sizeof(int) * o.blk_begin.size());
     if (o.blocked && row_color) std::memcpy(row_color, o.row_color.data(), o.row_color.size());
+    return GMG_OK;
+}
+
+// Debug / test access to the device-resident layouts: which = 0 A (off-diagonal), 1 A_in, 2 A_out, 3 P (U), 4 R (U^T).
+static DevSell* pick_sell(gmg_handle h, int k, int which) {
+    Level& l = h->lv[k];
+    switch (which) { case 0: return &l.Aoff; case 1: return &l.Ain; case 2: return &l.Aout; case 3: return &l.P; case 4: return &l.R; default: return nullptr; }
+}
+
+int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    DevSell* s = pick_sell(h, k, which);
+    if (!s || !info) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    info[0] = s->n_slices; info[1] = s->lpr; info[2] = s->stored; info[3] = s->row_of ? 1 : 0;
+    return GMG_OK;
+}
+
+int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int* col, double* val, int* row_of, double* diag) {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    DevSell* s = pick_sell(h, k, which);
+    if (!s) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    Level& l = h->lv[k];
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (slice_ptr && s->slice_ptr) HIPCHK(hipMemcpy(slice_ptr, s->slice_ptr, sizeof(int64_t) * (s->n_slices + 1), hipMemcpyDeviceToHost));
+    if (val && s->val) HIPCHK(hipMemcpy(val, s->val, sizeof(double) * s->stored, hipMemcpyDeviceToHost));
+    if (col) {
+        if (which == 1 && l.ain_col16) {
+            std::vector<unsigned short> c16((size_t)s->stored);
+            HIPCHK(hipMemcpy(c16.data(), l.ain_col16, sizeof(unsigned short) * s->stored, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < s->stored; ++i) col[i] = c16[i];
+        } else if (s->col) HIPCHK(hipMemcpy(col, s->col, sizeof(int) * s->stored, hipMemcpyDeviceToHost));
+    }
+    if (row_of && s->row_of) HIPCHK(hipMemcpy(row_of, s->row_of, sizeof(int) * (size_t)s->n_slices * (64 / s->lpr), hipMemcpyDeviceToHost));
+    if (diag && which == 0 && l.diag) HIPCHK(hipMemcpy(diag, l.diag, sizeof(double) * l.n_pad, hipMemcpyDeviceToHost));
     return GMG_OK;
 }
 

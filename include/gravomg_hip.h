@@ -63,6 +63,8 @@ typedef struct {
                               1 on larger ones (throughput-bound) */
     int block_from_level;  /* levels >= this use the block-hybrid sweep (one launch per sweep); default 1:
                               level 0 keeps the exact multicolour sweep, the launch-bound coarse levels are blocked */
+    int device_setup;      /* 1 (default): build the SELL layouts on the GPU from the uploaded matrices + orderings;
+                              0: build them with the host planner (the specification the device builder is tested against) */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
 } gmg_config;
@@ -101,6 +103,11 @@ int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin);
 /* Blocked levels (block-hybrid Gauss-Seidel): *n_blocks (0 if the level is colour-major), blk_begin[n_blocks+1]
  * (device rows) and row_color[n_pad] (colour of a row inside its block).  Output pointers may be NULL. */
 int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, unsigned char* row_color);
+/* Test access to the device-resident SELL layouts of level k: which = 0 A (off-diagonal part), 1 A_in, 2 A_out,
+ * 3 P (U_k), 4 R (U_k^T).  info[0..3] = n_slices, lanes per row, stored entries, has row_of.  Copy-out pointers may be
+ * NULL; col receives 32-bit columns also for the 16-bit A_in; diag (which = 0 only) the level's diagonal. */
+int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info);
+int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int* col, double* val, int* row_of, double* diag);
 /* Named timers in ms, same keys as the reference's solverTiming (multigrid_solver.cpp:1394,1403,1445-1448):
  * "reduction", "coarsest_solve", "cycles", "solver_total", "iterations", "residue"; plus "upload",
  * "coarse_host_ms" (host back-substitutions inside the cycles). */
