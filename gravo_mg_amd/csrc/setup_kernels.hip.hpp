@@ -127,4 +127,100 @@ __global__ void ell3_ptr(const int* __restrict__ cnt, int n, int* __restrict__ p
     pend[i] = 3 * i + cnt[i];
 }
 
+// Sort the (<= 3) entries of every ELL-3 row by column (ell3_from_csc fills the slots in arbitrary order).
+__global__ void ell3_sort(const int* __restrict__ cnt, int n, int* __restrict__ ecol, double* __restrict__ eval) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int m = cnt[i] < 3 ? cnt[i] : 3;
+    int c[3]; double v[3];
+    for (int s = 0; s < 3; ++s) { c[s] = s < m ? ecol[3 * i + s] : 0x7fffffff; v[s] = s < m ? eval[3 * i + s] : 0.0; }
+#define GMG_CSWAP(a, b) if (c[a] > c[b]) { int tc = c[a]; c[a] = c[b]; c[b] = tc; double tv = v[a]; v[a] = v[b]; v[b] = tv; }
+    GMG_CSWAP(0, 1) GMG_CSWAP(1, 2) GMG_CSWAP(0, 1)
+#undef GMG_CSWAP
+    for (int s = 0; s < m; ++s) { ecol[3 * i + s] = c[s]; eval[3 * i + s] = v[s]; }
+}
+
+// Galerkin product Ac = U^T A U (gravomg/src/multigrid_solver.cpp:1387-1392), one wavefront (= one 64-thread block) per
+// coarse row p.  Inputs: A in compressed storage (symmetric: rows == columns), U by coarse column (its CSC storage) and
+// by fine row (ELL-3, sorted).  Step 1: the distinct output columns q of row p are collected in an LDS hash set (order
+// independent) and sorted.  Step 2 (PASS 1): every lane owns one output column and the whole wave walks the triples
+//     for i in column p of U (ascending) / for j in row i of A (as stored) / for c in row j of U (ascending)
+// in the SAME order as the host implementation (host_sparse.hpp::galerkin_rap), adding w = (u_ip a_ij) * u_jq to its
+// accumulator when q matches -- with separately rounded multiply and add, so the result is bitwise the host's.
+// PASS 0 only counts the distinct columns (row lengths for the prefix sum).
+constexpr int kRapSet = 256;      // hash-set capacity per coarse row (rows with more distinct columns -> host fallback)
+template <int PASS>
+__global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, const int* __restrict__ a_idx, const double* __restrict__ a_val,
+                                               const int* __restrict__ u_cptr, const int* __restrict__ u_ridx, const double* __restrict__ u_cval,
+                                               const int* __restrict__ ur_cnt, const int* __restrict__ ur_col, const double* __restrict__ ur_val,
+                                               int n_coarse, const int* __restrict__ c_ptr, int* __restrict__ c_cnt, int* __restrict__ c_idx,
+                                               double* __restrict__ c_val, int* __restrict__ err_flag) {
+#pragma clang fp contract(off)      // multiply and add rounded separately, like the host implementation (no FMA)
+    __shared__ int keys[kRapSet];
+    const int p = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (p >= n_coarse) return;
+    for (int s = lane; s < kRapSet; s += 64) keys[s] = 0x7fffffff;
+    __syncthreads();
+    const int ub = u_cptr[p], ue = u_cptr[p + 1];
+    // ---- step 1: set of distinct coarse columns
+    for (int t = ub + lane; t < ue; t += 64) {
+        const int i = u_ridx[t];
+        for (int b = a_ptr[i]; b < a_ptr[i + 1]; ++b) {
+            const int j = a_idx[b];
+            const int m = ur_cnt[j] < 3 ? ur_cnt[j] : 3;
+            for (int s = 0; s < m; ++s) {
+                const int q = ur_col[3 * j + s];
+                unsigned hsh = ((unsigned)q * 2654435761u) >> 24;
+                int probes = 0;
+                while (true) {
+                    const int old = atomicCAS(&keys[hsh], 0x7fffffff, q);
+                    if (old == 0x7fffffff || old == q) break;
+                    hsh = (hsh + 1) & (kRapSet - 1);
+                    if (++probes >= kRapSet) { atomicExch(err_flag, 4); break; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- bitonic sort of the 256 slots (empty = INT_MAX sorts to the end)
+    for (int k = 2; k <= kRapSet; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = lane; idx < kRapSet; idx += 64) {
+                const int partner = idx ^ j;
+                if (partner > idx) {
+                    const int a = keys[idx], b = keys[partner];
+                    const bool up = (idx & k) == 0;
+                    if ((a > b) == up) { keys[idx] = b; keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    int cnt = 0;
+    for (int s = lane; s < kRapSet; s += 64) cnt += keys[s] != 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (PASS == 0) {
+        if (lane == 0) c_cnt[p] = cnt;
+        return;
+    }
+    // ---- step 2: numeric, lane-owned output columns, triples walked in the host's order
+    const int out0 = c_ptr[p];
+    for (int base = 0; base < cnt; base += 64) {
+        const int mine = base + lane < cnt ? keys[base + lane] : -1;
+        double acc = 0.0;
+        for (int t = ub; t < ue; ++t) {
+            const int i = u_ridx[t];
+            const double uip = u_cval[t];
+            for (int b = a_ptr[i]; b < a_ptr[i + 1]; ++b) {
+                const int j = a_idx[b];
+                const double w = uip * a_val[b];
+                const int m = ur_cnt[j] < 3 ? ur_cnt[j] : 3;
+                for (int s = 0; s < m; ++s)
+                    if (ur_col[3 * j + s] == mine) acc = acc + w * ur_val[3 * j + s];
+            }
+        }
+        if (mine >= 0) { c_idx[out0 + base + lane] = mine; c_val[out0 + base + lane] = acc; }
+    }
+}
+
 }  // namespace gmgs

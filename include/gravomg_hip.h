@@ -65,6 +65,8 @@ typedef struct {
                               level 0 keeps the exact multicolour sweep, the launch-bound coarse levels are blocked */
     int device_setup;      /* 1 (default): build the SELL layouts on the GPU from the uploaded matrices + orderings;
                               0: build them with the host planner (the specification the device builder is tested against) */
+    int device_rap;        /* 1 (default): Galerkin products U^T A U on the GPU (bitwise equal to the host implementation, which
+                              remains the fallback and the specification); needs device_setup = 1 */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
 } gmg_config;

@@ -80,3 +80,25 @@ def test_long_rows_fall_back_to_the_host_planner(cabi):
         e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(lhs)
         e.load_problem(P.rhs, P.rhs)
     assert np.array_equal(dev.run_cycles(2, 2), host.run_cycles(2, 2))
+
+
+@pytest.mark.parametrize("case", ["torus-L3", "random-order", "pointcloud", "smoothing", "bilaplacian"])
+def test_device_galerkin_is_bitwise_the_host_galerkin(cabi, case):
+    """gmgs::rap_rows walks the (i, j, c) triples in the host implementation's order with separately rounded
+    multiply and add: A_k (k >= 1) must be bit-identical, pattern included (multigrid_solver.cpp:1387-1392)."""
+    P = {"torus-L3": lambda: problems.torus_problem(96, 80, "poisson", 30),
+         "random-order": lambda: problems.torus_problem(48, 40, "poisson", 40, order="random"),
+         "pointcloud": lambda: problems.pointcloud_problem(3000),
+         "smoothing": lambda: problems.torus_problem(64, 60, "smoothing", 60),
+         "bilaplacian": lambda: problems.torus_problem(48, 40, "bilaplacian", 40)}[case]()
+    engs = []
+    for dev in (True, False):
+        e = cabi.Engine(device_rap=dev)
+        e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
+        engs.append(e)
+    for k in range(1, engs[0].num_levels + 1):
+        a, b = engs[0].level_operator(k), engs[1].level_operator(k)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+        assert np.array_equal(a.data, b.data)
+        assert a.has_sorted_indices
+    assert engs[0].timing("reduction") > 0
