@@ -213,6 +213,19 @@ int upload_csr(gmg_handle h, DevCsr& d, const Compressed& m) {
     return GMG_OK;
 }
 
+int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const int* idx, const double* val) {
+    free_csr(d);
+    d.n_outer = n_outer;
+    const size_t nnz = (size_t)ptr[n_outer];
+    HIPCHK(hipMalloc((void**)&d.ptr, sizeof(int) * ((size_t)n_outer + 1)));
+    HIPCHK(hipMalloc((void**)&d.idx, sizeof(int) * std::max<size_t>(nnz, 1)));
+    HIPCHK(hipMalloc((void**)&d.val, sizeof(double) * std::max<size_t>(nnz, 1)));
+    HIPCHK(hipMemcpyAsync(d.ptr, ptr, sizeof(int) * ((size_t)n_outer + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d.idx, idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d.val, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
 template <class T>
 struct DevTmp {                       // scratch device array freed at scope exit
     T* p = nullptr;
@@ -813,14 +826,14 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
     if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
     h->mass.assign(mass_diag, mass_diag + n);
     if (h->has_device && h->system_ready) {
-        // re-upload in device numbering
+        // device numbering (padding rows get weight 1: they carry r = b = 0)
         Level& l = h->lv[0];
         if (l.n != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
-        std::vector<double> m(l.n_pad, 1.0), mi(l.n_pad, 1.0);
-        for (int r = 0; r < l.n_pad; ++r) if (l.ord.new2old[r] >= 0) { m[r] = h->mass[l.ord.new2old[r]]; mi[r] = 1.0 / m[r]; }
-        int rc;
-        if ((rc = upload(h, &h->d_mass, m))) return rc;
-        if ((rc = upload(h, &h->d_minv, mi))) return rc;
+        int rc = ensure_stage(h, (size_t)n);
+        if (rc) return rc;
+        for (double** p : {&h->d_mass, &h->d_minv}) if (!*p) HIPCHK(hipMalloc((void**)p, sizeof(double) * l.n_pad));
+        HIPCHK(hipMemcpyAsync(h->d_stage, h->mass.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(gmgk::permute_mass, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.d_new2old, l.n_pad, h->d_mass, h->d_minv);
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return GMG_OK;
@@ -846,6 +859,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     //   per level k : transfer layouts P_k, R_k once the orderings of levels k and k+1 exist
     // The uploads follow on the calling thread once their inputs are ready.
     auto t_all = clk::now();
+    h->timing["setup_wait_ordering"] = 0.0; h->timing["setup_device_layout"] = 0.0;
     const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
     bool device_setup = h->cfg.device_setup != 0;
     struct LevelStage {
@@ -862,17 +876,20 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     std::future<bool> factor_done;
     std::vector<double> inv;        // dense A_L^{-1} (device coarse mode)
     double ms_factor = 0;
-    h->lv[0].A.assign(n, n, colptr, rowidx, val);
+    // Host copy of the LHS (kept for gmg_get_level_operator, the level-0 ordering and the host fallbacks): 250 MB at
+    // 3 M vertices, made in the background while the device works from the caller's arrays.
+    std::shared_future<void> lhs_copied = std::async(std::launch::async, [&] { h->lv[0].A.assign(n, n, colptr, rowidx, val); }).share();
     std::function<void(int)> spawn_level_ops;
     auto spawn_level = [&](int k) {
         Level& l = h->lv[k];
-        l.n = l.A.n_outer;
+        l.n = k == 0 ? n : l.A.n_outer;
         ord_done[k] = std::async(std::launch::async, [&, k] {
             auto t = clk::now();
             Level& lk = h->lv[k];
             const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
             if (k == L) lk.ord = identity_ordering(lk.n);
-            else if (blocked) lk.ord = make_block_ordering(lk.A, h->cfg.block_rows);
+            else if (blocked) { if (k == 0) lhs_copied.wait(); lk.ord = make_block_ordering(lk.A, h->cfg.block_rows); }
+            else if (k == 0) lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma);   // the caller's arrays
             else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
             lk.n_pad = lk.ord.n_pad;
             stage[k].ms_order = ms_since(t);
@@ -930,7 +947,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             rc = upload_csr(h, dUs[k], h->U[k]);
             if (rc == GMG_OK) rc = build_ell3(h, e3s[k], dUs[k], h->U[k].n_inner, d_rap_err.p);
         }
-        if (rc == GMG_OK) rc = upload_csr(h, dAs[0], h->lv[0].A);
+        if (rc == GMG_OK) rc = upload_csr_raw(h, dAs[0], n, colptr, rowidx, val);
         int k = 1;
         for (; k <= L && rc == GMG_OK; ++k) {
             rc = device_rap(h, dAs[k - 1], dUs[k - 1], e3s[k - 1], dAs[k], h->lv[k].A, d_rap_err.p);
@@ -938,15 +955,17 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             if (rc == GMG_OK) { (void)hipMemcpy(&herr, d_rap_err.p, sizeof(int), hipMemcpyDeviceToHost); if (herr) break; }
             if (rc == GMG_OK) spawn_level(k);
         }
-        if (rc != GMG_OK) { free_dev_inputs(); for (int j = 0; j < k && j <= L; ++j) if (ord_done[j].valid()) ord_done[j].wait(); return rc; }
+        if (rc != GMG_OK) { free_dev_inputs(); lhs_copied.wait(); for (int j = 0; j < k && j <= L; ++j) if (ord_done[j].valid()) ord_done[j].wait(); return rc; }
         if (k <= L) {
             // a coarse row with more distinct columns than the device hash set holds (or a U row with > 3 entries):
             // finish the chain with the host implementation
             device_rap_ok = false;
             free_dev_inputs();
+            lhs_copied.wait();
             for (; k <= L; ++k) { h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads); spawn_level(k); }
         }
     } else {
+        lhs_copied.wait();
         for (int k = 1; k <= L; ++k) {
             h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads);
             spawn_level(k);
@@ -983,13 +1002,17 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if ((rc_all = d_err.alloc(h, 1)) == GMG_OK) {
             (void)hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream);
             for (int k = 0; k <= L && rc_all == GMG_OK; ++k) {
+                auto tw = clk::now();
                 ord_done[k].wait();
+                h->timing["setup_wait_ordering"] += ms_since(tw);
                 if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); break; }
                 rc_all = upload(h, &h->lv[k].d_new2old, h->lv[k].ord.new2old);
             }
+            auto tlay = clk::now();
             for (int k = 0; k < L && rc_all == GMG_OK; ++k)
                 rc_all = device_layout_level(h, k, d_err.p, device_rap_ok ? &dAs[k] : nullptr, device_rap_ok ? &dUs[k] : nullptr, device_rap_ok ? &e3s[k] : nullptr);
             free_dev_inputs();
+            h->timing["setup_device_layout"] = ms_since(tlay);
             if (rc_all == GMG_OK) {
                 (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
                 (void)hipStreamSynchronize(h->stream);
@@ -1034,6 +1057,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         ms_h2d += ms_since(tu);
     }
     {   // never leave with tasks still referencing this frame
+        lhs_copied.wait();
         for (int k = 0; k <= L; ++k) if (ord_done[k].valid()) ord_done[k].wait();
         for (int k = 0; k < L; ++k) { if (op_done[k].valid()) op_done[k].wait(); if (tr_done[k].valid()) tr_done[k].wait(); }
     }
@@ -1044,6 +1068,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     h->coarse_work.assign(h->lv[L].A.n_outer, 0.0);
     h->timing["coarsest_solve"] = ms_factor;
     h->timing["setup_ordering"] = 0.0; h->timing["setup_sell"] = 0.0;
+    for (int k = 0; k <= L; ++k) h->timing["setup_ordering_l" + std::to_string(k)] = stage[k].ms_order;
     for (int k = 0; k <= L; ++k) { h->timing["setup_ordering"] = std::max(h->timing["setup_ordering"], stage[k].ms_order); h->timing["setup_sell"] = std::max(h->timing["setup_sell"], stage[k].ms_sell); }
     h->timing["setup_h2d"] = ms_h2d;
     (void)tl;

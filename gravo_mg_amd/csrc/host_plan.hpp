@@ -101,7 +101,15 @@ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Greedy first-fit colouring in natural order (4 colours on a valence-6 mesh,
 // 13-18 on Galerkin levels).  A is symmetric; self-loops ignored.
-inline int greedy_coloring(const Compressed& A, std::vector<int>& color) {
+// Sparsity pattern by reference (the caller's arrays): what the colour-major ordering needs of a matrix.
+struct PatternView {
+    int n_outer;
+    const int* ptr;
+    const int* idx;
+};
+
+template <class Mat>
+inline int greedy_coloring(const Mat& A, std::vector<int>& color) {
     const int n = A.n_outer;
     color.assign(n, -1);
     std::vector<int> forbid;
@@ -121,7 +129,8 @@ inline int greedy_coloring(const Compressed& A, std::vector<int>& color) {
 }
 
 // multicolor = false -> a single "colour" holding every row (Jacobi-type smoothers, coarsest level).
-inline LevelOrdering make_ordering(const Compressed& A, bool multicolor, int row_align, int sigma) {
+template <class Mat>
+inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma) {
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
@@ -164,14 +173,15 @@ inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
     const int n = A.n_outer;
     o.n = n;
     o.blocked = true;
+    // ---- phase 1 (sequential graph traversal): grow the blocks, record their members in BFS order
     std::vector<int> block_of(n, -1);
-    std::vector<int> members, queue, cand;
-    std::vector<int> color(n, -1);
-    std::vector<char> forbid;
+    std::vector<int> members;                 // all blocks back to back
+    std::vector<int> mem_begin{0};            // block -> first member
+    std::vector<int> cand;
+    members.reserve(n);
+    cand.reserve((size_t)n / 2 + 16);
     size_t cand_head = 0;
     int scan = 0;
-    o.blk_begin.push_back(0);
-    std::vector<int> order_tmp;
     while (true) {
         int seed = -1;
         while (cand_head < cand.size()) {
@@ -183,56 +193,68 @@ inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
             if (scan >= n) break;
             seed = scan;
         }
-        const int b = o.n_blocks();
-        members.clear(); queue.clear();
-        block_of[seed] = b; members.push_back(seed); queue.push_back(seed);
-        size_t head = 0;
-        while (head < queue.size() && (int)members.size() < block_rows) {
-            int v = queue[head++];
-            for (int p = A.ptr[v]; p < A.ptr[v + 1] && (int)members.size() < block_rows; ++p) {
+        const int b = (int)mem_begin.size() - 1;
+        const size_t first = members.size();
+        block_of[seed] = b; members.push_back(seed);
+        size_t head = first;
+        while (head < members.size() && (int)(members.size() - first) < block_rows) {
+            int v = members[head++];
+            for (int p = A.ptr[v]; p < A.ptr[v + 1] && (int)(members.size() - first) < block_rows; ++p) {
                 int w = A.idx[p];
-                if (block_of[w] < 0) { block_of[w] = b; members.push_back(w); queue.push_back(w); }
+                if (block_of[w] < 0) { block_of[w] = b; members.push_back(w); }
             }
         }
-        // unassigned neighbours of the unexpanded tail become seed candidates for the next blocks
-        for (size_t q = head; q < queue.size(); ++q) {
-            int v = queue[q];
+        // one unassigned neighbour of each unexpanded tail vertex becomes a seed candidate for the next blocks
+        for (size_t q = head; q < members.size(); ++q) {
+            int v = members[q];
             for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p)
-                if (block_of[A.idx[p]] < 0) cand.push_back(A.idx[p]);
+                if (block_of[A.idx[p]] < 0) { cand.push_back(A.idx[p]); break; }
         }
-        // in-block greedy colouring (BFS order)
-        int ncol = 0;
-        for (int v : members) {
-            forbid.assign((size_t)ncol + 1, 0);
-            for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) {
-                int w = A.idx[p];
-                if (w != v && block_of[w] == b && color[w] >= 0) forbid[color[w]] = 1;
-            }
-            int c = 0;
-            while (c < ncol && forbid[c]) ++c;
-            color[v] = c;
-            if (c == ncol) ++ncol;
-        }
-        std::stable_sort(members.begin(), members.end(), [&](int x, int y) { return color[x] < color[y]; });
-        const int begin = o.blk_begin.back();
-        const int padded = round_up((int)members.size(), kSlice);
-        order_tmp.clear();
-        o.new2old.resize((size_t)begin + padded, -1);
-        o.row_color.resize((size_t)begin + padded, 0);
-        for (size_t i = 0; i < members.size(); ++i) {
-            o.new2old[begin + i] = members[i];
-            o.row_color[begin + i] = (unsigned char)std::min(color[members[i]], 255);
-        }
-        o.blk_begin.push_back(begin + padded);
-        o.blk_ncolors.push_back(ncol);
-        o.n_colors = std::max(o.n_colors, ncol);
+        mem_begin.push_back((int)members.size());
     }
-    o.n_pad = o.blk_begin.back();
-    if (o.n_pad == 0) { o.n_pad = kSlice; o.new2old.assign(kSlice, -1); o.row_color.assign(kSlice, 0); }
+    const int nb = (int)mem_begin.size() - 1;
+    // ---- phase 2 (threaded over blocks): greedy colouring of the in-block subgraph in BFS order, colour sort, padding
+    o.blk_begin.assign((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; ++b) o.blk_begin[b + 1] = o.blk_begin[b] + round_up(mem_begin[b + 1] - mem_begin[b], kSlice);
+    o.n_pad = nb ? o.blk_begin[nb] : kSlice;
+    o.new2old.assign(o.n_pad, -1);
+    o.row_color.assign(o.n_pad, 0);
+    o.blk_ncolors.assign(nb, 0);
+    std::vector<int> color(n, -1);
+    parallel_ranges(nb, hw_threads(), [&](int lo, int hi, int) {
+        std::vector<char> forbid;
+        std::vector<int> mem;
+        for (int b = lo; b < hi; ++b) {
+            int ncol = 0;
+            for (int m = mem_begin[b]; m < mem_begin[b + 1]; ++m) {
+                const int v = members[m];
+                forbid.assign((size_t)ncol + 1, 0);
+                for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) {
+                    int w = A.idx[p];
+                    if (w != v && block_of[w] == b && color[w] >= 0) forbid[color[w]] = 1;
+                }
+                int c = 0;
+                while (c < ncol && forbid[c]) ++c;
+                color[v] = c;
+                if (c == ncol) ++ncol;
+            }
+            mem.assign(members.begin() + mem_begin[b], members.begin() + mem_begin[b + 1]);
+            std::stable_sort(mem.begin(), mem.end(), [&](int x, int y) { return color[x] < color[y]; });
+            const int begin = o.blk_begin[b];
+            for (size_t i = 0; i < mem.size(); ++i) {
+                o.new2old[begin + i] = mem[i];
+                o.row_color[begin + i] = (unsigned char)std::min(color[mem[i]], 255);
+            }
+            o.blk_ncolors[b] = ncol;
+        }
+    });
+    for (int b = 0; b < nb; ++b) o.n_colors = std::max(o.n_colors, o.blk_ncolors[b]);
     o.color_begin = {0, o.n_pad};      // not colour-major: a single range
     o.old2new.assign(n, -1);
-    for (int r = 0; r < o.n_pad; ++r)
-        if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
+    parallel_ranges(o.n_pad, hw_threads(), [&](int lo, int hi, int) {
+        for (int r = lo; r < hi; ++r)
+            if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
+    });
     return o;
 }
 

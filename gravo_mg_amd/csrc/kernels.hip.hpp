@@ -459,6 +459,17 @@ __global__ void permute_out(const double* __restrict__ src, int ld, int n_pad, c
     for (int c = 0; c < D; ++c) dst[old + (int64_t)c * n] = src[r + (int64_t)c * ld];
 }
 
+// Lumped mass and its inverse in device numbering (weights of the M / M^-1 residual norms); padding rows get 1.
+__global__ void permute_mass(const double* __restrict__ mass, const int* __restrict__ new2old, int n_pad, double* __restrict__ m,
+                             double* __restrict__ minv) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    const int old = new2old[r];
+    const double v = old >= 0 ? mass[old] : 1.0;
+    m[r] = v;
+    minv[r] = 1.0 / v;
+}
+
 // Coarsest level, GMG_COARSE_DEVICE_INVERSE: e = Ainv * rc, Ainv dense symmetric n x n (ld = n), one wave
 // per row, lanes stride the row (coalesced), wave reduction.  x/y leading dimension ldv.
 template <int D>

@@ -7,5 +7,5 @@ for rep in range(2):
     eng = cabi.Engine()
     eng.use_hierarchy(H); eng.set_mass(mass)
     t = time.perf_counter(); eng.set_system(lhs); tot = time.perf_counter() - t
-    print("set_system %.0f ms:" % (1e3 * tot), {k: round(eng.timing(k)) for k in ("reduction", "coarsest_solve", "upload", "setup_ordering", "setup_sell", "setup_h2d")})
+    print("set_system %.0f ms:" % (1e3 * tot), {k: round(eng.timing(k)) for k in ("reduction", "coarsest_solve", "upload", "setup_ordering", "setup_ordering_l0", "setup_ordering_l1", "setup_ordering_l2", "setup_wait_ordering", "setup_device_layout", "setup_total")})
     t = time.perf_counter(); x, it, res, conv = eng.solve(rhs); print("solve call %.1f ms, cycles %.1f ms, iters %d" % (1e3 * (time.perf_counter() - t), eng.timing("cycles"), it))
