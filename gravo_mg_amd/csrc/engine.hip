@@ -97,6 +97,10 @@ struct gmg_solver_s {
     bool dist_ready = false;
     double *own_x0 = nullptr, *own_b0 = nullptr, *own_r0 = nullptr;   // engine-owned buffers parked while external ones are bound
     bool bound = false;
+    // orderings of the last system, reusable while the sparsity pattern of the LHS and the hierarchy are unchanged
+    bool ord_cache_valid = false;
+    uint64_t ord_cache_key[2] = {0, 0};
+    std::vector<LevelOrdering> ord_cache;
 };
 
 namespace {
@@ -402,6 +406,29 @@ int device_layout_level(gmg_handle h, int k, int* d_err, DevCsr* pre_A, DevCsr* 
     free_csr(dU);
     free_ell3(e3);
     return GMG_OK;
+}
+
+// 2 x 64-bit FNV-1a style digest of the LHS sparsity pattern (threaded; chunk digests combined in order)
+void pattern_key(int n, const int* colptr, const int* rowidx, int threads, uint64_t key[2]) {
+    const int64_t nnz = colptr[n];
+    const int T = std::max(1, std::min(threads, 64));
+    std::vector<uint64_t> part((size_t)T * 2, 0);
+    auto digest = [](const int* p, int64_t cnt, uint64_t seed) {
+        uint64_t h = 1469598103934665603ull ^ seed;
+        for (int64_t i = 0; i < cnt; ++i) { h ^= (uint32_t)p[i]; h *= 1099511628211ull; h ^= h >> 29; }
+        return h;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+        pool.emplace_back([&, t] {
+            int64_t lo = nnz * t / T, hi = nnz * (t + 1) / T;
+            part[2 * t] = digest(rowidx + lo, hi - lo, 0x9e3779b97f4a7c15ull * (t + 1));
+            int64_t plo = (int64_t)(n + 1) * t / T, phi = (int64_t)(n + 1) * (t + 1) / T;
+            part[2 * t + 1] = digest(colptr + plo, phi - plo, 0xc2b2ae3d27d4eb4full * (t + 1));
+        });
+    for (auto& th : pool) th.join();
+    key[0] = 1469598103934665603ull ^ (uint64_t)n; key[1] = 0x84222325cbf29ce4ull ^ (uint64_t)nnz;
+    for (int t = 0; t < T; ++t) { key[0] = (key[0] ^ part[2 * t]) * 1099511628211ull; key[1] = (key[1] ^ part[2 * t + 1]) * 1099511628211ull; }
 }
 
 constexpr int kNormBlocks = 2048;      // residual-norm partial sums: 8 blocks per CU, grid-stride
@@ -750,6 +777,7 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->block_lanes = 0;
     cfg->device_setup = 1;
     cfg->device_rap = 1;
+    cfg->reorder_fine = 2;
     cfg->host_threads = 0;
     cfg->verbose = 0;
     return GMG_OK;
@@ -766,7 +794,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
@@ -805,6 +833,7 @@ int gmg_set_num_levels(gmg_handle h, int L) {
     if (!h || L < 0 || L > 64) return h ? fail(h, GMG_ERR_INVALID, "invalid level count") : GMG_ERR_INVALID;
     if (h->has_device) drop_system(h);
     h->L = L;
+    h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
     h->U_set.assign(L, 0);
     return GMG_OK;
@@ -819,6 +848,7 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
     if (h->has_device) drop_system(h);
     h->U[k].assign(n_coarse, n_fine, colptr, rowidx, val);
     h->U_set[k] = 1;
+    h->ord_cache_valid = false;
     return GMG_OK;
 }
 
@@ -879,6 +909,10 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     // Host copy of the LHS (kept for gmg_get_level_operator, the level-0 ordering and the host fallbacks): 250 MB at
     // 3 M vertices, made in the background while the device works from the caller's arrays.
     std::shared_future<void> lhs_copied = std::async(std::launch::async, [&] { h->lv[0].A.assign(n, n, colptr, rowidx, val); }).share();
+    uint64_t pat_key[2];
+    pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
+    const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1];
+    h->timing["setup_ordering_cached"] = ord_hit ? 1.0 : 0.0;
     std::function<void(int)> spawn_level_ops;
     auto spawn_level = [&](int k) {
         Level& l = h->lv[k];
@@ -887,9 +921,10 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             auto t = clk::now();
             Level& lk = h->lv[k];
             const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
-            if (k == L) lk.ord = identity_ordering(lk.n);
+            if (ord_hit) lk.ord = h->ord_cache[k];          // same pattern + same hierarchy => same orderings
+            else if (k == L) lk.ord = identity_ordering(lk.n);
             else if (blocked) { if (k == 0) lhs_copied.wait(); lk.ord = make_block_ordering(lk.A, h->cfg.block_rows); }
-            else if (k == 0) lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma);   // the caller's arrays
+            else if (k == 0) lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, h->cfg.reorder_fine);   // the caller's arrays
             else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
             lk.n_pad = lk.ord.n_pad;
             stage[k].ms_order = ms_since(t);
@@ -1084,6 +1119,12 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         int rc;
         if ((rc = upload(h, &h->d_ainv, inv))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (!ord_hit) {
+        h->ord_cache.resize(L + 1);
+        for (int k = 0; k <= L; ++k) h->ord_cache[k] = h->lv[k].ord;
+        h->ord_cache_key[0] = pat_key[0]; h->ord_cache_key[1] = pat_key[1];
+        h->ord_cache_valid = true;
     }
     h->system_ready = true;
     if (!h->mass.empty()) {

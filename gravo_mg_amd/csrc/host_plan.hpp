@@ -17,7 +17,9 @@
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -77,6 +79,7 @@ struct LevelOrdering {
     std::vector<int> old2new;         // n
     // "blocked" levels (block-hybrid Gauss-Seidel, one launch per sweep): rows grouped into compact
     // blocks of <= block_rows rows, colour-sorted inside a block, each block padded to 64 rows.
+    bool reordered = false;           // colour-major level whose rows follow a BFS patch order instead of the input order
     bool blocked = false;
     std::vector<int> blk_begin;       // n_blocks + 1, device rows (multiples of 64)
     std::vector<int> blk_ncolors;     // n_blocks
@@ -108,13 +111,15 @@ struct PatternView {
     const int* idx;
 };
 
+// Greedy first-fit colouring; vertices visited in `order` (natural order if empty).
 template <class Mat>
-inline int greedy_coloring(const Mat& A, std::vector<int>& color) {
+inline int greedy_coloring(const Mat& A, std::vector<int>& color, const std::vector<int>& order = std::vector<int>()) {
     const int n = A.n_outer;
     color.assign(n, -1);
     std::vector<int> forbid;
     int ncol = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int t = 0; t < n; ++t) {
+        const int i = order.empty() ? t : order[t];
         forbid.assign((size_t)ncol + 1, 0);
         for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
             int j = A.idx[p];
@@ -128,14 +133,79 @@ inline int greedy_coloring(const Mat& A, std::vector<int>& color) {
     return ncol;
 }
 
-// multicolor = false -> a single "colour" holding every row (Jacobi-type smoothers, coarsest level).
+// Breadth-first growth of compact patches of <= block_rows vertices over the matrix graph: seeds are taken on the
+// frontier of what is already assigned, so consecutive patches are neighbours.  members = visit order (all patches
+// back to back), mem_begin = patch boundaries.
 template <class Mat>
-inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma) {
+inline void grow_patches(const Mat& A, int block_rows, std::vector<int>& block_of, std::vector<int>& members, std::vector<int>& mem_begin) {
+    const int n = A.n_outer;
+    block_of.assign(n, -1);
+    members.clear(); members.reserve(n);
+    mem_begin.assign(1, 0);
+    std::vector<int> cand;
+    cand.reserve((size_t)n / 2 + 16);
+    size_t cand_head = 0;
+    int scan = 0;
+    while (true) {
+        int seed = -1;
+        while (cand_head < cand.size()) {
+            int c = cand[cand_head++];
+            if (block_of[c] < 0) { seed = c; break; }
+        }
+        if (seed < 0) {
+            while (scan < n && block_of[scan] >= 0) ++scan;
+            if (scan >= n) break;
+            seed = scan;
+        }
+        const int b = (int)mem_begin.size() - 1;
+        const size_t first = members.size();
+        block_of[seed] = b; members.push_back(seed);
+        size_t head = first;
+        while (head < members.size() && (int)(members.size() - first) < block_rows) {
+            int v = members[head++];
+            for (int p = A.ptr[v]; p < A.ptr[v + 1] && (int)(members.size() - first) < block_rows; ++p) {
+                int w = A.idx[p];
+                if (block_of[w] < 0) { block_of[w] = b; members.push_back(w); }
+            }
+        }
+        // one unassigned neighbour of each unexpanded tail vertex becomes a seed candidate for the next patches
+        for (size_t q = head; q < members.size(); ++q) {
+            int v = members[q];
+            for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p)
+                if (block_of[A.idx[p]] < 0) { cand.push_back(A.idx[p]); break; }
+        }
+        mem_begin.push_back((int)members.size());
+    }
+}
+
+// Mean |row - column| over the stored entries (sampled): a cheap measure of how far a row's x-gathers reach.
+template <class Mat>
+inline double mean_index_distance(const Mat& A) {
+    const int n = A.n_outer;
+    const int step = std::max(1, n / 65536);
+    double sum = 0.0; long cnt = 0;
+    for (int i = 0; i < n; i += step)
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) { sum += std::abs(A.idx[p] - i); ++cnt; }
+    return cnt ? sum / cnt : 0.0;
+}
+
+// multicolor = false -> a single "colour" holding every row (Jacobi-type smoothers, coarsest level).
+// reorder: 0 never, 1 always, 2 automatic -- when the input vertex order has poor locality (a randomly ordered scan
+// or point cloud: every gather of x misses the caches, measured 3x per V-cycle at 3 M vertices) the rows inside a
+// colour follow a breadth-first patch order instead of the input order.
+template <class Mat>
+inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma, int reorder = 0) {
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
+    std::vector<int> base;      // visit order (empty = natural)
+    if (reorder == 1 || (reorder == 2 && n > 65536 && mean_index_distance(A) > std::max(32768.0, n / 32.0))) {
+        std::vector<int> block_of, mem_begin;
+        grow_patches(A, 4096, block_of, base, mem_begin);
+        o.reordered = true;
+    }
     std::vector<int> color;
-    if (multicolor) o.n_colors = greedy_coloring(A, color);
+    if (multicolor) o.n_colors = greedy_coloring(A, color, base);
     else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
     std::vector<int> count(o.n_colors, 0);
     for (int i = 0; i < n; ++i) count[color[i]]++;
@@ -146,7 +216,7 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     o.new2old.assign(o.n_pad, -1);
     o.old2new.assign(n, -1);
     std::vector<int> fill(o.color_begin.begin(), o.color_begin.end() - (o.n_colors ? 1 : 0));
-    for (int i = 0; i < n; ++i) o.new2old[fill[color[i]]++] = i;
+    for (int t = 0; t < n; ++t) { const int i = base.empty() ? t : base[t]; o.new2old[fill[color[i]]++] = i; }
     if (sigma > 0) {
         for (int c = 0; c < o.n_colors; ++c) {
             int lo = o.color_begin[c], hi = lo + count[c];
@@ -174,44 +244,8 @@ inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
     o.n = n;
     o.blocked = true;
     // ---- phase 1 (sequential graph traversal): grow the blocks, record their members in BFS order
-    std::vector<int> block_of(n, -1);
-    std::vector<int> members;                 // all blocks back to back
-    std::vector<int> mem_begin{0};            // block -> first member
-    std::vector<int> cand;
-    members.reserve(n);
-    cand.reserve((size_t)n / 2 + 16);
-    size_t cand_head = 0;
-    int scan = 0;
-    while (true) {
-        int seed = -1;
-        while (cand_head < cand.size()) {
-            int c = cand[cand_head++];
-            if (block_of[c] < 0) { seed = c; break; }
-        }
-        if (seed < 0) {
-            while (scan < n && block_of[scan] >= 0) ++scan;
-            if (scan >= n) break;
-            seed = scan;
-        }
-        const int b = (int)mem_begin.size() - 1;
-        const size_t first = members.size();
-        block_of[seed] = b; members.push_back(seed);
-        size_t head = first;
-        while (head < members.size() && (int)(members.size() - first) < block_rows) {
-            int v = members[head++];
-            for (int p = A.ptr[v]; p < A.ptr[v + 1] && (int)(members.size() - first) < block_rows; ++p) {
-                int w = A.idx[p];
-                if (block_of[w] < 0) { block_of[w] = b; members.push_back(w); }
-            }
-        }
-        // one unassigned neighbour of each unexpanded tail vertex becomes a seed candidate for the next blocks
-        for (size_t q = head; q < members.size(); ++q) {
-            int v = members[q];
-            for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p)
-                if (block_of[A.idx[p]] < 0) { cand.push_back(A.idx[p]); break; }
-        }
-        mem_begin.push_back((int)members.size());
-    }
+    std::vector<int> block_of, members, mem_begin;
+    grow_patches(A, block_rows, block_of, members, mem_begin);
     const int nb = (int)mem_begin.size() - 1;
     // ---- phase 2 (threaded over blocks): greedy colouring of the in-block subgraph in BFS order, colour sort, padding
     o.blk_begin.assign((size_t)nb + 1, 0);

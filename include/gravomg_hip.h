@@ -67,6 +67,8 @@ typedef struct {
                               0: build them with the host planner (the specification the device builder is tested against) */
     int device_rap;        /* 1 (default): Galerkin products U^T A U on the GPU (bitwise equal to the host implementation, which
                               remains the fallback and the specification); needs device_setup = 1 */
+    int reorder_fine;      /* locality reordering of the finest level before colouring: 0 never, 1 always, 2 (default)
+                              automatic = when the input vertex order has a large bandwidth (random-order scans, point clouds) */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
 } gmg_config;

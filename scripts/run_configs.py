@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""BASELINE.json's configs at FULL size on one MI355X (SURVEY.md 8d's synthetic stand-ins), with the
+size-independent checks the domain offers: the solve reaches the reference's stopping test, the oracle's
+residualCheck of the returned solution agrees with the GPU's, the residual history contracts monotonically, and
+(where it finishes in seconds) the 1-core oracle needs the same number of V-cycles.
+
+  python scripts/run_configs.py [--configs 1 2 3 4 4r] [--oracle-max-n 800000] > profiles/r01/configs.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gravo_mg_amd import cabi, meshgen  # noqa: E402
+
+
+def build(cfg):
+    if cfg == "1":      # demos/smoothing.py call pattern: M + 1e-3 S, rhs = M V (n x 3), ~36 k vertices
+        V, F = meshgen.torus_mesh(190, 190)
+        S, mass = meshgen.cotan_laplacian(V, F)
+        lhs, rhs = meshgen.smoothing_system(S, mass, V)
+        return "cfg1 torus 190x190 smoothing d=3", V, S, mass, lhs, rhs
+    if cfg == "2":      # ~720 k cotan Poisson
+        V, F = meshgen.torus_mesh(850, 850)
+        S, mass = meshgen.cotan_laplacian(V, F)
+        lhs, rhs = meshgen.poisson_system(S, mass)
+        return "cfg2 torus 850x850 Poisson d=1", V, S, mass, lhs, rhs
+    if cfg == "3":      # ~2 M point cloud, kNN graph Laplacian (stand-in for robust_laplacian)
+        P = meshgen.torus_points(2_000_000, noise=0.0005)
+        S, mass = meshgen.knn_graph_laplacian(P, 8)
+        lhs, rhs = meshgen.poisson_system(S, mass)
+        return "cfg3 point cloud 2M kNN(8) Poisson d=1", P, S, mass, lhs, rhs
+    if cfg in ("4", "4r"):   # ~3 M mesh Poisson (the bench workload), natural / random vertex order
+        V, F = meshgen.torus_mesh(1732, 1732, order="random" if cfg == "4r" else "natural")
+        S, mass = meshgen.cotan_laplacian(V, F)
+        lhs, rhs = meshgen.poisson_system(S, mass)
+        return f"cfg4 torus 1732x1732 Poisson d=1 ({'random' if cfg == '4r' else 'natural'} vertex order)", V, S, mass, lhs, rhs
+    raise ValueError(cfg)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", nargs="+", default=["1", "2", "3", "4", "4r"])
+    ap.add_argument("--oracle-max-n", type=int, default=800_000, help="run the full CPU oracle solve up to this size")
+    args = ap.parse_args()
+    out = []
+    for cfg in args.configs:
+        t = time.perf_counter()
+        name, pos, S, mass, lhs, rhs = build(cfg)
+        t_build = time.perf_counter() - t
+        neigh = meshgen.neighbors_from_stiffness(S)
+        t = time.perf_counter()
+        H = cabi.Hierarchy(pos, neigh)
+        t_hier = time.perf_counter() - t
+        eng = cabi.Engine()
+        eng.use_hierarchy(H)
+        eng.set_mass(mass)
+        t = time.perf_counter()
+        eng.set_system(lhs)
+        t_setup = time.perf_counter() - t
+        t = time.perf_counter()
+        x, it, res, conv = eng.solve(rhs, tol=1e-4, stop_type=2, max_iter=100)
+        t_solve = time.perf_counter() - t
+        eng.load_problem(rhs, rhs)
+        eng.run_cycles(3, 2)
+        t = time.perf_counter()
+        eng.run_cycles(10, 2)
+        ms_cycle = 1e2 * (time.perf_counter() - t)
+        rec = {
+            "config": name, "n": int(lhs.shape[0]), "nnz": int(lhs.nnz), "d": int(rhs.shape[1]),
+            "levels": [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)],
+            "colors": [eng.level_info(k)["n_colors"] for k in range(eng.num_levels + 1)],
+            "gpu_iterations": it, "gpu_residue": res, "residue_history": [float(v) for v in conv[:, 1]],
+            "ms_per_cycle": ms_cycle, "set_system_ms": 1e3 * t_setup, "solve_call_ms": 1e3 * t_solve,
+            "hierarchy_s": t_hier, "input_build_s": t_build,
+            "checks": {},
+        }
+        from oracle import oracle
+        chk = oracle.residual_check(lhs, mass, rhs, x, 2)
+        rec["checks"]["reaches_tolerance"] = bool(res <= 1e-4 and it < 100)
+        rec["checks"]["oracle_residual_check_of_gpu_solution"] = chk
+        rec["checks"]["oracle_agrees"] = bool(abs(chk - res) <= 1e-3 * res + 1e-7)
+        rec["checks"]["history_contracts"] = bool(np.all(np.diff(conv[:, 1]) < 0))
+        if lhs.shape[0] <= args.oracle_max_n:
+            O = oracle.Hierarchy(H.U, mass)
+            t = time.perf_counter()
+            O.set_system(lhs)
+            xo, ito, reso, convo = O.solve(rhs, tol=1e-4)
+            rec["oracle"] = {"iterations": ito, "residue": reso, "total_s": time.perf_counter() - t,
+                             "ms_per_cycle": float(convo[-1, 0] / ito)}
+            m = mass[:, None]
+            rec["checks"]["same_iterations_as_oracle"] = bool(abs(it - ito) <= 1)
+            rec["checks"]["solution_distance_M"] = float(np.sqrt((m * (x - xo) ** 2).sum() / (m * xo ** 2).sum()))
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+        del eng
+    ok = all(all(v for k, v in r["checks"].items() if isinstance(v, bool)) for r in out)
+    print(json.dumps({"all_checks_pass": ok}), flush=True)
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

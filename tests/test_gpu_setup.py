@@ -102,3 +102,31 @@ def test_device_galerkin_is_bitwise_the_host_galerkin(cabi, case):
         assert np.array_equal(a.data, b.data)
         assert a.has_sorted_indices
     assert engs[0].timing("reduction") > 0
+
+
+def test_ordering_cache_reused_for_same_pattern(cabi):
+    """demos/smoothing.py re-solves with a new tau: same sparsity pattern, new values.  The second gmg_set_system reuses
+    the orderings (and must give exactly what a fresh engine gives); a different pattern or hierarchy must not."""
+    import scipy.sparse as sp
+    from gravo_mg_amd import meshgen
+    P = problems.torus_problem(64, 60, "smoothing", 60)
+    lhs2 = (sp.diags(P.mass) + 5e-3 * P.S).tocsc()
+    eng = cabi.Engine()
+    eng.set_prolongations(P.U); eng.set_mass(P.mass)
+    eng.set_system(P.lhs)
+    assert eng.timing("setup_ordering_cached") == 0.0
+    eng.set_system(lhs2)
+    assert eng.timing("setup_ordering_cached") == 1.0
+    fresh = cabi.Engine()
+    fresh.set_prolongations(P.U); fresh.set_mass(P.mass); fresh.set_system(lhs2)
+    xa, ita, resa, _ = eng.solve(P.rhs, tol=1e-8)
+    xb, itb, resb, _ = fresh.solve(P.rhs, tol=1e-8)
+    assert ita == itb and np.array_equal(xa, xb)
+    # a different pattern (one extra symmetric coupling) misses the cache
+    E = sp.coo_matrix(([-1e-9, -1e-9], ([0, 777], [777, 0])), shape=lhs2.shape)
+    eng.set_system(sp.csc_matrix(lhs2 + E))
+    assert eng.timing("setup_ordering_cached") == 0.0
+    # a new hierarchy invalidates it as well
+    eng.set_prolongations(P.U[:1])
+    eng.set_system(lhs2)
+    assert eng.timing("setup_ordering_cached") == 0.0
