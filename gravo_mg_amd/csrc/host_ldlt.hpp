@@ -29,7 +29,7 @@ public:
     bool factor(const Compressed& A) {
         n = A.n_outer;
         ok = false;
-        min_degree(A);
+        if (n > kMinDegreeMax) nested_dissection(A); else min_degree(A);
         std::vector<int> inv(n);
         for (int i = 0; i < n; ++i) inv[perm[i]] = i;
         // Upper triangle (incl. diagonal) of C = P A P^T, by columns, unsorted rows are fine.
@@ -119,8 +119,73 @@ public:
 
     long factor_nnz() const { return (long)Lp.empty() ? 0 : Lp[n]; }
 
+    static constexpr int kMinDegreeMax = 2500;    // up to here the exact minimum-degree ordering (quadratic, but overlapped with the rest of the setup) gives ~6 % less fill
+
 private:
-    // Minimum-degree ordering on the explicit elimination graph (adequate for n <~ 10^4).
+    // Nested dissection with breadth-first level-set separators: O(E log n), fill O(n log n) on mesh-like graphs.
+    // A region is split by the middle level of a BFS started at a pseudo-peripheral vertex (edges of a BFS only join
+    // equal or adjacent levels, so a whole level separates); the two halves are ordered first, the separator last.
+    void nested_dissection(const Compressed& A) {
+        perm.clear(); perm.reserve(n);
+        std::vector<int> region(n, 0), level(n, -1), queue;
+        int next_region = 1;
+        struct Task { std::vector<int> nodes; int id; };
+        // explicit stack; a task's separator is emitted AFTER its two halves, so push a marker task holding it
+        struct Item { std::vector<int> nodes; int id; bool emit; };
+        std::vector<Item> stack;
+        { std::vector<int> all(n); for (int i = 0; i < n; ++i) all[i] = i; stack.push_back({std::move(all), 0, false}); }
+        std::vector<int> out_rev;      // built in reverse (separators first), reversed at the end
+        out_rev.reserve(n);
+        while (!stack.empty()) {
+            Item it = std::move(stack.back());
+            stack.pop_back();
+            if (it.emit || (int)it.nodes.size() <= 48) { for (auto r = it.nodes.rbegin(); r != it.nodes.rend(); ++r) out_rev.push_back(*r); continue; }
+            const int id = it.id;
+            auto bfs = [&](int start) {      // levels inside region `id`; returns the visit order in `queue`
+                queue.clear(); queue.push_back(start); level[start] = 0;
+                for (size_t h = 0; h < queue.size(); ++h) {
+                    int v = queue[h];
+                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { int w = A.idx[p]; if (region[w] == id && level[w] < 0) { level[w] = level[v] + 1; queue.push_back(w); } }
+                }
+            };
+            for (int v : it.nodes) level[v] = -1;
+            bfs(it.nodes[0]);
+            if (queue.size() < it.nodes.size()) {
+                // disconnected region: peel this component off and handle both parts independently
+                std::vector<int> comp(queue), rest;
+                const int idc = next_region++, idr = next_region++;
+                for (int v : comp) region[v] = idc;
+                for (int v : it.nodes) if (level[v] < 0) { rest.push_back(v); region[v] = idr; }
+                stack.push_back({std::move(rest), idr, false});
+                stack.push_back({std::move(comp), idc, false});
+                continue;
+            }
+            const int far = queue.back();
+            for (int v : it.nodes) level[v] = -1;
+            bfs(far);
+            const int depth = level[queue.back()];
+            if (depth < 2) { for (auto r = it.nodes.rbegin(); r != it.nodes.rend(); ++r) out_rev.push_back(*r); continue; }   // clique-like: no separator
+            // middle level by vertex count
+            std::vector<int> cnt(depth + 1, 0);
+            for (int v : queue) cnt[level[v]]++;
+            int mid = 1, acc = cnt[0];
+            while (mid < depth - 1 && acc + cnt[mid] < (int)queue.size() / 2) { acc += cnt[mid]; ++mid; }
+            std::vector<int> a, b, sep;
+            const int ida = next_region++, idb = next_region++;
+            for (int v : queue) {
+                if (level[v] < mid) { a.push_back(v); region[v] = ida; }
+                else if (level[v] > mid) { b.push_back(v); region[v] = idb; }
+                else { sep.push_back(v); region[v] = -1; }
+            }
+            // processing order (stack, reversed output): separator is emitted first into out_rev => eliminated last
+            stack.push_back({std::move(a), ida, false});
+            stack.push_back({std::move(b), idb, false});
+            stack.push_back({std::move(sep), -1, true});
+        }
+        perm.assign(out_rev.rbegin(), out_rev.rend());
+    }
+
+    // Minimum-degree ordering on the explicit elimination graph (exact but quadratic: small n only).
     void min_degree(const Compressed& A) {
         std::vector<std::vector<int>> adj(n);
         for (int j = 0; j < n; ++j) {

@@ -244,3 +244,20 @@ def test_host_ldlt(cabi):
     with pytest.raises(cabi.GmgError) as ei:
         cabi.host_ldlt_solve(Z, np.ones(2))
     assert ei.value.code == cabi.GMG_ERR_NUMERIC
+
+
+def test_host_ldlt_nested_dissection_path(cabi):
+    """Above 2500 unknowns the coarsest solver orders by nested dissection (BFS level-set separators)."""
+    P = problems.torus_problem(120, 100, "smoothing", 2000)
+    A = sp.csc_matrix(P.lhs)
+    assert A.shape[0] == 12000
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal((A.shape[0], 2))
+    x, nnzL = cabi.host_ldlt_solve(A, b)
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
+    assert nnzL < 60 * A.shape[0]                     # O(n log n) fill on a 2-D mesh graph, far from the dense n^2/2
+    # block-diagonal (disconnected) input exercises the component peeling
+    B = sp.block_diag([A[:3000, :3000] + sp.identity(3000), sp.identity(50) * 2.0, A[:2600, :2600] + sp.identity(2600)], format="csc")
+    y = rng.standard_normal(B.shape[0])
+    z, _ = cabi.host_ldlt_solve(B, y)
+    assert np.linalg.norm(B @ z - y) <= 1e-12 * np.linalg.norm(y)
