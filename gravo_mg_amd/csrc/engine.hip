@@ -41,6 +41,7 @@ struct DevSell {
     int64_t* slice_ptr = nullptr;
     int* col = nullptr;
     double* val = nullptr;
+    float* val32 = nullptr;       // fp32 copy of val (mixed-precision inner cycle); shares slice_ptr / col / row_of
     int* row_of = nullptr;
 };
 
@@ -58,6 +59,7 @@ struct Level {
     unsigned char* d_row_color = nullptr;
     int* d_new2old = nullptr;
     double *x = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;   // n_pad * dcap
+    float *diag32 = nullptr, *x32 = nullptr, *b32 = nullptr, *r32 = nullptr, *tmp32 = nullptr;   // mixed precision
 };
 
 }  // namespace
@@ -144,6 +146,7 @@ void free_sell(DevSell& s) {
     if (s.slice_ptr) (void)hipFree(s.slice_ptr);
     if (s.col) (void)hipFree(s.col);
     if (s.val) (void)hipFree(s.val);
+    if (s.val32) (void)hipFree(s.val32);
     if (s.row_of) (void)hipFree(s.row_of);
     s = DevSell();
 }
@@ -166,6 +169,7 @@ void free_level(Level& l) {
     if (l.d_blk_ncolors) { (void)hipFree(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
     if (l.d_row_color) { (void)hipFree(l.d_row_color); l.d_row_color = nullptr; }
     for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (l.d_new2old) { (void)hipFree(l.d_new2old); l.d_new2old = nullptr; }
 }
 
@@ -448,9 +452,31 @@ inline int grid_for(int n_slices) {
         default: { constexpr int D = 4; __VA_ARGS__; } break; \
     }
 
+// Precision selector: the fp64 arrays, or their fp32 twins (same layout, same index arrays).
+template <class T> struct Prec;
+template <> struct Prec<double> {
+    static const double* val(const DevSell& s) { return s.val; }
+    static const double* diag(const Level& l) { return l.diag; }
+    static double* x(Level& l) { return l.x; }
+    static double* b(Level& l) { return l.b; }
+    static double* r(Level& l) { return l.r; }
+    static double* tmp(Level& l) { return l.tmp; }
+};
+template <> struct Prec<float> {
+    static const float* val(const DevSell& s) { return s.val32; }
+    static const float* diag(const Level& l) { return l.diag32; }
+    static float* x(Level& l) { return l.x32; }
+    static float* b(Level& l) { return l.b32; }
+    static float* r(Level& l) { return l.r32; }
+    static float* tmp(Level& l) { return l.tmp32; }
+};
+
+template <class T>
 void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
     const bool fine = &l == &h->lv[0];
+    T* x = Prec<T>::x(l);
+    const T* b = Prec<T>::b(l);
     for (int it = 0; it < iters; ++it)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
@@ -458,108 +484,116 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
                 int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
                 if (se <= sb) continue;
                 if (fine) {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
-                                                      l.x + (size_t)c0 * ld, ld, sb, se, 1));
+                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
                 } else {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
-                                                      l.x + (size_t)c0 * ld, ld, sb, se, 1));
+                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
                 }
             }
         }
 }
 
+template <class T>
 void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
-    double* in = l.x; double* out = l.tmp;
+    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
+    const T* b = Prec<T>::b(l);
     for (int it = 0; it < iters; ++it) {
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::jacobi_sweep<D>, dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                              l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld,
-                                              in + (size_t)c0 * ld, out + (size_t)c0 * ld, ld, l.Aoff.n_slices, h->cfg.jacobi_omega, 1));
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::jacobi_sweep<T, D>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                              in + (size_t)c0 * ld, out + (size_t)c0 * ld, ld, l.Aoff.n_slices, (T)h->cfg.jacobi_omega, 1));
         }
         std::swap(in, out);
     }
-    if (in != l.x) (void)hipMemcpyAsync(l.x, in, sizeof(double) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+    if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
 }
 
 // block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
+template <class T>
 void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
     const int nb = l.ord.n_blocks();
-    double* in = l.x; double* out = l.tmp;
+    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
+    const T* b = Prec<T>::b(l);
     for (int it = 0; it < iters; ++it) {
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             if (l.Ain.lpr == 4) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
-                                                  l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
+                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
                                                   out + (size_t)c0 * ld, ld));
             } else {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, l.Ain.val, l.Aout.slice_ptr,
-                                                  l.Aout.col, l.Aout.val, l.diag, l.b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
+                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
                                                   out + (size_t)c0 * ld, ld));
             }
         }
         std::swap(in, out);
     }
-    if (in != l.x) (void)hipMemcpyAsync(l.x, in, sizeof(double) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+    if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
 }
 
+template <class T = double>
 void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
     if (iters <= 0) return;
-    if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps(h, l, d, iters);
-    else if (l.ord.blocked) launch_block_sweeps(h, l, d, iters);
-    else launch_gs_sweeps(h, l, d, iters);
+    if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps<T>(h, l, d, iters);
+    else if (l.ord.blocked) launch_block_sweeps<T>(h, l, d, iters);
+    else launch_gs_sweeps<T>(h, l, d, iters);
 }
 
 // y = A x (mode 0) or y = b - A x (mode 1)
-template <int LPR>
-void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const double* b, const double* x, double* y) {
+template <class T, int LPR>
+void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
     const int ld = l.n_pad;
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         if (mode == 1) {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                              l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, b + (size_t)c0 * ld, x + (size_t)c0 * ld,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
                                               y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
         } else {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 0, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                              l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, (const double*)nullptr, x + (size_t)c0 * ld,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
                                               y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
         }
     }
 }
-void launch_spmv(gmg_handle h, Level& l, int d, int mode, const double* b, const double* x, double* y) {
-    if (l.Aoff.lpr == 4) launch_spmv_lpr<4>(h, l, d, mode, b, x, y);
-    else launch_spmv_lpr<1>(h, l, d, mode, b, x, y);
+template <class T>
+void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
+    if (l.Aoff.lpr == 4) launch_spmv_lpr<T, 4>(h, l, d, mode, b, x, y);
+    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y);
 }
 
 // coarse.b = U^T fine.r
-template <int LPR>
-void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
+template <class T, int LPR>
+void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 0, LPR>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                          fine.R.slice_ptr, fine.R.col, fine.R.val, fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                          fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
                                           dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1));
     }
 }
-void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
-    if (fine.R.lpr == 4) launch_restrict_lpr<4>(h, fine, coarse, d, src, dst);
-    else launch_restrict_lpr<1>(h, fine, coarse, d, src, dst);
+template <class T>
+void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+    if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst);
+    else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst);
 }
 
 // fine.x += U coarse.x   (U has <= 3 entries per row: always one lane per row)
-void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const double* src, double* dst) {
+template <class T>
+void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                          fine.P.slice_ptr, fine.P.col, fine.P.val, (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                          fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
                                           coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1));
     }
 }
@@ -603,6 +637,14 @@ int ensure_vectors(gmg_handle h, int d) {
             if (*p) { (void)hipFree(*p); *p = nullptr; }
             if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
             size_t bytes = sizeof(double) * (size_t)l.n_pad * d;
+            HIPCHK(hipMalloc((void**)p, bytes));
+            HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
+        }
+        for (float** p : {&l.x32, &l.b32, &l.r32, &l.tmp32}) {
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+            if (!h->cfg.inner_precision) continue;
+            if (p == &l.tmp32 && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
+            size_t bytes = sizeof(float) * (size_t)l.n_pad * d;
             HIPCHK(hipMalloc((void**)p, bytes));
             HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
         }
@@ -654,40 +696,56 @@ int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
 
 // ---- V-cycle legs --------------------------------------------------------------------------------------
 
+template <class T = double>
 void enqueue_down(gmg_handle h, int d, int k0 = 0) {
     const int L = h->L;
     for (int k = k0; k < L; ++k) {
         Level& l = h->lv[k];
-        if (k > 0) (void)hipMemsetAsync(l.x, 0, sizeof(double) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
-        launch_smooth(h, l, d, h->cfg.pre_iters);                                                 // :1063
-        launch_spmv(h, l, d, 1, l.b, l.x, l.r);                                                   // :1066
-        launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b);                              // :1069
+        if (k > 0) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
+        launch_smooth<T>(h, l, d, h->cfg.pre_iters);                                                 // :1063
+        launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l));                    // :1066
+        launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
     }
 }
 
+template <class T = double>
 void enqueue_up(gmg_handle h, int d, int k0 = 0) {
     for (int k = h->L - 1; k >= k0; --k) {
         Level& l = h->lv[k];
-        launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);                           // :1082
-        launch_smooth(h, l, d, h->cfg.post_iters);                                                // :1085
+        launch_prolong_add<T>(h, l, h->lv[k + 1], d, Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l));     // :1082
+        launch_smooth<T>(h, l, d, h->cfg.post_iters);                                                // :1085
     }
 }
 
+inline void launch_cvt(gmg_handle h, const double* src, float* dst, size_t n) {
+    hipLaunchKernelGGL(gmgk::cvt_f64_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
+}
+inline void launch_cvt(gmg_handle h, const float* src, double* dst, size_t n) {
+    hipLaunchKernelGGL(gmgk::cvt_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
+}
+
+// e = A_L^{-1} rc with the dense inverse (always applied in fp64; the fp32 cycle converts around it)
+template <class T = double>
 void enqueue_coarse_device(gmg_handle h, int d) {
     Level& c = h->lv[h->L];
+    const size_t cnt = (size_t)c.n_pad * d;
+    if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::dense_symv<D>, dim3((c.n + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock), dim3(gmgk::kBlock), 0,
                                           h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad));
     }
+    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
 }
 
-// Host coarsest solve (:1075): D2H rc, LDL^T back-substitution per column, H2D eps.
+// Host coarsest solve (:1075): D2H rc, LDL^T back-substitution per column (fp64), H2D eps.
+template <class T = double>
 int coarse_host_roundtrip(gmg_handle h, int d) {
     Level& c = h->lv[h->L];
     const size_t cnt = (size_t)c.n_pad * d;
     double* rc = h->h_pinned;
     double* e = h->h_pinned + cnt;
+    if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
     HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     auto t0 = clk::now();
@@ -695,6 +753,24 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
     for (int col = 0; col < d; ++col) h->coarse.solve(rc + (size_t)col * c.n_pad, e + (size_t)col * c.n_pad, h->coarse_work.data());
     h->timing["coarse_host_ms"] += ms_since(t0);
     HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
+    return GMG_OK;
+}
+
+// Mixed precision: fp64 residual of the current iterate -> fp32 right-hand side of the inner cycle, plus the norm sums
+// of that same residual (h_norm after the copy + sync).  type < 0: weights of type 0.
+int launch_residual_to_f32(gmg_handle h, int d, int type) {
+    Level& l = h->lv[0];
+    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
+    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_to_f32_with_norm<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
+                                          l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, 0, l.Aoff.n_slices,
+                                          l.b32 + (size_t)c0 * l.n_pad, h->d_partials));
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
+    }
+    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
     return GMG_OK;
 }
 
@@ -718,29 +794,47 @@ int run_graph(gmg_handle h, int key, F&& enqueue) {
     return GMG_OK;
 }
 
-// One V-cycle on the resident problem; with_norm >= 0 also enqueues the residual check of that type
+// One V-cycle on the resident problem; norm_type >= 0 also enqueues the residual check of that type
 // (result in h_norm after the stream is synchronised by the caller).
-int vcycle_resident(gmg_handle h, int d, int norm_type) {
+template <class T>
+int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
     int rc;
     const int nt = norm_type < 0 ? 9 : norm_type;
+    constexpr bool mixed = sizeof(T) == 4;
+    // mixed precision: the fp32 cycle starts from a zero guess on the defect b32 = b - A x (already in place), its
+    // result is added to the fp64 iterate, and the new defect + its norms are formed in one fp64 pass
+    auto head = [&] { if (mixed) (void)hipMemsetAsync(h->lv[0].x32, 0, sizeof(float) * (size_t)h->lv[0].n_pad * d, h->stream); };
+    auto tail = [&](int& err) {
+        if (mixed) {
+            const size_t cnt = (size_t)h->lv[0].n_pad * d;
+            hipLaunchKernelGGL(gmgk::add_correction, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->lv[0].x32, h->lv[0].x, (int64_t)cnt);
+            err = launch_residual_to_f32(h, d, norm_type);
+        } else if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+    };
     if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
         int err = GMG_OK;
-        rc = run_graph(h, G_FULL * 10000 + d * 10 + nt, [&] {
-            enqueue_down(h, d);
-            enqueue_coarse_device(h, d);
-            enqueue_up(h, d);
-            if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+        rc = run_graph(h, key_salt + G_FULL * 10000 + d * 10 + nt, [&] {
+            head();
+            enqueue_down<T>(h, d);
+            enqueue_coarse_device<T>(h, d);
+            enqueue_up<T>(h, d);
+            tail(err);
         });
         return rc ? rc : err;
     }
-    if ((rc = run_graph(h, G_DOWN * 10000 + d * 10, [&] { enqueue_down(h, d); }))) return rc;
-    if ((rc = coarse_host_roundtrip(h, d))) return rc;
+    if ((rc = run_graph(h, key_salt + G_DOWN * 10000 + d * 10, [&] { head(); enqueue_down<T>(h, d); }))) return rc;
+    if ((rc = coarse_host_roundtrip<T>(h, d))) return rc;
     int err = GMG_OK;
-    rc = run_graph(h, G_UP * 10000 + d * 10 + nt, [&] {
-        enqueue_up(h, d);
-        if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+    rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
+        enqueue_up<T>(h, d);
+        tail(err);
     });
     return rc ? rc : err;
+}
+
+int vcycle_resident(gmg_handle h, int d, int norm_type) {
+    if (h->cfg.inner_precision) return vcycle_legs<float>(h, d, norm_type, 100000);
+    return vcycle_legs<double>(h, d, norm_type, 0);
 }
 
 int check_level(gmg_handle h, int k, bool allow_coarsest) {
@@ -778,6 +872,7 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->device_setup = 1;
     cfg->device_rap = 1;
     cfg->reorder_fine = 2;
+    cfg->inner_precision = 0;
     cfg->host_threads = 0;
     cfg->verbose = 0;
     return GMG_OK;
@@ -794,7 +889,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.reorder_fine < 0 || c.reorder_fine > 2 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
@@ -1120,6 +1215,25 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if ((rc = upload(h, &h->d_ainv, inv))) return rc;
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    if (h->cfg.inner_precision) {
+        // fp32 twins of every value array (same layout): the inner V-cycle of the mixed-precision iteration
+        auto twin = [&](DevSell& m) -> int {
+            if (!m.val || m.stored <= 0) return GMG_OK;
+            if (m.val32) { (void)hipFree(m.val32); m.val32 = nullptr; }
+            HIPCHK(hipMalloc((void**)&m.val32, sizeof(float) * (size_t)m.stored));
+            launch_cvt(h, m.val, m.val32, (size_t)m.stored);
+            return GMG_OK;
+        };
+        for (int k = 0; k < L; ++k) {
+            Level& l = h->lv[k];
+            int rc;
+            if ((rc = twin(l.Aoff)) || (rc = twin(l.Ain)) || (rc = twin(l.Aout)) || (rc = twin(l.P)) || (rc = twin(l.R))) return rc;
+            if (l.diag32) { (void)hipFree(l.diag32); l.diag32 = nullptr; }
+            HIPCHK(hipMalloc((void**)&l.diag32, sizeof(float) * (size_t)l.n_pad));
+            launch_cvt(h, l.diag, l.diag32, (size_t)l.n_pad);
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if (!ord_hit) {
         h->ord_cache.resize(L + 1);
         for (int k = 0; k <= L; ++k) h->ord_cache[k] = h->lv[k].ord;
@@ -1245,7 +1359,7 @@ int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters
     Level& l = h->lv[k];
     if ((rc = to_device(h, k, b, d, l.b))) return rc;
     if ((rc = to_device(h, k, x, d, l.x))) return rc;
-    launch_smooth(h, l, d, iters);
+    launch_smooth<double>(h, l, d, iters);
     h->loaded_d = 0;
     return to_host(h, k, l.x, d, x);
 }
@@ -1259,7 +1373,7 @@ int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, d
     Level& l = h->lv[k];
     if ((rc = to_device(h, k, b, d, l.b))) return rc;
     if ((rc = to_device(h, k, x, d, l.x))) return rc;
-    launch_spmv(h, l, d, 1, l.b, l.x, l.r);
+    launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r);
     h->loaded_d = 0;
     return to_host(h, k, l.r, d, r);
 }
@@ -1272,7 +1386,7 @@ int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y) {
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
     if ((rc = to_device(h, k, x, d, l.x))) return rc;
-    launch_spmv(h, l, d, 0, nullptr, l.x, l.r);
+    launch_spmv<double>(h, l, d, 0, nullptr, l.x, l.r);
     h->loaded_d = 0;
     return to_host(h, k, l.r, d, y);
 }
@@ -1285,7 +1399,7 @@ int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc_out) {
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
     if ((rc = to_device(h, k, r, d, l.r))) return rc;
-    launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b);
+    launch_restrict<double>(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b);
     h->loaded_d = 0;
     return to_host(h, k + 1, h->lv[k + 1].b, d, rc_out);
 }
@@ -1299,7 +1413,7 @@ int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x) {
     Level& l = h->lv[k];
     if ((rc = to_device(h, k + 1, e, d, h->lv[k + 1].x))) return rc;
     if ((rc = to_device(h, k, x, d, l.x))) return rc;
-    launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);
+    launch_prolong_add<double>(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);
     h->loaded_d = 0;
     return to_host(h, k, l.x, d, x);
 }
@@ -1312,8 +1426,8 @@ int gmg_coarse_solve(gmg_handle h, const double* rc_in, int d, double* e) {
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& c = h->lv[h->L];
     if ((rc = to_device(h, h->L, rc_in, d, c.b))) return rc;
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device(h, d);
-    else if ((rc = coarse_host_roundtrip(h, d))) return rc;
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
+    else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
     h->loaded_d = 0;
     return to_host(h, h->L, c.x, d, e);
 }
@@ -1346,6 +1460,7 @@ int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) {
     Level& l = h->lv[0];
     if ((rc = to_device(h, 0, b, d, l.b))) return rc;
     if ((rc = to_device(h, 0, x0, d, l.x))) return rc;
+    if (h->cfg.inner_precision && (rc = launch_residual_to_f32(h, d, -1))) return rc;    // defect of the initial guess -> b32
     HIPCHK(hipStreamSynchronize(h->stream));
     h->loaded_d = d;
     return GMG_OK;
@@ -1480,7 +1595,7 @@ int gmg_dist_smooth_color(gmg_handle h, int c) {
     if (se > sb)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                               l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1));
         }
     return GMG_OK;
@@ -1499,7 +1614,7 @@ int gmg_dist_residual_own(gmg_handle h) {
         if (se <= sb) continue;
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<double, D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                               l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, l.r + (size_t)c0 * ld, ld,
                                               sb, se, 1));
         }
@@ -1513,11 +1628,11 @@ int gmg_dist_coarse_cycle(gmg_handle h) {
     int rc = dist_ready(h);
     if (rc) return rc;
     const int d = h->loaded_d;
-    launch_restrict(h, h->lv[0], h->lv[1], d, h->lv[0].r, h->lv[1].b);
-    enqueue_down(h, d, 1);
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device(h, d);
-    else if ((rc = coarse_host_roundtrip(h, d))) return rc;
-    enqueue_up(h, d, 1);
+    launch_restrict<double>(h, h->lv[0], h->lv[1], d, h->lv[0].r, h->lv[1].b);
+    enqueue_down<double>(h, d, 1);
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
+    else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
+    enqueue_up<double>(h, d, 1);
     return GMG_OK;
 }
 
@@ -1535,7 +1650,7 @@ int gmg_dist_prolong_own(gmg_handle h) {
         if (se <= sb) continue;
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.P.slice_ptr, l.P.col,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<double, D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.P.slice_ptr, l.P.col,
                                               l.P.val, (const int*)nullptr, cl.x + (size_t)c0 * cl.n_pad, cl.n_pad, l.x + (size_t)c0 * l.n_pad, l.n_pad,
                                               sb, se, 1));
         }
@@ -1602,10 +1717,10 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     int launches = 1;
     auto body = [&]() {
         switch (kind) {
-            case 0: launch_smooth(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors; break;
-            case 1: launch_spmv(h, l, d, 1, l.b, l.x, l.r); break;
-            case 2: launch_restrict(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b); break;
-            case 3: launch_prolong_add(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x); break;
+            case 0: launch_smooth<double>(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors; break;
+            case 1: launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r); break;
+            case 2: launch_restrict<double>(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b); break;
+            case 3: launch_prolong_add<double>(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x); break;
             case 4: (void)launch_norm(h, d, 0); launches = 2; break;
             default: break;
         }

@@ -32,14 +32,14 @@ __device__ __forceinline__ int wave_slice(int n_slices_total, int xcd_swizzle) {
 
 // W entries of this lane's row, all loads issued before the first use: W column loads + W value loads in flight,
 // then W*D gathers in flight, then the FMAs in stored order (the accumulation order is that of a plain loop).
-template <int D, int W>
-__device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const double* __restrict__ vp, const double* x, int ld,
-                                              double (&acc)[D]) {
+template <class T, int D, int W>
+__device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const T* __restrict__ vp, const T* x, int ld,
+                                              T (&acc)[D]) {
     int c[W];
-    double v[W];
+    T v[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) { c[j] = __builtin_nontemporal_load(cp + j * 64); v[j] = __builtin_nontemporal_load(vp + j * 64); }
-    double xv[W][D];
+    T xv[W][D];
 #pragma unroll
     for (int j = 0; j < W; ++j)
 #pragma unroll
@@ -53,32 +53,32 @@ __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const 
 // acc[c] = sum_j val[j] * x[col[j] + c*ld] over this lane's row of slice s.  The slice width is wave-uniform, so
 // the dispatch on it is a scalar branch: full groups of 8, then one width-specialised tail (no serialized
 // remainder loop -- with 6-7 entries per mesh row and 3 per prolongation row the tail IS the row).
-template <int D, int G = 8>
+template <class T, int D, int G = 8>
 __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                        const double* __restrict__ val, const double* x, int ld, int s, int lane,
-                                        double (&acc)[D]) {
+                                        const T* __restrict__ val, const T* x, int ld, int s, int lane,
+                                        T (&acc)[D]) {
     const int64_t p0 = slice_ptr[s];
     int w = (int)((slice_ptr[s + 1] - p0) >> 6);
     const int* cp = col + p0 + lane;
-    const double* vp = val + p0 + lane;
+    const T* vp = val + p0 + lane;
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (; w >= G; w -= G, cp += G * 64, vp += G * 64) row_dot_group<D, G>(cp, vp, x, ld, acc);
+    for (; w >= G; w -= G, cp += G * 64, vp += G * 64) row_dot_group<T, D, G>(cp, vp, x, ld, acc);
     switch (w) {                                                   // w < G here
-        case 1: row_dot_group<D, 1>(cp, vp, x, ld, acc); break;
-        case 2: row_dot_group<D, 2>(cp, vp, x, ld, acc); break;
-        case 3: row_dot_group<D, 3>(cp, vp, x, ld, acc); break;
-        case 4: if (G > 4) row_dot_group<D, 4>(cp, vp, x, ld, acc); break;
-        case 5: if (G > 4) row_dot_group<D, 5>(cp, vp, x, ld, acc); break;
-        case 6: if (G > 4) row_dot_group<D, 6>(cp, vp, x, ld, acc); break;
-        case 7: if (G > 4) row_dot_group<D, 7>(cp, vp, x, ld, acc); break;
+        case 1: row_dot_group<T, D, 1>(cp, vp, x, ld, acc); break;
+        case 2: row_dot_group<T, D, 2>(cp, vp, x, ld, acc); break;
+        case 3: row_dot_group<T, D, 3>(cp, vp, x, ld, acc); break;
+        case 4: if (G > 4) row_dot_group<T, D, 4>(cp, vp, x, ld, acc); break;
+        case 5: if (G > 4) row_dot_group<T, D, 5>(cp, vp, x, ld, acc); break;
+        case 6: if (G > 4) row_dot_group<T, D, 6>(cp, vp, x, ld, acc); break;
+        case 7: if (G > 4) row_dot_group<T, D, 7>(cp, vp, x, ld, acc); break;
         default: break;
     }
 }
 
 // Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
-template <int D>
-__device__ __forceinline__ void quad_reduce(double (&acc)[D]) {
+template <class T, int D>
+__device__ __forceinline__ void quad_reduce(T (&acc)[D]) {
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         acc[c] += __shfl_xor(acc[c], 1, 64);
@@ -91,18 +91,18 @@ __device__ __forceinline__ void quad_reduce(double (&acc)[D]) {
 // Rows of one colour do not couple, so the parallel update equals the reference's sequential sweep in
 // the colour-permuted ordering.  FINE tags the level-0 instantiation so that profilers report the dominant
 // (fine-level) launches under their own kernel name.
-template <int D, int FINE>
+template <class T, int D, int FINE>
 __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                   const double* __restrict__ val, const double* __restrict__ diag,
-                                                   const double* __restrict__ b, double* x, int ld, int slice_begin,
+                                                   const T* __restrict__ val, const T* __restrict__ diag,
+                                                   const T* __restrict__ b, T* x, int ld, int slice_begin,
                                                    int slice_end, int xcd_swizzle) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
-    double acc[D];
-    row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
-    const double dg = diag[row];
+    T acc[D];
+    row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    const T dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
 }
@@ -116,20 +116,20 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
 //     Gauss-Seidel inside the block) with __syncthreads() between colours.  Each lane keeps its row's
 //     in-block entries (16-bit local column + value) in registers, loaded before the colour loop, so a
 //     colour step is LDS gathers + FMAs only;
-//   * x_out != x_in (double buffer): other blocks read x_in while this one writes, so the result is
+//   * x_out != x_in (T buffer): other blocks read x_in while this one writes, so the result is
 //     deterministic.
 // In matrix form one sweep is x_out = x_in + T^{-1} (b - A x_in), T = D + strict-lower(A restricted to the
 // block diagonal, device order); tests/test_gpu_parity.py checks exactly that.
 constexpr int kBlockRows = 1024;
-template <int D, int WIN>
+template <class T, int D, int WIN>
 __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
                                                        const unsigned char* __restrict__ row_color,
                                                        const int64_t* __restrict__ in_ptr, const unsigned short* __restrict__ in_col,
-                                                       const double* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
-                                                       const int* __restrict__ out_col, const double* __restrict__ out_val,
-                                                       const double* __restrict__ diag, const double* __restrict__ b,
-                                                       const double* __restrict__ x_in, double* __restrict__ x_out, int ld) {
-    __shared__ double xs[D][kBlockRows];
+                                                       const T* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
+                                                       const int* __restrict__ out_col, const T* __restrict__ out_val,
+                                                       const T* __restrict__ diag, const T* __restrict__ b,
+                                                       const T* __restrict__ x_in, T* __restrict__ x_out, int ld) {
+    __shared__ T xs[D][kBlockRows];
     const int blk = blockIdx.x;
     const int r0 = blk_begin[blk];
     const int nrows = blk_begin[blk + 1] - r0;            // multiple of 64
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const bool active = wave * 64 < nrows;                 // wave-uniform
     const int row = r0 + t;
-    double rhs[D], dg = 1.0;
+    T rhs[D], dg = 1.0;
     int mycolor = -1, w = 0;
     int64_t p0 = 0;
 #pragma unroll
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     // chunks of CH entries (CH independent LDS gathers in flight instead of one wait per entry).  The 16-bit
     // local columns are packed two per register.
     constexpr int CH = D == 1 ? 8 : 4;
-    double v[WIN];
+    T v[WIN];
     unsigned cpk[WIN / 2];
 #pragma unroll
     for (int j = 0; j < WIN; ++j) v[j] = 0.0;
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
                         cpk[j >> 1] |= (unsigned)in_col[p0 + (int64_t)j * 64 + lane] << ((j & 1) * 16);
                     }
             }
-        double acc[D];
-        row_dot<D, (D == 1 ? 8 : 4)>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+        T acc[D];
+        row_dot<T, D, (D == 1 ? 8 : 4)>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
 #pragma unroll
         for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
         dg = 1.0 / diag[row];      // reciprocal once, outside the sequential colour loop
@@ -179,13 +179,13 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     const int nc = blk_ncolors[blk];
     for (int col = 0; col < nc; ++col) {
         if (mycolor == col) {
-            double s_[D];
+            T s_[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) s_[c] = 0.0;
 #pragma unroll
             for (int j0 = 0; j0 < WIN; j0 += CH)
                 if (j0 < w) {
-                    double xv[CH][D];
+                    T xv[CH][D];
 #pragma unroll
                     for (int j = 0; j < CH; ++j) {
                         const int cj = (cpk[(j0 + j) >> 1] >> (((j0 + j) & 1) * 16)) & 0xffff;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
                         for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
                 }
             for (int j = WIN; j < w; ++j) {                 // rows longer than the register window (rare)
-                const double vj = in_val[p0 + (int64_t)j * 64 + lane];
+                const T vj = in_val[p0 + (int64_t)j * 64 + lane];
                 const int cj = in_col[p0 + (int64_t)j * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < D; ++c) s_[c] += vj * xs[c][cj];
@@ -219,15 +219,15 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
 // row is spread over four lanes: each lane keeps <= WQ in-block entries in registers, gathers them from LDS in one
 // batch, and the quad adds its four partial sums with two cross-lane steps.  Same mathematics as gs_block.
 constexpr int kQuadBlockRows = 256;
-template <int D, int WQ>
+template <class T, int D, int WQ>
 __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
                                                         const unsigned char* __restrict__ row_color,
                                                         const int64_t* __restrict__ in_ptr, const unsigned short* __restrict__ in_col,
-                                                        const double* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
-                                                        const int* __restrict__ out_col, const double* __restrict__ out_val,
-                                                        const double* __restrict__ diag, const double* __restrict__ b,
-                                                        const double* __restrict__ x_in, double* __restrict__ x_out, int ld) {
-    __shared__ double xs[D][kQuadBlockRows];
+                                                        const T* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
+                                                        const int* __restrict__ out_col, const T* __restrict__ out_val,
+                                                        const T* __restrict__ diag, const T* __restrict__ b,
+                                                        const T* __restrict__ x_in, T* __restrict__ x_out, int ld) {
+    __shared__ T xs[D][kQuadBlockRows];
     const int blk = blockIdx.x;
     const int r0 = blk_begin[blk];
     const int nrows = blk_begin[blk + 1] - r0;            // multiple of 64, <= 256
@@ -237,12 +237,12 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
     const int lrow = t >> 2;
     const int row = r0 + lrow;
     const bool writer = (t & 3) == 0;
-    double rhs[D], dg = 1.0;
+    T rhs[D], dg = 1.0;
     int mycolor = -1, w = 0;
     int64_t p0 = 0;
 #pragma unroll
     for (int c = 0; c < D; ++c) rhs[c] = 0.0;
-    double v[WQ];
+    T v[WQ];
     unsigned cpk[WQ / 2];
 #pragma unroll
     for (int j = 0; j < WQ; ++j) v[j] = 0.0;
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
                 v[j] = __builtin_nontemporal_load(in_val + p0 + (int64_t)j * 64 + lane);
                 cpk[j >> 1] |= (unsigned)__builtin_nontemporal_load(in_col + p0 + (int64_t)j * 64 + lane) << ((j & 1) * 16);
             }
-        double acc[D];
-        row_dot<D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
-        quad_reduce<D>(acc);
+        T acc[D];
+        row_dot<T, D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+        quad_reduce<T, D>(acc);
 #pragma unroll
         for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
         dg = 1.0 / diag[row];
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
     const int nc = blk_ncolors[blk];
     for (int col = 0; col < nc; ++col) {
         if (mycolor == col) {
-            double s_[D];
-            double xv[WQ][D];
+            T s_[D];
+            T xv[WQ][D];
 #pragma unroll
             for (int j = 0; j < WQ; ++j) {
                 const int cj = (cpk[j >> 1] >> ((j & 1) * 16)) & 0xffff;
@@ -289,12 +289,12 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
 #pragma unroll
                 for (int c = 0; c < D; ++c) s_[c] += v[j] * xv[j][c];
             for (int j = WQ; j < w; ++j) {                  // rows with more than 4*WQ in-block entries (rare)
-                const double vj = in_val[p0 + (int64_t)j * 64 + lane];
+                const T vj = in_val[p0 + (int64_t)j * 64 + lane];
                 const int cj = in_col[p0 + (int64_t)j * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < D; ++c) s_[c] += vj * xs[c][cj];
             }
-            quad_reduce<D>(s_);
+            quad_reduce<T, D>(s_);
             if (writer) {
 #pragma unroll
                 for (int c = 0; c < D; ++c) xs[c][lrow] = (rhs[c] - s_[c]) * dg;
@@ -309,45 +309,45 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
 }
 
 // Weighted Jacobi sweep: x_out = x_in + omega * (b - A x_in) / diag.
-template <int D>
+template <class T, int D>
 __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                       const double* __restrict__ val, const double* __restrict__ diag,
-                                                       const double* __restrict__ b, const double* __restrict__ x_in,
-                                                       double* __restrict__ x_out, int ld, int n_slices, double omega,
+                                                       const T* __restrict__ val, const T* __restrict__ diag,
+                                                       const T* __restrict__ b, const T* __restrict__ x_in,
+                                                       T* __restrict__ x_out, int ld, int n_slices, T omega,
                                                        int xcd_swizzle) {
     const int s = wave_slice(n_slices, xcd_swizzle);
     if (s >= n_slices) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
-    double acc[D];
-    row_dot<D>(slice_ptr, col, val, x_in, ld, s, lane, acc);
-    const double dg = diag[row];
+    T acc[D];
+    row_dot<T, D>(slice_ptr, col, val, x_in, ld, s, lane, acc);
+    const T dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        const double xi = x_in[row + (int64_t)c * ld];
+        const T xi = x_in[row + (int64_t)c * ld];
         x_out[row + (int64_t)c * ld] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
     }
 }
 
 // MODE 0: y = A x      MODE 1: y = b - A x   (gravomg/src/multigrid_solver.cpp:1066)
 // LPR = lanes per row of the SELL layout (1, or 4 on the coarse levels): slices then hold 64 / LPR rows.
-template <int D, int MODE, int LPR>
+template <class T, int D, int MODE, int LPR>
 __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                    const double* __restrict__ val, const double* __restrict__ diag,
-                                                    const double* __restrict__ b, const double* __restrict__ x,
-                                                    double* __restrict__ y, int ld, int slice_begin, int slice_end,
+                                                    const T* __restrict__ val, const T* __restrict__ diag,
+                                                    const T* __restrict__ b, const T* __restrict__ x,
+                                                    T* __restrict__ y, int ld, int slice_begin, int slice_end,
                                                     int xcd_swizzle) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * (64 / LPR) + lane / LPR;
-    double acc[D];
-    row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
-    if (LPR == 4) { quad_reduce<D>(acc); if (lane & 3) return; }
-    const double dg = diag[row];
+    T acc[D];
+    row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
+    const T dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        const double ax = acc[c] + dg * x[row + (int64_t)c * ld];
+        const T ax = acc[c] + dg * x[row + (int64_t)c * ld];
         y[row + (int64_t)c * ld] = MODE == 1 ? b[row + (int64_t)c * ld] - ax : ax;
     }
 }
@@ -356,17 +356,17 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
 //                       ADD = 1: y[out_row] += sum val * x[col]  (prolongation x += U e, :1082)
 // row_of (may be null) maps the slice row to the output row (-1 = none); ldx/ldy are the leading
 // dimensions of the source / destination level.  LPR as in spmv_full.
-template <int D, int ADD, int LPR>
+template <class T, int D, int ADD, int LPR>
 __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                   const double* __restrict__ val, const int* __restrict__ row_of,
-                                                   const double* __restrict__ x, int ldx, double* __restrict__ y, int ldy,
+                                                   const T* __restrict__ val, const int* __restrict__ row_of,
+                                                   const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                    int slice_begin, int slice_end, int xcd_swizzle) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
-    double acc[D];
-    row_dot<D>(slice_ptr, col, val, x, ldx, s, lane, acc);
-    if (LPR == 4) { quad_reduce<D>(acc); if (lane & 3) return; }
+    T acc[D];
+    row_dot<T, D>(slice_ptr, col, val, x, ldx, s, lane, acc);
+    if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const int srow = s * (64 / LPR) + lane / LPR;
     const int row = row_of ? row_of[srow] : srow;
     if (row < 0) return;
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
          s += gridDim.x * kWavesPerBlock) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot<D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll
@@ -439,6 +439,68 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restri
         if (threadIdx.x == 0) out[c] = red[0];
         __syncthreads();
     }
+}
+
+// ---- mixed precision (fp32 inner V-cycle inside an fp64 defect-correction loop, BASELINE config 5) ----------------
+// r = b - A x in fp64 (fine operator, fp64 iterate), written as the fp32 right-hand side of the inner cycle, and the
+// partial sums of the residual norms of the SAME residual (so the check costs no second pass over A).
+template <int D>
+__global__ __launch_bounds__(kBlock) void residual_to_f32_with_norm(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                                    const double* __restrict__ val, const double* __restrict__ diag,
+                                                                    const double* __restrict__ b, const double* __restrict__ x,
+                                                                    const double* __restrict__ weight, int ld, int slice_begin, int slice_end,
+                                                                    float* __restrict__ r32, double* __restrict__ partials) {
+    __shared__ double red[kWavesPerBlock][2 * D];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double sums[2 * D];
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
+    for (int s = slice_begin + __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave); s < slice_end;
+         s += gridDim.x * kWavesPerBlock) {
+        const int row = s * 64 + lane;
+        double acc[D];
+        row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        const double dg = diag[row];
+        const double w = weight ? weight[row] : 1.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double bi = b[row + (int64_t)c * ld];
+            const double r = bi - (acc[c] + dg * x[row + (int64_t)c * ld]);
+            r32[row + (int64_t)c * ld] = (float)r;
+            sums[2 * c] += (r * w) * r;
+            sums[2 * c + 1] += (bi * w) * bi;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) {
+        double v = sums[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        double v = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) v += red[w2][threadIdx.x];
+        partials[(int64_t)blockIdx.x * (2 * D) + threadIdx.x] = v;
+    }
+}
+
+// x (fp64) += e (fp32): the correction of one inner V-cycle
+__global__ void add_correction(const float* __restrict__ e, double* __restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += (double)e[i];
+}
+
+__global__ void cvt_f64_to_f32(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+__global__ void cvt_f32_to_f64(const float* __restrict__ src, double* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (double)src[i];
 }
 
 // Natural (host) numbering <-> device numbering.  src natural: column-major n x D.

@@ -69,6 +69,10 @@ typedef struct {
                               remains the fallback and the specification); needs device_setup = 1 */
     int reorder_fine;      /* locality reordering of the finest level before colouring: 0 never, 1 always, 2 (default)
                               automatic = when the input vertex order has a large bandwidth (random-order scans, point clouds) */
+    int inner_precision;   /* 0 (default): everything in fp64.  1: mixed precision -- the V-cycle runs in fp32 (fp32 copies of all
+                              operators) as the correction operator of an fp64 defect-correction loop: r = b - A x in fp64,
+                              e = Vcycle32(r) from a zero guess, x += e.  Same iteration as the fp64 V-cycle with initial guess
+                              (every stage is affine); the residual check uses the fp64 residual that feeds the next cycle */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
 } gmg_config;

@@ -1,0 +1,75 @@
+"""Mixed precision (BASELINE config 5): fp32 inner V-cycle as the correction operator of an fp64 defect-correction
+loop.  In exact arithmetic vcycle(A, b, x) == x + vcycle(A, b - A x, 0), so the mixed iteration must
+follow the fp64 iteration's residual history until the fp32 unit round-off (~6e-8 relative per correction) matters,
+keep converging beyond it (the residual is always evaluated in fp64), and agree with the CPU oracle."""
+import numpy as np
+import pytest
+
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cabi, P, **kw):
+    out = []
+    for prec in (0, 1):
+        e = cabi.Engine(inner_precision=prec, **kw)
+        e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
+        out.append(e)
+    return out
+
+
+@pytest.mark.parametrize("case", ["smoothing-d3", "smoothing-L3", "bilaplacian"])
+def test_mixed_follows_fp64_history_and_converges(cabi, oracle, case):
+    P = {"smoothing-d3": lambda: problems.torus_problem(64, 60, "smoothing", 60),
+         "smoothing-L3": lambda: problems.torus_problem(96, 80, "smoothing", 30),
+         "bilaplacian": lambda: problems.torus_problem(48, 40, "bilaplacian", 40)}[case]()
+    f64, mix = _pair(cabi, P)
+    # same residual history while the corrections are far above fp32 round-off
+    f64.load_problem(P.rhs, P.rhs); mix.load_problem(P.rhs, P.rhs)
+    h64, h32 = f64.run_cycles(6, 2), mix.run_cycles(6, 2)
+    big = h64 > 1e-5
+    assert big.sum() >= 2
+    np.testing.assert_allclose(h32[big], h64[big], rtol=2e-3)
+    # reference stopping test
+    x64, it64, res64, _ = f64.solve(P.rhs, tol=1e-4)
+    x32, it32, res32, conv = mix.solve(P.rhs, tol=1e-4)
+    if case != "bilaplacian":          # the Bilaplacian V-cycle contracts by ~0.9 per cycle: compare histories, not counts
+        assert res32 <= 1e-4 and abs(it32 - it64) <= 1
+    assert abs(oracle.residual_check(P.lhs, P.mass, P.rhs, x32, 2) - res32) <= 1e-3 * res32 + 1e-7
+    m = P.mass[:, None] if x64.ndim == 2 else P.mass
+    assert np.sqrt((m * (x32 - x64) ** 2).sum() / (m * x64 ** 2).sum()) <= 1e-3
+    # beyond single precision: the outer loop is fp64, so the residual keeps dropping below 1e-7
+    if case.startswith("smoothing"):
+        xt, itt, rest, _ = mix.solve(P.rhs, tol=1e-11, max_iter=60)
+        xr, itr, resr, _ = f64.solve(P.rhs, tol=1e-11, max_iter=60)
+        assert rest <= 1e-11 and itt <= itr + 2
+        assert np.linalg.norm(xt - xr) <= 1e-9 * np.linalg.norm(xr)
+
+
+@pytest.mark.parametrize("kw", [dict(coarse_mode=1), dict(smoother=1), dict(block_rows=0), dict(block_lanes=1, block_rows=256), dict(use_graph=False)],
+                         ids=["device-coarse", "jacobi", "exact-gs", "lane1-blocks", "no-graph"])
+def test_mixed_variants(cabi, kw):
+    P = problems.torus_problem(64, 60, "smoothing", 60)
+    f64, mix = _pair(cabi, P, **kw)
+    x64, it64, res64, _ = f64.solve(P.rhs, tol=1e-8, max_iter=200)
+    x32, it32, res32, _ = mix.solve(P.rhs, tol=1e-8, max_iter=200)
+    assert res32 <= 1e-8 and abs(it32 - it64) <= 2
+    assert np.linalg.norm(x32 - x64) <= 1e-6 * np.linalg.norm(x64)
+    # single-cycle entry point: x + V32(b - A x) vs the fp64 cycle
+    a, b = f64.vcycle(P.rhs, P.rhs), mix.vcycle(P.rhs, P.rhs)
+    assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(a)
+
+
+def test_mixed_on_nearly_singular_poisson_still_converges(cabi, oracle):
+    """lhs = 1e-6 M + S: tau*M is ~1e-12 of the stiffness entries, below fp32 resolution, so the fp32 operators lose the
+    regularisation that fixes the constant mode.  The fp64 outer loop still drives the true residual to the tolerance
+    (the coarsest solve and the defect are fp64), only with more cycles -- mixed precision is meant for the
+    well-conditioned smoothing / Bilaplacian systems (config 5), the Poisson headline stays fp64."""
+    P = problems.torus_problem(96, 80, "poisson", 30)
+    f64, mix = _pair(cabi, P)
+    x64, it64, res64, _ = f64.solve(P.rhs, tol=1e-4)
+    x32, it32, res32, conv = mix.solve(P.rhs, tol=1e-4, max_iter=100)
+    assert res32 <= 1e-4 and it64 <= it32 <= 6 * it64
+    assert np.all(np.diff(conv[1:, 1]) < 0)
+    assert abs(oracle.residual_check(P.lhs, P.mass, P.rhs, x32, 2) - res32) <= 1e-3 * res32 + 1e-7
