@@ -119,6 +119,7 @@ public:
 
     long factor_nnz() const { return (long)Lp.empty() ? 0 : Lp[n]; }
 
+    static constexpr int kLeaf = 320;             // nested dissection stops at regions of this size
     static constexpr int kMinDegreeMax = 2500;    // up to here the exact minimum-degree ordering (quadratic, but overlapped with the rest of the setup) gives ~6 % less fill
 
 private:
@@ -139,7 +140,12 @@ private:
         while (!stack.empty()) {
             Item it = std::move(stack.back());
             stack.pop_back();
-            if (it.emit || (int)it.nodes.size() <= 48) { for (auto r = it.nodes.rbegin(); r != it.nodes.rend(); ++r) out_rev.push_back(*r); continue; }
+            if (it.emit) { for (auto r = it.nodes.rbegin(); r != it.nodes.rend(); ++r) out_rev.push_back(*r); continue; }
+            if ((int)it.nodes.size() <= kLeaf) {      // leaf region: exact minimum degree on its own subgraph
+                std::vector<int> ord = leaf_min_degree(A, it.nodes, region, it.id);
+                for (auto r = ord.rbegin(); r != ord.rend(); ++r) out_rev.push_back(*r);
+                continue;
+            }
             const int id = it.id;
             auto bfs = [&](int start) {      // levels inside region `id`; returns the visit order in `queue`
                 queue.clear(); queue.push_back(start); level[start] = 0;
@@ -183,6 +189,42 @@ private:
             stack.push_back({std::move(sep), -1, true});
         }
         perm.assign(out_rev.rbegin(), out_rev.rend());
+    }
+
+    // Exact minimum degree restricted to the vertices of one region (ids local to `nodes`).
+    static std::vector<int> leaf_min_degree(const Compressed& A, const std::vector<int>& nodes, const std::vector<int>& region, int id) {
+        const int m = (int)nodes.size();
+        std::vector<int> local(m);
+        std::vector<std::pair<int, int>> key(m);
+        for (int i = 0; i < m; ++i) key[i] = {nodes[i], i};
+        std::sort(key.begin(), key.end());
+        auto find = [&](int g) { auto it = std::lower_bound(key.begin(), key.end(), std::make_pair(g, -1)); return it->second; };
+        std::vector<std::vector<int>> adj(m);
+        for (int i = 0; i < m; ++i) {
+            const int g = nodes[i];
+            for (int p = A.ptr[g]; p < A.ptr[g + 1]; ++p) { int w = A.idx[p]; if (w != g && region[w] == id) adj[i].push_back(find(w)); }
+            std::sort(adj[i].begin(), adj[i].end());
+            adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+        }
+        std::vector<char> done(m, 0);
+        std::vector<int> out, merged;
+        out.reserve(m);
+        for (int step = 0; step < m; ++step) {
+            int v = -1; size_t best = ~(size_t)0;
+            for (int j = 0; j < m; ++j) if (!done[j] && adj[j].size() < best) { best = adj[j].size(); v = j; }
+            done[v] = 1;
+            out.push_back(nodes[v]);
+            const std::vector<int>& nv = adj[v];
+            for (int u : nv) {
+                merged.clear();
+                std::set_union(adj[u].begin(), adj[u].end(), nv.begin(), nv.end(), std::back_inserter(merged));
+                std::vector<int>& au = adj[u];
+                au.clear();
+                for (int w : merged) if (w != u && w != v) au.push_back(w);
+            }
+            adj[v].clear();
+        }
+        return out;
     }
 
     // Minimum-degree ordering on the explicit elimination graph (exact but quadratic: small n only).

@@ -41,7 +41,50 @@ def build(cfg):
         S, mass = meshgen.cotan_laplacian(V, F)
         lhs, rhs = meshgen.poisson_system(S, mass)
         return f"cfg4 torus 1732x1732 Poisson d=1 ({'random' if cfg == '4r' else 'natural'} vertex order)", V, S, mass, lhs, rhs
+    if cfg in ("5", "5b"):   # Bilaplacian data smoothing M + tau S M^-1 S on the ~3 M mesh, mixed precision (fp32 inner V-cycle)
+        tau = 1e-3 if cfg == "5" else 1e-9       # 1e-3: the reference's smoothing parameter (comparison_smoothing.sh:2-3)
+        V, F = meshgen.torus_mesh(1732, 1732)
+        S, mass = meshgen.cotan_laplacian(V, F)
+        lhs, rhs = meshgen.smoothing_system(meshgen.bilaplacian(S, mass), mass, V[:, :1], tau=tau)
+        return f"cfg5 torus 1732x1732 Bilaplacian smoothing tau={tau:g} d=1, mixed precision", V, S, mass, lhs, rhs
     raise ValueError(cfg)
+
+
+def run_bilaplacian(name, H, mass, lhs, rhs, t_build, t_hier):
+    """Config 5: the reference V-cycle contracts slowly on 4th-order operators (factor ~0.9+ per cycle), so
+    parity is 'same residual history as the fp64 path / the CPU restatement after N cycles' plus time per cycle."""
+    from oracle import oracle
+    rec = {"config": name, "n": int(lhs.shape[0]), "nnz": int(lhs.nnz), "d": int(rhs.shape[1]), "checks": {}}
+    hist = {}
+    for label, prec in (("fp64", 0), ("mixed", 1)):
+        eng = cabi.Engine(inner_precision=prec)
+        eng.use_hierarchy(H); eng.set_mass(mass)
+        t = time.perf_counter(); eng.set_system(lhs); rec[f"set_system_ms_{label}"] = 1e3 * (time.perf_counter() - t)
+        eng.load_problem(rhs, rhs)
+        hist[label] = eng.run_cycles(12, 2)
+        eng.load_problem(rhs, rhs); eng.run_cycles(3, 2)
+        t = time.perf_counter(); eng.run_cycles(10, 2); rec[f"ms_per_cycle_{label}"] = 1e2 * (time.perf_counter() - t)
+        if prec == 1:
+            x = eng.fetch_solution()
+            rec["checks"]["oracle_residual_check_of_mixed_iterate"] = oracle.residual_check(lhs, mass, rhs, x, 2)
+        rec["levels"] = [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)]
+        del eng
+    rec["history_fp64"] = [float(v) for v in hist["fp64"]]
+    rec["history_mixed"] = [float(v) for v in hist["mixed"]]
+    rec["checks"]["mixed_history_matches_fp64"] = bool(np.allclose(hist["mixed"], hist["fp64"], rtol=2e-3))
+    rec["history_contracts"] = bool(np.all(np.diff(hist["mixed"]) < 0))     # informational: see the oracle's own history
+    O = oracle.Hierarchy(H.U, mass)
+    t = time.perf_counter(); O.set_system(lhs)
+    xo, ito, reso, convo = O.solve(rhs, tol=0.0, max_iter=3)
+    rec["oracle"] = {"history": [float(v) for v in convo[:, 1]], "total_s": time.perf_counter() - t, "ms_per_cycle": float(convo[-1, 0] / ito)}
+    # lexicographic (oracle) vs multicolour (GPU) Gauss-Seidel: same smoother class, different sweep order.  With the
+    # reference's tau = 1e-3 the reference algorithm itself does not contract on this mesh (the oracle's residual GROWS
+    # from x0 = rhs); parity is "same behaviour": same trend, same magnitude within a factor 2.
+    ratio = hist["fp64"][:3] / convo[:, 1]
+    rec["checks"]["oracle_same_magnitude"] = bool(np.all((ratio > 0.5) & (ratio < 2.0)))
+    rec["checks"]["oracle_same_trend"] = bool(np.sign(hist["fp64"][2] - hist["fp64"][0]) == np.sign(convo[2, 1] - convo[0, 1]))
+    rec["hierarchy_s"], rec["input_build_s"] = t_hier, t_build
+    return rec
 
 
 def main():
@@ -58,6 +101,11 @@ def main():
         t = time.perf_counter()
         H = cabi.Hierarchy(pos, neigh)
         t_hier = time.perf_counter() - t
+        if cfg in ("5", "5b"):
+            rec = run_bilaplacian(name, H, mass, lhs, rhs, t_build, t_hier)
+            print(json.dumps(rec), flush=True)
+            out.append(rec)
+            continue
         eng = cabi.Engine()
         eng.use_hierarchy(H)
         eng.set_mass(mass)
