@@ -268,3 +268,25 @@ def test_errors_are_loud(cabi):
     eng.set_system(P.lhs)
     with pytest.raises(cabi.GmgError):
         eng.residual_norm(P.rhs, P.rhs, 2)                       # mass not set
+
+
+def test_more_than_four_right_hand_sides(cabi, oracle):
+    """d > 4 is processed in column chunks of <= 4 (the reference is only safe for d in {1, 3})."""
+    P = problems.torus_problem(64, 60, "smoothing", 60)
+    rng = np.random.default_rng(11)
+    B = P.mass[:, None] * rng.standard_normal((P.n, 6))
+    eng = cabi.Engine()
+    eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    A = eng.level_operator(0)
+    X = rng.standard_normal((P.n, 6))
+    assert rel(eng.spmv(0, X), A @ X) <= 1e-13
+    assert rel(eng.residual(0, B, X), B - A @ X) <= 1e-13
+    assert rel(eng.restrict(0, X), P.U[0].T @ X) <= 1e-13
+    x, it, res, _ = eng.solve(B, tol=1e-8)
+    assert res <= 1e-8
+    for t in (0, 2, 3):
+        assert abs(eng.residual_norm(B, x, t) - oracle.residual_check(P.lhs, P.mass, B, x, t)) <= 1e-6 * oracle.residual_check(P.lhs, P.mass, B, x, t) + 1e-14
+    # each column is solved as if alone: same answer as a d = 1 solve of that column
+    x1, _, _, _ = eng.solve(B[:, 4], tol=1e-10)
+    xa, _, _, _ = eng.solve(B, tol=1e-10)
+    assert rel(xa[:, 4], x1) <= 1e-7
