@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--block-rows", type=int, default=None, help="block-hybrid GS rows per block (engine default if unset)")
     ap.add_argument("--block-from-level", type=int, default=None)
     ap.add_argument("--block-lanes", type=int, default=None)
+    ap.add_argument("--no-variants", action="store_true", help="skip the informational device-coarse-apply timing")
     ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU code path even with one rank")
     args = ap.parse_args()
 
@@ -104,6 +105,7 @@ def main():
         from gravo_mg_amd import dist_bench
         return dist_bench.main(args)
 
+    import numpy as np
     import torch
     from gravo_mg_amd import cabi
 
@@ -164,6 +166,24 @@ def main():
         "other_fine_kernels": kern,
     }
 
+    # ---- informational variant (never `value`): the coarsest solve applied on the device ----
+    variants = {}
+    if args.coarse == "host" and not args.no_variants:
+        del eng
+        eng2 = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE, use_graph=not args.no_graph, **kw)
+        eng2.use_hierarchy(H)
+        eng2.set_mass(mass)
+        eng2.set_system(lhs)
+        eng2.load_problem(rhs, rhs)
+        eng2.run_cycles(args.warmup, 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res2 = eng2.run_cycles(args.steps, 2)
+        torch.cuda.synchronize()
+        variants["device_coarse_apply"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / args.steps,
+                                           "residues_match_host_mode": bool(np.allclose(res2, residues, rtol=1e-6))}
+        del eng2
+
     cpu = cpu_baseline(H, mass, lhs, rhs, args.cpu_cycles) if args.cpu_cycles > 0 else None
 
     out = {
@@ -177,6 +197,7 @@ def main():
         "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms, "solver_timing_ms": timing,
         "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
         "timed_residues_tail": [float(r) for r in residues[-3:]],
+        "variants": variants,
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -165,3 +165,30 @@ def bilaplacian(S, mass):
     B = (S @ sp.diags(1.0 / mass) @ S).tocsc()
     B.sort_indices()
     return B
+
+
+def sphere_mesh(n: int, seed: int = 3, order: str = "spatial"):
+    """Irregular triangle mesh: n random points on the unit sphere, triangulated by their convex hull (valence 3..12,
+    mean 6).  order "spatial" sorts the vertices along a Morton curve of their coordinates (scanner-like locality);
+    "random" keeps the random order.  Area-normalised and centred like the torus meshes."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(seed)
+    P = rng.standard_normal((n, 3))
+    P /= np.linalg.norm(P, axis=1, keepdims=True)
+    if order == "spatial":
+        q = np.clip(((P + 1.0) * 0.5 * 1023).astype(np.int64), 0, 1023)
+        key = np.zeros(n, np.int64)
+        for b in range(10):
+            for a in range(3):
+                key |= ((q[:, a] >> b) & 1) << (3 * b + a)
+        P = P[np.argsort(key, kind="stable")]
+    elif order != "random":
+        raise ValueError(order)
+    hull = ConvexHull(P)
+    F = hull.simplices.astype(np.int32)
+    # consistent outward orientation (hull simplices are unordered)
+    c = P[F].mean(axis=1)
+    nrm = np.cross(P[F[:, 1]] - P[F[:, 0]], P[F[:, 2]] - P[F[:, 0]])
+    flip = np.einsum("ij,ij->i", nrm, c) < 0
+    F[flip] = F[flip][:, [0, 2, 1]]
+    return normalize_area(P, F), F

@@ -47,6 +47,11 @@ def build(cfg):
         S, mass = meshgen.cotan_laplacian(V, F)
         lhs, rhs = meshgen.smoothing_system(meshgen.bilaplacian(S, mass), mass, V[:, :1], tau=tau)
         return f"cfg5 torus 1732x1732 Bilaplacian smoothing tau={tau:g} d=1, mixed precision", V, S, mass, lhs, rhs
+    if cfg == "6":      # irregular-valence mesh (random points on a sphere, hull triangulation): 7 colours, ragged rows
+        V, F = meshgen.sphere_mesh(1_000_000)
+        S, mass = meshgen.cotan_laplacian(V, F)
+        lhs, rhs = meshgen.poisson_system(S, mass)
+        return "cfg6 irregular sphere 1M Poisson d=1 (valence 3..13)", V, S, mass, lhs, rhs
     raise ValueError(cfg)
 
 

@@ -45,6 +45,17 @@ def pointcloud_problem(n=3000, k=8, lower_bound=80):
     return Problem(P, S, mass, H.U, lhs, rhs, f"pointcloud{n}")
 
 
+@functools.lru_cache(maxsize=None)
+def sphere_problem(n=6000, lower_bound=80, order="spatial"):
+    """Irregular-valence mesh (random points on a sphere, convex-hull triangulation): 6-8 colours, ragged rows."""
+    V, F = meshgen.sphere_mesh(n, order=order)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    H = cabi.Hierarchy(V, neigh, lower_bound=lower_bound)
+    lhs, rhs = meshgen.poisson_system(S, mass)
+    return Problem(V, S, mass, H.U, lhs, rhs, f"sphere{n}-{order}")
+
+
 def permuted_system(A, new2old):
     """P A P^T restricted to the real rows of a device ordering (padding rows dropped)."""
     order = new2old[new2old >= 0]

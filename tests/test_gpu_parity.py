@@ -23,7 +23,7 @@ def rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
 
 
-@pytest.fixture(scope="module", params=["poisson-d1", "smoothing-d3", "pointcloud", "random-order"])
+@pytest.fixture(scope="module", params=["poisson-d1", "smoothing-d3", "pointcloud", "random-order", "irregular-sphere"])
 def setup(request, cabi):
     if request.param == "poisson-d1":
         P = problems.torus_problem(96, 80, "poisson", 30)          # 7680 -> ~1250 -> ~200 -> ~33: L = 3
@@ -31,6 +31,8 @@ def setup(request, cabi):
         P = problems.torus_problem(64, 60, "smoothing", 60)        # L = 2, d = 3
     elif request.param == "pointcloud":
         P = problems.pointcloud_problem(3000)
+    elif request.param == "irregular-sphere":
+        P = problems.sphere_problem(6000)                           # valence 3..12, 7 colours
     else:
         P = problems.torus_problem(48, 40, "poisson", 60, order="random")
     assert cabi.device_count() > 0, "gpu tests need a HIP device"
