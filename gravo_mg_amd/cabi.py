@@ -168,6 +168,18 @@ def _f64(a, shape2d: bool = True) -> np.ndarray:
     return np.asfortranarray(a)
 
 
+def _csc_layout(m) -> sp.csc_matrix:
+    """CSC with int32 indices and float64 values, without the (single-threaded) canonical-format passes of _csc."""
+    m = m if sp.isspmatrix_csc(m) else sp.csc_matrix(m)
+    if m.indptr.dtype != np.int32 or m.indices.dtype != np.int32:
+        if m.nnz >= 2**31:
+            raise ValueError("matrix too large for int32 indices")
+        m = sp.csc_matrix((m.data, m.indices.astype(np.int32), m.indptr.astype(np.int32)), shape=m.shape)
+    if m.data.dtype != np.float64:
+        m = m.astype(np.float64)
+    return m
+
+
 def _csc(m) -> sp.csc_matrix:
     m = sp.csc_matrix(m)
     if not m.has_sorted_indices:
@@ -301,7 +313,7 @@ class Engine:
         self._chk(lib().gmg_set_mass(self._h, m.shape[0], _pd(m)))
 
     def set_system(self, lhs):
-        a = _csc(lhs)
+        a = _csc_layout(lhs)        # the engine checks (threaded) and canonicalises the storage itself
         if a.shape[0] != a.shape[1]:
             raise ValueError("lhs must be square")
         self._chk(lib().gmg_set_system(self._h, a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data)))

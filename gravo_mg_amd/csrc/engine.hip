@@ -15,6 +15,7 @@
 #include <functional>
 #include <future>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -32,6 +33,47 @@ using namespace gmg;
 using clk = std::chrono::steady_clock;
 static inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
+// ---- device memory pool (per handle) ------------------------------------------------------------------------
+// hipFree costs ~0.2 ms and synchronises the device; a setup allocates and releases ~100 arrays.  Blocks released
+// by a handle are parked in its pool and handed out again (same stream => stream order makes the reuse safe); the
+// pool is emptied when the handle is destroyed or when the parked bytes exceed what is in use.
+struct DevPool {
+    std::multimap<size_t, void*> parked;
+    std::map<void*, size_t> size_of;      // every block this pool handed out (live or parked)
+    size_t parked_bytes = 0, live_bytes = 0;
+    static size_t round_up(size_t b) { return (std::max<size_t>(b, 1) + 511) & ~(size_t)511; }
+    hipError_t alloc(void** p, size_t bytes) {
+        const size_t need = round_up(bytes);
+        auto it = parked.lower_bound(need);
+        if (it != parked.end() && it->first <= need + need / 8 + 65536) {
+            *p = it->second; parked_bytes -= it->first; live_bytes += it->first; parked.erase(it);
+            return hipSuccess;
+        }
+        hipError_t e = hipMalloc(p, need);
+        if (e != hipSuccess) { trim(); (void)hipGetLastError(); e = hipMalloc(p, need); }
+        if (e == hipSuccess) { size_of[*p] = need; live_bytes += need; }
+        return e;
+    }
+    void release(void* p) {
+        auto it = size_of.find(p);
+        if (it == size_of.end()) { (void)hipFree(p); return; }          // not ours (allocated outside a pool scope)
+        parked.emplace(it->second, p); parked_bytes += it->second; live_bytes -= std::min(live_bytes, it->second);
+        if (parked_bytes > std::max<size_t>(live_bytes, (size_t)2 << 30)) trim();
+    }
+    void trim() {
+        for (auto& kv : parked) { (void)hipFree(kv.second); size_of.erase(kv.second); }
+        parked.clear(); parked_bytes = 0;
+    }
+};
+static thread_local DevPool* tl_pool = nullptr;     // set for the duration of a C-ABI call on a handle (PoolScope)
+struct PoolScope {
+    DevPool* prev;
+    explicit PoolScope(DevPool* p) : prev(tl_pool) { tl_pool = p; }
+    ~PoolScope() { tl_pool = prev; }
+};
+static inline hipError_t dev_malloc(void** p, size_t bytes) { return tl_pool ? tl_pool->alloc(p, bytes) : hipMalloc(p, bytes); }
+static inline hipError_t dev_free(void* p) { if (!p) return hipSuccess; if (tl_pool) { tl_pool->release(p); return hipSuccess; } return hipFree(p); }
+
 namespace {
 
 struct DevSell {
@@ -45,10 +87,27 @@ struct DevSell {
     int* row_of = nullptr;
 };
 
+// natural-numbering compressed matrix on the device (A_k, U_k by coarse column)
+struct DevCsr {
+    int n_outer = 0;
+    int *ptr = nullptr, *idx = nullptr;
+    double* val = nullptr;
+};
+
+// U_k regrouped by fine row (<= 3 entries per row, sorted by coarse column) for the prolongation layout and the RAP.
+struct DevEll3 {
+    int n = 0;
+    int *cnt = nullptr, *col = nullptr;
+    double* val = nullptr;
+};
+
 struct Level {
     int n = 0, n_pad = 0;
+    int64_t nnz = 0;              // entries of A_k
     LevelOrdering ord;
-    Compressed A;                 // natural numbering, host copy (Abar[k])
+    Compressed A;                 // natural numbering, host copy (Abar[k]); filled on demand (ensure_host_A) except on level L
+    bool hostA_pattern = false, hostA_values = false;
+    DevCsr dA;                    // natural numbering, device copy: RAP input, layout source, source of the lazy host copy
     DevSell Aoff;                 // off-diagonal part, device numbering
     double* diag = nullptr;       // n_pad
     DevSell P, R;                 // U_k (rows: this level) and U_k^T (rows: next level); unused on level L
@@ -69,6 +128,7 @@ struct gmg_hierarchy_s {
 };
 
 struct gmg_solver_s {
+    DevPool pool;
     gmg_config cfg;
     std::string err;
     bool has_device = false;
@@ -76,6 +136,10 @@ struct gmg_solver_s {
     int L = -1;
     std::vector<Compressed> U;
     std::vector<char> U_set;
+    std::vector<DevCsr> dU;               // device copies of U_k (kept while the hierarchy is unchanged)
+    std::vector<DevEll3> dE3;             // and their by-row regrouping
+    bool dU_ready = false;
+    bool dU_flagged = false;              // ell3_from_csc found a U row with more than 3 entries (host paths only)
     std::vector<double> mass;
     std::vector<Level> lv;
     SparseLDLT coarse;
@@ -121,35 +185,36 @@ int fail(gmg_handle h, int code, const std::string& msg) {
     } while (0)
 
 #define NEED_DEVICE()                                                                     \
+    if (!h) return GMG_ERR_INVALID;                                                       \
+    PoolScope pool_scope_(&h->pool);                                                      \
     do {                                                                                  \
-        if (!h) return GMG_ERR_INVALID;                                                   \
         if (!h->has_device) return fail(h, GMG_ERR_NO_DEVICE, "no usable HIP device (libgravomg_hip has no CPU fallback)"); \
     } while (0)
 
 template <class T>
 int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
-    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(hipMalloc((void**)dst, bytes));
+    HIPCHK(dev_malloc((void**)dst, bytes));
     if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
     return GMG_OK;
 }
 
 template <class T>
 int upload(gmg_handle h, T** dst, const RawVec<T>& src) {
-    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(hipMalloc((void**)dst, bytes));
+    HIPCHK(dev_malloc((void**)dst, bytes));
     if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
     return GMG_OK;
 }
 
 void free_sell(DevSell& s) {
-    if (s.slice_ptr) (void)hipFree(s.slice_ptr);
-    if (s.col) (void)hipFree(s.col);
-    if (s.val) (void)hipFree(s.val);
-    if (s.val32) (void)hipFree(s.val32);
-    if (s.row_of) (void)hipFree(s.row_of);
+    if (s.slice_ptr) (void)dev_free(s.slice_ptr);
+    if (s.col) (void)dev_free(s.col);
+    if (s.val) (void)dev_free(s.val);
+    if (s.val32) (void)dev_free(s.val32);
+    if (s.row_of) (void)dev_free(s.row_of);
     s = DevSell();
 }
 
@@ -164,15 +229,37 @@ int upload_sell(gmg_handle h, DevSell& d, const SellHost& s) {
     return GMG_OK;
 }
 
+void free_csr(DevCsr& m) {
+    if (m.ptr) (void)dev_free(m.ptr);
+    if (m.idx) (void)dev_free(m.idx);
+    if (m.val) (void)dev_free(m.val);
+    m = DevCsr();
+}
+
+void free_ell3(DevEll3& e) {
+    if (e.cnt) (void)dev_free(e.cnt);
+    if (e.col) (void)dev_free(e.col);
+    if (e.val) (void)dev_free(e.val);
+    e = DevEll3();
+}
+
+void drop_device_transfers(gmg_handle h) {
+    for (auto& m : h->dU) free_csr(m);
+    for (auto& e : h->dE3) free_ell3(e);
+    h->dU.clear(); h->dE3.clear();
+    h->dU_ready = false;
+}
+
 void free_level(Level& l) {
+    free_csr(l.dA);
     free_sell(l.Aoff); free_sell(l.P); free_sell(l.R); free_sell(l.Ain); free_sell(l.Aout);
-    if (l.ain_col16) { (void)hipFree(l.ain_col16); l.ain_col16 = nullptr; }
-    if (l.d_blk_begin) { (void)hipFree(l.d_blk_begin); l.d_blk_begin = nullptr; }
-    if (l.d_blk_ncolors) { (void)hipFree(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
-    if (l.d_row_color) { (void)hipFree(l.d_row_color); l.d_row_color = nullptr; }
-    for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    if (l.d_new2old) { (void)hipFree(l.d_new2old); l.d_new2old = nullptr; }
+    if (l.ain_col16) { (void)dev_free(l.ain_col16); l.ain_col16 = nullptr; }
+    if (l.d_blk_begin) { (void)dev_free(l.d_blk_begin); l.d_blk_begin = nullptr; }
+    if (l.d_blk_ncolors) { (void)dev_free(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
+    if (l.d_row_color) { (void)dev_free(l.d_row_color); l.d_row_color = nullptr; }
+    for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)dev_free(*p); *p = nullptr; }
+    for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)dev_free(*p); *p = nullptr; }
+    if (l.d_new2old) { (void)dev_free(l.d_new2old); l.d_new2old = nullptr; }
 }
 
 void drop_graphs(gmg_handle h) {
@@ -194,27 +281,14 @@ void drop_system(gmg_handle h) {
     h->system_ready = false;
     h->dcap = 0;
     h->loaded_d = 0;
-    if (h->d_mass) { (void)hipFree(h->d_mass); h->d_mass = nullptr; }
-    if (h->d_minv) { (void)hipFree(h->d_minv); h->d_minv = nullptr; }
-    if (h->d_ainv) { (void)hipFree(h->d_ainv); h->d_ainv = nullptr; }
+    if (h->d_mass) { (void)dev_free(h->d_mass); h->d_mass = nullptr; }
+    if (h->d_minv) { (void)dev_free(h->d_minv); h->d_minv = nullptr; }
+    if (h->d_ainv) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
 }
 
 constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
 
 // ---- device-side layout construction (setup_kernels.hip.hpp) ------------------------------------------------
-struct DevCsr {
-    int n_outer = 0;
-    int *ptr = nullptr, *idx = nullptr;
-    double* val = nullptr;
-};
-
-void free_csr(DevCsr& m) {
-    if (m.ptr) (void)hipFree(m.ptr);
-    if (m.idx) (void)hipFree(m.idx);
-    if (m.val) (void)hipFree(m.val);
-    m = DevCsr();
-}
-
 int upload_csr(gmg_handle h, DevCsr& d, const Compressed& m) {
     free_csr(d);
     d.n_outer = m.n_outer;
@@ -227,9 +301,9 @@ int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const i
     free_csr(d);
     d.n_outer = n_outer;
     const size_t nnz = (size_t)ptr[n_outer];
-    HIPCHK(hipMalloc((void**)&d.ptr, sizeof(int) * ((size_t)n_outer + 1)));
-    HIPCHK(hipMalloc((void**)&d.idx, sizeof(int) * std::max<size_t>(nnz, 1)));
-    HIPCHK(hipMalloc((void**)&d.val, sizeof(double) * std::max<size_t>(nnz, 1)));
+    HIPCHK(dev_malloc((void**)&d.ptr, sizeof(int) * ((size_t)n_outer + 1)));
+    HIPCHK(dev_malloc((void**)&d.idx, sizeof(int) * std::max<size_t>(nnz, 1)));
+    HIPCHK(dev_malloc((void**)&d.val, sizeof(double) * std::max<size_t>(nnz, 1)));
     HIPCHK(hipMemcpyAsync(d.ptr, ptr, sizeof(int) * ((size_t)n_outer + 1), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d.idx, idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(d.val, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
@@ -237,11 +311,26 @@ int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const i
 }
 
 template <class T>
-struct DevTmp {                       // scratch device array freed at scope exit
+struct DevTmp {                       // scratch device array released at scope exit (stream-ordered reuse through the pool)
     T* p = nullptr;
-    ~DevTmp() { if (p) (void)hipFree(p); }
-    int alloc(gmg_handle h, size_t n) { HIPCHK(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return GMG_OK; }
+    ~DevTmp() { if (p) (void)dev_free(p); }
+    int alloc(gmg_handle h, size_t n) { HIPCHK(dev_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return GMG_OK; }
 };
+
+// out[0..n] = exclusive prefix sums of in[0..n) on the stream; *total_host (pinned or pageable) receives out[n] after
+// the caller synchronises.
+template <class TIn, class TOut>
+int device_scan(gmg_handle h, const TIn* in, int n, TOut* out, TOut* total_host) {
+    const int tiles = std::max(1, (n + gmgs::kScanTile - 1) / gmgs::kScanTile);
+    DevTmp<TOut> tile;
+    int rc;
+    if ((rc = tile.alloc(h, (size_t)tiles + 1))) return rc;
+    hipLaunchKernelGGL((gmgs::scan_tile_sums<TIn, TOut>), dim3(tiles), dim3(256), 0, h->stream, in, n, tile.p);
+    hipLaunchKernelGGL((gmgs::scan_tile_offsets<TOut>), dim3(1), dim3(1024), 0, h->stream, tile.p, tiles, tile.p + tiles);
+    hipLaunchKernelGGL((gmgs::scan_tile_apply<TIn, TOut>), dim3(tiles), dim3(256), 0, h->stream, in, n, (const TOut*)tile.p, out);
+    if (total_host) HIPCHK(hipMemcpyAsync(total_host, tile.p + tiles, sizeof(TOut), hipMemcpyDeviceToHost, h->stream));
+    return GMG_OK;
+}
 
 // Builds one SELL matrix on the device.  pbeg/pend/idx/val: source rows (natural numbering); f: row/column maps and
 // filter; d_order: optional slice-position -> device-row map (uploaded by the caller; also stored as row_of);
@@ -256,162 +345,266 @@ int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pe
     DevTmp<int64_t> widths;
     int rc;
     if ((rc = len.alloc(h, n_rows_pad)) || (rc = widths.alloc(h, out.n_slices))) return rc;
+    HIPCHK(dev_malloc((void**)&out.slice_ptr, sizeof(int64_t) * ((size_t)out.n_slices + 1)));
     hipLaunchKernelGGL(gmgs::row_lengths, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, f, d_order, n_rows_pad, len.p, d_err);
     hipLaunchKernelGGL(gmgs::slice_widths, dim3((out.n_slices + 255) / 256), dim3(256), 0, h->stream, len.p, lpr, out.n_slices, widths.p);
-    std::vector<int64_t> sp((size_t)out.n_slices + 1, 0);
-    HIPCHK(hipMemcpyAsync(sp.data() + 1, widths.p, sizeof(int64_t) * out.n_slices, hipMemcpyDeviceToHost, h->stream));
+    int64_t total = 0;
+    if ((rc = device_scan<int64_t, int64_t>(h, widths.p, out.n_slices, out.slice_ptr, &total))) return rc;
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int i = 0; i < out.n_slices; ++i) sp[i + 1] += sp[i];
-    out.stored = sp[out.n_slices];
-    if ((rc = upload(h, &out.slice_ptr, sp))) return rc;
-    HIPCHK(hipMalloc((void**)&out.val, std::max<int64_t>(out.stored, 1) * sizeof(double)));
+    out.stored = total;
+    HIPCHK(dev_malloc((void**)&out.val, std::max<int64_t>(out.stored, 1) * sizeof(double)));
     if (col16_out) {
-        if (*col16_out) { (void)hipFree(*col16_out); *col16_out = nullptr; }
-        HIPCHK(hipMalloc((void**)col16_out, std::max<int64_t>(out.stored, 1) * sizeof(unsigned short)));
+        if (*col16_out) { (void)dev_free(*col16_out); *col16_out = nullptr; }
+        HIPCHK(dev_malloc((void**)col16_out, std::max<int64_t>(out.stored, 1) * sizeof(unsigned short)));
         hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
                            n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
     } else {
-        HIPCHK(hipMalloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
+        HIPCHK(dev_malloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
         hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
                            out.slice_ptr, out.col, out.val, d_diag, d_err);
     }
-    HIPCHK(hipStreamSynchronize(h->stream));      // sp (host) is read by the async upload
     return GMG_OK;
-}
-
-// U_k regrouped by fine row (<= 3 entries per row, sorted by coarse column) for the prolongation layout and the RAP.
-struct DevEll3 {
-    int n = 0;
-    int *cnt = nullptr, *col = nullptr;
-    double* val = nullptr;
-};
-
-void free_ell3(DevEll3& e) {
-    if (e.cnt) (void)hipFree(e.cnt);
-    if (e.col) (void)hipFree(e.col);
-    if (e.val) (void)hipFree(e.val);
-    e = DevEll3();
 }
 
 int build_ell3(gmg_handle h, DevEll3& e, const DevCsr& dU, int n_fine, int* d_err) {
     free_ell3(e);
     e.n = n_fine;
-    HIPCHK(hipMalloc((void**)&e.cnt, sizeof(int) * std::max(n_fine, 1)));
-    HIPCHK(hipMalloc((void**)&e.col, sizeof(int) * (size_t)std::max(n_fine, 1) * 3));
-    HIPCHK(hipMalloc((void**)&e.val, sizeof(double) * (size_t)std::max(n_fine, 1) * 3));
+    HIPCHK(dev_malloc((void**)&e.cnt, sizeof(int) * std::max(n_fine, 1)));
+    HIPCHK(dev_malloc((void**)&e.col, sizeof(int) * (size_t)std::max(n_fine, 1) * 3));
+    HIPCHK(dev_malloc((void**)&e.val, sizeof(double) * (size_t)std::max(n_fine, 1) * 3));
     HIPCHK(hipMemsetAsync(e.cnt, 0, sizeof(int) * n_fine, h->stream));
     hipLaunchKernelGGL(gmgs::ell3_from_csc, dim3((dU.n_outer + 255) / 256), dim3(256), 0, h->stream, dU.ptr, dU.idx, dU.val, dU.n_outer, e.cnt, e.col, e.val, d_err);
     hipLaunchKernelGGL(gmgs::ell3_sort, dim3((n_fine + 255) / 256), dim3(256), 0, h->stream, e.cnt, n_fine, e.col, e.val);
     return GMG_OK;
 }
 
-// Ac = U^T A U on the device (setup_kernels.hip.hpp::rap_rows): count pass, host prefix sum, fill pass; the result is
-// left on the device (dC) and copied to the host (the orderings and the coarsest factorisation run there).
-int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& e3, DevCsr& dC, Compressed& C, int* d_err) {
+// Device copies of every U_k (by coarse column, and regrouped by fine row): built once per hierarchy.
+int ensure_device_transfers(gmg_handle h) {
+    if (h->dU_ready) return GMG_OK;
+    const int L = h->L;
+    drop_device_transfers(h);
+    h->dU.assign(L, DevCsr());
+    h->dE3.assign(L, DevEll3());
+    DevTmp<int> d_err;
+    int rc, herr = 0;
+    if ((rc = d_err.alloc(h, 1))) return rc;
+    HIPCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream));
+    for (int k = 0; k < L; ++k) {
+        rc = upload_csr(h, h->dU[k], h->U[k]);
+        if (rc == GMG_OK) rc = build_ell3(h, h->dE3[k], h->dU[k], h->U[k].n_inner, d_err.p);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // pageable host arrays have been consumed
+    h->dU_flagged = herr != 0;      // a U row with more than 3 entries: the device RAP / layout builder cannot take it
+    h->dU_ready = true;
+    return GMG_OK;
+}
+
+// Host copy of A_k (natural numbering), on demand: the device keeps the master copy (Level::dA).
+int ensure_host_A(gmg_handle h, int k, bool values) {
+    Level& l = h->lv[k];
+    if (l.hostA_pattern && (l.hostA_values || !values)) return GMG_OK;
+    if (!l.dA.ptr) return fail(h, GMG_ERR_STATE, "level operator is neither on the host nor on the device");
+    const int n = l.dA.n_outer;
+    l.A.n_outer = n; l.A.n_inner = n;
+    if (!l.hostA_pattern) {
+        l.A.ptr.resize((size_t)n + 1);
+        HIPCHK(hipMemcpyAsync(l.A.ptr.data(), l.dA.ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        l.A.idx.resize((size_t)l.A.ptr[n]);
+        HIPCHK(hipMemcpyAsync(l.A.idx.data(), l.dA.idx, sizeof(int) * l.A.idx.size(), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (values && !l.hostA_values) {
+        l.A.val.resize((size_t)l.nnz);
+        HIPCHK(hipMemcpyAsync(l.A.val.data(), l.dA.val, sizeof(double) * l.A.val.size(), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    l.hostA_pattern = true;
+    l.hostA_values = l.hostA_values || values;
+    return GMG_OK;
+}
+
+// Ac = U^T A U on the device (setup_kernels.hip.hpp::rap_rows): count pass, device prefix sum, fill pass.  The result
+// stays on the device (dC); `pattern` (row pointers + column indices, for the host ordering of that level) and
+// `values` say what is copied to the host as well.  Returns 1 when the device kernel cannot take the input.
+int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& e3, DevCsr& dC, Compressed& C, bool pattern, bool values,
+               int64_t* nnz_out, int* d_err) {
     const int nc = dU.n_outer;
     free_csr(dC);
     dC.n_outer = nc;
     DevTmp<int> cnt;
     int rc;
     if ((rc = cnt.alloc(h, nc))) return rc;
+    HIPCHK(dev_malloc((void**)&dC.ptr, sizeof(int) * ((size_t)nc + 1)));
     hipLaunchKernelGGL(gmgs::rap_rows<0>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                        (const int*)nullptr, cnt.p, (int*)nullptr, (double*)nullptr, d_err);
+    int nnz = 0, herr = 0;
+    if ((rc = device_scan<int, int>(h, cnt.p, nc, dC.ptr, &nnz))) return rc;
+    HIPCHK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     C.n_outer = nc; C.n_inner = nc;
-    C.ptr.assign((size_t)nc + 1, 0);
-    HIPCHK(hipMemcpyAsync(C.ptr.data() + 1, cnt.p, sizeof(int) * nc, hipMemcpyDeviceToHost, h->stream));
+    if (pattern || values) {
+        C.ptr.resize((size_t)nc + 1);
+        HIPCHK(hipMemcpyAsync(C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
-    for (int p = 0; p < nc; ++p) C.ptr[p + 1] += C.ptr[p];
-    const int nnz = C.ptr[nc];
-    if ((rc = upload(h, &dC.ptr, C.ptr))) return rc;
-    HIPCHK(hipMalloc((void**)&dC.idx, sizeof(int) * std::max(nnz, 1)));
-    HIPCHK(hipMalloc((void**)&dC.val, sizeof(double) * std::max(nnz, 1)));
+    if (herr) { free_csr(dC); return 1; }       // a coarse row overflows the device hash set (or a U row has > 3 entries): host fallback
+    *nnz_out = nnz;
+    HIPCHK(dev_malloc((void**)&dC.idx, sizeof(int) * std::max(nnz, 1)));
+    HIPCHK(dev_malloc((void**)&dC.val, sizeof(double) * std::max(nnz, 1)));
     hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                        (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
-    C.idx.resize(nnz); C.val.resize(nnz);
-    HIPCHK(hipMemcpyAsync(C.idx.data(), dC.idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(C.val.data(), dC.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (pattern || values) { C.idx.resize(nnz); HIPCHK(hipMemcpyAsync(C.idx.data(), dC.idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, h->stream)); }
+    if (values) { C.val.resize(nnz); HIPCHK(hipMemcpyAsync(C.val.data(), dC.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, h->stream)); }
+    if (pattern || values) HIPCHK(hipStreamSynchronize(h->stream));
     return GMG_OK;
 }
 
-// Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device.  Returns 1 when the
-// device builder cannot take the input (a row longer than gmgs::kMaxRow, a prolongation row with more than 3 entries):
+// Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device from Level::dA and the
+// device copies of U_k.  A row longer than gmgs::kMaxRow or a prolongation row with more than 3 entries raises *d_err:
 // the caller then falls back to the host planner.
-int device_layout_level(gmg_handle h, int k, int* d_err, DevCsr* pre_A, DevCsr* pre_U, DevEll3* pre_e3) {
+int device_layout_level(gmg_handle h, int k, int* d_err) {
     const int L = h->L;
     Level& l = h->lv[k];
     int rc;
-    DevCsr dA;
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;      // synchronising phase timers on stderr
+    auto tph = clk::now();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(h->stream);
+        std::fprintf(stderr, "[gmg setup] level %d %-10s %.2f ms\n", k, what, ms_since(tph));
+        tph = clk::now();
+    };
     DevTmp<int> d_old2new, d_blk_of_row;
-    if (pre_A && pre_A->ptr) { dA = *pre_A; *pre_A = DevCsr(); }        // take ownership (freed below)
-    else if ((rc = upload_csr(h, dA, l.A))) return rc;
-    if ((rc = upload(h, &d_old2new.p, l.ord.old2new))) { free_csr(dA); return rc; }
+    if (!l.dA.ptr) {
+        if ((rc = ensure_host_A(h, k, true)) || (rc = upload_csr(h, l.dA, l.A))) return rc;
+    }
+    const DevCsr& dA = l.dA;
+    if ((rc = upload(h, &d_old2new.p, l.ord.old2new))) return rc;
+    phase("old2new");
     gmgs::RowFilter f{l.d_new2old, d_old2new.p, nullptr, nullptr, 0, 1};
     const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
     const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
-    HIPCHK(hipMalloc((void**)&l.diag, sizeof(double) * l.n_pad));
-    if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) { free_csr(dA); return rc; }
-    l.Aoff.nnz_real = l.A.nnz() - l.n;
+    HIPCHK(dev_malloc((void**)&l.diag, sizeof(double) * l.n_pad));
+    if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) return rc;
+    l.Aoff.nnz_real = l.nnz - l.n;
+    phase("A");
     if (l.ord.blocked) {
-        std::vector<int> blk_of_row(l.n_pad, 0);
-        for (int b = 0; b < l.ord.n_blocks(); ++b)
-            for (int r = l.ord.blk_begin[b]; r < l.ord.blk_begin[b + 1]; ++r) blk_of_row[r] = b;
-        if ((rc = upload(h, &d_blk_of_row.p, blk_of_row)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
-            (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) { free_csr(dA); return rc; }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = d_blk_of_row.alloc(h, l.n_pad)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
+            (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
+        hipLaunchKernelGGL(gmgs::block_of_rows, dim3(std::max(1, l.ord.n_blocks())), dim3(64), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), d_blk_of_row.p);
         gmgs::RowFilter fin{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
         gmgs::RowFilter fout{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
         if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err)) ||
-            (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) { free_csr(dA); return rc; }
+            (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) return rc;
     }
-    free_csr(dA);
+    phase("A split");
     if (k == L) return GMG_OK;
     // ---- transfers k <-> k+1
     Level& c = h->lv[k + 1];
-    DevCsr dU;
-    DevEll3 e3;
+    const DevCsr& dU = h->dU[k];
+    const DevEll3& e3 = h->dE3[k];
     DevTmp<int> d_old2new_c, d_order, d_pbeg, d_pend;
-    if (pre_U && pre_U->ptr) { dU = *pre_U; *pre_U = DevCsr(); }
-    else if ((rc = upload_csr(h, dU, h->U[k]))) return rc;
-    if (pre_e3 && pre_e3->cnt) { e3 = *pre_e3; *pre_e3 = DevEll3(); }
-    else if ((rc = build_ell3(h, e3, dU, l.n, d_err))) { free_csr(dU); return rc; }
-    if ((rc = upload(h, &d_old2new_c.p, c.ord.old2new))) { free_csr(dU); free_ell3(e3); return rc; }
+    if ((rc = upload(h, &d_old2new_c.p, c.ord.old2new))) return rc;
     // restriction: rows = coarse points (columns of the CSC U), sorted by length inside windows like the host planner
     {
         const Compressed& U = h->U[k];
         const int np = c.n_pad, sigma = h->cfg.sigma;
-        std::vector<int> order(np);
-        auto len_of = [&](int r) { int old = c.ord.new2old[r]; return old >= 0 ? U.ptr[old + 1] - U.ptr[old] : 0; };
-        if (sigma > 0) {
+        if (sigma > 0 && sigma <= gmgs::kWindowSortMax) {
+            int pow2 = 1;
+            while (pow2 < sigma) pow2 <<= 1;
+            if ((rc = d_order.alloc(h, np))) return rc;
+            hipLaunchKernelGGL(gmgs::window_order_by_length, dim3((np + sigma - 1) / sigma), dim3(256), 0, h->stream, dU.ptr, c.d_new2old, np, sigma, pow2, d_order.p);
+        } else if (sigma > 0) {
+            std::vector<int> order(np);
+            auto len_of = [&](int r) { int old = c.ord.new2old[r]; return old >= 0 ? U.ptr[old + 1] - U.ptr[old] : 0; };
             const int nwin = (np + sigma - 1) / sigma;
-            parallel_ranges(nwin, h->cfg.host_threads, [&](int lo, int hi, int) {
-                for (int wi = lo; wi < hi; ++wi) {
-                    int w = wi * sigma, we = std::min(np, w + sigma);
-                    std::iota(order.begin() + w, order.begin() + we, w);
-                    std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) { return len_of(a) > len_of(b); });
-                }
-            });
-            if ((rc = upload(h, &d_order.p, order))) { free_csr(dU); free_ell3(e3); return rc; }
-            HIPCHK(hipStreamSynchronize(h->stream));
+            for (int wi = 0; wi < nwin; ++wi) {
+                int w = wi * sigma, we = std::min(np, w + sigma);
+                std::iota(order.begin() + w, order.begin() + we, w);
+                std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) { return len_of(a) > len_of(b); });
+            }
+            if ((rc = upload(h, &d_order.p, order))) return rc;
+            HIPCHK(hipStreamSynchronize(h->stream));      // `order` (pageable) dies at scope end
         }
+        phase("R order");
         gmgs::RowFilter fr{c.d_new2old, d_old2new.p, nullptr, nullptr, 0, 0};
         const int lpr_r = h->cfg.block_lanes == 1 ? 1 : 4;
-        if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) { free_csr(dU); free_ell3(e3); return rc; }
+        if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) return rc;
         l.R.nnz_real = U.nnz();
         if (sigma > 0) { l.R.row_of = d_order.p; d_order.p = nullptr; }     // the order array becomes the output-row map
+        phase("R");
     }
-    // prolongation: rows = fine points; U is stored by coarse column, so first regroup it by fine row (<= 3 per row)
+    // prolongation: rows = fine points; U is stored by coarse column, so it was regrouped by fine row (<= 3 per row)
     {
         const int nf = l.n;
-        if ((rc = d_pbeg.alloc(h, nf)) || (rc = d_pend.alloc(h, nf))) { free_csr(dU); free_ell3(e3); return rc; }
+        if ((rc = d_pbeg.alloc(h, nf)) || (rc = d_pend.alloc(h, nf))) return rc;
         hipLaunchKernelGGL(gmgs::ell3_ptr, dim3((nf + 255) / 256), dim3(256), 0, h->stream, e3.cnt, nf, d_pbeg.p, d_pend.p);
         gmgs::RowFilter fp{l.d_new2old, d_old2new_c.p, nullptr, nullptr, 0, 0};
-        if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) { free_csr(dU); free_ell3(e3); return rc; }
+        if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) return rc;
         l.P.nnz_real = h->U[k].nnz();
     }
-    free_csr(dU);
-    free_ell3(e3);
+    HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
+    phase("P");
     return GMG_OK;
+}
+
+// One threaded pass over a compressed pattern: 0 = canonical (indices in range, strictly ascending inside each outer
+// vector), 1 = in range but unsorted or with duplicates, 2 = an index out of range / a non-monotone pointer array.
+int inspect_pattern(int n_outer, int n_inner, const int* ptr, const int* idx, int threads) {
+    if (ptr[0] != 0) return 2;
+    std::vector<int> worst(std::max(threads, 1) + 1, 0);
+    parallel_ranges(n_outer, threads, [&](int lo, int hi, int t) {
+        int w = 0;
+        for (int j = lo; j < hi && w < 2; ++j) {
+            if (ptr[j + 1] < ptr[j]) { w = 2; break; }
+            int prev = -1;
+            for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
+                const int i = idx[p];
+                if (i < 0 || i >= n_inner) { w = 2; break; }
+                if (i <= prev) w = 1;
+                prev = i;
+            }
+        }
+        worst[std::min(t, (int)worst.size() - 1)] = w;
+    });
+    int w = 0;
+    for (int v : worst) w = std::max(w, v);
+    return w;
+}
+
+// Sorted, duplicate-free copy of a compressed matrix (duplicates are summed, like Eigen's setFromTriplets / scipy's
+// sum_duplicates): what the engine requires of the LHS, made here when the caller's storage is not canonical.
+Compressed canonical_copy(int n_outer, int n_inner, const int* ptr, const int* idx, const double* val, int threads) {
+    Compressed out;
+    out.n_outer = n_outer; out.n_inner = n_inner;
+    std::vector<int> cnt((size_t)n_outer + 1, 0);
+    std::vector<std::vector<std::pair<int, double>>> cols(n_outer);
+    parallel_ranges(n_outer, threads, [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j) {
+            auto& c = cols[j];
+            c.reserve(ptr[j + 1] - ptr[j]);
+            for (int p = ptr[j]; p < ptr[j + 1]; ++p) c.emplace_back(idx[p], val[p]);
+            std::stable_sort(c.begin(), c.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            size_t w = 0;
+            for (size_t r = 0; r < c.size(); ++r) {
+                if (w > 0 && c[w - 1].first == c[r].first) c[w - 1].second += c[r].second;
+                else c[w++] = c[r];
+            }
+            c.resize(w);
+            cnt[j + 1] = (int)w;
+        }
+    });
+    for (int j = 0; j < n_outer; ++j) cnt[j + 1] += cnt[j];
+    out.ptr = cnt;
+    out.idx.resize(cnt[n_outer]); out.val.resize(cnt[n_outer]);
+    parallel_ranges(n_outer, threads, [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j) {
+            int q = out.ptr[j];
+            for (auto& e : cols[j]) { out.idx[q] = e.first; out.val[q] = e.second; ++q; }
+        }
+    });
+    return out;
 }
 
 // 2 x 64-bit FNV-1a style digest of the LHS sparsity pattern (threaded; chunk digests combined in order)
@@ -636,18 +829,18 @@ int ensure_vectors(gmg_handle h, int d) {
     unbind_level0(h);
     for (auto& l : h->lv) {
         for (double** p : {&l.x, &l.b, &l.r, &l.tmp}) {
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
+            if (*p) { (void)dev_free(*p); *p = nullptr; }
             if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
             size_t bytes = sizeof(double) * (size_t)l.n_pad * d;
-            HIPCHK(hipMalloc((void**)p, bytes));
+            HIPCHK(dev_malloc((void**)p, bytes));
             HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
         }
         for (float** p : {&l.x32, &l.b32, &l.r32, &l.tmp32}) {
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
+            if (*p) { (void)dev_free(*p); *p = nullptr; }
             if (!h->cfg.inner_precision) continue;
             if (p == &l.tmp32 && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
             size_t bytes = sizeof(float) * (size_t)l.n_pad * d;
-            HIPCHK(hipMalloc((void**)p, bytes));
+            HIPCHK(dev_malloc((void**)p, bytes));
             HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
         }
     }
@@ -660,8 +853,8 @@ int ensure_vectors(gmg_handle h, int d) {
     }
     if (h->h_norm) (void)hipHostFree(h->h_norm);
     HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, hipHostMallocDefault));
-    if (h->d_norm) (void)hipFree(h->d_norm);
-    HIPCHK(hipMalloc((void**)&h->d_norm, sizeof(double) * 2 * d));
+    if (h->d_norm) (void)dev_free(h->d_norm);
+    HIPCHK(dev_malloc((void**)&h->d_norm, sizeof(double) * 2 * d));
     h->dcap = d;
     h->loaded_d = 0;
     return GMG_OK;
@@ -669,8 +862,8 @@ int ensure_vectors(gmg_handle h, int d) {
 
 int ensure_stage(gmg_handle h, size_t n_doubles) {
     if (n_doubles <= h->stage_cap) return GMG_OK;
-    if (h->d_stage) (void)hipFree(h->d_stage);
-    HIPCHK(hipMalloc((void**)&h->d_stage, sizeof(double) * n_doubles));
+    if (h->d_stage) (void)dev_free(h->d_stage);
+    HIPCHK(dev_malloc((void**)&h->d_stage, sizeof(double) * n_doubles));
     h->stage_cap = n_doubles;
     return GMG_OK;
 }
@@ -948,17 +1141,20 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
 
 void gmg_destroy(gmg_handle h) {
     if (!h) return;
+    PoolScope pool_scope_(&h->pool);
     if (h->has_device) {
         (void)hipSetDevice(h->cfg.device);
         (void)hipStreamSynchronize(h->stream);
         drop_system(h);
-        for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)hipFree(*p);
+        drop_device_transfers(h);
+        for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)dev_free(*p);
         if (h->h_pinned) (void)hipHostFree(h->h_pinned);
         for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]); if (h->h_stage_ev[i]) (void)hipEventDestroy(h->h_stage_ev[i]); }
         if (h->h_norm) (void)hipHostFree(h->h_norm);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         (void)hipStreamDestroy(h->own_stream);
+        h->pool.trim();
     }
     delete h;
 }
@@ -967,7 +1163,8 @@ const char* gmg_last_error(gmg_handle h) { return h ? h->err.c_str() : "null han
 
 int gmg_set_num_levels(gmg_handle h, int L) {
     if (!h || L < 0 || L > 64) return h ? fail(h, GMG_ERR_INVALID, "invalid level count") : GMG_ERR_INVALID;
-    if (h->has_device) drop_system(h);
+    PoolScope pool_scope_(&h->pool);
+    if (h->has_device) { drop_system(h); drop_device_transfers(h); }
     h->L = L;
     h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
@@ -977,11 +1174,12 @@ int gmg_set_num_levels(gmg_handle h, int L) {
 
 int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const int* colptr, const int* rowidx, const double* val) {
     if (!h) return GMG_ERR_INVALID;
+    PoolScope pool_scope_(&h->pool);
     if (h->L < 0) return fail(h, GMG_ERR_STATE, "call gmg_set_num_levels first");
     if (k < 0 || k >= h->L || n_fine <= 0 || n_coarse <= 0 || !colptr || !rowidx || !val) return fail(h, GMG_ERR_INVALID, "bad prolongation arguments");
     for (int j = 0; j < n_coarse; ++j) if (colptr[j + 1] < colptr[j]) return fail(h, GMG_ERR_INVALID, "colptr not monotone");
     for (int p = 0; p < colptr[n_coarse]; ++p) if (rowidx[p] < 0 || rowidx[p] >= n_fine) return fail(h, GMG_ERR_INVALID, "row index out of range in U");
-    if (h->has_device) drop_system(h);
+    if (h->has_device) { drop_system(h); drop_device_transfers(h); }
     h->U[k].assign(n_coarse, n_fine, colptr, rowidx, val);
     h->U_set[k] = 1;
     h->ord_cache_valid = false;
@@ -990,6 +1188,7 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
 
 int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
     if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
+    PoolScope pool_scope_(&h->pool);
     h->mass.assign(mass_diag, mass_diag + n);
     if (h->has_device && h->system_ready) {
         // device numbering (padding rows get weight 1: they carry r = b = 0)
@@ -997,7 +1196,7 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
         if (l.n != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
         int rc = ensure_stage(h, (size_t)n);
         if (rc) return rc;
-        for (double** p : {&h->d_mass, &h->d_minv}) if (!*p) HIPCHK(hipMalloc((void**)p, sizeof(double) * l.n_pad));
+        for (double** p : {&h->d_mass, &h->d_minv}) if (!*p) HIPCHK(dev_malloc((void**)p, sizeof(double) * l.n_pad));
         HIPCHK(hipMemcpyAsync(h->d_stage, h->mass.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(gmgk::permute_mass, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.d_new2old, l.n_pad, h->d_mass, h->d_minv);
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1013,7 +1212,16 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     if (h->U[0].n_inner != n) return fail(h, GMG_ERR_INVALID, "system size does not match U[0]");
     for (int k = 0; k + 1 < h->L; ++k)
         if (h->U[k].n_outer != h->U[k + 1].n_inner) return fail(h, GMG_ERR_INVALID, "U[k] / U[k+1] shapes do not chain");
-    for (int p = 0; p < colptr[n]; ++p) if (rowidx[p] < 0 || rowidx[p] >= n) return fail(h, GMG_ERR_INVALID, "index out of range in LHS");
+    auto t_all = clk::now();
+    Compressed canon;       // only filled when the caller's storage is unsorted or has duplicates
+    {
+        const int what = inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads);
+        if (what == 2) return fail(h, GMG_ERR_INVALID, "index out of range in LHS");
+        if (what == 1) {
+            canon = canonical_copy(n, n, colptr, rowidx, val, h->cfg.host_threads);
+            colptr = canon.ptr.data(); rowidx = canon.idx.data(); val = canon.val.data();
+        }
+    }
     HIPCHK(hipSetDevice(h->cfg.device));
     drop_system(h);
     const int L = h->L;
@@ -1024,10 +1232,15 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     //   level L     : LDL^T factorisation of A_L (:1401) (+ dense inverse for GMG_COARSE_DEVICE_INVERSE)
     //   per level k : transfer layouts P_k, R_k once the orderings of levels k and k+1 exist
     // The uploads follow on the calling thread once their inputs are ready.
-    auto t_all = clk::now();
+    auto mark = [&](const std::string& what) { h->timing["t_" + what] = ms_since(t_all); };   // setup timeline (ms since entry)
     h->timing["setup_wait_ordering"] = 0.0; h->timing["setup_device_layout"] = 0.0;
     const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
     bool device_setup = h->cfg.device_setup != 0;
+    if (device_setup) {
+        int rc = ensure_device_transfers(h);        // no-op when gmg_use_hierarchy (or an earlier system) made them
+        if (rc) return rc;
+        if (h->dU_flagged) device_setup = false;    // prolongation rows with more than 3 entries: host planner and host RAP
+    }
     struct LevelStage {
         SellHost sa, sin, sout, sp, sr;
         std::vector<double> dg;
@@ -1044,22 +1257,32 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     double ms_factor = 0;
     // Host copy of the LHS (kept for gmg_get_level_operator, the level-0 ordering and the host fallbacks): 250 MB at
     // 3 M vertices, made in the background while the device works from the caller's arrays.
-    std::shared_future<void> lhs_copied = std::async(std::launch::async, [&] { h->lv[0].A.assign(n, n, colptr, rowidx, val); }).share();
+    // Host copy of the LHS: only where a host stage needs it (host RAP, host planner, block ordering of level 0); the
+    // default path works from the caller's arrays and the device copy, and gmg_get_level_operator fetches on demand.
+    double ms_lhs_copied = 0;
+    const bool need_host_A0 = !device_setup || !h->cfg.device_rap || (mc && h->cfg.block_rows > 0 && h->cfg.block_from_level <= 0);
+    h->lv[0].n = n; h->lv[0].nnz = colptr[n];
+    std::shared_future<void> lhs_copied;
+    if (need_host_A0) {
+        lhs_copied = std::async(std::launch::async, [&] { h->lv[0].A.assign(n, n, colptr, rowidx, val); ms_lhs_copied = ms_since(t_all); }).share();
+        h->lv[0].hostA_pattern = h->lv[0].hostA_values = true;      // valid once lhs_copied is ready (every reader waits on it)
+    }
+    auto wait_lhs = [&] { if (lhs_copied.valid()) lhs_copied.wait(); };
     uint64_t pat_key[2];
     pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
+    mark("pattern_key");
     const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1];
     h->timing["setup_ordering_cached"] = ord_hit ? 1.0 : 0.0;
     std::function<void(int)> spawn_level_ops;
     auto spawn_level = [&](int k) {
         Level& l = h->lv[k];
-        l.n = k == 0 ? n : l.A.n_outer;
         ord_done[k] = std::async(std::launch::async, [&, k] {
             auto t = clk::now();
             Level& lk = h->lv[k];
             const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
             if (ord_hit) lk.ord = h->ord_cache[k];          // same pattern + same hierarchy => same orderings
             else if (k == L) lk.ord = identity_ordering(lk.n);
-            else if (blocked) { if (k == 0) lhs_copied.wait(); lk.ord = make_block_ordering(lk.A, h->cfg.block_rows); }
+            else if (blocked) { if (k == 0) wait_lhs(); lk.ord = make_block_ordering(lk.A, h->cfg.block_rows); }
             else if (k == 0) lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, h->cfg.reorder_fine);   // the caller's arrays
             else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
             lk.n_pad = lk.ord.n_pad;
@@ -1105,40 +1328,49 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     };
     auto t0 = clk::now();
     spawn_level(0);
-    // device-resident copies of A_k, U_k (CSC) and U_k by rows, shared by the device RAP and the device layout builder
-    std::vector<DevCsr> dAs(L + 1), dUs(L);
-    std::vector<DevEll3> e3s(L);
+    auto join_tasks = [&] {     // never leave with tasks still referencing this frame
+        wait_lhs();
+        for (int j = 0; j <= L; ++j) if (ord_done[j].valid()) ord_done[j].wait();
+        for (int j = 0; j < L; ++j) { if (op_done[j].valid()) op_done[j].wait(); if (tr_done[j].valid()) tr_done[j].wait(); }
+    };
+    auto host_level_from_A = [&](int k) { Level& l = h->lv[k]; l.n = l.A.n_outer; l.nnz = l.A.nnz(); l.hostA_pattern = l.hostA_values = true; };
+    // The device keeps A_k (Level::dA) and U_k (h->dU, h->dE3, built once per hierarchy) in natural numbering: inputs of
+    // the device RAP and of the device layout builder, and the source of the on-demand host copies.
     DevTmp<int> d_rap_err;
     bool device_rap_ok = device_setup && h->cfg.device_rap != 0;
-    auto free_dev_inputs = [&] { for (auto& m : dAs) free_csr(m); for (auto& m : dUs) free_csr(m); for (auto& e : e3s) free_ell3(e); };
-    if (device_rap_ok) {
+    if (device_setup) {
         int rc = d_rap_err.alloc(h, 1);
         if (rc == GMG_OK) rc = hipMemsetAsync(d_rap_err.p, 0, sizeof(int), h->stream) == hipSuccess ? GMG_OK : GMG_ERR_HIP;
-        for (int k = 0; k < L && rc == GMG_OK; ++k) {
-            rc = upload_csr(h, dUs[k], h->U[k]);
-            if (rc == GMG_OK) rc = build_ell3(h, e3s[k], dUs[k], h->U[k].n_inner, d_rap_err.p);
-        }
-        if (rc == GMG_OK) rc = upload_csr_raw(h, dAs[0], n, colptr, rowidx, val);
+        if (rc != GMG_OK) { join_tasks(); return rc; }
+    }
+    if (device_rap_ok) {
+        int rc = upload_csr_raw(h, h->lv[0].dA, n, colptr, rowidx, val);
+        mark("upload_A0");
         int k = 1;
         for (; k <= L && rc == GMG_OK; ++k) {
-            rc = device_rap(h, dAs[k - 1], dUs[k - 1], e3s[k - 1], dAs[k], h->lv[k].A, d_rap_err.p);
-            int herr = 0;
-            if (rc == GMG_OK) { (void)hipMemcpy(&herr, d_rap_err.p, sizeof(int), hipMemcpyDeviceToHost); if (herr) break; }
-            if (rc == GMG_OK) spawn_level(k);
+            Level& lk = h->lv[k];
+            const bool want_pattern = !ord_hit && k < L, want_values = k == L;
+            rc = device_rap(h, h->lv[k - 1].dA, h->dU[k - 1], h->dE3[k - 1], lk.dA, lk.A, want_pattern, want_values, &lk.nnz, d_rap_err.p);
+            if (rc != GMG_OK) break;
+            lk.n = lk.dA.n_outer;
+            lk.hostA_pattern = want_pattern || want_values; lk.hostA_values = want_values;
+            spawn_level(k);
+            mark("rap_l" + std::to_string(k));
         }
-        if (rc != GMG_OK) { free_dev_inputs(); lhs_copied.wait(); for (int j = 0; j < k && j <= L; ++j) if (ord_done[j].valid()) ord_done[j].wait(); return rc; }
-        if (k <= L) {
+        if (rc != GMG_OK && rc != 1) { join_tasks(); return rc; }
+        if (rc == 1) {
             // a coarse row with more distinct columns than the device hash set holds (or a U row with > 3 entries):
             // finish the chain with the host implementation
             device_rap_ok = false;
-            free_dev_inputs();
-            lhs_copied.wait();
-            for (; k <= L; ++k) { h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads); spawn_level(k); }
+            wait_lhs();
+            if ((rc = ensure_host_A(h, k - 1, true))) { join_tasks(); return rc; }
+            for (; k <= L; ++k) { h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads); host_level_from_A(k); spawn_level(k); }
         }
     } else {
-        lhs_copied.wait();
+        wait_lhs();
         for (int k = 1; k <= L; ++k) {
             h->lv[k].A = galerkin_rap(h->lv[k - 1].A, h->U[k - 1], h->cfg.host_threads);
+            host_level_from_A(k);
             spawn_level(k);
             spawn_transfer(k - 1);
         }
@@ -1146,7 +1378,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     h->timing["reduction"] = ms_since(t0);
     factor_done = std::async(std::launch::async, [&] {
         auto t = clk::now();
-        bool ok = h->coarse.factor(h->lv[L].A);
+        bool ok = h->coarse.factor(h->lv[L].A, ord_hit);
         if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
             const int nl = h->lv[L].A.n_outer;
             inv.resize((size_t)nl * nl);
@@ -1176,14 +1408,15 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
                 auto tw = clk::now();
                 ord_done[k].wait();
                 h->timing["setup_wait_ordering"] += ms_since(tw);
+                mark("ordering_ready_l" + std::to_string(k));
                 if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); break; }
                 rc_all = upload(h, &h->lv[k].d_new2old, h->lv[k].ord.new2old);
             }
             auto tlay = clk::now();
             for (int k = 0; k < L && rc_all == GMG_OK; ++k)
-                rc_all = device_layout_level(h, k, d_err.p, device_rap_ok ? &dAs[k] : nullptr, device_rap_ok ? &dUs[k] : nullptr, device_rap_ok ? &e3s[k] : nullptr);
-            free_dev_inputs();
+                rc_all = device_layout_level(h, k, d_err.p);
             h->timing["setup_device_layout"] = ms_since(tlay);
+            mark("device_layout");
             if (rc_all == GMG_OK) {
                 (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
                 (void)hipStreamSynchronize(h->stream);
@@ -1191,8 +1424,10 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
                 else if (herr != 0) {
                     // rows too long for the device builder: redo the layout with the host planner
                     device_setup = false;
-                    for (int k = 0; k <= L; ++k) { if (k < L) { spawn_level_ops(k); } }
-                    for (int k = 0; k < L; ++k) spawn_transfer(k);
+                    wait_lhs();
+                    for (int k = 0; k < L && rc_all == GMG_OK; ++k) rc_all = ensure_host_A(h, k, true);
+                    for (int k = 0; k < L && rc_all == GMG_OK; ++k) spawn_level_ops(k);
+                    for (int k = 0; k < L && rc_all == GMG_OK; ++k) spawn_transfer(k);
                 }
             }
         }
@@ -1227,12 +1462,11 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if ((rc = upload_sell(h, l.P, stage[k].sp)) || (rc = upload_sell(h, l.R, stage[k].sr))) { rc_all = rc; break; }
         ms_h2d += ms_since(tu);
     }
-    {   // never leave with tasks still referencing this frame
-        lhs_copied.wait();
-        for (int k = 0; k <= L; ++k) if (ord_done[k].valid()) ord_done[k].wait();
-        for (int k = 0; k < L; ++k) { if (op_done[k].valid()) op_done[k].wait(); if (tr_done[k].valid()) tr_done[k].wait(); }
-    }
+    join_tasks();
+    h->timing["t_lhs_copied"] = ms_lhs_copied;
+    mark("tasks_joined");
     const bool factor_ok = factor_done.get();
+    mark("factor_joined");
     (void)hipStreamSynchronize(h->stream);      // staged host arrays die at scope end
     if (rc_all != GMG_OK) return err_all.empty() ? rc_all : fail(h, rc_all, err_all);
     if (!factor_ok) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
@@ -1246,8 +1480,8 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     {
         int nblk = kNormBlocks;
         if (nblk > h->partial_blocks) {
-            if (h->d_partials) (void)hipFree(h->d_partials);
-            HIPCHK(hipMalloc((void**)&h->d_partials, sizeof(double) * (size_t)nblk * 8));
+            if (h->d_partials) (void)dev_free(h->d_partials);
+            HIPCHK(dev_malloc((void**)&h->d_partials, sizeof(double) * (size_t)nblk * 8));
             h->partial_blocks = nblk;
         }
     }
@@ -1260,8 +1494,8 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         // fp32 twins of every value array (same layout): the inner V-cycle of the mixed-precision iteration
         auto twin = [&](DevSell& m) -> int {
             if (!m.val || m.stored <= 0) return GMG_OK;
-            if (m.val32) { (void)hipFree(m.val32); m.val32 = nullptr; }
-            HIPCHK(hipMalloc((void**)&m.val32, sizeof(float) * (size_t)m.stored));
+            if (m.val32) { (void)dev_free(m.val32); m.val32 = nullptr; }
+            HIPCHK(dev_malloc((void**)&m.val32, sizeof(float) * (size_t)m.stored));
             launch_cvt(h, m.val, m.val32, (size_t)m.stored);
             return GMG_OK;
         };
@@ -1269,8 +1503,8 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             Level& l = h->lv[k];
             int rc;
             if ((rc = twin(l.Aoff)) || (rc = twin(l.Ain)) || (rc = twin(l.Aout)) || (rc = twin(l.P)) || (rc = twin(l.R))) return rc;
-            if (l.diag32) { (void)hipFree(l.diag32); l.diag32 = nullptr; }
-            HIPCHK(hipMalloc((void**)&l.diag32, sizeof(float) * (size_t)l.n_pad));
+            if (l.diag32) { (void)dev_free(l.diag32); l.diag32 = nullptr; }
+            HIPCHK(dev_malloc((void**)&l.diag32, sizeof(float) * (size_t)l.n_pad));
             launch_cvt(h, l.diag, l.diag32, (size_t)l.n_pad);
         }
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1289,6 +1523,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    mark("mass_done");
     h->timing["upload"] = ms_since(t_all) - h->timing["reduction"];      // everything of the setup that is not the RAP chain
     h->timing["setup_total"] = ms_since(t_all);                          // wall time of this call (the coarsest factorisation overlaps)
     h->timing["coarse_host_ms"] = 0.0;
@@ -1303,7 +1538,7 @@ int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int
     if (rc) return rc;
     Level& l = h->lv[k];
     if (n) *n = l.n;
-    if (nnz) *nnz = l.A.nnz();
+    if (nnz) *nnz = l.nnz;
     if (n_colors) *n_colors = l.ord.n_colors;
     if (n_pad) *n_pad = l.n_pad;
     return GMG_OK;
@@ -1313,6 +1548,10 @@ int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double
     if (!h) return GMG_ERR_INVALID;
     int rc = check_level(h, k, true);
     if (rc) return rc;
+    {
+        PoolScope pool_scope_(&h->pool);
+        if ((rc = ensure_host_A(h, k, true))) return rc;
+    }
     const Compressed& A = h->lv[k].A;
     if (colptr) std::memcpy(colptr, A.ptr.data(), sizeof(int) * (A.n_outer + 1));
     if (rowidx) std::memcpy(rowidx, A.idx.data(), sizeof(int) * A.nnz());
@@ -1735,7 +1974,7 @@ int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_ou
     int rc = check_level(h, k, false);
     if (rc) return rc;
     const Level& l = h->lv[k];
-    const double s = 8.0, n = l.n, z = (double)l.A.nnz(), u = (double)h->U[k].nnz(), nc = h->lv[k + 1].n;
+    const double s = 8.0, n = l.n, z = (double)l.nnz, u = (double)h->U[k].nnz(), nc = h->lv[k + 1].n;
     // matrix stream (value + int32 index) + row pointer + the dense vectors, each touched once
     const double sweep = z * (s + 4) + 4 * (n + 1) + 3 * n * d * s;
     switch (kind) {
@@ -1842,6 +2081,12 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) {
     for (int k = 0; k < (int)hh->res.U.size(); ++k) {
         const Compressed& u = hh->res.U[k];
         if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
+    }
+    if (h->has_device && h->cfg.device_setup && h->L > 0) {
+        // the device copies of U_k belong to the hierarchy, not to a system: make them now (gmg_set_system would otherwise)
+        PoolScope pool_scope_(&h->pool);
+        HIPCHK(hipSetDevice(h->cfg.device));
+        if ((rc = ensure_device_transfers(h))) return rc;
     }
     return GMG_OK;
 }

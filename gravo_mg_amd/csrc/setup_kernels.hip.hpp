@@ -104,6 +104,109 @@ __global__ void sell_fill(const int* __restrict__ pbeg, const int* __restrict__ 
     }
 }
 
+// ---- exclusive prefix sums on the device (slice pointers, RAP row pointers): out[0] = 0, out[i + 1] = in[0] + .. + in[i].
+// Three small launches: per-tile sums, one block scanning the tile sums, per-tile rescan with the tile offset.
+constexpr int kScanTile = 2048;     // items per 256-thread block (8 per thread)
+
+template <class TIn, class TOut>
+__global__ __launch_bounds__(256) void scan_tile_sums(const TIn* __restrict__ in, int n, TOut* __restrict__ tile_sum) {
+    __shared__ TOut red[256];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
+    TOut s = 0;
+    for (int j = 0; j < 8; ++j) if (base + j < n) s += (TOut)in[base + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = red[0];
+}
+
+// one block: tile_sum[t] -> exclusive offsets (in place); the grand total goes to *total
+template <class TOut>
+__global__ __launch_bounds__(1024) void scan_tile_offsets(TOut* __restrict__ tile_sum, int n_tiles, TOut* __restrict__ total) {
+    __shared__ TOut buf[1024];
+    __shared__ TOut carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const TOut v = i < n_tiles ? tile_sum[i] : (TOut)0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            TOut t = (int)threadIdx.x >= off ? buf[threadIdx.x - off] : (TOut)0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sum[i] = carry + buf[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += buf[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+template <class TIn, class TOut>
+__global__ __launch_bounds__(256) void scan_tile_apply(const TIn* __restrict__ in, int n, const TOut* __restrict__ tile_off, TOut* __restrict__ out) {
+    __shared__ TOut part[256];
+    const int base = blockIdx.x * kScanTile + threadIdx.x * 8;
+    TOut v[8];
+    TOut s = 0;
+    for (int j = 0; j < 8; ++j) { v[j] = base + j < n ? (TOut)in[base + j] : (TOut)0; s += v[j]; }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        TOut t = (int)threadIdx.x >= off ? part[threadIdx.x - off] : (TOut)0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    TOut run = tile_off[blockIdx.x] + part[threadIdx.x] - s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+    for (int j = 0; j < 8; ++j) { run += v[j]; if (base + j < n) out[base + j + 1] = run; }
+}
+
+// Slice order of the restriction rows: inside every window of `sigma` device rows, rows sorted by descending length,
+// ties in row order (what std::stable_sort gives the host planner).  One block per window, bitonic sort in LDS of the
+// unique keys (32767 - len) << 16 | position.  len = entries of the U column of the row's natural index.
+constexpr int kWindowSortMax = 4096;
+__global__ __launch_bounds__(256) void window_order_by_length(const int* __restrict__ u_cptr, const int* __restrict__ new2old, int np, int sigma,
+                                                              int pow2, int* __restrict__ order) {
+    __shared__ int key[kWindowSortMax];
+    const int w0 = blockIdx.x * sigma;
+    const int cnt = min(sigma, np - w0);
+    for (int i = threadIdx.x; i < pow2; i += blockDim.x) {
+        int k = 0x7fffffff;
+        if (i < cnt) {
+            const int old = new2old[w0 + i];
+            const int len = old >= 0 ? min(u_cptr[old + 1] - u_cptr[old], 32767) : 0;
+            k = ((32767 - len) << 16) | i;
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    for (int size = 2; size <= pow2; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < pow2; i += blockDim.x) {
+                const int j = i ^ stride;
+                if (j > i) {
+                    const bool up = (i & size) == 0;
+                    const int a = key[i], b = key[j];
+                    if ((a > b) == up) { key[i] = b; key[j] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) order[w0 + i] = w0 + (key[i] & 0xffff);
+}
+
+// row -> block map of a blocked ordering (blk_begin: n_blocks + 1 device rows)
+__global__ void block_of_rows(const int* __restrict__ blk_begin, int n_blocks, int* __restrict__ blk_of_row) {
+    const int b = blockIdx.x;
+    if (b >= n_blocks) return;
+    for (int r = blk_begin[b] + threadIdx.x; r < blk_begin[b + 1]; r += blockDim.x) blk_of_row[r] = b;
+}
+
 // Rows of U (<= 3 entries each, gravomg/src/multigrid_solver.cpp:371-373) from its CSC storage: ELL-3 staging written
 // as a CSR with a fixed stride of 3 (ptr3[i] = 3 i, unused slots hold column -1).
 __global__ void ell3_from_csc(const int* __restrict__ colptr, const int* __restrict__ rowidx, const double* __restrict__ val, int n_coarse,

@@ -130,3 +130,116 @@ def test_ordering_cache_reused_for_same_pattern(cabi):
     eng.set_prolongations(P.U[:1])
     eng.set_system(lhs2)
     assert eng.timing("setup_ordering_cached") == 0.0
+
+
+def test_non_canonical_lhs_storage_is_accepted(cabi):
+    """Unsorted row indices and duplicate entries (summed, like Eigen's setFromTriplets) give the same system."""
+    import scipy.sparse as sp
+    P = problems.torus_problem(48, 40, "poisson", 60)
+    A = sp.csc_matrix(P.lhs); A.sort_indices()
+    rng = np.random.default_rng(5)
+    ptr, idx, val = [0], [], []
+    for j in range(A.shape[0]):
+        r = A.indices[A.indptr[j]:A.indptr[j + 1]].copy(); v = A.data[A.indptr[j]:A.indptr[j + 1]].copy()
+        if j % 3 == 0:                 # split the first entry in two halves (a duplicate)
+            r = np.concatenate([r, r[:1]]); v = np.concatenate([v, v[:1] * 0.5]); v[0] *= 0.5
+        perm = rng.permutation(len(r))
+        idx.append(r[perm]); val.append(v[perm]); ptr.append(ptr[-1] + len(r))
+    messy = sp.csc_matrix((np.concatenate(val), np.concatenate(idx).astype(np.int32), np.array(ptr, np.int32)), shape=A.shape)
+    assert not messy.has_canonical_format
+    ref = cabi.Engine(); ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(A)
+    eng = cabi.Engine(); eng.set_prolongations(P.U); eng.set_mass(P.mass)
+    eng._chk(cabi.lib().gmg_set_system(eng._h, A.shape[0], cabi._pi(messy.indptr), cabi._pi(messy.indices), cabi._pd(messy.data)))
+    eng._n0 = A.shape[0]
+    assert abs(eng.level_operator(0) - A).max() <= 1e-15 * abs(A).max()
+    ref.load_problem(P.rhs, P.rhs); eng.load_problem(P.rhs, P.rhs)
+    assert np.allclose(eng.run_cycles(3, 2), ref.run_cycles(3, 2), rtol=1e-9)
+
+
+def test_level_operators_are_fetched_on_demand_and_repeat_systems_reuse_the_pattern(cabi):
+    """Second set_system with the same pattern (ordering cache hit: no host copies of the middle levels are made) must
+    give the same operators and iterates as the first."""
+    P = problems.torus_problem(96, 80, "poisson", 30)
+    eng = cabi.Engine(); eng.set_prolongations(P.U); eng.set_mass(P.mass)
+    eng.set_system(P.lhs)
+    first = [eng.level_operator(k) for k in range(eng.num_levels + 1)]
+    eng.load_problem(P.rhs, P.rhs); h1 = eng.run_cycles(3, 2)
+    eng.set_system(P.lhs)
+    assert eng.timing("setup_ordering_cached") == 1.0
+    eng.load_problem(P.rhs, P.rhs); h2 = eng.run_cycles(3, 2)
+    assert np.array_equal(h1, h2)
+    for k, a in enumerate(first):
+        b = eng.level_operator(k)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data), k
+    # a different matrix with the same pattern
+    lhs2 = P.lhs.copy(); lhs2.data *= 1.5
+    eng.set_system(lhs2)
+    assert eng.timing("setup_ordering_cached") == 1.0
+    assert np.allclose(eng.level_operator(eng.num_levels).toarray(), 1.5 * first[-1].toarray(), rtol=1e-12)
+    x, it, res, _ = eng.solve(1.5 * P.rhs, tol=1e-6)
+    assert res <= 1e-6
+
+
+def _star_coupled(P, hub, n_links, rng):
+    """lhs + sum_j w (e_hub - e_j)(e_hub - e_j)^T: one very long row / column (SPD is preserved)."""
+    import scipy.sparse as sp
+    n = P.lhs.shape[0]
+    others = rng.choice(np.setdiff1d(np.arange(n), [hub]), n_links, replace=False)
+    w = 1e-3 * abs(P.lhs.diagonal()).mean()
+    rows = np.concatenate([np.full(n_links, hub), others, np.full(n_links, hub), others])
+    cols = np.concatenate([np.full(n_links, hub), others, others, np.full(n_links, hub)])
+    vals = np.concatenate([np.full(2 * n_links, w), np.full(2 * n_links, -w)])
+    return sp.csc_matrix(P.lhs + sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsc())
+
+
+@pytest.mark.parametrize("n_links", [150, 600], ids=["long-row", "long-row-and-rap-overflow"])
+def test_inputs_the_device_builders_cannot_take_fall_back_to_the_host_builders(cabi, oracle, n_links):
+    """A row longer than the device SELL builder's private buffer (96) and a coarse row with more distinct columns than
+    the device RAP's hash set (256): same operators and iterates as the host-planned engine, and the solve converges."""
+    P = problems.torus_problem(96, 80, "poisson", 30)
+    lhs = _star_coupled(P, 1234, n_links, np.random.default_rng(3))
+    dev, host = [cabi.Engine(device_setup=d) for d in (True, False)]
+    for e in (dev, host):
+        e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(lhs)
+    O = oracle.Hierarchy(P.U, P.mass); O.set_system(lhs)
+    for k in range(dev.num_levels + 1):
+        a, b = dev.level_operator(k), host.level_operator(k)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data), k
+        A = O.level_operator(k)
+        assert abs(a - A).max() <= 1e-12 * abs(A).max()
+    dev.load_problem(P.rhs, P.rhs); host.load_problem(P.rhs, P.rhs)
+    assert np.array_equal(dev.run_cycles(3, 2), host.run_cycles(3, 2))
+    x, it, res, _ = dev.solve(P.rhs, tol=1e-6)
+    assert res <= 1e-6 and it < 60
+    assert abs(oracle.residual_check(lhs, P.mass, P.rhs, x, 2) - res) <= 1e-3 * res + 1e-7
+
+
+def test_prolongation_rows_with_more_than_three_entries_use_the_host_builders(cabi, oracle):
+    """The device RAP / layout builder assume <= 3 entries per prolongation row (what the reference builds); other
+    hierarchies go through the host builders with identical semantics."""
+    import scipy.sparse as sp
+    P = problems.torus_problem(64, 60, "smoothing", 60)     # well conditioned: far-away prolongation entries do not stall it
+    U0 = sp.lil_matrix(P.U[0])
+    rng = np.random.default_rng(11)
+    for i in rng.choice(U0.shape[0], 40, replace=False):
+        free = np.setdiff1d(np.arange(U0.shape[1]), U0.rows[i])
+        for j in rng.choice(free, 2, replace=False):
+            U0[i, j] = 0.01
+    Us = [sp.csc_matrix(U0)] + list(P.U[1:])
+    assert (np.diff(sp.csr_matrix(Us[0]).indptr) > 3).any()
+    eng = cabi.Engine(); eng.set_prolongations(Us); eng.set_mass(P.mass)
+    for rep in range(2):            # the second call reuses the cached orderings and the flagged device transfers
+        eng.set_system(P.lhs)
+        O = oracle.Hierarchy(Us, P.mass); O.set_system(P.lhs)
+        for k in range(eng.num_levels + 1):
+            A = O.level_operator(k)
+            assert abs(eng.level_operator(k) - A).max() <= 1e-12 * abs(A).max(), (rep, k)
+        r = np.random.default_rng(1).standard_normal((P.n, 1))
+        assert rel(eng.restrict(0, r), Us[0].T @ r) <= 1e-13
+        x, it, res, _ = eng.solve(P.rhs, tol=1e-6)
+        xo, ito, reso, _ = O.solve(P.rhs, tol=1e-6)
+        assert res <= 1e-6 and reso <= 1e-6 and abs(it - ito) <= 2
+
+
+def rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
