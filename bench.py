@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--order", default="natural", choices=["natural", "random"])
     ap.add_argument("--cpu-cycles", type=int, default=3, help="V-cycles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--coarse", default="host", choices=["host", "device"])
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the cycle legs from hipGraphs (same cycle time, ~5 ms instantiation per system)")
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--block-rows", type=int, default=None, help="block-hybrid GS rows per block (engine default if unset)")
     ap.add_argument("--block-from-level", type=int, default=None)
@@ -122,7 +122,7 @@ def main():
     if args.block_lanes is not None:
         kw["block_lanes"] = args.block_lanes
     eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT,
-                      use_graph=not args.no_graph, **kw)
+                      use_graph=args.graph, **kw)
     eng.use_hierarchy(H)
     eng.set_mass(mass)
     t = time.perf_counter()
@@ -170,7 +170,7 @@ def main():
     variants = {}
     if args.coarse == "host" and not args.no_variants:
         del eng
-        eng2 = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE, use_graph=not args.no_graph, **kw)
+        eng2 = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE, use_graph=args.graph, **kw)
         eng2.use_hierarchy(H)
         eng2.set_mass(mass)
         eng2.set_system(lhs)
@@ -192,7 +192,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
-                   "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": not args.no_graph,
+                   "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": args.graph,
                    "tolerance": 1e-4, "stopping_criteria": 2},
         "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms, "solver_timing_ms": timing,
         "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,

@@ -257,7 +257,7 @@ class Engine:
     """One gmg_handle: device-resident hierarchy + V-cycle on one HIP stream."""
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
-                 coarse_mode=COARSE_HOST_LDLT, use_graph=True, sigma=1024, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
+                 coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=1024, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
                  device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, device=0, verbose=False):
         l = lib()
         cfg = GmgConfig()
@@ -512,10 +512,13 @@ def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024, 
     n = a.shape[0]
     if mode == 0:
         block_rows = row_align
-    cap = n + 64 * (n // 64 + 2) if mode == 1 else n + row_align * 256
     info = (C.c_int64 * 6)()
-    new2old = np.empty(cap, np.int32); color_begin = np.zeros(257, np.int32)
-    blk_begin = np.zeros(n // 64 + 3, np.int32); row_color = np.zeros(cap, np.uint8)
+    # sizes first (null outputs), then the arrays: the padded length and the block count depend on the graph
+    rc = lib().gmg_host_plan_level(n, _pi(a.indptr), _pi(a.indices), _pd(a.data), int(mode), int(block_rows), int(sigma), info, None, None, None, None)
+    if rc:
+        raise GmgError(rc, "gmg_host_plan_level")
+    new2old = np.empty(int(info[0]), np.int32); color_begin = np.zeros(int(info[1]) + 1, np.int32)
+    blk_begin = np.zeros(int(info[2]) + 1, np.int32); row_color = np.zeros(int(info[0]), np.uint8)
     rc = lib().gmg_host_plan_level(n, _pi(a.indptr), _pi(a.indices), _pd(a.data), int(mode), int(block_rows), int(sigma), info,
                                    _pi(new2old), _pi(color_begin), _pi(blk_begin), row_color.ctypes.data_as(C.POINTER(C.c_ubyte)))
     if rc:

@@ -139,6 +139,9 @@ struct gmg_solver_s {
     std::vector<DevCsr> dU;               // device copies of U_k (kept while the hierarchy is unchanged)
     std::vector<DevEll3> dE3;             // and their by-row regrouping
     bool dU_ready = false;
+    // patches of the blocked levels k >= 1, grown over the coarse point graph of U_{k-1} (hierarchy data, host only)
+    std::vector<PatchSet> patches;
+    bool patches_ready = false;
     bool dU_flagged = false;              // ell3_from_csc found a U row with more than 3 entries (host paths only)
     std::vector<double> mass;
     std::vector<Level> lv;
@@ -169,6 +172,9 @@ struct gmg_solver_s {
     bool ord_cache_valid = false;
     uint64_t ord_cache_key[2] = {0, 0};
     std::vector<LevelOrdering> ord_cache;
+    // the orderings live in the levels while a system is set; they move into ord_cache when the next one arrives
+    uint64_t live_key[2] = {0, 0};
+    bool live_key_valid = false;
 };
 
 namespace {
@@ -248,6 +254,24 @@ void drop_device_transfers(gmg_handle h) {
     for (auto& e : h->dE3) free_ell3(e);
     h->dU.clear(); h->dE3.clear();
     h->dU_ready = false;
+}
+
+// Patches of every blocked level k >= 1 (see coarse_point_graph): depend on the hierarchy and on block_rows only.
+void build_patches(gmg_handle h) {
+    const int L = h->L;
+    h->patches.assign(L + 1, PatchSet());
+    const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
+    if (mc && h->cfg.block_rows > 0) {
+        std::vector<std::future<void>> jobs;
+        for (int k = std::max(1, h->cfg.block_from_level); k < L; ++k)
+            jobs.push_back(std::async(std::launch::async, [h, k] {
+                const Compressed& U = h->U[k - 1];
+                Compressed G = coarse_point_graph(U, transpose_parallel(U));
+                h->patches[k] = grow_patch_set(G, h->cfg.block_rows);
+            }));
+        for (auto& j : jobs) j.get();
+    }
+    h->patches_ready = true;
 }
 
 void free_level(Level& l) {
@@ -610,22 +634,22 @@ Compressed canonical_copy(int n_outer, int n_inner, const int* ptr, const int* i
 // 2 x 64-bit FNV-1a style digest of the LHS sparsity pattern (threaded; chunk digests combined in order)
 void pattern_key(int n, const int* colptr, const int* rowidx, int threads, uint64_t key[2]) {
     const int64_t nnz = colptr[n];
-    const int T = std::max(1, std::min(threads, 64));
+    (void)threads;
+    const int T = 32;       // fixed: the digest depends on the chunking
     std::vector<uint64_t> part((size_t)T * 2, 0);
     auto digest = [](const int* p, int64_t cnt, uint64_t seed) {
         uint64_t h = 1469598103934665603ull ^ seed;
         for (int64_t i = 0; i < cnt; ++i) { h ^= (uint32_t)p[i]; h *= 1099511628211ull; h ^= h >> 29; }
         return h;
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < T; ++t)
-        pool.emplace_back([&, t] {
+    parallel_ranges(T, T, [&](int t0, int t1, int) {
+        for (int t = t0; t < t1; ++t) {
             int64_t lo = nnz * t / T, hi = nnz * (t + 1) / T;
             part[2 * t] = digest(rowidx + lo, hi - lo, 0x9e3779b97f4a7c15ull * (t + 1));
             int64_t plo = (int64_t)(n + 1) * t / T, phi = (int64_t)(n + 1) * (t + 1) / T;
             part[2 * t + 1] = digest(colptr + plo, phi - plo, 0xc2b2ae3d27d4eb4full * (t + 1));
-        });
-    for (auto& th : pool) th.join();
+        }
+    }, 1);
     key[0] = 1469598103934665603ull ^ (uint64_t)n; key[1] = 0x84222325cbf29ce4ull ^ (uint64_t)nnz;
     for (int t = 0; t < T; ++t) { key[0] = (key[0] ^ part[2 * t]) * 1099511628211ull; key[1] = (key[1] ^ part[2 * t + 1]) * 1099511628211ull; }
 }
@@ -885,12 +909,12 @@ int ensure_host_stage(gmg_handle h, size_t n_doubles) {
 inline void threaded_copy(double* dst, const double* src, size_t n, int threads) {
     const int T = (int)std::min<size_t>(std::max(1, std::min(threads, 16)), n / 65536 + 1);
     if (T <= 1) { std::memcpy(dst, src, sizeof(double) * n); return; }
-    std::vector<std::thread> pool;
-    for (int t = 0; t < T; ++t) {
-        size_t lo = n * t / T, hi = n * (t + 1) / T;
-        pool.emplace_back([=] { std::memcpy(dst + lo, src + lo, sizeof(double) * (hi - lo)); });
-    }
-    for (auto& th : pool) th.join();
+    parallel_ranges(T, T, [&](int t0, int t1, int) {
+        for (int t = t0; t < t1; ++t) {
+            size_t lo = n * t / T, hi = n * (t + 1) / T;
+            std::memcpy(dst + lo, src + lo, sizeof(double) * (hi - lo));
+        }
+    }, 1);
 }
 
 // host natural n x d  ->  device numbering (level k) buffer
@@ -1016,10 +1040,14 @@ int run_graph(gmg_handle h, int key, F&& enqueue) {
     if (it == h->graphs.end()) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
+        auto tc = clk::now();
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         enqueue();
         HIPCHK(hipStreamEndCapture(h->stream, &g));
+        h->timing["graph_capture_ms"] += ms_since(tc);
+        tc = clk::now();
         HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        h->timing["graph_instantiate_ms"] += ms_since(tc);
         (void)hipGraphDestroy(g);
         it = h->graphs.emplace(key, ge).first;
     }
@@ -1096,7 +1124,7 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->pre_iters = 2;       // gravomg_bindings/src/gravomg/core.py:10
     cfg->post_iters = 2;
     cfg->coarse_mode = GMG_COARSE_HOST_LDLT;
-    cfg->use_graph = 1;
+    cfg->use_graph = 0;      // measured: the cycle is not launch-bound (eager == graph per cycle) and instantiating costs ~5 ms per system
     cfg->sigma = 1024;
     cfg->row_align = 64;
     cfg->block_rows = 64;
@@ -1165,6 +1193,7 @@ int gmg_set_num_levels(gmg_handle h, int L) {
     if (!h || L < 0 || L > 64) return h ? fail(h, GMG_ERR_INVALID, "invalid level count") : GMG_ERR_INVALID;
     PoolScope pool_scope_(&h->pool);
     if (h->has_device) { drop_system(h); drop_device_transfers(h); }
+    h->patches.clear(); h->patches_ready = false;
     h->L = L;
     h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
@@ -1180,17 +1209,17 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
     for (int j = 0; j < n_coarse; ++j) if (colptr[j + 1] < colptr[j]) return fail(h, GMG_ERR_INVALID, "colptr not monotone");
     for (int p = 0; p < colptr[n_coarse]; ++p) if (rowidx[p] < 0 || rowidx[p] >= n_fine) return fail(h, GMG_ERR_INVALID, "row index out of range in U");
     if (h->has_device) { drop_system(h); drop_device_transfers(h); }
+    h->patches.clear(); h->patches_ready = false;
     h->U[k].assign(n_coarse, n_fine, colptr, rowidx, val);
     h->U_set[k] = 1;
     h->ord_cache_valid = false;
     return GMG_OK;
 }
 
-int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
-    if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
-    PoolScope pool_scope_(&h->pool);
-    h->mass.assign(mass_diag, mass_diag + n);
-    if (h->has_device && h->system_ready) {
+// h->mass (natural numbering) -> device numbering of level 0 (d_mass, d_minv); needs a system (the ordering)
+static int upload_mass(gmg_handle h) {
+    const int n = (int)h->mass.size();
+    {
         // device numbering (padding rows get weight 1: they carry r = b = 0)
         Level& l = h->lv[0];
         if (l.n != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
@@ -1201,6 +1230,14 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
         hipLaunchKernelGGL(gmgk::permute_mass, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.d_new2old, l.n_pad, h->d_mass, h->d_minv);
         HIPCHK(hipStreamSynchronize(h->stream));
     }
+    return GMG_OK;
+}
+
+int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
+    if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
+    PoolScope pool_scope_(&h->pool);
+    h->mass.assign(mass_diag, mass_diag + n);
+    if (h->has_device && h->system_ready) return upload_mass(h);
     return GMG_OK;
 }
 
@@ -1223,8 +1260,15 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         }
     }
     HIPCHK(hipSetDevice(h->cfg.device));
-    drop_system(h);
     const int L = h->L;
+    if (h->system_ready && h->live_key_valid && (int)h->lv.size() == L + 1) {
+        h->ord_cache.resize(L + 1);
+        for (int k = 0; k <= L; ++k) h->ord_cache[k] = std::move(h->lv[k].ord);
+        h->ord_cache_key[0] = h->live_key[0]; h->ord_cache_key[1] = h->live_key[1];
+        h->ord_cache_valid = true;
+    }
+    h->live_key_valid = false;
+    drop_system(h);
     h->lv.resize(L + 1);
     // Host setup as a small task graph (everything below the RAP chain is independent per level):
     //   main thread : A_1 .. A_L by Galerkin products (multigrid_solver.cpp:1387-1392)
@@ -1268,11 +1312,16 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         h->lv[0].hostA_pattern = h->lv[0].hostA_values = true;      // valid once lhs_copied is ready (every reader waits on it)
     }
     auto wait_lhs = [&] { if (lhs_copied.valid()) lhs_copied.wait(); };
+    // pinned staging for one right-hand side (the solve's b / x transfers): page-locking costs milliseconds, do it now
+    std::future<int> stage_ready = std::async(std::launch::async, [h, n] { (void)hipSetDevice(h->cfg.device); return ensure_host_stage(h, (size_t)n); });
     uint64_t pat_key[2];
     pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
     mark("pattern_key");
     const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1];
     h->timing["setup_ordering_cached"] = ord_hit ? 1.0 : 0.0;
+    h->ord_cache_valid = false;       // a hit moves the cached orderings into the levels; the next call moves them back
+    std::shared_future<void> patches_done;      // hierarchies set level by level (gmg_set_prolongation): grown now, in the background
+    if (!h->patches_ready && !ord_hit) patches_done = std::async(std::launch::async, [h] { build_patches(h); }).share();
     std::function<void(int)> spawn_level_ops;
     auto spawn_level = [&](int k) {
         Level& l = h->lv[k];
@@ -1280,9 +1329,13 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             auto t = clk::now();
             Level& lk = h->lv[k];
             const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
-            if (ord_hit) lk.ord = h->ord_cache[k];          // same pattern + same hierarchy => same orderings
+            if (ord_hit) lk.ord = std::move(h->ord_cache[k]);          // same pattern + same hierarchy => same orderings
             else if (k == L) lk.ord = identity_ordering(lk.n);
-            else if (blocked) { if (k == 0) wait_lhs(); lk.ord = make_block_ordering(lk.A, h->cfg.block_rows); }
+            else if (blocked) {
+                if (k == 0) wait_lhs();
+                if (patches_done.valid()) patches_done.wait();
+                lk.ord = make_block_ordering(lk.A, h->cfg.block_rows, k < (int)h->patches.size() ? &h->patches[k] : nullptr);
+            }
             else if (k == 0) lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, h->cfg.reorder_fine);   // the caller's arrays
             else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
             lk.n_pad = lk.ord.n_pad;
@@ -1330,6 +1383,8 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     spawn_level(0);
     auto join_tasks = [&] {     // never leave with tasks still referencing this frame
         wait_lhs();
+        if (patches_done.valid()) patches_done.wait();
+        if (stage_ready.valid()) (void)stage_ready.get();
         for (int j = 0; j <= L; ++j) if (ord_done[j].valid()) ord_done[j].wait();
         for (int j = 0; j < L; ++j) { if (op_done[j].valid()) op_done[j].wait(); if (tr_done[j].valid()) tr_done[j].wait(); }
     };
@@ -1509,17 +1564,13 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         }
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    if (!ord_hit) {
-        h->ord_cache.resize(L + 1);
-        for (int k = 0; k <= L; ++k) h->ord_cache[k] = h->lv[k].ord;
-        h->ord_cache_key[0] = pat_key[0]; h->ord_cache_key[1] = pat_key[1];
-        h->ord_cache_valid = true;
-    }
+    h->live_key[0] = pat_key[0]; h->live_key[1] = pat_key[1];
+    h->live_key_valid = true;
+    h->ord_cache_valid = false;       // (moved into the levels on a hit; refilled from them by the next call)
     h->system_ready = true;
     if (!h->mass.empty()) {
         if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
-        std::vector<double> keep = h->mass;
-        int rc = gmg_set_mass(h, n, keep.data());
+        int rc = upload_mass(h);
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -2082,6 +2133,7 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) {
         const Compressed& u = hh->res.U[k];
         if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
     }
+    if (h->has_device && h->L > 0) build_patches(h);      // hierarchy data as well: the compact patches of the blocked levels
     if (h->has_device && h->cfg.device_setup && h->L > 0) {
         // the device copies of U_k belong to the hierarchy, not to a system: make them now (gmg_set_system would otherwise)
         PoolScope pool_scope_(&h->pool);

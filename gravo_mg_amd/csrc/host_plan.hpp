@@ -15,6 +15,9 @@
 // Everything here runs once per system on the host; the passes over rows are threaded (parallel_ranges) and the
 // large arrays are left uninitialised until their single parallel fill.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -198,55 +201,152 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    auto tph = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gmg setup] make_ordering n=%d %-12s %.2f ms\n", n, what, std::chrono::duration<double, std::milli>(now - tph).count());
+        tph = now;
+    };
     std::vector<int> base;      // visit order (empty = natural)
     if (reorder == 1 || (reorder == 2 && n > 65536 && mean_index_distance(A) > std::max(32768.0, n / 32.0))) {
         std::vector<int> block_of, mem_begin;
         grow_patches(A, 4096, block_of, base, mem_begin);
         o.reordered = true;
     }
+    phase("locality");
     std::vector<int> color;
     if (multicolor) o.n_colors = greedy_coloring(A, color, base);
     else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
+    phase("colouring");
+    // Stable counting sort of the visit sequence by colour, threaded: per-chunk histograms give every chunk its write
+    // offsets, so the result does not depend on the number of threads.
+    const int T = std::max(1, std::min(hw_threads(), 32));
+    const int nchunk = n >= 65536 ? T : 1;
+    const int chunk = (n + nchunk - 1) / std::max(nchunk, 1);
+    std::vector<std::vector<int>> hist(nchunk, std::vector<int>(o.n_colors, 0));
+    parallel_ranges(nchunk, nchunk, [&](int lo, int hi, int) {
+        for (int q = lo; q < hi; ++q) {
+            const int t0 = q * chunk, t1 = std::min(n, t0 + chunk);
+            std::vector<int>& hq = hist[q];
+            for (int t = t0; t < t1; ++t) hq[color[base.empty() ? t : base[t]]]++;
+        }
+    }, 1);
     std::vector<int> count(o.n_colors, 0);
-    for (int i = 0; i < n; ++i) count[color[i]]++;
+    for (int q = 0; q < nchunk; ++q) for (int c = 0; c < o.n_colors; ++c) count[c] += hist[q][c];
     o.color_begin.assign(o.n_colors + 1, 0);
     for (int c = 0; c < o.n_colors; ++c) o.color_begin[c + 1] = o.color_begin[c] + round_up(count[c], row_align);
     o.n_pad = o.n_colors ? o.color_begin[o.n_colors] : 0;
     if (o.n_pad == 0) o.n_pad = row_align;
     o.new2old.assign(o.n_pad, -1);
     o.old2new.assign(n, -1);
-    std::vector<int> fill(o.color_begin.begin(), o.color_begin.end() - (o.n_colors ? 1 : 0));
-    for (int t = 0; t < n; ++t) { const int i = base.empty() ? t : base[t]; o.new2old[fill[color[i]]++] = i; }
+    {
+        std::vector<int> run(o.color_begin.begin(), o.color_begin.end() - (o.n_colors ? 1 : 0));
+        for (int q = 0; q < nchunk; ++q) for (int c = 0; c < o.n_colors; ++c) { const int h = hist[q][c]; hist[q][c] = run[c]; run[c] += h; }
+    }
+    parallel_ranges(nchunk, nchunk, [&](int lo, int hi, int) {
+        for (int q = lo; q < hi; ++q) {
+            const int t0 = q * chunk, t1 = std::min(n, t0 + chunk);
+            std::vector<int>& fill = hist[q];
+            for (int t = t0; t < t1; ++t) { const int i = base.empty() ? t : base[t]; o.new2old[fill[color[i]]++] = i; }
+        }
+    }, 1);
+    phase("bucket");
     if (sigma > 0) {
+        std::vector<std::pair<int, int>> windows;
         for (int c = 0; c < o.n_colors; ++c) {
-            int lo = o.color_begin[c], hi = lo + count[c];
-            for (int w = lo; w < hi; w += sigma) {
-                int we = std::min(hi, w + sigma);
-                std::stable_sort(o.new2old.begin() + w, o.new2old.begin() + we, [&](int a, int b) {
+            const int lo = o.color_begin[c], hi = lo + count[c];
+            for (int w = lo; w < hi; w += sigma) windows.emplace_back(w, std::min(hi, w + sigma));
+        }
+        parallel_ranges((int)windows.size(), T, [&](int lo, int hi, int) {
+            for (int q = lo; q < hi; ++q)
+                std::stable_sort(o.new2old.begin() + windows[q].first, o.new2old.begin() + windows[q].second, [&](int a, int b) {
                     return (A.ptr[a + 1] - A.ptr[a]) > (A.ptr[b + 1] - A.ptr[b]);
                 });
-            }
-        }
+        }, 64);
     }
-    for (int r = 0; r < o.n_pad; ++r)
-        if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
+    phase("window sort");
+    parallel_ranges(o.n_pad, T, [&](int lo, int hi, int) {
+        for (int r = lo; r < hi; ++r)
+            if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
+    });
+    phase("inverse");
     return o;
 }
 
-// Block ordering for the block-hybrid smoother.  Blocks are grown breadth-first over the matrix graph
+// The compact patches of a blocked level (grow_patches output).
+struct PatchSet {
+    std::vector<int> block_of, members, mem_begin;
+    int n = 0;
+    bool valid() const { return !mem_begin.empty(); }
+};
+
+template <class Mat>
+inline PatchSet grow_patch_set(const Mat& G, int block_rows) {
+    PatchSet p;
+    p.n = G.n_outer;
+    grow_patches(G, block_rows, p.block_of, p.members, p.mem_begin);
+    return p;
+}
+
+// Graph on the coarse points of one prolongation: p ~ q when some fine row interpolates from both (the edges of the
+// coarse triangulation the barycentric weights come from).  pattern(U^T U), symmetric, sorted, with the diagonal.
+// It is known as soon as the hierarchy is, so the patches of level k + 1 can be grown before any system arrives.
+// U: by coarse column (outer = coarse); Urows: the same matrix by fine row (outer = fine).
+inline Compressed coarse_point_graph(const Compressed& U, const Compressed& Urows) {
+    const int nc = U.n_outer;
+    Compressed G;
+    G.n_outer = nc; G.n_inner = nc;
+    std::vector<std::vector<int>> adj(nc);
+    parallel_ranges(nc, std::min(hw_threads(), 32), [&](int lo, int hi, int) {
+        for (int p = lo; p < hi; ++p) {
+            std::vector<int>& a = adj[p];
+            for (int e = U.ptr[p]; e < U.ptr[p + 1]; ++e) {
+                const int i = U.idx[e];
+                for (int f = Urows.ptr[i]; f < Urows.ptr[i + 1]; ++f) a.push_back(Urows.idx[f]);
+            }
+            a.push_back(p);
+            std::sort(a.begin(), a.end());
+            a.erase(std::unique(a.begin(), a.end()), a.end());
+        }
+    });
+    G.ptr.assign((size_t)nc + 1, 0);
+    for (int p = 0; p < nc; ++p) G.ptr[p + 1] = G.ptr[p] + (int)adj[p].size();
+    G.idx.resize(G.ptr[nc]);
+    parallel_ranges(nc, std::min(hw_threads(), 32), [&](int lo, int hi, int) {
+        for (int p = lo; p < hi; ++p) std::copy(adj[p].begin(), adj[p].end(), G.idx.begin() + G.ptr[p]);
+    });
+    return G;
+}
+
+// Block ordering for the block-hybrid smoother.  Blocks are grown breadth-first over a graph of the level
 // from seeds taken on the frontier of what is already assigned, so they are compact patches whatever the
 // input vertex order is (a contiguous range of a row-major mesh ordering would be a thin strip with nearly
-// every edge cut).  Inside a block: greedy colouring of the in-block subgraph in BFS order, rows sorted by
+// every edge cut).  Inside a block: greedy colouring of the in-block subgraph of A in BFS order, rows sorted by
 // colour.  Every block is padded to a multiple of 64 rows so SELL slices never straddle blocks.
-inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
+// `patches`: grown beforehand (over the coarse point graph of the hierarchy) or, if null, grown here over A's graph.
+template <class Mat>
+inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const PatchSet* patches = nullptr) {
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
     o.blocked = true;
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    auto tph = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gmg setup] make_block_ordering n=%d %-12s %.2f ms\n", n, what, std::chrono::duration<double, std::milli>(now - tph).count());
+        tph = now;
+    };
     // ---- phase 1 (sequential graph traversal): grow the blocks, record their members in BFS order
-    std::vector<int> block_of, members, mem_begin;
-    grow_patches(A, block_rows, block_of, members, mem_begin);
+    PatchSet own;
+    if (!patches || !patches->valid() || patches->n != n) { own = grow_patch_set(A, block_rows); patches = &own; }
+    const std::vector<int>&block_of = patches->block_of, &members = patches->members, &mem_begin = patches->mem_begin;
+    phase("grow");
     const int nb = (int)mem_begin.size() - 1;
+    const int T = std::max(1, std::min(hw_threads(), 32));
     // ---- phase 2 (threaded over blocks): greedy colouring of the in-block subgraph in BFS order, colour sort, padding
     o.blk_begin.assign((size_t)nb + 1, 0);
     for (int b = 0; b < nb; ++b) o.blk_begin[b + 1] = o.blk_begin[b] + round_up(mem_begin[b + 1] - mem_begin[b], kSlice);
@@ -255,7 +355,7 @@ inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
     o.row_color.assign(o.n_pad, 0);
     o.blk_ncolors.assign(nb, 0);
     std::vector<int> color(n, -1);
-    parallel_ranges(nb, hw_threads(), [&](int lo, int hi, int) {
+    parallel_ranges(nb, T, [&](int lo, int hi, int) {
         std::vector<char> forbid;
         std::vector<int> mem;
         for (int b = lo; b < hi; ++b) {
@@ -281,14 +381,16 @@ inline LevelOrdering make_block_ordering(const Compressed& A, int block_rows) {
             }
             o.blk_ncolors[b] = ncol;
         }
-    });
+    }, 64);
+    phase("colour+sort");
     for (int b = 0; b < nb; ++b) o.n_colors = std::max(o.n_colors, o.blk_ncolors[b]);
     o.color_begin = {0, o.n_pad};      // not colour-major: a single range
     o.old2new.assign(n, -1);
-    parallel_ranges(o.n_pad, hw_threads(), [&](int lo, int hi, int) {
+    parallel_ranges(o.n_pad, T, [&](int lo, int hi, int) {
         for (int r = lo; r < hi; ++r)
             if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
-    });
+    }, 65536);
+    phase("inverse");
     return o;
 }
 

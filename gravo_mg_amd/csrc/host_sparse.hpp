@@ -10,7 +10,14 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <pthread.h>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace gmg {
@@ -36,17 +43,95 @@ inline int hw_threads() {
     return (int)std::min(t, 128u);
 }
 
-template <class F>
-inline void parallel_ranges(int n, int nthreads, F&& f) {
-    if (nthreads <= 1 || n < 4096) { f(0, n, 0); return; }
-    std::vector<std::thread> pool;
-    int chunk = (n + nthreads - 1) / nthreads;
-    for (int t = 0; t < nthreads; ++t) {
-        int lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        pool.emplace_back([&f, lo, hi, t] { f(lo, hi, t); });
+// ---- worker pool -----------------------------------------------------------------------------------------------
+// The host has hundreds of cores and the setup issues dozens of short parallel loops: spawning std::threads per loop
+// costs milliseconds (20-30 us per thread).  One lazily created pool serves them all.  A caller runs the first range
+// itself and, while waiting for the others, executes queued work (so loops may nest and pool threads may submit).
+class WorkerPool {
+public:
+    static WorkerPool& instance() {
+        static WorkerPool* p = new WorkerPool();      // leaked on purpose: no destruction order problems at exit
+        return *p;
     }
-    for (auto& th : pool) th.join();
+    struct Batch {
+        std::atomic<int> pending{0};
+    };
+    void submit(Batch& b, std::function<void()> fn) {
+        b.pending.fetch_add(1, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            ensure_workers();
+            q_.emplace_back(&b, std::move(fn));
+        }
+        cv_.notify_one();
+    }
+    void wait(Batch& b) {
+        while (b.pending.load(std::memory_order_acquire) > 0) {
+            std::pair<Batch*, std::function<void()>> job;
+            {
+                std::unique_lock<std::mutex> g(m_);
+                if (q_.empty()) { g.unlock(); std::this_thread::yield(); continue; }
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job.second();
+            job.first->pending.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    int size() const { return n_workers_; }
+
+private:
+    WorkerPool() {
+        unsigned t = std::thread::hardware_concurrency();
+        n_workers_ = (int)std::max(1u, std::min(t ? t : 1u, 64u));
+        pthread_atfork(nullptr, nullptr, [] { instance().after_fork(); });
+    }
+    void after_fork() {         // the child of a fork() has no worker threads: start over
+        new (&m_) std::mutex();
+        new (&cv_) std::condition_variable();
+        q_.clear();
+        started_ = false;
+    }
+    void ensure_workers() {     // called with m_ held
+        if (started_) return;
+        started_ = true;
+        for (int i = 0; i < n_workers_; ++i)
+            std::thread([this] {
+                for (;;) {
+                    std::pair<Batch*, std::function<void()>> job;
+                    {
+                        std::unique_lock<std::mutex> g(m_);
+                        cv_.wait(g, [this] { return !q_.empty(); });
+                        job = std::move(q_.front());
+                        q_.pop_front();
+                    }
+                    job.second();
+                    job.first->pending.fetch_sub(1, std::memory_order_release);
+                }
+            }).detach();
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::pair<Batch*, std::function<void()>>> q_;
+    int n_workers_ = 1;
+    bool started_ = false;
+};
+
+// f(lo, hi, t) over [0, n) split into `nthreads` contiguous ranges run on the worker pool (range 0 on the caller);
+// n < min_serial items run inline (raise or lower it with the weight of an item).
+template <class F>
+inline void parallel_ranges(int n, int nthreads, F&& f, int min_serial = 4096) {
+    if (nthreads <= 1 || n < min_serial || n < 2) { f(0, n, 0); return; }
+    WorkerPool& pool = WorkerPool::instance();
+    WorkerPool::Batch batch;
+    const int chunk = (n + nthreads - 1) / nthreads;
+    for (int t = 1; t < nthreads; ++t) {
+        const int lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) break;
+        pool.submit(batch, [&f, lo, hi, t] { f(lo, hi, t); });
+    }
+    f(0, std::min(n, chunk), 0);
+    pool.wait(batch);
 }
 
 // Transpose of the compressed layout (CSC <-> CSR of the same matrix); output inner indices sorted.

@@ -251,6 +251,7 @@ __global__ void ell3_sort(const int* __restrict__ cnt, int n, int* __restrict__ 
 // in the SAME order as the host implementation (host_sparse.hpp::galerkin_rap), adding w = (u_ip a_ij) * u_jq to its
 // accumulator when q matches -- with separately rounded multiply and add, so the result is bitwise the host's.
 // PASS 0 only counts the distinct columns (row lengths for the prefix sum).
+constexpr int kRapSlots = 768;     // (column, product) list of one chunk of children in LDS: 3 per entry of A
 constexpr int kRapSet = 256;      // hash-set capacity per coarse row (rows with more distinct columns -> host fallback)
 template <int PASS>
 __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, const int* __restrict__ a_idx, const double* __restrict__ a_val,
@@ -306,24 +307,82 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
         if (lane == 0) c_cnt[p] = cnt;
         return;
     }
-    // ---- step 2: numeric, lane-owned output columns, triples walked in the host's order
+    // ---- step 2: numeric.  Every lane owns up to 4 output columns (cnt <= 256).  The triples of a chunk of children
+    // are first gathered IN PARALLEL into LDS as (q, (u_ip a_ij) * u_jq) in the host's walk order -- slot of (child,
+    // entry, s) = 3 * (entries of the earlier children + entry) + s -- then every lane runs down the list once and adds
+    // the products of its columns: the same additions in the same order as the host, at LDS-broadcast cost.
+    __shared__ int sq[kRapSlots];
+    __shared__ double sv[kRapSlots];
+    __shared__ int c_incl[64], c_beg[64];
+    __shared__ double c_uip[64];
     const int out0 = c_ptr[p];
-    for (int base = 0; base < cnt; base += 64) {
-        const int mine = base + lane < cnt ? keys[base + lane] : -1;
-        double acc = 0.0;
-        for (int t = ub; t < ue; ++t) {
-            const int i = u_ridx[t];
-            const double uip = u_cval[t];
-            for (int b = a_ptr[i]; b < a_ptr[i + 1]; ++b) {
-                const int j = a_idx[b];
-                const double w = uip * a_val[b];
-                const int m = ur_cnt[j] < 3 ? ur_cnt[j] : 3;
-                for (int s = 0; s < m; ++s)
-                    if (ur_col[3 * j + s] == mine) acc = acc + w * ur_val[3 * j + s];
+    int mine[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < 4; ++g) mine[g] = g * 64 + lane < cnt ? keys[g * 64 + lane] : -1;
+    const int groups = (cnt + 63) >> 6;
+    int t0 = ub;
+    while (t0 < ue) {
+        // lane l looks at child t0 + l: how many children fit the LDS list?
+        const int tt = t0 + lane;
+        const int ci = tt < ue ? u_ridx[tt] : -1;
+        const int cb = ci >= 0 ? a_ptr[ci] : 0;
+        const int len = ci >= 0 ? a_ptr[ci + 1] - cb : 0;
+        int incl = len;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        const unsigned long long fits = __ballot(tt < ue && incl * 3 <= kRapSlots);
+        const int m = __popcll(fits);          // incl is non-decreasing: the fitting children are a prefix
+        __syncthreads();                       // the previous chunk's list has been consumed
+        if (m == 0) {
+            // a single row of A longer than the list: walk it straight from memory (all lanes, same order)
+            const int i = u_ridx[t0];
+            const double uip = u_cval[t0];
+            for (int e = a_ptr[i]; e < a_ptr[i + 1]; ++e) {
+                const int j = a_idx[e];
+                const double w = uip * a_val[e];
+                const int mj = ur_cnt[j] < 3 ? ur_cnt[j] : 3;
+                for (int s2 = 0; s2 < mj; ++s2) {
+                    const int q = ur_col[3 * j + s2];
+                    const double pr = w * ur_val[3 * j + s2];
+                    for (int g = 0; g < groups; ++g) if (q == mine[g]) acc[g] = acc[g] + pr;
+                }
+            }
+            t0 += 1;
+            continue;
+        }
+        c_incl[lane] = incl; c_beg[lane] = cb; c_uip[lane] = tt < ue ? u_cval[tt] : 0.0;
+        __syncthreads();
+        const int pairs = c_incl[m - 1];
+        for (int x = lane; x < pairs; x += 64) {
+            int c = 0;                          // child of pair x: first c with c_incl[c] > x
+            while (c_incl[c] <= x) ++c;
+            const int e = c_beg[c] + (x - (c > 0 ? c_incl[c - 1] : 0));
+            const int j = a_idx[e];
+            const double w = c_uip[c] * a_val[e];
+            const int mj = ur_cnt[j] < 3 ? ur_cnt[j] : 3;
+            for (int s2 = 0; s2 < 3; ++s2) {
+                const bool on = s2 < mj;
+                sq[3 * x + s2] = on ? ur_col[3 * j + s2] : -2;
+                sv[3 * x + s2] = on ? w * ur_val[3 * j + s2] : 0.0;
             }
         }
-        if (mine >= 0) { c_idx[out0 + base + lane] = mine; c_val[out0 + base + lane] = acc; }
+        __syncthreads();
+        const int slots = 3 * pairs;
+        if (groups == 1) {
+            double a0 = acc[0];
+            const int m0 = mine[0];
+            for (int x = 0; x < slots; ++x) if (sq[x] == m0) a0 = a0 + sv[x];
+            acc[0] = a0;
+        } else {
+            for (int x = 0; x < slots; ++x) {
+                const int q = sq[x];
+                const double pr = sv[x];
+                for (int g = 0; g < groups; ++g) if (q == mine[g]) acc[g] = acc[g] + pr;
+            }
+        }
+        t0 += m;
     }
+    for (int g = 0; g < groups; ++g)
+        if (mine[g] >= 0) { c_idx[out0 + g * 64 + lane] = mine[g]; c_val[out0 + g * 64 + lane] = acc[g]; }
 }
 
 }  // namespace gmgs

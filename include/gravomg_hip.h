@@ -53,7 +53,7 @@ typedef struct {
     int pre_iters;         /* MultigridSolver::preIters  (gravomg_bindings/src/cpp/core.cpp:55) */
     int post_iters;        /* MultigridSolver::postIters (core.cpp:56) */
     int coarse_mode;       /* GMG_COARSE_*: where the coarsest direct solve is applied (default host) */
-    int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs (default 1) */
+    int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs; 0 (default): plain stream launches */
     int sigma;             /* SELL sorting window in rows (multiple of 64; 0 = no sorting; default 1024) */
     int row_align;         /* colour classes padded to this many rows (multiple of 64; default 64) */
     int block_rows;        /* block-hybrid Gauss-Seidel: rows per block (multiple of 64, <= 1024, <= 256 unless

@@ -229,11 +229,11 @@ def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
     assert dx2 <= 100 * tight
 
 
-@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "no_graph", "exact_gs", "blocked_all", "small_blocks", "lane_per_row_blocks"])
+@pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "graph", "exact_gs", "blocked_all", "small_blocks", "lane_per_row_blocks"])
 def test_engine_variants(cabi, oracle, variant):
     P = problems.torus_problem(48, 40, "poisson", 60)
     kw = {"jacobi": dict(smoother=cabi.SMOOTHER_JACOBI), "device_coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
-          "no_graph": dict(use_graph=False), "exact_gs": dict(block_rows=0), "blocked_all": dict(block_from_level=0),
+          "graph": dict(use_graph=True), "exact_gs": dict(block_rows=0), "blocked_all": dict(block_from_level=0),
           "small_blocks": dict(block_rows=128), "lane_per_row_blocks": dict(block_lanes=1, block_rows=1024)}[variant]
     eng = cabi.Engine(**kw)
     eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
