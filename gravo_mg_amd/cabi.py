@@ -107,6 +107,7 @@ SIGNATURES = {
     "gmg_hierarchy_get_prolongation": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gmg_hierarchy_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
+    "gmg_finalize_hierarchy": (C.c_int, [_vp]),
     "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
     "gmg_host_plan_level": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _ip, _ip,
                                       C.POINTER(C.c_ubyte)]),
@@ -293,7 +294,7 @@ class Engine:
             pass
 
     # -- hierarchy input
-    def set_prolongations(self, U: Sequence):
+    def set_prolongations(self, U: Sequence, finalize: bool = True):
         l = lib()
         self._chk(l.gmg_set_num_levels(self._h, len(U)))
         self._sizes = []
@@ -303,6 +304,8 @@ class Engine:
             if k == 0:
                 self._sizes.append(u.shape[0])
             self._sizes.append(u.shape[1])
+        if finalize and len(U):
+            self._chk(l.gmg_finalize_hierarchy(self._h))
 
     def use_hierarchy(self, hier: Hierarchy):
         self._chk(lib().gmg_use_hierarchy(self._h, hier._h))

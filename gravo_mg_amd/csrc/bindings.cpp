@@ -9,6 +9,9 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -49,6 +52,64 @@ MGBS::SparseMatrix to_sparse(const py::object& obj) {
     m.inner.assign(indices.data(), indices.data() + indices.size());
     m.values.assign(data.data(), data.data() + data.size());
     return m;
+}
+
+// A system matrix mapped in place (no copy): the reference's API receives scipy CSR (gravomg/core.py:74-77) and pybind11
+// converts it to Eigen's column-major storage on every call (core.cpp:68) -- ~100 ms of single-threaded work at 3 M
+// vertices, twice the whole GPU solve.  Here CSC input is mapped as it is, and CSR input of a SYMMETRIC matrix (the
+// only kind the algorithm accepts, multigrid_solver.cpp:1200-1208) is mapped as the CSC of its transpose, i.e. of
+// itself.  Symmetry is spot-checked on a few thousand entries; anything else goes through scipy's conversion.
+struct MappedSparse {
+    MGBS::SparseMatrix m;
+    std::vector<py::object> keep;      // the numpy arrays the view points into
+};
+
+bool looks_symmetric(int n, const int* ptr, const int* idx, const double* val) {
+    const int64_t nnz = ptr[n];
+    if (nnz == 0) return true;
+    uint64_t state = 0x9e3779b97f4a7c15ull;
+    for (int s = 0; s < 4096; ++s) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const int64_t p = (int64_t)((state >> 11) % (uint64_t)nnz);
+        const int i = (int)(std::upper_bound(ptr, ptr + n + 1, (int)p) - ptr) - 1;     // outer index holding entry p
+        const int j = idx[p];
+        if (j < 0 || j >= n) return false;
+        bool found = false;
+        for (int q = ptr[j]; q < ptr[j + 1]; ++q)
+            if (idx[q] == i) {
+                const double a = val[p], b = val[q];
+                if (std::abs(a - b) > 1e-10 * std::max(std::abs(a), std::abs(b))) return false;
+                found = true;
+                break;
+            }
+        if (!found) return false;
+    }
+    return true;
+}
+
+MappedSparse map_system_matrix(const py::object& obj) {
+    py::object sp = py::module_::import("scipy.sparse");
+    py::object mat = obj;
+    const bool is_csc = sp.attr("isspmatrix_csc")(mat).cast<bool>();
+    const bool is_csr = !is_csc && sp.attr("isspmatrix_csr")(mat).cast<bool>();
+    if (!is_csc && !is_csr) mat = sp.attr("csc_matrix")(mat);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        MappedSparse out;
+        auto shape = mat.attr("shape").cast<std::pair<py::ssize_t, py::ssize_t>>();
+        auto indptr = mat.attr("indptr").cast<py::array_t<int, py::array::c_style | py::array::forcecast>>();
+        auto indices = mat.attr("indices").cast<py::array_t<int, py::array::c_style | py::array::forcecast>>();
+        auto data = mat.attr("data").cast<py::array_t<double, py::array::c_style | py::array::forcecast>>();
+        const bool row_major = attempt == 0 && is_csr;
+        if (row_major && (shape.first != shape.second || !looks_symmetric((int)shape.first, indptr.data(), indices.data(), data.data()))) {
+            mat = sp.attr("csc_matrix")(mat);      // not (recognisably) symmetric: the real conversion
+            continue;
+        }
+        out.m.rows_ = (int)shape.first; out.m.cols_ = (int)shape.second;
+        out.m.outerView = indptr.data(); out.m.innerView = indices.data(); out.m.valuesView = data.data();
+        out.keep = {mat, indptr, indices, data};
+        return out;
+    }
+    throw std::runtime_error("could not map the system matrix");
 }
 
 py::object from_sparse(const MGBS::SparseMatrix& m) {
@@ -103,6 +164,7 @@ public:
         solver->preIters = pre_iters;
         solver->postIters = post_iters;
         solver->isSmootherGaussSeidel = true;
+        (void)solver->prepareEngine();       // hierarchy -> device now (part of the construction phase); errors resurface in solve()
     }
 
     void construct_sig21_hierarchy(py::object) { throw std::runtime_error("the SIG21 comparison hierarchy is out of scope of the MI355X hot-path build"); }
@@ -112,7 +174,8 @@ public:
 
     // core.cpp:68-72: x0 = rhs
     py::array_t<double> solve(py::object lhs, DenseIn rhs) {
-        MGBS::SparseMatrix A = to_sparse(lhs);
+        MappedSparse mapped = map_system_matrix(lhs);
+        MGBS::SparseMatrix& A = mapped.m;
         MGBS::MatrixXd b = to_dense(rhs);
         if (A.rows() != A.cols() || A.rows() != b.rows()) throw std::invalid_argument("lhs must be n x n and rhs n x d");
         MGBS::MatrixXd x = b;
@@ -157,7 +220,8 @@ public:
     void write_convergence(std::string file) { MGBS::writeConvergence(solver->convergence, file); }
 
     double residual(py::object lhs, DenseIn rhs, DenseIn solution, int type = 2) {
-        MGBS::SparseMatrix A = to_sparse(lhs);
+        MappedSparse mapped = map_system_matrix(lhs);
+        MGBS::SparseMatrix& A = mapped.m;
         solver->clearError();
         double r = solver->residualCheck(A, to_dense(rhs), to_dense(solution), type);
         check();

@@ -2133,12 +2133,22 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) {
         const Compressed& u = hh->res.U[k];
         if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
     }
-    if (h->has_device && h->L > 0) build_patches(h);      // hierarchy data as well: the compact patches of the blocked levels
-    if (h->has_device && h->cfg.device_setup && h->L > 0) {
-        // the device copies of U_k belong to the hierarchy, not to a system: make them now (gmg_set_system would otherwise)
+    return gmg_finalize_hierarchy(h);
+}
+
+int gmg_finalize_hierarchy(gmg_handle h) {
+    if (!h) return GMG_ERR_INVALID;
+    if (h->L <= 0) return fail(h, GMG_ERR_STATE, "no hierarchy set");
+    for (int k = 0; k < h->L; ++k) if (!h->U_set[k]) return fail(h, GMG_ERR_STATE, "prolongation matrix missing for level " + std::to_string(k));
+    if (!h->has_device) return GMG_OK;
+    // data that belongs to the hierarchy, not to a system (gmg_set_system would make it on its first call otherwise):
+    // the compact patches of the blocked levels, the device copies of U_k
+    if (!h->patches_ready) build_patches(h);
+    if (h->cfg.device_setup) {
         PoolScope pool_scope_(&h->pool);
         HIPCHK(hipSetDevice(h->cfg.device));
-        if ((rc = ensure_device_transfers(h))) return rc;
+        int rc = ensure_device_transfers(h);
+        if (rc) return rc;
     }
     return GMG_OK;
 }

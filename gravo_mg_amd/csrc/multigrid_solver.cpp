@@ -6,12 +6,48 @@
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <thread>
 
 namespace MGBS {
 
 namespace {
 bool configEqual(const gmg_config& a, const gmg_config& b) { return std::memcmp(&a, &b, sizeof(gmg_config)) == 0; }
+
+// FNV-1a style digest of a byte range taken 8 bytes at a time, in up to 16 chunks hashed concurrently and combined in
+// order (the chunking is fixed by the length, so the digest is a function of the content only).
+uint64_t digestBytes(const void* data, size_t bytes, uint64_t seed) {
+    const size_t words = bytes / 8;
+    const int chunks = (int)std::min<size_t>(16, words / (1u << 16) + 1);
+    std::vector<uint64_t> part(chunks, 0);
+    auto work = [&](int c) {
+        const uint64_t* p = (const uint64_t*)data;
+        const size_t lo = words * c / chunks, hi = words * (c + 1) / chunks;
+        uint64_t h = 1469598103934665603ull ^ seed ^ (0x9e3779b97f4a7c15ull * (uint64_t)(c + 1));
+        for (size_t i = lo; i < hi; ++i) { uint64_t w; std::memcpy(&w, p + i, 8); h = (h ^ w) * 1099511628211ull; h ^= h >> 31; }
+        part[c] = h;
+    };
+    if (chunks == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int c = 1; c < chunks; ++c) th.emplace_back(work, c);
+        work(0);
+        for (auto& t : th) t.join();
+    }
+    uint64_t h = 1469598103934665603ull ^ seed ^ (uint64_t)bytes;
+    for (int c = 0; c < chunks; ++c) h = (h ^ part[c]) * 1099511628211ull;
+    const unsigned char* tail = (const unsigned char*)data + words * 8;
+    for (size_t i = 0; i < bytes - words * 8; ++i) h = (h ^ tail[i]) * 1099511628211ull;
+    return h;
+}
 }  // namespace
+
+std::pair<uint64_t, uint64_t> SparseMatrix::digest() const {
+    const size_t nnz = (size_t)nonZeros();
+    uint64_t a = digestBytes(outerPtr(), sizeof(int) * ((size_t)cols_ + 1), (uint64_t)rows_ * 0x100000001b3ull + (uint64_t)cols_);
+    a ^= digestBytes(innerPtr(), sizeof(int) * nnz, 0x51ed270b7f4a7c15ull) * 0x9e3779b97f4a7c15ull;
+    const uint64_t b = digestBytes(valuePtr(), sizeof(double) * nnz, 0xc2b2ae3d27d4eb4full);
+    return {a, b};
+}
 
 MultigridSolver::MultigridSolver(MatrixXd& V_, MatrixXi& neigh_, SparseMatrix& M_) : V(V_), neigh(neigh_), M(M_) {
     hierarchyTiming["n_vertices"] = V.rows();               // multigrid_solver.cpp:21
@@ -84,29 +120,38 @@ int MultigridSolver::ensureEngine() {
     return GMG_OK;
 }
 
-int MultigridSolver::ensureSystem(const SparseMatrix& LHS) {
+int MultigridSolver::prepareEngine() {
     int rc = ensureEngine();
     if (rc) return rc;
-    bool sameU = uploadedU_.size() == U.size();
-    for (size_t k = 0; sameU && k < U.size(); ++k) sameU = uploadedU_[k].sameAs(U[k]);
-    if (!sameU) {
+    // `U` is a public member the caller may replace (set_prolongation_matrices): compare content digests
+    std::vector<std::pair<uint64_t, uint64_t>> digU(U.size());
+    for (size_t k = 0; k < U.size(); ++k) digU[k] = U[k].digest();
+    if (digU != uploadedU_) {
         if ((rc = gmg_set_num_levels(engine_, (int)U.size()))) { err_ = gmg_last_error(engine_); return rc; }
         for (size_t k = 0; k < U.size(); ++k)
-            if ((rc = gmg_set_prolongation(engine_, (int)k, U[k].rows(), U[k].cols(), U[k].outer.data(), U[k].inner.data(), U[k].values.data()))) {
+            if ((rc = gmg_set_prolongation(engine_, (int)k, U[k].rows(), U[k].cols(), U[k].outerPtr(), U[k].innerPtr(), U[k].valuePtr()))) {
                 err_ = gmg_last_error(engine_);
                 return rc;
             }
-        uploadedU_ = U;
+        if (!U.empty() && (rc = gmg_finalize_hierarchy(engine_))) { err_ = gmg_last_error(engine_); return rc; }
+        uploadedU_ = digU;
         systemReady_ = false;
     }
-    if (!systemReady_ || !uploadedLHS_.sameAs(LHS)) {
+    return GMG_OK;
+}
+
+int MultigridSolver::ensureSystem(const SparseMatrix& LHS) {
+    int rc = prepareEngine();
+    if (rc) return rc;
+    const std::pair<uint64_t, uint64_t> digLHS = LHS.digest();
+    if (!systemReady_ || uploadedLHS_ != digLHS) {
         // mass diagonal for the M / M^-1 norms (multigrid_solver.cpp:1248-1264)
         std::vector<double> md(M.cols(), 0.0);
         for (int j = 0; j < M.cols(); ++j)
-            for (int p = M.outer[j]; p < M.outer[j + 1]; ++p) if (M.inner[p] == j) md[j] = M.values[p];
+            for (int p = M.outerPtr()[j]; p < M.outerPtr()[j + 1]; ++p) if (M.innerPtr()[p] == j) md[j] = M.valuePtr()[p];
         if ((rc = gmg_set_mass(engine_, (int)md.size(), md.data()))) { err_ = gmg_last_error(engine_); return rc; }
-        if ((rc = gmg_set_system(engine_, LHS.rows(), LHS.outer.data(), LHS.inner.data(), LHS.values.data()))) { err_ = gmg_last_error(engine_); systemReady_ = false; return rc; }
-        uploadedLHS_ = LHS;
+        if ((rc = gmg_set_system(engine_, LHS.rows(), LHS.outerPtr(), LHS.innerPtr(), LHS.valuePtr()))) { err_ = gmg_last_error(engine_); systemReady_ = false; return rc; }
+        uploadedLHS_ = digLHS;
         systemReady_ = true;
     }
     return GMG_OK;
@@ -147,7 +192,7 @@ void MultigridSolver::solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int s
         auto t0 = clk::now();
         int64_t nnzL = 0;
         std::vector<double> out(x.data.size());
-        int rc = gmg_host_ldlt_solve(LHS.rows(), LHS.outer.data(), LHS.inner.data(), LHS.values.data(), rhs.data.data(), rhs.cols(), out.data(), &nnzL);
+        int rc = gmg_host_ldlt_solve(LHS.rows(), LHS.outerPtr(), LHS.innerPtr(), LHS.valuePtr(), rhs.data.data(), rhs.cols(), out.data(), &nnzL);
         if (rc != GMG_OK) { err_ = "direct solve failed (zero pivot)"; std::cout << "ERROR! " << err_ << std::endl; return; }
         x.data = out;
         solverTiming["direct_total"] = ms(t0);

@@ -11,9 +11,11 @@
 #ifndef GRAVOMG_AMD_MULTIGRID_SOLVER_H
 #define GRAVOMG_AMD_MULTIGRID_SOLVER_H
 
+#include <cstdint>
 #include <map>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/gravomg_hip.h"
@@ -30,10 +32,20 @@ struct SparseMatrix {
     std::vector<int> outer;      // cols_+1
     std::vector<int> inner;      // nnz
     std::vector<double> values;  // nnz
+    // Optional non-owning view of caller storage (like Eigen::Map<SparseMatrix>): when set, the three arrays above are
+    // unused.  The pybind11 shim maps the caller's scipy arrays this way instead of copying 250 MB per solve.
+    const int* outerView = nullptr;
+    const int* innerView = nullptr;
+    const double* valuesView = nullptr;
     int rows() const { return rows_; }
     int cols() const { return cols_; }
-    int nonZeros() const { return outer.empty() ? 0 : outer[cols_]; }
-    bool sameAs(const SparseMatrix& o) const { return rows_ == o.rows_ && cols_ == o.cols_ && outer == o.outer && inner == o.inner && values == o.values; }
+    const int* outerPtr() const { return outerView ? outerView : outer.data(); }
+    const int* innerPtr() const { return outerView ? innerView : inner.data(); }
+    const double* valuePtr() const { return outerView ? valuesView : values.data(); }
+    int nonZeros() const { return (outerView || !outer.empty()) ? outerPtr()[cols_] : 0; }
+    // 128-bit content digest (shape, pattern, values), threaded: how the solver recognises an unchanged matrix without
+    // keeping a copy of it.
+    std::pair<uint64_t, uint64_t> digest() const;
 };
 
 struct MatrixXd {
@@ -109,6 +121,8 @@ public:
 
     /* MI355X engine knobs (not in the reference) */
     gmg_config engineConfig;
+    /* Creates the device engine and hands it the hierarchy (`U`) now rather than inside the first solve(); optional. */
+    int prepareEngine();
     const char* lastError() const;
     void clearError() { err_.clear(); }
 
@@ -116,8 +130,8 @@ private:
     int ensureEngine();
     int ensureSystem(const SparseMatrix& LHS);
     gmg_handle engine_ = nullptr;
-    std::vector<SparseMatrix> uploadedU_;
-    SparseMatrix uploadedLHS_;
+    std::vector<std::pair<uint64_t, uint64_t>> uploadedU_;     // digests of what the engine holds
+    std::pair<uint64_t, uint64_t> uploadedLHS_{0, 0};
     bool systemReady_ = false;
     gmg_config createdWith_;
     std::string err_;

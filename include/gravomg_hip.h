@@ -211,8 +211,12 @@ int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coars
 int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val);
 /* hierarchyTiming keys of the reference (multigrid_solver.cpp:21,57,90-97). */
 int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out);
-/* Convenience: feed every U_k of a built hierarchy into a solver handle. */
+/* Convenience: feed every U_k of a built hierarchy into a solver handle (and finalize it, see below). */
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
+/* Optional, after the last gmg_set_prolongation: build what depends on the hierarchy only (the reference's
+ * buildHierarchy phase, multigrid_solver.cpp:15-60) -- the device copies of U_k and the compact row patches of the
+ * block-hybrid smoother's levels -- now instead of inside the first gmg_set_system.  Idempotent. */
+int gmg_finalize_hierarchy(gmg_handle h);
 
 /* Host-only Galerkin product Ac = U^T A U (CSC in / CSC out, caller sizes the output with the first call:
  * pass colptr_out only to get nnz in colptr_out[n_coarse]).  Exposed for the RAP parity tests. */
@@ -224,16 +228,15 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
  * host logic.  mode 0: colour-major ordering (exact multicolour Gauss-Seidel), mode 1: block ordering
  * (block-hybrid Gauss-Seidel, `block_rows` rows per block).  In mode 0 `block_rows` is the colour-class
  * alignment (the config's row_align; 0 = 64).  info[0..5] = n_pad, n_colors, n_blocks,
- * stored SELL entries (off-diagonal), real off-diagonal entries, 0.  new2old must hold n + 64*(n/64 + 2)
- * ints if mode 1 and n + row_align*256 if mode 0 (only n_pad are written); color_begin 257 ints; blk_begin
- * n/64 + 3 ints; row_color like new2old (bytes).  Output pointers may be NULL. */
+ * stored SELL entries (off-diagonal), real off-diagonal entries, 0.  Output pointers may be NULL: call once
+ * with NULL outputs for the sizes, then with new2old / row_color of n_pad entries, color_begin of
+ * n_colors + 1 and blk_begin of n_blocks + 1 entries. */
 int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma,
                         int64_t* info, int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color);
 /* Host-only: x = A^{-1} b with the coarsest-level solver (minimum-degree + sparse LDL^T, host_ldlt.hpp),
  * b/x column-major n x d.  Returns GMG_ERR_NUMERIC on a zero pivot.  factor_nnz (optional) = nnz(L). */
 int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x,
                         int64_t* factor_nnz);
-
 #ifdef __cplusplus
 }
 #endif

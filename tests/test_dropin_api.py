@@ -136,3 +136,20 @@ def test_reference_call_pattern_smoothing_and_poisson(gravomg, oracle, tmp_path)
         gravomg.MultigridSolver(V, neigh, M, lower_bound=40, cycle_type=1).solve(lhs, rhs)
     xd = solver.direct_solve(lhs, rhs)
     assert np.linalg.norm(lhs @ xd - rhs) <= 1e-10 * np.linalg.norm(rhs)
+
+
+@pytest.mark.gpu
+def test_system_matrix_storage_formats_give_the_same_answers(gravomg, oracle):
+    """The shim maps CSC storage in place, maps CSR storage of a symmetric matrix as its own transpose, and converts
+    everything else (COO, ...) like pybind11's Eigen caster would: same results on every route."""
+    V, F, S, M, mass = _problem()
+    neigh = gravomg.util.neighbors_from_stiffness(S)
+    solver = gravomg.MultigridSolver(V, neigh, M, lower_bound=60)
+    lhs = sp.csr_matrix(M + 1e-3 * S)
+    rhs = M @ V
+    x_csr = solver.solve(lhs, rhs)
+    x_csc = solver.solve(sp.csc_matrix(lhs), rhs)          # gravomg.core prints a conversion notice and converts to CSR
+    x_coo = solver.solver.solve(sp.coo_matrix(lhs), rhs)    # straight into the pybind11 shim
+    assert np.array_equal(x_csr, x_csc) and np.array_equal(x_csr, x_coo)
+    assert abs(solver.residual(lhs, rhs, x_csr) - oracle.residual_check(lhs, mass, rhs, x_csr, 2)) <= 1e-9
+    assert solver.residual(lhs, rhs, x_csr) == solver.residual(sp.csc_matrix(lhs), rhs, x_csr)
