@@ -196,8 +196,16 @@ inline double mean_index_distance(const Mat& A) {
 // reorder: 0 never, 1 always, 2 automatic -- when the input vertex order has poor locality (a randomly ordered scan
 // or point cloud: every gather of x misses the caches, measured 3x per V-cycle at 3 M vertices) the rows inside a
 // colour follow a breadth-first patch order instead of the input order.
+// ext_base: a locality-preserving visit order supplied by the caller (the hierarchy's cluster order, see
+// cluster_order below); used instead of growing patches when a reordering is due.
 template <class Mat>
-inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma, int reorder = 0) {
+inline bool wants_locality_reorder(const Mat& A, int reorder) {
+    const int n = A.n_outer;
+    return reorder == 1 || (reorder == 2 && n > 65536 && mean_index_distance(A) > std::max(32768.0, n / 32.0));
+}
+
+template <class Mat>
+inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma, int reorder = 0, const std::vector<int>* ext_base = nullptr) {
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
@@ -210,9 +218,12 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
         tph = now;
     };
     std::vector<int> base;      // visit order (empty = natural)
-    if (reorder == 1 || (reorder == 2 && n > 65536 && mean_index_distance(A) > std::max(32768.0, n / 32.0))) {
-        std::vector<int> block_of, mem_begin;
-        grow_patches(A, 4096, block_of, base, mem_begin);
+    if (wants_locality_reorder(A, reorder)) {
+        if (ext_base && (int)ext_base->size() == n) base = *ext_base;
+        else {
+            std::vector<int> block_of, mem_begin;
+            grow_patches(A, 4096, block_of, base, mem_begin);
+        }
         o.reordered = true;
     }
     phase("locality");
@@ -392,6 +403,57 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
     }, 65536);
     phase("inverse");
     return o;
+}
+
+// Locality-preserving order of the finest level's points derived from the hierarchy alone: the coarsest points in
+// breadth-first order over their point graph, and on every finer level the points grouped by parent (the coarse point
+// with the largest prolongation weight), parents in the order just built, siblings in index order.  Points that are
+// close on the surface end up close in the order whatever the input numbering is.  Urows[k]: U_k by fine row;
+// GL: point graph of the coarsest level.  Returns new -> old of level 0.
+inline std::vector<int> cluster_order(const std::vector<Compressed>& Urows, const Compressed& GL) {
+    const int L = (int)Urows.size();
+    const int nL = GL.n_outer;
+    // coarsest level: BFS order over GL (restarting at the lowest unvisited index)
+    std::vector<int> pos(nL, -1);
+    {
+        std::vector<int> queue;
+        queue.reserve(nL);
+        for (int s = 0; s < nL; ++s) {
+            if (pos[s] >= 0) continue;
+            pos[s] = (int)queue.size(); queue.push_back(s);
+            for (size_t h = queue.size() - 1; h < queue.size(); ++h) {
+                const int v = queue[h];
+                for (int p = GL.ptr[v]; p < GL.ptr[v + 1]; ++p) { const int w = GL.idx[p]; if (pos[w] < 0) { pos[w] = (int)queue.size(); queue.push_back(w); } }
+            }
+        }
+    }
+    std::vector<int> order;
+    for (int k = L - 1; k >= 0; --k) {
+        const Compressed& R = Urows[k];
+        const int nf = R.n_outer, nc = R.n_inner;
+        const int T = std::max(1, std::min(hw_threads(), 32));
+        // key[i] = position of i's parent in the coarse order (orphans last)
+        std::vector<int> key(nf);
+        parallel_ranges(nf, T, [&](int lo, int hi, int) {
+            for (int i = lo; i < hi; ++i) {
+                int best = -1; double bw = -1.0;
+                for (int p = R.ptr[i]; p < R.ptr[i + 1]; ++p) {
+                    const double w = std::abs(R.val[p]);
+                    if (w > bw || (w == bw && R.idx[p] < best)) { bw = w; best = R.idx[p]; }
+                }
+                key[i] = best >= 0 ? pos[best] : nc;
+            }
+        });
+        // stable counting sort by key
+        std::vector<int> start((size_t)nc + 2, 0);
+        for (int i = 0; i < nf; ++i) start[key[i] + 1]++;
+        for (int c = 0; c <= nc; ++c) start[c + 1] += start[c];
+        order.assign(nf, 0);
+        for (int i = 0; i < nf; ++i) order[start[key[i]]++] = i;
+        pos.assign(nf, 0);
+        parallel_ranges(nf, T, [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) pos[order[r]] = r; });
+    }
+    return order;
 }
 
 inline LevelOrdering identity_ordering(int n) {

@@ -200,6 +200,24 @@ __global__ __launch_bounds__(256) void window_order_by_length(const int* __restr
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) order[w0 + i] = w0 + (key[i] & 0xffff);
 }
 
+// The sparsity pattern permuted symmetrically: new row r = old row perm[r], columns renumbered by inv (old -> new).
+// Two launches around a prefix sum; column order inside a row is kept (the colouring that consumes it does not care).
+__global__ void perm_row_lengths(const int* __restrict__ ptr, const int* __restrict__ perm, int n, int* __restrict__ len) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int old = perm[r];
+    len[r] = ptr[old + 1] - ptr[old];
+}
+
+__global__ void perm_fill(const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ perm, const int* __restrict__ inv,
+                          const int* __restrict__ pptr, int n, int* __restrict__ pidx) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int old = perm[r];
+    const int b = ptr[old], e = ptr[old + 1], o = pptr[r];
+    for (int q = b; q < e; ++q) pidx[o + (q - b)] = inv[idx[q]];
+}
+
 // row -> block map of a blocked ordering (blk_begin: n_blocks + 1 device rows)
 __global__ void block_of_rows(const int* __restrict__ blk_begin, int n_blocks, int* __restrict__ blk_of_row) {
     const int b = blockIdx.x;
