@@ -1048,7 +1048,7 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
     HIPCHK(hipStreamSynchronize(h->stream));
     auto t0 = clk::now();
     std::memset(e, 0, sizeof(double) * cnt);
-    for (int col = 0; col < d; ++col) h->coarse.solve(rc + (size_t)col * c.n_pad, e + (size_t)col * c.n_pad, h->coarse_work.data());
+    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
     h->timing["coarse_host_ms"] += ms_since(t0);
     HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
     if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
@@ -1592,7 +1592,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     (void)hipStreamSynchronize(h->stream);      // staged host arrays die at scope end
     if (rc_all != GMG_OK) return err_all.empty() ? rc_all : fail(h, rc_all, err_all);
     if (!factor_ok) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
-    h->coarse_work.assign(h->lv[L].A.n_outer, 0.0);
+    h->coarse_work.assign((size_t)h->lv[L].A.n_outer * 4, 0.0);
     h->timing["coarsest_solve"] = ms_factor;
     h->timing["setup_ordering"] = 0.0; h->timing["setup_sell"] = 0.0;
     for (int k = 0; k <= L; ++k) h->timing["setup_ordering_l" + std::to_string(k)] = stage[k].ms_order;

@@ -121,6 +121,47 @@ public:
         for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     }
 
+    // d right-hand sides at once (columns b + c*ldb -> x + c*ldx): every entry of L is loaded once and used d times.
+    // Per column the operations and their order are those of solve(), so the results are bitwise the same.
+    // work: n * min(d, 4) doubles.
+    void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work) const {
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            const int dc = std::min(4, d - c0);
+            switch (dc) {
+                case 1: solve(b + c0 * ldb, x + c0 * ldx, work); break;
+                case 2: solve_block<2>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+                case 3: solve_block<3>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+                default: solve_block<4>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+            }
+        }
+    }
+
+    template <int DC>
+    void solve_block(const double* b, size_t ldb, double* x, size_t ldx, double* y) const {
+        for (int i = 0; i < n; ++i) for (int c = 0; c < DC; ++c) y[(size_t)i * DC + c] = b[c * ldb + perm[i]];
+        for (int j = 0; j < n; ++j) {
+            double yj[DC];
+            for (int c = 0; c < DC; ++c) yj[c] = y[(size_t)j * DC + c];
+            for (int p = Lp[j]; p < Lp[j + 1]; ++p) {
+                const double l = Lx[p];
+                double* t = y + (size_t)Li[p] * DC;
+                for (int c = 0; c < DC; ++c) t[c] -= l * yj[c];
+            }
+        }
+        for (int j = 0; j < n; ++j) for (int c = 0; c < DC; ++c) y[(size_t)j * DC + c] /= D[j];
+        for (int j = n - 1; j >= 0; --j) {
+            double sj[DC];
+            for (int c = 0; c < DC; ++c) sj[c] = y[(size_t)j * DC + c];
+            for (int p = Lp[j]; p < Lp[j + 1]; ++p) {
+                const double l = Lx[p];
+                const double* t = y + (size_t)Li[p] * DC;
+                for (int c = 0; c < DC; ++c) sj[c] -= l * t[c];
+            }
+            for (int c = 0; c < DC; ++c) y[(size_t)j * DC + c] = sj[c];
+        }
+        for (int i = 0; i < n; ++i) for (int c = 0; c < DC; ++c) x[c * ldx + perm[i]] = y[(size_t)i * DC + c];
+    }
+
     long factor_nnz() const { return (long)Lp.empty() ? 0 : Lp[n]; }
 
     static constexpr int kLeaf = 320;             // nested dissection stops at regions of this size
