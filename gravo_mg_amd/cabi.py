@@ -97,6 +97,9 @@ SIGNATURES = {
     "gmg_dist_coarse_cycle": (C.c_int, [_vp]),
     "gmg_dist_prolong_own": (C.c_int, [_vp]),
     "gmg_dist_norm_partial": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_dist_residual_all": (C.c_int, [_vp]),
+    "gmg_dist_prolong_all": (C.c_int, [_vp]),
+    "gmg_dist_norm_all": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
@@ -488,6 +491,17 @@ class Engine:
     def dist_norm_partial(self, type: int, d: int) -> np.ndarray:
         sums = np.zeros(2 * d)
         self._chk(lib().gmg_dist_norm_partial(self._h, int(type), _pd(sums)))
+        return sums
+
+    def dist_residual_all(self):
+        self._chk(lib().gmg_dist_residual_all(self._h))
+
+    def dist_prolong_all(self):
+        self._chk(lib().gmg_dist_prolong_all(self._h))
+
+    def dist_norm_all(self, type: int, d: int) -> np.ndarray:
+        sums = np.zeros(2 * d)
+        self._chk(lib().gmg_dist_norm_all(self._h, int(type), _pd(sums)))
         return sums
 
 

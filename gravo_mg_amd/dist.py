@@ -5,14 +5,13 @@ of level 0 is colour-major; every colour class is padded to 64*P rows and cut in
 rank p owns piece p of every colour.  Levels >= 1 are small (<= n_0/6) and are REPLICATED: every rank runs them
 redundantly, which needs no communication at all.
 
-Exchange steps per V-cycle (each an in-place all-gather of one colour's segment of a level-0 vector; a rank's
-input is its own piece of the output buffer):
-    after every colour of every Gauss-Seidel sweep ......... x  (the next colour reads it)
-    after the residual ..................................... r  (the replicated restriction needs all of it)
-    after the prolongation ................................. x
-plus one all-reduce of 2*d doubles per residual check.  Because the colours are GLOBAL, the distributed sweep is
-the same multicolour Gauss-Seidel as on one GPU: results are independent of P up to the summation order of the
-norm.  (A halo-only exchange would move O(sqrt(n/P)) instead of n/(C*P) values per step -- the collective count,
+Exchange steps per V-cycle (each an in-place all-gather of one colour's segment of x; a rank's input is its own
+piece of the output buffer): one after every colour of every Gauss-Seidel sweep (the next colour reads it) --
+16 per cycle on a 4-colour mesh with 2+2 sweeps.  After such an exchange every rank holds the complete x, so the
+cheap steps around the sweeps (residual, prolongation-add, residual norm) are computed REDUNDANTLY on all rows
+instead of being exchanged (`replicate=True`, the default; `replicate=False` keeps them row-partitioned with an
+all-gather of r / x and an all-reduce of the norm sums: 24 collectives + 1 per cycle).  Because the colours are
+GLOBAL, the distributed sweep is the same multicolour Gauss-Seidel as on one GPU: results are independent of P.  (A halo-only exchange would move O(sqrt(n/P)) instead of n/(C*P) values per step -- the collective count,
 i.e. the latency, stays the same; at 3 M vertices the path is latency-bound either way)
 
 The local work is done by a *backend*: `EngineBackend` launches this rank's share on its GPU through the C-ABI
@@ -33,8 +32,9 @@ class DistVCycle:
     """V-cycle + residual check + solve loop over `world` ranks.  `backend` provides the local steps and the
     level-0 vectors x, b, r as flat torch tensors of length d * n_pad (column-major)."""
 
-    def __init__(self, backend, group=None):
+    def __init__(self, backend, group=None, replicate: bool = True):
         self.be = backend
+        self.replicate = bool(replicate)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -77,17 +77,23 @@ class DistVCycle:
     def vcycle(self):
         with self.be.stream_context():              # kernels and collectives ordered on the backend's stream
             self.smooth(self.be.pre_iters)              # :1063
-            self.be.residual_own()                      # :1066
-            self._allgather_all(self.be.r)
+            if self.replicate:
+                self.be.residual_all()                  # :1066, all rows on every rank (x is complete)
+            else:
+                self.be.residual_own()
+                self._allgather_all(self.be.r)
             self.be.coarse_cycle()                      # :1069-1079 (replicated)
-            self.be.prolong_own()                       # :1082
-            self._allgather_all(self.be.x)
+            if self.replicate:
+                self.be.prolong_all()                   # :1082
+            else:
+                self.be.prolong_own()
+                self._allgather_all(self.be.x)
             self.smooth(self.be.post_iters)             # :1085
 
     # -- residualCheck (:1228-1277) ---------------------------------------------------------------------------
     def residual_norm(self, type: int = 2) -> float:
-        sums = torch.as_tensor(np.asarray(self.be.norm_partial(type), dtype=np.float64))
-        if self.world > 1:
+        sums = torch.as_tensor(np.asarray(self.be.norm_all(type) if self.replicate else self.be.norm_partial(type), dtype=np.float64))
+        if self.world > 1 and not self.replicate:
             with self.be.stream_context():
                 t = sums.to(self.be.x.device)
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -158,3 +164,12 @@ class EngineBackend:
 
     def norm_partial(self, type):
         return self.eng.dist_norm_partial(type, self.d)
+
+    def residual_all(self):
+        self.eng.dist_residual_all()
+
+    def prolong_all(self):
+        self.eng.dist_prolong_all()
+
+    def norm_all(self, type):
+        return self.eng.dist_norm_all(type, self.d)

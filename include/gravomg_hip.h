@@ -179,6 +179,12 @@ int gmg_dist_coarse_cycle(gmg_handle h);
 int gmg_dist_prolong_own(gmg_handle h);
 /* This rank's share of the residual-norm sums: sums[2c] = sum w r^2, sums[2c+1] = sum w b^2 for rhs column c. */
 int gmg_dist_norm_partial(gmg_handle h, int type, double* sums);
+/* The same three steps over ALL rows of level 0: after the exchange that follows every colour sweep each rank holds
+ * the complete x0, so these can be computed redundantly instead of being exchanged (no collective for r0, for the
+ * prolongated x0 or for the norm sums, which then are identical on every rank). */
+int gmg_dist_residual_all(gmg_handle h);
+int gmg_dist_prolong_all(gmg_handle h);
+int gmg_dist_norm_all(gmg_handle h, int type, double* sums);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:
