@@ -1,0 +1,82 @@
+"""BASELINE.json's headline size (the ~3 M-vertex mesh Poisson problem of bench.py) through size-independent
+properties -- the oracle needs minutes for full solves at this size, so parity is checked on what does not depend on
+the size: the V-cycle is an affine map with a linear part, right-hand-side columns do not interact, the residual
+history contracts monotonically to the reference's stopping test, the oracle's one-pass residualCheck of the returned
+solution agrees with the device's, every Galerkin level is U^T A U of the level above (checked on random probes
+through the device operators), and a second set_system with the same pattern reproduces the first bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(cabi):
+    from gravo_mg_amd import meshgen
+    V, F = meshgen.torus_mesh(1732, 1732)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    H = cabi.Hierarchy(V, meshgen.neighbors_from_stiffness(S), ratio=8.0, lower_bound=1000)
+    lhs, rhs = meshgen.poisson_system(S, mass, tau=1e-6, seed=42, d=1)
+    eng = cabi.Engine()
+    eng.use_hierarchy(H); eng.set_mass(mass); eng.set_system(lhs)
+    return dict(V=V, S=S, mass=mass, H=H, lhs=lhs, rhs=rhs, eng=eng)
+
+
+def test_solve_reaches_the_stopping_test_and_the_oracle_agrees(big, oracle):
+    eng, lhs, rhs, mass = big["eng"], big["lhs"], big["rhs"], big["mass"]
+    x, it, res, conv = eng.solve(rhs, tol=1e-4, stop_type=2, max_iter=100)
+    assert it == 7 and res <= 1e-4                                   # the count DESIGN.md / bench.py quote
+    assert np.all(np.diff(conv[:, 1]) < 0)                           # monotone contraction
+    assert np.all(conv[1:, 1] / conv[:-1, 1] < 0.45)                 # ... at the multigrid rate, every cycle
+    chk = oracle.residual_check(lhs, mass, rhs, x, 2)                # one CPU SpMV: the reference's own stopping quantity
+    assert abs(chk - res) <= 1e-3 * res + 1e-7
+    for t in (0, 1, 3):                                              # the other residualCheck types
+        assert abs(eng.residual_norm(rhs, x, t) - oracle.residual_check(lhs, mass, rhs, x, t)) <= 1e-3 * oracle.residual_check(lhs, mass, rhs, x, t) + 1e-7
+
+
+def test_vcycle_is_affine_and_columns_do_not_interact(big):
+    eng, rhs = big["eng"], big["rhs"]
+    n = rhs.shape[0]
+    rng = np.random.default_rng(7)
+    b1, b2 = rhs[:, 0].copy(), rng.standard_normal(n) * np.abs(rhs[:, 0]).mean()
+    x1, x2 = rng.standard_normal(n), rng.standard_normal(n)
+    v = lambda b, x: eng.vcycle(b[:, None], x[:, None])[:, 0]
+    y1, y2, y12, y0 = v(b1, x1), v(b2, x2), v(b1 + b2, x1 + x2), v(np.zeros(n), np.zeros(n))
+    assert np.abs(y0).max() == 0.0                                   # V(0, 0) = 0: the map is linear in (b, x)
+    scale = np.abs(y1).max() + np.abs(y2).max()
+    # superposition, to rounding: the coarsest solve of tau*M + S (tau = 1e-6) amplifies rounding along the near-null
+    # constant mode by ~1/tau, so the defect is a constant of relative size ~1e-10 rather than 1e-15
+    assert np.abs(y12 - (y1 + y2)).max() <= 1e-9 * scale
+    # three right-hand sides at once == one at a time, bit for bit (no cross-column arithmetic anywhere on the path)
+    B = np.column_stack([b1, b2, b1 - 2 * b2]); X = np.column_stack([x1, x2, x1 + x2])
+    Y = eng.vcycle(B, X)
+    assert np.array_equal(Y[:, 0], y1) and np.array_equal(Y[:, 1], y2)
+    assert np.array_equal(Y[:, 2], v(B[:, 2].copy(), X[:, 2].copy()))
+
+
+def test_galerkin_levels_and_transfers_on_random_probes(big):
+    """A_{k+1} z == U_k^T (A_k (U_k z)) through the device operators, restriction is the transpose of prolongation."""
+    eng, H = big["eng"], big["H"]
+    rng = np.random.default_rng(3)
+    for k in range(eng.num_levels):
+        nf, nc = eng.level_info(k)["n"], eng.level_info(k + 1)["n"]
+        z = rng.standard_normal((nc, 1)); w = rng.standard_normal((nf, 1))
+        Uz = eng.prolong_add(k, z, np.zeros((nf, 1)))
+        lhs_side = eng.spmv(k + 1, z) if k + 1 < eng.num_levels else eng.level_operator(k + 1) @ z    # the coarsest level only has its factor on the host
+        rhs_side = eng.restrict(k, eng.spmv(k, Uz))
+        assert np.linalg.norm(lhs_side - rhs_side) <= 1e-12 * np.linalg.norm(rhs_side)
+        assert abs((w * Uz).sum() - (eng.restrict(k, w) * z).sum()) <= 1e-12 * np.linalg.norm(w) * np.linalg.norm(Uz)
+        assert np.linalg.norm(Uz - H.U[k] @ z) <= 1e-13 * np.linalg.norm(Uz)
+
+
+def test_repeated_system_is_reproduced_bit_for_bit(big, cabi):
+    eng, lhs, rhs = big["eng"], big["lhs"], big["rhs"]
+    eng.load_problem(rhs, rhs); h1 = eng.run_cycles(4, 2); x1 = eng.fetch_solution()
+    eng.set_system(lhs)                                              # same pattern: cached orderings, fresh RAP + layouts
+    assert eng.timing("setup_ordering_cached") == 1.0
+    eng.load_problem(rhs, rhs); h2 = eng.run_cycles(4, 2); x2 = eng.fetch_solution()
+    assert np.array_equal(h1, h2) and np.array_equal(x1, x2)
+    other = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE)      # the device-side coarse apply: same iteration to rounding
+    other.use_hierarchy(big["H"]); other.set_mass(big["mass"]); other.set_system(lhs)
+    other.load_problem(rhs, rhs); h3 = other.run_cycles(4, 2)
+    assert np.allclose(h3, h1, rtol=1e-6)
