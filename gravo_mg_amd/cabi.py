@@ -41,7 +41,7 @@ class GmgConfig(C.Structure):
         ("device", C.c_int), ("smoother", C.c_int), ("jacobi_omega", C.c_double), ("pre_iters", C.c_int),
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
-        ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("host_threads", C.c_int),
+        ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
         ("verbose", C.c_int),
     ]
 
@@ -262,7 +262,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=1024, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, device=0, verbose=False):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -271,7 +271,7 @@ class Engine:
         cfg.use_graph, cfg.sigma, cfg.row_align, cfg.verbose = int(bool(use_graph)), int(sigma), int(row_align), int(bool(verbose))
         cfg.block_rows, cfg.block_from_level, cfg.block_lanes = int(block_rows), int(block_from_level), int(block_lanes)
         cfg.device_setup, cfg.device_rap, cfg.reorder_fine = int(bool(device_setup)), int(bool(device_rap)), int(reorder_fine)
-        cfg.inner_precision = int(inner_precision)
+        cfg.inner_precision, cfg.block_csr = int(inner_precision), int(bool(block_csr))
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -358,7 +358,8 @@ class Engine:
         return bb, rc
 
     def debug_sell(self, k: int, which: int) -> dict:
-        """Device-resident SELL layout (0 A, 1 A_in, 2 A_out, 3 P, 4 R) copied back, for layout parity tests."""
+        """Device-resident SELL layout (0 A, 1 A_in, 2 A_out, 3 P, 4 R) copied back, for layout parity tests.  5 = the
+        block-CSR of a big blocked level: slice_ptr holds the row pointers, row_of the per-row start of the in-block entries."""
         info = (C.c_int64 * 4)()
         self._chk(lib().gmg_debug_sell_info(self._h, int(k), int(which), info))
         ns, lpr, stored, has_row_of = (int(v) for v in info)

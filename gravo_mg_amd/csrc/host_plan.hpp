@@ -650,6 +650,55 @@ inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering
     return csr_to_sell(np, ocol.n_pad, st, sort_sigma, lpr);
 }
 
+// Block-CSR of the OFF-BLOCK operator of a blocked level (the specification of setup_kernels.hip.hpp::csr_fill with the
+// off-block filter): the entries of device row r that leave r's block, ascending device column; mid[r] = end of the row
+// (csr_fill writes in-block entries after it when its filter keeps them; here there are none).
+struct BlockCsrHost {
+    std::vector<int> ptr, mid;      // n_pad + 1, n_pad
+    RawVec<int> col;
+    RawVec<double> val;
+    int max_block_entries = 0;
+};
+
+inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& ord, BlockCsrHost& out) {
+    const int np = ord.n_pad;
+    out.ptr.assign((size_t)np + 1, 0);
+    out.mid.assign(np, 0);
+    std::vector<int> blk_of(np, 0);
+    for (int b = 0; b < ord.n_blocks(); ++b) for (int r = ord.blk_begin[b]; r < ord.blk_begin[b + 1]; ++r) blk_of[r] = b;
+    parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
+        for (int r = lo; r < hi; ++r) {
+            const int old = ord.new2old[r];
+            int n = 0;
+            if (old >= 0) {
+                const int b = blk_of[r], r0 = ord.blk_begin[b], r1 = ord.blk_begin[b + 1];
+                for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int c = ord.old2new[A.idx[p]]; n += A.idx[p] != old && (c < r0 || c >= r1); }
+            }
+            out.ptr[r + 1] = n;
+        }
+    });
+    for (int r = 0; r < np; ++r) out.ptr[r + 1] += out.ptr[r];
+    out.col.resize(out.ptr[np]); out.val.resize(out.ptr[np]);
+    const int nb = ord.n_blocks();
+    parallel_ranges(nb, hw_threads(), [&](int lo, int hi, int) {
+        std::vector<std::pair<int, double>> e;
+        for (int b = lo; b < hi; ++b) {
+            const int r0 = ord.blk_begin[b], r1 = ord.blk_begin[b + 1];
+            for (int r = r0; r < r1; ++r) {
+                const int old = ord.new2old[r];
+                e.clear();
+                if (old >= 0) for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) if (A.idx[p] != old) e.emplace_back(ord.old2new[A.idx[p]], A.val[p]);
+                std::stable_sort(e.begin(), e.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+                int q = out.ptr[r];
+                for (auto& t : e) if (t.first < r0 || t.first >= r1) { out.col[q] = t.first; out.val[q] = t.second; ++q; }
+                out.mid[r] = q;
+            }
+        }
+    }, 64);
+    out.max_block_entries = 0;
+    for (int b = 0; b < nb; ++b) out.max_block_entries = std::max(out.max_block_entries, out.ptr[ord.blk_begin[b + 1]] - out.ptr[ord.blk_begin[b]]);
+}
+
 // Rows of U (fine-row major) from its CSC storage, threaded: per-row counts with atomics, prefix sum, scatter.
 // Entry order inside a row is arbitrary (the builders above sort every row by device column anyway).
 inline Compressed transpose_parallel(const Compressed& a) {

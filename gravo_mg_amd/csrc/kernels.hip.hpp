@@ -214,6 +214,125 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     }
 }
 
+// The same sweep with the OFF-BLOCK operator in block-CSR storage (big blocked levels, 64-row blocks, one wavefront per
+// block).  A block's SELL slice is as wide as its longest row, and off-block entries are concentrated on the block's
+// border rows (interior rows have none): the padded off-block SELL operator stored 2.99x its real entries on the
+// 506 k-row level (PMC: the sweep moved 218 MB for 103 MB of entries and was bound by it).  Here the off-block
+// entries of the level are a plain CSR in device numbering; rows of a block are contiguous, so a block's entries are
+// ONE contiguous chunk, which the wave copies into LDS with perfectly coalesced loads; every lane then sums its row's
+// couplings from there (x gathered from the previous iterate).  The in-block operator stays in SELL (its entries go
+// to registers for the colour loop, exactly as in gs_block).  Same arithmetic, same order: results are bitwise those
+// of gs_block.
+template <class T, int D, int WIN>
+__global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
+                                                      const unsigned char* __restrict__ row_color,
+                                                      const int64_t* __restrict__ in_ptr, const unsigned short* __restrict__ in_col,
+                                                      const T* __restrict__ in_val, const int* __restrict__ out_ptr,
+                                                      const int* __restrict__ out_col, const T* __restrict__ out_val,
+                                                      const T* __restrict__ diag, const T* __restrict__ b, const T* __restrict__ x_in,
+                                                      T* __restrict__ x_out, int ld, int cap) {
+    extern __shared__ unsigned char smem_raw[];
+    T* sval = reinterpret_cast<T*>(smem_raw);                          // cap values
+    int* scol = reinterpret_cast<int*>(sval + cap);                    // cap columns
+    T* xs = reinterpret_cast<T*>(scol + cap);                          // D x 64: the block's x
+    const int blk = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int r0 = blk_begin[blk];                                     // 64 rows (padding rows: no entries, diag 1, b 0)
+    const int row = r0 + lane;
+    const int s = r0 >> 6;
+    const int e0 = out_ptr[r0], e1 = out_ptr[r0 + 64];
+    const int cnt = e1 - e0;
+    for (int e = lane; e < cnt; e += 64) { sval[e] = out_val[e0 + e]; scol[e] = out_col[e0 + e]; }
+#pragma unroll
+    for (int c = 0; c < D; ++c) xs[c * 64 + lane] = x_in[row + (int64_t)c * ld];
+    // in-block entries of this lane's row: SELL -> registers (zero-padded window, 16-bit local columns packed in pairs)
+    constexpr int CH = D == 1 ? 8 : 4;
+    T v[WIN];
+    unsigned cpk[WIN / 2];
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) v[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < WIN / 2; ++j) cpk[j] = 0u;
+    const int64_t p0 = in_ptr[s];
+    const int w = (int)((in_ptr[s + 1] - p0) >> 6);
+#pragma unroll
+    for (int j0 = 0; j0 < WIN; j0 += 8)
+        if (j0 < w) {
+#pragma unroll
+            for (int j = j0; j < j0 + 8; ++j)
+                if (j < w) {
+                    v[j] = in_val[p0 + (int64_t)j * 64 + lane];
+                    cpk[j >> 1] |= (unsigned)in_col[p0 + (int64_t)j * 64 + lane] << ((j & 1) * 16);
+                }
+        }
+    const int mb = out_ptr[row] - e0, me = out_ptr[row + 1] - e0;
+    T rhs[D];
+    const T dg = (T)1.0 / diag[row];
+    const int mycolor = row_color[row];
+    __syncthreads();
+    // ---- off-block couplings (previous iterate), four gathers in flight; summed in stored order like gs_block
+    {
+        T acc[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = 0.0;
+        int e = mb;
+        for (; e + 4 <= me; e += 4) {
+            int cc[4]; T vv[4]; T xv[4][D];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cc[j] = scol[e + j]; vv[j] = sval[e + j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < D; ++c) xv[j][c] = x_in[cc[j] + (int64_t)c * ld];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[c] += vv[j] * xv[j][c];
+        }
+        for (; e < me; ++e) {
+            const int cj = scol[e]; const T vj = sval[e];
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] += vj * x_in[cj + (int64_t)c * ld];
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
+    }
+    const int nc = blk_ncolors[blk];
+    for (int col = 0; col < nc; ++col) {
+        if (mycolor == col) {
+            T s_[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] = 0.0;
+#pragma unroll
+            for (int j0 = 0; j0 < WIN; j0 += CH)
+                if (j0 < w) {
+                    T xv[CH][D];
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const int cj = (cpk[(j0 + j) >> 1] >> (((j0 + j) & 1) * 16)) & 0xffff;
+#pragma unroll
+                        for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + cj];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
+                }
+            for (int j = WIN; j < w; ++j) {                            // rows longer than the register window (rare)
+                const T vj = in_val[p0 + (int64_t)j * 64 + lane];
+                const int cj = in_col[p0 + (int64_t)j * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < D; ++c) s_[c] += vj * xs[c * 64 + cj];
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - s_[c]) * dg;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
+}
+
 // The same sweep on the QUAD layout (4 lanes per row; blocks of <= 256 rows = 1024 threads).  A colour step is the
 // critical path of the coarse levels -- 13-16 of them run back to back with one or two wavefronts active -- so the
 // row is spread over four lanes: each lane keeps <= WQ in-block entries in registers, gathers them from LDS in one

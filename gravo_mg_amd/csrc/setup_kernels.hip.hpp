@@ -104,6 +104,47 @@ __global__ void sell_fill(const int* __restrict__ pbeg, const int* __restrict__ 
     }
 }
 
+// Block-CSR of a big blocked level (kernels.hip.hpp::gs_blockcsr): off-diagonal entries of device row r at
+// [row_ptr[r], row_ptr[r + 1]), device column numbers, the entries that leave the row's block first (ascending column),
+// then the in-block ones (ascending column) from row_mid[r] on.  row_ptr comes from row_lengths (mode 0) + a prefix sum.
+__global__ void csr_fill(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx, const double* __restrict__ val,
+                         RowFilter f, const int* __restrict__ blk_of_row, const int* __restrict__ blk_begin, int n_rows_pad,
+                         const int* __restrict__ row_ptr, int* __restrict__ row_mid, int* __restrict__ col, double* __restrict__ out_val,
+                         int* __restrict__ err_flag) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows_pad) return;
+    const int old = f.new2old_row[r];
+    int cs[kMaxRow];
+    double vs[kMaxRow];
+    int n = 0;
+    if (old >= 0) {
+        for (int p = pbeg[old]; p < pend[old]; ++p) {
+            const int oc = idx[p];
+            int c;
+            if (!keep_entry(f, r, old, oc, c)) continue;
+            if (n >= kMaxRow) { atomicExch(err_flag, 1); break; }
+            int q = n;
+            const double v = val[p];
+            while (q > 0 && cs[q - 1] > c) { cs[q] = cs[q - 1]; vs[q] = vs[q - 1]; --q; }
+            cs[q] = c; vs[q] = v;
+            ++n;
+        }
+    }
+    const int b = blk_of_row[r];
+    const int r0 = blk_begin[b], r1 = blk_begin[b + 1];
+    int q = row_ptr[r];
+    for (int e = 0; e < n; ++e) if (cs[e] < r0 || cs[e] >= r1) { col[q] = cs[e]; out_val[q] = vs[e]; ++q; }
+    row_mid[r] = q;
+    for (int e = 0; e < n; ++e) if (cs[e] >= r0 && cs[e] < r1) { col[q] = cs[e]; out_val[q] = vs[e]; ++q; }
+}
+
+// max over the blocks of their entry count (LDS capacity the sweep kernel needs)
+__global__ void block_entry_max(const int* __restrict__ blk_begin, int n_blocks, const int* __restrict__ row_ptr, int* __restrict__ out_max) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    atomicMax(out_max, row_ptr[blk_begin[b + 1]] - row_ptr[blk_begin[b]]);
+}
+
 // ---- exclusive prefix sums on the device (slice pointers, RAP row pointers): out[0] = 0, out[i + 1] = in[0] + .. + in[i].
 // Three small launches: per-tile sums, one block scanning the tile sums, per-tile rescan with the tile offset.
 constexpr int kScanTile = 2048;     // items per 256-thread block (8 per thread)

@@ -73,6 +73,9 @@ typedef struct {
                               operators) as the correction operator of an fp64 defect-correction loop: r = b - A x in fp64,
                               e = Vcycle32(r) from a zero guess, x += e.  Same iteration as the fp64 V-cycle with initial guess
                               (every stage is affine); the residual check uses the fp64 residual that feeds the next cycle */
+    int block_csr;         /* 1 (default): blocked levels with one lane per row and 64-row blocks (the big ones) store their
+                              operator as a block-ordered CSR staged through LDS by the sweep instead of two padded SELL
+                              operators (half the traffic: a block's SELL slices are as wide as its longest row); 0: SELL */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
 } gmg_config;

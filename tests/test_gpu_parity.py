@@ -91,8 +91,22 @@ def test_block_hybrid_sweep_matches_matrix_form(setup, oracle):
     """Blocked levels (default: every level >= 1): one sweep == x + T^-1 (b - A x) with
     T = D + strict-lower(A restricted to the block diagonal) in device order: Jacobi between blocks, exact
     Gauss-Seidel inside a block.  The residual comes from the oracle, T^-1 from scipy."""
-    import scipy.sparse.linalg as spla
     P, eng = setup
+    _check_block_sweeps(P, eng, oracle)
+
+
+def test_block_hybrid_sweep_of_the_big_level_kernels(setup, cabi, oracle):
+    """The same identity for the kernels big blocked levels use (one lane per row, 64-row blocks): the SELL sweep for one
+    right-hand side and the sweep with the off-block operator in block-CSR for several (forced here by block_lanes=1)."""
+    P, _ = setup
+    for kw in (dict(block_lanes=1), dict(block_lanes=1, block_csr=False)):
+        eng = cabi.Engine(**kw)
+        eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+        _check_block_sweeps(P, eng, oracle)
+
+
+def _check_block_sweeps(P, eng, oracle):
+    import scipy.sparse.linalg as spla
     rng = np.random.default_rng(7)
     checked = 0
     for k in range(len(P.U)):
