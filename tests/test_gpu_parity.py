@@ -286,12 +286,13 @@ def test_errors_are_loud(cabi):
         eng.residual_norm(P.rhs, P.rhs, 2)                       # mass not set
 
 
-def test_more_than_four_right_hand_sides(cabi, oracle):
+@pytest.mark.parametrize("kw", [dict(), dict(block_lanes=1)], ids=["default", "big-level-kernels"])
+def test_more_than_four_right_hand_sides(cabi, oracle, kw):
     """d > 4 is processed in column chunks of <= 4 (the reference is only safe for d in {1, 3})."""
     P = problems.torus_problem(64, 60, "smoothing", 60)
     rng = np.random.default_rng(11)
     B = P.mass[:, None] * rng.standard_normal((P.n, 6))
-    eng = cabi.Engine()
+    eng = cabi.Engine(**kw)
     eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
     A = eng.level_operator(0)
     X = rng.standard_normal((P.n, 6))
