@@ -5,8 +5,9 @@
 // back-substitution once per V-cycle at :1075).  Eigen is a third-party dependency that is not
 // present; this is an independent implementation of the same mathematical object: a fill-reducing
 // symmetric permutation (minimum degree on the explicit elimination graph -- the coarsest level has
-// 1 000 ... ~8 000 unknowns) followed by an up-looking sparse LDL^T driven by the
-// elimination tree.
+// 1 000 ... ~8 000 unknowns) followed by a sparse LDL^T.  Two implementations: SparseLDLT (simplicial,
+// up-looking, driven by the elimination tree: the compact reference) and SupernodalLDLT (dense panels, the one the
+// engine uses: 3-4x faster factorisation and 2x faster back-substitution on the ~21-entries-per-row Galerkin operators).
 #pragma once
 #include <algorithm>
 #include <cmath>
@@ -162,6 +163,12 @@ public:
         for (int i = 0; i < n; ++i) for (int c = 0; c < DC; ++c) x[c * ldx + perm[i]] = y[(size_t)i * DC + c];
     }
 
+    // the fill-reducing permutation alone (what factor() starts with)
+    void compute_ordering(const Compressed& A) {
+        n = A.n_outer;
+        if (n > kMinDegreeMax) nested_dissection(A); else min_degree(A);
+    }
+
     long factor_nnz() const { return (long)Lp.empty() ? 0 : Lp[n]; }
 
     static constexpr int kLeaf = 320;             // nested dissection stops at regions of this size
@@ -312,6 +319,349 @@ private:
             }
         }
     }
+};
+
+// ---- supernodal LDL^T -------------------------------------------------------------------------------------------
+// Same factorisation, organised by supernodes (runs of columns with identical structure below the diagonal, stored as
+// dense column-major panels) and computed left-looking with dense kernels.  The Galerkin coarsest operator has ~21
+// entries per row, so nnz(L)/n is 100-150 and the elimination spends its time in dense-ish blocks: the simplicial code
+// above runs at ~2 GFLOP/s (one scattered multiply-add per entry), the panels at several times that, and the
+// back-substitution of a V-cycle streams values only (indices once per supernode) with contiguous inner loops.
+// The inner kernels are compiled twice (baseline x86-64 and AVX2+FMA) and picked at run time.
+class SupernodalLDLT {
+public:
+    int n = 0;
+    bool ok = false;
+    std::vector<int> perm;              // new -> old
+
+    bool factor(const Compressed& A, bool reuse_perm = false) {
+        ok = false;
+        if (!(reuse_perm && n == A.n_outer && (int)perm.size() == n && symbolic_ready_)) {
+            SparseLDLT ord;
+            ord.compute_ordering(A);
+            perm = ord.perm;
+            n = A.n_outer;
+            symbolic(A);
+        }
+        numeric(A);
+        return ok;
+    }
+
+    long factor_nnz() const { return nnz_l_; }
+
+    void solve(const double* b, double* x, double* work) const { solve_multi(b, 0, x, 0, 1, work); }
+
+    // d right-hand sides (columns b + c*ldb -> x + c*ldx); work: n * min(d, 4) doubles.  The columns of a chunk go through
+    // a supernode one after the other, so its panel is read from memory once per chunk.
+    void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work) const {
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            const int dc = std::min(4, d - c0);
+            switch (dc) {
+                case 1: solve_chunk<1>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+                case 2: solve_chunk<2>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+                case 3: solve_chunk<3>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+                default: solve_chunk<4>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
+            }
+        }
+    }
+
+private:
+    static constexpr int kMaxWidth = 48;        // columns per supernode (panel stays in L1/L2)
+    bool symbolic_ready_ = false;
+    long nnz_l_ = 0;
+    int max_rows_ = 0;                           // longest below-diagonal row structure of a supernode
+    mutable std::vector<double> scratch_;        // gathered right-hand-side rows of one supernode (a handle is not thread-safe)
+    std::vector<int> inv_;                       // old -> new
+    std::vector<int> Cp_, Ci_;                   // upper triangle of P A P^T by columns (pattern)
+    int ns_ = 0;
+    std::vector<int> sn_first_;                  // ns + 1: first column of each supernode
+    std::vector<int> sn_of_;                     // column -> supernode
+    std::vector<int> rows_ptr_, rows_;           // below-diagonal row structure of each supernode (sorted)
+    std::vector<size_t> pan_ptr_;                // offset of each panel in pan_
+    std::vector<double> pan_;                    // panels: (w + r) x w column-major, ld = w + r
+    std::vector<double> D_;
+
+    // upper triangle of P A P^T by columns (row indices only) + elimination tree + column counts of L
+    void upper_and_etree(const Compressed& A, std::vector<int>& parent, std::vector<int>& lnz) {
+        inv_.assign(n, 0);
+        for (int i = 0; i < n; ++i) inv_[perm[i]] = i;
+        Cp_.assign(n + 1, 0);
+        for (int k = 0; k < n; ++k) {
+            const int old = perm[k];
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) if (inv_[A.idx[p]] <= k) Cp_[k + 1]++;
+        }
+        for (int k = 0; k < n; ++k) Cp_[k + 1] += Cp_[k];
+        Ci_.resize(Cp_[n]);
+        for (int k = 0; k < n; ++k) {
+            int q = Cp_[k];
+            const int old = perm[k];
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int i = inv_[A.idx[p]]; if (i <= k) Ci_[q++] = i; }
+        }
+        parent.assign(n, -1); lnz.assign(n, 0);
+        std::vector<int> flag(n, -1);
+        for (int k = 0; k < n; ++k) {
+            flag[k] = k;
+            for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
+                int i = Ci_[p];
+                while (i < k && flag[i] != k) { if (parent[i] < 0) parent[i] = k; lnz[i]++; flag[i] = k; i = parent[i]; }
+            }
+        }
+    }
+
+    void symbolic(const Compressed& A) {
+        std::vector<int> parent, lnz;
+        upper_and_etree(A, parent, lnz);
+        {   // postorder the elimination tree (same fill; makes every subtree, hence every supernode, a run of columns)
+            std::vector<int> head(n, -1), nxt(n, -1), post, stack;
+            for (int j = n - 1; j >= 0; --j) if (parent[j] >= 0) { nxt[j] = head[parent[j]]; head[parent[j]] = j; }
+            post.reserve(n);
+            for (int root = 0; root < n; ++root) {
+                if (parent[root] >= 0) continue;
+                stack.push_back(root);
+                while (!stack.empty()) {
+                    const int v = stack.back();
+                    const int c = head[v];
+                    if (c >= 0) { head[v] = nxt[c]; stack.push_back(c); }
+                    else { post.push_back(v); stack.pop_back(); }
+                }
+            }
+            std::vector<int> p2(n);
+            for (int k = 0; k < n; ++k) p2[k] = perm[post[k]];
+            perm.swap(p2);
+            upper_and_etree(A, parent, lnz);
+        }
+        // column structures of L (rows ascending: filled row by row)
+        std::vector<int> Lp(n + 1, 0), fill(n, 0), flag(n, -1);
+        for (int k = 0; k < n; ++k) Lp[k + 1] = Lp[k] + lnz[k];
+        std::vector<int> Li(Lp[n]);
+        for (int k = 0; k < n; ++k) {
+            flag[k] = k;
+            for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
+                int i = Ci_[p];
+                while (i < k && flag[i] != k) { Li[Lp[i] + fill[i]++] = k; flag[i] = k; i = parent[i]; }
+            }
+        }
+        // fundamental supernodes: column j + 1 joins j's supernode when it is j's parent and has the same structure
+        std::vector<int> first;
+        int start = 0;
+        for (int j = 0; j < n; ++j) {
+            const bool last = j + 1 == n;
+            const bool join = !last && parent[j] == j + 1 && lnz[j] == lnz[j + 1] + 1 && (j + 1 - start) < kMaxWidth;
+            if (!join) { first.push_back(start); start = j + 1; }
+        }
+        first.push_back(n);
+        // relaxed amalgamation: a supernode is merged into the one that follows it when that one starts at its parent column
+        // and the explicit zeros this stores are few -- wider panels, fewer tiny ones (most fundamental supernodes are 1 wide)
+        sn_first_.clear();
+        {
+            const int nf = (int)first.size() - 1;
+            int cur_first = first[0];
+            long cur_zeros = 0;
+            for (int q = 0; q < nf; ++q) {
+                const int lastc = first[q + 1] - 1;                  // last column of the (possibly merged) current supernode
+                bool merge = false;
+                if (q + 1 < nf && parent[lastc] == first[q + 1]) {
+                    const int wp = first[q + 2] - first[q + 1];
+                    const int lp = first[q + 2] - 1;
+                    const long wc = first[q + 1] - cur_first;
+                    const long extra = wc * ((long)(wp + lnz[lp]) - lnz[lastc]);       // zeros added to the child's columns
+                    const long merged = (wc + wp) * (long)(wp + lnz[lp]) + wc * (wc - 1) / 2;
+                    merge = wc + wp <= kMaxWidth && (cur_zeros + extra) * 4 <= merged;
+                    if (merge) cur_zeros += extra;
+                }
+                if (!merge) { sn_first_.push_back(cur_first); cur_first = first[q + 1]; cur_zeros = 0; }
+            }
+        }
+        ns_ = (int)sn_first_.size();
+        sn_first_.push_back(n);
+        sn_of_.assign(n, 0);
+        rows_ptr_.assign(ns_ + 1, 0);
+        for (int s = 0; s < ns_; ++s) {
+            for (int j = sn_first_[s]; j < sn_first_[s + 1]; ++j) sn_of_[j] = s;
+            rows_ptr_[s + 1] = rows_ptr_[s] + lnz[sn_first_[s + 1] - 1];
+        }
+        rows_.resize(rows_ptr_[ns_]);
+        pan_ptr_.assign(ns_ + 1, 0);
+        nnz_l_ = Lp[n];
+        for (int s = 0; s < ns_; ++s) {
+            const int l = sn_first_[s + 1] - 1, w = sn_first_[s + 1] - sn_first_[s];
+            std::copy(Li.begin() + Lp[l], Li.begin() + Lp[l + 1], rows_.begin() + rows_ptr_[s]);
+            pan_ptr_[s + 1] = pan_ptr_[s] + (size_t)(w + lnz[l]) * w;
+        }
+        max_rows_ = 0;
+        for (int q = 0; q < ns_; ++q) max_rows_ = std::max(max_rows_, rows_ptr_[q + 1] - rows_ptr_[q]);
+        pan_.assign(pan_ptr_[ns_], 0.0);
+        D_.assign(n, 0.0);
+        symbolic_ready_ = true;
+    }
+
+    // dense kernels, compiled for the baseline ISA and for AVX2+FMA
+#define GMG_LDLT_KERNELS(SUFFIX, ATTR)                                                                                          \
+    /* in-place LDL^T of the (m x w) panel P (ld): unit lower factor below the diagonal, d[] the pivots; false on a zero pivot */  \
+    ATTR static bool panel_factor##SUFFIX(double* P, int ld, int m, int w, double* d) {                                        \
+        for (int j = 0; j < w; ++j) {                                                                                            \
+            double* cj = P + (size_t)j * ld;                                                                                     \
+            const double dj = cj[j];                                                                                             \
+            if (dj == 0.0 || !std::isfinite(dj)) return false;                                                                   \
+            d[j] = dj;                                                                                                           \
+            const double inv = 1.0 / dj;                                                                                         \
+            for (int k = j + 1; k < w; ++k) {                                                                                    \
+                double* ck = P + (size_t)k * ld;                                                                                 \
+                const double f = cj[k] * inv;                                                                                    \
+                for (int i = k; i < m; ++i) ck[i] -= cj[i] * f;                                                                  \
+            }                                                                                                                    \
+            for (int i = j + 1; i < m; ++i) cj[i] *= inv;                                                                        \
+        }                                                                                                                        \
+        return true;                                                                                                             \
+    }                                                                                                                            \
+    /* U (k x k1, ld k, lower trapezoid: rows i >= j of column j) = Lk (k x w, ld) diag(d) Lk[0..k1)^T */                          \
+    ATTR static void panel_update##SUFFIX(const double* Lk, int ld, int k, int k1, int w, const double* d, double* U) {         \
+        for (int j = 0; j < k1; ++j) {                                                                                           \
+            double* uj = U + (size_t)j * k;                                                                                      \
+            for (int i = j; i < k; ++i) uj[i] = 0.0;                                                                             \
+            for (int c = 0; c < w; ++c) {                                                                                        \
+                const double* lc = Lk + (size_t)c * ld;                                                                          \
+                const double f = lc[j] * d[c];                                                                                   \
+                for (int i = j; i < k; ++i) uj[i] += lc[i] * f;                                                                  \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    }                                                                                                                            \
+    /* dot product with four independent partial sums (the explicit re-association lets it vectorise) */                        \
+    ATTR static double dot4##SUFFIX(const double* a, const double* b, int m) {                                                  \
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;                                                                           \
+        int i = 0;                                                                                                               \
+        for (; i + 4 <= m; i += 4) { s0 += a[i] * b[i]; s1 += a[i + 1] * b[i + 1]; s2 += a[i + 2] * b[i + 2]; s3 += a[i + 3] * b[i + 3]; } \
+        for (; i < m; ++i) s0 += a[i] * b[i];                                                                                    \
+        return (s0 + s1) + (s2 + s3);                                                                                            \
+    }                                                                                                                            \
+    /* one right-hand side: forward step of a supernode, ys <- L_d^-1 ys (unit lower, w x w), t = L_b ys (r) */                  \
+    ATTR static void sn_forward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, double* t) {                        \
+        for (int j = 0; j < w; ++j) {                                                                                            \
+            const double* cj = P + (size_t)j * ld;                                                                               \
+            const double yj = ys[j];                                                                                             \
+            for (int i = j + 1; i < w; ++i) ys[i] -= cj[i] * yj;                                                                 \
+        }                                                                                                                        \
+        for (int i = 0; i < r; ++i) t[i] = 0.0;                                                                                  \
+        for (int j = 0; j < w; ++j) {                                                                                            \
+            const double* cb = P + (size_t)j * ld + w;                                                                           \
+            const double yj = ys[j];                                                                                             \
+            for (int i = 0; i < r; ++i) t[i] += cb[i] * yj;                                                                      \
+        }                                                                                                                        \
+    }                                                                                                                            \
+    /* ... and its backward step: ys <- L_d^-T (ys - L_b^T t) */                                                                 \
+    ATTR static void sn_backward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, const double* t) {                 \
+        for (int j = w - 1; j >= 0; --j) {                                                                                       \
+            const double* cj = P + (size_t)j * ld;                                                                               \
+            ys[j] -= dot4##SUFFIX(cj + w, t, r) + dot4##SUFFIX(cj + j + 1, ys + j + 1, w - 1 - j);                               \
+        }                                                                                                                        \
+    }
+    GMG_LDLT_KERNELS(_base, )
+    // (this header is host-only code, but engine.hip is also parsed by hipcc's device pass, which knows no x86 features)
+#if defined(__HIP_DEVICE_COMPILE__)
+    GMG_LDLT_KERNELS(_avx2, )
+    static bool has_avx2() { return false; }
+#else
+    GMG_LDLT_KERNELS(_avx2, __attribute__((target("avx2,fma"))))
+    static bool has_avx2() {
+        static const bool v = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"); }();
+        return v;
+    }
+#endif
+#undef GMG_LDLT_KERNELS
+
+    template <int DC>
+    void solve_chunk(const double* b, size_t ldb, double* x, size_t ldx, double* work) const {
+        const bool avx = has_avx2();
+        const size_t nt = (size_t)max_rows_ + 1;
+        if (scratch_.size() < nt) scratch_.resize(nt);
+        double* t = scratch_.data();
+        for (int c = 0; c < DC; ++c) for (int i = 0; i < n; ++i) work[(size_t)c * n + i] = b[(size_t)c * ldb + perm[i]];
+        for (int s = 0; s < ns_; ++s) {                          // forward: L z = y
+            const int f = sn_first_[s], w = sn_first_[s + 1] - f;
+            const int* R = rows_.data() + rows_ptr_[s];
+            const int r = rows_ptr_[s + 1] - rows_ptr_[s];
+            const double* P = pan_.data() + pan_ptr_[s];
+            for (int c = 0; c < DC; ++c) {       // column after column through the same panel (it stays in cache); per column the
+                double* y = work + (size_t)c * n;    // arithmetic is that of a single right-hand side, so columns cannot interact
+                if (avx) sn_forward1_avx2(P, w + r, w, r, y + f, t); else sn_forward1_base(P, w + r, w, r, y + f, t);
+                for (int i = 0; i < r; ++i) y[R[i]] -= t[i];
+            }
+        }
+        for (int c = 0; c < DC; ++c) { double* y = work + (size_t)c * n; for (int j = 0; j < n; ++j) y[j] /= D_[j]; }
+        for (int s = ns_ - 1; s >= 0; --s) {                     // backward: L^T x = z
+            const int f = sn_first_[s], w = sn_first_[s + 1] - f;
+            const int* R = rows_.data() + rows_ptr_[s];
+            const int r = rows_ptr_[s + 1] - rows_ptr_[s];
+            const double* P = pan_.data() + pan_ptr_[s];
+            for (int c = 0; c < DC; ++c) {
+                double* y = work + (size_t)c * n;
+                for (int i = 0; i < r; ++i) t[i] = y[R[i]];
+                if (avx) sn_backward1_avx2(P, w + r, w, r, y + f, t); else sn_backward1_base(P, w + r, w, r, y + f, t);
+            }
+        }
+        for (int c = 0; c < DC; ++c) for (int i = 0; i < n; ++i) x[(size_t)c * ldx + perm[i]] = work[(size_t)c * n + i];
+    }
+
+    void numeric(const Compressed& A) {
+        std::fill(pan_.begin(), pan_.end(), 0.0);
+        const bool avx = has_avx2();
+        std::vector<int> relpos(n, -1);          // row -> row index inside the current panel
+        std::vector<int> head(ns_, -1), next(ns_, -1), pos(ns_, 0);      // pending descendants of each supernode, their progress
+        std::vector<double> U;
+        for (int s = 0; s < ns_; ++s) {
+            const int f = sn_first_[s], w = sn_first_[s + 1] - f;
+            const int* R = rows_.data() + rows_ptr_[s];
+            const int r = rows_ptr_[s + 1] - rows_ptr_[s];
+            const int ld = w + r;
+            double* P = pan_.data() + pan_ptr_[s];
+            for (int j = 0; j < w; ++j) relpos[f + j] = j;
+            for (int i = 0; i < r; ++i) relpos[R[i]] = w + i;
+            s_assemble(A, s, f, w, P, ld, relpos);
+            // updates from the descendants that reach this supernode
+            for (int dd = head[s]; dd >= 0;) {
+                const int nxt = next[dd];
+                const int fd = sn_first_[dd], wd = sn_first_[dd + 1] - fd;
+                const int* Rd = rows_.data() + rows_ptr_[dd];
+                const int rd = rows_ptr_[dd + 1] - rows_ptr_[dd];
+                const int ldd = wd + rd;
+                const int p0 = pos[dd];
+                int k1 = 0;
+                while (p0 + k1 < rd && Rd[p0 + k1] < f + w) ++k1;
+                const int k = rd - p0;
+                const double* Lk = pan_.data() + pan_ptr_[dd] + wd + p0;
+                U.resize((size_t)k * k1);
+                if (avx) panel_update_avx2(Lk, ldd, k, k1, wd, D_.data() + fd, U.data());
+                else panel_update_base(Lk, ldd, k, k1, wd, D_.data() + fd, U.data());
+                for (int j = 0; j < k1; ++j) {
+                    double* tc = P + (size_t)(Rd[p0 + j] - f) * ld;
+                    const double* uj = U.data() + (size_t)j * k;
+                    for (int i = j; i < k; ++i) tc[relpos[Rd[p0 + i]]] -= uj[i];
+                }
+                pos[dd] = p0 + k1;
+                if (pos[dd] < rd) { const int t = sn_of_[Rd[pos[dd]]]; next[dd] = head[t]; head[t] = dd; }
+                dd = nxt;
+            }
+            if (!(avx ? panel_factor_avx2(P, ld, ld, w, D_.data() + f) : panel_factor_base(P, ld, ld, w, D_.data() + f))) return;
+            if (r > 0) { const int t = sn_of_[R[0]]; pos[s] = 0; next[s] = head[t]; head[t] = s; }
+        }
+        ok = true;
+    }
+
+    // panel of supernode s <- the entries of P A P^T in its columns (lower triangle)
+    void s_assemble(const Compressed& A, int s, int f, int w, double* P, int ld, const std::vector<int>& relpos) const {
+        (void)s;
+        // lower column c of the permuted matrix = {(i, c) : i >= c}; by symmetry these are the upper entries (c, i), which
+        // sit in the upper COLUMN i.  Walk A's column perm[c] directly instead: its entries (perm^-1(row), c) with row' >= c.
+        for (int j = 0; j < w; ++j) {
+            const int c = f + j, old = perm[c];
+            double* pc = P + (size_t)j * ld;
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+                const int i = inv_[A.idx[p]];
+                if (i >= c) pc[relpos[i]] += A.val[p];
+            }
+        }
+    }
+
 };
 
 }  // namespace gmg

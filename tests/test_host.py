@@ -261,3 +261,22 @@ def test_host_ldlt_nested_dissection_path(cabi):
     y = rng.standard_normal(B.shape[0])
     z, _ = cabi.host_ldlt_solve(B, y)
     assert np.linalg.norm(B @ z - y) <= 1e-12 * np.linalg.norm(y)
+
+
+def test_host_ldlt_many_right_hand_sides_and_galerkin_operator(cabi):
+    """The supernodal solver on what it is built for (a Galerkin coarsest operator, ~20 entries per row) with six
+    right-hand sides (chunks of four): every column equals its own single-column solve and scipy's."""
+    P = problems.torus_problem(140, 120, "smoothing", 1500)
+    A = sp.csc_matrix(P.lhs)
+    for U in P.U:
+        A = sp.csc_matrix(U.T @ A @ U)
+    assert 1500 <= A.shape[0] <= 12000 and A.nnz / A.shape[0] > 12
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal((A.shape[0], 6))
+    X, nnzL = cabi.host_ldlt_solve(A, B)
+    lu = spla.splu(A)
+    for c in range(6):
+        x1, _ = cabi.host_ldlt_solve(A, B[:, c].copy())
+        assert np.array_equal(X[:, c], x1)
+        assert np.linalg.norm(X[:, c] - lu.solve(B[:, c])) <= 1e-10 * np.linalg.norm(X[:, c])
+    assert nnzL > A.nnz // 2
