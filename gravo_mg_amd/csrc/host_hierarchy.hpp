@@ -1,4 +1,5 @@
-// host_hierarchy.hpp -- Graph-Voronoi prolongation hierarchy (host, sequential graph algorithm).
+// host_hierarchy.hpp -- Graph-Voronoi prolongation hierarchy (host; the greedy sampling and the Dijkstra clustering are
+// sequential by definition, the per-point / per-cell stages run on all cores with the sequential stages' exact output).
 //
 // Restates, with its own data structures, what the reference's constructor does on its default path:
 //   MGBS::MultigridSolver::buildHierarchy / constructProlongation
@@ -19,6 +20,9 @@
 //     ascending key order wins (:375-383), edge distances are stored as float (std::map<int,float>, :336).
 #pragma once
 #include <algorithm>
+#include <memory>
+#include <atomic>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <limits>
@@ -93,19 +97,34 @@ public:
             R.timing["cluster"] += ms(t1, t2);
 
             // coarse adjacency: clusters that touch through a fine edge (:178-187); sorted unique lists
+            // (the lists are SETS -- sorted, unique -- so they can be collected cluster by cluster on all cores: the fine
+            // points of every cluster first, by a counting sort of `nearest`)
             std::vector<std::vector<int>> cadj(nc);
-            for (int f = 0; f < nf; ++f)
-                for (int j = 0; j < nbK; ++j) {
-                    int g = NB[(size_t)f * nbK + j];
-                    if (g < 0) break;
-                    if (nearest[f] != nearest[g]) cadj[nearest[f]].push_back(nearest[g]);
-                }
-            int max_nb = 0;
-            for (auto& a : cadj) {
-                std::sort(a.begin(), a.end());
-                a.erase(std::unique(a.begin(), a.end()), a.end());
-                max_nb = std::max(max_nb, (int)a.size());
+            std::vector<int> mem_ptr((size_t)nc + 1, 0), members(nf);
+            for (int f = 0; f < nf; ++f) mem_ptr[nearest[f] + 1]++;
+            for (int c = 0; c < nc; ++c) mem_ptr[c + 1] += mem_ptr[c];
+            {
+                std::vector<int> fillp(mem_ptr.begin(), mem_ptr.end() - 1);
+                for (int f = 0; f < nf; ++f) members[fillp[nearest[f]]++] = f;
             }
+            const int T = std::max(1, std::min(hw_threads(), 64));
+            parallel_ranges(nc, T, [&](int lo, int hi, int) {
+                for (int c = lo; c < hi; ++c) {
+                    std::vector<int>& a = cadj[c];
+                    for (int m = mem_ptr[c]; m < mem_ptr[c + 1]; ++m) {
+                        const int f = members[m];
+                        for (int j = 0; j < nbK; ++j) {
+                            int g = NB[(size_t)f * nbK + j];
+                            if (g < 0) break;
+                            if (nearest[g] != c) a.push_back(nearest[g]);
+                        }
+                    }
+                    std::sort(a.begin(), a.end());
+                    a.erase(std::unique(a.begin(), a.end()), a.end());
+                }
+            }, 256);
+            int max_nb = 0;
+            for (auto& a : cadj) max_nb = std::max(max_nb, (int)a.size());
             // homogeneous table for the next level (:196-205): self first, then at most max_nb-1 neighbours
             std::vector<int> NBc((size_t)nc * std::max(max_nb, 1), -1);
             const int Kc = std::max(max_nb, 1);
@@ -143,36 +162,65 @@ public:
             R.timing["next_positions"] += ms(t3, t4);
 
             // candidate triangles from mutually adjacent Voronoi cells (:247-281)
-            std::vector<std::array<int, 3>> tris;
-            std::vector<V3> tri_normal;
-            std::vector<std::vector<int>> tris_of(nc);
-            for (int c = 0; c < nc; ++c) {
-                const auto& a = cadj[c];
-                for (size_t i2 = 0; i2 < a.size(); ++i2) {
-                    int v2 = a[i2];
-                    if (v2 < c) continue;
-                    for (size_t i3 = i2 + 1; i3 < a.size(); ++i3) {
-                        int v3 = a[i3];
-                        if (v3 < c) continue;
-                        if (!opt.check_voronoi || std::binary_search(cadj[v2].begin(), cadj[v2].end(), v3)) {
-                            int t = (int)tris.size();
-                            tris.push_back({c, v2, v3});
-                            tri_normal.push_back(detail::normalized(detail::cross(Pc[v2] - Pc[c], Pc[v3] - Pc[c])));
-                            tris_of[c].push_back(t); tris_of[v2].push_back(t); tris_of[v3].push_back(t);
+            // Triangle t is created by its lowest cell; ids follow the cells' order, and every cell lists its triangles in
+            // ascending id -- the order the sequential construction produces and the "first containing triangle" rule
+            // below depends on.  Built on all cores: per-cell lists, ids by a prefix sum, cell lists by a stable counting sort.
+            std::vector<std::vector<std::array<int, 3>>> local(nc);
+            parallel_ranges(nc, T, [&](int lo, int hi, int) {
+                for (int c = lo; c < hi; ++c) {
+                    const auto& a = cadj[c];
+                    for (size_t i2 = 0; i2 < a.size(); ++i2) {
+                        int v2 = a[i2];
+                        if (v2 < c) continue;
+                        for (size_t i3 = i2 + 1; i3 < a.size(); ++i3) {
+                            int v3 = a[i3];
+                            if (v3 < c) continue;
+                            if (!opt.check_voronoi || std::binary_search(cadj[v2].begin(), cadj[v2].end(), v3)) local[c].push_back({c, v2, v3});
                         }
                     }
                 }
+            }, 256);
+            std::vector<int> tri_first((size_t)nc + 1, 0);
+            for (int c = 0; c < nc; ++c) tri_first[c + 1] = tri_first[c] + (int)local[c].size();
+            const int ntri = tri_first[nc];
+            std::vector<std::array<int, 3>> tris(ntri);
+            std::vector<V3> tri_normal(ntri);
+            parallel_ranges(nc, T, [&](int lo, int hi, int) {
+                for (int c = lo; c < hi; ++c)
+                    for (size_t q = 0; q < local[c].size(); ++q) {
+                        const auto& tr = local[c][q];
+                        tris[tri_first[c] + q] = tr;
+                        tri_normal[tri_first[c] + q] = detail::normalized(detail::cross(Pc[tr[1]] - Pc[tr[0]], Pc[tr[2]] - Pc[tr[0]]));
+                    }
+            }, 256);
+            std::vector<int> tof_ptr((size_t)nc + 1, 0);
+            for (int t = 0; t < ntri; ++t) for (int q = 0; q < 3; ++q) tof_ptr[tris[t][q] + 1]++;
+            for (int c = 0; c < nc; ++c) tof_ptr[c + 1] += tof_ptr[c];
+            std::vector<int> tof(tof_ptr[nc]);
+            {
+                std::vector<int> fillp(tof_ptr.begin(), tof_ptr.end() - 1);
+                for (int t = 0; t < ntri; ++t) for (int q = 0; q < 3; ++q) tof[fillp[tris[t][q]]++] = t;
             }
             auto t5 = clk::now();
             R.timing["triangle_finding"] += ms(t4, t5);
 
             // per fine point: pick coarse parents and weights (:291-452)
-            std::vector<int> trow; std::vector<int> tcol; std::vector<double> tval;
-            trow.reserve((size_t)nf * 3); tcol.reserve((size_t)nf * 3); tval.reserve((size_t)nf * 3);
+            // Every fine point is independent: chunks of points on all cores, each with its own triplet list, concatenated in
+            // chunk order afterwards (= the sequential emission order).
+            const int nchunk = nf >= 8192 ? T : 1;
+            const int chunk_len = (nf + nchunk - 1) / nchunk;
+            struct Chunk { std::vector<int> row, col; std::vector<double> val; std::array<int, 4> kinds{0, 0, 0, 0}; };
+            std::vector<Chunk> chunks(nchunk);
+            parallel_ranges(nchunk, nchunk, [&](int q0, int q1, int) {
+            for (int q = q0; q < q1; ++q) {
+            Chunk& ck = chunks[q];
+            std::vector<int>& trow = ck.row; std::vector<int>& tcol = ck.col; std::vector<double>& tval = ck.val;
+            std::array<int, 4>& kinds = ck.kinds;
+            const int f_lo = q * chunk_len, f_hi = std::min(nf, f_lo + chunk_len);
+            trow.reserve((size_t)(f_hi - f_lo) * 3); tcol.reserve((size_t)(f_hi - f_lo) * 3); tval.reserve((size_t)(f_hi - f_lo) * 3);
             auto emit = [&](int f, int c, double w) { trow.push_back(f); tcol.push_back(c); tval.push_back(w); };
-            std::array<int, 4> kinds{0, 0, 0, 0};
             std::map<int, float> inside_edge;
-            for (int f = 0; f < nf; ++f) {
+            for (int f = f_lo; f < f_hi; ++f) {
                 const V3 p = P[f];
                 const int c = nearest[f];
                 const V3 pc = Pc[c];
@@ -188,7 +236,8 @@ public:
                 bool found = false;
                 std::array<int, 3> best{0, 0, 0};
                 double bary[3] = {0, 0, 0};
-                for (int t : tris_of[c]) {
+                for (int tq = tof_ptr[c]; tq < tof_ptr[c + 1]; ++tq) {
+                    const int t = tof[tq];
                     std::array<int, 3> tri = tris[t];
                     while (tri[0] != c) std::rotate(tri.begin(), tri.begin() + 1, tri.end());
                     double b[3];
@@ -227,6 +276,21 @@ public:
                 double w[3];
                 inv_dist_weights(Pc, p, from, cnt, w);
                 for (int j = 0; j < cnt; ++j) emit(f, from[j], w[j]);
+            }
+            }
+            }, 1);
+            std::vector<int> trow, tcol; std::vector<double> tval;
+            std::array<int, 4> kinds{0, 0, 0, 0};
+            {
+                size_t total = 0;
+                for (auto& ck : chunks) total += ck.row.size();
+                trow.reserve(total); tcol.reserve(total); tval.reserve(total);
+                for (auto& ck : chunks) {
+                    trow.insert(trow.end(), ck.row.begin(), ck.row.end());
+                    tcol.insert(tcol.end(), ck.col.begin(), ck.col.end());
+                    tval.insert(tval.end(), ck.val.begin(), ck.val.end());
+                    for (int z = 0; z < 4; ++z) kinds[z] += ck.kinds[z];
+                }
             }
             auto t6 = clk::now();
             R.timing["triangle_selection"] += ms(t5, t6);
@@ -361,26 +425,52 @@ private:
         emit(f, other, w2);
     }
 
-    // Eigen's setFromTriplets semantics: duplicates are summed, explicit zeros are kept, inner indices sorted.
+    // Eigen's setFromTriplets semantics: duplicates are summed, explicit zeros are kept, inner indices sorted.  The
+    // triplets arrive grouped by row (ascending) with at most a handful per row, so duplicates can only be neighbours in
+    // the list: they are merged there, then the columns are filled on all cores (atomic slot counters) and each column
+    // is sorted by row -- every (row, column) is unique by then, so the result does not depend on the fill order.
     static Compressed from_triplets(int nrows, int ncols, const std::vector<int>& r, const std::vector<int>& c, const std::vector<double>& v) {
+        const size_t nt = r.size();
+        std::vector<char> keep(nt, 1);
+        std::vector<double> vm(v);
+        for (size_t t = 0; t < nt;) {                       // rows are short: quadratic merge inside a row
+            size_t e = t;
+            while (e < nt && r[e] == r[t]) ++e;
+            for (size_t i = t; i < e; ++i)
+                if (keep[i])
+                    for (size_t j = i + 1; j < e; ++j)
+                        if (keep[j] && c[j] == c[i]) { vm[i] += vm[j]; keep[j] = 0; }
+            t = e;
+        }
         Compressed M;
         M.n_outer = ncols; M.n_inner = nrows;
-        std::vector<int> cnt((size_t)ncols + 1, 0);
-        for (int cc : c) cnt[cc + 1]++;
-        for (int j = 0; j < ncols; ++j) cnt[j + 1] += cnt[j];
-        std::vector<int> ri(r.size()); std::vector<double> vv(r.size());
-        std::vector<int> next(cnt.begin(), cnt.end() - 1);
-        for (size_t t = 0; t < r.size(); ++t) { int q = next[c[t]]++; ri[q] = r[t]; vv[q] = v[t]; }   // rows arrive ascending
+        const int T = std::max(1, std::min(hw_threads(), 64));
+        std::unique_ptr<std::atomic<int>[]> cnt(new std::atomic<int>[(size_t)ncols + 1]);
+        parallel_ranges(ncols + 1, T, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) cnt[j].store(0, std::memory_order_relaxed); });
+        parallel_ranges((int)nt, T, [&](int lo, int hi, int) {
+            for (int t = lo; t < hi; ++t) if (keep[t]) cnt[c[t]].fetch_add(1, std::memory_order_relaxed);
+        });
         M.ptr.assign((size_t)ncols + 1, 0);
-        for (int j = 0; j < ncols; ++j) {
-            int lo = cnt[j], hi = cnt[j + 1];
-            int last = -1;
-            for (int q = lo; q < hi; ++q) {
-                if (ri[q] == last) { M.val.back() += vv[q]; continue; }
-                M.idx.push_back(ri[q]); M.val.push_back(vv[q]); last = ri[q];
+        for (int j = 0; j < ncols; ++j) M.ptr[j + 1] = M.ptr[j] + cnt[j].load(std::memory_order_relaxed);
+        parallel_ranges(ncols, T, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) cnt[j].store(M.ptr[j], std::memory_order_relaxed); });
+        M.idx.resize(M.ptr[ncols]); M.val.resize(M.ptr[ncols]);
+        parallel_ranges((int)nt, T, [&](int lo, int hi, int) {
+            for (int t = lo; t < hi; ++t)
+                if (keep[t]) { const int q = cnt[c[t]].fetch_add(1, std::memory_order_relaxed); M.idx[q] = r[t]; M.val[q] = vm[t]; }
+        });
+        parallel_ranges(ncols, T, [&](int lo, int hi, int) {
+            std::vector<std::pair<int, double>> tmp;
+            for (int j = lo; j < hi; ++j) {
+                const int b0 = M.ptr[j], e0 = M.ptr[j + 1];
+                bool sorted = true;
+                for (int q = b0 + 1; q < e0; ++q) if (M.idx[q] < M.idx[q - 1]) { sorted = false; break; }
+                if (sorted) continue;
+                tmp.clear();
+                for (int q = b0; q < e0; ++q) tmp.emplace_back(M.idx[q], M.val[q]);
+                std::sort(tmp.begin(), tmp.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+                for (int q = b0; q < e0; ++q) { M.idx[q] = tmp[q - b0].first; M.val[q] = tmp[q - b0].second; }
             }
-            M.ptr[j + 1] = (int)M.idx.size();
-        }
+        }, 256);
         return M;
     }
 };
