@@ -1,0 +1,50 @@
+"""One engine handle driven through many systems: different sizes, patterns, hierarchies, numbers of right-hand sides,
+interleaved with repeats (ordering cache hits), failures (singular / malformed input) and re-use after a failure.
+Guards the per-handle device memory pool, the ordering cache and the error paths."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from tests import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_device_bytes():
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    return free
+
+
+def test_one_handle_many_systems(cabi, oracle):
+    eng = cabi.Engine()
+    cases = [problems.torus_problem(48, 40, "poisson", 60), problems.torus_problem(64, 60, "smoothing", 60),
+             problems.pointcloud_problem(3000), problems.torus_problem(96, 80, "poisson", 30), problems.sphere_problem(6000),
+             problems.torus_problem(48, 40, "poisson", 60, order="random")]
+    rng = np.random.default_rng(0)
+    free_after_warmup = None
+    for rnd in range(4):
+        for P in (cases if rnd % 2 == 0 else cases[::-1]):
+            eng.set_prolongations(P.U); eng.set_mass(P.mass)
+            for rep in range(2):                                   # second call: same pattern -> cached orderings
+                scale = 1.0 + 0.5 * rep
+                eng.set_system(P.lhs * scale)
+                assert eng.timing("setup_ordering_cached") == float(rep)
+                d = int(rng.integers(1, 6))
+                B = np.repeat(P.rhs[:, :1], d, axis=1) * rng.uniform(0.5, 2.0, size=(1, d))
+                x, it, res, _ = eng.solve(B, tol=1e-6, max_iter=100)
+                assert res <= 1e-6 and x.shape == B.shape
+                assert abs(oracle.residual_check(P.lhs * scale, P.mass, B, x, 2) - res) <= 1e-3 * res + 1e-7
+            # a malformed system in between must fail loudly and leave the handle usable
+            bad = sp.csc_matrix(P.lhs.shape)
+            with pytest.raises(cabi.GmgError):
+                eng.set_system(bad + sp.identity(P.n, format="csc") * 0.0)
+            with pytest.raises(cabi.GmgError):
+                eng.solve(P.rhs)                                    # no system after the failure
+            eng.set_system(P.lhs)
+            x, it, res, _ = eng.solve(P.rhs, tol=1e-6)
+            assert res <= 1e-6
+        if rnd == 1:
+            free_after_warmup = _free_device_bytes()
+    # the pool parks blocks for reuse but must not grow without bound: two more rounds cost (almost) no extra device memory
+    assert free_after_warmup - _free_device_bytes() < 64 << 20
