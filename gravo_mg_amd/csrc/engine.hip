@@ -1096,6 +1096,7 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
     HIPCHK(hipStreamSynchronize(h->stream));
     auto t0 = clk::now();
     std::memset(e, 0, sizeof(double) * cnt);
+    if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
     h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
     h->timing["coarse_host_ms"] += ms_since(t0);
     HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
@@ -1655,7 +1656,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     (void)hipStreamSynchronize(h->stream);      // staged host arrays die at scope end
     if (rc_all != GMG_OK) return err_all.empty() ? rc_all : fail(h, rc_all, err_all);
     if (!factor_ok) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
-    h->coarse_work.assign((size_t)h->lv[L].A.n_outer * 4, 0.0);
+    h->coarse_work.assign((size_t)h->lv[L].A.n_outer * 4, 0.0);       // grown by coarse_host_roundtrip for more than 4 columns
     h->timing["coarsest_solve"] = ms_factor;
     h->timing["setup_ordering"] = 0.0; h->timing["setup_sell"] = 0.0;
     for (int k = 0; k <= L; ++k) h->timing["setup_ordering_l" + std::to_string(k)] = stage[k].ms_order;
@@ -2370,7 +2371,7 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
     // the engine's coarsest-level solver (supernodal), cross-checked here against the simplicial implementation it replaced
     SupernodalLDLT f;
     if (!f.factor(A)) return GMG_ERR_NUMERIC;
-    std::vector<double> w((size_t)n * 4);
+    std::vector<double> w((size_t)n * d);
     f.solve_multi(b, (size_t)n, x, (size_t)n, d, w.data());
     if (factor_nnz) *factor_nnz = f.factor_nnz();
     if (std::getenv("GMG_LDLT_CROSSCHECK")) {

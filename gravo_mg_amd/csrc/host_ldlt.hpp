@@ -349,20 +349,21 @@ public:
 
     long factor_nnz() const { return nnz_l_; }
 
-    void solve(const double* b, double* x, double* work) const { solve_multi(b, 0, x, 0, 1, work); }
+    void solve(const double* b, double* x, double* work) const {
+        std::vector<double> t((size_t)max_rows_ + 1);       // own scratch: callable concurrently (the dense-inverse build does)
+        solve_column(b, x, work, t.data());
+    }
 
-    // d right-hand sides (columns b + c*ldb -> x + c*ldx); work: n * min(d, 4) doubles.  The columns of a chunk go through
-    // a supernode one after the other, so its panel is read from memory once per chunk.
+    // d right-hand sides (columns b + c*ldb -> x + c*ldx); work: n * d doubles.  Every column is an independent
+    // single-column solve (so columns cannot interact and a column's result does not depend on d); with more than one
+    // column they run concurrently on the worker pool -- the factor is read-only and shared.
     void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work) const {
-        for (int c0 = 0; c0 < d; c0 += 4) {
-            const int dc = std::min(4, d - c0);
-            switch (dc) {
-                case 1: solve_chunk<1>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
-                case 2: solve_chunk<2>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
-                case 3: solve_chunk<3>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
-                default: solve_chunk<4>(b + c0 * ldb, ldb, x + c0 * ldx, ldx, work); break;
-            }
-        }
+        const size_t nt = (size_t)max_rows_ + 1;
+        if (scratch_.size() < nt * (size_t)d) scratch_.resize(nt * (size_t)d);
+        if (d == 1) { solve_column(b, x, work, scratch_.data()); return; }
+        parallel_ranges(d, d, [&](int c0, int c1, int) {
+            for (int c = c0; c < c1; ++c) solve_column(b + (size_t)c * ldb, x + (size_t)c * ldx, work + (size_t)c * n, scratch_.data() + nt * c);
+        }, 2);
     }
 
 private:
@@ -569,37 +570,27 @@ private:
 #endif
 #undef GMG_LDLT_KERNELS
 
-    template <int DC>
-    void solve_chunk(const double* b, size_t ldb, double* x, size_t ldx, double* work) const {
+    void solve_column(const double* b, double* x, double* y, double* t) const {
         const bool avx = has_avx2();
-        const size_t nt = (size_t)max_rows_ + 1;
-        if (scratch_.size() < nt) scratch_.resize(nt);
-        double* t = scratch_.data();
-        for (int c = 0; c < DC; ++c) for (int i = 0; i < n; ++i) work[(size_t)c * n + i] = b[(size_t)c * ldb + perm[i]];
+        for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
         for (int s = 0; s < ns_; ++s) {                          // forward: L z = y
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
             const int* R = rows_.data() + rows_ptr_[s];
             const int r = rows_ptr_[s + 1] - rows_ptr_[s];
             const double* P = pan_.data() + pan_ptr_[s];
-            for (int c = 0; c < DC; ++c) {       // column after column through the same panel (it stays in cache); per column the
-                double* y = work + (size_t)c * n;    // arithmetic is that of a single right-hand side, so columns cannot interact
-                if (avx) sn_forward1_avx2(P, w + r, w, r, y + f, t); else sn_forward1_base(P, w + r, w, r, y + f, t);
-                for (int i = 0; i < r; ++i) y[R[i]] -= t[i];
-            }
+            if (avx) sn_forward1_avx2(P, w + r, w, r, y + f, t); else sn_forward1_base(P, w + r, w, r, y + f, t);
+            for (int i = 0; i < r; ++i) y[R[i]] -= t[i];
         }
-        for (int c = 0; c < DC; ++c) { double* y = work + (size_t)c * n; for (int j = 0; j < n; ++j) y[j] /= D_[j]; }
+        for (int j = 0; j < n; ++j) y[j] /= D_[j];
         for (int s = ns_ - 1; s >= 0; --s) {                     // backward: L^T x = z
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
             const int* R = rows_.data() + rows_ptr_[s];
             const int r = rows_ptr_[s + 1] - rows_ptr_[s];
             const double* P = pan_.data() + pan_ptr_[s];
-            for (int c = 0; c < DC; ++c) {
-                double* y = work + (size_t)c * n;
-                for (int i = 0; i < r; ++i) t[i] = y[R[i]];
-                if (avx) sn_backward1_avx2(P, w + r, w, r, y + f, t); else sn_backward1_base(P, w + r, w, r, y + f, t);
-            }
+            for (int i = 0; i < r; ++i) t[i] = y[R[i]];
+            if (avx) sn_backward1_avx2(P, w + r, w, r, y + f, t); else sn_backward1_base(P, w + r, w, r, y + f, t);
         }
-        for (int c = 0; c < DC; ++c) for (int i = 0; i < n; ++i) x[(size_t)c * ldx + perm[i]] = work[(size_t)c * n + i];
+        for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     }
 
     void numeric(const Compressed& A) {
