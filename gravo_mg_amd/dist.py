@@ -45,6 +45,7 @@ class DistVCycle:
         for c in range(self.n_colors):
             assert (self.color_begin[c + 1] - self.color_begin[c]) % (64 * self.world) == 0, "colour classes must be 64*world aligned"
         self.n_collectives = 0
+        self._send = {}
 
     # -- exchange ------------------------------------------------------------------------------------------
     def _allgather_color(self, buf: torch.Tensor, c: int):
@@ -57,10 +58,16 @@ class DistVCycle:
         for col in range(self.d):
             seg = buf[col * self.n_pad + lo: col * self.n_pad + hi]
             mine = seg[self.rank * piece: (self.rank + 1) * piece]
+            # the send buffer is a copy of this rank's piece (a few MB, device to device): no reliance on a backend's
+            # handling of an input that aliases the output
+            send = self._send.get(piece)
+            if send is None or send.device != mine.device or send.dtype != mine.dtype:
+                send = self._send[piece] = torch.empty_like(mine)
+            send.copy_(mine)
             try:
-                dist.all_gather_into_tensor(seg, mine, group=self.group)
+                dist.all_gather_into_tensor(seg, send, group=self.group)
             except (RuntimeError, NotImplementedError):          # backends without the flat variant (old gloo)
-                dist.all_gather(list(seg.chunk(self.world)), mine.clone(), group=self.group)
+                dist.all_gather(list(seg.chunk(self.world)), send, group=self.group)
             self.n_collectives += 1
 
     def _allgather_all(self, buf: torch.Tensor):
