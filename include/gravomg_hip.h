@@ -17,7 +17,7 @@
  *     must be symmetric (the reference's Gauss-Seidel depends on it, multigrid_solver.cpp:1200-1208).
  *   - dense multi-vectors are column-major n x d (Eigen::MatrixXd): column c starts at ptr + c*n.
  *   - host pointers are borrowed for the duration of the call only; device memory, the HIP stream and
- *     the captured hipGraphs are owned by the handle.  A handle is not thread-safe.
+ *     the (optional) captured hipGraphs are owned by the handle.  A handle is not thread-safe.
  *   - all device entry points fail with GMG_ERR_NO_DEVICE when no HIP device is usable; there is no
  *     CPU fallback behind this interface.
  */
