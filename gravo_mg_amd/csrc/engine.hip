@@ -1,10 +1,13 @@
-// engine.hip -- libgravomg_hip.so: device state, launch sequences and the C-ABI of include/gravomg_hip.h.
+// engine.hip -- libgravomg_hip.so: the C-ABI of include/gravomg_hip.h over the device engine.
 //
-// One handle = one HIP device, one stream.  The hierarchy (all A_k as SELL-64 + diagonal, all U_k / U_k^T)
-// is uploaded once per system (gmg_set_system); a V-cycle is a fixed launch sequence on that stream
-// (smooth -> residual -> restrict ... coarse solve ... prolong-add -> smooth), captured into hipGraphs and
-// replayed.  The coarsest direct solve stays on the host (sparse LDL^T, host_ldlt.hpp) unless
-// GMG_COARSE_DEVICE_INVERSE is selected.
+// One handle = one HIP device, one stream.  The hierarchy (all A_k as SELL-64 + diagonal, all U_k / U_k^T) is built on
+// the device once per system (gmg_set_system); a V-cycle is a fixed launch sequence on that stream (smooth -> residual
+// -> restrict ... coarse solve ... prolong-add -> smooth), optionally captured into hipGraphs.  The coarsest direct
+// solve stays on the host (supernodal LDL^T, host_ldlt.hpp) unless GMG_COARSE_DEVICE_INVERSE is selected.
+//
+// One translation unit, in four files: engine_state.hip.hpp (memory pool, level / handle structures, helpers),
+// engine_setup.hip.hpp (device-side layout construction, Galerkin products), engine_cycle.hip.hpp (launch helpers,
+// V-cycle legs) and this file (the extern "C" entry points, incl. the setup pipeline of gmg_set_system).
 //
 // Reference call sites this replaces: gravomg/src/multigrid_solver.cpp:1059-1088 (V-cycle),
 // :1194-1226 (smoother), :1228-1277 (norms), :1387-1419 (solve loop).
@@ -33,1174 +36,9 @@ using namespace gmg;
 using clk = std::chrono::steady_clock;
 static inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
 
-// ---- device memory pool (per handle) ------------------------------------------------------------------------
-// hipFree costs ~0.2 ms and synchronises the device; a setup allocates and releases ~100 arrays.  Blocks released
-// by a handle are parked in its pool and handed out again (same stream => stream order makes the reuse safe); the
-// pool is emptied when the handle is destroyed or when the parked bytes exceed what is in use.
-struct DevPool {
-    std::multimap<size_t, void*> parked;
-    std::map<void*, size_t> size_of;      // every block this pool handed out (live or parked)
-    size_t parked_bytes = 0, live_bytes = 0;
-    static size_t round_up(size_t b) { return (std::max<size_t>(b, 1) + 511) & ~(size_t)511; }
-    hipError_t alloc(void** p, size_t bytes) {
-        const size_t need = round_up(bytes);
-        auto it = parked.lower_bound(need);
-        if (it != parked.end() && it->first <= need + need / 8 + 65536) {
-            *p = it->second; parked_bytes -= it->first; live_bytes += it->first; parked.erase(it);
-            return hipSuccess;
-        }
-        hipError_t e = hipMalloc(p, need);
-        if (e != hipSuccess) { trim(); (void)hipGetLastError(); e = hipMalloc(p, need); }
-        if (e == hipSuccess) { size_of[*p] = need; live_bytes += need; }
-        return e;
-    }
-    void release(void* p) {
-        auto it = size_of.find(p);
-        if (it == size_of.end()) { (void)hipFree(p); return; }          // not ours (allocated outside a pool scope)
-        parked.emplace(it->second, p); parked_bytes += it->second; live_bytes -= std::min(live_bytes, it->second);
-        if (parked_bytes > std::max<size_t>(live_bytes, (size_t)2 << 30)) trim();
-    }
-    void trim() {
-        for (auto& kv : parked) { (void)hipFree(kv.second); size_of.erase(kv.second); }
-        parked.clear(); parked_bytes = 0;
-    }
-};
-static thread_local DevPool* tl_pool = nullptr;     // set for the duration of a C-ABI call on a handle (PoolScope)
-struct PoolScope {
-    DevPool* prev;
-    explicit PoolScope(DevPool* p) : prev(tl_pool) { tl_pool = p; }
-    ~PoolScope() { tl_pool = prev; }
-};
-static inline hipError_t dev_malloc(void** p, size_t bytes) { return tl_pool ? tl_pool->alloc(p, bytes) : hipMalloc(p, bytes); }
-static inline hipError_t dev_free(void* p) { if (!p) return hipSuccess; if (tl_pool) { tl_pool->release(p); return hipSuccess; } return hipFree(p); }
-
-namespace {
-
-struct DevSell {
-    int n_slices = 0;
-    int lpr = 1;                  // lanes per row of the SELL layout (1 or 4)
-    int64_t stored = 0, nnz_real = 0;
-    int64_t* slice_ptr = nullptr;
-    int* col = nullptr;
-    double* val = nullptr;
-    float* val32 = nullptr;       // fp32 copy of val (mixed-precision inner cycle); shares slice_ptr / col / row_of
-    int* row_of = nullptr;
-};
-
-// natural-numbering compressed matrix on the device (A_k, U_k by coarse column)
-struct DevCsr {
-    int n_outer = 0;
-    int *ptr = nullptr, *idx = nullptr;
-    double* val = nullptr;
-};
-
-// U_k regrouped by fine row (<= 3 entries per row, sorted by coarse column) for the prolongation layout and the RAP.
-struct DevEll3 {
-    int n = 0;
-    int *cnt = nullptr, *col = nullptr;
-    double* val = nullptr;
-};
-
-struct Level {
-    int n = 0, n_pad = 0;
-    int64_t nnz = 0;              // entries of A_k
-    LevelOrdering ord;
-    Compressed A;                 // natural numbering, host copy (Abar[k]); filled on demand (ensure_host_A) except on level L
-    bool hostA_pattern = false, hostA_values = false;
-    DevCsr dA;                    // natural numbering, device copy: RAP input, layout source, source of the lazy host copy
-    DevSell Aoff;                 // off-diagonal part, device numbering
-    double* diag = nullptr;       // n_pad
-    DevSell P, R;                 // U_k (rows: this level) and U_k^T (rows: next level); unused on level L
-    // blocked levels (block-hybrid Gauss-Seidel): in-block part (16-bit local columns) + off-block part
-    DevSell Ain, Aout;
-    unsigned short* ain_col16 = nullptr;
-    // big blocked levels: block-CSR storage instead of the two padded SELL operators (kernels.hip.hpp::gs_blockcsr)
-    bool use_bcsr = false;
-    int *bc_ptr = nullptr, *bc_mid = nullptr, *bc_col = nullptr;
-    double* bc_val = nullptr;
-    float* bc_val32 = nullptr;
-    int bc_cap = 0;               // entries of the largest block, rounded up to 64 (LDS capacity of the sweep)
-    int64_t bc_nnz = 0;
-    int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
-    unsigned char* d_row_color = nullptr;
-    int* d_new2old = nullptr;
-    double *x = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;   // n_pad * dcap
-    float *diag32 = nullptr, *x32 = nullptr, *b32 = nullptr, *r32 = nullptr, *tmp32 = nullptr;   // mixed precision
-};
-
-}  // namespace
-
-struct gmg_hierarchy_s {
-    HierarchyResult res;
-};
-
-struct gmg_solver_s {
-    DevPool pool;
-    gmg_config cfg;
-    std::string err;
-    bool has_device = false;
-    hipStream_t stream = nullptr;
-    int L = -1;
-    std::vector<Compressed> U;
-    std::vector<char> U_set;
-    std::vector<DevCsr> dU;               // device copies of U_k (kept while the hierarchy is unchanged)
-    std::vector<DevEll3> dE3;             // and their by-row regrouping
-    bool dU_ready = false;
-    // patches of the blocked levels k >= 1, grown over the coarse point graph of U_{k-1} (hierarchy data, host only)
-    std::vector<PatchSet> patches;
-    std::vector<int> cluster_order;       // locality-preserving order of the level-0 points derived from U (new -> old)
-    int *d_cluster_order = nullptr, *d_cluster_inv = nullptr;      // device copies (order, and old -> new position)
-    RawVec<int> reo_ptr, reo_idx;         // LHS pattern permuted into cluster order (staging for the level-0 colouring)
-    bool patches_ready = false;
-    bool dU_flagged = false;              // ell3_from_csc found a U row with more than 3 entries (host paths only)
-    std::vector<double> mass;
-    std::vector<Level> lv;
-    SupernodalLDLT coarse;
-    bool system_ready = false;
-    int dcap = 0;
-    double *d_mass = nullptr, *d_minv = nullptr;
-    double* d_stage = nullptr; size_t stage_cap = 0;
-    double* h_stage[2] = {nullptr, nullptr}; size_t h_stage_cap = 0;      // pinned host staging (double-buffered) for b / x
-    hipEvent_t h_stage_ev[2] = {nullptr, nullptr}; int h_stage_flip = 0;
-    double* d_partials = nullptr; int partial_blocks = 0;
-    double* d_norm = nullptr;
-    double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
-    double* h_norm = nullptr;
-    double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
-    std::vector<double> coarse_work;
-    std::map<std::string, double> timing;
-    std::map<int, hipGraphExec_t> graphs;
-    int loaded_d = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // multi-GPU (one process per GPU): this rank's share of level 0, externally owned level-0 vectors
-    hipStream_t own_stream = nullptr;
-    int rank = 0, world = 1;
-    bool dist_ready = false;
-    bool dist_all_rows = false;
-    double *own_x0 = nullptr, *own_b0 = nullptr, *own_r0 = nullptr;   // engine-owned buffers parked while external ones are bound
-    bool bound = false;
-    // orderings of the last system, reusable while the sparsity pattern of the LHS and the hierarchy are unchanged
-    bool ord_cache_valid = false;
-    uint64_t ord_cache_key[2] = {0, 0};
-    std::vector<LevelOrdering> ord_cache;
-    // the orderings live in the levels while a system is set; they move into ord_cache when the next one arrives
-    uint64_t live_key[2] = {0, 0};
-    bool live_key_valid = false;
-};
-
-namespace {
-
-int fail(gmg_handle h, int code, const std::string& msg) {
-    if (h) h->err = msg;
-    return code;
-}
-
-#define HIPCHK(call)                                                                                       \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess) return fail(h, GMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-#define NEED_DEVICE()                                                                     \
-    if (!h) return GMG_ERR_INVALID;                                                       \
-    PoolScope pool_scope_(&h->pool);                                                      \
-    do {                                                                                  \
-        if (!h->has_device) return fail(h, GMG_ERR_NO_DEVICE, "no usable HIP device (libgravomg_hip has no CPU fallback)"); \
-    } while (0)
-
-template <class T>
-int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
-    if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
-    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(dev_malloc((void**)dst, bytes));
-    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
-    return GMG_OK;
-}
-
-template <class T>
-int upload(gmg_handle h, T** dst, const RawVec<T>& src) {
-    if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
-    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(dev_malloc((void**)dst, bytes));
-    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
-    return GMG_OK;
-}
-
-void free_sell(DevSell& s) {
-    if (s.slice_ptr) (void)dev_free(s.slice_ptr);
-    if (s.col) (void)dev_free(s.col);
-    if (s.val) (void)dev_free(s.val);
-    if (s.val32) (void)dev_free(s.val32);
-    if (s.row_of) (void)dev_free(s.row_of);
-    s = DevSell();
-}
-
-int upload_sell(gmg_handle h, DevSell& d, const SellHost& s) {
-    free_sell(d);
-    d.n_slices = s.n_slices; d.stored = s.stored(); d.nnz_real = s.nnz_real; d.lpr = s.lpr;
-    int rc;
-    if ((rc = upload(h, &d.slice_ptr, s.slice_ptr))) return rc;
-    if ((rc = upload(h, &d.col, s.col))) return rc;
-    if ((rc = upload(h, &d.val, s.val))) return rc;
-    if (!s.row_of.empty() && (rc = upload(h, &d.row_of, s.row_of))) return rc;
-    return GMG_OK;
-}
-
-void free_csr(DevCsr& m) {
-    if (m.ptr) (void)dev_free(m.ptr);
-    if (m.idx) (void)dev_free(m.idx);
-    if (m.val) (void)dev_free(m.val);
-    m = DevCsr();
-}
-
-void free_ell3(DevEll3& e) {
-    if (e.cnt) (void)dev_free(e.cnt);
-    if (e.col) (void)dev_free(e.col);
-    if (e.val) (void)dev_free(e.val);
-    e = DevEll3();
-}
-
-void drop_device_transfers(gmg_handle h) {
-    if (h->d_cluster_order) { (void)dev_free(h->d_cluster_order); h->d_cluster_order = nullptr; }
-    if (h->d_cluster_inv) { (void)dev_free(h->d_cluster_inv); h->d_cluster_inv = nullptr; }
-    for (auto& m : h->dU) free_csr(m);
-    for (auto& e : h->dE3) free_ell3(e);
-    h->dU.clear(); h->dE3.clear();
-    h->dU_ready = false;
-}
-
-// Patches of every blocked level k >= 1 (see coarse_point_graph): depend on the hierarchy and on block_rows only.
-void build_patches(gmg_handle h) {
-    const int L = h->L;
-    h->patches.assign(L + 1, PatchSet());
-    h->cluster_order.clear();
-    const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
-    // U_k by fine row: shared by the coarse point graphs (patches of level k + 1) and the cluster order of level 0
-    std::vector<Compressed> Urows(L);
-    {
-        std::vector<std::future<void>> jobs;
-        for (int k = 0; k < L; ++k) jobs.push_back(std::async(std::launch::async, [h, k, &Urows] { Urows[k] = transpose_parallel(h->U[k]); }));
-        for (auto& j : jobs) j.get();
-    }
-    std::vector<std::future<void>> jobs;
-    if (mc && h->cfg.block_rows > 0)
-        for (int k = std::max(1, h->cfg.block_from_level); k < L; ++k)
-            jobs.push_back(std::async(std::launch::async, [h, k, &Urows] {
-                Compressed G = coarse_point_graph(h->U[k - 1], Urows[k - 1]);
-                h->patches[k] = grow_patch_set(G, h->cfg.block_rows);
-            }));
-    if (mc && h->cfg.reorder_fine != 0 && L > 0)
-        jobs.push_back(std::async(std::launch::async, [h, L, &Urows] {
-            Compressed GL = coarse_point_graph(h->U[L - 1], Urows[L - 1]);
-            h->cluster_order = cluster_order(Urows, GL);
-        }));
-    for (auto& j : jobs) j.get();
-    h->patches_ready = true;
-}
-
-void free_level(Level& l) {
-    free_csr(l.dA);
-    free_sell(l.Aoff); free_sell(l.P); free_sell(l.R); free_sell(l.Ain); free_sell(l.Aout);
-    if (l.ain_col16) { (void)dev_free(l.ain_col16); l.ain_col16 = nullptr; }
-    for (int** p : {&l.bc_ptr, &l.bc_mid, &l.bc_col}) { if (*p) (void)dev_free(*p); *p = nullptr; }
-    if (l.bc_val) { (void)dev_free(l.bc_val); l.bc_val = nullptr; }
-    if (l.bc_val32) { (void)dev_free(l.bc_val32); l.bc_val32 = nullptr; }
-    l.use_bcsr = false; l.bc_cap = 0; l.bc_nnz = 0;
-    if (l.d_blk_begin) { (void)dev_free(l.d_blk_begin); l.d_blk_begin = nullptr; }
-    if (l.d_blk_ncolors) { (void)dev_free(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
-    if (l.d_row_color) { (void)dev_free(l.d_row_color); l.d_row_color = nullptr; }
-    for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)dev_free(*p); *p = nullptr; }
-    for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)dev_free(*p); *p = nullptr; }
-    if (l.d_new2old) { (void)dev_free(l.d_new2old); l.d_new2old = nullptr; }
-}
-
-void drop_graphs(gmg_handle h) {
-    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
-    h->graphs.clear();
-}
-
-void unbind_level0(gmg_handle h) {
-    if (h->bound && !h->lv.empty()) { h->lv[0].x = h->own_x0; h->lv[0].b = h->own_b0; h->lv[0].r = h->own_r0; }
-    h->bound = false; h->own_x0 = h->own_b0 = h->own_r0 = nullptr;
-}
-
-void drop_system(gmg_handle h) {
-    drop_graphs(h);
-    unbind_level0(h);
-    h->dist_ready = false;
-    for (auto& l : h->lv) free_level(l);
-    h->lv.clear();
-    h->system_ready = false;
-    h->dcap = 0;
-    h->loaded_d = 0;
-    if (h->d_mass) { (void)dev_free(h->d_mass); h->d_mass = nullptr; }
-    if (h->d_minv) { (void)dev_free(h->d_minv); h->d_minv = nullptr; }
-    if (h->d_ainv) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
-}
-
-constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
-constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)
-inline bool wants_block_csr(gmg_handle h, int lpr) { return h->cfg.block_csr != 0 && lpr == 1 && h->cfg.block_rows == 64; }
-
-// ---- device-side layout construction (setup_kernels.hip.hpp) ------------------------------------------------
-int upload_csr(gmg_handle h, DevCsr& d, const Compressed& m) {
-    free_csr(d);
-    d.n_outer = m.n_outer;
-    int rc;
-    if ((rc = upload(h, &d.ptr, m.ptr)) || (rc = upload(h, &d.idx, m.idx)) || (rc = upload(h, &d.val, m.val))) return rc;
-    return GMG_OK;
-}
-
-int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const int* idx, const double* val) {
-    free_csr(d);
-    d.n_outer = n_outer;
-    const size_t nnz = (size_t)ptr[n_outer];
-    HIPCHK(dev_malloc((void**)&d.ptr, sizeof(int) * ((size_t)n_outer + 1)));
-    HIPCHK(dev_malloc((void**)&d.idx, sizeof(int) * std::max<size_t>(nnz, 1)));
-    HIPCHK(dev_malloc((void**)&d.val, sizeof(double) * std::max<size_t>(nnz, 1)));
-    HIPCHK(hipMemcpyAsync(d.ptr, ptr, sizeof(int) * ((size_t)n_outer + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d.idx, idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d.val, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
-    return GMG_OK;
-}
-
-template <class T>
-struct DevTmp {                       // scratch device array released at scope exit (stream-ordered reuse through the pool)
-    T* p = nullptr;
-    ~DevTmp() { if (p) (void)dev_free(p); }
-    int alloc(gmg_handle h, size_t n) { HIPCHK(dev_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return GMG_OK; }
-};
-
-// out[0..n] = exclusive prefix sums of in[0..n) on the stream; *total_host (pinned or pageable) receives out[n] after
-// the caller synchronises.
-template <class TIn, class TOut>
-int device_scan(gmg_handle h, const TIn* in, int n, TOut* out, TOut* total_host) {
-    const int tiles = std::max(1, (n + gmgs::kScanTile - 1) / gmgs::kScanTile);
-    DevTmp<TOut> tile;
-    int rc;
-    if ((rc = tile.alloc(h, (size_t)tiles + 1))) return rc;
-    hipLaunchKernelGGL((gmgs::scan_tile_sums<TIn, TOut>), dim3(tiles), dim3(256), 0, h->stream, in, n, tile.p);
-    hipLaunchKernelGGL((gmgs::scan_tile_offsets<TOut>), dim3(1), dim3(1024), 0, h->stream, tile.p, tiles, tile.p + tiles);
-    hipLaunchKernelGGL((gmgs::scan_tile_apply<TIn, TOut>), dim3(tiles), dim3(256), 0, h->stream, in, n, (const TOut*)tile.p, out);
-    if (total_host) HIPCHK(hipMemcpyAsync(total_host, tile.p + tiles, sizeof(TOut), hipMemcpyDeviceToHost, h->stream));
-    return GMG_OK;
-}
-
-// Builds one SELL matrix on the device.  pbeg/pend/idx/val: source rows (natural numbering); f: row/column maps and
-// filter; d_order: optional slice-position -> device-row map (uploaded by the caller; also stored as row_of);
-// col16: write 16-bit columns into *col16_out (in-block part of a blocked level) instead of out.col.
-int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pend, const int* idx, const double* val, gmgs::RowFilter f,
-                      const int* d_order, int n_rows_pad, int lpr, unsigned short** col16_out, double* d_diag, int* d_err) {
-    free_sell(out);
-    const int rps = 64 / lpr;
-    out.lpr = lpr;
-    out.n_slices = n_rows_pad / rps;
-    DevTmp<int> len;
-    DevTmp<int64_t> widths;
-    int rc;
-    if ((rc = len.alloc(h, n_rows_pad)) || (rc = widths.alloc(h, out.n_slices))) return rc;
-    HIPCHK(dev_malloc((void**)&out.slice_ptr, sizeof(int64_t) * ((size_t)out.n_slices + 1)));
-    hipLaunchKernelGGL(gmgs::row_lengths, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, f, d_order, n_rows_pad, len.p, d_err);
-    hipLaunchKernelGGL(gmgs::slice_widths, dim3((out.n_slices + 255) / 256), dim3(256), 0, h->stream, len.p, lpr, out.n_slices, widths.p);
-    int64_t total = 0;
-    if ((rc = device_scan<int64_t, int64_t>(h, widths.p, out.n_slices, out.slice_ptr, &total))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
-    out.stored = total;
-    HIPCHK(dev_malloc((void**)&out.val, std::max<int64_t>(out.stored, 1) * sizeof(double)));
-    if (col16_out) {
-        if (*col16_out) { (void)dev_free(*col16_out); *col16_out = nullptr; }
-        HIPCHK(dev_malloc((void**)col16_out, std::max<int64_t>(out.stored, 1) * sizeof(unsigned short)));
-        hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
-                           n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
-    } else {
-        HIPCHK(dev_malloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
-        hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
-                           out.slice_ptr, out.col, out.val, d_diag, d_err);
-    }
-    return GMG_OK;
-}
-
-int build_ell3(gmg_handle h, DevEll3& e, const DevCsr& dU, int n_fine, int* d_err) {
-    free_ell3(e);
-    e.n = n_fine;
-    HIPCHK(dev_malloc((void**)&e.cnt, sizeof(int) * std::max(n_fine, 1)));
-    HIPCHK(dev_malloc((void**)&e.col, sizeof(int) * (size_t)std::max(n_fine, 1) * 3));
-    HIPCHK(dev_malloc((void**)&e.val, sizeof(double) * (size_t)std::max(n_fine, 1) * 3));
-    HIPCHK(hipMemsetAsync(e.cnt, 0, sizeof(int) * n_fine, h->stream));
-    hipLaunchKernelGGL(gmgs::ell3_from_csc, dim3((dU.n_outer + 255) / 256), dim3(256), 0, h->stream, dU.ptr, dU.idx, dU.val, dU.n_outer, e.cnt, e.col, e.val, d_err);
-    hipLaunchKernelGGL(gmgs::ell3_sort, dim3((n_fine + 255) / 256), dim3(256), 0, h->stream, e.cnt, n_fine, e.col, e.val);
-    return GMG_OK;
-}
-
-// Device copies of every U_k (by coarse column, and regrouped by fine row): built once per hierarchy.
-int ensure_device_transfers(gmg_handle h) {
-    if (h->dU_ready) return GMG_OK;
-    const int L = h->L;
-    drop_device_transfers(h);
-    h->dU.assign(L, DevCsr());
-    h->dE3.assign(L, DevEll3());
-    DevTmp<int> d_err;
-    int rc, herr = 0;
-    if ((rc = d_err.alloc(h, 1))) return rc;
-    HIPCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream));
-    for (int k = 0; k < L; ++k) {
-        rc = upload_csr(h, h->dU[k], h->U[k]);
-        if (rc == GMG_OK) rc = build_ell3(h, h->dE3[k], h->dU[k], h->U[k].n_inner, d_err.p);
-        if (rc) return rc;
-    }
-    HIPCHK(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));      // pageable host arrays have been consumed
-    h->dU_flagged = herr != 0;      // a U row with more than 3 entries: the device RAP / layout builder cannot take it
-    h->dU_ready = true;
-    return GMG_OK;
-}
-
-// LHS pattern in the hierarchy's cluster order (h->cluster_order), made on the device from the uploaded LHS and copied
-// to h->reo_ptr / h->reo_idx: the level-0 colouring then walks a locally ordered graph instead of chasing pointers
-// through a randomly numbered one (3 M vertices in random order: 450 ms -> 20 ms).
-int device_permute_pattern(gmg_handle h, const DevCsr& dA, int n, int64_t nnz) {
-    int rc;
-    if (!h->d_cluster_order) {
-        std::vector<int> inv(n);
-        const std::vector<int>& ord = h->cluster_order;
-        parallel_ranges(n, std::min(h->cfg.host_threads, 32), [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) inv[ord[r]] = r; });
-        if ((rc = upload(h, &h->d_cluster_order, ord)) || (rc = upload(h, &h->d_cluster_inv, inv))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
-    DevTmp<int> len, pptr, pidx;
-    if ((rc = len.alloc(h, n)) || (rc = pptr.alloc(h, (size_t)n + 1)) || (rc = pidx.alloc(h, (size_t)nnz))) return rc;
-    hipLaunchKernelGGL(gmgs::perm_row_lengths, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, h->d_cluster_order, n, len.p);
-    if ((rc = device_scan<int, int>(h, len.p, n, pptr.p, nullptr))) return rc;
-    hipLaunchKernelGGL(gmgs::perm_fill, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.idx, h->d_cluster_order, h->d_cluster_inv, pptr.p, n, pidx.p);
-    h->reo_ptr.resize((size_t)n + 1);
-    h->reo_idx.resize((size_t)nnz);
-    HIPCHK(hipMemcpyAsync(h->reo_ptr.data(), pptr.p, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->reo_idx.data(), pidx.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return GMG_OK;
-}
-
-// Host copy of A_k (natural numbering), on demand: the device keeps the master copy (Level::dA).
-int ensure_host_A(gmg_handle h, int k, bool values) {
-    Level& l = h->lv[k];
-    if (l.hostA_pattern && (l.hostA_values || !values)) return GMG_OK;
-    if (!l.dA.ptr) return fail(h, GMG_ERR_STATE, "level operator is neither on the host nor on the device");
-    const int n = l.dA.n_outer;
-    l.A.n_outer = n; l.A.n_inner = n;
-    if (!l.hostA_pattern) {
-        l.A.ptr.resize((size_t)n + 1);
-        HIPCHK(hipMemcpyAsync(l.A.ptr.data(), l.dA.ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        l.A.idx.resize((size_t)l.A.ptr[n]);
-        HIPCHK(hipMemcpyAsync(l.A.idx.data(), l.dA.idx, sizeof(int) * l.A.idx.size(), hipMemcpyDeviceToHost, h->stream));
-    }
-    if (values && !l.hostA_values) {
-        l.A.val.resize((size_t)l.nnz);
-        HIPCHK(hipMemcpyAsync(l.A.val.data(), l.dA.val, sizeof(double) * l.A.val.size(), hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    l.hostA_pattern = true;
-    l.hostA_values = l.hostA_values || values;
-    return GMG_OK;
-}
-
-// Ac = U^T A U on the device (setup_kernels.hip.hpp::rap_rows): count pass, device prefix sum, fill pass.  The result
-// stays on the device (dC); `pattern` (row pointers + column indices, for the host ordering of that level) and
-// `values` say what is copied to the host as well.  Returns 1 when the device kernel cannot take the input.
-int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& e3, DevCsr& dC, Compressed& C, bool pattern, bool values,
-               int64_t* nnz_out, int* d_err) {
-    const int nc = dU.n_outer;
-    free_csr(dC);
-    dC.n_outer = nc;
-    DevTmp<int> cnt;
-    int rc;
-    if ((rc = cnt.alloc(h, nc))) return rc;
-    HIPCHK(dev_malloc((void**)&dC.ptr, sizeof(int) * ((size_t)nc + 1)));
-    hipLaunchKernelGGL(gmgs::rap_rows<0>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
-                       (const int*)nullptr, cnt.p, (int*)nullptr, (double*)nullptr, d_err);
-    int nnz = 0, herr = 0;
-    if ((rc = device_scan<int, int>(h, cnt.p, nc, dC.ptr, &nnz))) return rc;
-    HIPCHK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    C.n_outer = nc; C.n_inner = nc;
-    if (pattern || values) {
-        C.ptr.resize((size_t)nc + 1);
-        HIPCHK(hipMemcpyAsync(C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (herr) { free_csr(dC); return 1; }       // a coarse row overflows the device hash set (or a U row has > 3 entries): host fallback
-    *nnz_out = nnz;
-    HIPCHK(dev_malloc((void**)&dC.idx, sizeof(int) * std::max(nnz, 1)));
-    HIPCHK(dev_malloc((void**)&dC.val, sizeof(double) * std::max(nnz, 1)));
-    hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
-                       (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
-    if (pattern || values) { C.idx.resize(nnz); HIPCHK(hipMemcpyAsync(C.idx.data(), dC.idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, h->stream)); }
-    if (values) { C.val.resize(nnz); HIPCHK(hipMemcpyAsync(C.val.data(), dC.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, h->stream)); }
-    if (pattern || values) HIPCHK(hipStreamSynchronize(h->stream));
-    return GMG_OK;
-}
-
-// Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device from Level::dA and the
-// device copies of U_k.  A row longer than gmgs::kMaxRow or a prolongation row with more than 3 entries raises *d_err:
-// the caller then falls back to the host planner.
-int device_layout_level(gmg_handle h, int k, int* d_err) {
-    const int L = h->L;
-    Level& l = h->lv[k];
-    int rc;
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;      // synchronising phase timers on stderr
-    auto tph = clk::now();
-    auto phase = [&](const char* what) {
-        if (!trace) return;
-        (void)hipStreamSynchronize(h->stream);
-        std::fprintf(stderr, "[gmg setup] level %d %-10s %.2f ms\n", k, what, ms_since(tph));
-        tph = clk::now();
-    };
-    DevTmp<int> d_old2new, d_blk_of_row;
-    if (!l.dA.ptr) {
-        if ((rc = ensure_host_A(h, k, true)) || (rc = upload_csr(h, l.dA, l.A))) return rc;
-    }
-    const DevCsr& dA = l.dA;
-    if ((rc = upload(h, &d_old2new.p, l.ord.old2new))) return rc;
-    phase("old2new");
-    gmgs::RowFilter f{l.d_new2old, d_old2new.p, nullptr, nullptr, 0, 1};
-    const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
-    const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
-    HIPCHK(dev_malloc((void**)&l.diag, sizeof(double) * l.n_pad));
-    if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) return rc;
-    l.Aoff.nnz_real = l.nnz - l.n;
-    phase("A");
-    if (l.ord.blocked) {
-        if ((rc = d_blk_of_row.alloc(h, l.n_pad)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
-            (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
-        hipLaunchKernelGGL(gmgs::block_of_rows, dim3(std::max(1, l.ord.n_blocks())), dim3(64), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), d_blk_of_row.p);
-        gmgs::RowFilter fin{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
-        gmgs::RowFilter fout{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
-        if (wants_block_csr(h, lpr)) {
-            // off-block operator as a block-ordered CSR; its row pointers first: they tell whether the largest block's
-            // chunk fits the sweep's LDS budget
-            DevTmp<int> len, d_max;
-            int nnz = 0, bmax = 0;
-            if ((rc = len.alloc(h, l.n_pad)) || (rc = d_max.alloc(h, 1))) return rc;
-            HIPCHK(dev_malloc((void**)&l.bc_ptr, sizeof(int) * ((size_t)l.n_pad + 1)));
-            HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(int), h->stream));
-            hipLaunchKernelGGL(gmgs::row_lengths, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, fout, (const int*)nullptr, l.n_pad, len.p, d_err);
-            if ((rc = device_scan<int, int>(h, len.p, l.n_pad, l.bc_ptr, &nnz))) return rc;
-            hipLaunchKernelGGL(gmgs::block_entry_max, dim3((l.ord.n_blocks() + 255) / 256), dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.bc_ptr, d_max.p);
-            HIPCHK(hipMemcpyAsync(&bmax, d_max.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            if (bmax <= kBcsrMaxBlockEntries) {
-                l.use_bcsr = true;
-                l.bc_cap = (bmax + 63) / 64 * 64;
-                l.bc_nnz = nnz;
-                HIPCHK(dev_malloc((void**)&l.bc_mid, sizeof(int) * (size_t)l.n_pad));
-                HIPCHK(dev_malloc((void**)&l.bc_col, sizeof(int) * (size_t)std::max(nnz, 1)));
-                HIPCHK(dev_malloc((void**)&l.bc_val, sizeof(double) * (size_t)std::max(nnz, 1)));
-                hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, d_blk_of_row.p,
-                                   l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
-            } else { (void)dev_free(l.bc_ptr); l.bc_ptr = nullptr; }
-        }
-        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err))) return rc;
-        // the padded SELL form of the off-block operator is kept as well: with one right-hand side the sweep that
-        // streams it straight into registers is the faster one (42 vs 47 us on the 506 k-row level; 104 vs 60 us at d = 3)
-        if ((rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) return rc;
-    }
-    phase("A split");
-    if (k == L) return GMG_OK;
-    // ---- transfers k <-> k+1
-    Level& c = h->lv[k + 1];
-    const DevCsr& dU = h->dU[k];
-    const DevEll3& e3 = h->dE3[k];
-    DevTmp<int> d_old2new_c, d_order, d_pbeg, d_pend;
-    if ((rc = upload(h, &d_old2new_c.p, c.ord.old2new))) return rc;
-    // restriction: rows = coarse points (columns of the CSC U), sorted by length inside windows like the host planner
-    {
-        const Compressed& U = h->U[k];
-        const int np = c.n_pad, sigma = h->cfg.sigma;
-        if (sigma > 0 && sigma <= gmgs::kWindowSortMax) {
-            int pow2 = 1;
-            while (pow2 < sigma) pow2 <<= 1;
-            if ((rc = d_order.alloc(h, np))) return rc;
-            hipLaunchKernelGGL(gmgs::window_order_by_length, dim3((np + sigma - 1) / sigma), dim3(256), 0, h->stream, dU.ptr, c.d_new2old, np, sigma, pow2, d_order.p);
-        } else if (sigma > 0) {
-            std::vector<int> order(np);
-            auto len_of = [&](int r) { int old = c.ord.new2old[r]; return old >= 0 ? U.ptr[old + 1] - U.ptr[old] : 0; };
-            const int nwin = (np + sigma - 1) / sigma;
-            for (int wi = 0; wi < nwin; ++wi) {
-                int w = wi * sigma, we = std::min(np, w + sigma);
-                std::iota(order.begin() + w, order.begin() + we, w);
-                std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) { return len_of(a) > len_of(b); });
-            }
-            if ((rc = upload(h, &d_order.p, order))) return rc;
-            HIPCHK(hipStreamSynchronize(h->stream));      // `order` (pageable) dies at scope end
-        }
-        phase("R order");
-        gmgs::RowFilter fr{c.d_new2old, d_old2new.p, nullptr, nullptr, 0, 0};
-        const int lpr_r = h->cfg.block_lanes == 1 ? 1 : 4;
-        if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) return rc;
-        l.R.nnz_real = U.nnz();
-        if (sigma > 0) { l.R.row_of = d_order.p; d_order.p = nullptr; }     // the order array becomes the output-row map
-        phase("R");
-    }
-    // prolongation: rows = fine points; U is stored by coarse column, so it was regrouped by fine row (<= 3 per row)
-    {
-        const int nf = l.n;
-        if ((rc = d_pbeg.alloc(h, nf)) || (rc = d_pend.alloc(h, nf))) return rc;
-        hipLaunchKernelGGL(gmgs::ell3_ptr, dim3((nf + 255) / 256), dim3(256), 0, h->stream, e3.cnt, nf, d_pbeg.p, d_pend.p);
-        gmgs::RowFilter fp{l.d_new2old, d_old2new_c.p, nullptr, nullptr, 0, 0};
-        if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) return rc;
-        l.P.nnz_real = h->U[k].nnz();
-    }
-    HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
-    phase("P");
-    return GMG_OK;
-}
-
-// One threaded pass over a compressed pattern: 0 = canonical (indices in range, strictly ascending inside each outer
-// vector), 1 = in range but unsorted or with duplicates, 2 = an index out of range / a non-monotone pointer array.
-int inspect_pattern(int n_outer, int n_inner, const int* ptr, const int* idx, int threads) {
-    if (ptr[0] != 0) return 2;
-    std::vector<int> worst(std::max(threads, 1) + 1, 0);
-    parallel_ranges(n_outer, threads, [&](int lo, int hi, int t) {
-        int w = 0;
-        for (int j = lo; j < hi && w < 2; ++j) {
-            if (ptr[j + 1] < ptr[j]) { w = 2; break; }
-            int prev = -1;
-            for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
-                const int i = idx[p];
-                if (i < 0 || i >= n_inner) { w = 2; break; }
-                if (i <= prev) w = 1;
-                prev = i;
-            }
-        }
-        worst[std::min(t, (int)worst.size() - 1)] = w;
-    });
-    int w = 0;
-    for (int v : worst) w = std::max(w, v);
-    return w;
-}
-
-// Sorted, duplicate-free copy of a compressed matrix (duplicates are summed, like Eigen's setFromTriplets / scipy's
-// sum_duplicates): what the engine requires of the LHS, made here when the caller's storage is not canonical.
-Compressed canonical_copy(int n_outer, int n_inner, const int* ptr, const int* idx, const double* val, int threads) {
-    Compressed out;
-    out.n_outer = n_outer; out.n_inner = n_inner;
-    std::vector<int> cnt((size_t)n_outer + 1, 0);
-    std::vector<std::vector<std::pair<int, double>>> cols(n_outer);
-    parallel_ranges(n_outer, threads, [&](int lo, int hi, int) {
-        for (int j = lo; j < hi; ++j) {
-            auto& c = cols[j];
-            c.reserve(ptr[j + 1] - ptr[j]);
-            for (int p = ptr[j]; p < ptr[j + 1]; ++p) c.emplace_back(idx[p], val[p]);
-            std::stable_sort(c.begin(), c.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
-            size_t w = 0;
-            for (size_t r = 0; r < c.size(); ++r) {
-                if (w > 0 && c[w - 1].first == c[r].first) c[w - 1].second += c[r].second;
-                else c[w++] = c[r];
-            }
-            c.resize(w);
-            cnt[j + 1] = (int)w;
-        }
-    });
-    for (int j = 0; j < n_outer; ++j) cnt[j + 1] += cnt[j];
-    out.ptr = cnt;
-    out.idx.resize(cnt[n_outer]); out.val.resize(cnt[n_outer]);
-    parallel_ranges(n_outer, threads, [&](int lo, int hi, int) {
-        for (int j = lo; j < hi; ++j) {
-            int q = out.ptr[j];
-            for (auto& e : cols[j]) { out.idx[q] = e.first; out.val[q] = e.second; ++q; }
-        }
-    });
-    return out;
-}
-
-// 2 x 64-bit FNV-1a style digest of the LHS sparsity pattern (threaded; chunk digests combined in order)
-void pattern_key(int n, const int* colptr, const int* rowidx, int threads, uint64_t key[2]) {
-    const int64_t nnz = colptr[n];
-    (void)threads;
-    const int T = 32;       // fixed: the digest depends on the chunking
-    std::vector<uint64_t> part((size_t)T * 2, 0);
-    auto digest = [](const int* p, int64_t cnt, uint64_t seed) {
-        uint64_t h = 1469598103934665603ull ^ seed;
-        for (int64_t i = 0; i < cnt; ++i) { h ^= (uint32_t)p[i]; h *= 1099511628211ull; h ^= h >> 29; }
-        return h;
-    };
-    parallel_ranges(T, T, [&](int t0, int t1, int) {
-        for (int t = t0; t < t1; ++t) {
-            int64_t lo = nnz * t / T, hi = nnz * (t + 1) / T;
-            part[2 * t] = digest(rowidx + lo, hi - lo, 0x9e3779b97f4a7c15ull * (t + 1));
-            int64_t plo = (int64_t)(n + 1) * t / T, phi = (int64_t)(n + 1) * (t + 1) / T;
-            part[2 * t + 1] = digest(colptr + plo, phi - plo, 0xc2b2ae3d27d4eb4full * (t + 1));
-        }
-    }, 1);
-    key[0] = 1469598103934665603ull ^ (uint64_t)n; key[1] = 0x84222325cbf29ce4ull ^ (uint64_t)nnz;
-    for (int t = 0; t < T; ++t) { key[0] = (key[0] ^ part[2 * t]) * 1099511628211ull; key[1] = (key[1] ^ part[2 * t + 1]) * 1099511628211ull; }
-}
-
-constexpr int kNormBlocks = 2048;      // residual-norm partial sums: 8 blocks per CU, grid-stride
-
-inline int grid_for(int n_slices) {
-    int g = (n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
-    return (g + 7) / 8 * 8;    // multiple of 8 so the XCD swizzle is a bijection
-}
-
-// ---- launch helpers (all on h->stream; column chunks of <= 4) ----------------------------------------
-
-#define DISPATCH_D(dc, ...)              \
-    switch (dc) {                        \
-        case 1: { constexpr int D = 1; __VA_ARGS__; } break; \
-        case 2: { constexpr int D = 2; __VA_ARGS__; } break; \
-        case 3: { constexpr int D = 3; __VA_ARGS__; } break; \
-        default: { constexpr int D = 4; __VA_ARGS__; } break; \
-    }
-
-// Precision selector: the fp64 arrays, or their fp32 twins (same layout, same index arrays).
-template <class T> struct Prec;
-template <> struct Prec<double> {
-    static const double* val(const DevSell& s) { return s.val; }
-    static const double* diag(const Level& l) { return l.diag; }
-    static const double* bcval(const Level& l) { return l.bc_val; }
-    static double* x(Level& l) { return l.x; }
-    static double* b(Level& l) { return l.b; }
-    static double* r(Level& l) { return l.r; }
-    static double* tmp(Level& l) { return l.tmp; }
-};
-template <> struct Prec<float> {
-    static const float* val(const DevSell& s) { return s.val32; }
-    static const float* diag(const Level& l) { return l.diag32; }
-    static const float* bcval(const Level& l) { return l.bc_val32; }
-    static float* x(Level& l) { return l.x32; }
-    static float* b(Level& l) { return l.b32; }
-    static float* r(Level& l) { return l.r32; }
-    static float* tmp(Level& l) { return l.tmp32; }
-};
-
-template <class T>
-void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
-    const int ld = l.n_pad;
-    const bool fine = &l == &h->lv[0];
-    T* x = Prec<T>::x(l);
-    const T* b = Prec<T>::b(l);
-    for (int it = 0; it < iters; ++it)
-        for (int c0 = 0; c0 < d; c0 += 4) {
-            int dc = std::min(4, d - c0);
-            for (int c = 0; c < l.ord.n_colors; ++c) {
-                int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
-                if (se <= sb) continue;
-                if (fine) {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
-                } else {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
-                }
-            }
-        }
-}
-
-template <class T>
-void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
-    const int ld = l.n_pad;
-    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
-    const T* b = Prec<T>::b(l);
-    for (int it = 0; it < iters; ++it) {
-        for (int c0 = 0; c0 < d; c0 += 4) {
-            int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::jacobi_sweep<T, D>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                              in + (size_t)c0 * ld, out + (size_t)c0 * ld, ld, l.Aoff.n_slices, (T)h->cfg.jacobi_omega, 1));
-        }
-        std::swap(in, out);
-    }
-    if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
-}
-
-// block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
-template <class T>
-void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
-    const int ld = l.n_pad;
-    const int nb = l.ord.n_blocks();
-    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
-    const T* b = Prec<T>::b(l);
-    for (int it = 0; it < iters; ++it) {
-        for (int c0 = 0; c0 < d; c0 += 4) {
-            int dc = std::min(4, d - c0);
-            if (l.use_bcsr && d > 1) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
-                                                  (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.bc_ptr, l.bc_col,
-                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld, out + (size_t)c0 * ld,
-                                                  ld, l.bc_cap));
-            } else if (l.Ain.lpr == 4) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
-                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
-                                                  out + (size_t)c0 * ld, ld));
-            } else {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
-                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
-                                                  out + (size_t)c0 * ld, ld));
-            }
-        }
-        std::swap(in, out);
-    }
-    if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
-}
-
-template <class T = double>
-void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
-    if (iters <= 0) return;
-    if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps<T>(h, l, d, iters);
-    else if (l.ord.blocked) launch_block_sweeps<T>(h, l, d, iters);
-    else launch_gs_sweeps<T>(h, l, d, iters);
-}
-
-// y = A x (mode 0) or y = b - A x (mode 1)
-template <class T, int LPR>
-void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
-    const int ld = l.n_pad;
-    for (int c0 = 0; c0 < d; c0 += 4) {
-        int dc = std::min(4, d - c0);
-        if (mode == 1) {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
-                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
-        } else {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
-                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
-        }
-    }
-}
-template <class T>
-void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
-    if (l.Aoff.lpr == 4) launch_spmv_lpr<T, 4>(h, l, d, mode, b, x, y);
-    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y);
-}
-
-// coarse.b = U^T fine.r
-template <class T, int LPR>
-void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
-    for (int c0 = 0; c0 < d; c0 += 4) {
-        int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                          fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
-                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1));
-    }
-}
-template <class T>
-void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
-    if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst);
-    else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst);
-}
-
-// fine.x += U coarse.x   (U has <= 3 entries per row: always one lane per row)
-template <class T>
-void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
-    for (int c0 = 0; c0 < d; c0 += 4) {
-        int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                          fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
-                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1));
-    }
-}
-
-// sums of w r^2 / w b^2 per column -> h_norm[2*d] (after the caller synchronises the stream)
-int launch_norm(gmg_handle h, int d, int type) {
-    Level& l = h->lv[0];
-    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
-    for (int c0 = 0; c0 < d; c0 += 4) {
-        int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
-                                          l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
-                                          l.n_pad, 0, l.Aoff.n_slices, h->d_partials));
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
-    }
-    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
-    return GMG_OK;
-}
-
-double norm_from_sums(const double* s, int d, int type) {
-    if (type == 3) {
-        double t = 0.0;
-        for (int c = 0; c < d; ++c) t += s[2 * c];
-        return std::sqrt(t);
-    }
-    double out = 0.0;
-    for (int c = 0; c < d; ++c) {
-        double v = type == 0 ? std::sqrt(s[2 * c]) / std::sqrt(s[2 * c + 1]) : std::sqrt(s[2 * c] / s[2 * c + 1]);
-        if (c == 0 || v > out) out = v;
-    }
-    return out;
-}
-
-int ensure_vectors(gmg_handle h, int d) {
-    if (d <= h->dcap) return GMG_OK;
-    drop_graphs(h);
-    unbind_level0(h);
-    for (auto& l : h->lv) {
-        for (double** p : {&l.x, &l.b, &l.r, &l.tmp}) {
-            if (*p) { (void)dev_free(*p); *p = nullptr; }
-            if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
-            size_t bytes = sizeof(double) * (size_t)l.n_pad * d;
-            HIPCHK(dev_malloc((void**)p, bytes));
-            HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
-        }
-        for (float** p : {&l.x32, &l.b32, &l.r32, &l.tmp32}) {
-            if (*p) { (void)dev_free(*p); *p = nullptr; }
-            if (!h->cfg.inner_precision) continue;
-            if (p == &l.tmp32 && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
-            size_t bytes = sizeof(float) * (size_t)l.n_pad * d;
-            HIPCHK(dev_malloc((void**)p, bytes));
-            HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
-        }
-    }
-    Level& c = h->lv[h->L];
-    size_t need = (size_t)c.n_pad * d * 2;
-    if (need > h->pinned_cap) {
-        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-        HIPCHK(hipHostMalloc((void**)&h->h_pinned, sizeof(double) * need, hipHostMallocDefault));
-        h->pinned_cap = need;
-    }
-    if (h->h_norm) (void)hipHostFree(h->h_norm);
-    HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, hipHostMallocDefault));
-    if (h->d_norm) (void)dev_free(h->d_norm);
-    HIPCHK(dev_malloc((void**)&h->d_norm, sizeof(double) * 2 * d));
-    h->dcap = d;
-    h->loaded_d = 0;
-    return GMG_OK;
-}
-
-int ensure_stage(gmg_handle h, size_t n_doubles) {
-    if (n_doubles <= h->stage_cap) return GMG_OK;
-    if (h->d_stage) (void)dev_free(h->d_stage);
-    HIPCHK(dev_malloc((void**)&h->d_stage, sizeof(double) * n_doubles));
-    h->stage_cap = n_doubles;
-    return GMG_OK;
-}
-
-// Pinned, double-buffered host staging: the caller's (pageable) vectors are copied in with a few threads and moved by
-// DMA at PCIe speed (a pageable hipMemcpy of 24 MB runs at a fraction of that: 3 vectors cost ~18 ms per solve at 3 M).
-int ensure_host_stage(gmg_handle h, size_t n_doubles) {
-    if (n_doubles <= h->h_stage_cap) return GMG_OK;
-    for (int i = 0; i < 2; ++i) {
-        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
-        h->h_stage[i] = nullptr;
-        HIPCHK(hipHostMalloc((void**)&h->h_stage[i], sizeof(double) * n_doubles, hipHostMallocDefault));
-        if (!h->h_stage_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->h_stage_ev[i], hipEventDisableTiming));
-    }
-    h->h_stage_cap = n_doubles;
-    return GMG_OK;
-}
-
-inline void threaded_copy(double* dst, const double* src, size_t n, int threads) {
-    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, 16)), n / 65536 + 1);
-    if (T <= 1) { std::memcpy(dst, src, sizeof(double) * n); return; }
-    parallel_ranges(T, T, [&](int t0, int t1, int) {
-        for (int t = t0; t < t1; ++t) {
-            size_t lo = n * t / T, hi = n * (t + 1) / T;
-            std::memcpy(dst + lo, src + lo, sizeof(double) * (hi - lo));
-        }
-    }, 1);
-}
-
-// host natural n x d  ->  device numbering (level k) buffer
-int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
-    Level& l = h->lv[k];
-    const size_t cnt = (size_t)l.n * d;
-    int rc = ensure_stage(h, cnt);
-    if (rc) return rc;
-    if ((rc = ensure_host_stage(h, cnt))) return rc;
-    const int f = h->h_stage_flip;
-    h->h_stage_flip ^= 1;
-    HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));          // the previous DMA out of this staging buffer is done
-    threaded_copy(h->h_stage[f], src, cnt, h->cfg.host_threads);
-    HIPCHK(hipMemcpyAsync(h->d_stage, h->h_stage[f], sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipEventRecord(h->h_stage_ev[f], h->stream));
-    hipLaunchKernelGGL(gmgk::permute_in, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.n, l.d_new2old, dst, l.n_pad, l.n_pad, d);
-    // d_stage is reused by the next call: order is guaranteed by the single stream
-    return GMG_OK;
-}
-
-int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
-    Level& l = h->lv[k];
-    const size_t cnt = (size_t)l.n * d;
-    int rc = ensure_stage(h, cnt);
-    if (rc) return rc;
-    if ((rc = ensure_host_stage(h, cnt))) return rc;
-    const int f = h->h_stage_flip;
-    h->h_stage_flip ^= 1;
-    HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));
-    hipLaunchKernelGGL(gmgk::permute_out, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, src, l.n_pad, l.n_pad, l.d_new2old, h->d_stage, l.n, d);
-    HIPCHK(hipMemcpyAsync(h->h_stage[f], h->d_stage, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    threaded_copy(dst, h->h_stage[f], cnt, h->cfg.host_threads);
-    return GMG_OK;
-}
-
-// ---- V-cycle legs --------------------------------------------------------------------------------------
-
-template <class T = double>
-void enqueue_down(gmg_handle h, int d, int k0 = 0) {
-    const int L = h->L;
-    for (int k = k0; k < L; ++k) {
-        Level& l = h->lv[k];
-        if (k > 0) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
-        launch_smooth<T>(h, l, d, h->cfg.pre_iters);                                                 // :1063
-        launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l));                    // :1066
-        launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
-    }
-}
-
-template <class T = double>
-void enqueue_up(gmg_handle h, int d, int k0 = 0) {
-    for (int k = h->L - 1; k >= k0; --k) {
-        Level& l = h->lv[k];
-        launch_prolong_add<T>(h, l, h->lv[k + 1], d, Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l));     // :1082
-        launch_smooth<T>(h, l, d, h->cfg.post_iters);                                                // :1085
-    }
-}
-
-inline void launch_cvt(gmg_handle h, const double* src, float* dst, size_t n) {
-    hipLaunchKernelGGL(gmgk::cvt_f64_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
-}
-inline void launch_cvt(gmg_handle h, const float* src, double* dst, size_t n) {
-    hipLaunchKernelGGL(gmgk::cvt_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
-}
-
-// e = A_L^{-1} rc with the dense inverse (always applied in fp64; the fp32 cycle converts around it)
-template <class T = double>
-void enqueue_coarse_device(gmg_handle h, int d) {
-    Level& c = h->lv[h->L];
-    const size_t cnt = (size_t)c.n_pad * d;
-    if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);
-    for (int c0 = 0; c0 < d; c0 += 4) {
-        int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::dense_symv<D>, dim3((c.n + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock), dim3(gmgk::kBlock), 0,
-                                          h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad));
-    }
-    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
-}
-
-// Host coarsest solve (:1075): D2H rc, LDL^T back-substitution per column (fp64), H2D eps.
-template <class T = double>
-int coarse_host_roundtrip(gmg_handle h, int d) {
-    Level& c = h->lv[h->L];
-    const size_t cnt = (size_t)c.n_pad * d;
-    double* rc = h->h_pinned;
-    double* e = h->h_pinned + cnt;
-    if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
-    HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    auto t0 = clk::now();
-    std::memset(e, 0, sizeof(double) * cnt);
-    if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
-    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
-    h->timing["coarse_host_ms"] += ms_since(t0);
-    HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
-    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
-    return GMG_OK;
-}
-
-// Mixed precision: fp64 residual of the current iterate -> fp32 right-hand side of the inner cycle, plus the norm sums
-// of that same residual (h_norm after the copy + sync).  type < 0: weights of type 0.
-int launch_residual_to_f32(gmg_handle h, int d, int type) {
-    Level& l = h->lv[0];
-    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
-    for (int c0 = 0; c0 < d; c0 += 4) {
-        int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_to_f32_with_norm<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
-                                          l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, 0, l.Aoff.n_slices,
-                                          l.b32 + (size_t)c0 * l.n_pad, h->d_partials));
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
-    }
-    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
-    return GMG_OK;
-}
-
-enum { G_DOWN = 1, G_UP = 2, G_FULL = 3 };
-
-template <class F>
-int run_graph(gmg_handle h, int key, F&& enqueue) {
-    if (!h->cfg.use_graph) { enqueue(); return GMG_OK; }
-    auto it = h->graphs.find(key);
-    if (it == h->graphs.end()) {
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        auto tc = clk::now();
-        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        enqueue();
-        HIPCHK(hipStreamEndCapture(h->stream, &g));
-        h->timing["graph_capture_ms"] += ms_since(tc);
-        tc = clk::now();
-        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-        h->timing["graph_instantiate_ms"] += ms_since(tc);
-        (void)hipGraphDestroy(g);
-        it = h->graphs.emplace(key, ge).first;
-    }
-    HIPCHK(hipGraphLaunch(it->second, h->stream));
-    return GMG_OK;
-}
-
-// One V-cycle on the resident problem; norm_type >= 0 also enqueues the residual check of that type
-// (result in h_norm after the stream is synchronised by the caller).
-template <class T>
-int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
-    int rc;
-    const int nt = norm_type < 0 ? 9 : norm_type;
-    constexpr bool mixed = sizeof(T) == 4;
-    // mixed precision: the fp32 cycle starts from a zero guess on the defect b32 = b - A x (already in place), its
-    // result is added to the fp64 iterate, and the new defect + its norms are formed in one fp64 pass
-    auto head = [&] { if (mixed) (void)hipMemsetAsync(h->lv[0].x32, 0, sizeof(float) * (size_t)h->lv[0].n_pad * d, h->stream); };
-    auto tail = [&](int& err) {
-        if (mixed) {
-            const size_t cnt = (size_t)h->lv[0].n_pad * d;
-            hipLaunchKernelGGL(gmgk::add_correction, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->lv[0].x32, h->lv[0].x, (int64_t)cnt);
-            err = launch_residual_to_f32(h, d, norm_type);
-        } else if (norm_type >= 0) err = launch_norm(h, d, norm_type);
-    };
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
-        int err = GMG_OK;
-        rc = run_graph(h, key_salt + G_FULL * 10000 + d * 10 + nt, [&] {
-            head();
-            enqueue_down<T>(h, d);
-            enqueue_coarse_device<T>(h, d);
-            enqueue_up<T>(h, d);
-            tail(err);
-        });
-        return rc ? rc : err;
-    }
-    if ((rc = run_graph(h, key_salt + G_DOWN * 10000 + d * 10, [&] { head(); enqueue_down<T>(h, d); }))) return rc;
-    if ((rc = coarse_host_roundtrip<T>(h, d))) return rc;
-    int err = GMG_OK;
-    rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
-        enqueue_up<T>(h, d);
-        tail(err);
-    });
-    return rc ? rc : err;
-}
-
-int vcycle_resident(gmg_handle h, int d, int norm_type) {
-    if (h->cfg.inner_precision) return vcycle_legs<float>(h, d, norm_type, 100000);
-    return vcycle_legs<double>(h, d, norm_type, 0);
-}
-
-int check_level(gmg_handle h, int k, bool allow_coarsest) {
-    if (!h->system_ready) return fail(h, GMG_ERR_STATE, "no system set (call gmg_set_system first)");
-    if (k < 0 || k > h->L || (!allow_coarsest && k == h->L)) return fail(h, GMG_ERR_INVALID, "level index out of range");
-    return GMG_OK;
-}
-
-int check_norm_type(gmg_handle h, int type) {
-    if (type < 0 || type > 3) return fail(h, GMG_ERR_INVALID, "residual norm type must be 0..3");
-    if ((type == 1 || type == 2) && !h->d_mass) return fail(h, GMG_ERR_STATE, "mass matrix not set (gmg_set_mass) but an M-weighted norm was requested");
-    return GMG_OK;
-}
-
-}  // namespace
+#include "engine_state.hip.hpp"
+#include "engine_setup.hip.hpp"
+#include "engine_cycle.hip.hpp"
 
 // =========================================================================================================
 extern "C" {

@@ -1,0 +1,465 @@
+// engine_cycle.hip.hpp -- part of libgravomg_hip.so's single translation unit (included by engine.hip, in this order:
+// engine_state, engine_setup, engine_cycle).  Kernel launch helpers and the V-cycle legs.
+#pragma once
+
+namespace {
+
+// ---- launch helpers (all on h->stream; column chunks of <= 4) ----------------------------------------
+
+#define DISPATCH_D(dc, ...)              \
+    switch (dc) {                        \
+        case 1: { constexpr int D = 1; __VA_ARGS__; } break; \
+        case 2: { constexpr int D = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int D = 3; __VA_ARGS__; } break; \
+        default: { constexpr int D = 4; __VA_ARGS__; } break; \
+    }
+
+// Precision selector: the fp64 arrays, or their fp32 twins (same layout, same index arrays).
+template <class T> struct Prec;
+template <> struct Prec<double> {
+    static const double* val(const DevSell& s) { return s.val; }
+    static const double* diag(const Level& l) { return l.diag; }
+    static const double* bcval(const Level& l) { return l.bc_val; }
+    static double* x(Level& l) { return l.x; }
+    static double* b(Level& l) { return l.b; }
+    static double* r(Level& l) { return l.r; }
+    static double* tmp(Level& l) { return l.tmp; }
+};
+template <> struct Prec<float> {
+    static const float* val(const DevSell& s) { return s.val32; }
+    static const float* diag(const Level& l) { return l.diag32; }
+    static const float* bcval(const Level& l) { return l.bc_val32; }
+    static float* x(Level& l) { return l.x32; }
+    static float* b(Level& l) { return l.b32; }
+    static float* r(Level& l) { return l.r32; }
+    static float* tmp(Level& l) { return l.tmp32; }
+};
+
+template <class T>
+void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const int ld = l.n_pad;
+    const bool fine = &l == &h->lv[0];
+    T* x = Prec<T>::x(l);
+    const T* b = Prec<T>::b(l);
+    for (int it = 0; it < iters; ++it)
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            for (int c = 0; c < l.ord.n_colors; ++c) {
+                int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
+                if (se <= sb) continue;
+                if (fine) {
+                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
+                } else {
+                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
+                }
+            }
+        }
+}
+
+template <class T>
+void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const int ld = l.n_pad;
+    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
+    const T* b = Prec<T>::b(l);
+    for (int it = 0; it < iters; ++it) {
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::jacobi_sweep<T, D>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                              in + (size_t)c0 * ld, out + (size_t)c0 * ld, ld, l.Aoff.n_slices, (T)h->cfg.jacobi_omega, 1));
+        }
+        std::swap(in, out);
+    }
+    if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+}
+
+// block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
+template <class T>
+void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const int ld = l.n_pad;
+    const int nb = l.ord.n_blocks();
+    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
+    const T* b = Prec<T>::b(l);
+    for (int it = 0; it < iters; ++it) {
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            if (l.use_bcsr && d > 1) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
+                                                  (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.bc_ptr, l.bc_col,
+                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld, out + (size_t)c0 * ld,
+                                                  ld, l.bc_cap));
+            } else if (l.Ain.lpr == 4) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
+                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                                  out + (size_t)c0 * ld, ld));
+            } else {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
+                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
+                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                                  out + (size_t)c0 * ld, ld));
+            }
+        }
+        std::swap(in, out);
+    }
+    if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+}
+
+template <class T = double>
+void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
+    if (iters <= 0) return;
+    if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps<T>(h, l, d, iters);
+    else if (l.ord.blocked) launch_block_sweeps<T>(h, l, d, iters);
+    else launch_gs_sweeps<T>(h, l, d, iters);
+}
+
+// y = A x (mode 0) or y = b - A x (mode 1)
+template <class T, int LPR>
+void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
+    const int ld = l.n_pad;
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        if (mode == 1) {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
+                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
+        } else {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                              l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
+                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
+        }
+    }
+}
+template <class T>
+void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
+    if (l.Aoff.lpr == 4) launch_spmv_lpr<T, 4>(h, l, d, mode, b, x, y);
+    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y);
+}
+
+// coarse.b = U^T fine.r
+template <class T, int LPR>
+void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                          fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
+                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1));
+    }
+}
+template <class T>
+void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+    if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst);
+    else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst);
+}
+
+// fine.x += U coarse.x   (U has <= 3 entries per row: always one lane per row)
+template <class T>
+void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                          fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
+                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1));
+    }
+}
+
+// sums of w r^2 / w b^2 per column -> h_norm[2*d] (after the caller synchronises the stream)
+int launch_norm(gmg_handle h, int d, int type) {
+    Level& l = h->lv[0];
+    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
+    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+                                          l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
+                                          l.n_pad, 0, l.Aoff.n_slices, h->d_partials));
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
+    }
+    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
+    return GMG_OK;
+}
+
+double norm_from_sums(const double* s, int d, int type) {
+    if (type == 3) {
+        double t = 0.0;
+        for (int c = 0; c < d; ++c) t += s[2 * c];
+        return std::sqrt(t);
+    }
+    double out = 0.0;
+    for (int c = 0; c < d; ++c) {
+        double v = type == 0 ? std::sqrt(s[2 * c]) / std::sqrt(s[2 * c + 1]) : std::sqrt(s[2 * c] / s[2 * c + 1]);
+        if (c == 0 || v > out) out = v;
+    }
+    return out;
+}
+
+int ensure_vectors(gmg_handle h, int d) {
+    if (d <= h->dcap) return GMG_OK;
+    drop_graphs(h);
+    unbind_level0(h);
+    for (auto& l : h->lv) {
+        for (double** p : {&l.x, &l.b, &l.r, &l.tmp}) {
+            if (*p) { (void)dev_free(*p); *p = nullptr; }
+            if (p == &l.tmp && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
+            size_t bytes = sizeof(double) * (size_t)l.n_pad * d;
+            HIPCHK(dev_malloc((void**)p, bytes));
+            HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
+        }
+        for (float** p : {&l.x32, &l.b32, &l.r32, &l.tmp32}) {
+            if (*p) { (void)dev_free(*p); *p = nullptr; }
+            if (!h->cfg.inner_precision) continue;
+            if (p == &l.tmp32 && h->cfg.smoother != GMG_SMOOTHER_JACOBI && !l.ord.blocked) continue;
+            size_t bytes = sizeof(float) * (size_t)l.n_pad * d;
+            HIPCHK(dev_malloc((void**)p, bytes));
+            HIPCHK(hipMemsetAsync(*p, 0, bytes, h->stream));
+        }
+    }
+    Level& c = h->lv[h->L];
+    size_t need = (size_t)c.n_pad * d * 2;
+    if (need > h->pinned_cap) {
+        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+        HIPCHK(hipHostMalloc((void**)&h->h_pinned, sizeof(double) * need, hipHostMallocDefault));
+        h->pinned_cap = need;
+    }
+    if (h->h_norm) (void)hipHostFree(h->h_norm);
+    HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, hipHostMallocDefault));
+    if (h->d_norm) (void)dev_free(h->d_norm);
+    HIPCHK(dev_malloc((void**)&h->d_norm, sizeof(double) * 2 * d));
+    h->dcap = d;
+    h->loaded_d = 0;
+    return GMG_OK;
+}
+
+int ensure_stage(gmg_handle h, size_t n_doubles) {
+    if (n_doubles <= h->stage_cap) return GMG_OK;
+    if (h->d_stage) (void)dev_free(h->d_stage);
+    HIPCHK(dev_malloc((void**)&h->d_stage, sizeof(double) * n_doubles));
+    h->stage_cap = n_doubles;
+    return GMG_OK;
+}
+
+// Pinned, double-buffered host staging: the caller's (pageable) vectors are copied in with a few threads and moved by
+// DMA at PCIe speed (a pageable hipMemcpy of 24 MB runs at a fraction of that: 3 vectors cost ~18 ms per solve at 3 M).
+int ensure_host_stage(gmg_handle h, size_t n_doubles) {
+    if (n_doubles <= h->h_stage_cap) return GMG_OK;
+    for (int i = 0; i < 2; ++i) {
+        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        h->h_stage[i] = nullptr;
+        HIPCHK(hipHostMalloc((void**)&h->h_stage[i], sizeof(double) * n_doubles, hipHostMallocDefault));
+        if (!h->h_stage_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->h_stage_ev[i], hipEventDisableTiming));
+    }
+    h->h_stage_cap = n_doubles;
+    return GMG_OK;
+}
+
+inline void threaded_copy(double* dst, const double* src, size_t n, int threads) {
+    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, 16)), n / 65536 + 1);
+    if (T <= 1) { std::memcpy(dst, src, sizeof(double) * n); return; }
+    parallel_ranges(T, T, [&](int t0, int t1, int) {
+        for (int t = t0; t < t1; ++t) {
+            size_t lo = n * t / T, hi = n * (t + 1) / T;
+            std::memcpy(dst + lo, src + lo, sizeof(double) * (hi - lo));
+        }
+    }, 1);
+}
+
+// host natural n x d  ->  device numbering (level k) buffer
+int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
+    Level& l = h->lv[k];
+    const size_t cnt = (size_t)l.n * d;
+    int rc = ensure_stage(h, cnt);
+    if (rc) return rc;
+    if ((rc = ensure_host_stage(h, cnt))) return rc;
+    const int f = h->h_stage_flip;
+    h->h_stage_flip ^= 1;
+    HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));          // the previous DMA out of this staging buffer is done
+    threaded_copy(h->h_stage[f], src, cnt, h->cfg.host_threads);
+    HIPCHK(hipMemcpyAsync(h->d_stage, h->h_stage[f], sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->h_stage_ev[f], h->stream));
+    hipLaunchKernelGGL(gmgk::permute_in, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.n, l.d_new2old, dst, l.n_pad, l.n_pad, d);
+    // d_stage is reused by the next call: order is guaranteed by the single stream
+    return GMG_OK;
+}
+
+int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
+    Level& l = h->lv[k];
+    const size_t cnt = (size_t)l.n * d;
+    int rc = ensure_stage(h, cnt);
+    if (rc) return rc;
+    if ((rc = ensure_host_stage(h, cnt))) return rc;
+    const int f = h->h_stage_flip;
+    h->h_stage_flip ^= 1;
+    HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));
+    hipLaunchKernelGGL(gmgk::permute_out, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, src, l.n_pad, l.n_pad, l.d_new2old, h->d_stage, l.n, d);
+    HIPCHK(hipMemcpyAsync(h->h_stage[f], h->d_stage, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    threaded_copy(dst, h->h_stage[f], cnt, h->cfg.host_threads);
+    return GMG_OK;
+}
+
+// ---- V-cycle legs --------------------------------------------------------------------------------------
+
+template <class T = double>
+void enqueue_down(gmg_handle h, int d, int k0 = 0) {
+    const int L = h->L;
+    for (int k = k0; k < L; ++k) {
+        Level& l = h->lv[k];
+        if (k > 0) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
+        launch_smooth<T>(h, l, d, h->cfg.pre_iters);                                                 // :1063
+        launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l));                    // :1066
+        launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
+    }
+}
+
+template <class T = double>
+void enqueue_up(gmg_handle h, int d, int k0 = 0) {
+    for (int k = h->L - 1; k >= k0; --k) {
+        Level& l = h->lv[k];
+        launch_prolong_add<T>(h, l, h->lv[k + 1], d, Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l));     // :1082
+        launch_smooth<T>(h, l, d, h->cfg.post_iters);                                                // :1085
+    }
+}
+
+inline void launch_cvt(gmg_handle h, const double* src, float* dst, size_t n) {
+    hipLaunchKernelGGL(gmgk::cvt_f64_to_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
+}
+inline void launch_cvt(gmg_handle h, const float* src, double* dst, size_t n) {
+    hipLaunchKernelGGL(gmgk::cvt_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
+}
+
+// e = A_L^{-1} rc with the dense inverse (always applied in fp64; the fp32 cycle converts around it)
+template <class T = double>
+void enqueue_coarse_device(gmg_handle h, int d) {
+    Level& c = h->lv[h->L];
+    const size_t cnt = (size_t)c.n_pad * d;
+    if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::dense_symv<D>, dim3((c.n + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock), dim3(gmgk::kBlock), 0,
+                                          h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad));
+    }
+    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
+}
+
+// Host coarsest solve (:1075): D2H rc, LDL^T back-substitution per column (fp64), H2D eps.
+template <class T = double>
+int coarse_host_roundtrip(gmg_handle h, int d) {
+    Level& c = h->lv[h->L];
+    const size_t cnt = (size_t)c.n_pad * d;
+    double* rc = h->h_pinned;
+    double* e = h->h_pinned + cnt;
+    if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
+    HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    auto t0 = clk::now();
+    std::memset(e, 0, sizeof(double) * cnt);
+    if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
+    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
+    h->timing["coarse_host_ms"] += ms_since(t0);
+    HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
+    return GMG_OK;
+}
+
+// Mixed precision: fp64 residual of the current iterate -> fp32 right-hand side of the inner cycle, plus the norm sums
+// of that same residual (h_norm after the copy + sync).  type < 0: weights of type 0.
+int launch_residual_to_f32(gmg_handle h, int d, int type) {
+    Level& l = h->lv[0];
+    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
+    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_to_f32_with_norm<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
+                                          l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, 0, l.Aoff.n_slices,
+                                          l.b32 + (size_t)c0 * l.n_pad, h->d_partials));
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
+    }
+    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
+    return GMG_OK;
+}
+
+enum { G_DOWN = 1, G_UP = 2, G_FULL = 3 };
+
+template <class F>
+int run_graph(gmg_handle h, int key, F&& enqueue) {
+    if (!h->cfg.use_graph) { enqueue(); return GMG_OK; }
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        auto tc = clk::now();
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        enqueue();
+        HIPCHK(hipStreamEndCapture(h->stream, &g));
+        h->timing["graph_capture_ms"] += ms_since(tc);
+        tc = clk::now();
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        h->timing["graph_instantiate_ms"] += ms_since(tc);
+        (void)hipGraphDestroy(g);
+        it = h->graphs.emplace(key, ge).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, h->stream));
+    return GMG_OK;
+}
+
+// One V-cycle on the resident problem; norm_type >= 0 also enqueues the residual check of that type
+// (result in h_norm after the stream is synchronised by the caller).
+template <class T>
+int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
+    int rc;
+    const int nt = norm_type < 0 ? 9 : norm_type;
+    constexpr bool mixed = sizeof(T) == 4;
+    // mixed precision: the fp32 cycle starts from a zero guess on the defect b32 = b - A x (already in place), its
+    // result is added to the fp64 iterate, and the new defect + its norms are formed in one fp64 pass
+    auto head = [&] { if (mixed) (void)hipMemsetAsync(h->lv[0].x32, 0, sizeof(float) * (size_t)h->lv[0].n_pad * d, h->stream); };
+    auto tail = [&](int& err) {
+        if (mixed) {
+            const size_t cnt = (size_t)h->lv[0].n_pad * d;
+            hipLaunchKernelGGL(gmgk::add_correction, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->lv[0].x32, h->lv[0].x, (int64_t)cnt);
+            err = launch_residual_to_f32(h, d, norm_type);
+        } else if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+    };
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
+        int err = GMG_OK;
+        rc = run_graph(h, key_salt + G_FULL * 10000 + d * 10 + nt, [&] {
+            head();
+            enqueue_down<T>(h, d);
+            enqueue_coarse_device<T>(h, d);
+            enqueue_up<T>(h, d);
+            tail(err);
+        });
+        return rc ? rc : err;
+    }
+    if ((rc = run_graph(h, key_salt + G_DOWN * 10000 + d * 10, [&] { head(); enqueue_down<T>(h, d); }))) return rc;
+    if ((rc = coarse_host_roundtrip<T>(h, d))) return rc;
+    int err = GMG_OK;
+    rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
+        enqueue_up<T>(h, d);
+        tail(err);
+    });
+    return rc ? rc : err;
+}
+
+int vcycle_resident(gmg_handle h, int d, int norm_type) {
+    if (h->cfg.inner_precision) return vcycle_legs<float>(h, d, norm_type, 100000);
+    return vcycle_legs<double>(h, d, norm_type, 0);
+}
+
+int check_level(gmg_handle h, int k, bool allow_coarsest) {
+    if (!h->system_ready) return fail(h, GMG_ERR_STATE, "no system set (call gmg_set_system first)");
+    if (k < 0 || k > h->L || (!allow_coarsest && k == h->L)) return fail(h, GMG_ERR_INVALID, "level index out of range");
+    return GMG_OK;
+}
+
+int check_norm_type(gmg_handle h, int type) {
+    if (type < 0 || type > 3) return fail(h, GMG_ERR_INVALID, "residual norm type must be 0..3");
+    if ((type == 1 || type == 2) && !h->d_mass) return fail(h, GMG_ERR_STATE, "mass matrix not set (gmg_set_mass) but an M-weighted norm was requested");
+    return GMG_OK;
+}
+
+}  // namespace

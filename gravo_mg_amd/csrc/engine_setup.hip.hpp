@@ -1,0 +1,407 @@
+// engine_setup.hip.hpp -- part of libgravomg_hip.so's single translation unit (included by engine.hip, in this order:
+// engine_state, engine_setup, engine_cycle).  Device-side construction of the level data: SELL / block-CSR layouts, Galerkin products, pattern checks.
+#pragma once
+
+namespace {
+
+// ---- device-side layout construction (setup_kernels.hip.hpp) ------------------------------------------------
+int upload_csr(gmg_handle h, DevCsr& d, const Compressed& m) {
+    free_csr(d);
+    d.n_outer = m.n_outer;
+    int rc;
+    if ((rc = upload(h, &d.ptr, m.ptr)) || (rc = upload(h, &d.idx, m.idx)) || (rc = upload(h, &d.val, m.val))) return rc;
+    return GMG_OK;
+}
+
+int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const int* idx, const double* val) {
+    free_csr(d);
+    d.n_outer = n_outer;
+    const size_t nnz = (size_t)ptr[n_outer];
+    HIPCHK(dev_malloc((void**)&d.ptr, sizeof(int) * ((size_t)n_outer + 1)));
+    HIPCHK(dev_malloc((void**)&d.idx, sizeof(int) * std::max<size_t>(nnz, 1)));
+    HIPCHK(dev_malloc((void**)&d.val, sizeof(double) * std::max<size_t>(nnz, 1)));
+    HIPCHK(hipMemcpyAsync(d.ptr, ptr, sizeof(int) * ((size_t)n_outer + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d.idx, idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(d.val, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
+template <class T>
+struct DevTmp {                       // scratch device array released at scope exit (stream-ordered reuse through the pool)
+    T* p = nullptr;
+    ~DevTmp() { if (p) (void)dev_free(p); }
+    int alloc(gmg_handle h, size_t n) { HIPCHK(dev_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T))); return GMG_OK; }
+};
+
+// out[0..n] = exclusive prefix sums of in[0..n) on the stream; *total_host (pinned or pageable) receives out[n] after
+// the caller synchronises.
+template <class TIn, class TOut>
+int device_scan(gmg_handle h, const TIn* in, int n, TOut* out, TOut* total_host) {
+    const int tiles = std::max(1, (n + gmgs::kScanTile - 1) / gmgs::kScanTile);
+    DevTmp<TOut> tile;
+    int rc;
+    if ((rc = tile.alloc(h, (size_t)tiles + 1))) return rc;
+    hipLaunchKernelGGL((gmgs::scan_tile_sums<TIn, TOut>), dim3(tiles), dim3(256), 0, h->stream, in, n, tile.p);
+    hipLaunchKernelGGL((gmgs::scan_tile_offsets<TOut>), dim3(1), dim3(1024), 0, h->stream, tile.p, tiles, tile.p + tiles);
+    hipLaunchKernelGGL((gmgs::scan_tile_apply<TIn, TOut>), dim3(tiles), dim3(256), 0, h->stream, in, n, (const TOut*)tile.p, out);
+    if (total_host) HIPCHK(hipMemcpyAsync(total_host, tile.p + tiles, sizeof(TOut), hipMemcpyDeviceToHost, h->stream));
+    return GMG_OK;
+}
+
+// Builds one SELL matrix on the device.  pbeg/pend/idx/val: source rows (natural numbering); f: row/column maps and
+// filter; d_order: optional slice-position -> device-row map (uploaded by the caller; also stored as row_of);
+// col16: write 16-bit columns into *col16_out (in-block part of a blocked level) instead of out.col.
+int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pend, const int* idx, const double* val, gmgs::RowFilter f,
+                      const int* d_order, int n_rows_pad, int lpr, unsigned short** col16_out, double* d_diag, int* d_err) {
+    free_sell(out);
+    const int rps = 64 / lpr;
+    out.lpr = lpr;
+    out.n_slices = n_rows_pad / rps;
+    DevTmp<int> len;
+    DevTmp<int64_t> widths;
+    int rc;
+    if ((rc = len.alloc(h, n_rows_pad)) || (rc = widths.alloc(h, out.n_slices))) return rc;
+    HIPCHK(dev_malloc((void**)&out.slice_ptr, sizeof(int64_t) * ((size_t)out.n_slices + 1)));
+    hipLaunchKernelGGL(gmgs::row_lengths, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, f, d_order, n_rows_pad, len.p, d_err);
+    hipLaunchKernelGGL(gmgs::slice_widths, dim3((out.n_slices + 255) / 256), dim3(256), 0, h->stream, len.p, lpr, out.n_slices, widths.p);
+    int64_t total = 0;
+    if ((rc = device_scan<int64_t, int64_t>(h, widths.p, out.n_slices, out.slice_ptr, &total))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out.stored = total;
+    HIPCHK(dev_malloc((void**)&out.val, std::max<int64_t>(out.stored, 1) * sizeof(double)));
+    if (col16_out) {
+        if (*col16_out) { (void)dev_free(*col16_out); *col16_out = nullptr; }
+        HIPCHK(dev_malloc((void**)col16_out, std::max<int64_t>(out.stored, 1) * sizeof(unsigned short)));
+        hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
+                           n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
+    } else {
+        HIPCHK(dev_malloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
+        hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
+                           out.slice_ptr, out.col, out.val, d_diag, d_err);
+    }
+    return GMG_OK;
+}
+
+int build_ell3(gmg_handle h, DevEll3& e, const DevCsr& dU, int n_fine, int* d_err) {
+    free_ell3(e);
+    e.n = n_fine;
+    HIPCHK(dev_malloc((void**)&e.cnt, sizeof(int) * std::max(n_fine, 1)));
+    HIPCHK(dev_malloc((void**)&e.col, sizeof(int) * (size_t)std::max(n_fine, 1) * 3));
+    HIPCHK(dev_malloc((void**)&e.val, sizeof(double) * (size_t)std::max(n_fine, 1) * 3));
+    HIPCHK(hipMemsetAsync(e.cnt, 0, sizeof(int) * n_fine, h->stream));
+    hipLaunchKernelGGL(gmgs::ell3_from_csc, dim3((dU.n_outer + 255) / 256), dim3(256), 0, h->stream, dU.ptr, dU.idx, dU.val, dU.n_outer, e.cnt, e.col, e.val, d_err);
+    hipLaunchKernelGGL(gmgs::ell3_sort, dim3((n_fine + 255) / 256), dim3(256), 0, h->stream, e.cnt, n_fine, e.col, e.val);
+    return GMG_OK;
+}
+
+// Device copies of every U_k (by coarse column, and regrouped by fine row): built once per hierarchy.
+int ensure_device_transfers(gmg_handle h) {
+    if (h->dU_ready) return GMG_OK;
+    const int L = h->L;
+    drop_device_transfers(h);
+    h->dU.assign(L, DevCsr());
+    h->dE3.assign(L, DevEll3());
+    DevTmp<int> d_err;
+    int rc, herr = 0;
+    if ((rc = d_err.alloc(h, 1))) return rc;
+    HIPCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream));
+    for (int k = 0; k < L; ++k) {
+        rc = upload_csr(h, h->dU[k], h->U[k]);
+        if (rc == GMG_OK) rc = build_ell3(h, h->dE3[k], h->dU[k], h->U[k].n_inner, d_err.p);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));      // pageable host arrays have been consumed
+    h->dU_flagged = herr != 0;      // a U row with more than 3 entries: the device RAP / layout builder cannot take it
+    h->dU_ready = true;
+    return GMG_OK;
+}
+
+// LHS pattern in the hierarchy's cluster order (h->cluster_order), made on the device from the uploaded LHS and copied
+// to h->reo_ptr / h->reo_idx: the level-0 colouring then walks a locally ordered graph instead of chasing pointers
+// through a randomly numbered one (3 M vertices in random order: 450 ms -> 20 ms).
+int device_permute_pattern(gmg_handle h, const DevCsr& dA, int n, int64_t nnz) {
+    int rc;
+    if (!h->d_cluster_order) {
+        std::vector<int> inv(n);
+        const std::vector<int>& ord = h->cluster_order;
+        parallel_ranges(n, std::min(h->cfg.host_threads, 32), [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) inv[ord[r]] = r; });
+        if ((rc = upload(h, &h->d_cluster_order, ord)) || (rc = upload(h, &h->d_cluster_inv, inv))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    DevTmp<int> len, pptr, pidx;
+    if ((rc = len.alloc(h, n)) || (rc = pptr.alloc(h, (size_t)n + 1)) || (rc = pidx.alloc(h, (size_t)nnz))) return rc;
+    hipLaunchKernelGGL(gmgs::perm_row_lengths, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, h->d_cluster_order, n, len.p);
+    if ((rc = device_scan<int, int>(h, len.p, n, pptr.p, nullptr))) return rc;
+    hipLaunchKernelGGL(gmgs::perm_fill, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.idx, h->d_cluster_order, h->d_cluster_inv, pptr.p, n, pidx.p);
+    h->reo_ptr.resize((size_t)n + 1);
+    h->reo_idx.resize((size_t)nnz);
+    HIPCHK(hipMemcpyAsync(h->reo_ptr.data(), pptr.p, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->reo_idx.data(), pidx.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+// Host copy of A_k (natural numbering), on demand: the device keeps the master copy (Level::dA).
+int ensure_host_A(gmg_handle h, int k, bool values) {
+    Level& l = h->lv[k];
+    if (l.hostA_pattern && (l.hostA_values || !values)) return GMG_OK;
+    if (!l.dA.ptr) return fail(h, GMG_ERR_STATE, "level operator is neither on the host nor on the device");
+    const int n = l.dA.n_outer;
+    l.A.n_outer = n; l.A.n_inner = n;
+    if (!l.hostA_pattern) {
+        l.A.ptr.resize((size_t)n + 1);
+        HIPCHK(hipMemcpyAsync(l.A.ptr.data(), l.dA.ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        l.A.idx.resize((size_t)l.A.ptr[n]);
+        HIPCHK(hipMemcpyAsync(l.A.idx.data(), l.dA.idx, sizeof(int) * l.A.idx.size(), hipMemcpyDeviceToHost, h->stream));
+    }
+    if (values && !l.hostA_values) {
+        l.A.val.resize((size_t)l.nnz);
+        HIPCHK(hipMemcpyAsync(l.A.val.data(), l.dA.val, sizeof(double) * l.A.val.size(), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    l.hostA_pattern = true;
+    l.hostA_values = l.hostA_values || values;
+    return GMG_OK;
+}
+
+// Ac = U^T A U on the device (setup_kernels.hip.hpp::rap_rows): count pass, device prefix sum, fill pass.  The result
+// stays on the device (dC); `pattern` (row pointers + column indices, for the host ordering of that level) and
+// `values` say what is copied to the host as well.  Returns 1 when the device kernel cannot take the input.
+int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& e3, DevCsr& dC, Compressed& C, bool pattern, bool values,
+               int64_t* nnz_out, int* d_err) {
+    const int nc = dU.n_outer;
+    free_csr(dC);
+    dC.n_outer = nc;
+    DevTmp<int> cnt;
+    int rc;
+    if ((rc = cnt.alloc(h, nc))) return rc;
+    HIPCHK(dev_malloc((void**)&dC.ptr, sizeof(int) * ((size_t)nc + 1)));
+    hipLaunchKernelGGL(gmgs::rap_rows<0>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
+                       (const int*)nullptr, cnt.p, (int*)nullptr, (double*)nullptr, d_err);
+    int nnz = 0, herr = 0;
+    if ((rc = device_scan<int, int>(h, cnt.p, nc, dC.ptr, &nnz))) return rc;
+    HIPCHK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    C.n_outer = nc; C.n_inner = nc;
+    if (pattern || values) {
+        C.ptr.resize((size_t)nc + 1);
+        HIPCHK(hipMemcpyAsync(C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (herr) { free_csr(dC); return 1; }       // a coarse row overflows the device hash set (or a U row has > 3 entries): host fallback
+    *nnz_out = nnz;
+    HIPCHK(dev_malloc((void**)&dC.idx, sizeof(int) * std::max(nnz, 1)));
+    HIPCHK(dev_malloc((void**)&dC.val, sizeof(double) * std::max(nnz, 1)));
+    hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
+                       (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
+    if (pattern || values) { C.idx.resize(nnz); HIPCHK(hipMemcpyAsync(C.idx.data(), dC.idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, h->stream)); }
+    if (values) { C.val.resize(nnz); HIPCHK(hipMemcpyAsync(C.val.data(), dC.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, h->stream)); }
+    if (pattern || values) HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+// Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device from Level::dA and the
+// device copies of U_k.  A row longer than gmgs::kMaxRow or a prolongation row with more than 3 entries raises *d_err:
+// the caller then falls back to the host planner.
+int device_layout_level(gmg_handle h, int k, int* d_err) {
+    const int L = h->L;
+    Level& l = h->lv[k];
+    int rc;
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;      // synchronising phase timers on stderr
+    auto tph = clk::now();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(h->stream);
+        std::fprintf(stderr, "[gmg setup] level %d %-10s %.2f ms\n", k, what, ms_since(tph));
+        tph = clk::now();
+    };
+    DevTmp<int> d_old2new, d_blk_of_row;
+    if (!l.dA.ptr) {
+        if ((rc = ensure_host_A(h, k, true)) || (rc = upload_csr(h, l.dA, l.A))) return rc;
+    }
+    const DevCsr& dA = l.dA;
+    if ((rc = upload(h, &d_old2new.p, l.ord.old2new))) return rc;
+    phase("old2new");
+    gmgs::RowFilter f{l.d_new2old, d_old2new.p, nullptr, nullptr, 0, 1};
+    const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
+    const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
+    HIPCHK(dev_malloc((void**)&l.diag, sizeof(double) * l.n_pad));
+    if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) return rc;
+    l.Aoff.nnz_real = l.nnz - l.n;
+    phase("A");
+    if (l.ord.blocked) {
+        if ((rc = d_blk_of_row.alloc(h, l.n_pad)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
+            (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
+        hipLaunchKernelGGL(gmgs::block_of_rows, dim3(std::max(1, l.ord.n_blocks())), dim3(64), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), d_blk_of_row.p);
+        gmgs::RowFilter fin{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
+        gmgs::RowFilter fout{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
+        if (wants_block_csr(h, lpr)) {
+            // off-block operator as a block-ordered CSR; its row pointers first: they tell whether the largest block's
+            // chunk fits the sweep's LDS budget
+            DevTmp<int> len, d_max;
+            int nnz = 0, bmax = 0;
+            if ((rc = len.alloc(h, l.n_pad)) || (rc = d_max.alloc(h, 1))) return rc;
+            HIPCHK(dev_malloc((void**)&l.bc_ptr, sizeof(int) * ((size_t)l.n_pad + 1)));
+            HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(int), h->stream));
+            hipLaunchKernelGGL(gmgs::row_lengths, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, fout, (const int*)nullptr, l.n_pad, len.p, d_err);
+            if ((rc = device_scan<int, int>(h, len.p, l.n_pad, l.bc_ptr, &nnz))) return rc;
+            hipLaunchKernelGGL(gmgs::block_entry_max, dim3((l.ord.n_blocks() + 255) / 256), dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.bc_ptr, d_max.p);
+            HIPCHK(hipMemcpyAsync(&bmax, d_max.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (bmax <= kBcsrMaxBlockEntries) {
+                l.use_bcsr = true;
+                l.bc_cap = (bmax + 63) / 64 * 64;
+                l.bc_nnz = nnz;
+                HIPCHK(dev_malloc((void**)&l.bc_mid, sizeof(int) * (size_t)l.n_pad));
+                HIPCHK(dev_malloc((void**)&l.bc_col, sizeof(int) * (size_t)std::max(nnz, 1)));
+                HIPCHK(dev_malloc((void**)&l.bc_val, sizeof(double) * (size_t)std::max(nnz, 1)));
+                hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, d_blk_of_row.p,
+                                   l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
+            } else { (void)dev_free(l.bc_ptr); l.bc_ptr = nullptr; }
+        }
+        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err))) return rc;
+        // the padded SELL form of the off-block operator is kept as well: with one right-hand side the sweep that
+        // streams it straight into registers is the faster one (42 vs 47 us on the 506 k-row level; 104 vs 60 us at d = 3)
+        if ((rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) return rc;
+    }
+    phase("A split");
+    if (k == L) return GMG_OK;
+    // ---- transfers k <-> k+1
+    Level& c = h->lv[k + 1];
+    const DevCsr& dU = h->dU[k];
+    const DevEll3& e3 = h->dE3[k];
+    DevTmp<int> d_old2new_c, d_order, d_pbeg, d_pend;
+    if ((rc = upload(h, &d_old2new_c.p, c.ord.old2new))) return rc;
+    // restriction: rows = coarse points (columns of the CSC U), sorted by length inside windows like the host planner
+    {
+        const Compressed& U = h->U[k];
+        const int np = c.n_pad, sigma = h->cfg.sigma;
+        if (sigma > 0 && sigma <= gmgs::kWindowSortMax) {
+            int pow2 = 1;
+            while (pow2 < sigma) pow2 <<= 1;
+            if ((rc = d_order.alloc(h, np))) return rc;
+            hipLaunchKernelGGL(gmgs::window_order_by_length, dim3((np + sigma - 1) / sigma), dim3(256), 0, h->stream, dU.ptr, c.d_new2old, np, sigma, pow2, d_order.p);
+        } else if (sigma > 0) {
+            std::vector<int> order(np);
+            auto len_of = [&](int r) { int old = c.ord.new2old[r]; return old >= 0 ? U.ptr[old + 1] - U.ptr[old] : 0; };
+            const int nwin = (np + sigma - 1) / sigma;
+            for (int wi = 0; wi < nwin; ++wi) {
+                int w = wi * sigma, we = std::min(np, w + sigma);
+                std::iota(order.begin() + w, order.begin() + we, w);
+                std::stable_sort(order.begin() + w, order.begin() + we, [&](int a, int b) { return len_of(a) > len_of(b); });
+            }
+            if ((rc = upload(h, &d_order.p, order))) return rc;
+            HIPCHK(hipStreamSynchronize(h->stream));      // `order` (pageable) dies at scope end
+        }
+        phase("R order");
+        gmgs::RowFilter fr{c.d_new2old, d_old2new.p, nullptr, nullptr, 0, 0};
+        const int lpr_r = h->cfg.block_lanes == 1 ? 1 : 4;
+        if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) return rc;
+        l.R.nnz_real = U.nnz();
+        if (sigma > 0) { l.R.row_of = d_order.p; d_order.p = nullptr; }     // the order array becomes the output-row map
+        phase("R");
+    }
+    // prolongation: rows = fine points; U is stored by coarse column, so it was regrouped by fine row (<= 3 per row)
+    {
+        const int nf = l.n;
+        if ((rc = d_pbeg.alloc(h, nf)) || (rc = d_pend.alloc(h, nf))) return rc;
+        hipLaunchKernelGGL(gmgs::ell3_ptr, dim3((nf + 255) / 256), dim3(256), 0, h->stream, e3.cnt, nf, d_pbeg.p, d_pend.p);
+        gmgs::RowFilter fp{l.d_new2old, d_old2new_c.p, nullptr, nullptr, 0, 0};
+        if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) return rc;
+        l.P.nnz_real = h->U[k].nnz();
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
+    phase("P");
+    return GMG_OK;
+}
+
+// One threaded pass over a compressed pattern: 0 = canonical (indices in range, strictly ascending inside each outer
+// vector), 1 = in range but unsorted or with duplicates, 2 = an index out of range / a non-monotone pointer array.
+int inspect_pattern(int n_outer, int n_inner, const int* ptr, const int* idx, int threads) {
+    if (ptr[0] != 0) return 2;
+    std::vector<int> worst(std::max(threads, 1) + 1, 0);
+    parallel_ranges(n_outer, threads, [&](int lo, int hi, int t) {
+        int w = 0;
+        for (int j = lo; j < hi && w < 2; ++j) {
+            if (ptr[j + 1] < ptr[j]) { w = 2; break; }
+            int prev = -1;
+            for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
+                const int i = idx[p];
+                if (i < 0 || i >= n_inner) { w = 2; break; }
+                if (i <= prev) w = 1;
+                prev = i;
+            }
+        }
+        worst[std::min(t, (int)worst.size() - 1)] = w;
+    });
+    int w = 0;
+    for (int v : worst) w = std::max(w, v);
+    return w;
+}
+
+// Sorted, duplicate-free copy of a compressed matrix (duplicates are summed, like Eigen's setFromTriplets / scipy's
+// sum_duplicates): what the engine requires of the LHS, made here when the caller's storage is not canonical.
+Compressed canonical_copy(int n_outer, int n_inner, const int* ptr, const int* idx, const double* val, int threads) {
+    Compressed out;
+    out.n_outer = n_outer; out.n_inner = n_inner;
+    std::vector<int> cnt((size_t)n_outer + 1, 0);
+    std::vector<std::vector<std::pair<int, double>>> cols(n_outer);
+    parallel_ranges(n_outer, threads, [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j) {
+            auto& c = cols[j];
+            c.reserve(ptr[j + 1] - ptr[j]);
+            for (int p = ptr[j]; p < ptr[j + 1]; ++p) c.emplace_back(idx[p], val[p]);
+            std::stable_sort(c.begin(), c.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& b) { return a.first < b.first; });
+            size_t w = 0;
+            for (size_t r = 0; r < c.size(); ++r) {
+                if (w > 0 && c[w - 1].first == c[r].first) c[w - 1].second += c[r].second;
+                else c[w++] = c[r];
+            }
+            c.resize(w);
+            cnt[j + 1] = (int)w;
+        }
+    });
+    for (int j = 0; j < n_outer; ++j) cnt[j + 1] += cnt[j];
+    out.ptr = cnt;
+    out.idx.resize(cnt[n_outer]); out.val.resize(cnt[n_outer]);
+    parallel_ranges(n_outer, threads, [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j) {
+            int q = out.ptr[j];
+            for (auto& e : cols[j]) { out.idx[q] = e.first; out.val[q] = e.second; ++q; }
+        }
+    });
+    return out;
+}
+
+// 2 x 64-bit FNV-1a style digest of the LHS sparsity pattern (threaded; chunk digests combined in order)
+void pattern_key(int n, const int* colptr, const int* rowidx, int threads, uint64_t key[2]) {
+    const int64_t nnz = colptr[n];
+    (void)threads;
+    const int T = 32;       // fixed: the digest depends on the chunking
+    std::vector<uint64_t> part((size_t)T * 2, 0);
+    auto digest = [](const int* p, int64_t cnt, uint64_t seed) {
+        uint64_t h = 1469598103934665603ull ^ seed;
+        for (int64_t i = 0; i < cnt; ++i) { h ^= (uint32_t)p[i]; h *= 1099511628211ull; h ^= h >> 29; }
+        return h;
+    };
+    parallel_ranges(T, T, [&](int t0, int t1, int) {
+        for (int t = t0; t < t1; ++t) {
+            int64_t lo = nnz * t / T, hi = nnz * (t + 1) / T;
+            part[2 * t] = digest(rowidx + lo, hi - lo, 0x9e3779b97f4a7c15ull * (t + 1));
+            int64_t plo = (int64_t)(n + 1) * t / T, phi = (int64_t)(n + 1) * (t + 1) / T;
+            part[2 * t + 1] = digest(colptr + plo, phi - plo, 0xc2b2ae3d27d4eb4full * (t + 1));
+        }
+    }, 1);
+    key[0] = 1469598103934665603ull ^ (uint64_t)n; key[1] = 0x84222325cbf29ce4ull ^ (uint64_t)nnz;
+    for (int t = 0; t < T; ++t) { key[0] = (key[0] ^ part[2 * t]) * 1099511628211ull; key[1] = (key[1] ^ part[2 * t + 1]) * 1099511628211ull; }
+}
+
+constexpr int kNormBlocks = 2048;      // residual-norm partial sums: 8 blocks per CU, grid-stride
+
+inline int grid_for(int n_slices) {
+    int g = (n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock;
+    return (g + 7) / 8 * 8;    // multiple of 8 so the XCD swizzle is a bijection
+}
+
+}  // namespace

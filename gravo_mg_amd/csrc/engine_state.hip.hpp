@@ -1,0 +1,314 @@
+// engine_state.hip.hpp -- part of libgravomg_hip.so's single translation unit (included by engine.hip, in this order:
+// engine_state, engine_setup, engine_cycle).  Device memory pool, level / handle structures, error and upload helpers.
+#pragma once
+
+// ---- device memory pool (per handle) ------------------------------------------------------------------------
+// hipFree costs ~0.2 ms and synchronises the device; a setup allocates and releases ~100 arrays.  Blocks released
+// by a handle are parked in its pool and handed out again (same stream => stream order makes the reuse safe); the
+// pool is emptied when the handle is destroyed or when the parked bytes exceed what is in use.
+struct DevPool {
+    std::multimap<size_t, void*> parked;
+    std::map<void*, size_t> size_of;      // every block this pool handed out (live or parked)
+    size_t parked_bytes = 0, live_bytes = 0;
+    static size_t round_up(size_t b) { return (std::max<size_t>(b, 1) + 511) & ~(size_t)511; }
+    hipError_t alloc(void** p, size_t bytes) {
+        const size_t need = round_up(bytes);
+        auto it = parked.lower_bound(need);
+        if (it != parked.end() && it->first <= need + need / 8 + 65536) {
+            *p = it->second; parked_bytes -= it->first; live_bytes += it->first; parked.erase(it);
+            return hipSuccess;
+        }
+        hipError_t e = hipMalloc(p, need);
+        if (e != hipSuccess) { trim(); (void)hipGetLastError(); e = hipMalloc(p, need); }
+        if (e == hipSuccess) { size_of[*p] = need; live_bytes += need; }
+        return e;
+    }
+    void release(void* p) {
+        auto it = size_of.find(p);
+        if (it == size_of.end()) { (void)hipFree(p); return; }          // not ours (allocated outside a pool scope)
+        parked.emplace(it->second, p); parked_bytes += it->second; live_bytes -= std::min(live_bytes, it->second);
+        if (parked_bytes > std::max<size_t>(live_bytes, (size_t)2 << 30)) trim();
+    }
+    void trim() {
+        for (auto& kv : parked) { (void)hipFree(kv.second); size_of.erase(kv.second); }
+        parked.clear(); parked_bytes = 0;
+    }
+};
+static thread_local DevPool* tl_pool = nullptr;     // set for the duration of a C-ABI call on a handle (PoolScope)
+struct PoolScope {
+    DevPool* prev;
+    explicit PoolScope(DevPool* p) : prev(tl_pool) { tl_pool = p; }
+    ~PoolScope() { tl_pool = prev; }
+};
+static inline hipError_t dev_malloc(void** p, size_t bytes) { return tl_pool ? tl_pool->alloc(p, bytes) : hipMalloc(p, bytes); }
+static inline hipError_t dev_free(void* p) { if (!p) return hipSuccess; if (tl_pool) { tl_pool->release(p); return hipSuccess; } return hipFree(p); }
+
+namespace {
+
+struct DevSell {
+    int n_slices = 0;
+    int lpr = 1;                  // lanes per row of the SELL layout (1 or 4)
+    int64_t stored = 0, nnz_real = 0;
+    int64_t* slice_ptr = nullptr;
+    int* col = nullptr;
+    double* val = nullptr;
+    float* val32 = nullptr;       // fp32 copy of val (mixed-precision inner cycle); shares slice_ptr / col / row_of
+    int* row_of = nullptr;
+};
+
+// natural-numbering compressed matrix on the device (A_k, U_k by coarse column)
+struct DevCsr {
+    int n_outer = 0;
+    int *ptr = nullptr, *idx = nullptr;
+    double* val = nullptr;
+};
+
+// U_k regrouped by fine row (<= 3 entries per row, sorted by coarse column) for the prolongation layout and the RAP.
+struct DevEll3 {
+    int n = 0;
+    int *cnt = nullptr, *col = nullptr;
+    double* val = nullptr;
+};
+
+struct Level {
+    int n = 0, n_pad = 0;
+    int64_t nnz = 0;              // entries of A_k
+    LevelOrdering ord;
+    Compressed A;                 // natural numbering, host copy (Abar[k]); filled on demand (ensure_host_A) except on level L
+    bool hostA_pattern = false, hostA_values = false;
+    DevCsr dA;                    // natural numbering, device copy: RAP input, layout source, source of the lazy host copy
+    DevSell Aoff;                 // off-diagonal part, device numbering
+    double* diag = nullptr;       // n_pad
+    DevSell P, R;                 // U_k (rows: this level) and U_k^T (rows: next level); unused on level L
+    // blocked levels (block-hybrid Gauss-Seidel): in-block part (16-bit local columns) + off-block part
+    DevSell Ain, Aout;
+    unsigned short* ain_col16 = nullptr;
+    // big blocked levels: block-CSR storage instead of the two padded SELL operators (kernels.hip.hpp::gs_blockcsr)
+    bool use_bcsr = false;
+    int *bc_ptr = nullptr, *bc_mid = nullptr, *bc_col = nullptr;
+    double* bc_val = nullptr;
+    float* bc_val32 = nullptr;
+    int bc_cap = 0;               // entries of the largest block, rounded up to 64 (LDS capacity of the sweep)
+    int64_t bc_nnz = 0;
+    int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
+    unsigned char* d_row_color = nullptr;
+    int* d_new2old = nullptr;
+    double *x = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;   // n_pad * dcap
+    float *diag32 = nullptr, *x32 = nullptr, *b32 = nullptr, *r32 = nullptr, *tmp32 = nullptr;   // mixed precision
+};
+
+}  // namespace
+
+struct gmg_hierarchy_s {
+    HierarchyResult res;
+};
+
+struct gmg_solver_s {
+    DevPool pool;
+    gmg_config cfg;
+    std::string err;
+    bool has_device = false;
+    hipStream_t stream = nullptr;
+    int L = -1;
+    std::vector<Compressed> U;
+    std::vector<char> U_set;
+    std::vector<DevCsr> dU;               // device copies of U_k (kept while the hierarchy is unchanged)
+    std::vector<DevEll3> dE3;             // and their by-row regrouping
+    bool dU_ready = false;
+    // patches of the blocked levels k >= 1, grown over the coarse point graph of U_{k-1} (hierarchy data, host only)
+    std::vector<PatchSet> patches;
+    std::vector<int> cluster_order;       // locality-preserving order of the level-0 points derived from U (new -> old)
+    int *d_cluster_order = nullptr, *d_cluster_inv = nullptr;      // device copies (order, and old -> new position)
+    RawVec<int> reo_ptr, reo_idx;         // LHS pattern permuted into cluster order (staging for the level-0 colouring)
+    bool patches_ready = false;
+    bool dU_flagged = false;              // ell3_from_csc found a U row with more than 3 entries (host paths only)
+    std::vector<double> mass;
+    std::vector<Level> lv;
+    SupernodalLDLT coarse;
+    bool system_ready = false;
+    int dcap = 0;
+    double *d_mass = nullptr, *d_minv = nullptr;
+    double* d_stage = nullptr; size_t stage_cap = 0;
+    double* h_stage[2] = {nullptr, nullptr}; size_t h_stage_cap = 0;      // pinned host staging (double-buffered) for b / x
+    hipEvent_t h_stage_ev[2] = {nullptr, nullptr}; int h_stage_flip = 0;
+    double* d_partials = nullptr; int partial_blocks = 0;
+    double* d_norm = nullptr;
+    double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
+    double* h_norm = nullptr;
+    double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
+    std::vector<double> coarse_work;
+    std::map<std::string, double> timing;
+    std::map<int, hipGraphExec_t> graphs;
+    int loaded_d = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // multi-GPU (one process per GPU): this rank's share of level 0, externally owned level-0 vectors
+    hipStream_t own_stream = nullptr;
+    int rank = 0, world = 1;
+    bool dist_ready = false;
+    bool dist_all_rows = false;
+    double *own_x0 = nullptr, *own_b0 = nullptr, *own_r0 = nullptr;   // engine-owned buffers parked while external ones are bound
+    bool bound = false;
+    // orderings of the last system, reusable while the sparsity pattern of the LHS and the hierarchy are unchanged
+    bool ord_cache_valid = false;
+    uint64_t ord_cache_key[2] = {0, 0};
+    std::vector<LevelOrdering> ord_cache;
+    // the orderings live in the levels while a system is set; they move into ord_cache when the next one arrives
+    uint64_t live_key[2] = {0, 0};
+    bool live_key_valid = false;
+};
+
+namespace {
+
+int fail(gmg_handle h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail(h, GMG_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define NEED_DEVICE()                                                                     \
+    if (!h) return GMG_ERR_INVALID;                                                       \
+    PoolScope pool_scope_(&h->pool);                                                      \
+    do {                                                                                  \
+        if (!h->has_device) return fail(h, GMG_ERR_NO_DEVICE, "no usable HIP device (libgravomg_hip has no CPU fallback)"); \
+    } while (0)
+
+template <class T>
+int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
+    if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(dev_malloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
+template <class T>
+int upload(gmg_handle h, T** dst, const RawVec<T>& src) {
+    if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(dev_malloc((void**)dst, bytes));
+    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    return GMG_OK;
+}
+
+void free_sell(DevSell& s) {
+    if (s.slice_ptr) (void)dev_free(s.slice_ptr);
+    if (s.col) (void)dev_free(s.col);
+    if (s.val) (void)dev_free(s.val);
+    if (s.val32) (void)dev_free(s.val32);
+    if (s.row_of) (void)dev_free(s.row_of);
+    s = DevSell();
+}
+
+int upload_sell(gmg_handle h, DevSell& d, const SellHost& s) {
+    free_sell(d);
+    d.n_slices = s.n_slices; d.stored = s.stored(); d.nnz_real = s.nnz_real; d.lpr = s.lpr;
+    int rc;
+    if ((rc = upload(h, &d.slice_ptr, s.slice_ptr))) return rc;
+    if ((rc = upload(h, &d.col, s.col))) return rc;
+    if ((rc = upload(h, &d.val, s.val))) return rc;
+    if (!s.row_of.empty() && (rc = upload(h, &d.row_of, s.row_of))) return rc;
+    return GMG_OK;
+}
+
+void free_csr(DevCsr& m) {
+    if (m.ptr) (void)dev_free(m.ptr);
+    if (m.idx) (void)dev_free(m.idx);
+    if (m.val) (void)dev_free(m.val);
+    m = DevCsr();
+}
+
+void free_ell3(DevEll3& e) {
+    if (e.cnt) (void)dev_free(e.cnt);
+    if (e.col) (void)dev_free(e.col);
+    if (e.val) (void)dev_free(e.val);
+    e = DevEll3();
+}
+
+void drop_device_transfers(gmg_handle h) {
+    if (h->d_cluster_order) { (void)dev_free(h->d_cluster_order); h->d_cluster_order = nullptr; }
+    if (h->d_cluster_inv) { (void)dev_free(h->d_cluster_inv); h->d_cluster_inv = nullptr; }
+    for (auto& m : h->dU) free_csr(m);
+    for (auto& e : h->dE3) free_ell3(e);
+    h->dU.clear(); h->dE3.clear();
+    h->dU_ready = false;
+}
+
+// Patches of every blocked level k >= 1 (see coarse_point_graph): depend on the hierarchy and on block_rows only.
+void build_patches(gmg_handle h) {
+    const int L = h->L;
+    h->patches.assign(L + 1, PatchSet());
+    h->cluster_order.clear();
+    const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
+    // U_k by fine row: shared by the coarse point graphs (patches of level k + 1) and the cluster order of level 0
+    std::vector<Compressed> Urows(L);
+    {
+        std::vector<std::future<void>> jobs;
+        for (int k = 0; k < L; ++k) jobs.push_back(std::async(std::launch::async, [h, k, &Urows] { Urows[k] = transpose_parallel(h->U[k]); }));
+        for (auto& j : jobs) j.get();
+    }
+    std::vector<std::future<void>> jobs;
+    if (mc && h->cfg.block_rows > 0)
+        for (int k = std::max(1, h->cfg.block_from_level); k < L; ++k)
+            jobs.push_back(std::async(std::launch::async, [h, k, &Urows] {
+                Compressed G = coarse_point_graph(h->U[k - 1], Urows[k - 1]);
+                h->patches[k] = grow_patch_set(G, h->cfg.block_rows);
+            }));
+    if (mc && h->cfg.reorder_fine != 0 && L > 0)
+        jobs.push_back(std::async(std::launch::async, [h, L, &Urows] {
+            Compressed GL = coarse_point_graph(h->U[L - 1], Urows[L - 1]);
+            h->cluster_order = cluster_order(Urows, GL);
+        }));
+    for (auto& j : jobs) j.get();
+    h->patches_ready = true;
+}
+
+void free_level(Level& l) {
+    free_csr(l.dA);
+    free_sell(l.Aoff); free_sell(l.P); free_sell(l.R); free_sell(l.Ain); free_sell(l.Aout);
+    if (l.ain_col16) { (void)dev_free(l.ain_col16); l.ain_col16 = nullptr; }
+    for (int** p : {&l.bc_ptr, &l.bc_mid, &l.bc_col}) { if (*p) (void)dev_free(*p); *p = nullptr; }
+    if (l.bc_val) { (void)dev_free(l.bc_val); l.bc_val = nullptr; }
+    if (l.bc_val32) { (void)dev_free(l.bc_val32); l.bc_val32 = nullptr; }
+    l.use_bcsr = false; l.bc_cap = 0; l.bc_nnz = 0;
+    if (l.d_blk_begin) { (void)dev_free(l.d_blk_begin); l.d_blk_begin = nullptr; }
+    if (l.d_blk_ncolors) { (void)dev_free(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
+    if (l.d_row_color) { (void)dev_free(l.d_row_color); l.d_row_color = nullptr; }
+    for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)dev_free(*p); *p = nullptr; }
+    for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)dev_free(*p); *p = nullptr; }
+    if (l.d_new2old) { (void)dev_free(l.d_new2old); l.d_new2old = nullptr; }
+}
+
+void drop_graphs(gmg_handle h) {
+    for (auto& kv : h->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+    h->graphs.clear();
+}
+
+void unbind_level0(gmg_handle h) {
+    if (h->bound && !h->lv.empty()) { h->lv[0].x = h->own_x0; h->lv[0].b = h->own_b0; h->lv[0].r = h->own_r0; }
+    h->bound = false; h->own_x0 = h->own_b0 = h->own_r0 = nullptr;
+}
+
+void drop_system(gmg_handle h) {
+    drop_graphs(h);
+    unbind_level0(h);
+    h->dist_ready = false;
+    for (auto& l : h->lv) free_level(l);
+    h->lv.clear();
+    h->system_ready = false;
+    h->dcap = 0;
+    h->loaded_d = 0;
+    if (h->d_mass) { (void)dev_free(h->d_mass); h->d_mass = nullptr; }
+    if (h->d_minv) { (void)dev_free(h->d_minv); h->d_minv = nullptr; }
+    if (h->d_ainv) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
+}
+
+constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
+constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)
+inline bool wants_block_csr(gmg_handle h, int lpr) { return h->cfg.block_csr != 0 && lpr == 1 && h->cfg.block_rows == 64; }
+
+}  // namespace
