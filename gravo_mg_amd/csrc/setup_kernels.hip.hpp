@@ -310,7 +310,7 @@ __global__ void ell3_sort(const int* __restrict__ cnt, int n, int* __restrict__ 
 // in the SAME order as the host implementation (host_sparse.hpp::galerkin_rap), adding w = (u_ip a_ij) * u_jq to its
 // accumulator when q matches -- with separately rounded multiply and add, so the result is bitwise the host's.
 // PASS 0 only counts the distinct columns (row lengths for the prefix sum).
-constexpr int kRapSlots = 768;     // (column, product) list of one chunk of children in LDS: 3 per entry of A
+constexpr int kRapSlots = 192;     // (column, product) list of one chunk of children in LDS: 3 per entry of A
 constexpr int kRapSet = 256;      // hash-set capacity per coarse row (rows with more distinct columns -> host fallback)
 template <int PASS>
 __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, const int* __restrict__ a_idx, const double* __restrict__ a_val,
