@@ -70,7 +70,7 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
             int dc = std::min(4, d - c0);
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::jacobi_sweep<T, D>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                              in + (size_t)c0 * ld, out + (size_t)c0 * ld, ld, l.Aoff.n_slices, (T)h->cfg.jacobi_omega, 1));
+                                              (in ? in + (size_t)c0 * ld : nullptr), out + (size_t)c0 * ld, ld, l.Aoff.n_slices, (T)h->cfg.jacobi_omega, 1));
         }
         std::swap(in, out);
     }
@@ -79,10 +79,13 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
 
 // block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
 template <class T>
-void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
+void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zero = false) {
     const int ld = l.n_pad;
     const int nb = l.ord.n_blocks();
-    T* in = Prec<T>::x(l); T* out = Prec<T>::tmp(l);
+    // from_zero: the iterate is the zero vector (the coarse correction's initial guess, multigrid_solver.cpp:1072-1073): the
+    // first sweep gets no input vector -- it neither reads x nor gathers the off-block couplings (all zero) -- and the
+    // caller skips the memset
+    T* in = from_zero ? nullptr : Prec<T>::x(l); T* out = Prec<T>::tmp(l);
     const T* b = Prec<T>::b(l);
     for (int it = 0; it < iters; ++it) {
         for (int c0 = 0; c0 < d; c0 += 4) {
@@ -91,30 +94,36 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters) {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                                   (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, l.d_blk_begin,
                                                   l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.bc_ptr, l.bc_col,
-                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld, out + (size_t)c0 * ld,
+                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr), out + (size_t)c0 * ld,
                                                   ld, l.bc_cap));
             } else if (l.Ain.lpr == 4) {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
                                                   l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
-                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
                                                   out + (size_t)c0 * ld, ld));
             } else {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
                                                   l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
-                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, in + (size_t)c0 * ld,
+                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
                                                   out + (size_t)c0 * ld, ld));
             }
         }
-        std::swap(in, out);
+        if (it == 0 && from_zero) { in = out; out = Prec<T>::x(l); }      // the result of sweep 1 is in tmp; ping-pong from there
+        else std::swap(in, out);
     }
     if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
 }
 
+// true when smoothing level l from a zero iterate needs no materialised zero vector (block sweeps, at least one of them)
+inline bool smooth_from_zero_ok(gmg_handle h, const Level& l, int iters) {
+    return iters > 0 && h->cfg.smoother != GMG_SMOOTHER_JACOBI && l.ord.blocked;
+}
+
 template <class T = double>
-void launch_smooth(gmg_handle h, Level& l, int d, int iters) {
+void launch_smooth(gmg_handle h, Level& l, int d, int iters, bool from_zero = false) {
     if (iters <= 0) return;
     if (h->cfg.smoother == GMG_SMOOTHER_JACOBI) launch_jacobi_sweeps<T>(h, l, d, iters);
-    else if (l.ord.blocked) launch_block_sweeps<T>(h, l, d, iters);
+    else if (l.ord.blocked) launch_block_sweeps<T>(h, l, d, iters, from_zero);
     else launch_gs_sweeps<T>(h, l, d, iters);
 }
 
@@ -309,8 +318,9 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
     const int L = h->L;
     for (int k = k0; k < L; ++k) {
         Level& l = h->lv[k];
-        if (k > 0) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);   // eps.setZero, :1072-1073
-        launch_smooth<T>(h, l, d, h->cfg.pre_iters);                                                 // :1063
+        const bool from_zero = k > 0 && smooth_from_zero_ok(h, l, h->cfg.pre_iters);      // eps.setZero (:1072-1073) folded into the first sweep
+        if (k > 0 && !from_zero) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);
+        launch_smooth<T>(h, l, d, h->cfg.pre_iters, from_zero);                                     // :1063
         launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l));                    // :1066
         launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
     }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
     if (active) {
         const int s = (r0 >> 6) + wave;
 #pragma unroll
-        for (int c = 0; c < D; ++c) xs[c][t] = x_in[row + (int64_t)c * ld];
+        for (int c = 0; c < D; ++c) xs[c][t] = x_in ? x_in[row + (int64_t)c * ld] : (T)0.0;      // x_in == nullptr: sweep from a zero iterate
         p0 = in_ptr[s];
         w = (int)((in_ptr[s + 1] - p0) >> 6);
 #pragma unroll
@@ -169,7 +169,11 @@ __global__ __launch_bounds__(kBlockRows) void gs_block(const int* __restrict__ b
                     }
             }
         T acc[D];
-        row_dot<T, D, (D == 1 ? 8 : 4)>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+        if (x_in) row_dot<T, D, (D == 1 ? 8 : 4)>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
+        else {                     // zero iterate: nothing couples in from outside the block
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = 0.0;
+        }
 #pragma unroll
         for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
         dg = 1.0 / diag[row];      // reciprocal once, outside the sequential colour loop
@@ -242,9 +246,9 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
     const int s = r0 >> 6;
     const int e0 = out_ptr[r0], e1 = out_ptr[r0 + 64];
     const int cnt = e1 - e0;
-    for (int e = lane; e < cnt; e += 64) { sval[e] = out_val[e0 + e]; scol[e] = out_col[e0 + e]; }
+    if (x_in) for (int e = lane; e < cnt; e += 64) { sval[e] = out_val[e0 + e]; scol[e] = out_col[e0 + e]; }
 #pragma unroll
-    for (int c = 0; c < D; ++c) xs[c * 64 + lane] = x_in[row + (int64_t)c * ld];
+    for (int c = 0; c < D; ++c) xs[c * 64 + lane] = x_in ? x_in[row + (int64_t)c * ld] : (T)0.0;     // nullptr: zero iterate
     // in-block entries of this lane's row: SELL -> registers (zero-padded window, 16-bit local columns packed in pairs)
     constexpr int CH = D == 1 ? 8 : 4;
     T v[WIN];
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
         T acc[D];
 #pragma unroll
         for (int c = 0; c < D; ++c) acc[c] = 0.0;
-        int e = mb;
+        int e = x_in ? mb : me;            // zero iterate: no off-block couplings
         for (; e + 4 <= me; e += 4) {
             int cc[4]; T vv[4]; T xv[4][D];
 #pragma unroll
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
         const int s = (r0 >> 4) + wave;
         if (writer) {
 #pragma unroll
-            for (int c = 0; c < D; ++c) xs[c][lrow] = x_in[row + (int64_t)c * ld];
+            for (int c = 0; c < D; ++c) xs[c][lrow] = x_in ? x_in[row + (int64_t)c * ld] : (T)0.0;
         }
         p0 = in_ptr[s];
         w = (int)((in_ptr[s + 1] - p0) >> 6);
@@ -382,8 +386,11 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
                 cpk[j >> 1] |= (unsigned)__builtin_nontemporal_load(in_col + p0 + (int64_t)j * 64 + lane) << ((j & 1) * 16);
             }
         T acc[D];
-        row_dot<T, D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc);
-        quad_reduce<T, D>(acc);
+        if (x_in) { row_dot<T, D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc); quad_reduce<T, D>(acc); }
+        else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = 0.0;
+        }
 #pragma unroll
         for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
         dg = 1.0 / diag[row];
