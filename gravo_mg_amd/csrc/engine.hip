@@ -779,12 +779,17 @@ int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) {
     int rc = check_level(h, 0, false);
     if (rc) return rc;
     if (!b || !x0 || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    auto tl = clk::now();
     if ((rc = ensure_vectors(h, d))) return rc;
+    h->timing["load_vectors"] = ms_since(tl); tl = clk::now();
     Level& l = h->lv[0];
     if ((rc = to_device(h, 0, b, d, l.b))) return rc;
+    h->timing["load_b"] = ms_since(tl); tl = clk::now();
     if ((rc = to_device(h, 0, x0, d, l.x))) return rc;
+    h->timing["load_x"] = ms_since(tl); tl = clk::now();
     if (h->cfg.inner_precision && (rc = launch_residual_to_f32(h, d, -1))) return rc;    // defect of the initial guess -> b32
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->timing["load_sync"] = ms_since(tl);
     h->loaded_d = d;
     return GMG_OK;
 }
@@ -829,6 +834,7 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle (multigrid_solver.cpp:1411-1417)
     auto t_all = clk::now();
     if ((rc = gmg_load_problem(h, rhs, x, d))) return rc;
+    h->timing["solve_load"] = ms_since(t_all);
     h->timing["coarse_host_ms"] = 0.0;
     auto t0 = clk::now();
     double residue = 0.0;
@@ -842,7 +848,9 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
         if (h->cfg.verbose) std::printf("%d,%f,%.14f \n", it, ms_since(t0), residue);
     } while (residue > tol && it < max_iter);
     h->timing["cycles"] = ms_since(t0);
+    auto t_f = clk::now();
     if ((rc = gmg_fetch_solution(h, x))) return rc;
+    h->timing["solve_fetch"] = ms_since(t_f);
     h->timing["iterations"] = it;
     h->timing["residue"] = residue;
     h->timing["solve_call"] = ms_since(t_all);
