@@ -91,6 +91,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
         h->own_stream = h->stream;
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
+        (void)ensure_bounce(h);         // 2 x 16 MB pinned, once per handle (page-locking is not free: not inside gmg_set_system)
     }
     *out = h;
     return GMG_OK;     // host-only entry points work without a device; device ones report GMG_ERR_NO_DEVICE
@@ -110,6 +111,7 @@ void gmg_destroy(gmg_handle h) {
         if (h->h_norm) (void)hipHostFree(h->h_norm);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
+        for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
         (void)hipStreamDestroy(h->own_stream);
         h->pool.trim();
     }
@@ -155,7 +157,7 @@ static int upload_mass(gmg_handle h) {
         int rc = ensure_stage(h, (size_t)n);
         if (rc) return rc;
         for (double** p : {&h->d_mass, &h->d_minv}) if (!*p) HIPCHK(dev_malloc((void**)p, sizeof(double) * l.n_pad));
-        HIPCHK(hipMemcpyAsync(h->d_stage, h->mass.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+        if ((rc = h2d(h, h->d_stage, h->mass.data(), sizeof(double) * (size_t)n))) return rc;
         hipLaunchKernelGGL(gmgk::permute_mass, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.d_new2old, l.n_pad, h->d_mass, h->d_minv);
         HIPCHK(hipStreamSynchronize(h->stream));
     }

@@ -20,9 +20,8 @@ int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const i
     HIPCHK(dev_malloc((void**)&d.ptr, sizeof(int) * ((size_t)n_outer + 1)));
     HIPCHK(dev_malloc((void**)&d.idx, sizeof(int) * std::max<size_t>(nnz, 1)));
     HIPCHK(dev_malloc((void**)&d.val, sizeof(double) * std::max<size_t>(nnz, 1)));
-    HIPCHK(hipMemcpyAsync(d.ptr, ptr, sizeof(int) * ((size_t)n_outer + 1), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d.idx, idx, sizeof(int) * nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(d.val, val, sizeof(double) * nnz, hipMemcpyHostToDevice, h->stream));
+    int rc;
+    if ((rc = h2d(h, d.ptr, ptr, sizeof(int) * ((size_t)n_outer + 1))) || (rc = h2d(h, d.idx, idx, sizeof(int) * nnz)) || (rc = h2d(h, d.val, val, sizeof(double) * nnz))) return rc;
     return GMG_OK;
 }
 
@@ -136,9 +135,7 @@ int device_permute_pattern(gmg_handle h, const DevCsr& dA, int n, int64_t nnz) {
     hipLaunchKernelGGL(gmgs::perm_fill, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.idx, h->d_cluster_order, h->d_cluster_inv, pptr.p, n, pidx.p);
     h->reo_ptr.resize((size_t)n + 1);
     h->reo_idx.resize((size_t)nnz);
-    HIPCHK(hipMemcpyAsync(h->reo_ptr.data(), pptr.p, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpyAsync(h->reo_idx.data(), pidx.p, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = d2h(h, h->reo_ptr.data(), pptr.p, sizeof(int) * ((size_t)n + 1))) || (rc = d2h(h, h->reo_idx.data(), pidx.p, sizeof(int) * (size_t)nnz))) return rc;
     return GMG_OK;
 }
 
@@ -151,14 +148,13 @@ int ensure_host_A(gmg_handle h, int k, bool values) {
     l.A.n_outer = n; l.A.n_inner = n;
     if (!l.hostA_pattern) {
         l.A.ptr.resize((size_t)n + 1);
-        HIPCHK(hipMemcpyAsync(l.A.ptr.data(), l.dA.ptr, sizeof(int) * ((size_t)n + 1), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        { int r2 = d2h(h, l.A.ptr.data(), l.dA.ptr, sizeof(int) * ((size_t)n + 1)); if (r2) return r2; }
         l.A.idx.resize((size_t)l.A.ptr[n]);
-        HIPCHK(hipMemcpyAsync(l.A.idx.data(), l.dA.idx, sizeof(int) * l.A.idx.size(), hipMemcpyDeviceToHost, h->stream));
+        { int r2 = d2h(h, l.A.idx.data(), l.dA.idx, sizeof(int) * l.A.idx.size()); if (r2) return r2; }
     }
     if (values && !l.hostA_values) {
         l.A.val.resize((size_t)l.nnz);
-        HIPCHK(hipMemcpyAsync(l.A.val.data(), l.dA.val, sizeof(double) * l.A.val.size(), hipMemcpyDeviceToHost, h->stream));
+        { int r2 = d2h(h, l.A.val.data(), l.dA.val, sizeof(double) * l.A.val.size()); if (r2) return r2; }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     l.hostA_pattern = true;
@@ -186,7 +182,7 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
     C.n_outer = nc; C.n_inner = nc;
     if (pattern || values) {
         C.ptr.resize((size_t)nc + 1);
-        HIPCHK(hipMemcpyAsync(C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1), hipMemcpyDeviceToHost, h->stream));
+        { int r2 = d2h(h, C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1)); if (r2) return r2; }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     if (herr) { free_csr(dC); return 1; }       // a coarse row overflows the device hash set (or a U row has > 3 entries): host fallback
@@ -195,8 +191,8 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
     HIPCHK(dev_malloc((void**)&dC.val, sizeof(double) * std::max(nnz, 1)));
     hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                        (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
-    if (pattern || values) { C.idx.resize(nnz); HIPCHK(hipMemcpyAsync(C.idx.data(), dC.idx, sizeof(int) * nnz, hipMemcpyDeviceToHost, h->stream)); }
-    if (values) { C.val.resize(nnz); HIPCHK(hipMemcpyAsync(C.val.data(), dC.val, sizeof(double) * nnz, hipMemcpyDeviceToHost, h->stream)); }
+    if (pattern || values) { C.idx.resize(nnz); { int r2 = d2h(h, C.idx.data(), dC.idx, sizeof(int) * nnz); if (r2) return r2; } }
+    if (values) { C.val.resize(nnz); { int r2 = d2h(h, C.val.data(), dC.val, sizeof(double) * nnz); if (r2) return r2; } }
     if (pattern || values) HIPCHK(hipStreamSynchronize(h->stream));
     return GMG_OK;
 }

@@ -130,6 +130,8 @@ struct gmg_solver_s {
     double *d_mass = nullptr, *d_minv = nullptr;
     double* d_stage = nullptr; size_t stage_cap = 0;
     double* h_stage[2] = {nullptr, nullptr}; size_t h_stage_cap = 0;      // pinned host staging (double-buffered) for b / x
+    void* bounce[2] = {nullptr, nullptr};                                  // pinned bounce buffers for the set-up's pageable copies
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr}; int bounce_flip = 0;
     hipEvent_t h_stage_ev[2] = {nullptr, nullptr}; int h_stage_flip = 0;
     double* d_partials = nullptr; int partial_blocks = 0;
     double* d_norm = nullptr;
@@ -177,12 +179,87 @@ int fail(gmg_handle h, int code, const std::string& msg) {
         if (!h->has_device) return fail(h, GMG_ERR_NO_DEVICE, "no usable HIP device (libgravomg_hip has no CPU fallback)"); \
     } while (0)
 
+// Host <-> device copies of pageable memory (the caller's arrays, std::vectors) go through two pinned bounce buffers:
+// worker threads copy a chunk in while the previous one is on the wire.  Handing pageable memory to hipMemcpyAsync
+// makes the runtime pin and unpin it (252 MB for the LHS at 3 M vertices); on hosts where that is expensive (IOMMU
+// translation on) the deferred unpinning stalled the NEXT DMA by 10-35 ms -- seen as a late start of the first
+// right-hand-side upload after a set-up -- and the set-up itself was slower.  The bounce costs a threaded memcpy and
+// behaves the same everywhere.  A side effect: the source may be freed as soon as h2d returns.
+constexpr size_t kBounceBytes = (size_t)16 << 20;
+constexpr size_t kBounceMin = (size_t)256 << 10;       // smaller copies use the runtime's own staging
+
+static int ensure_bounce(gmg_handle h) {
+    for (int i = 0; i < 2; ++i) {
+        if (!h->bounce[i]) HIPCHK(hipHostMalloc(&h->bounce[i], kBounceBytes, hipHostMallocDefault));
+        if (!h->bounce_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->bounce_ev[i], hipEventDisableTiming));
+    }
+    return GMG_OK;
+}
+
+static void threaded_copy_bytes(void* dst, const void* src, size_t bytes, int threads) {
+    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, 16)), bytes / ((size_t)1 << 20) + 1);
+    if (T <= 1) { std::memcpy(dst, src, bytes); return; }
+    parallel_ranges(T, T, [&](int t0, int t1, int) {
+        for (int t = t0; t < t1; ++t) {
+            const size_t lo = bytes * t / T / 64 * 64, hi = t + 1 == T ? bytes : bytes * (t + 1) / T / 64 * 64;
+            std::memcpy((char*)dst + lo, (const char*)src + lo, hi - lo);
+        }
+    }, 1);
+}
+
+static int h2d(gmg_handle h, void* dst, const void* src, size_t bytes) {
+    if (bytes < kBounceMin) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return GMG_OK; }
+    int rc = ensure_bounce(h);
+    if (rc) return rc;
+    for (size_t off = 0; off < bytes; off += kBounceBytes) {
+        const size_t len = std::min(kBounceBytes, bytes - off);
+        const int f = h->bounce_flip;
+        h->bounce_flip ^= 1;
+        HIPCHK(hipEventSynchronize(h->bounce_ev[f]));                  // the previous DMA out of this buffer is done
+        threaded_copy_bytes(h->bounce[f], (const char*)src + off, len, h->cfg.host_threads);
+        HIPCHK(hipMemcpyAsync((char*)dst + off, h->bounce[f], len, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipEventRecord(h->bounce_ev[f], h->stream));
+    }
+    return GMG_OK;
+}
+
+// (synchronous: the data is in dst when this returns)
+static int d2h(gmg_handle h, void* dst, const void* src, size_t bytes) {
+    if (bytes < kBounceMin) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return GMG_OK;
+    }
+    int rc = ensure_bounce(h);
+    if (rc) return rc;
+    const size_t nchunk = (bytes + kBounceBytes - 1) / kBounceBytes;
+    auto issue = [&](size_t c) -> int {
+        const int f = (int)(c & 1);
+        const size_t off = c * kBounceBytes, len = std::min(kBounceBytes, bytes - off);
+        HIPCHK(hipMemcpyAsync(h->bounce[f], (const char*)src + off, len, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->bounce_ev[f], h->stream));
+        return GMG_OK;
+    };
+    HIPCHK(hipEventSynchronize(h->bounce_ev[0]));
+    HIPCHK(hipEventSynchronize(h->bounce_ev[1]));
+    if ((rc = issue(0))) return rc;
+    for (size_t c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk && (rc = issue(c + 1))) return rc;        // next chunk on the wire while this one is copied out
+        const int f = (int)(c & 1);
+        const size_t off = c * kBounceBytes, len = std::min(kBounceBytes, bytes - off);
+        HIPCHK(hipEventSynchronize(h->bounce_ev[f]));
+        threaded_copy_bytes((char*)dst + off, h->bounce[f], len, h->cfg.host_threads);
+    }
+    h->bounce_flip = 0;
+    return GMG_OK;
+}
+
 template <class T>
 int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
     if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
     HIPCHK(dev_malloc((void**)dst, bytes));
-    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    if (!src.empty()) return h2d(h, *dst, src.data(), src.size() * sizeof(T));
     return GMG_OK;
 }
 
@@ -191,7 +268,7 @@ int upload(gmg_handle h, T** dst, const RawVec<T>& src) {
     if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
     HIPCHK(dev_malloc((void**)dst, bytes));
-    if (!src.empty()) HIPCHK(hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    if (!src.empty()) return h2d(h, *dst, src.data(), src.size() * sizeof(T));
     return GMG_OK;
 }
 
