@@ -109,6 +109,7 @@ void gmg_destroy(gmg_handle h) {
         if (h->h_pinned) (void)hipHostFree(h->h_pinned);
         for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]); if (h->h_stage_ev[i]) (void)hipEventDestroy(h->h_stage_ev[i]); }
         if (h->h_norm) (void)hipHostFree(h->h_norm);
+        if (h->h_flag) (void)hipHostFree(h->h_flag);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
@@ -768,7 +769,7 @@ int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int
     if ((rc = to_device(h, 0, b, d, l.b))) return rc;
     if ((rc = to_device(h, 0, x, d, l.x))) return rc;
     if ((rc = launch_norm(h, d, type))) return rc;
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if ((rc = wait_norm(h))) return rc;
     h->loaded_d = 0;
     *out = norm_from_sums(h->h_norm, d, type);
     return GMG_OK;
@@ -806,7 +807,7 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     for (int i = 0; i < n_cycles; ++i) {
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
         if (stop_type >= 0) {
-            HIPCHK(hipStreamSynchronize(h->stream));
+            if ((rc = wait_norm(h))) return rc;
             if (residues) residues[i] = norm_from_sums(h->h_norm, d, stop_type);
         }
     }
@@ -843,7 +844,7 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     int it = 0;
     do {
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
+        if ((rc = wait_norm(h))) return rc;
         residue = norm_from_sums(h->h_norm, d, stop_type);
         if (conv) { conv[2 * it] = ms_since(t0); conv[2 * it + 1] = residue; }
         ++it;
@@ -1018,7 +1019,8 @@ int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) {
                                               l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, sb, se,
                                               h->d_partials + (size_t)c * nblk * 2 * dc));
         }
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0);
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0,
+                           (unsigned long long*)nullptr, 0ull);
     }
     HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -177,19 +177,58 @@ void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T
     }
 }
 
-// sums of w r^2 / w b^2 per column -> h_norm[2*d] (after the caller synchronises the stream)
+// Polled completion.  Slot 0: residual-norm sums in h_norm; slot 1: the coarsest right-hand side in h_pinned.
+inline bool polled(gmg_handle h) { return !h->cfg.use_graph && h->h_flag; }
+
+int wait_flag(gmg_handle h, int slot) {
+    const unsigned long long want = h->flag_seq[slot];
+    auto t0 = clk::now();
+    double next_query_ms = 20.0;
+    for (unsigned spin = 1;; ++spin) {
+        if (__atomic_load_n(h->h_flag + 8 * slot, __ATOMIC_ACQUIRE) == want) return GMG_OK;
+        // safety net only (the runtime's query is not free and may touch the queue): a finished stream implies the data
+        // is visible, flag or not; an error state must not spin for ever
+        if ((spin & 4095u) == 0 && ms_since(t0) > next_query_ms) {
+            hipError_t q = hipStreamQuery(h->stream);
+            if (q == hipSuccess) return GMG_OK;
+            if (q != hipErrorNotReady) HIPCHK(q);
+            next_query_ms += 20.0;
+        }
+        __builtin_ia32_pause();
+    }
+}
+
+// the result of the last launch_norm / launch_residual_to_f32 is in h_norm when this returns
+int wait_norm(gmg_handle h) {
+    if (polled(h)) return wait_flag(h, 0);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+// the reduction of one group of <= 4 columns: into h_norm + flag when polled, into d_norm (+ a copy later) otherwise
+void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
+    if (polled(h))
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->h_norm + 2 * c0,
+                           last ? h->h_flag : nullptr, last ? ++h->flag_seq[0] : 0ull);
+    else
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0,
+                           (unsigned long long*)nullptr, 0ull);
+}
+
+// sums of w r^2 / w b^2 per column -> h_norm[2*d] (after wait_norm)
 int launch_norm(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
     const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
+    const bool poll = polled(h);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                           l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
                                           l.n_pad, 0, l.Aoff.n_slices, h->d_partials));
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
+        launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
     }
-    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
+    if (!poll) HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
     return GMG_OK;
 }
 
@@ -237,6 +276,11 @@ int ensure_vectors(gmg_handle h, int d) {
     }
     if (h->h_norm) (void)hipHostFree(h->h_norm);
     HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, hipHostMallocDefault));
+    if (!h->h_flag) {
+        HIPCHK(hipHostMalloc((void**)&h->h_flag, 128, hipHostMallocDefault));
+        std::memset(h->h_flag, 0, 128);
+    }
+
     if (h->d_norm) (void)dev_free(h->d_norm);
     HIPCHK(dev_malloc((void**)&h->d_norm, sizeof(double) * 2 * d));
     h->dcap = d;
@@ -364,8 +408,14 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
     double* rc = h->h_pinned;
     double* e = h->h_pinned + cnt;
     if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
-    HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    if (polled(h)) {
+        hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1]);
+        int w = wait_flag(h, 1);
+        if (w) return w;
+    } else {
+        HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     auto t0 = clk::now();
     std::memset(e, 0, sizeof(double) * cnt);
     if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
@@ -387,9 +437,9 @@ int launch_residual_to_f32(gmg_handle h, int d, int type) {
         DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_to_f32_with_norm<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
                                           l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, 0, l.Aoff.n_slices,
                                           l.b32 + (size_t)c0 * l.n_pad, h->d_partials));
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0);
+        launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
     }
-    HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
+    if (!polled(h)) HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
     return GMG_OK;
 }
 

@@ -137,6 +137,9 @@ struct gmg_solver_s {
     double* d_norm = nullptr;
     double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
     double* h_norm = nullptr;
+    // polled completion (stream launches only): a kernel writes its small result into pinned memory and then a sequence
+    // number into h_flag[slot]; the host spins on that word (wait_flag) instead of a copy + hipStreamSynchronize
+    unsigned long long* h_flag = nullptr; unsigned long long flag_seq[2] = {0, 0};
     double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
     std::vector<double> coarse_work;
     std::map<std::string, double> timing;

@@ -503,6 +503,44 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
     }
 }
 
+// out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of 256 threads, fixed order.
+__device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp, double* __restrict__ out,
+                                                      double* red) {
+    for (int c = 0; c < ncomp; ++c) {
+        double v = 0.0;
+        for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += partials[(int64_t)i * ncomp + c];
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = kBlock / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[c] = red[0];
+        __syncthreads();
+    }
+}
+
+// flag != nullptr: `out` is host-visible pinned memory and `seq` is published in *flag after the sums -- the host polls
+// that word instead of paying a copy kernel and a stream synchronisation per residual check.
+__global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
+                                                          double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
+    __shared__ double red[kBlock];
+    block_reduce_partials(partials, n_blocks, ncomp, out, red);
+    if (flag) {
+        __threadfence_system();
+        if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// n doubles -> host-visible pinned memory, then the sequence word (one block; the coarsest right-hand side)
+__global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restrict__ src, double* __restrict__ dst, int n,
+                                                          unsigned long long* flag, unsigned long long seq) {
+    for (int i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Residual norms (gravomg/src/multigrid_solver.cpp:1228-1277): per block, partial sums of
 // w_i r_i^2 and w_i b_i^2 for r = A x - b and w = weight ? weight[i] : 1.
 // partials layout: [block][2*D].  Reduced by reduce_partials (deterministic order).
@@ -546,24 +584,6 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
 #pragma unroll
         for (int w2 = 0; w2 < kWavesPerBlock; ++w2) v += red[w2][threadIdx.x];
         partials[(int64_t)blockIdx.x * (2 * D) + threadIdx.x] = v;
-    }
-}
-
-// out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of 256 threads, fixed order.
-__global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
-                                                          double* __restrict__ out) {
-    __shared__ double red[kBlock];
-    for (int c = 0; c < ncomp; ++c) {
-        double v = 0.0;
-        for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += partials[(int64_t)i * ncomp + c];
-        red[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = kBlock / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[c] = red[0];
-        __syncthreads();
     }
 }
 
