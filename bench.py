@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--block-lanes", type=int, default=None)
     ap.add_argument("--no-variants", action="store_true", help="skip the informational device-coarse-apply timing")
     ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU code path even with one rank")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="N > 1: publish only the entries other ranks read after a colour sweep (halo) or whole colour segments")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -100,6 +100,8 @@ SIGNATURES = {
     "gmg_dist_residual_all": (C.c_int, [_vp]),
     "gmg_dist_prolong_all": (C.c_int, [_vp]),
     "gmg_dist_norm_all": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_dist_gather": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gmg_dist_scatter": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
@@ -504,6 +506,14 @@ class Engine:
         sums = np.zeros(2 * d)
         self._chk(lib().gmg_dist_norm_all(self._h, int(type), _pd(sums)))
         return sums
+
+    def dist_gather(self, src_ptr: int, idx_ptr: int, n: int, dst_ptr: int):
+        """dst[i] = src[idx[i]] on the engine stream (device pointers)."""
+        self._chk(lib().gmg_dist_gather(self._h, src_ptr, idx_ptr, int(n), dst_ptr))
+
+    def dist_scatter(self, src_ptr: int, pos_ptr: int, idx_ptr: int, n: int, dst_ptr: int):
+        """dst[idx[i]] = src[pos[i]] on the engine stream (device pointers)."""
+        self._chk(lib().gmg_dist_scatter(self._h, src_ptr, pos_ptr, idx_ptr, int(n), dst_ptr))
 
 
 def host_galerkin(A, U) -> sp.csc_matrix:

@@ -1047,6 +1047,19 @@ int gmg_dist_norm_all(gmg_handle h, int type, double* sums) {
     return gmg_dist_norm_partial(h, type, sums);
 }
 
+int gmg_dist_gather(gmg_handle h, const double* src, const int64_t* idx, int64_t n, double* dst) {
+    NEED_DEVICE();
+    if (n < 0 || (n > 0 && (!src || !idx || !dst))) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if (n) hipLaunchKernelGGL(gmgk::gather_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, idx, n, dst);
+    return GMG_OK;
+}
+int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const int64_t* idx, int64_t n, double* dst) {
+    NEED_DEVICE();
+    if (n < 0 || (n > 0 && (!src || !pos || !idx || !dst))) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if (n) hipLaunchKernelGGL(gmgk::scatter_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, pos, idx, n, dst);
+    return GMG_OK;
+}
+
 // ---- measurement --------------------------------------------------------------------------------------------
 
 int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out) {

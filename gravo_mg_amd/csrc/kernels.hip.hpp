@@ -532,6 +532,17 @@ __global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restri
     }
 }
 
+// halo exchange (multi-GPU): pack / unpack of the published entries
+__global__ void gather_entries(const double* __restrict__ src, const int64_t* __restrict__ idx, int64_t n, double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void scatter_entries(const double* __restrict__ src, const int64_t* __restrict__ pos, const int64_t* __restrict__ idx, int64_t n,
+                                double* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[idx[i]] = src[pos[i]];
+}
+
 // n doubles -> host-visible pinned memory, then the sequence word (one block; the coarsest right-hand side)
 __global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restrict__ src, double* __restrict__ dst, int n,
                                                           unsigned long long* flag, unsigned long long seq) {

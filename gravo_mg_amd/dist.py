@@ -11,8 +11,17 @@ piece of the output buffer): one after every colour of every Gauss-Seidel sweep 
 cheap steps around the sweeps (residual, prolongation-add, residual norm) are computed REDUNDANTLY on all rows
 instead of being exchanged (`replicate=True`, the default; `replicate=False` keeps them row-partitioned with an
 all-gather of r / x and an all-reduce of the norm sums: 24 collectives + 1 per cycle).  Because the colours are
-GLOBAL, the distributed sweep is the same multicolour Gauss-Seidel as on one GPU: results are independent of P.  (A halo-only exchange would move O(sqrt(n/P)) instead of n/(C*P) values per step -- the collective count,
-i.e. the latency, stays the same; at 3 M vertices the path is latency-bound either way)
+GLOBAL, the distributed sweep is the same multicolour Gauss-Seidel as on one GPU: results are independent of P.
+
+`halo=HaloPlan(...)` (what bench.py uses for N > 1) replaces the whole-segment all-gathers by a HALO exchange
+(SURVEY.md 8e "v2"): after a colour sweep a rank publishes only those of its entries of x that rows of OTHER ranks
+read -- O(boundary) values instead of n/(C*P) -- packed into a fixed-size buffer, all-gathered, and unpacked by the
+receivers (pack + collective + unpack, all d columns at once).  x is then complete on a rank only on its own rows and
+their halo, so residual, prolongation and norm are row-partitioned: one all-gather of r per colour segment before the
+replicated coarse part (24 MB per cycle at 3 M vertices instead of 16 x 6 MB), one halo exchange of x after the
+prolongation, one all-reduce of the norm sums.  The iterates are still those of the global multicolour sweep
+(independent of P); the norm sums are added across ranks, so residues agree to rounding.  `gather_solution()`
+completes x on every rank (solve() calls it once at the end).
 
 The local work is done by a *backend*: `EngineBackend` launches this rank's share on its GPU through the C-ABI
 (gmg_dist_* in include/gravomg_hip.h).  tests/test_dist_gloo.py plugs in a numpy backend to check the
@@ -28,13 +37,73 @@ import torch
 import torch.distributed as dist
 
 
+def row_owner(color_begin, n_pad: int, world: int) -> np.ndarray:
+    """Owner rank of every device row of level 0: piece p of every (64*world-aligned) colour class."""
+    cb = np.asarray(color_begin, np.int64)
+    rows = np.arange(n_pad, dtype=np.int64)
+    col = np.searchsorted(cb, rows, side="right") - 1
+    piece = np.maximum((cb[1:] - cb[:-1]) // world, 1)
+    return ((rows - cb[col]) // piece[col]).astype(np.int32), col.astype(np.int32)
+
+
+class HaloPlan:
+    """Index lists of the halo exchange, the same on every rank (built from the replicated matrix pattern).
+
+    indptr/indices: pattern of the level-0 operator (natural numbering, CSR or CSC -- it is symmetric);
+    new2old/color_begin/n_pad: the device ordering of level 0 (Engine.level_ordering(0) / host_plan_level).
+    For key c (a colour) or "all": rank q publishes pub[q][key] (device rows it owns that another rank's rows read);
+    the send buffer holds d * maxlen[key] values (column k at k * maxlen), the receive buffer world such pieces."""
+
+    def __init__(self, indptr, indices, new2old, color_begin, n_pad: int, world: int, rank: int, d: int, device=None):
+        new2old = np.asarray(new2old, np.int64)
+        n = int(len(indptr) - 1)
+        real = new2old >= 0
+        old2new = np.empty(n, np.int64)
+        old2new[new2old[real]] = np.nonzero(real)[0]
+        owner, color = row_owner(color_begin, n_pad, world)
+        ri = np.repeat(old2new, np.diff(np.asarray(indptr, np.int64)))      # device row of every entry
+        ci = old2new[np.asarray(indices, np.int64)]
+        read_elsewhere = np.zeros(n_pad, bool)
+        read_elsewhere[ci[owner[ri] != owner[ci]]] = True
+        need = np.nonzero(read_elsewhere)[0]                                  # sorted device rows
+        self.world, self.rank, self.d, self.n_pad = world, rank, d, n_pad
+        self.n_colors = len(color_begin) - 1
+        self.keys = list(range(self.n_colors)) + ["all"]
+        self.maxlen, self.n_send, self.n_recv = {}, {}, {}
+        self._t = {}
+        dev = device
+        for key in self.keys:
+            sel = need if key == "all" else need[color[need] == key]
+            pub = [sel[owner[sel] == q] for q in range(world)]
+            m = max(1, max(len(p_) for p_ in pub))
+            cols = np.arange(d, dtype=np.int64)
+            mine = pub[rank]
+            send_idx = (mine[None, :] + cols[:, None] * n_pad).ravel()
+            send_pos = (np.arange(len(mine), dtype=np.int64)[None, :] + cols[:, None] * m).ravel()
+            rp, rx = [], []
+            for q in range(world):
+                if q == rank or len(pub[q]) == 0:
+                    continue
+                rp.append((q * d * m + np.arange(len(pub[q]), dtype=np.int64)[None, :] + cols[:, None] * m).ravel())
+                rx.append((pub[q][None, :] + cols[:, None] * n_pad).ravel())
+            recv_pos = np.concatenate(rp) if rp else np.zeros(0, np.int64)
+            recv_idx = np.concatenate(rx) if rx else np.zeros(0, np.int64)
+            self.maxlen[key], self.n_send[key], self.n_recv[key] = m, len(send_idx), len(recv_idx)
+            self._t[key] = tuple(torch.as_tensor(a, device=dev) for a in (send_idx, send_pos, recv_pos, recv_idx))
+        self.published_rows = int(len(need))
+
+    def tensors(self, key):
+        return self._t[key]
+
+
 class DistVCycle:
     """V-cycle + residual check + solve loop over `world` ranks.  `backend` provides the local steps and the
     level-0 vectors x, b, r as flat torch tensors of length d * n_pad (column-major)."""
 
-    def __init__(self, backend, group=None, replicate: bool = True):
+    def __init__(self, backend, group=None, replicate: bool = True, halo: Optional[HaloPlan] = None):
         self.be = backend
-        self.replicate = bool(replicate)
+        self.halo = halo
+        self.replicate = bool(replicate) and halo is None        # a halo exchange leaves x incomplete: row-partitioned steps
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -74,12 +143,49 @@ class DistVCycle:
         for c in range(self.n_colors):
             self._allgather_color(buf, c)
 
+    def _halo_exchange(self, buf: torch.Tensor, key):
+        """Publish this rank's entries of `buf` that other ranks read (colour `key`, or every colour for "all")."""
+        if self.world == 1:
+            return
+        hp = self.halo
+        send_idx, send_pos, recv_pos, recv_idx = hp.tensors(key)
+        m = hp.maxlen[key] * self.d
+        bufs = self._send.get(("halo", key))
+        if bufs is None or bufs[0].device != buf.device:
+            bufs = self._send[("halo", key)] = (torch.zeros(m, dtype=buf.dtype, device=buf.device),
+                                                torch.zeros(m * self.world, dtype=buf.dtype, device=buf.device))
+        send, recv = bufs
+        gather = getattr(self.be, "halo_gather", None)
+        if gather is not None:
+            gather(buf, send_idx, send_pos, send)
+        elif send_idx.numel():
+            send.index_copy_(0, send_pos, buf.index_select(0, send_idx))
+        try:
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(recv.chunk(self.world)), send, group=self.group)
+        self.n_collectives += 1
+        scatter = getattr(self.be, "halo_scatter", None)
+        if scatter is not None:
+            scatter(recv, recv_pos, recv_idx, buf)
+        elif recv_idx.numel():
+            buf.index_copy_(0, recv_idx, recv.index_select(0, recv_pos))
+
+    def gather_solution(self):
+        """Complete x on every rank (needed after halo-mode cycles before the solution is read)."""
+        if self.halo is not None and self.world > 1:
+            with self.be.stream_context():
+                self._allgather_all(self.be.x)
+
     # -- the cycle (gravomg/src/multigrid_solver.cpp:1059-1088) ----------------------------------------------
     def smooth(self, iters: int):
         for _ in range(iters):
             for c in range(self.n_colors):
                 self.be.smooth_color(c)
-                self._allgather_color(self.be.x, c)
+                if self.halo is not None:
+                    self._halo_exchange(self.be.x, c)
+                else:
+                    self._allgather_color(self.be.x, c)
 
     def vcycle(self):
         with self.be.stream_context():              # kernels and collectives ordered on the backend's stream
@@ -92,6 +198,9 @@ class DistVCycle:
             self.be.coarse_cycle()                      # :1069-1079 (replicated)
             if self.replicate:
                 self.be.prolong_all()                   # :1082
+            elif self.halo is not None:
+                self.be.prolong_own()
+                self._halo_exchange(self.be.x, "all")
             else:
                 self.be.prolong_own()
                 self._allgather_all(self.be.x)
@@ -122,6 +231,7 @@ class DistVCycle:
             it += 1
             if not (res > tol and it < max_iter):
                 break
+        self.gather_solution()
         return it, res, residues
 
 
@@ -180,3 +290,13 @@ class EngineBackend:
 
     def norm_all(self, type):
         return self.eng.dist_norm_all(type, self.d)
+
+    # pack / unpack of a halo exchange: one launch each on the engine stream (gmg_dist_gather / gmg_dist_scatter)
+    def halo_gather(self, buf, send_idx, send_pos, send):
+        if self.d == 1:                         # column 0 only: positions are 0..n-1
+            self.eng.dist_gather(buf.data_ptr(), send_idx.data_ptr(), send_idx.numel(), send.data_ptr())
+        else:
+            self.eng.dist_scatter(buf.data_ptr(), send_idx.data_ptr(), send_pos.data_ptr(), send_idx.numel(), send.data_ptr())
+
+    def halo_scatter(self, recv, recv_pos, recv_idx, buf):
+        self.eng.dist_scatter(recv.data_ptr(), recv_pos.data_ptr(), recv_idx.data_ptr(), recv_idx.numel(), buf.data_ptr())

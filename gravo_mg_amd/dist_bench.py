@@ -16,7 +16,7 @@ def main(args):
     import torch.distributed as dist
 
     from gravo_mg_amd import cabi
-    from gravo_mg_amd.dist import DistVCycle, EngineBackend
+    from gravo_mg_amd.dist import DistVCycle, EngineBackend, HaloPlan
 
     import bench as single
 
@@ -31,8 +31,15 @@ def main(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
+    # GMG_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that): a functional end-to-end check of the
+    # N > 1 path on a 1-GPU box, not a measurement
+    backend = os.environ.get("GMG_DIST_BACKEND", "nccl")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or args.gpus <= 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     workload = f"torus{args.n1}x{args.n2}-poisson-tau1e-6-d1-{args.order}"
@@ -44,7 +51,14 @@ def main(args):
     eng.set_system(lhs)
     levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
     be = EngineBackend(eng, 1, rank, world, torch.device("cuda", local))
-    dv = DistVCycle(be)
+    halo = None
+    if world > 1 and args.exchange == "halo":
+        t = time.perf_counter()
+        new2old, cb = eng.level_ordering(0)
+        A = lhs.tocsr()
+        halo = HaloPlan(A.indptr, A.indices, new2old, cb, be.n_pad, world, rank, 1, device=be.device)
+        single.log(f"[bench] rank {rank}: halo plan {halo.published_rows} published rows of {lhs.shape[0]} ({time.perf_counter() - t:.1f}s)")
+    dv = DistVCycle(be, halo=halo)
 
     def run(k):
         out = []
@@ -91,10 +105,13 @@ def main(args):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
                        "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": False,
-                       "partition": f"level 0 colour sweeps split {world}-way by rows, everything else replicated; one RCCL all-gather of x per colour sweep",
+                       "partition": (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
+                                     f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle"
+                                     if halo is not None else
+                                     f"level 0 colour sweeps split {world}-way by rows, everything else replicated; one RCCL all-gather of x per colour sweep"),
                        "tolerance": 1e-4, "stopping_criteria": 2},
             "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms,
-            "collectives_per_cycle": colls / max(args.steps + args.warmup, 1),
+            "collectives_per_cycle": colls / max(args.steps + args.warmup, 1), "collective_backend": backend,
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
             "timed_residues_tail": [float(r) for r in residues[-3:]],
             "roofline": roofline, "cpu_baseline": None,

@@ -189,6 +189,11 @@ int gmg_dist_norm_partial(gmg_handle h, int type, double* sums);
 int gmg_dist_residual_all(gmg_handle h);
 int gmg_dist_prolong_all(gmg_handle h);
 int gmg_dist_norm_all(gmg_handle h, int type, double* sums);
+/* Halo exchange helpers (gravo_mg_amd/dist.py, `halo` mode: after a colour sweep a rank publishes only the entries of
+ * x0 that rows of other ranks read).  dst[i] = src[idx[i]] and dst[idx[i]] = src[pos[i]] for i < n, on the handle's
+ * stream; every pointer is a device pointer. */
+int gmg_dist_gather(gmg_handle h, const double* src, const int64_t* idx, int64_t n, double* dst);
+int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const int64_t* idx, int64_t n, double* dst);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:

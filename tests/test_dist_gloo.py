@@ -121,11 +121,11 @@ class NumpyBackend:
         return self.Pm.T @ self._v(self.x)
 
 
-def _worker(rank, world, port, kind, out_dir, replicate):
+def _worker(rank, world, port, kind, out_dir, mode):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from gravo_mg_amd import cabi
-    from gravo_mg_amd.dist import DistVCycle
+    from gravo_mg_amd.dist import DistVCycle, HaloPlan
     from tests import problems
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -133,12 +133,18 @@ def _worker(rank, world, port, kind, out_dir, replicate):
         P = problems.torus_problem(48, 40, kind, 40) if kind != "smoothing" else problems.torus_problem(40, 36, "smoothing", 60)
         plan = cabi.host_plan_level(P.lhs, mode=0, row_align=64 * world)
         be = NumpyBackend(P, plan, rank, world)
-        dv = DistVCycle(be, replicate=replicate)
+        halo = None
+        if mode == "halo":
+            A = sp.csr_matrix(P.lhs)
+            halo = HaloPlan(A.indptr, A.indices, plan["new2old"], plan["color_begin"], plan["n_pad"], world, rank, P.rhs.shape[1])
+            assert 0 < halo.published_rows < P.lhs.shape[0]
+        dv = DistVCycle(be, replicate=mode == "replicate", halo=halo)
         be.load(P.rhs, P.rhs)
         hist = []
         for _ in range(3):
             dv.vcycle()
             hist.append([dv.residual_norm(t) for t in range(4)])
+        dv.gather_solution()
         x3 = be.solution()
         be.load(P.rhs, P.rhs)
         it, res, residues = dv.solve(1e-4, 2, 50)
@@ -172,11 +178,12 @@ def _single(kind):
     return P, x3, np.array(hist), it, res, be.solution()
 
 
-@pytest.mark.parametrize("world,kind,replicate", [(2, "poisson", True), (3, "smoothing", True), (2, "poisson", False), (3, "smoothing", False)])
-def test_row_partitioned_vcycle_is_independent_of_world_size(world, kind, replicate, tmp_path, cabi, oracle):
+@pytest.mark.parametrize("world,kind,mode", [(2, "poisson", "replicate"), (3, "smoothing", "replicate"), (2, "poisson", "partitioned"),
+                                             (3, "smoothing", "partitioned"), (2, "poisson", "halo"), (3, "smoothing", "halo")])
+def test_row_partitioned_vcycle_is_independent_of_world_size(world, kind, mode, tmp_path, cabi, oracle):
     import torch.multiprocessing as mp
     P, x3, hist, it, res, x = _single(kind)
-    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), replicate), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, str(tmp_path), mode), nprocs=world, join=True)
     outs = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
     for o in outs:
         # every rank ends with the complete, identical iterate ...
@@ -189,7 +196,11 @@ def test_row_partitioned_vcycle_is_independent_of_world_size(world, kind, replic
         # exchanges per cycle: (pre+post) sweeps * colours; row-partitioned residual / prolongation / norm add their own
         C, d = int(o["ncolors"]), P.rhs.shape[1]
         cycles = 3 + it
-        assert int(o["ncoll"]) == (cycles * (4 * C * d) if replicate else cycles * (6 * C * d) + (3 * 4 + it))
+        want = {"replicate": cycles * (4 * C * d), "partitioned": cycles * (6 * C * d) + (3 * 4 + it),
+                # halo: one small exchange per colour sweep (all columns at once), r all-gathered per colour segment, one
+                # exchange after the prolongation, the norm all-reduce, and x completed once after the cycles / the solve
+                "halo": cycles * (4 * C + C * d + 1) + (3 * 4 + it) + 2 * C * d}[mode]
+        assert int(o["ncoll"]) == want
     # and it is the reference's answer: the oracle's residual check agrees on the distributed solution
     chk = oracle.residual_check(P.lhs, P.mass, P.rhs, outs[0]["x"], 2)
     assert chk <= 1e-4 and abs(chk - float(outs[0]["res"])) <= 1e-3 * chk + 1e-9

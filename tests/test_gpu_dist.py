@@ -97,3 +97,85 @@ def test_emulated_ranks_on_one_device(cabi, world):
         sums = sum(b.norm_partial(2) for b in bes)
         want = ref.norm_partial(2)
         np.testing.assert_allclose(sums, want, rtol=1e-12)
+
+
+@pytest.mark.parametrize("world,kind", [(2, "poisson"), (4, "poisson"), (3, "smoothing")])
+def test_emulated_halo_exchange_on_one_device(cabi, world, kind):
+    """Halo mode (dist.HaloPlan + gmg_dist_gather / gmg_dist_scatter): after a colour sweep a rank publishes only the
+    entries other ranks read.  Ranks emulated on one device, the all-gather of the packed buffers replaced by a
+    concatenation.  Own rows must equal the single-engine iterate bitwise; after completing x, everything does."""
+    import scipy.sparse as sp
+    import torch
+    from gravo_mg_amd.dist import EngineBackend, HaloPlan, row_owner
+    P = problems.torus_problem(96, 80, "poisson", 30) if kind == "poisson" else problems.torus_problem(64, 60, "smoothing", 60)
+    d = P.rhs.shape[1]
+    ref = EngineBackend(_engine(cabi, P, world), d, 0, 1)
+    bes = [EngineBackend(_engine(cabi, P, world), d, r, world) for r in range(world)]
+    cb, n_pad, C = bes[0].color_begin, bes[0].n_pad, len(bes[0].color_begin) - 1
+    new2old, _ = bes[0].eng.level_ordering(0)
+    A = sp.csr_matrix(P.lhs)
+    dev = bes[0].x.device
+    plans = [HaloPlan(A.indptr, A.indices, new2old, cb, n_pad, world, r, d, device=dev) for r in range(world)]
+    assert 0 < plans[0].published_rows < 0.5 * P.lhs.shape[0]
+    owner, _ = row_owner(cb, n_pad, world)
+    own = [torch.as_tensor(np.concatenate([np.nonzero(owner == r)[0] + k * n_pad for k in range(d)]), device=dev) for r in range(world)]
+    for b in bes + [ref]:
+        b.load(P.rhs, P.rhs)
+    torch.cuda.synchronize()
+
+    def halo(name, key):
+        sends = []
+        for r, b in enumerate(bes):
+            si, sp_, _, _ = plans[r].tensors(key)
+            send = torch.zeros(plans[r].maxlen[key] * d, dtype=torch.float64, device=dev)
+            with b.stream_context():
+                b.halo_gather(getattr(b, name), si, sp_, send)
+            sends.append(send)
+        torch.cuda.synchronize()
+        recv = torch.cat(sends)
+        for r, b in enumerate(bes):
+            _, _, rp, ri = plans[r].tensors(key)
+            with b.stream_context():
+                b.halo_scatter(recv, rp, ri, getattr(b, name))
+        torch.cuda.synchronize()
+
+    def full(name):
+        torch.cuda.synchronize()
+        for src in range(world):
+            for dst in range(world):
+                if dst != src:
+                    getattr(bes[dst], name)[own[src]] = getattr(bes[src], name)[own[src]]
+        torch.cuda.synchronize()
+
+    def cycle_ranks():
+        for _ in range(2):
+            for c in range(C):
+                for b in bes: b.smooth_color(c)
+                halo("x", c)
+        for b in bes: b.residual_own()
+        full("r")
+        for b in bes: b.coarse_cycle()
+        for b in bes: b.prolong_own()
+        halo("x", "all")
+        for _ in range(2):
+            for c in range(C):
+                for b in bes: b.smooth_color(c)
+                halo("x", c)
+
+    def cycle_ref():
+        for _ in range(2):
+            for c in range(C): ref.smooth_color(c)
+        ref.residual_own(); ref.coarse_cycle(); ref.prolong_own()
+        for _ in range(2):
+            for c in range(C): ref.smooth_color(c)
+
+    for _ in range(3):
+        cycle_ranks(); cycle_ref()
+        torch.cuda.synchronize()
+        for r, b in enumerate(bes):
+            assert torch.equal(b.x[own[r]], ref.x[own[r]])
+        sums = sum(b.norm_partial(2) for b in bes)
+        np.testing.assert_allclose(sums, ref.norm_partial(2), rtol=1e-12)
+    full("x")
+    for b in bes:
+        assert torch.equal(b.x, ref.x)
