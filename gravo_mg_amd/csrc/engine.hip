@@ -423,18 +423,26 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         int herr = 0;
         if ((rc_all = d_err.alloc(h, 1)) == GMG_OK) {
             (void)hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream);
-            for (int k = 0; k <= L && rc_all == GMG_OK; ++k) {
+            // the coarse levels first: their orderings are short jobs, while level 0's (a sequential greedy colouring of
+            // the whole mesh) is the longest host task of the set-up and may still be running
+            auto ordering_of = [&](int k) {
                 auto tw = clk::now();
                 ord_done[k].wait();
                 h->timing["setup_wait_ordering"] += ms_since(tw);
                 mark("ordering_ready_l" + std::to_string(k));
-                if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); break; }
+                if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); return; }
                 rc_all = upload(h, &h->lv[k].d_new2old, h->lv[k].ord.new2old);
-            }
+            };
+            double ms_layout = 0;
+            for (int k = L; k >= 1 && rc_all == GMG_OK; --k) ordering_of(k);
             auto tlay = clk::now();
-            for (int k = 0; k < L && rc_all == GMG_OK; ++k)
-                rc_all = device_layout_level(h, k, d_err.p);
-            h->timing["setup_device_layout"] = ms_since(tlay);
+            for (int k = 1; k < L && rc_all == GMG_OK; ++k) rc_all = device_layout_level(h, k, d_err.p);
+            ms_layout += ms_since(tlay);
+            if (rc_all == GMG_OK) ordering_of(0);
+            tlay = clk::now();
+            if (rc_all == GMG_OK) rc_all = device_layout_level(h, 0, d_err.p);
+            ms_layout += ms_since(tlay);
+            h->timing["setup_device_layout"] = ms_layout;
             mark("device_layout");
             if (rc_all == GMG_OK) {
                 (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);

@@ -200,7 +200,8 @@ static int ensure_bounce(gmg_handle h) {
 }
 
 static void threaded_copy_bytes(void* dst, const void* src, size_t bytes, int threads) {
-    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, 16)), bytes / ((size_t)1 << 20) + 1);
+    static const int cap = [] { const char* e = std::getenv("GMG_BOUNCE_THREADS"); return e ? std::max(1, std::atoi(e)) : 16; }();
+    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, cap)), bytes / ((size_t)1 << 20) + 1);
     if (T <= 1) { std::memcpy(dst, src, bytes); return; }
     parallel_ranges(T, T, [&](int t0, int t1, int) {
         for (int t = t0; t < t1; ++t) {

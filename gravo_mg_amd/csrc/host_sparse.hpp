@@ -9,6 +9,8 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -16,6 +18,8 @@
 #include <functional>
 #include <mutex>
 #include <pthread.h>
+#include <sched.h>
+#include <string>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -37,11 +41,58 @@ struct Compressed {
     }
 };
 
-inline int hw_threads() {
-    unsigned t = std::thread::hardware_concurrency();
-    if (t == 0) t = 1;
-    return (int)std::min(t, 128u);
+// CPUs this process may actually use: hardware threads, cut down to the scheduler affinity mask and to the cgroup CPU
+// quota.  A container on a 256-thread host with a 16-CPU quota reports 256 hardware threads; running 64-128 threads
+// there exhausts the quota within a period and the kernel then stalls the WHOLE process for tens of milliseconds
+// (seen as set-ups three times slower than usual and as DMAs that start late on some boxes).
+inline int cpu_budget() {
+    static const int v = [] {
+        long t = (long)std::thread::hardware_concurrency();
+        if (t <= 0) t = 1;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) t = std::min<long>(t, c); }
+        auto apply_v2 = [&](const std::string& file) {
+            if (FILE* f = std::fopen(file.c_str(), "r")) {
+                char q[64]; long long period = 0;
+                if (std::fscanf(f, "%63s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+                    const long long quota = std::atoll(q);
+                    if (quota > 0) t = std::min<long>(t, (long)std::max<long long>(1, (quota + period - 1) / period));
+                }
+                std::fclose(f);
+            }
+        };
+        auto read_ll = [](const char* file, long long& out) {
+            FILE* f = std::fopen(file, "r");
+            if (!f) return false;
+            const bool ok = std::fscanf(f, "%lld", &out) == 1;
+            std::fclose(f);
+            return ok;
+        };
+        apply_v2("/sys/fs/cgroup/cpu.max");
+        if (FILE* f = std::fopen("/proc/self/cgroup", "r")) {          // cgroup v2 line "0::/path": every ancestor's limit applies
+            char line[1024];
+            while (std::fgets(line, sizeof(line), f)) {
+                if (std::strncmp(line, "0::", 3) != 0) continue;
+                std::string path(line + 3);
+                while (!path.empty() && (path.back() == '\n' || path.back() == '/')) path.pop_back();
+                while (!path.empty()) {
+                    apply_v2("/sys/fs/cgroup" + path + "/cpu.max");
+                    const size_t cut = path.find_last_of('/');
+                    path = cut == std::string::npos ? std::string() : path.substr(0, cut);
+                }
+            }
+            std::fclose(f);
+        }
+        long long quota = 0, period = 0;                                 // cgroup v1
+        if (read_ll("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota) && read_ll("/sys/fs/cgroup/cpu/cpu.cfs_period_us", period) && quota > 0 && period > 0)
+            t = std::min<long>(t, (long)std::max<long long>(1, (quota + period - 1) / period));
+        if (const char* e = std::getenv("GMG_HOST_THREADS")) { const int o = std::atoi(e); if (o > 0) t = o; }
+        return (int)std::max<long>(1, t);
+    }();
+    return v;
 }
+
+inline int hw_threads() { return std::min(cpu_budget(), 128); }
 
 // ---- worker pool -----------------------------------------------------------------------------------------------
 // The host has hundreds of cores and the setup issues dozens of short parallel loops: spawning std::threads per loop
@@ -82,8 +133,7 @@ public:
 
 private:
     WorkerPool() {
-        unsigned t = std::thread::hardware_concurrency();
-        n_workers_ = (int)std::max(1u, std::min(t ? t : 1u, 64u));
+        n_workers_ = std::max(1, std::min(cpu_budget(), 64));
         pthread_atfork(nullptr, nullptr, [] { instance().after_fork(); });
     }
     void after_fork() {         // the child of a fork() has no worker threads: start over
