@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <future>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -114,9 +115,12 @@ struct PatternView {
     const int* idx;
 };
 
-// Greedy first-fit colouring; vertices visited in `order` (natural order if empty).
+// Greedy first-fit colouring; vertices visited in `order` (natural order if empty).  Inherently sequential (a vertex
+// sees the colours of the neighbours visited before it) and the longest host task of a set-up, so the loop works on
+// one byte per vertex (3 MB instead of 12 at 3 M vertices: stays in cache) and finds the first free colour in a 64-bit
+// mask; colours >= 64 (or > 254 colours in all) take the general path.  The result is the same either way.
 template <class Mat>
-inline int greedy_coloring(const Mat& A, std::vector<int>& color, const std::vector<int>& order = std::vector<int>()) {
+inline int greedy_coloring_general(const Mat& A, std::vector<int>& color, const std::vector<int>& order) {
     const int n = A.n_outer;
     color.assign(n, -1);
     std::vector<int> forbid;
@@ -133,6 +137,49 @@ inline int greedy_coloring(const Mat& A, std::vector<int>& color, const std::vec
         color[i] = c;
         if (c == ncol) ++ncol;
     }
+    return ncol;
+}
+
+// One byte per vertex; returns -1 (c8 unusable) when more than 254 colours would be needed.
+template <class Mat>
+inline int greedy_coloring_bytes(const Mat& A, RawVec<unsigned char>& c8, const std::vector<int>& order) {
+    const int n = A.n_outer;
+    constexpr unsigned char kNone = 255;
+    c8.resize((size_t)std::max(n, 1));
+    std::memset(c8.data(), kNone, (size_t)n);
+    unsigned char* cc = c8.data();
+    int ncol = 0;
+    std::vector<unsigned char> forbid;
+    for (int t = 0; t < n; ++t) {
+        const int i = order.empty() ? t : order[t];
+        uint64_t mask = 0;
+        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
+            const unsigned c = cc[A.idx[p]];               // the vertex itself is still kNone here
+            if (c < 64) mask |= (uint64_t)1 << c;
+        }
+        int c;
+        if (~mask != 0) c = __builtin_ctzll(~mask);        // first free colour below 64 (== ncol when 0..ncol-1 are all taken)
+        else {                                              // 0..63 all taken: first free colour >= 64
+            forbid.assign((size_t)ncol + 1, 0);
+            for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) { const unsigned cj = cc[A.idx[p]]; if (cj != kNone) forbid[cj] = 1; }
+            c = 64;
+            while (c < ncol && forbid[c]) ++c;
+        }
+        if (c >= 254) return -1;
+        cc[i] = (unsigned char)c;
+        if (c >= ncol) ncol = c + 1;
+    }
+    return ncol;
+}
+
+template <class Mat>
+inline int greedy_coloring(const Mat& A, std::vector<int>& color, const std::vector<int>& order = std::vector<int>()) {
+    RawVec<unsigned char> c8;
+    const int ncol = greedy_coloring_bytes(A, c8, order);
+    if (ncol < 0) return greedy_coloring_general(A, color, order);
+    const int n = A.n_outer;
+    color.resize((size_t)n);
+    parallel_ranges(n, hw_threads(), [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) color[i] = c8[i]; }, 1 << 16);
     return ncol;
 }
 
@@ -227,9 +274,21 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
         o.reordered = true;
     }
     phase("locality");
+    // While the (sequential) colouring runs, another thread first-touches the two index arrays of the result: fresh
+    // memory costs ~0.2 ms per MB of page faults on one core, more than the bucketing that fills them.
+    const int n_pad_max = n + 256 * std::max(row_align, 1);
+    auto prefill = std::async(std::launch::async, [&] {
+        o.new2old.assign((size_t)n_pad_max, -1);
+        o.old2new.assign((size_t)n, -1);
+    });
     std::vector<int> color;
-    if (multicolor) o.n_colors = greedy_coloring(A, color, base);
-    else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
+    RawVec<unsigned char> c8;
+    if (multicolor) {
+        o.n_colors = greedy_coloring_bytes(A, c8, base);
+        if (o.n_colors < 0) { c8.resize(0); o.n_colors = greedy_coloring_general(A, color, base); }
+    } else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
+    const bool bytes = !c8.empty();
+    auto colour_of = [&](int i) -> int { return bytes ? (int)c8[(size_t)i] : color[(size_t)i]; };
     phase("colouring");
     // Stable counting sort of the visit sequence by colour, threaded: per-chunk histograms give every chunk its write
     // offsets, so the result does not depend on the number of threads.
@@ -241,7 +300,7 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
         for (int q = lo; q < hi; ++q) {
             const int t0 = q * chunk, t1 = std::min(n, t0 + chunk);
             std::vector<int>& hq = hist[q];
-            for (int t = t0; t < t1; ++t) hq[color[base.empty() ? t : base[t]]]++;
+            for (int t = t0; t < t1; ++t) hq[colour_of(base.empty() ? t : base[t])]++;
         }
     }, 1);
     std::vector<int> count(o.n_colors, 0);
@@ -250,8 +309,9 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     for (int c = 0; c < o.n_colors; ++c) o.color_begin[c + 1] = o.color_begin[c] + round_up(count[c], row_align);
     o.n_pad = o.n_colors ? o.color_begin[o.n_colors] : 0;
     if (o.n_pad == 0) o.n_pad = row_align;
-    o.new2old.assign(o.n_pad, -1);
-    o.old2new.assign(n, -1);
+    prefill.wait();
+    if (o.n_pad <= n_pad_max) o.new2old.resize((size_t)o.n_pad);       // shrinks: no reallocation
+    else o.new2old.assign((size_t)o.n_pad, -1);
     {
         std::vector<int> run(o.color_begin.begin(), o.color_begin.end() - (o.n_colors ? 1 : 0));
         for (int q = 0; q < nchunk; ++q) for (int c = 0; c < o.n_colors; ++c) { const int h = hist[q][c]; hist[q][c] = run[c]; run[c] += h; }
@@ -260,7 +320,7 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
         for (int q = lo; q < hi; ++q) {
             const int t0 = q * chunk, t1 = std::min(n, t0 + chunk);
             std::vector<int>& fill = hist[q];
-            for (int t = t0; t < t1; ++t) { const int i = base.empty() ? t : base[t]; o.new2old[fill[color[i]]++] = i; }
+            for (int t = t0; t < t1; ++t) { const int i = base.empty() ? t : base[t]; o.new2old[fill[colour_of(i)]++] = i; }
         }
     }, 1);
     phase("bucket");
