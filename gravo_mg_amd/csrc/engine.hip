@@ -91,6 +91,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
         h->own_stream = h->stream;
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
+        if (const char* e = std::getenv("GMG_POLL")) h->poll = std::atoi(e) != 0;
         (void)ensure_bounce(h);         // 2 x 16 MB pinned, once per handle (page-locking is not free: not inside gmg_set_system)
     }
     *out = h;

@@ -178,7 +178,7 @@ void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T
 }
 
 // Polled completion.  Slot 0: residual-norm sums in h_norm; slot 1: the coarsest right-hand side in h_pinned.
-inline bool polled(gmg_handle h) { return !h->cfg.use_graph && h->h_flag; }
+inline bool polled(gmg_handle h) { return !h->cfg.use_graph && h->poll && h->h_flag; }
 
 int wait_flag(gmg_handle h, int slot) {
     const unsigned long long want = h->flag_seq[slot];

@@ -140,6 +140,7 @@ struct gmg_solver_s {
     // polled completion (stream launches only): a kernel writes its small result into pinned memory and then a sequence
     // number into h_flag[slot]; the host spins on that word (wait_flag) instead of a copy + hipStreamSynchronize
     unsigned long long* h_flag = nullptr; unsigned long long flag_seq[2] = {0, 0};
+    bool poll = true;             // GMG_POLL=0: copy + hipStreamSynchronize instead (the waiting thread then sleeps instead of spinning)
     double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
     std::vector<double> coarse_work;
     std::map<std::string, double> timing;
