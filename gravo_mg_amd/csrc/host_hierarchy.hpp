@@ -20,6 +20,7 @@
 //     ascending key order wins (:375-383), edge distances are stored as float (std::map<int,float>, :336).
 #pragma once
 #include <algorithm>
+#include <future>
 #include <memory>
 #include <atomic>
 #include <array>
@@ -62,6 +63,20 @@ inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
 inline V3 normalized(V3 a) { double z = dot(a, a); return z > 0 ? (1.0 / std::sqrt(z)) * a : a; }
 struct HeapItem { int v; double dist; bool operator>(const HeapItem& o) const { return dist > o.dist; } };
+// Read-only window on a contiguous array: the caller's positions / neighbour table on level 0 (no 170 MB copy), the
+// builder's own vectors on the coarser levels.
+template <class T>
+struct View {
+    const T* p = nullptr;
+    size_t n = 0;
+    View() {}
+    View(const T* p_, size_t n_) : p(p_), n(n_) {}
+    View(const std::vector<T>& v) : p(v.data()), n(v.size()) {}
+    const T& operator[](size_t i) const { return p[i]; }
+    size_t size() const { return n; }
+    const T* data() const { return p; }
+};
+static_assert(sizeof(V3) == 3 * sizeof(double), "V3 must overlay a row of the n x 3 position array");
 }  // namespace detail
 
 class HierarchyBuilder {
@@ -73,17 +88,22 @@ public:
         auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         HierarchyResult R;
         auto t_all = clk::now();
-        for (const char* key : {"PDS", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection"}) R.timing[key] = 0.0;
+        for (const char* key : {"PDS", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection",
+                                "prepare", "edge_length", "assemble"}) R.timing[key] = 0.0;      // the last three: not in the reference's list
         R.timing["n_vertices"] = n;
-        std::vector<V3> P(n);
-        for (int i = 0; i < n; ++i) P[i] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
-        std::vector<int> NB(neigh, neigh + (size_t)n * K);
+        std::vector<V3> P_own;                 // storage of the coarser levels; level 0 reads the caller's arrays in place
+        std::vector<int> NB_own;
+        detail::View<V3> P(reinterpret_cast<const V3*>(pos), (size_t)n);
+        detail::View<int> NB(neigh, (size_t)n * K);
         int nbK = K;
         R.dof.push_back(n);
+        R.timing["prepare"] = ms(t_all, clk::now());
         int level = 0;
         while ((int)P.size() > opt.lower_bound && level < 10) {                      // :103
             const int nf = (int)P.size();
+            auto te = clk::now();
             const double radius = std::cbrt(opt.ratio) * average_edge_length(P, NB, nbK);   // :104
+            R.timing["edge_length"] += ms(te, clk::now());
             std::vector<double> D(nf, std::numeric_limits<double>::max());
             std::vector<int> nearest(nf, 0);
             auto t0 = clk::now();
@@ -297,10 +317,13 @@ public:
             R.row_kinds.push_back(kinds);
 
             R.U.push_back(from_triplets(nf, nc, trow, tcol, tval));
+            R.timing["assemble"] += ms(t6, clk::now());
             R.samples.push_back(std::move(sample));
             R.dof.push_back(nc);
-            P.swap(Pc);
-            NB.swap(NBc);
+            P_own.swap(Pc);
+            NB_own.swap(NBc);
+            P = detail::View<V3>(P_own);
+            NB = detail::View<int>(NB_own);
             nbK = Kc;
             ++level;
         }
@@ -310,7 +333,9 @@ public:
     }
 
 private:
-    static double average_edge_length(const std::vector<V3>& P, const std::vector<int>& NB, int K) {   // :695-711
+    // (sequential on purpose: the loop is bound by its chain of dependent additions, ~1.3 ns each, and the radius must
+    // have the bits of the reference's running sum; computing the lengths on all threads first was slower, 38 -> 72 ms)
+    static double average_edge_length(detail::View<V3> P, detail::View<int> NB, int K) {   // :695-711
         double sum = 0.0; long cnt = 0;
         const int n = (int)P.size();
         for (int i = 0; i < n; ++i)
@@ -324,7 +349,7 @@ private:
     }
 
     // :975-1013  greedy disk sampling over the one- and two-ring, first come first served in index order
-    static std::vector<int> fast_disk_sample(const std::vector<V3>& P, const std::vector<int>& NB, int K, double radius,
+    static std::vector<int> fast_disk_sample(detail::View<V3> P, detail::View<int> NB, int K, double radius,
                                              std::vector<double>& D, std::vector<int>& nearest) {
         const int n = (int)P.size();
         std::vector<char> visited(n, 0);
@@ -356,7 +381,7 @@ private:
     }
 
     // :1015-1056  multi-source Dijkstra; D/nearest arrive pre-seeded by the sampler and are only ever lowered
-    static void voronoi_dijkstra(const std::vector<V3>& P, const std::vector<int>& src, const std::vector<int>& NB, int K,
+    static void voronoi_dijkstra(detail::View<V3> P, const std::vector<int>& src, detail::View<int> NB, int K,
                                  std::vector<double>& D, std::vector<int>& nearest) {
         std::priority_queue<detail::HeapItem, std::vector<detail::HeapItem>, std::greater<detail::HeapItem>> heap;
         for (int i = 0; i < (int)src.size(); ++i) {
@@ -429,21 +454,45 @@ private:
     // triplets arrive grouped by row (ascending) with at most a handful per row, so duplicates can only be neighbours in
     // the list: they are merged there, then the columns are filled on all cores (atomic slot counters) and each column
     // is sorted by row -- every (row, column) is unique by then, so the result does not depend on the fill order.
-    static Compressed from_triplets(int nrows, int ncols, const std::vector<int>& r, const std::vector<int>& c, const std::vector<double>& v) {
+    // (the triplet values are consumed: duplicates inside a row are merged into the first occurrence in place)
+    static Compressed from_triplets(int nrows, int ncols, const std::vector<int>& r, const std::vector<int>& c, std::vector<double>& vm) {
         const size_t nt = r.size();
-        std::vector<char> keep(nt, 1);
-        std::vector<double> vm(v);
-        for (size_t t = 0; t < nt;) {                       // rows are short: quadratic merge inside a row
-            size_t e = t;
-            while (e < nt && r[e] == r[t]) ++e;
-            for (size_t i = t; i < e; ++i)
-                if (keep[i])
-                    for (size_t j = i + 1; j < e; ++j)
-                        if (keep[j] && c[j] == c[i]) { vm[i] += vm[j]; keep[j] = 0; }
-            t = e;
-        }
+        std::unique_ptr<char[]> keep(new char[std::max<size_t>(nt, 1)]);
+        const int Tm = std::max(1, std::min(hw_threads(), 64));
+        std::vector<size_t> kept_of((size_t)Tm, 0);
+        // rows are short runs of consecutive triplets and independent of each other: every thread takes a range of
+        // triplets moved forward to the next row boundary (quadratic merge inside a row, as in the sequential loop)
+        parallel_ranges(Tm, Tm, [&](int q0, int q1, int) {
+            for (int q = q0; q < q1; ++q) {
+                size_t t = nt * (size_t)q / Tm, te = nt * (size_t)(q + 1) / Tm;
+                while (t > 0 && t < nt && r[t] == r[t - 1]) ++t;
+                while (te > 0 && te < nt && r[te] == r[te - 1]) ++te;
+                size_t kept = 0;
+                while (t < te) {
+                    size_t e = t;
+                    while (e < nt && r[e] == r[t]) ++e;
+                    for (size_t i = t; i < e; ++i) keep[i] = 1;
+                    for (size_t i = t; i < e; ++i)
+                        if (keep[i]) {
+                            ++kept;
+                            for (size_t j = i + 1; j < e; ++j)
+                                if (keep[j] && c[j] == c[i]) { vm[i] += vm[j]; keep[j] = 0; }
+                        }
+                    t = e;
+                }
+                kept_of[q] = kept;
+            }
+        }, 1);
+        size_t total = 0;
+        for (size_t k : kept_of) total += k;
         Compressed M;
         M.n_outer = ncols; M.n_inner = nrows;
+        // the index / value arrays are first-touched (zero-filled) by two helper threads while the columns are counted
+        auto sized = std::async(std::launch::async, [&M, total] {
+            auto other = std::async(std::launch::async, [&M, total] { M.val.resize(total); });
+            M.idx.resize(total);
+            other.wait();
+        });
         const int T = std::max(1, std::min(hw_threads(), 64));
         std::unique_ptr<std::atomic<int>[]> cnt(new std::atomic<int>[(size_t)ncols + 1]);
         parallel_ranges(ncols + 1, T, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) cnt[j].store(0, std::memory_order_relaxed); });
@@ -453,7 +502,7 @@ private:
         M.ptr.assign((size_t)ncols + 1, 0);
         for (int j = 0; j < ncols; ++j) M.ptr[j + 1] = M.ptr[j] + cnt[j].load(std::memory_order_relaxed);
         parallel_ranges(ncols, T, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) cnt[j].store(M.ptr[j], std::memory_order_relaxed); });
-        M.idx.resize(M.ptr[ncols]); M.val.resize(M.ptr[ncols]);
+        sized.wait();
         parallel_ranges((int)nt, T, [&](int lo, int hi, int) {
             for (int t = lo; t < hi; ++t)
                 if (keep[t]) { const int q = cnt[c[t]].fetch_add(1, std::memory_order_relaxed); M.idx[q] = r[t]; M.val[q] = vm[t]; }

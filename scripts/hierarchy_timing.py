@@ -8,5 +8,5 @@ S, mass = meshgen.cotan_laplacian(V, F)
 nb = meshgen.neighbors_from_stiffness(S)
 for rep in range(2):
     t = time.perf_counter(); H = cabi.Hierarchy(V, nb); dt = time.perf_counter() - t
-    keys = ["hierarchy", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection", "levels"]
+    keys = ["hierarchy", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection", "prepare", "edge_length", "assemble", "levels"]
     print(order, round(dt, 3), {k: round(H.timing(k), 1) for k in keys})
