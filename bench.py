@@ -89,7 +89,7 @@ def main():
     ap.add_argument("--n1", type=int, default=1732)
     ap.add_argument("--n2", type=int, default=1732)
     ap.add_argument("--order", default="natural", choices=["natural", "random"])
-    ap.add_argument("--cpu-cycles", type=int, default=3, help="V-cycles timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-cycles", type=int, default=25, help="V-cycles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--coarse", default="host", choices=["host", "device"])
     ap.add_argument("--graph", action="store_true", help="replay the cycle legs from hipGraphs (same cycle time, ~5 ms instantiation per system)")
     ap.add_argument("--kernel-reps", type=int, default=50)
