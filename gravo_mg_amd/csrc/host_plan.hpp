@@ -331,10 +331,12 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
             for (int w = lo; w < hi; w += sigma) windows.emplace_back(w, std::min(hi, w + sigma));
         }
         parallel_ranges((int)windows.size(), T, [&](int lo, int hi, int) {
-            for (int q = lo; q < hi; ++q)
-                std::stable_sort(o.new2old.begin() + windows[q].first, o.new2old.begin() + windows[q].second, [&](int a, int b) {
-                    return (A.ptr[a + 1] - A.ptr[a]) > (A.ptr[b + 1] - A.ptr[b]);
-                });
+            for (int q = lo; q < hi; ++q) {
+                auto longer = [&](int a, int b) { return (A.ptr[a + 1] - A.ptr[a]) > (A.ptr[b + 1] - A.ptr[b]); };
+                const auto w0 = o.new2old.begin() + windows[q].first, w1 = o.new2old.begin() + windows[q].second;
+                // a regular mesh has one row length: nothing to do (a stable sort leaves a sorted window as it is)
+                if (!std::is_sorted(w0, w1, longer)) std::stable_sort(w0, w1, longer);
+            }
         }, 64);
     }
     phase("window sort");
