@@ -259,8 +259,8 @@ static int d2h(gmg_handle h, void* dst, const void* src, size_t bytes) {
     return GMG_OK;
 }
 
-template <class T>
-int upload(gmg_handle h, T** dst, const std::vector<T>& src) {
+template <class T, class A>
+int upload(gmg_handle h, T** dst, const std::vector<T, A>& src) {
     if (*dst) { (void)dev_free(*dst); *dst = nullptr; }
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
     HIPCHK(dev_malloc((void**)dst, bytes));

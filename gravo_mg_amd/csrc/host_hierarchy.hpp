@@ -487,12 +487,7 @@ private:
         for (size_t k : kept_of) total += k;
         Compressed M;
         M.n_outer = ncols; M.n_inner = nrows;
-        // the index / value arrays are first-touched (zero-filled) by two helper threads while the columns are counted
-        auto sized = std::async(std::launch::async, [&M, total] {
-            auto other = std::async(std::launch::async, [&M, total] { M.val.resize(total); });
-            M.idx.resize(total);
-            other.wait();
-        });
+        M.idx.resize(total); M.val.resize(total);      // not zero-filled (default_init_allocator): first touched by the threaded fill
         const int T = std::max(1, std::min(hw_threads(), 64));
         std::unique_ptr<std::atomic<int>[]> cnt(new std::atomic<int>[(size_t)ncols + 1]);
         parallel_ranges(ncols + 1, T, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) cnt[j].store(0, std::memory_order_relaxed); });
@@ -502,7 +497,6 @@ private:
         M.ptr.assign((size_t)ncols + 1, 0);
         for (int j = 0; j < ncols; ++j) M.ptr[j + 1] = M.ptr[j] + cnt[j].load(std::memory_order_relaxed);
         parallel_ranges(ncols, T, [&](int lo, int hi, int) { for (int j = lo; j < hi; ++j) cnt[j].store(M.ptr[j], std::memory_order_relaxed); });
-        sized.wait();
         parallel_ranges((int)nt, T, [&](int lo, int hi, int) {
             for (int t = lo; t < hi; ++t)
                 if (keep[t]) { const int q = cnt[c[t]].fetch_add(1, std::memory_order_relaxed); M.idx[q] = r[t]; M.val[q] = vm[t]; }
