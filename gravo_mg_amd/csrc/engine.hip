@@ -174,6 +174,120 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
     return GMG_OK;
 }
 
+// fp32 twins of the value arrays (mixed precision); `alloc`: (re)allocate them, otherwise they exist with the right sizes
+static int refresh_fp32_twins(gmg_handle h, bool alloc) {
+    const int L = h->L;
+    auto twin = [&](DevSell& m) -> int {
+        if (!m.val || m.stored <= 0) return GMG_OK;
+        if (alloc || !m.val32) {
+            if (m.val32) { (void)dev_free(m.val32); m.val32 = nullptr; }
+            HIPCHK(dev_malloc((void**)&m.val32, sizeof(float) * (size_t)m.stored));
+        }
+        launch_cvt(h, m.val, m.val32, (size_t)m.stored);
+        return GMG_OK;
+    };
+    for (int k = 0; k < L; ++k) {
+        Level& l = h->lv[k];
+        int rc;
+        if ((rc = twin(l.Aoff)) || (rc = twin(l.Ain)) || (rc = twin(l.Aout)) || (rc = twin(l.P)) || (rc = twin(l.R))) return rc;
+        if (l.use_bcsr) {
+            if (alloc || !l.bc_val32) {
+                if (l.bc_val32) { (void)dev_free(l.bc_val32); l.bc_val32 = nullptr; }
+                HIPCHK(dev_malloc((void**)&l.bc_val32, sizeof(float) * (size_t)std::max<int64_t>(l.bc_nnz, 1)));
+            }
+            launch_cvt(h, l.bc_val, l.bc_val32, (size_t)l.bc_nnz);
+        }
+        if (alloc || !l.diag32) {
+            if (l.diag32) { (void)dev_free(l.diag32); l.diag32 = nullptr; }
+            HIPCHK(dev_malloc((void**)&l.diag32, sizeof(float) * (size_t)l.n_pad));
+        }
+        launch_cvt(h, l.diag, l.diag32, (size_t)l.n_pad);
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+// dense inverse of the coarsest operator from the host factor (GMG_COARSE_DEVICE_INVERSE)
+static void coarse_inverse(gmg_handle h, std::vector<double>& inv) {
+    const int nl = h->lv[h->L].A.n_outer;
+    inv.resize((size_t)nl * nl);
+    parallel_ranges(nl, h->cfg.host_threads, [&](int lo, int hi, int) {
+        std::vector<double> e(nl, 0.0), w(nl);
+        for (int j = lo; j < hi; ++j) {
+            e[j] = 1.0;
+            h->coarse.solve(e.data(), inv.data() + (size_t)j * nl, w.data());
+            e[j] = 0.0;
+        }
+    });
+}
+
+// gmg_set_system for a matrix with the sparsity pattern of the live system: values only.  Returns 1 when it cannot be
+// done in place (nothing has been changed then, except values that the full path overwrites anyway).
+static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all) {
+    const int L = h->L;
+    auto mark = [&](const std::string& what) { h->timing["t_" + what] = ms_since(t_all); };
+    for (int k = 0; k <= L; ++k) if (!h->lv[k].dA.ptr || !h->lv[k].dA.idx || !h->lv[k].dA.val) return 1;
+    for (int k = 0; k < L; ++k) if (!h->lv[k].d_old2new || !h->lv[k].diag) return 1;
+    if (!h->lv[L].hostA_pattern) return 1;
+    for (auto it = h->timing.begin(); it != h->timing.end();) it = it->first.rfind("t_", 0) == 0 ? h->timing.erase(it) : std::next(it);
+    mark("pattern_key");
+    int rc;
+    DevTmp<int> d_err;
+    if ((rc = d_err.alloc(h, 1))) return rc;
+    HIPCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream));
+    h->loaded_d = 0;
+    for (int k = 0; k <= L; ++k) h->lv[k].hostA_values = false;          // host copies (if any) keep their pattern only
+    if ((rc = h2d(h, h->lv[0].dA.val, val, sizeof(double) * (size_t)h->lv[0].nnz))) return rc;
+    mark("upload_A0");
+    auto t0 = clk::now();
+    for (int k = 1; k <= L; ++k) {
+        Level& lk = h->lv[k];
+        if ((rc = device_rap(h, h->lv[k - 1].dA, h->dU[k - 1], h->dE3[k - 1], lk.dA, lk.A, false, k == L, &lk.nnz, d_err.p, true))) return rc < 0 ? rc : GMG_ERR_STATE;
+        if (k == L) lk.hostA_values = true;
+        mark("rap_l" + std::to_string(k));
+    }
+    h->timing["reduction"] = ms_since(t0);
+    double ms_factor = 0;
+    std::vector<double> inv;
+    std::future<bool> factor_done = std::async(std::launch::async, [&] {
+        auto t = clk::now();
+        bool ok = h->coarse.factor(h->lv[L].A, true);
+        if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) coarse_inverse(h, inv);
+        ms_factor = ms_since(t);
+        return ok;
+    });
+    auto tl = clk::now();
+    for (int k = 0; k < L && rc == GMG_OK; ++k) rc = device_refill_level(h, k, d_err.p);
+    int herr = 0;
+    if (rc == GMG_OK) {
+        (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+    }
+    h->timing["setup_device_layout"] = ms_since(tl);
+    mark("device_layout");
+    const bool factor_ok = factor_done.get();
+    mark("factor_joined");
+    if (rc != GMG_OK) return rc;
+    if (herr == 2) return fail(h, GMG_ERR_NUMERIC, "system matrix has a missing or zero diagonal entry");
+    if (herr != 0) { h->refill_ready = false; return fail(h, GMG_ERR_STATE, "value refresh failed on the device"); }
+    if (!factor_ok) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
+        if ((rc = upload(h, &h->d_ainv, inv))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (h->cfg.inner_precision && (rc = refresh_fp32_twins(h, false))) return rc;
+    h->timing["coarsest_solve"] = ms_factor;
+    h->timing["setup_ordering_cached"] = 1.0;
+    h->timing["setup_values_only"] = 1.0;
+    h->timing["setup_ordering"] = 0.0; h->timing["setup_sell"] = 0.0; h->timing["setup_wait_ordering"] = 0.0;
+    for (int k = 0; k <= L; ++k) h->timing["setup_ordering_l" + std::to_string(k)] = 0.0;
+    mark("mass_done");
+    h->timing["upload"] = ms_since(t_all) - h->timing["reduction"];
+    h->timing["setup_total"] = ms_since(t_all);
+    h->timing["coarse_host_ms"] = 0.0;
+    return GMG_OK;
+}
+
 int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) {
     NEED_DEVICE();
     if (h->L <= 0) return fail(h, GMG_ERR_STATE, "hierarchy has no transfer levels (U is empty)");
@@ -194,6 +308,19 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     }
     HIPCHK(hipSetDevice(h->cfg.device));
     const int L = h->L;
+    uint64_t pat_key[2] = {0, 0};
+    bool have_key = false;
+    if (h->system_ready && h->live_key_valid && h->refill_ready && (int)h->lv.size() == L + 1 && h->lv[0].n == n) {
+        // Same sparsity pattern as the live system (and the same hierarchy: refill_ready dies with it)?  Then every
+        // structure on the device stands and only values move: LHS values up, numeric Galerkin passes, value refill of
+        // the layouts, numeric LDL^T.  (The demos' usage: lhs = M + tau * S with a new tau per frame.)
+        pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
+        have_key = true;
+        if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz) {
+            int rc = refresh_system_values(h, n, val, t_all);
+            if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything
+        }
+    }
     if (h->system_ready && h->live_key_valid && (int)h->lv.size() == L + 1) {
         h->ord_cache.resize(L + 1);
         for (int k = 0; k <= L; ++k) h->ord_cache[k] = std::move(h->lv[k].ord);
@@ -249,11 +376,11 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     auto wait_lhs = [&] { if (lhs_copied.valid()) lhs_copied.wait(); };
     // pinned staging for one right-hand side (the solve's b / x transfers): page-locking costs milliseconds, do it now
     std::future<int> stage_ready = std::async(std::launch::async, [h, n] { (void)hipSetDevice(h->cfg.device); return ensure_host_stage(h, (size_t)n); });
-    uint64_t pat_key[2];
-    pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
+    if (!have_key) pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
     mark("pattern_key");
     const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1];
     h->timing["setup_ordering_cached"] = ord_hit ? 1.0 : 0.0;
+    h->timing["setup_values_only"] = 0.0;
     h->ord_cache_valid = false;       // a hit moves the cached orderings into the levels; the next call moves them back
     std::shared_future<void> patches_done;      // hierarchies set level by level (gmg_set_prolongation): grown now, in the background
     if (!h->patches_ready && !ord_hit) patches_done = std::async(std::launch::async, [h] { build_patches(h); }).share();
@@ -399,18 +526,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     factor_done = std::async(std::launch::async, [&] {
         auto t = clk::now();
         bool ok = h->coarse.factor(h->lv[L].A, ord_hit);
-        if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
-            const int nl = h->lv[L].A.n_outer;
-            inv.resize((size_t)nl * nl);
-            parallel_ranges(nl, h->cfg.host_threads, [&](int lo, int hi, int) {
-                std::vector<double> e(nl, 0.0), w(nl);
-                for (int j = lo; j < hi; ++j) {
-                    e[j] = 1.0;
-                    h->coarse.solve(e.data(), inv.data() + (size_t)j * nl, w.data());
-                    e[j] = 0.0;
-                }
-            });
-        }
+        if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) coarse_inverse(h, inv);
         ms_factor = ms_since(t);
         return ok;
     });
@@ -528,32 +644,14 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     }
     if (h->cfg.inner_precision) {
         // fp32 twins of every value array (same layout): the inner V-cycle of the mixed-precision iteration
-        auto twin = [&](DevSell& m) -> int {
-            if (!m.val || m.stored <= 0) return GMG_OK;
-            if (m.val32) { (void)dev_free(m.val32); m.val32 = nullptr; }
-            HIPCHK(dev_malloc((void**)&m.val32, sizeof(float) * (size_t)m.stored));
-            launch_cvt(h, m.val, m.val32, (size_t)m.stored);
-            return GMG_OK;
-        };
-        for (int k = 0; k < L; ++k) {
-            Level& l = h->lv[k];
-            int rc;
-            if ((rc = twin(l.Aoff)) || (rc = twin(l.Ain)) || (rc = twin(l.Aout)) || (rc = twin(l.P)) || (rc = twin(l.R))) return rc;
-            if (l.use_bcsr) {
-                if (l.bc_val32) { (void)dev_free(l.bc_val32); l.bc_val32 = nullptr; }
-                HIPCHK(dev_malloc((void**)&l.bc_val32, sizeof(float) * (size_t)std::max<int64_t>(l.bc_nnz, 1)));
-                launch_cvt(h, l.bc_val, l.bc_val32, (size_t)l.bc_nnz);
-            }
-            if (l.diag32) { (void)dev_free(l.diag32); l.diag32 = nullptr; }
-            HIPCHK(dev_malloc((void**)&l.diag32, sizeof(float) * (size_t)l.n_pad));
-            launch_cvt(h, l.diag, l.diag32, (size_t)l.n_pad);
-        }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        int rc = refresh_fp32_twins(h, true);
+        if (rc) return rc;
     }
     h->live_key[0] = pat_key[0]; h->live_key[1] = pat_key[1];
     h->live_key_valid = true;
     h->ord_cache_valid = false;       // (moved into the levels on a hit; refilled from them by the next call)
     h->system_ready = true;
+    h->refill_ready = device_setup && device_rap_ok && h->cfg.device_setup != 0;
     if (!h->mass.empty()) {
         if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
         int rc = upload_mass(h);

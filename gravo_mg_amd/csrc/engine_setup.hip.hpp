@@ -51,7 +51,17 @@ int device_scan(gmg_handle h, const TIn* in, int n, TOut* out, TOut* total_host)
 // filter; d_order: optional slice-position -> device-row map (uploaded by the caller; also stored as row_of);
 // col16: write 16-bit columns into *col16_out (in-block part of a blocked level) instead of out.col.
 int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pend, const int* idx, const double* val, gmgs::RowFilter f,
-                      const int* d_order, int n_rows_pad, int lpr, unsigned short** col16_out, double* d_diag, int* d_err) {
+                      const int* d_order, int n_rows_pad, int lpr, unsigned short** col16_out, double* d_diag, int* d_err, bool refill = false) {
+    if (refill) {        // same pattern as the matrix this layout was built from: slice pointers stand, entries are rewritten
+        if (!out.slice_ptr || !out.val) return fail(h, GMG_ERR_STATE, "refill of a layout that was never built");
+        if (col16_out)
+            hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
+                               n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
+        else
+            hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
+                               out.slice_ptr, out.col, out.val, d_diag, d_err);
+        return GMG_OK;
+    }
     free_sell(out);
     const int rps = 64 / lpr;
     out.lpr = lpr;
@@ -165,9 +175,26 @@ int ensure_host_A(gmg_handle h, int k, bool values) {
 // Ac = U^T A U on the device (setup_kernels.hip.hpp::rap_rows): count pass, device prefix sum, fill pass.  The result
 // stays on the device (dC); `pattern` (row pointers + column indices, for the host ordering of that level) and
 // `values` say what is copied to the host as well.  Returns 1 when the device kernel cannot take the input.
+// reuse_pattern: dC still holds the product of the previous system, whose sparsity pattern (and hierarchy) is the same as
+// this one's -- row pointers and column indices are valid already, only the numeric pass runs (*nnz_out must hold the
+// known count).
 int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& e3, DevCsr& dC, Compressed& C, bool pattern, bool values,
-               int64_t* nnz_out, int* d_err) {
+               int64_t* nnz_out, int* d_err, bool reuse_pattern = false) {
     const int nc = dU.n_outer;
+    if (reuse_pattern && dC.ptr && dC.idx && dC.val && dC.n_outer == nc && *nnz_out > 0 && !pattern) {
+        const int64_t nnz = *nnz_out;
+        hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
+                           (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
+        C.n_outer = nc; C.n_inner = nc;
+        if (values) {
+            int r2;
+            C.ptr.resize((size_t)nc + 1); C.idx.resize((size_t)nnz); C.val.resize((size_t)nnz);
+            if ((r2 = d2h(h, C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1))) || (r2 = d2h(h, C.idx.data(), dC.idx, sizeof(int) * (size_t)nnz)) ||
+                (r2 = d2h(h, C.val.data(), dC.val, sizeof(double) * (size_t)nnz))) return r2;
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        return GMG_OK;
+    }
     free_csr(dC);
     dC.n_outer = nc;
     DevTmp<int> cnt;
@@ -212,7 +239,15 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         std::fprintf(stderr, "[gmg setup] level %d %-10s %.2f ms\n", k, what, ms_since(tph));
         tph = clk::now();
     };
-    DevTmp<int> d_old2new, d_blk_of_row;
+    struct Ref {
+        int*& p;
+        int alloc(gmg_handle h, size_t n) {
+            if (p) { (void)dev_free(p); p = nullptr; }
+            HIPCHK(dev_malloc((void**)&p, std::max<size_t>(n, 1) * sizeof(int)));
+            return GMG_OK;
+        }
+    };
+    Ref d_old2new{l.d_old2new}, d_blk_of_row{l.d_blk_of_row};       // owned by the level (refresh_system_values reuses them)
     if (!l.dA.ptr) {
         if ((rc = ensure_host_A(h, k, true)) || (rc = upload_csr(h, l.dA, l.A))) return rc;
     }
@@ -309,6 +344,28 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     }
     HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
     phase("P");
+    return GMG_OK;
+}
+
+// The value arrays of level k's operator layouts rewritten from Level::dA (same sparsity pattern as when they were
+// built, new values): the fill kernels of device_layout_level without its counting, scanning and allocating.
+int device_refill_level(gmg_handle h, int k, int* d_err) {
+    Level& l = h->lv[k];
+    int rc;
+    if (!l.dA.ptr || !l.d_old2new || !l.d_new2old || !l.diag) return fail(h, GMG_ERR_STATE, "level layout cannot be refilled");
+    const DevCsr& dA = l.dA;
+    gmgs::RowFilter f{l.d_new2old, l.d_old2new, nullptr, nullptr, 0, 1};
+    if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, l.Aoff.lpr, nullptr, l.diag, d_err, true))) return rc;
+    if (l.ord.blocked) {
+        if (!l.d_blk_of_row || !l.d_blk_begin) return fail(h, GMG_ERR_STATE, "level layout cannot be refilled");
+        gmgs::RowFilter fin{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 1, 1};
+        gmgs::RowFilter fout{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 2, 1};
+        if (l.use_bcsr)
+            hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, l.d_blk_of_row,
+                               l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
+        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, l.Ain.lpr, &l.ain_col16, nullptr, d_err, true)) ||
+            (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
+    }
     return GMG_OK;
 }
 

@@ -93,6 +93,8 @@ struct Level {
     int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
     unsigned char* d_row_color = nullptr;
     int* d_new2old = nullptr;
+    int* d_old2new = nullptr;         // kept after the layout (with d_blk_of_row) so that a system with the same pattern can
+    int* d_blk_of_row = nullptr;      // refill the value arrays in place (refresh_system_values)
     double *x = nullptr, *b = nullptr, *r = nullptr, *tmp = nullptr;   // n_pad * dcap
     float *diag32 = nullptr, *x32 = nullptr, *b32 = nullptr, *r32 = nullptr, *tmp32 = nullptr;   // mixed precision
 };
@@ -151,6 +153,8 @@ struct gmg_solver_s {
     hipStream_t own_stream = nullptr;
     int rank = 0, world = 1;
     bool dist_ready = false;
+    bool refill_ready = false;        // the live layout was built by the device builders from device-resident A_k: a system with
+                                      // the same sparsity pattern only needs its values refreshed
     bool dist_all_rows = false;
     double *own_x0 = nullptr, *own_b0 = nullptr, *own_r0 = nullptr;   // engine-owned buffers parked while external ones are bound
     bool bound = false;
@@ -363,6 +367,8 @@ void free_level(Level& l) {
     for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)dev_free(*p); *p = nullptr; }
     for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)dev_free(*p); *p = nullptr; }
     if (l.d_new2old) { (void)dev_free(l.d_new2old); l.d_new2old = nullptr; }
+    if (l.d_old2new) { (void)dev_free(l.d_old2new); l.d_old2new = nullptr; }
+    if (l.d_blk_of_row) { (void)dev_free(l.d_blk_of_row); l.d_blk_of_row = nullptr; }
 }
 
 void drop_graphs(gmg_handle h) {
@@ -376,6 +382,7 @@ void unbind_level0(gmg_handle h) {
 }
 
 void drop_system(gmg_handle h) {
+    h->refill_ready = false;
     drop_graphs(h);
     unbind_level0(h);
     h->dist_ready = false;
