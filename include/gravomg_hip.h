@@ -101,7 +101,11 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
 int gmg_set_mass(gmg_handle h, int n, const double* mass_diag);
 /* LHS for the next solves.  Performs what solve() does before its loop (multigrid_solver.cpp:1387-1401):
  * Galerkin products Abar[k] = U[k-1]^T Abar[k-1] U[k-1], coarsest LDL^T factorisation, plus the device
- * layout (colouring, SELL) and the upload.  Timings land in "reduction", "coarsest_solve", "upload". */
+ * layout (colouring, SELL) and the upload.  Timings land in "reduction", "coarsest_solve", "upload".
+ * The reference recomputes all of this on every solve(); here a matrix with the sparsity pattern of the live system
+ * (recognised by a 128-bit digest of colptr/rowidx) only refreshes values in place -- numeric Galerkin passes, layout
+ * refill, numeric LDL^T; timing key "setup_values_only" = 1 -- and a matrix with a pattern seen before on this handle
+ * reuses the orderings ("setup_ordering_cached" = 1).  Results are those of a fresh handle in every case. */
 int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val);
 
 /* ---- introspection -------------------------------------------------------------------------- */
