@@ -318,6 +318,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         have_key = true;
         if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz) {
             int rc = refresh_system_values(h, n, val, t_all);
+            if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
             if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything
         }
     }
