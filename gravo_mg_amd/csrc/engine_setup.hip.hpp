@@ -183,7 +183,7 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
     const int nc = dU.n_outer;
     if (reuse_pattern && dC.ptr && dC.idx && dC.val && dC.n_outer == nc && *nnz_out > 0 && !pattern) {
         const int64_t nnz = *nnz_out;
-        hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
+        hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                            (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
         C.n_outer = nc; C.n_inner = nc;
         if (values) {

@@ -309,7 +309,8 @@ __global__ void ell3_sort(const int* __restrict__ cnt, int n, int* __restrict__ 
 //     for i in column p of U (ascending) / for j in row i of A (as stored) / for c in row j of U (ascending)
 // in the SAME order as the host implementation (host_sparse.hpp::galerkin_rap), adding w = (u_ip a_ij) * u_jq to its
 // accumulator when q matches -- with separately rounded multiply and add, so the result is bitwise the host's.
-// PASS 0 only counts the distinct columns (row lengths for the prefix sum).
+// PASS 0 only counts the distinct columns (row lengths for the prefix sum); PASS 2 is the numeric step alone, for a
+// product whose pattern (c_ptr, c_idx) is already known.
 constexpr int kRapSlots = 192;     // (column, product) list of one chunk of children in LDS: 3 per entry of A
 constexpr int kRapSet = 256;      // hash-set capacity per coarse row (rows with more distinct columns -> host fallback)
 template <int PASS>
@@ -326,6 +327,15 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
     for (int s = lane; s < kRapSet; s += 64) keys[s] = 0x7fffffff;
     __syncthreads();
     const int ub = u_cptr[p], ue = u_cptr[p + 1];
+    int cnt = 0;
+    if (PASS == 2) {
+        // the row's sorted columns are known (same sparsity pattern as the product c_idx was computed from): no hash set,
+        // no sort -- straight to the numeric step
+        const int o0 = c_ptr[p];
+        cnt = c_ptr[p + 1] - o0;
+        for (int s = lane; s < cnt; s += 64) keys[s] = c_idx[o0 + s];
+        __syncthreads();
+    } else {
     // ---- step 1: set of distinct coarse columns
     for (int t = ub + lane; t < ue; t += 64) {
         const int i = u_ridx[t];
@@ -359,9 +369,9 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
             }
             __syncthreads();
         }
-    int cnt = 0;
     for (int s = lane; s < kRapSet; s += 64) cnt += keys[s] != 0x7fffffff;
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    }
     if (PASS == 0) {
         if (lane == 0) c_cnt[p] = cnt;
         return;
