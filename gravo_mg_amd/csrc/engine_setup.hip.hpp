@@ -195,6 +195,14 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
         }
         return GMG_OK;
     }
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;      // synchronising phase timers on stderr
+    auto tph = clk::now();
+    auto phase = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(h->stream);
+        std::fprintf(stderr, "[gmg setup] rap nc=%d %-10s %.2f ms\n", nc, what, ms_since(tph));
+        tph = clk::now();
+    };
     free_csr(dC);
     dC.n_outer = nc;
     DevTmp<int> cnt;
@@ -203,6 +211,7 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
     HIPCHK(dev_malloc((void**)&dC.ptr, sizeof(int) * ((size_t)nc + 1)));
     hipLaunchKernelGGL(gmgs::rap_rows<0>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                        (const int*)nullptr, cnt.p, (int*)nullptr, (double*)nullptr, d_err);
+    phase("count");
     int nnz = 0, herr = 0;
     if ((rc = device_scan<int, int>(h, cnt.p, nc, dC.ptr, &nnz))) return rc;
     HIPCHK(hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -212,15 +221,18 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
         { int r2 = d2h(h, C.ptr.data(), dC.ptr, sizeof(int) * ((size_t)nc + 1)); if (r2) return r2; }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    phase("scan+ptr");
     if (herr) { free_csr(dC); return 1; }       // a coarse row overflows the device hash set (or a U row has > 3 entries): host fallback
     *nnz_out = nnz;
     HIPCHK(dev_malloc((void**)&dC.idx, sizeof(int) * std::max(nnz, 1)));
     HIPCHK(dev_malloc((void**)&dC.val, sizeof(double) * std::max(nnz, 1)));
     hipLaunchKernelGGL(gmgs::rap_rows<1>, dim3(nc), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                        (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err);
+    phase("numeric");
     if (pattern || values) { C.idx.resize(nnz); { int r2 = d2h(h, C.idx.data(), dC.idx, sizeof(int) * nnz); if (r2) return r2; } }
     if (values) { C.val.resize(nnz); { int r2 = d2h(h, C.val.data(), dC.val, sizeof(double) * nnz); if (r2) return r2; } }
     if (pattern || values) HIPCHK(hipStreamSynchronize(h->stream));
+    phase("fetch");
     return GMG_OK;
 }
 

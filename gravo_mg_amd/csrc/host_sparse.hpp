@@ -20,6 +20,9 @@
 #include <mutex>
 #include <pthread.h>
 #include <sched.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <new>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -31,10 +34,30 @@ namespace gmg {
 // std::allocator whose value-less construct() default-initialises: resize(n) of a vector of ints / doubles allocates
 // without writing, so a 36-70 MB index / value array is first touched by whoever fills it (the threaded copies) instead
 // of being zero-filled, page fault by page fault, on the calling thread (~0.17 ms per MB).
+// Large blocks are 2 MiB-aligned and marked MADV_HUGEPAGE: first-touching fresh 4 KiB pages costs ~0.17 ms per MB and
+// does not scale with threads (the faults serialise on the process's memory map), so a 36 MB pattern fetched from the
+// device took 8 ms where the copy itself needs 1.5.
 template <class T>
 struct default_init_allocator : std::allocator<T> {
     template <class U> struct rebind { using other = default_init_allocator<U>; };
     using std::allocator<T>::allocator;
+    static constexpr size_t kHuge = (size_t)2 << 20;
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= 2 * kHuge) {
+            void* q = nullptr;
+            const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+            if (posix_memalign(&q, kHuge, rounded) == 0) {
+                (void)madvise(q, rounded, MADV_HUGEPAGE);
+                return static_cast<T*>(q);
+            }
+            throw std::bad_alloc();
+        }
+        void* q = std::malloc(std::max<size_t>(bytes, 1));
+        if (!q) throw std::bad_alloc();
+        return static_cast<T*>(q);
+    }
+    void deallocate(T* p, size_t) noexcept { std::free(p); }
     template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
     template <class U, class... Args> void construct(U* p, Args&&... args) { ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...); }
 };
