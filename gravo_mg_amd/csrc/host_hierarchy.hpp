@@ -229,12 +229,12 @@ public:
             // chunk order afterwards (= the sequential emission order).
             const int nchunk = nf >= 8192 ? T : 1;
             const int chunk_len = (nf + nchunk - 1) / nchunk;
-            struct Chunk { std::vector<int> row, col; std::vector<double> val; std::array<int, 4> kinds{0, 0, 0, 0}; };
+            struct Chunk { IndexVec row, col; ValueVec val; std::array<int, 4> kinds{0, 0, 0, 0}; };
             std::vector<Chunk> chunks(nchunk);
             parallel_ranges(nchunk, nchunk, [&](int q0, int q1, int) {
             for (int q = q0; q < q1; ++q) {
             Chunk& ck = chunks[q];
-            std::vector<int>& trow = ck.row; std::vector<int>& tcol = ck.col; std::vector<double>& tval = ck.val;
+            IndexVec& trow = ck.row; IndexVec& tcol = ck.col; ValueVec& tval = ck.val;
             std::array<int, 4>& kinds = ck.kinds;
             const int f_lo = q * chunk_len, f_hi = std::min(nf, f_lo + chunk_len);
             trow.reserve((size_t)(f_hi - f_lo) * 3); tcol.reserve((size_t)(f_hi - f_lo) * 3); tval.reserve((size_t)(f_hi - f_lo) * 3);
@@ -299,18 +299,22 @@ public:
             }
             }
             }, 1);
-            std::vector<int> trow, tcol; std::vector<double> tval;
+            IndexVec trow, tcol; ValueVec tval;           // (not zero-filled, huge pages: 144 MB at 3 M vertices)
             std::array<int, 4> kinds{0, 0, 0, 0};
             {
-                size_t total = 0;
-                for (auto& ck : chunks) total += ck.row.size();
-                trow.reserve(total); tcol.reserve(total); tval.reserve(total);
-                for (auto& ck : chunks) {
-                    trow.insert(trow.end(), ck.row.begin(), ck.row.end());
-                    tcol.insert(tcol.end(), ck.col.begin(), ck.col.end());
-                    tval.insert(tval.end(), ck.val.begin(), ck.val.end());
-                    for (int z = 0; z < 4; ++z) kinds[z] += ck.kinds[z];
-                }
+                std::vector<size_t> at((size_t)nchunk + 1, 0);
+                for (int q = 0; q < nchunk; ++q) at[q + 1] = at[q] + chunks[q].row.size();
+                const size_t total = at[nchunk];
+                trow.resize(total); tcol.resize(total); tval.resize(total);
+                parallel_ranges(nchunk, nchunk, [&](int q0, int q1, int) {
+                    for (int q = q0; q < q1; ++q) {
+                        const Chunk& ck = chunks[q];
+                        std::copy(ck.row.begin(), ck.row.end(), trow.begin() + at[q]);
+                        std::copy(ck.col.begin(), ck.col.end(), tcol.begin() + at[q]);
+                        std::copy(ck.val.begin(), ck.val.end(), tval.begin() + at[q]);
+                    }
+                }, 1);
+                for (auto& ck : chunks) for (int z = 0; z < 4; ++z) kinds[z] += ck.kinds[z];
             }
             auto t6 = clk::now();
             R.timing["triangle_selection"] += ms(t5, t6);
@@ -455,7 +459,7 @@ private:
     // the list: they are merged there, then the columns are filled on all cores (atomic slot counters) and each column
     // is sorted by row -- every (row, column) is unique by then, so the result does not depend on the fill order.
     // (the triplet values are consumed: duplicates inside a row are merged into the first occurrence in place)
-    static Compressed from_triplets(int nrows, int ncols, const std::vector<int>& r, const std::vector<int>& c, std::vector<double>& vm) {
+    static Compressed from_triplets(int nrows, int ncols, const IndexVec& r, const IndexVec& c, ValueVec& vm) {
         const size_t nt = r.size();
         std::unique_ptr<char[]> keep(new char[std::max<size_t>(nt, 1)]);
         const int Tm = std::max(1, std::min(hw_threads(), 64));
