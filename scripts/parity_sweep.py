@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Parity sweep at oracle-checkable sizes: many problem kinds x engine variants, GPU solve vs the 1-core oracle solve of
+the same system (same hierarchy, same stopping test).  Per case: V-cycles to tolerance on both sides, the M-norm
+distance of the two solutions relative to the solution, the oracle's residualCheck of the GPU solution.
+
+  python scripts/parity_sweep.py > profiles/r01/parity_sweep.json
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from gravo_mg_amd import cabi, meshgen  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+
+def problems():
+    rng = np.random.default_rng(7)
+    for n1, n2, order in ((60, 50, "natural"), (180, 150, "natural"), (400, 380, "natural"), (400, 380, "random"), (700, 640, "natural")):
+        V, F = meshgen.torus_mesh(n1, n2, order=order)
+        S, mass = meshgen.cotan_laplacian(V, F)
+        yield f"torus {n1}x{n2} {order} Poisson d=1", V, S, mass, *meshgen.poisson_system(S, mass), 1e-4
+        if n1 <= 400:
+            yield f"torus {n1}x{n2} {order} smoothing d=3", V, S, mass, *meshgen.smoothing_system(S, mass, V), 1e-6
+    for n in (20_000, 200_000):
+        P = meshgen.torus_points(n, noise=0.002)
+        S, mass = meshgen.knn_graph_laplacian(P, 8)
+        yield f"point cloud {n} kNN(8) Poisson d=1", P, S, mass, *meshgen.poisson_system(S, mass), 1e-4
+    for n in (30_000, 300_000):
+        V, F = meshgen.sphere_mesh(n)
+        S, mass = meshgen.cotan_laplacian(V, F)
+        lhs, rhs = meshgen.poisson_system(S, mass, d=2, seed=int(rng.integers(1 << 30)))
+        yield f"irregular sphere {n} Poisson d=2", V, S, mass, lhs, rhs, 1e-4
+
+
+VARIANTS = {
+    "default": {},
+    "device-coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
+    "jacobi": dict(smoother=cabi.SMOOTHER_JACOBI) if hasattr(cabi, "SMOOTHER_JACOBI") else None,
+    "host-builders": dict(device_setup=False),
+    "graph": dict(use_graph=True),
+}
+
+
+def main():
+    oracle.build()
+    out, worst = [], 0.0
+    for name, V, S, mass, lhs, rhs, tol in problems():
+        nb = meshgen.neighbors_from_stiffness(S)
+        H = cabi.Hierarchy(V, nb, ratio=8.0, lower_bound=1000 if V.shape[0] > 20_000 else 100)
+        if len(H.U) == 0:
+            continue
+        O = oracle.Hierarchy(H.U, mass)
+        t = time.perf_counter()
+        O.set_system(lhs)
+        xo, ito, reso, _ = O.solve(rhs, tol=tol, stop_type=2, max_iter=100)
+        t_oracle = time.perf_counter() - t
+        xnorm = np.sqrt((mass[:, None] * xo ** 2).sum())
+        for vname, kw in VARIANTS.items():
+            if kw is None:
+                continue
+            eng = cabi.Engine(**kw)
+            eng.use_hierarchy(H); eng.set_mass(mass); eng.set_system(lhs)
+            x, it, res, _ = eng.solve(rhs, tol=tol, stop_type=2, max_iter=100)
+            dist = float(np.sqrt((mass[:, None] * (x - xo) ** 2).sum()) / xnorm)
+            chk = float(oracle.residual_check(lhs, mass, rhs, x, 2))
+            jac = vname == "jacobi"
+            rec = {"problem": name, "n": int(V.shape[0]), "levels": len(H.U), "variant": vname, "tolerance": tol,
+                   "gpu_iterations": int(it), "oracle_iterations": int(ito), "gpu_residue": float(res), "oracle_residue": float(reso),
+                   "oracle_check_of_gpu_solution": chk, "solution_distance_M_rel": dist, "oracle_seconds": t_oracle,
+                   "ok": bool(chk <= tol * 1.0001 and abs(chk - res) <= 1e-3 * max(chk, 1e-300) + 1e-9 and dist <= 30 * tol and (jac or abs(it - ito) <= max(2, ito // 3)))}
+            worst = max(worst, dist / tol)
+            out.append(rec)
+            print(json.dumps(rec), flush=True)
+            del eng
+    print(json.dumps({"cases": len(out), "all_ok": all(r["ok"] for r in out), "worst_solution_distance_over_tolerance": worst,
+                      "iteration_pairs_gs": sorted({(r["gpu_iterations"], r["oracle_iterations"]) for r in out if r["variant"] != "jacobi"})}))
+
+
+if __name__ == "__main__":
+    main()
