@@ -435,15 +435,29 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
             int ncol = 0;
             for (int m = mem_begin[b]; m < mem_begin[b + 1]; ++m) {
                 const int v = members[m];
-                forbid.assign((size_t)ncol + 1, 0);
+                // the members come in breadth-first order, their rows from all over A: fetch the row a few members ahead
+                if (m + 6 < mem_begin[b + 1]) { const int vn = members[m + 6]; __builtin_prefetch(&A.idx[A.ptr[vn]]); __builtin_prefetch(&A.idx[A.ptr[vn]] + 16); }
+                // first free colour from a 64-bit mask of the neighbours' colours (the general list only beyond 64 colours)
+                uint64_t mask = 0;
                 for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) {
-                    int w = A.idx[p];
-                    if (w != v && block_of[w] == b && color[w] >= 0) forbid[color[w]] = 1;
+                    const int w = A.idx[p];
+                    if (w == v || block_of[w] != b) continue;
+                    const int cw = color[w];
+                    if (cw >= 0 && cw < 64) mask |= (uint64_t)1 << cw;
                 }
-                int c = 0;
-                while (c < ncol && forbid[c]) ++c;
+                int c;
+                if (~mask != 0) c = __builtin_ctzll(~mask);
+                else {
+                    forbid.assign((size_t)ncol + 1, 0);
+                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) {
+                        const int w = A.idx[p];
+                        if (w != v && block_of[w] == b && color[w] >= 0) forbid[color[w]] = 1;
+                    }
+                    c = 64;
+                    while (c < ncol && forbid[c]) ++c;
+                }
                 color[v] = c;
-                if (c == ncol) ++ncol;
+                if (c >= ncol) ncol = c + 1;
             }
             mem.assign(members.begin() + mem_begin[b], members.begin() + mem_begin[b + 1]);
             std::stable_sort(mem.begin(), mem.end(), [&](int x, int y) { return color[x] < color[y]; });
