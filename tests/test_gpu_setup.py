@@ -133,16 +133,22 @@ def test_ordering_cache_reused_for_same_pattern(cabi):
     assert eng.timing("setup_ordering_cached") == 0.0
 
 
-@pytest.mark.parametrize("variant", ["default", "mixed", "device-coarse", "host-builders", "d3-blockcsr"])
+@pytest.mark.parametrize("variant", ["default", "mixed", "device-coarse", "host-builders", "d3-blockcsr", "random-order", "jacobi"])
 def test_same_pattern_refreshes_values_in_place(cabi, variant):
     """A system with the sparsity pattern of the live one (new tau) only moves values: LHS values up, numeric Galerkin
     passes, value refill of the layouts, numeric LDL^T (timing key setup_values_only).  Every array on the device and
     every iterate must equal what a fresh engine builds from scratch -- bitwise."""
     import scipy.sparse as sp
     big = variant == "d3-blockcsr"
-    P = problems.torus_problem(300, 280, "smoothing", 400) if big else problems.torus_problem(96, 80, "smoothing", 60)
+    if big:
+        P = problems.torus_problem(300, 280, "smoothing", 400)
+    elif variant == "random-order":       # level 0 renumbered for locality (cluster order from the hierarchy)
+        P = problems.torus_problem(160, 140, "smoothing", 100, order="random")
+    else:
+        P = problems.torus_problem(96, 80, "smoothing", 60)
     kw = {"mixed": dict(inner_precision=1), "device-coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
-          "host-builders": dict(device_setup=False), "d3-blockcsr": dict(block_lanes=1)}.get(variant, {})
+          "host-builders": dict(device_setup=False), "d3-blockcsr": dict(block_lanes=1),
+          "jacobi": dict(smoother=cabi.SMOOTHER_JACOBI)}.get(variant, {})
     lhs2 = (sp.diags(P.mass) + 7e-3 * P.S).tocsc()
     lhs3 = (sp.diags(P.mass) + 2e-4 * P.S).tocsr()          # CSR of a symmetric matrix: same arrays as its CSC
     eng = cabi.Engine(**kw)
