@@ -102,17 +102,18 @@ public:
         while ((int)P.size() > opt.lower_bound && level < 10) {                      // :103
             const int nf = (int)P.size();
             auto te = clk::now();
-            const double radius = std::cbrt(opt.ratio) * average_edge_length(P, NB, nbK);   // :104
+            ValueVec EL;
+            const double radius = std::cbrt(opt.ratio) * average_edge_length(P, NB, nbK, EL);   // :104
             R.timing["edge_length"] += ms(te, clk::now());
             std::vector<double> D(nf, std::numeric_limits<double>::max());
             std::vector<int> nearest(nf, 0);
             auto t0 = clk::now();
-            std::vector<int> sample = fast_disk_sample(P, NB, nbK, radius, D, nearest);     // :128
+            std::vector<int> sample = fast_disk_sample(P, NB, nbK, radius, D, nearest, EL);     // :128
             if ((int)sample.size() < opt.lower_bound) break;                                // :156-159
             const int nc = (int)sample.size();
             auto t1 = clk::now();
             R.timing["sampling"] += ms(t0, t1);
-            voronoi_dijkstra(P, sample, NB, nbK, D, nearest);                               // :170
+            voronoi_dijkstra(P, sample, NB, nbK, D, nearest, EL);                           // :170
             auto t2 = clk::now();
             R.timing["cluster"] += ms(t1, t2);
 
@@ -337,24 +338,32 @@ public:
     }
 
 private:
-    // (sequential on purpose: the loop is bound by its chain of dependent additions, ~1.3 ns each, and the radius must
-    // have the bits of the reference's running sum; computing the lengths on all threads first was slower, 38 -> 72 ms)
-    static double average_edge_length(detail::View<V3> P, detail::View<int> NB, int K) {   // :695-711
-        double sum = 0.0; long cnt = 0;
+    // EL keeps every edge length (slot i*K + j = |P[i] - P[NB[i*K + j]]|): the sampler and the clustering need the same
+    // lengths again (56 per sample, one per relaxation) and read them instead of recomputing gathers + square roots.
+    static double average_edge_length(detail::View<V3> P, detail::View<int> NB, int K, ValueVec& EL) {   // :695-711
         const int n = (int)P.size();
-        for (int i = 0; i < n; ++i)
-            for (int j = 0; j < K; ++j) {
-                int g = NB[(size_t)i * K + j];
-                if (g < 0) continue;
-                double d = detail::norm(P[i] - P[g]);
-                if (d > 0) { sum += d; ++cnt; }
-            }
+        EL.resize((size_t)n * K);
+        // the lengths (gathers + square roots) on all threads ...
+        parallel_ranges(n, hw_threads(), [&](int lo, int hi, int) {
+            for (int i = lo; i < hi; ++i)
+                for (int j = 0; j < K; ++j) {
+                    const int g = NB[(size_t)i * K + j];
+                    EL[(size_t)i * K + j] = g < 0 ? 0.0 : detail::norm(P[i] - P[g]);
+                }
+        }, 1 << 14);
+        // ... their sum in the reference's order (i outer, j inner): absent and zero-length edges hold +0.0 and are skipped
+        // like there, so the running sum has the bits of the sequential loop
+        double sum = 0.0; long cnt = 0;
+        const size_t m = (size_t)n * K;
+        const double* el = EL.data();
+        for (size_t q = 0; q < m; ++q)
+            if (el[q] > 0) { sum += el[q]; ++cnt; }
         return sum / (double)cnt;
     }
 
     // :975-1013  greedy disk sampling over the one- and two-ring, first come first served in index order
     static std::vector<int> fast_disk_sample(detail::View<V3> P, detail::View<int> NB, int K, double radius,
-                                             std::vector<double>& D, std::vector<int>& nearest) {
+                                             std::vector<double>& D, std::vector<int>& nearest, const ValueVec& EL) {
         const int n = (int)P.size();
         std::vector<char> visited(n, 0);
         std::vector<int> sel;
@@ -366,14 +375,14 @@ private:
             for (int j = 0; j < K; ++j) {
                 int g = NB[(size_t)i * K + j];
                 if (g < 0) break;
-                double d1 = detail::norm(P[i] - P[g]);
+                double d1 = EL[(size_t)i * K + j];                      // = norm(P[i] - P[g])
                 if (!(d1 < radius)) continue;
                 visited[g] = 1;
                 if (d1 < D[g]) { D[g] = d1; nearest[g] = sidx; }
                 for (int j2 = 0; j2 < K; ++j2) {
                     int g2 = NB[(size_t)g * K + j2];
                     if (g2 < 0) break;
-                    double d2 = d1 + detail::norm(P[g] - P[g2]);
+                    double d2 = d1 + EL[(size_t)g * K + j2];            // = d1 + norm(P[g] - P[g2])
                     if (d2 < radius) {
                         visited[g2] = 1;
                         if (d2 < D[g2]) { D[g2] = d2; nearest[g2] = sidx; }
@@ -386,7 +395,7 @@ private:
 
     // :1015-1056  multi-source Dijkstra; D/nearest arrive pre-seeded by the sampler and are only ever lowered
     static void voronoi_dijkstra(detail::View<V3> P, const std::vector<int>& src, detail::View<int> NB, int K,
-                                 std::vector<double>& D, std::vector<int>& nearest) {
+                                 std::vector<double>& D, std::vector<int>& nearest, const ValueVec& EL) {
         std::priority_queue<detail::HeapItem, std::vector<detail::HeapItem>, std::greater<detail::HeapItem>> heap;
         for (int i = 0; i < (int)src.size(); ++i) {
             D[src[i]] = 0.0;
@@ -400,7 +409,7 @@ private:
             for (int j = 0; j < K; ++j) {
                 int g = NB[(size_t)it.v * K + j];
                 if (g < 0) continue;
-                double cand = it.dist + detail::norm(P[g] - P[it.v]);
+                double cand = it.dist + EL[(size_t)it.v * K + j];      // = norm(P[g] - P[it.v]): the same squares, the same sum
                 if (cand < D[g]) { D[g] = cand; heap.push({g, cand}); nearest[g] = owner; }
             }
         }
