@@ -63,6 +63,23 @@ inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b
 inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
 inline V3 normalized(V3 a) { double z = dot(a, a); return z > 0 ? (1.0 / std::sqrt(z)) * a : a; }
 struct HeapItem { int v; double dist; bool operator>(const HeapItem& o) const { return dist > o.dist; } };
+// std::map<int, float> for a handful of keys (the "inside edge" bookkeeping of one fine point: two keys per tested
+// triangle): same interface and the same ascending-key iteration order, but a sorted array instead of a heap node per
+// key -- the map's allocations were a third of the triangle selection.
+struct SmallIntFloatMap {
+    std::vector<std::pair<int, float>> kv;
+    void clear() { kv.clear(); }
+    size_t find_pos(int key) const { size_t i = 0; while (i < kv.size() && kv[i].first < key) ++i; return i; }
+    int count(int key) const { const size_t i = find_pos(key); return i < kv.size() && kv[i].first == key; }
+    float& operator[](int key) {
+        const size_t i = find_pos(key);
+        if (i == kv.size() || kv[i].first != key) kv.insert(kv.begin() + i, {key, 0.f});
+        return kv[i].second;
+    }
+    std::vector<std::pair<int, float>>::const_iterator begin() const { return kv.begin(); }
+    std::vector<std::pair<int, float>>::const_iterator end() const { return kv.end(); }
+};
+
 // Read-only window on a contiguous array: the caller's positions / neighbour table on level 0 (no 170 MB copy), the
 // builder's own vectors on the coarser levels.
 template <class T>
@@ -240,7 +257,7 @@ public:
             const int f_lo = q * chunk_len, f_hi = std::min(nf, f_lo + chunk_len);
             trow.reserve((size_t)(f_hi - f_lo) * 3); tcol.reserve((size_t)(f_hi - f_lo) * 3); tval.reserve((size_t)(f_hi - f_lo) * 3);
             auto emit = [&](int f, int c, double w) { trow.push_back(f); tcol.push_back(c); tval.push_back(w); };
-            std::map<int, float> inside_edge;
+            detail::SmallIntFloatMap inside_edge;
             for (int f = f_lo; f < f_hi; ++f) {
                 const V3 p = P[f];
                 const int c = nearest[f];
@@ -418,7 +435,7 @@ private:
     // :471-507  barycentric test of the projection of p onto the triangle's plane; returns |distance to plane|
     // when inside, -1 otherwise, and records the "inside edge" bookkeeping.
     static double in_triangle(V3 p, const std::array<int, 3>& tri, V3 nrm, const std::vector<V3>& pos, double bary[3],
-                              std::map<int, float>& inside_edge) {
+                              detail::SmallIntFloatMap& inside_edge) {
         const V3 v1 = pos[tri[0]], v2 = pos[tri[1]], v3 = pos[tri[2]];
         const V3 v1p = p - v1, e12 = v2 - v1, e13 = v3 - v1;
         const double plane_dist = detail::dot(p - v1, nrm);
