@@ -1293,14 +1293,16 @@ int gmg_finalize_hierarchy(gmg_handle h) {
     if (!h->has_device) return GMG_OK;
     // data that belongs to the hierarchy, not to a system (gmg_set_system would make it on its first call otherwise):
     // the compact patches of the blocked levels, the device copies of U_k
-    if (!h->patches_ready) build_patches(h);
+    // (the patches are host work on helper threads, the transfers device work driven from this thread: side by side)
+    std::future<void> patches;
+    if (!h->patches_ready) patches = std::async(std::launch::async, [h] { build_patches(h); });
+    int rc = GMG_OK;
     if (h->cfg.device_setup) {
         PoolScope pool_scope_(&h->pool);
-        HIPCHK(hipSetDevice(h->cfg.device));
-        int rc = ensure_device_transfers(h);
-        if (rc) return rc;
+        rc = hipSetDevice(h->cfg.device) == hipSuccess ? ensure_device_transfers(h) : fail(h, GMG_ERR_HIP, "hipSetDevice failed");
     }
-    return GMG_OK;
+    if (patches.valid()) patches.get();
+    return rc;
 }
 
 int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const double* a_val, int n_coarse, const int* u_colptr,

@@ -329,6 +329,9 @@ void drop_device_transfers(gmg_handle h) {
 // Patches of every blocked level k >= 1 (see coarse_point_graph): depend on the hierarchy and on block_rows only.
 void build_patches(gmg_handle h) {
     const int L = h->L;
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    auto t_bp = clk::now();
+    auto tr = [&](const char* what, clk::time_point t0) { if (trace) std::fprintf(stderr, "[gmg setup] build_patches %-18s %.2f ms (at %.2f)\n", what, ms_since(t0), ms_since(t_bp)); };
     h->patches.assign(L + 1, PatchSet());
     h->cluster_order.clear();
     const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
@@ -339,17 +342,23 @@ void build_patches(gmg_handle h) {
         for (int k = 0; k < L; ++k) jobs.push_back(std::async(std::launch::async, [h, k, &Urows] { Urows[k] = transpose_parallel(h->U[k]); }));
         for (auto& j : jobs) j.get();
     }
+    tr("transposes", t_bp);
     std::vector<std::future<void>> jobs;
     if (mc && h->cfg.block_rows > 0)
         for (int k = std::max(1, h->cfg.block_from_level); k < L; ++k)
-            jobs.push_back(std::async(std::launch::async, [h, k, &Urows] {
+            jobs.push_back(std::async(std::launch::async, [h, k, &Urows, &tr] {
+                auto t0 = clk::now();
                 Compressed G = coarse_point_graph(h->U[k - 1], Urows[k - 1]);
+                tr(("point graph l" + std::to_string(k)).c_str(), t0); t0 = clk::now();
                 h->patches[k] = grow_patch_set(G, h->cfg.block_rows);
+                tr(("grow patches l" + std::to_string(k)).c_str(), t0);
             }));
     if (mc && h->cfg.reorder_fine != 0 && L > 0)
-        jobs.push_back(std::async(std::launch::async, [h, L, &Urows] {
+        jobs.push_back(std::async(std::launch::async, [h, L, &Urows, &tr] {
+            auto t0 = clk::now();
             Compressed GL = coarse_point_graph(h->U[L - 1], Urows[L - 1]);
             h->cluster_order = cluster_order(Urows, GL);
+            tr("cluster order", t0);
         }));
     for (auto& j : jobs) j.get();
     h->patches_ready = true;

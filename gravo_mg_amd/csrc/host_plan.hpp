@@ -375,6 +375,7 @@ inline Compressed coarse_point_graph(const Compressed& U, const Compressed& Urow
     parallel_ranges(nc, std::min(hw_threads(), 32), [&](int lo, int hi, int) {
         for (int p = lo; p < hi; ++p) {
             std::vector<int>& a = adj[p];
+            a.reserve((size_t)(U.ptr[p + 1] - U.ptr[p]) * 3 + 1);      // exact upper bound: one allocation per point
             for (int e = U.ptr[p]; e < U.ptr[p + 1]; ++e) {
                 const int i = U.idx[e];
                 for (int f = Urows.ptr[i]; f < Urows.ptr[i + 1]; ++f) a.push_back(Urows.idx[f]);
