@@ -41,9 +41,17 @@ static inline double ms_since(clk::time_point t0) { return std::chrono::duration
 #include "engine_cycle.hip.hpp"
 
 // =========================================================================================================
+// No exception leaves the C-ABI: std::bad_alloc (a 3 M-vertex set-up allocates hundreds of MB on the host), a failed
+// thread start, ... become a status code + gmg_last_error.
+#define GMG_CATCH_H                                                                                             \
+    catch (const std::exception& e_) { return h ? fail(h, GMG_ERR_STATE, std::string("exception: ") + e_.what()) : GMG_ERR_STATE; } \
+    catch (...) { return h ? fail(h, GMG_ERR_STATE, "unknown exception") : GMG_ERR_STATE; }
+#define GMG_CATCH_0                                              \
+    catch (...) { return GMG_ERR_STATE; }
+
 extern "C" {
 
-int gmg_config_default(gmg_config* cfg) {
+int gmg_config_default(gmg_config* cfg) try {
     if (!cfg) return GMG_ERR_INVALID;
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->device = 0;
@@ -66,15 +74,15 @@ int gmg_config_default(gmg_config* cfg) {
     cfg->host_threads = 0;
     cfg->verbose = 0;
     return GMG_OK;
-}
+} GMG_CATCH_0
 
-int gmg_device_count(void) {
+int gmg_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
-}
+} GMG_CATCH_0
 
-int gmg_create(const gmg_config* cfg, gmg_handle* out) {
+int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     if (!out) return GMG_ERR_INVALID;
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
@@ -96,7 +104,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) {
     }
     *out = h;
     return GMG_OK;     // host-only entry points work without a device; device ones report GMG_ERR_NO_DEVICE
-}
+} GMG_CATCH_0
 
 void gmg_destroy(gmg_handle h) {
     if (!h) return;
@@ -122,7 +130,7 @@ void gmg_destroy(gmg_handle h) {
 
 const char* gmg_last_error(gmg_handle h) { return h ? h->err.c_str() : "null handle"; }
 
-int gmg_set_num_levels(gmg_handle h, int L) {
+int gmg_set_num_levels(gmg_handle h, int L) try {
     if (!h || L < 0 || L > 64) return h ? fail(h, GMG_ERR_INVALID, "invalid level count") : GMG_ERR_INVALID;
     PoolScope pool_scope_(&h->pool);
     if (h->has_device) { drop_system(h); drop_device_transfers(h); }
@@ -132,9 +140,9 @@ int gmg_set_num_levels(gmg_handle h, int L) {
     h->U.assign(L, Compressed());
     h->U_set.assign(L, 0);
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const int* colptr, const int* rowidx, const double* val) {
+int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const int* colptr, const int* rowidx, const double* val) try {
     if (!h) return GMG_ERR_INVALID;
     PoolScope pool_scope_(&h->pool);
     if (h->L < 0) return fail(h, GMG_ERR_STATE, "call gmg_set_num_levels first");
@@ -147,7 +155,7 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
     h->U_set[k] = 1;
     h->ord_cache_valid = false;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // h->mass (natural numbering) -> device numbering of level 0 (d_mass, d_minv); needs a system (the ordering)
 static int upload_mass(gmg_handle h) {
@@ -166,13 +174,13 @@ static int upload_mass(gmg_handle h) {
     return GMG_OK;
 }
 
-int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) {
+int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) try {
     if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
     PoolScope pool_scope_(&h->pool);
     h->mass.assign(mass_diag, mass_diag + n);
     if (h->has_device && h->system_ready) return upload_mass(h);
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // fp32 twins of the value arrays (mixed precision); `alloc`: (re)allocate them, otherwise they exist with the right sizes
 static int refresh_fp32_twins(gmg_handle h, bool alloc) {
@@ -288,7 +296,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     return GMG_OK;
 }
 
-int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) {
+int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) try {
     NEED_DEVICE();
     if (h->L <= 0) return fail(h, GMG_ERR_STATE, "hierarchy has no transfer levels (U is empty)");
     for (int k = 0; k < h->L; ++k) if (!h->U_set[k]) return fail(h, GMG_ERR_STATE, "prolongation matrix missing for level " + std::to_string(k));
@@ -664,11 +672,11 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     h->timing["setup_total"] = ms_since(t_all);                          // wall time of this call (the coarsest factorisation overlaps)
     h->timing["coarse_host_ms"] = 0.0;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 int gmg_num_levels(gmg_handle h) { return h ? h->L : GMG_ERR_INVALID; }
 
-int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int* n_pad) {
+int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int* n_pad) try {
     if (!h) return GMG_ERR_INVALID;
     int rc = check_level(h, k, true);
     if (rc) return rc;
@@ -678,9 +686,9 @@ int gmg_level_info(gmg_handle h, int k, int* n, int64_t* nnz, int* n_colors, int
     if (n_colors) *n_colors = l.ord.n_colors;
     if (n_pad) *n_pad = l.n_pad;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double* val) {
+int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double* val) try {
     if (!h) return GMG_ERR_INVALID;
     int rc = check_level(h, k, true);
     if (rc) return rc;
@@ -693,9 +701,9 @@ int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double
     if (rowidx) std::memcpy(rowidx, A.idx.data(), sizeof(int) * A.nnz());
     if (val) std::memcpy(val, A.val.data(), sizeof(double) * A.nnz());
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin) {
+int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin) try {
     if (!h) return GMG_ERR_INVALID;
     int rc = check_level(h, k, true);
     if (rc) return rc;
@@ -705,9 +713,9 @@ int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin) 
         for (int c = 0; c <= o.n_colors; ++c) color_begin[c] = c < (int)o.color_begin.size() ? o.color_begin[c] : o.n_pad;
     }
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, unsigned char* row_color) {
+int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, unsigned char* row_color) try {
     if (!h) return GMG_ERR_INVALID;
     int rc = check_level(h, k, true);
     if (rc) return rc;
@@ -716,7 +724,7 @@ int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, uns
     if (o.blocked && blk_begin) std::memcpy(blk_begin, o.blk_begin.data(), sizeof(int) * o.blk_begin.size());
     if (o.blocked && row_color) std::memcpy(row_color, o.row_color.data(), o.row_color.size());
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // Debug / test access to the device-resident layouts: which = 0 A (off-diagonal), 1 A_in, 2 A_out, 3 P (U), 4 R (U^T).
 static DevSell* pick_sell(gmg_handle h, int k, int which) {
@@ -724,7 +732,7 @@ static DevSell* pick_sell(gmg_handle h, int k, int which) {
     switch (which) { case 0: return &l.Aoff; case 1: return &l.Ain; case 2: return &l.Aout; case 3: return &l.P; case 4: return &l.R; default: return nullptr; }
 }
 
-int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info) {
+int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -738,9 +746,9 @@ int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info) {
     if (!s || !info) return fail(h, GMG_ERR_INVALID, "bad arguments");
     info[0] = s->n_slices; info[1] = s->lpr; info[2] = s->stored; info[3] = s->row_of ? 1 : 0;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int* col, double* val, int* row_of, double* diag) {
+int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int* col, double* val, int* row_of, double* diag) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -772,19 +780,19 @@ int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int*
     if (row_of && s->row_of) HIPCHK(hipMemcpy(row_of, s->row_of, sizeof(int) * (size_t)s->n_slices * (64 / s->lpr), hipMemcpyDeviceToHost));
     if (diag && which == 0 && l.diag) HIPCHK(hipMemcpy(diag, l.diag, sizeof(double) * l.n_pad, hipMemcpyDeviceToHost));
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_get_timing(gmg_handle h, const char* key, double* out) {
+int gmg_get_timing(gmg_handle h, const char* key, double* out) try {
     if (!h || !key || !out) return GMG_ERR_INVALID;
     auto it = h->timing.find(key);
     if (it == h->timing.end()) return fail(h, GMG_ERR_INVALID, std::string("unknown timing key: ") + key);
     *out = it->second;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // ---- operators -------------------------------------------------------------------------------------------
 
-int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters) {
+int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -796,9 +804,9 @@ int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters
     launch_smooth<double>(h, l, d, iters);
     h->loaded_d = 0;
     return to_host(h, k, l.x, d, x);
-}
+} GMG_CATCH_H
 
-int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, double* r) {
+int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, double* r) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -810,9 +818,9 @@ int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, d
     launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r);
     h->loaded_d = 0;
     return to_host(h, k, l.r, d, r);
-}
+} GMG_CATCH_H
 
-int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y) {
+int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -823,9 +831,9 @@ int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y) {
     launch_spmv<double>(h, l, d, 0, nullptr, l.x, l.r);
     h->loaded_d = 0;
     return to_host(h, k, l.r, d, y);
-}
+} GMG_CATCH_H
 
-int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc_out) {
+int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc_out) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -836,9 +844,9 @@ int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc_out) {
     launch_restrict<double>(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b);
     h->loaded_d = 0;
     return to_host(h, k + 1, h->lv[k + 1].b, d, rc_out);
-}
+} GMG_CATCH_H
 
-int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x) {
+int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -850,9 +858,9 @@ int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x) {
     launch_prolong_add<double>(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x);
     h->loaded_d = 0;
     return to_host(h, k, l.x, d, x);
-}
+} GMG_CATCH_H
 
-int gmg_coarse_solve(gmg_handle h, const double* rc_in, int d, double* e) {
+int gmg_coarse_solve(gmg_handle h, const double* rc_in, int d, double* e) try {
     NEED_DEVICE();
     int rc = check_level(h, h->L, true);
     if (rc) return rc;
@@ -864,9 +872,9 @@ int gmg_coarse_solve(gmg_handle h, const double* rc_in, int d, double* e) {
     else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
     h->loaded_d = 0;
     return to_host(h, h->L, c.x, d, e);
-}
+} GMG_CATCH_H
 
-int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int type, double* out) {
+int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int type, double* out) try {
     NEED_DEVICE();
     int rc = check_level(h, 0, false);
     if (rc) return rc;
@@ -881,11 +889,11 @@ int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int
     h->loaded_d = 0;
     *out = norm_from_sums(h->h_norm, d, type);
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // ---- resident problem: load / run / fetch ------------------------------------------------------------------
 
-int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) {
+int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) try {
     NEED_DEVICE();
     int rc = check_level(h, 0, false);
     if (rc) return rc;
@@ -903,9 +911,9 @@ int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) {
     h->timing["load_sync"] = ms_since(tl);
     h->loaded_d = d;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) {
+int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) try {
     NEED_DEVICE();
     if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
     if (n_cycles < 0) return fail(h, GMG_ERR_INVALID, "bad cycle count");
@@ -921,24 +929,24 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_fetch_solution(gmg_handle h, double* x) {
+int gmg_fetch_solution(gmg_handle h, double* x) try {
     NEED_DEVICE();
     if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
     if (!x) return fail(h, GMG_ERR_INVALID, "bad arguments");
     return to_host(h, 0, h->lv[0].x, h->loaded_d, x);
-}
+} GMG_CATCH_H
 
-int gmg_vcycle(gmg_handle h, const double* b, double* x, int d) {
+int gmg_vcycle(gmg_handle h, const double* b, double* x, int d) try {
     int rc = gmg_load_problem(h, b, x, d);
     if (rc) return rc;
     if ((rc = gmg_run_cycles(h, 1, -1, nullptr))) return rc;
     return gmg_fetch_solution(h, x);
-}
+} GMG_CATCH_H
 
 int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter, int* iters_out,
-              double* residue_out, double* conv) {
+              double* residue_out, double* conv) try {
     NEED_DEVICE();
     int rc;
     if ((rc = check_norm_type(h, stop_type))) return rc;
@@ -969,21 +977,21 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     if (iters_out) *iters_out = it;
     if (residue_out) *residue_out = residue;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // ---- multi-GPU: one process per GPU, level 0 row-partitioned per colour, levels >= 1 replicated ---------------
 // The caller (gravo_mg_amd/dist.py) owns the level-0 vectors and performs the exchanges (RCCL all-gather of the
 // colour segment of x after every colour); these entry points only launch this rank's share of the work.
 
-int gmg_set_stream(gmg_handle h, void* hip_stream) {
+int gmg_set_stream(gmg_handle h, void* hip_stream) try {
     NEED_DEVICE();
     HIPCHK(hipStreamSynchronize(h->stream));
     drop_graphs(h);
     h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_dist_setup(gmg_handle h, int rank, int world) {
+int gmg_dist_setup(gmg_handle h, int rank, int world) try {
     NEED_DEVICE();
     int rc = check_level(h, 0, false);
     if (rc) return rc;
@@ -994,9 +1002,9 @@ int gmg_dist_setup(gmg_handle h, int rank, int world) {
         if ((o.color_begin[c + 1] - o.color_begin[c]) % (64 * world)) return fail(h, GMG_ERR_STATE, "colour classes are not aligned to 64*world rows: create the handle with row_align = 64*world");
     h->rank = rank; h->world = world; h->dist_ready = true;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d) {
+int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d) try {
     NEED_DEVICE();
     if (!h->dist_ready) return fail(h, GMG_ERR_STATE, "call gmg_dist_setup first");
     if (!x0 || !b0 || !r0 || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
@@ -1009,7 +1017,7 @@ int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d) {
     h->bound = true;
     h->loaded_d = d;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 namespace {
 inline void own_range(gmg_handle h, int c, int& sb, int& se) {
@@ -1031,7 +1039,7 @@ int dist_ready(gmg_handle h) {
 }  // namespace
 
 // One colour of one Gauss-Seidel sweep on this rank's rows of level 0.
-int gmg_dist_smooth_color(gmg_handle h, int c) {
+int gmg_dist_smooth_color(gmg_handle h, int c) try {
     NEED_DEVICE();
     int rc = dist_ready(h);
     if (rc) return rc;
@@ -1047,10 +1055,10 @@ int gmg_dist_smooth_color(gmg_handle h, int c) {
                                               l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1));
         }
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // r0[own rows] = b0 - A x0
-int gmg_dist_residual_own(gmg_handle h) {
+int gmg_dist_residual_own(gmg_handle h) try {
     NEED_DEVICE();
     int rc = dist_ready(h);
     if (rc) return rc;
@@ -1068,10 +1076,10 @@ int gmg_dist_residual_own(gmg_handle h) {
         }
     }
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // Replicated coarse part: b1 = U0^T r0 (needs the complete r0), levels 1..L-1 down, coarsest solve, back up to level 1.
-int gmg_dist_coarse_cycle(gmg_handle h) {
+int gmg_dist_coarse_cycle(gmg_handle h) try {
     NEED_DEVICE();
     int rc = dist_ready(h);
     if (rc) return rc;
@@ -1082,10 +1090,10 @@ int gmg_dist_coarse_cycle(gmg_handle h) {
     else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
     enqueue_up<double>(h, d, 1);
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // x0[own rows] += U0 x1
-int gmg_dist_prolong_own(gmg_handle h) {
+int gmg_dist_prolong_own(gmg_handle h) try {
     NEED_DEVICE();
     int rc = dist_ready(h);
     if (rc) return rc;
@@ -1104,10 +1112,10 @@ int gmg_dist_prolong_own(gmg_handle h) {
         }
     }
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // sums[2*c] / sums[2*c+1] = this rank's share of sum w r^2 / sum w b^2 for column c (host output; synchronises).
-int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) {
+int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) try {
     NEED_DEVICE();
     int rc = dist_ready(h);
     if (rc) return rc;
@@ -1134,43 +1142,43 @@ int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) {
     HIPCHK(hipStreamSynchronize(h->stream));
     std::memcpy(sums, h->h_norm, sizeof(double) * 2 * d);
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // The same three steps over ALL rows of level 0.  After the exchange that follows every colour sweep each rank holds the
 // complete x, so residual, prolongation-add and the norm sums can be computed redundantly instead of being exchanged:
 // 16 collectives per V-cycle (one per colour sweep) instead of 24 + an all-reduce, and the sums are identical on all ranks.
-int gmg_dist_residual_all(gmg_handle h) {
+int gmg_dist_residual_all(gmg_handle h) try {
     if (!h) return GMG_ERR_INVALID;
     AllRowsScope all(h);
     return gmg_dist_residual_own(h);
-}
-int gmg_dist_prolong_all(gmg_handle h) {
+} GMG_CATCH_H
+int gmg_dist_prolong_all(gmg_handle h) try {
     if (!h) return GMG_ERR_INVALID;
     AllRowsScope all(h);
     return gmg_dist_prolong_own(h);
-}
-int gmg_dist_norm_all(gmg_handle h, int type, double* sums) {
+} GMG_CATCH_H
+int gmg_dist_norm_all(gmg_handle h, int type, double* sums) try {
     if (!h) return GMG_ERR_INVALID;
     AllRowsScope all(h);
     return gmg_dist_norm_partial(h, type, sums);
-}
+} GMG_CATCH_H
 
-int gmg_dist_gather(gmg_handle h, const double* src, const int64_t* idx, int64_t n, double* dst) {
+int gmg_dist_gather(gmg_handle h, const double* src, const int64_t* idx, int64_t n, double* dst) try {
     NEED_DEVICE();
     if (n < 0 || (n > 0 && (!src || !idx || !dst))) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if (n) hipLaunchKernelGGL(gmgk::gather_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, idx, n, dst);
     return GMG_OK;
-}
-int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const int64_t* idx, int64_t n, double* dst) {
+} GMG_CATCH_H
+int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const int64_t* idx, int64_t n, double* dst) try {
     NEED_DEVICE();
     if (n < 0 || (n > 0 && (!src || !pos || !idx || !dst))) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if (n) hipLaunchKernelGGL(gmgk::scatter_entries, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, pos, idx, n, dst);
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // ---- measurement --------------------------------------------------------------------------------------------
 
-int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out) {
+int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out) try {
     if (!h || !bytes_out) return GMG_ERR_INVALID;
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -1186,9 +1194,9 @@ int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_ou
         default: return fail(h, GMG_ERR_INVALID, "unknown kernel kind");
     }
     return GMG_OK;
-}
+} GMG_CATCH_H
 
-int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out) {
+int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
@@ -1220,17 +1228,17 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     if (launches_out) *launches_out = launches;
     h->loaded_d = 0;
     return GMG_OK;
-}
+} GMG_CATCH_H
 
 // ---- host-only: hierarchy -----------------------------------------------------------------------------------
 
-int gmg_hierarchy_options_default(gmg_hierarchy_options* o) {
+int gmg_hierarchy_options_default(gmg_hierarchy_options* o) try {
     if (!o) return GMG_ERR_INVALID;
     o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0;
     return GMG_OK;
-}
+} GMG_CATCH_0
 
-int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt, gmg_hierarchy* out) {
+int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt, gmg_hierarchy* out) try {
     if (!pos || !neigh || n <= 0 || K <= 0 || !out) return GMG_ERR_INVALID;
     gmg_hierarchy_options o;
     if (opt) o = *opt; else gmg_hierarchy_options_default(&o);
@@ -1243,39 +1251,39 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     hh->res = HierarchyBuilder::build(pos, n, neigh, K, ho);
     *out = hh;
     return GMG_OK;
-}
+} GMG_CATCH_0
 
 void gmg_hierarchy_destroy(gmg_hierarchy hh) { delete hh; }
 
 int gmg_hierarchy_num_levels(gmg_hierarchy hh) { return hh ? (int)hh->res.U.size() : GMG_ERR_INVALID; }
 
-int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coarse, int* nnz) {
+int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coarse, int* nnz) try {
     if (!hh || k < 0 || k >= (int)hh->res.U.size()) return GMG_ERR_INVALID;
     const Compressed& u = hh->res.U[k];
     if (n_fine) *n_fine = u.n_inner;
     if (n_coarse) *n_coarse = u.n_outer;
     if (nnz) *nnz = u.nnz();
     return GMG_OK;
-}
+} GMG_CATCH_0
 
-int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val) {
+int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val) try {
     if (!hh || k < 0 || k >= (int)hh->res.U.size()) return GMG_ERR_INVALID;
     const Compressed& u = hh->res.U[k];
     if (colptr) std::memcpy(colptr, u.ptr.data(), sizeof(int) * (u.n_outer + 1));
     if (rowidx) std::memcpy(rowidx, u.idx.data(), sizeof(int) * u.nnz());
     if (val) std::memcpy(val, u.val.data(), sizeof(double) * u.nnz());
     return GMG_OK;
-}
+} GMG_CATCH_0
 
-int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out) {
+int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out) try {
     if (!hh || !key || !out) return GMG_ERR_INVALID;
     auto it = hh->res.timing.find(key);
     if (it == hh->res.timing.end()) return GMG_ERR_INVALID;
     *out = it->second;
     return GMG_OK;
-}
+} GMG_CATCH_0
 
-int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) {
+int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) try {
     if (!h || !hh) return GMG_ERR_INVALID;
     int rc = gmg_set_num_levels(h, (int)hh->res.U.size());
     if (rc) return rc;
@@ -1284,9 +1292,9 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) {
         if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
     }
     return gmg_finalize_hierarchy(h);
-}
+} GMG_CATCH_H
 
-int gmg_finalize_hierarchy(gmg_handle h) {
+int gmg_finalize_hierarchy(gmg_handle h) try {
     if (!h) return GMG_ERR_INVALID;
     if (h->L <= 0) return fail(h, GMG_ERR_STATE, "no hierarchy set");
     for (int k = 0; k < h->L; ++k) if (!h->U_set[k]) return fail(h, GMG_ERR_STATE, "prolongation matrix missing for level " + std::to_string(k));
@@ -1303,10 +1311,10 @@ int gmg_finalize_hierarchy(gmg_handle h) {
     }
     if (patches.valid()) patches.get();
     return rc;
-}
+} GMG_CATCH_H
 
 int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const double* a_val, int n_coarse, const int* u_colptr,
-                      const int* u_rowidx, const double* u_val, int* c_colptr, int* c_rowidx, double* c_val) {
+                      const int* u_rowidx, const double* u_val, int* c_colptr, int* c_rowidx, double* c_val) try {
     if (n <= 0 || n_coarse <= 0 || !a_colptr || !a_rowidx || !a_val || !u_colptr || !u_rowidx || !u_val || !c_colptr) return GMG_ERR_INVALID;
     Compressed A, U;
     A.assign(n, n, a_colptr, a_rowidx, a_val);
@@ -1316,10 +1324,10 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
     if (c_rowidx) std::memcpy(c_rowidx, C.idx.data(), sizeof(int) * C.nnz());
     if (c_val) std::memcpy(c_val, C.val.data(), sizeof(double) * C.nnz());
     return GMG_OK;
-}
+} GMG_CATCH_0
 
 int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma, int64_t* info,
-                        int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color) {
+                        int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color) try {
     if (n <= 0 || !colptr || !rowidx || !val || mode < 0 || mode > 1) return GMG_ERR_INVALID;
     if (mode == 1 && (block_rows <= 0 || block_rows > gmgk::kBlockRows || block_rows % 64)) return GMG_ERR_INVALID;
     if (sigma < 0 || sigma % 64) return GMG_ERR_INVALID;
@@ -1335,9 +1343,9 @@ int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const doubl
     if (blk_begin && o.blocked) std::memcpy(blk_begin, o.blk_begin.data(), sizeof(int) * o.blk_begin.size());
     if (row_color && o.blocked) std::memcpy(row_color, o.row_color.data(), o.row_color.size());
     return GMG_OK;
-}
+} GMG_CATCH_0
 
-int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x, int64_t* factor_nnz) {
+int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x, int64_t* factor_nnz) try {
     if (n <= 0 || !colptr || !rowidx || !val || !b || !x || d <= 0) return GMG_ERR_INVALID;
     Compressed A;
     A.assign(n, n, colptr, rowidx, val);
@@ -1360,6 +1368,6 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
         }
     }
     return GMG_OK;
-}
+} GMG_CATCH_0
 
 }  // extern "C"
