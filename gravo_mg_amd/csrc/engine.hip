@@ -553,7 +553,9 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             // the whole mesh) is the longest host task of the set-up and may still be running
             auto ordering_of = [&](int k) {
                 auto tw = clk::now();
-                ord_done[k].get();                 // (rethrows what the ordering task threw: caught at the C-ABI boundary)
+                // (an exception of the ordering task becomes an error code here: unwinding past the other tasks' futures
+                // would free what they still reference)
+                try { ord_done[k].get(); } catch (const std::exception& e) { rc_all = GMG_ERR_STATE; err_all = std::string("ordering of level ") + std::to_string(k) + ": " + e.what(); return; }
                 h->timing["setup_wait_ordering"] += ms_since(tw);
                 mark("ordering_ready_l" + std::to_string(k));
                 if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); return; }
@@ -590,7 +592,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     for (int k = 0; k <= L && rc_all == GMG_OK && !device_setup; ++k) {
         Level& l = h->lv[k];
         int rc;
-        ord_done[k].get();
+        try { ord_done[k].get(); } catch (const std::exception& e) { rc_all = GMG_ERR_STATE; err_all = std::string("ordering of level ") + std::to_string(k) + ": " + e.what(); break; }
         auto tu = clk::now();
         if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) { rc_all = rc; break; }
         ms_h2d += ms_since(tu);
