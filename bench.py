@@ -60,6 +60,21 @@ def load_pmc_traffic(workload):
     return None
 
 
+def cpu_quota():
+    """CPUs this container may use (cgroup v2 / v1 quota), or None when unlimited -- os.cpu_count() reports the host's."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
 def cpu_baseline(H, mass, lhs, rhs, cycles):
     """The oracle (line-by-line CPU restatement, 1 thread as the reference pins omp_set_num_threads(1),
     multigrid_solver.cpp:86-87) on the SAME workload: Galerkin setup + `cycles` V-cycles with residual check."""
@@ -77,7 +92,7 @@ def cpu_baseline(H, mass, lhs, rhs, cycles):
         "sample": f"{it} V-cycles + residual checks of the full {lhs.shape[0]}-vertex workload (x0=rhs) after the Galerkin setup",
         "setup_ms": {"reduction": O.timing["reduction"], "coarsest_solve": O.timing["coarsest_solve"], "total": 1e3 * setup_s},
         "residues": [float(r) for r in conv[:, 1]],
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "host_cpu_quota": cpu_quota(),
     }
 
 
