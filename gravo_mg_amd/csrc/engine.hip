@@ -73,6 +73,8 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->block_csr = 1;
     cfg->host_threads = 0;
     cfg->verbose = 0;
+    cfg->block_ep = 0;      // (first entry-parallel version: 49 us against 42 us of the SELL sweep on the 506 k-row level -- see profiles/README.md; off until it wins)
+    cfg->gs_omega = 1.2;      // measured (profiles/r02/a_iteration_ab.json): 7 -> 5 V-cycles to 1e-4 on the 3 M Poisson problem at the same cost per cycle
     return GMG_OK;
 } GMG_CATCH_0
 
@@ -87,7 +89,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
@@ -204,6 +206,13 @@ static int refresh_fp32_twins(gmg_handle h, bool alloc) {
                 HIPCHK(dev_malloc((void**)&l.bc_val32, sizeof(float) * (size_t)std::max<int64_t>(l.bc_nnz, 1)));
             }
             launch_cvt(h, l.bc_val, l.bc_val32, (size_t)l.bc_nnz);
+        }
+        if (l.use_ep) {
+            if (alloc || !l.ep_val32) {
+                if (l.ep_val32) { (void)dev_free(l.ep_val32); l.ep_val32 = nullptr; }
+                HIPCHK(dev_malloc((void**)&l.ep_val32, sizeof(float) * (size_t)std::max<int64_t>(l.ep_nnz, 1)));
+            }
+            launch_cvt(h, l.ep_val, l.ep_val32, (size_t)l.ep_nnz);
         }
         if (alloc || !l.diag32) {
             if (l.diag32) { (void)dev_free(l.diag32); l.diag32 = nullptr; }
@@ -356,8 +365,9 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     }
     struct LevelStage {
         SellHost sa, sin, sout, sp, sr;
-        BlockCsrHost bc;
-        bool use_bcsr = false;
+        BlockCsrHost bc, bin;
+        bool use_bcsr = false, use_ep = false;
+        std::vector<unsigned short> ep16;
         std::vector<double> dg;
         std::vector<unsigned short> c16;
         std::string err;
@@ -444,8 +454,14 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             if (lk.ord.blocked && wants_block_csr(h, lpr)) {
                 build_operator_blockcsr(lk.A, lk.ord, st.bc);
                 st.use_bcsr = st.bc.max_block_entries <= kBcsrMaxBlockEntries;
+                if (st.use_bcsr && wants_block_ep(h, lpr)) {
+                    build_operator_blockcsr(lk.A, lk.ord, st.bin, true);
+                    st.ep16.resize(st.bin.col.size());
+                    for (size_t i = 0; i < st.ep16.size(); ++i) st.ep16[i] = (unsigned short)st.bin.col[i];
+                    st.use_ep = true;
+                }
             }
-            if (lk.ord.blocked) {
+            if (lk.ord.blocked && !st.use_ep) {
                 build_operator_sell_split(lk.A, lk.ord, st.sin, st.sout, lpr);
                 st.c16.resize(st.sin.col.size());
                 parallel_ranges((int)st.sin.col.size(), h->cfg.host_threads, [&](int lo, int hi, int) { for (int i = lo; i < hi; ++i) st.c16[i] = (unsigned short)st.sin.col[i]; });
@@ -474,6 +490,9 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         for (int j = 0; j <= L; ++j) if (ord_done[j].valid()) ord_done[j].wait();
         for (int j = 0; j < L; ++j) { if (op_done[j].valid()) op_done[j].wait(); if (tr_done[j].valid()) tr_done[j].wait(); }
     };
+    // Whatever way this frame is left (an exception of a host stage included), no task may outlive the locals it
+    // references: the guard is declared after all of them, so it runs first.
+    struct JoinGuard { std::function<void()> f; ~JoinGuard() { try { f(); } catch (...) {} } } join_guard{join_tasks};
     auto t0 = clk::now();
     // Level 0 of a badly numbered input (random-order scans, point clouds) is renumbered for locality.  With the
     // hierarchy's cluster order at hand the LHS pattern is permuted on the device first, so that the (sequential) greedy
@@ -606,8 +625,13 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             l.use_bcsr = true;
             l.bc_cap = (st.bc.max_block_entries + 63) / 64 * 64;
             l.bc_nnz = st.bc.ptr[l.n_pad];
-            if ((rc = upload_sell(h, l.Ain, st.sin)) || (rc = upload_sell(h, l.Aout, st.sout)) || (rc = upload(h, &l.ain_col16, st.c16)) ||
-                (rc = upload(h, &l.bc_ptr, st.bc.ptr)) || (rc = upload(h, &l.bc_mid, st.bc.mid)) || (rc = upload(h, &l.bc_col, st.bc.col)) ||
+            if (st.use_ep) {
+                l.use_ep = true;
+                l.ep_nnz = st.bin.ptr[l.n_pad];
+                l.ep_cap = (std::max(st.bc.max_block_entries, st.bin.max_colour_entries) + 63) / 64 * 64;
+                if ((rc = upload(h, &l.ep_ptr, st.bin.ptr)) || (rc = upload(h, &l.ep_col, st.ep16)) || (rc = upload(h, &l.ep_val, st.bin.val))) { rc_all = rc; break; }
+            } else if ((rc = upload_sell(h, l.Ain, st.sin)) || (rc = upload_sell(h, l.Aout, st.sout)) || (rc = upload(h, &l.ain_col16, st.c16))) { rc_all = rc; break; }
+            if ((rc = upload(h, &l.bc_ptr, st.bc.ptr)) || (rc = upload(h, &l.bc_mid, st.bc.mid)) || (rc = upload(h, &l.bc_col, st.bc.col)) ||
                 (rc = upload(h, &l.bc_val, st.bc.val)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
                 (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) { rc_all = rc; break; }
         } else if (l.ord.blocked) {
@@ -658,17 +682,18 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         int rc = refresh_fp32_twins(h, true);
         if (rc) return rc;
     }
-    h->live_key[0] = pat_key[0]; h->live_key[1] = pat_key[1];
-    h->live_key_valid = true;
-    h->ord_cache_valid = false;       // (moved into the levels on a hit; refilled from them by the next call)
-    h->system_ready = true;
-    h->refill_ready = device_setup && device_rap_ok && h->cfg.device_setup != 0;
     if (!h->mass.empty()) {
         if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
         int rc = upload_mass(h);
         if (rc) return rc;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    // only now is there a system: a failure above leaves the handle without one (no solves on a half-built state)
+    h->live_key[0] = pat_key[0]; h->live_key[1] = pat_key[1];
+    h->live_key_valid = true;
+    h->ord_cache_valid = false;       // (moved into the levels on a hit; refilled from them by the next call)
+    h->system_ready = true;
+    h->refill_ready = device_setup && device_rap_ok && h->cfg.device_setup != 0;
     mark("mass_done");
     h->timing["upload"] = ms_since(t_all) - h->timing["reduction"];      // everything of the setup that is not the RAP chain
     h->timing["setup_total"] = ms_since(t_all);                          // wall time of this call (the coarsest factorisation overlaps)
@@ -744,6 +769,12 @@ int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info) try {
         info[0] = l.use_bcsr ? l.n_pad : 0; info[1] = 64; info[2] = l.use_bcsr ? l.bc_nnz : 0; info[3] = l.use_bcsr ? 1 : 0;
         return GMG_OK;
     }
+    if (which == 6) {      // in-block operator of the entry-parallel sweep (block-ordered CSR, local columns); row_of[0] <- ep_cap
+        Level& l = h->lv[k];
+        if (!info) return fail(h, GMG_ERR_INVALID, "bad arguments");
+        info[0] = l.use_ep ? l.n_pad : 0; info[1] = 64; info[2] = l.use_ep ? l.ep_nnz : 0; info[3] = l.use_ep ? 1 : 0;
+        return GMG_OK;
+    }
     DevSell* s = pick_sell(h, k, which);
     if (!s || !info) return fail(h, GMG_ERR_INVALID, "bad arguments");
     info[0] = s->n_slices; info[1] = s->lpr; info[2] = s->stored; info[3] = s->row_of ? 1 : 0;
@@ -764,6 +795,22 @@ int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int*
         if (row_of) HIPCHK(hipMemcpy(row_of, lb.bc_mid, sizeof(int) * (size_t)lb.n_pad, hipMemcpyDeviceToHost));
         if (col) HIPCHK(hipMemcpy(col, lb.bc_col, sizeof(int) * (size_t)lb.bc_nnz, hipMemcpyDeviceToHost));
         if (val) HIPCHK(hipMemcpy(val, lb.bc_val, sizeof(double) * (size_t)lb.bc_nnz, hipMemcpyDeviceToHost));
+        return GMG_OK;
+    }
+    if (which == 6) {      // slice_ptr <- row pointers (n_pad + 1), col <- local columns, row_of[0] <- product-buffer capacity
+        Level& lb = h->lv[k];
+        if (!lb.use_ep) return GMG_OK;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        std::vector<int> tmp((size_t)lb.n_pad + 1);
+        HIPCHK(hipMemcpy(tmp.data(), lb.ep_ptr, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));
+        if (slice_ptr) for (size_t i = 0; i < tmp.size(); ++i) slice_ptr[i] = tmp[i];
+        if (row_of) { std::memset(row_of, 0, sizeof(int) * (size_t)lb.n_pad); row_of[0] = lb.ep_cap; }
+        if (col) {
+            std::vector<unsigned short> c16((size_t)lb.ep_nnz);
+            HIPCHK(hipMemcpy(c16.data(), lb.ep_col, sizeof(unsigned short) * c16.size(), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < c16.size(); ++i) col[i] = c16[i];
+        }
+        if (val) HIPCHK(hipMemcpy(val, lb.ep_val, sizeof(double) * (size_t)lb.ep_nnz, hipMemcpyDeviceToHost));
         return GMG_OK;
     }
     DevSell* s = pick_sell(h, k, which);
@@ -1054,7 +1101,7 @@ int gmg_dist_smooth_color(gmg_handle h, int c) try {
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
-                                              l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1));
+                                              l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega));
         }
     return GMG_OK;
 } GMG_CATCH_H

@@ -20,6 +20,7 @@ template <> struct Prec<double> {
     static const double* val(const DevSell& s) { return s.val; }
     static const double* diag(const Level& l) { return l.diag; }
     static const double* bcval(const Level& l) { return l.bc_val; }
+    static const double* epval(const Level& l) { return l.ep_val; }
     static double* x(Level& l) { return l.x; }
     static double* b(Level& l) { return l.b; }
     static double* r(Level& l) { return l.r; }
@@ -29,6 +30,7 @@ template <> struct Prec<float> {
     static const float* val(const DevSell& s) { return s.val32; }
     static const float* diag(const Level& l) { return l.diag32; }
     static const float* bcval(const Level& l) { return l.bc_val32; }
+    static const float* epval(const Level& l) { return l.ep_val32; }
     static float* x(Level& l) { return l.x32; }
     static float* b(Level& l) { return l.b32; }
     static float* r(Level& l) { return l.r32; }
@@ -39,6 +41,7 @@ template <class T>
 void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
     const bool fine = &l == &h->lv[0];
+    const T omega = fine ? (T)h->cfg.gs_omega : (T)1.0;       // over-relaxation on the finest level only (gmg_config::gs_omega)
     T* x = Prec<T>::x(l);
     const T* b = Prec<T>::b(l);
     for (int it = 0; it < iters; ++it)
@@ -50,11 +53,11 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
                 if (fine) {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega));
                 } else {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1));
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega));
                 }
             }
         }
@@ -90,7 +93,14 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
     for (int it = 0; it < iters; ++it) {
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            if (l.use_bcsr && d > 1) {
+            if (l.use_ep) {
+                const char* dbg_env = std::getenv("GMG_EP_DBG"); const int dbg = dbg_env ? std::atoi(dbg_env) : 0;
+                const int grid = (nb + 7) / 8 * 8;          // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, grid)
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), (size_t)D * ((size_t)l.ep_cap + 64) * sizeof(T), h->stream,
+                                                  l.d_blk_begin, l.d_blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.bc_ptr, l.bc_col,
+                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                                  out + (size_t)c0 * ld, ld, l.ep_cap, nb, dbg));
+            } else if (l.use_bcsr && d > 1) {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                                   (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, l.d_blk_begin,
                                                   l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.bc_ptr, l.bc_col,
@@ -178,6 +188,10 @@ void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T
 }
 
 // Polled completion.  Slot 0: residual-norm sums in h_norm; slot 1: the coarsest right-hand side in h_pinned.
+// The polled words and the data they announce are written by a kernel and read by the host while the stream is still
+// busy: that needs fine-grained (coherent) pinned memory, requested explicitly -- what hipHostMallocDefault gives depends on
+// the ROCm version and on HIP_HOST_COHERENT.
+constexpr unsigned kPolledHostFlags = hipHostMallocCoherent | hipHostMallocMapped;
 inline bool polled(gmg_handle h) { return !h->cfg.use_graph && h->poll && h->h_flag; }
 
 int wait_flag(gmg_handle h, int slot) {
@@ -190,7 +204,12 @@ int wait_flag(gmg_handle h, int slot) {
         // is visible, flag or not; an error state must not spin for ever
         if ((spin & 4095u) == 0 && ms_since(t0) > next_query_ms) {
             hipError_t q = hipStreamQuery(h->stream);
-            if (q == hipSuccess) return GMG_OK;
+            if (q == hipSuccess) {
+                // the stream is idle, so the data is visible -- but the flag never showed up while it ran: this host does not
+                // see device writes to pinned memory in flight.  Stop polling on this handle (copy + synchronise instead)
+                if (__atomic_load_n(h->h_flag + 8 * slot, __ATOMIC_ACQUIRE) != want) { h->poll = false; h->timing["poll_disabled"] = 1.0; }
+                return GMG_OK;
+            }
             if (q != hipErrorNotReady) HIPCHK(q);
             next_query_ms += 20.0;
         }
@@ -271,13 +290,13 @@ int ensure_vectors(gmg_handle h, int d) {
     size_t need = (size_t)c.n_pad * d * 2;
     if (need > h->pinned_cap) {
         if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-        HIPCHK(hipHostMalloc((void**)&h->h_pinned, sizeof(double) * need, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&h->h_pinned, sizeof(double) * need, kPolledHostFlags));
         h->pinned_cap = need;
     }
     if (h->h_norm) (void)hipHostFree(h->h_norm);
-    HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, kPolledHostFlags));
     if (!h->h_flag) {
-        HIPCHK(hipHostMalloc((void**)&h->h_flag, 128, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&h->h_flag, 128, kPolledHostFlags));
         std::memset(h->h_flag, 0, 128);
     }
 

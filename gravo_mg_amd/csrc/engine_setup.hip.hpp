@@ -302,11 +302,34 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
                 hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, d_blk_of_row.p,
                                    l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
             } else { (void)dev_free(l.bc_ptr); l.bc_ptr = nullptr; }
+            if (l.use_bcsr && wants_block_ep(h, lpr)) {
+                // entry-parallel sweep: the in-block operator as block-ordered CSR too (16-bit local columns), and the size
+                // of the sweep's product buffer
+                int nnz_in = 0, cmax = 0;
+                HIPCHK(dev_malloc((void**)&l.ep_ptr, sizeof(int) * ((size_t)l.n_pad + 1)));
+                HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(int), h->stream));
+                hipLaunchKernelGGL(gmgs::row_lengths, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, fin, (const int*)nullptr, l.n_pad, len.p, d_err);
+                if ((rc = device_scan<int, int>(h, len.p, l.n_pad, l.ep_ptr, &nnz_in))) return rc;
+                hipLaunchKernelGGL(gmgs::block_colour_entry_max, dim3((l.ord.n_blocks() + 255) / 256), dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.d_row_color,
+                                   l.ep_ptr, d_max.p);
+                HIPCHK(hipMemcpyAsync(&cmax, d_max.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                l.ep_nnz = nnz_in;
+                l.ep_cap = (std::max(bmax, cmax) + 63) / 64 * 64;
+                HIPCHK(dev_malloc((void**)&l.ep_col, sizeof(unsigned short) * (size_t)std::max(nnz_in, 1)));
+                HIPCHK(dev_malloc((void**)&l.ep_val, sizeof(double) * (size_t)std::max(nnz_in, 1)));
+                hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, l.n_pad,
+                                   l.ep_ptr, l.ep_col, l.ep_val, d_err);
+                l.use_ep = true;
+            }
         }
-        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err))) return rc;
-        // the padded SELL form of the off-block operator is kept as well: with one right-hand side the sweep that
-        // streams it straight into registers is the faster one (42 vs 47 us on the 506 k-row level; 104 vs 60 us at d = 3)
-        if ((rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) return rc;
+        if (!l.use_ep) {
+            // (the entry-parallel sweep reads the two block-ordered CSR operators only: no padded SELL copies of the split operator)
+            if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err))) return rc;
+            // the padded SELL form of the off-block operator is kept as well: with one right-hand side the sweep that
+            // streams it straight into registers is the faster one (42 vs 47 us on the 506 k-row level; 104 vs 60 us at d = 3)
+            if ((rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, lpr, nullptr, nullptr, d_err))) return rc;
+        }
     }
     phase("A split");
     if (k == L) return GMG_OK;
@@ -375,8 +398,11 @@ int device_refill_level(gmg_handle h, int k, int* d_err) {
         if (l.use_bcsr)
             hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, l.d_blk_of_row,
                                l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
-        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, l.Ain.lpr, &l.ain_col16, nullptr, d_err, true)) ||
-            (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
+        if (l.use_ep)
+            hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, l.n_pad,
+                               l.ep_ptr, l.ep_col, l.ep_val, d_err);
+        else if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, l.Ain.lpr, &l.ain_col16, nullptr, d_err, true)) ||
+                 (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
     }
     return GMG_OK;
 }

@@ -735,9 +735,12 @@ struct BlockCsrHost {
     RawVec<int> col;
     RawVec<double> val;
     int max_block_entries = 0;
+    int max_colour_entries = 0;     // `inside` only: most entries of the rows of one colour of one block
 };
 
-inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& ord, BlockCsrHost& out) {
+// inside = false: the entries that LEAVE the row's block (device column).  inside = true: the entries that stay inside it
+// (column local to the block), the in-block operator of the entry-parallel sweep (setup_kernels.hip.hpp::csr_fill_plain).
+inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& ord, BlockCsrHost& out, bool inside = false) {
     const int np = ord.n_pad;
     out.ptr.assign((size_t)np + 1, 0);
     out.mid.assign(np, 0);
@@ -749,7 +752,7 @@ inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& or
             int n = 0;
             if (old >= 0) {
                 const int b = blk_of[r], r0 = ord.blk_begin[b], r1 = ord.blk_begin[b + 1];
-                for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int c = ord.old2new[A.idx[p]]; n += A.idx[p] != old && (c < r0 || c >= r1); }
+                for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int c = ord.old2new[A.idx[p]]; n += A.idx[p] != old && ((c < r0 || c >= r1) != inside); }
             }
             out.ptr[r + 1] = n;
         }
@@ -767,13 +770,24 @@ inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& or
                 if (old >= 0) for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) if (A.idx[p] != old) e.emplace_back(ord.old2new[A.idx[p]], A.val[p]);
                 std::stable_sort(e.begin(), e.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
                 int q = out.ptr[r];
-                for (auto& t : e) if (t.first < r0 || t.first >= r1) { out.col[q] = t.first; out.val[q] = t.second; ++q; }
+                for (auto& t : e) if ((t.first < r0 || t.first >= r1) != inside) { out.col[q] = inside ? t.first - r0 : t.first; out.val[q] = t.second; ++q; }
                 out.mid[r] = q;
             }
         }
     }, 64);
     out.max_block_entries = 0;
     for (int b = 0; b < nb; ++b) out.max_block_entries = std::max(out.max_block_entries, out.ptr[ord.blk_begin[b + 1]] - out.ptr[ord.blk_begin[b]]);
+    out.max_colour_entries = 0;
+    if (inside)
+        for (int b = 0; b < nb; ++b) {
+            int run = 0, cur = -1;
+            for (int r = ord.blk_begin[b]; r < ord.blk_begin[b + 1]; ++r) {
+                const int c = ord.row_color[r];
+                if (c != cur) { cur = c; run = 0; }
+                run += out.ptr[r + 1] - out.ptr[r];
+                out.max_colour_entries = std::max(out.max_colour_entries, run);
+            }
+        }
 }
 
 // Rows of U (fine-row major) from its CSC storage, threaded: per-row counts with atomics, prefix sum, scatter.

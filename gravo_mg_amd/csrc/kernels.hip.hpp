@@ -89,13 +89,13 @@ __device__ __forceinline__ void quad_reduce(T (&acc)[D]) {
 // One colour of a multicolour Gauss-Seidel sweep: rows [slice_begin*64, slice_end*64).
 //   x_i <- (b_i - sum_{j != i} a_ij x_j) / a_ii          (gravomg/src/multigrid_solver.cpp:1200-1208)
 // Rows of one colour do not couple, so the parallel update equals the reference's sequential sweep in
-// the colour-permuted ordering.  FINE tags the level-0 instantiation so that profilers report the dominant
+// the colour-permuted ordering.  omega != 1 relaxes the update (SOR, gmg_config::gs_omega).  FINE tags the level-0 instantiation so that profilers report the dominant
 // (fine-level) launches under their own kernel name.
 template <class T, int D, int FINE>
 __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const T* __restrict__ val, const T* __restrict__ diag,
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
-                                                   int slice_end, int xcd_swizzle) {
+                                                   int slice_end, int xcd_swizzle, T omega) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
@@ -103,8 +103,16 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
     T acc[D];
     row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
     const T dg = diag[row];
+    if (omega == (T)1.0) {                 // kernel argument: a scalar branch.  The reference's update, no read of x_i
 #pragma unroll
-    for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
+        for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
+    } else {                               // successive over-relaxation: x_i <- x_i + omega (x_i^GS - x_i)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const T xi = x[row + (int64_t)c * ld];
+            x[row + (int64_t)c * ld] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
+        }
+    }
 }
 
 // Block-hybrid Gauss-Seidel sweep, ONE launch per sweep (coarse levels, where a launch per colour is
@@ -337,6 +345,168 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
 }
 
+// The same sweep, ENTRY-PARALLEL (big blocked levels: 64-row blocks, one wavefront per block).  Both parts of the operator
+// are block-ordered CSR in device numbering (rows of a block are contiguous, so a block's entries are ONE chunk): nothing
+// is padded, a wave's loads are contiguous runs of entries whatever the row lengths are, and -- the point -- the number of
+// 64-lane gathers is ceil(entries / 64) instead of "length of the block's longest row" (the SELL sweeps above iterate to the
+// longest row: 2.96x the real off-block entries and 1.61x the in-block ones on the 506 k-row level, whose sweep moved
+// 200 MB for 103 MB of entries and paid one load -> gather round trip per group of 8 padded columns).
+//   1. every load the block needs is issued up front: off-block entries in kEpOut slots of 64 (column + value), in-block
+//      entries in kEpIn slots of 64 (16-bit local column + value; they stay in registers for the colour loop);
+//   2. off-block couplings (previous iterate): lane l gathers x for ITS ENTRIES, writes the products to LDS in entry order;
+//      then every lane sums the run of products that belongs to its row (CSR row pointers), ascending column order;
+//   3. colour loop: the in-block entries of one colour are one run (rows are colour-sorted inside a block); slot by slot the
+//      lanes holding entries of the current colour write value * x_lds[column] to LDS, and when the colour's run is
+//      complete its rows sum their products and update x in LDS.  Slots are walked with a compile-time index (registers),
+//      colours advance inside a slot (wave-uniform scalar control flow: ballot + readlane give the run boundaries).
+// Blocks with more entries than the register window (kEpIn * 64 in-block, kEpOut * 64 off-block) read the excess from
+// global memory in the same order.  Products are rounded before they are added (no fused multiply-add across lanes), the
+// summation order is that of the other block sweeps: same matrix form x_out = x_in + T^-1 (b - A x_in), tested to 1e-12.
+constexpr int kEpIn = 16, kEpOut = 8;
+template <class T, int D>
+__global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
+                                                  const unsigned char* __restrict__ row_color, const int* __restrict__ in_ptr,
+                                                  const unsigned short* __restrict__ in_col, const T* __restrict__ in_val,
+                                                  const int* __restrict__ out_ptr, const int* __restrict__ out_col,
+                                                  const T* __restrict__ out_val, const T* __restrict__ diag, const T* __restrict__ b,
+                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap, int n_blocks, int dbg) {
+    extern __shared__ unsigned char smem_raw[];
+    T* pbuf = reinterpret_cast<T*>(smem_raw);                          // D x cap products
+    T* xs = pbuf + (size_t)D * cap;                                    // D x 64: the block's x
+    // XCD-aware block map: block b runs on XCD b % 8; give every XCD a contiguous run of (spatially neighbouring) blocks
+    const int chunk = (int)(gridDim.x >> 3);
+    const int blk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3));
+    if (blk >= n_blocks) return;
+    const int lane = threadIdx.x;
+    const int r0 = blk_begin[blk];                                     // 64 rows (padding rows: no entries, diag 1, b 0, colour 0)
+    const int row = r0 + lane;
+    const int e0 = out_ptr[r0], e1 = out_ptr[r0 + 64];
+    const int q0 = in_ptr[r0], q1 = in_ptr[r0 + 64];
+    const int Ein = q1 - q0, Eout = x_in ? e1 - e0 : 0;                // zero iterate: nothing couples in from outside the block
+    // ---- 1. all loads in flight
+    T iv[kEpIn];
+    unsigned ic[kEpIn / 2];
+#pragma unroll
+    for (int m = 0; m < kEpIn / 2; ++m) ic[m] = 0u;
+#pragma unroll
+    for (int m = 0; m < kEpIn; ++m) {
+        iv[m] = (T)0.0;
+        if (64 * m < Ein) {                                            // wave-uniform
+            const int e = q0 + 64 * m + lane;
+            if (e < q1) { iv[m] = __builtin_nontemporal_load(in_val + e); ic[m >> 1] |= (unsigned)__builtin_nontemporal_load(in_col + e) << ((m & 1) * 16); }
+        }
+    }
+    int oc[kEpOut];
+    T ov[kEpOut];
+#pragma unroll
+    for (int k = 0; k < kEpOut; ++k) {
+        oc[k] = row; ov[k] = (T)0.0;
+        if (64 * k < Eout) {
+            const int e = e0 + 64 * k + lane;
+            if (e < e1) { oc[k] = __builtin_nontemporal_load(out_col + e); ov[k] = __builtin_nontemporal_load(out_val + e); }
+        }
+    }
+    const int ib = in_ptr[row] - q0, ie = in_ptr[row + 1] - q0;
+    const int ob = out_ptr[row] - e0, oe = x_in ? out_ptr[row + 1] - e0 : ob;
+    const int mycolor = row_color[row];
+    const T dg = (T)1.0 / diag[row];
+    T rhs[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) { rhs[c] = b[row + (int64_t)c * ld]; xs[c * 64 + lane] = x_in ? x_in[row + (int64_t)c * ld] : (T)0.0; }
+    // ---- 2. off-block couplings
+    if (Eout > 0 && !(dbg & 2)) {
+#pragma unroll
+        for (int k = 0; k < kEpOut; ++k)
+            if (64 * k < Eout) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) pbuf[c * cap + 64 * k + lane] = ov[k] * x_in[oc[k] + (int64_t)c * ld];
+            }
+        for (int e = 64 * kEpOut + lane; e < Eout; e += 64) {          // beyond the register window (rare)
+            const T v = out_val[e0 + e];
+            const int cj = out_col[e0 + e];
+#pragma unroll
+            for (int c = 0; c < D; ++c) pbuf[c * cap + e] = v * x_in[cj + (int64_t)c * ld];
+        }
+        __syncthreads();
+        T acc[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = (T)0.0;
+        for (int q = ob; q < oe; q += 4) {
+            T p[4][D];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < D; ++c) p[j][c] = q + j < oe ? pbuf[c * cap + q + j] : (T)0.0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[c] += p[j][c];
+        }
+#pragma unroll
+        for (int c = 0; c < D; ++c) rhs[c] -= acc[c];
+    }
+    __syncthreads();                                                   // xs complete; the product buffer is free again
+    // ---- 3. colour loop over the in-block entries
+    const int nc = blk_ncolors[blk];
+    // first in-block entry of colour cc (block-local): rows are colour-sorted, ib is non-decreasing over the lanes
+    auto colour_start = [&](int cc) -> int {
+        const unsigned long long mask = __ballot(mycolor >= cc);
+        return mask ? __builtin_amdgcn_readlane(ib, (int)__builtin_ctzll(mask)) : Ein;
+    };
+    auto finish_colour = [&](int cc, int qa) {                        // rows of colour cc: sum their run of products, update x
+        __syncthreads();
+        if (mycolor == cc && !(dbg & 4)) {
+            T s_[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] = (T)0.0;
+            for (int q = ib - qa; q < ie - qa; q += 4) {
+                T p[4][D];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) p[j][c] = q + j < ie - qa ? pbuf[c * cap + q + j] : (T)0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) s_[c] += p[j][c];
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - s_[c]) * dg;
+        }
+        __syncthreads();
+    };
+    int col = 0, qa = 0, qb = colour_start(1);
+#pragma unroll
+    for (int m = 0; m < kEpIn; ++m) {
+        if (64 * m >= Ein || col >= nc || (dbg & 1)) break;
+        const int e = 64 * m + lane;                                   // the entry this lane holds in slot m
+        const int cj = (ic[m >> 1] >> ((m & 1) * 16)) & 0xffff;
+        while (qa < 64 * m + 64) {                                     // colours with a piece in this slot (or empty ones before it)
+            if (e >= qa && e < qb && !(dbg & 8)) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) pbuf[c * cap + e - qa] = iv[m] * xs[c * 64 + cj];
+            }
+            if (qb > 64 * m + 64) break;                               // the colour continues in the next slot
+            finish_colour(col, qa);
+            if (++col >= nc) break;
+            qa = qb; qb = colour_start(col + 1);
+        }
+    }
+    for (; col < nc && !(dbg & 1); ++col) {                                          // entries beyond the register window, colours without entries
+        const int lo = qa > 64 * kEpIn ? qa : 64 * kEpIn;
+        for (int e = lo + lane; e < qb; e += 64) {
+            const T v = in_val[q0 + e];
+            const int cj = in_col[q0 + e];
+#pragma unroll
+            for (int c = 0; c < D; ++c) pbuf[c * cap + e - qa] = v * xs[c * 64 + cj];
+        }
+        finish_colour(col, qa);
+        qa = qb; qb = colour_start(col + 2);
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
+}
+
 // The same sweep on the QUAD layout (4 lanes per row; blocks of <= 256 rows = 1024 threads).  A colour step is the
 // critical path of the coarse levels -- 13-16 of them run back to back with one or two wavefronts active -- so the
 // row is spread over four lanes: each lane keeps <= WQ in-block entries in registers, gathers them from LDS in one
@@ -494,7 +664,9 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
     row_dot<T, D>(slice_ptr, col, val, x, ldx, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const int srow = s * (64 / LPR) + lane / LPR;
-    const int row = row_of ? row_of[srow] : srow;
+    // ADD = 1 is a read-modify-write of y: only safe when every output row is produced by exactly one slice row, so that
+    // instantiation never takes an output-row map (slice row == output row: unique by construction)
+    const int row = (!ADD && row_of) ? row_of[srow] : srow;
     if (row < 0) return;
 #pragma unroll
     for (int c = 0; c < D; ++c) {

@@ -138,6 +138,50 @@ __global__ void csr_fill(const int* __restrict__ pbeg, const int* __restrict__ p
     for (int e = 0; e < n; ++e) if (cs[e] >= r0 && cs[e] < r1) { col[q] = cs[e]; out_val[q] = vs[e]; ++q; }
 }
 
+// Plain block-ordered CSR of the entries the filter keeps (the in-block operator of the entry-parallel sweep, 16-bit local
+// columns): row r's kept entries, ascending column, at [row_ptr[r], row_ptr[r + 1]).
+template <class ColT>
+__global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx, const double* __restrict__ val,
+                               RowFilter f, int n_rows_pad, const int* __restrict__ row_ptr, ColT* __restrict__ col, double* __restrict__ out_val,
+                               int* __restrict__ err_flag) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows_pad) return;
+    const int old = f.new2old_row[r];
+    if (old < 0) return;
+    int cs[kMaxRow];
+    double vs[kMaxRow];
+    int n = 0;
+    for (int p = pbeg[old]; p < pend[old]; ++p) {
+        int c;
+        if (!keep_entry(f, r, old, idx[p], c)) continue;
+        if (n >= kMaxRow) { atomicExch(err_flag, 1); break; }
+        int q = n;
+        const double v = val[p];
+        while (q > 0 && cs[q - 1] > c) { cs[q] = cs[q - 1]; vs[q] = vs[q - 1]; --q; }
+        cs[q] = c; vs[q] = v;
+        ++n;
+    }
+    int q = row_ptr[r];
+    for (int e = 0; e < n; ++e, ++q) { col[q] = (ColT)cs[e]; out_val[q] = vs[e]; }
+}
+
+// max over (block, colour) of the in-block entries of that colour's rows (rows are colour-sorted inside a block, padding
+// rows -- colour 0, no entries -- at its end): the product buffer the entry-parallel sweep needs for one colour
+__global__ void block_colour_entry_max(const int* __restrict__ blk_begin, int n_blocks, const unsigned char* __restrict__ row_color,
+                                       const int* __restrict__ row_ptr, int* __restrict__ out_max) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    int best = 0, run = 0, cur = -1;
+    for (int r = blk_begin[b]; r < blk_begin[b + 1]; ++r) {
+        const int len = row_ptr[r + 1] - row_ptr[r];
+        const int c = row_color[r];
+        if (c != cur) { cur = c; run = 0; }
+        run += len;
+        best = run > best ? run : best;
+    }
+    atomicMax(out_max, best);
+}
+
 // max over the blocks of their entry count (LDS capacity the sweep kernel needs)
 __global__ void block_entry_max(const int* __restrict__ blk_begin, int n_blocks, const int* __restrict__ row_ptr, int* __restrict__ out_max) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -192,3 +192,42 @@ def sphere_mesh(n: int, seed: int = 3, order: str = "spatial"):
     flip = np.einsum("ij,ij->i", nrm, c) < 0
     F[flip] = F[flip][:, [0, 2, 1]]
     return normalize_area(P, F), F
+
+
+def baseline_config(cfg: str):
+    """BASELINE.json's configs as synthetic stand-ins at FULL size (no mesh ships with the reference and there
+    is no network).  Returns (name, positions, S, mass, lhs, rhs).  "4r": config 4 in random vertex order; "5": the
+    reference's smoothing parameter tau = 1e-3 (comparison_smoothing.sh:2-3), "5b": tau = 1e-9, for which the reference
+    iteration contracts at this size; "6": an irregular-valence mesh (not in BASELINE.json)."""
+    if cfg == "1":      # demos/smoothing.py call pattern: M + 1e-3 S, rhs = M V (n x 3), ~36 k vertices
+        V, F = torus_mesh(190, 190)
+        S, mass = cotan_laplacian(V, F)
+        lhs, rhs = smoothing_system(S, mass, V)
+        return "cfg1 torus 190x190 smoothing d=3", V, S, mass, lhs, rhs
+    if cfg == "2":      # ~720 k cotan Poisson
+        V, F = torus_mesh(850, 850)
+        S, mass = cotan_laplacian(V, F)
+        lhs, rhs = poisson_system(S, mass)
+        return "cfg2 torus 850x850 Poisson d=1", V, S, mass, lhs, rhs
+    if cfg == "3":      # ~2 M point cloud, kNN graph Laplacian (stand-in for robust_laplacian)
+        P = torus_points(2_000_000, noise=0.0005)
+        S, mass = knn_graph_laplacian(P, 8)
+        lhs, rhs = poisson_system(S, mass)
+        return "cfg3 point cloud 2M kNN(8) Poisson d=1", P, S, mass, lhs, rhs
+    if cfg in ("4", "4r"):   # ~3 M mesh Poisson (the bench workload), natural / random vertex order
+        V, F = torus_mesh(1732, 1732, order="random" if cfg == "4r" else "natural")
+        S, mass = cotan_laplacian(V, F)
+        lhs, rhs = poisson_system(S, mass)
+        return f"cfg4 torus 1732x1732 Poisson d=1 ({'random' if cfg == '4r' else 'natural'} vertex order)", V, S, mass, lhs, rhs
+    if cfg in ("5", "5b"):   # Bilaplacian data smoothing M + tau S M^-1 S on the ~3 M mesh (mixed precision: fp32 inner V-cycle)
+        tau = 1e-3 if cfg == "5" else 1e-9
+        V, F = torus_mesh(1732, 1732)
+        S, mass = cotan_laplacian(V, F)
+        lhs, rhs = smoothing_system(bilaplacian(S, mass), mass, V[:, :1], tau=tau)
+        return f"cfg5 torus 1732x1732 Bilaplacian smoothing tau={tau:g} d=1", V, S, mass, lhs, rhs
+    if cfg == "6":      # irregular-valence mesh (random points on a sphere, hull triangulation): 7 colours, ragged rows
+        V, F = sphere_mesh(1_000_000)
+        S, mass = cotan_laplacian(V, F)
+        lhs, rhs = poisson_system(S, mass)
+        return "cfg6 irregular sphere 1M Poisson d=1 (valence 3..13)", V, S, mass, lhs, rhs
+    raise ValueError(cfg)

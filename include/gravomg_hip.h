@@ -79,6 +79,14 @@ typedef struct {
                               wide as its longest row; 104 -> 60 us per sweep at d = 3 on a 506 k-row level); 0: SELL only */
     int host_threads;      /* threads for host-side setup (RAP, layout); 0 = all cores */
     int verbose;
+    double gs_omega;       /* relaxation factor of the level-0 multicolour sweep: x_i <- x_i + omega (x_i^GS - x_i) (SOR).  1.0 is the
+                              reference's Gauss-Seidel update (multigrid_solver.cpp:1200-1208) in colour order; the default over-relaxes
+                              (see gmg_config_default) because the colour ordering smooths a little less per sweep than the
+                              reference's lexicographic one (V-cycles to 1e-4 on the 3 M Poisson problem).
+                              Must lie in (0, 2): SOR converges for every symmetric positive definite system in that range. */
+    int block_ep;          /* 1 (default): big blocked levels (one lane per row, 64-row blocks, block_csr = 1) run the entry-parallel
+                              block sweep: in-block and off-block operators as unpadded block-ordered CSR, one 64-lane gather per
+                              64 ENTRIES instead of one per padded column of the block's longest row; 0: the SELL / block-CSR sweeps */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -1,0 +1,118 @@
+"""BASELINE.json's other configs at FULL size (synthetic stand-ins, gravo_mg_amd.meshgen.baseline_config): the 720 k mesh
+Poisson problem, the 2 M point cloud, the 3 M mesh in random vertex order and the 3 M Bilaplacian (fp64 and mixed precision,
+with the reference's tau = 1e-3 and with tau = 1e-9, for which the reference iteration contracts).
+
+The 1-core oracle finishes a full solve of these in seconds (0.2 s per V-cycle at 3 M vertices), so besides the
+size-independent properties the test runs the REFERENCE ALGORITHM itself on the same input:
+  * both reach the reference's stopping test (M-norm of the residual <= 1e-4, multigrid_solver.cpp:1408-1419); the V-cycle
+    counts are recorded side by side -- the device's smoother is a parallel re-ordering of the reference's Gauss-Seidel, so
+    the counts may differ; asserted: device <= oracle + 1;
+  * the two solutions agree to 20 x tol in the M-norm;
+  * the oracle's one-pass residualCheck of the device solution equals the device's own residue (all four norm types);
+  * the residual history contracts monotonically; the V-cycle is affine in (b, x).
+Per-cycle agreement to rounding (the check that also works where the iteration does not contract) is in
+tests/test_gpu_cycle_model.py at 109 k vertices.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RECORD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_configs.jsonl")
+
+
+def _record(**kw):
+    try:
+        os.makedirs(os.path.dirname(RECORD), exist_ok=True)
+        with open(RECORD, "a") as f:
+            f.write(json.dumps(kw) + "\n")
+    except OSError:
+        pass
+
+
+@pytest.fixture(scope="module", params=["2", "3", "4r", "5b", "5"])
+def case(request, cabi):
+    from gravo_mg_amd import meshgen
+    name, pos, S, mass, lhs, rhs = meshgen.baseline_config(request.param)
+    H = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S), ratio=8.0, lower_bound=1000)
+    eng = cabi.Engine()
+    eng.use_hierarchy(H); eng.set_mass(mass); eng.set_system(lhs)
+    yield dict(cfg=request.param, name=name, mass=mass, H=H, lhs=lhs, rhs=rhs, eng=eng)
+    eng.close()
+
+
+def _mdist(mass, x, y):
+    m = mass[:, None]
+    return float(np.sqrt((m * (x - y) ** 2).sum() / (m * y ** 2).sum()))
+
+
+def test_solve_against_the_reference_algorithm(case, cabi, oracle):
+    eng, lhs, rhs, mass, cfg = case["eng"], case["lhs"], case["rhs"], case["mass"], case["cfg"]
+    O = oracle.Hierarchy(case["H"].U, mass)
+    O.set_system(lhs)
+    if cfg == "5":
+        # The reference's own parameters (tau = 1e-3): the reference iteration does not reach 1e-4 from x0 = rhs at this size
+        # (the residue starts at ~1e3 and, over the first cycles, GROWS -- on the oracle and on the device alike).
+        # Parity is "same behaviour": same order of magnitude cycle by cycle, same trend, residues that the oracle
+        # confirms; fp32 inner cycles follow the fp64 history.  (Per-cycle agreement to rounding: test_gpu_cycle_model.py.)
+        eng.load_problem(rhs, rhs)
+        hist = eng.run_cycles(8, 2)
+        x = eng.fetch_solution()
+        chk = oracle.residual_check(lhs, mass, rhs, x, 2)
+        assert abs(chk - hist[-1]) <= 1e-6 * chk
+        xo, ito, reso, convo = O.solve(rhs, tol=0.0, max_iter=8)
+        ratio = hist / convo[:, 1]
+        assert np.all((ratio > 0.4) & (ratio < 2.5))
+        assert np.sign(hist[-1] - hist[2]) == np.sign(convo[-1, 1] - convo[2, 1])     # same trend
+        mix = cabi.Engine(inner_precision=1)
+        mix.use_hierarchy(case["H"]); mix.set_mass(mass); mix.set_system(lhs)
+        mix.load_problem(rhs, rhs)
+        hmix = mix.run_cycles(8, 2)
+        np.testing.assert_allclose(hmix, hist, rtol=5e-3)
+        assert abs(oracle.residual_check(lhs, mass, rhs, mix.fetch_solution(), 2) - hmix[-1]) <= 1e-6 * hmix[-1]
+        mix.close()
+        _record(config=case["name"], gpu_history=[float(v) for v in hist], mixed_history=[float(v) for v in hmix],
+                oracle_history=[float(v) for v in convo[:, 1]])
+        return
+    # tau = 1e-9 Bilaplacian: the reference iteration contracts, but by ~3 % per cycle at this size -- neither side reaches 1e-4
+    # within the reference's max_iter = 100 (oracle 4.0e-3, device 2.9e-3 after 100 cycles); the convergent leg stops at 3e-2
+    tol = 3e-2 if cfg == "5b" else 1e-4
+    x, it, res, conv = eng.solve(rhs, tol=tol, stop_type=2, max_iter=100)
+    xo, ito, reso, convo = O.solve(rhs, tol=tol, stop_type=2, max_iter=100)
+    _record(config=case["name"], gpu_iterations=int(it), oracle_iterations=int(ito), gpu_history=[float(v) for v in conv[:, 1]],
+            oracle_history=[float(v) for v in convo[:, 1]], solution_distance_M=_mdist(mass, x, xo))
+    assert res <= tol and reso <= tol and it < 100
+    assert it <= ito + 1, (it, ito)
+    assert np.all(np.diff(conv[:, 1]) < 0)
+    assert _mdist(mass, x, xo) <= 20 * tol
+    for t in (0, 1, 2, 3):
+        want = oracle.residual_check(lhs, mass, rhs, x, t)
+        assert abs(eng.residual_norm(rhs, x, t) - want) <= 1e-3 * want + 1e-7
+    if cfg == "5b":
+        # config 5 proper: the fp32 inner V-cycle inside the fp64 defect-correction loop reaches the same stopping test
+        mix = cabi.Engine(inner_precision=1)
+        mix.use_hierarchy(case["H"]); mix.set_mass(mass); mix.set_system(lhs)
+        xm, itm, resm, convm = mix.solve(rhs, tol=tol, stop_type=2, max_iter=100)
+        assert resm <= tol and abs(itm - it) <= 1
+        assert abs(oracle.residual_check(lhs, mass, rhs, xm, 2) - resm) <= 1e-3 * resm + 1e-7
+        assert _mdist(mass, xm, xo) <= 20 * tol
+        _record(config=case["name"] + " (mixed precision)", gpu_iterations=int(itm), oracle_iterations=int(ito),
+                gpu_history=[float(v) for v in convm[:, 1]])
+        mix.close()
+
+
+def test_vcycle_is_affine(case):
+    eng, rhs = case["eng"], case["rhs"]
+    n = rhs.shape[0]
+    rng = np.random.default_rng(7)
+    b1, b2 = rhs[:, 0].copy(), rng.standard_normal(n) * np.abs(rhs[:, 0]).mean()
+    x1, x2 = rng.standard_normal(n), rng.standard_normal(n)
+    v = lambda b, x: eng.vcycle(b[:, None], x[:, None])[:, 0]
+    y1, y2, y12, y0 = v(b1, x1), v(b2, x2), v(b1 + b2, x1 + x2), v(np.zeros(n), np.zeros(n))
+    assert np.abs(y0).max() == 0.0
+    # to rounding; the coarsest solve of the nearly singular Poisson operators (tau = 1e-6) amplifies rounding along the
+    # constant mode by ~1/tau: the defect is a constant of relative size ~1e-9
+    assert np.abs(y12 - (y1 + y2)).max() <= 1e-8 * (np.abs(y1).max() + np.abs(y2).max())

@@ -47,8 +47,8 @@ def test_mixed_follows_fp64_history_and_converges(cabi, oracle, case):
         assert np.linalg.norm(xt - xr) <= 1e-9 * np.linalg.norm(xr)
 
 
-@pytest.mark.parametrize("kw", [dict(coarse_mode=1), dict(smoother=1), dict(block_rows=0), dict(block_lanes=1, block_rows=256), dict(use_graph=True), dict(block_lanes=1)],
-                         ids=["device-coarse", "jacobi", "exact-gs", "lane1-blocks", "graph", "block-csr"])
+@pytest.mark.parametrize("kw", [dict(coarse_mode=1), dict(smoother=1), dict(block_rows=0), dict(block_lanes=1, block_rows=256), dict(use_graph=True), dict(block_lanes=1), dict(block_lanes=1, block_ep=False)],
+                         ids=["device-coarse", "jacobi", "exact-gs", "lane1-blocks", "graph", "entry-parallel", "block-csr"])
 def test_mixed_variants(cabi, kw):
     P = problems.torus_problem(64, 60, "smoothing", 60)
     f64, mix = _pair(cabi, P, **kw)

@@ -45,9 +45,10 @@ def setup(request, cabi):
 
 @pytest.fixture(scope="module")
 def setup_exact(setup, cabi):
-    """Same problem, exact (global) multicolour Gauss-Seidel on EVERY level (block_rows=0)."""
+    """Same problem, exact (global) multicolour Gauss-Seidel on EVERY level (block_rows=0), no over-relaxation:
+    the reference's update in colour order."""
     P, _ = setup
-    eng = cabi.Engine(block_rows=0)
+    eng = cabi.Engine(block_rows=0, gs_omega=1.0)
     eng.set_prolongations(P.U)
     eng.set_mass(P.mass)
     eng.set_system(P.lhs)
@@ -96,10 +97,11 @@ def test_block_hybrid_sweep_matches_matrix_form(setup, oracle):
 
 
 def test_block_hybrid_sweep_of_the_big_level_kernels(setup, cabi, oracle):
-    """The same identity for the kernels big blocked levels use (one lane per row, 64-row blocks): the SELL sweep for one
-    right-hand side and the sweep with the off-block operator in block-CSR for several (forced here by block_lanes=1)."""
+    """The same identity for the kernels big blocked levels use (one lane per row, 64-row blocks; forced here by
+    block_lanes=1): the entry-parallel sweep (default), and the sweeps it replaced -- SELL for one right-hand side, off-block
+    operator in block-CSR for several."""
     P, _ = setup
-    for kw in (dict(block_lanes=1), dict(block_lanes=1, block_csr=False)):
+    for kw in (dict(block_lanes=1), dict(block_lanes=1, block_ep=False), dict(block_lanes=1, block_csr=False)):      # entry-parallel, block-CSR / SELL, SELL only
         eng = cabi.Engine(**kw)
         eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
         _check_block_sweeps(P, eng, oracle)
@@ -167,6 +169,39 @@ def test_multicolor_gs_is_reference_gs_on_permuted_system(setup_exact, oracle):
                 assert rel(got, want) <= 1e-12
 
 
+def test_level0_sor_sweep_matches_model(setup, oracle):
+    """The default engine over-relaxes the level-0 colour sweep (gmg_config::gs_omega): per colour
+    x[rows] += omega (b - A x)[rows] / diag[rows], with the residual taken from the oracle."""
+    from tests.vcycle_model import VcycleModel
+    P, eng = setup
+    assert eng.gs_omega != 1.0
+    M = VcycleModel(eng, P.U, P.mass, P.lhs, oracle, eng.gs_omega)
+    rng = np.random.default_rng(12)
+    for d in (1, 3):
+        b = rng.standard_normal((P.n, d)); x = rng.standard_normal((P.n, d))
+        for iters in (1, 2):
+            assert rel(eng.smooth(0, b, x, iters), M.smooth(0, b, x, iters)) <= 1e-12
+
+
+def test_default_engine_vcycles_match_model_per_cycle(setup, oracle):
+    """Three consecutive V-cycles of the DEFAULT engine (level-0 multicolour SOR, block-hybrid sweeps below, host LDL^T)
+    against the model assembled from the oracle's operators with the device's orderings (tests/vcycle_model.py): the
+    same iteration, so the iterates agree to rounding cycle by cycle."""
+    import scipy.sparse.linalg as spla
+    from tests.vcycle_model import VcycleModel
+    P, eng = setup
+    M = VcycleModel(eng, P.U, P.mass, P.lhs, oracle, eng.gs_omega)
+    xg = P.rhs.copy(); xm = P.rhs.copy()
+    nA = spla.norm(P.lhs)
+    for cyc in range(3):
+        xg = eng.vcycle(P.rhs, xg)
+        xm = M.vcycle(P.rhs, xm)
+        # backward-error bound (insensitive to the 1/tau conditioning of the Poisson systems) and a forward bound
+        assert np.linalg.norm(P.lhs @ (xg - xm)) <= 1e-12 * nA * np.linalg.norm(xm), cyc
+        assert rel(xg, xm) <= (1e-11 if "smoothing" in P.name else 1e-6), cyc
+        xg = xm.copy()          # next cycle from identical input: no accumulation of conditioning-amplified rounding
+
+
 def test_norms(setup, oracle):
     P, eng = setup
     rng = np.random.default_rng(3)
@@ -229,7 +264,7 @@ def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
     O.set_system(P.lhs)
     xo, ito, reso, _ = O.solve(P.rhs, tol=tol)
     assert reso <= tol
-    assert abs(it - ito) <= 2, (it, ito)
+    assert it <= ito + 2, (it, ito)
     m = P.mass[:, None] if x.ndim == 2 else P.mass
     dx = np.sqrt((m * (x - xo) ** 2).sum()) / np.sqrt((m * xo ** 2).sum())
     assert dx <= 20 * tol
@@ -238,7 +273,7 @@ def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
     tight = 1e-10 if "smoothing" in P.name else 1e-6
     x2, it2, res2, _ = eng.solve(P.rhs, tol=tight, max_iter=100)
     xo2, ito2, reso2, _ = O.solve(P.rhs, tol=tight)
-    assert res2 <= tight and reso2 <= tight and abs(it2 - ito2) <= 2
+    assert res2 <= tight and reso2 <= tight and it2 <= ito2 + 2       # (the over-relaxed level-0 sweep usually needs fewer cycles)
     dx2 = np.sqrt((m * (x2 - xo2) ** 2).sum()) / np.sqrt((m * xo2 ** 2).sum())
     assert dx2 <= 100 * tight
 
@@ -249,11 +284,11 @@ def test_engine_variants(cabi, oracle, variant):
     kw = {"jacobi": dict(smoother=cabi.SMOOTHER_JACOBI), "device_coarse": dict(coarse_mode=cabi.COARSE_DEVICE_INVERSE),
           "graph": dict(use_graph=True), "exact_gs": dict(block_rows=0), "blocked_all": dict(block_from_level=0),
           "small_blocks": dict(block_rows=128), "lane_per_row_blocks": dict(block_lanes=1, block_rows=1024)}[variant]
-    eng = cabi.Engine(**kw)
+    eng = cabi.Engine(gs_omega=1.0, **kw)            # (no over-relaxation on either side: blocked_all has no colour-major level 0 to relax)
     eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
     x, it, res, _ = eng.solve(P.rhs, tol=1e-6, max_iter=200)
     assert res <= 1e-6
-    ref = cabi.Engine()
+    ref = cabi.Engine(gs_omega=1.0)
     ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(P.lhs)
     xr, itr, resr, _ = ref.solve(P.rhs, tol=1e-6, max_iter=200)
     assert rel(x, xr) <= 1e-5

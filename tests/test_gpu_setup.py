@@ -20,8 +20,8 @@ def _engines(cabi, P, **kw):
 
 @pytest.mark.parametrize("case", ["torus-L3", "random-order", "pointcloud", "smoothing", "bilaplacian"])
 @pytest.mark.parametrize("kw", [dict(), dict(block_lanes=1, block_rows=256), dict(block_lanes=4, block_rows=128), dict(block_rows=0),
-                                dict(block_from_level=0), dict(sigma=0), dict(reorder_fine=1), dict(block_lanes=1), dict(block_lanes=1, block_csr=0)],
-                         ids=["default", "lane1", "quad128", "exact", "blocked-all", "nosort", "cluster-reorder", "block-csr", "lane1-sell64"])
+                                dict(block_from_level=0), dict(sigma=0), dict(reorder_fine=1), dict(block_lanes=1), dict(block_lanes=1, block_ep=0), dict(block_lanes=1, block_csr=0)],
+                         ids=["default", "lane1", "quad128", "exact", "blocked-all", "nosort", "cluster-reorder", "entry-parallel", "block-csr", "lane1-sell64"])
 def test_device_layout_equals_host_layout(cabi, case, kw):
     P = {"torus-L3": lambda: problems.torus_problem(96, 80, "poisson", 30),
          "random-order": lambda: problems.torus_problem(48, 40, "poisson", 40, order="random"),
@@ -34,7 +34,7 @@ def test_device_layout_equals_host_layout(cabi, case, kw):
         nd, cd = dev.level_ordering(k); nh, ch = host.level_ordering(k)
         assert np.array_equal(nd, nh) and np.array_equal(cd, ch)
         blocked = dev.level_blocks(k) is not None
-        for which in ([0, 3, 4] + ([1, 2, 5] if blocked else [])):      # 5 = block-CSR (big blocked levels), else empty
+        for which in ([0, 3, 4] + ([1, 2, 5, 6] if blocked else [])):      # 5 / 6 = block-CSR off-block / in-block operators (big blocked levels), else empty
             a, b = dev.debug_sell(k, which), host.debug_sell(k, which)
             assert (a["n_slices"], a["lpr"]) == (b["n_slices"], b["lpr"]), (k, which)
             assert np.array_equal(a["slice_ptr"], b["slice_ptr"]), (k, which)
