@@ -73,7 +73,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->block_csr = 1;
     cfg->host_threads = 0;
     cfg->verbose = 0;
-    cfg->block_ep = 0;      // (first entry-parallel version: 49 us against 42 us of the SELL sweep on the 506 k-row level -- see profiles/README.md; off until it wins)
+    cfg->block_ep = 1;
     cfg->gs_omega = 1.2;      // measured (profiles/r02/a_iteration_ab.json): 7 -> 5 V-cycles to 1e-4 on the 3 M Poisson problem at the same cost per cycle
     return GMG_OK;
 } GMG_CATCH_0
@@ -208,11 +208,13 @@ static int refresh_fp32_twins(gmg_handle h, bool alloc) {
             launch_cvt(h, l.bc_val, l.bc_val32, (size_t)l.bc_nnz);
         }
         if (l.use_ep) {
-            if (alloc || !l.ep_val32) {
-                if (l.ep_val32) { (void)dev_free(l.ep_val32); l.ep_val32 = nullptr; }
+            if (alloc || !l.ep_val32 || !l.ee_val32) {
+                for (float** q : {&l.ep_val32, &l.ee_val32}) { if (*q) (void)dev_free(*q); *q = nullptr; }
                 HIPCHK(dev_malloc((void**)&l.ep_val32, sizeof(float) * (size_t)std::max<int64_t>(l.ep_nnz, 1)));
+                HIPCHK(dev_malloc((void**)&l.ee_val32, sizeof(float) * (size_t)std::max<int64_t>(l.ee_nnz, 1)));
             }
             launch_cvt(h, l.ep_val, l.ep_val32, (size_t)l.ep_nnz);
+            launch_cvt(h, l.ee_val, l.ee_val32, (size_t)l.ee_nnz);
         }
         if (alloc || !l.diag32) {
             if (l.diag32) { (void)dev_free(l.diag32); l.diag32 = nullptr; }
@@ -451,15 +453,18 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             const int lpr = (lk.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
             if (lk.ord.n_colors > 255) { st.ok = false; st.err = "more than 255 colours"; return; }
             if (!build_operator_sell(lk.A, lk.ord, lpr, st.sa, st.dg, st.err)) { st.ok = false; return; }
-            if (lk.ord.blocked && wants_block_csr(h, lpr)) {
-                build_operator_blockcsr(lk.A, lk.ord, st.bc);
-                st.use_bcsr = st.bc.max_block_entries <= kBcsrMaxBlockEntries;
-                if (st.use_bcsr && wants_block_ep(h, lpr)) {
-                    build_operator_blockcsr(lk.A, lk.ord, st.bin, true);
+            if (lk.ord.blocked && wants_block_ep(h, lpr)) {
+                build_operator_blockcsr(lk.A, lk.ord, st.bc, 3);       // "explicit" part
+                build_operator_blockcsr(lk.A, lk.ord, st.bin, 4);      // "lower" part
+                st.use_ep = st.bc.max_block_entries <= kEpMaxBlockEntries && st.bin.max_block_entries <= kEpMaxBlockEntries;
+                if (st.use_ep) {
                     st.ep16.resize(st.bin.col.size());
                     for (size_t i = 0; i < st.ep16.size(); ++i) st.ep16[i] = (unsigned short)st.bin.col[i];
-                    st.use_ep = true;
                 }
+            }
+            if (lk.ord.blocked && !st.use_ep && wants_block_csr(h, lpr)) {
+                build_operator_blockcsr(lk.A, lk.ord, st.bc);
+                st.use_bcsr = st.bc.max_block_entries <= kBcsrMaxBlockEntries;
             }
             if (lk.ord.blocked && !st.use_ep) {
                 build_operator_sell_split(lk.A, lk.ord, st.sin, st.sout, lpr);
@@ -621,17 +626,20 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if (!st.ok) { rc_all = GMG_ERR_NUMERIC; err_all = "level " + std::to_string(k) + ": " + st.err; break; }
         tu = clk::now();
         if ((rc = upload_sell(h, l.Aoff, st.sa)) || (rc = upload(h, &l.diag, st.dg))) { rc_all = rc; break; }
-        if (l.ord.blocked && st.use_bcsr) {
+        if (l.ord.blocked && st.use_ep) {
+            l.use_ep = true;
+            l.ee_nnz = st.bc.ptr[l.n_pad]; l.ep_nnz = st.bin.ptr[l.n_pad];
+            l.ep_cap_e = (st.bc.max_block_entries + 63) / 64 * 64; l.ep_cap_l = std::max(st.bin.max_block_entries, 1);
+            if ((rc = upload(h, &l.ee_ptr, st.bc.ptr)) || (rc = upload(h, &l.ee_col, st.bc.col)) || (rc = upload(h, &l.ee_val, st.bc.val)) ||
+                (rc = upload(h, &l.ep_ptr, st.bin.ptr)) || (rc = upload(h, &l.ep_col, st.ep16)) || (rc = upload(h, &l.ep_val, st.bin.val)) ||
+                (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) || (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) ||
+                (rc = upload(h, &l.d_row_color, l.ord.row_color))) { rc_all = rc; break; }
+        } else if (l.ord.blocked && st.use_bcsr) {
             l.use_bcsr = true;
             l.bc_cap = (st.bc.max_block_entries + 63) / 64 * 64;
             l.bc_nnz = st.bc.ptr[l.n_pad];
-            if (st.use_ep) {
-                l.use_ep = true;
-                l.ep_nnz = st.bin.ptr[l.n_pad];
-                l.ep_cap = (std::max(st.bc.max_block_entries, st.bin.max_colour_entries) + 63) / 64 * 64;
-                if ((rc = upload(h, &l.ep_ptr, st.bin.ptr)) || (rc = upload(h, &l.ep_col, st.ep16)) || (rc = upload(h, &l.ep_val, st.bin.val))) { rc_all = rc; break; }
-            } else if ((rc = upload_sell(h, l.Ain, st.sin)) || (rc = upload_sell(h, l.Aout, st.sout)) || (rc = upload(h, &l.ain_col16, st.c16))) { rc_all = rc; break; }
-            if ((rc = upload(h, &l.bc_ptr, st.bc.ptr)) || (rc = upload(h, &l.bc_mid, st.bc.mid)) || (rc = upload(h, &l.bc_col, st.bc.col)) ||
+            if ((rc = upload_sell(h, l.Ain, st.sin)) || (rc = upload_sell(h, l.Aout, st.sout)) || (rc = upload(h, &l.ain_col16, st.c16)) ||
+                (rc = upload(h, &l.bc_ptr, st.bc.ptr)) || (rc = upload(h, &l.bc_mid, st.bc.mid)) || (rc = upload(h, &l.bc_col, st.bc.col)) ||
                 (rc = upload(h, &l.bc_val, st.bc.val)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
                 (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) { rc_all = rc; break; }
         } else if (l.ord.blocked) {
@@ -769,10 +777,10 @@ int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info) try {
         info[0] = l.use_bcsr ? l.n_pad : 0; info[1] = 64; info[2] = l.use_bcsr ? l.bc_nnz : 0; info[3] = l.use_bcsr ? 1 : 0;
         return GMG_OK;
     }
-    if (which == 6) {      // in-block operator of the entry-parallel sweep (block-ordered CSR, local columns); row_of[0] <- ep_cap
+    if (which == 6 || which == 7) {      // unpadded block sweep: 6 = "lower" part (local columns), 7 = "explicit" part (device columns)
         Level& l = h->lv[k];
         if (!info) return fail(h, GMG_ERR_INVALID, "bad arguments");
-        info[0] = l.use_ep ? l.n_pad : 0; info[1] = 64; info[2] = l.use_ep ? l.ep_nnz : 0; info[3] = l.use_ep ? 1 : 0;
+        info[0] = l.use_ep ? l.n_pad : 0; info[1] = 64; info[2] = l.use_ep ? (which == 6 ? l.ep_nnz : l.ee_nnz) : 0; info[3] = l.use_ep ? 1 : 0;
         return GMG_OK;
     }
     DevSell* s = pick_sell(h, k, which);
@@ -797,20 +805,21 @@ int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int*
         if (val) HIPCHK(hipMemcpy(val, lb.bc_val, sizeof(double) * (size_t)lb.bc_nnz, hipMemcpyDeviceToHost));
         return GMG_OK;
     }
-    if (which == 6) {      // slice_ptr <- row pointers (n_pad + 1), col <- local columns, row_of[0] <- product-buffer capacity
+    if (which == 6 || which == 7) {      // slice_ptr <- row pointers (n_pad + 1), col <- columns, row_of[0] <- LDS capacity of that part
         Level& lb = h->lv[k];
         if (!lb.use_ep) return GMG_OK;
         HIPCHK(hipStreamSynchronize(h->stream));
+        const int64_t nnz = which == 6 ? lb.ep_nnz : lb.ee_nnz;
         std::vector<int> tmp((size_t)lb.n_pad + 1);
-        HIPCHK(hipMemcpy(tmp.data(), lb.ep_ptr, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tmp.data(), which == 6 ? lb.ep_ptr : lb.ee_ptr, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));
         if (slice_ptr) for (size_t i = 0; i < tmp.size(); ++i) slice_ptr[i] = tmp[i];
-        if (row_of) { std::memset(row_of, 0, sizeof(int) * (size_t)lb.n_pad); row_of[0] = lb.ep_cap; }
-        if (col) {
-            std::vector<unsigned short> c16((size_t)lb.ep_nnz);
+        if (row_of) { std::memset(row_of, 0, sizeof(int) * (size_t)lb.n_pad); row_of[0] = which == 6 ? lb.ep_cap_l : lb.ep_cap_e; }
+        if (col && which == 6) {
+            std::vector<unsigned short> c16((size_t)nnz);
             HIPCHK(hipMemcpy(c16.data(), lb.ep_col, sizeof(unsigned short) * c16.size(), hipMemcpyDeviceToHost));
             for (size_t i = 0; i < c16.size(); ++i) col[i] = c16[i];
-        }
-        if (val) HIPCHK(hipMemcpy(val, lb.ep_val, sizeof(double) * (size_t)lb.ep_nnz, hipMemcpyDeviceToHost));
+        } else if (col) HIPCHK(hipMemcpy(col, lb.ee_col, sizeof(int) * (size_t)nnz, hipMemcpyDeviceToHost));
+        if (val) HIPCHK(hipMemcpy(val, which == 6 ? lb.ep_val : lb.ee_val, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost));
         return GMG_OK;
     }
     DevSell* s = pick_sell(h, k, which);

@@ -21,6 +21,7 @@ template <> struct Prec<double> {
     static const double* diag(const Level& l) { return l.diag; }
     static const double* bcval(const Level& l) { return l.bc_val; }
     static const double* epval(const Level& l) { return l.ep_val; }
+    static const double* eeval(const Level& l) { return l.ee_val; }
     static double* x(Level& l) { return l.x; }
     static double* b(Level& l) { return l.b; }
     static double* r(Level& l) { return l.r; }
@@ -31,6 +32,7 @@ template <> struct Prec<float> {
     static const float* diag(const Level& l) { return l.diag32; }
     static const float* bcval(const Level& l) { return l.bc_val32; }
     static const float* epval(const Level& l) { return l.ep_val32; }
+    static const float* eeval(const Level& l) { return l.ee_val32; }
     static float* x(Level& l) { return l.x32; }
     static float* b(Level& l) { return l.b32; }
     static float* r(Level& l) { return l.r32; }
@@ -94,12 +96,12 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             if (l.use_ep) {
-                const char* dbg_env = std::getenv("GMG_EP_DBG"); const int dbg = dbg_env ? std::atoi(dbg_env) : 0;
                 const int grid = (nb + 7) / 8 * 8;          // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, grid)
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), (size_t)D * ((size_t)l.ep_cap + 64) * sizeof(T), h->stream,
-                                                  l.d_blk_begin, l.d_blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.bc_ptr, l.bc_col,
-                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                                  out + (size_t)c0 * ld, ld, l.ep_cap, nb, dbg));
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64),
+                                                  (size_t)D * 64 * sizeof(T) + std::max((size_t)l.ep_cap_e * sizeof(T), (size_t)l.ep_cap_l * (sizeof(T) + 2)), h->stream,
+                                                  l.d_blk_begin, l.d_blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
+                                                  Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                                  out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb));
             } else if (l.use_bcsr && d > 1) {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                                   (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, l.d_blk_begin,

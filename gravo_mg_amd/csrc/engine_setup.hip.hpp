@@ -279,7 +279,43 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         hipLaunchKernelGGL(gmgs::block_of_rows, dim3(std::max(1, l.ord.n_blocks())), dim3(64), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), d_blk_of_row.p);
         gmgs::RowFilter fin{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
         gmgs::RowFilter fout{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
-        if (wants_block_csr(h, lpr)) {
+        if (wants_block_ep(h, lpr)) {
+            // unpadded block sweep (gs_block_ep): "explicit" and "lower" parts as block-ordered CSRs.  Row pointers first:
+            // the largest block's chunks size the sweep's LDS buffers
+            gmgs::RowFilter fe{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 3, 1};
+            gmgs::RowFilter fl{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 4, 1};
+            DevTmp<int> len, d_max;
+            int nnz_e = 0, nnz_l = 0, bmax[2] = {0, 0};
+            if ((rc = len.alloc(h, l.n_pad)) || (rc = d_max.alloc(h, 2))) return rc;
+            HIPCHK(dev_malloc((void**)&l.ee_ptr, sizeof(int) * ((size_t)l.n_pad + 1)));
+            HIPCHK(dev_malloc((void**)&l.ep_ptr, sizeof(int) * ((size_t)l.n_pad + 1)));
+            HIPCHK(hipMemsetAsync(d_max.p, 0, 2 * sizeof(int), h->stream));
+            const dim3 gr((l.n_pad + 255) / 256), gb((l.ord.n_blocks() + 255) / 256);
+            hipLaunchKernelGGL(gmgs::row_lengths, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, fe, (const int*)nullptr, l.n_pad, len.p, d_err);
+            if ((rc = device_scan<int, int>(h, len.p, l.n_pad, l.ee_ptr, &nnz_e))) return rc;
+            hipLaunchKernelGGL(gmgs::block_entry_max, gb, dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.ee_ptr, d_max.p);
+            hipLaunchKernelGGL(gmgs::row_lengths, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, fl, (const int*)nullptr, l.n_pad, len.p, d_err);
+            if ((rc = device_scan<int, int>(h, len.p, l.n_pad, l.ep_ptr, &nnz_l))) return rc;
+            hipLaunchKernelGGL(gmgs::block_entry_max, gb, dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.ep_ptr, d_max.p + 1);
+            HIPCHK(hipMemcpyAsync(bmax, d_max.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (bmax[0] <= kEpMaxBlockEntries && bmax[1] <= kEpMaxBlockEntries) {
+                l.use_ep = true;
+                l.ee_nnz = nnz_e; l.ep_nnz = nnz_l;
+                l.ep_cap_e = (bmax[0] + 63) / 64 * 64; l.ep_cap_l = std::max(bmax[1], 1);
+                HIPCHK(dev_malloc((void**)&l.ee_col, sizeof(int) * (size_t)std::max(nnz_e, 1)));
+                HIPCHK(dev_malloc((void**)&l.ee_val, sizeof(double) * (size_t)std::max(nnz_e, 1)));
+                HIPCHK(dev_malloc((void**)&l.ep_col, sizeof(unsigned short) * (size_t)std::max(nnz_l, 1)));
+                HIPCHK(dev_malloc((void**)&l.ep_val, sizeof(double) * (size_t)std::max(nnz_l, 1)));
+                hipLaunchKernelGGL(gmgs::csr_fill_plain<int>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fe, l.n_pad, l.ee_ptr, l.ee_col, l.ee_val, d_err);
+                hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fl, l.n_pad, l.ep_ptr, l.ep_col,
+                                   l.ep_val, d_err);
+            } else {
+                (void)dev_free(l.ee_ptr); l.ee_ptr = nullptr;
+                (void)dev_free(l.ep_ptr); l.ep_ptr = nullptr;
+            }
+        }
+        if (!l.use_ep && wants_block_csr(h, lpr)) {
             // off-block operator as a block-ordered CSR; its row pointers first: they tell whether the largest block's
             // chunk fits the sweep's LDS budget
             DevTmp<int> len, d_max;
@@ -302,29 +338,9 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
                 hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, d_blk_of_row.p,
                                    l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
             } else { (void)dev_free(l.bc_ptr); l.bc_ptr = nullptr; }
-            if (l.use_bcsr && wants_block_ep(h, lpr)) {
-                // entry-parallel sweep: the in-block operator as block-ordered CSR too (16-bit local columns), and the size
-                // of the sweep's product buffer
-                int nnz_in = 0, cmax = 0;
-                HIPCHK(dev_malloc((void**)&l.ep_ptr, sizeof(int) * ((size_t)l.n_pad + 1)));
-                HIPCHK(hipMemsetAsync(d_max.p, 0, sizeof(int), h->stream));
-                hipLaunchKernelGGL(gmgs::row_lengths, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, fin, (const int*)nullptr, l.n_pad, len.p, d_err);
-                if ((rc = device_scan<int, int>(h, len.p, l.n_pad, l.ep_ptr, &nnz_in))) return rc;
-                hipLaunchKernelGGL(gmgs::block_colour_entry_max, dim3((l.ord.n_blocks() + 255) / 256), dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.d_row_color,
-                                   l.ep_ptr, d_max.p);
-                HIPCHK(hipMemcpyAsync(&cmax, d_max.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
-                l.ep_nnz = nnz_in;
-                l.ep_cap = (std::max(bmax, cmax) + 63) / 64 * 64;
-                HIPCHK(dev_malloc((void**)&l.ep_col, sizeof(unsigned short) * (size_t)std::max(nnz_in, 1)));
-                HIPCHK(dev_malloc((void**)&l.ep_val, sizeof(double) * (size_t)std::max(nnz_in, 1)));
-                hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, l.n_pad,
-                                   l.ep_ptr, l.ep_col, l.ep_val, d_err);
-                l.use_ep = true;
-            }
         }
         if (!l.use_ep) {
-            // (the entry-parallel sweep reads the two block-ordered CSR operators only: no padded SELL copies of the split operator)
+            // (the unpadded sweep reads its two block-ordered CSR operators only: no padded SELL copies of the split operator)
             if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, lpr, &l.ain_col16, nullptr, d_err))) return rc;
             // the padded SELL form of the off-block operator is kept as well: with one right-hand side the sweep that
             // streams it straight into registers is the faster one (42 vs 47 us on the 506 k-row level; 104 vs 60 us at d = 3)
@@ -395,14 +411,20 @@ int device_refill_level(gmg_handle h, int k, int* d_err) {
         if (!l.d_blk_of_row || !l.d_blk_begin) return fail(h, GMG_ERR_STATE, "level layout cannot be refilled");
         gmgs::RowFilter fin{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 1, 1};
         gmgs::RowFilter fout{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 2, 1};
+        if (l.use_ep) {
+            gmgs::RowFilter fe{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 3, 1};
+            gmgs::RowFilter fl{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 4, 1};
+            const dim3 gr((l.n_pad + 255) / 256);
+            hipLaunchKernelGGL(gmgs::csr_fill_plain<int>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fe, l.n_pad, l.ee_ptr, l.ee_col, l.ee_val, d_err);
+            hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fl, l.n_pad, l.ep_ptr, l.ep_col, l.ep_val,
+                               d_err);
+            return GMG_OK;
+        }
         if (l.use_bcsr)
             hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, l.d_blk_of_row,
                                l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
-        if (l.use_ep)
-            hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, l.n_pad,
-                               l.ep_ptr, l.ep_col, l.ep_val, d_err);
-        else if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, l.Ain.lpr, &l.ain_col16, nullptr, d_err, true)) ||
-                 (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
+        if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, l.Ain.lpr, &l.ain_col16, nullptr, d_err, true)) ||
+            (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
     }
     return GMG_OK;
 }

@@ -90,15 +90,16 @@ struct Level {
     float* bc_val32 = nullptr;
     int bc_cap = 0;               // entries of the largest block, rounded up to 64 (LDS capacity of the sweep)
     int64_t bc_nnz = 0;
-    // ... and, for the entry-parallel sweep (kernels.hip.hpp::gs_block_ep), the IN-BLOCK operator as block-ordered CSR too
-    // (16-bit local columns); the off-block part is the bc_* arrays above
+    // big blocked levels, default: the unpadded block sweep (kernels.hip.hpp::gs_block_ep) on two block-ordered CSRs --
+    // ee_*: "explicit" part (off-block entries + in-block entries with a later column; device columns),
+    // ep_*: "lower" part (in-block entries with an earlier column; 16-bit local columns).  No SELL split, no bc_* then.
     bool use_ep = false;
-    int* ep_ptr = nullptr;
+    int *ee_ptr = nullptr, *ee_col = nullptr, *ep_ptr = nullptr;
     unsigned short* ep_col = nullptr;
-    double* ep_val = nullptr;
-    float* ep_val32 = nullptr;
-    int64_t ep_nnz = 0;
-    int ep_cap = 0;               // product buffer of the sweep: max(off-block entries of a block, in-block entries of one colour of a block), rounded up to 64
+    double *ee_val = nullptr, *ep_val = nullptr;
+    float *ee_val32 = nullptr, *ep_val32 = nullptr;
+    int64_t ee_nnz = 0, ep_nnz = 0;
+    int ep_cap_e = 0, ep_cap_l = 0;      // most explicit / lower entries of one block (explicit: rounded up to 64): LDS capacity of the sweep
     int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
     unsigned char* d_row_color = nullptr;
     int* d_new2old = nullptr;
@@ -381,11 +382,11 @@ void free_level(Level& l) {
     if (l.bc_val) { (void)dev_free(l.bc_val); l.bc_val = nullptr; }
     if (l.bc_val32) { (void)dev_free(l.bc_val32); l.bc_val32 = nullptr; }
     l.use_bcsr = false; l.bc_cap = 0; l.bc_nnz = 0;
-    if (l.ep_ptr) { (void)dev_free(l.ep_ptr); l.ep_ptr = nullptr; }
+    for (int** q : {&l.ee_ptr, &l.ee_col, &l.ep_ptr}) { if (*q) (void)dev_free(*q); *q = nullptr; }
     if (l.ep_col) { (void)dev_free(l.ep_col); l.ep_col = nullptr; }
-    if (l.ep_val) { (void)dev_free(l.ep_val); l.ep_val = nullptr; }
-    if (l.ep_val32) { (void)dev_free(l.ep_val32); l.ep_val32 = nullptr; }
-    l.use_ep = false; l.ep_nnz = 0; l.ep_cap = 0;
+    for (double** q : {&l.ee_val, &l.ep_val}) { if (*q) (void)dev_free(*q); *q = nullptr; }
+    for (float** q : {&l.ee_val32, &l.ep_val32}) { if (*q) (void)dev_free(*q); *q = nullptr; }
+    l.use_ep = false; l.ee_nnz = l.ep_nnz = 0; l.ep_cap_e = l.ep_cap_l = 0;
     if (l.d_blk_begin) { (void)dev_free(l.d_blk_begin); l.d_blk_begin = nullptr; }
     if (l.d_blk_ncolors) { (void)dev_free(l.d_blk_ncolors); l.d_blk_ncolors = nullptr; }
     if (l.d_row_color) { (void)dev_free(l.d_row_color); l.d_row_color = nullptr; }
@@ -422,8 +423,9 @@ void drop_system(gmg_handle h) {
 }
 
 constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
+constexpr int kEpMaxBlockEntries = 6144;        // largest explicit / lower chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
 constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)
 inline bool wants_block_csr(gmg_handle h, int lpr) { return h->cfg.block_csr != 0 && lpr == 1 && h->cfg.block_rows == 64; }
-inline bool wants_block_ep(gmg_handle h, int lpr) { return wants_block_csr(h, lpr) && h->cfg.block_ep != 0; }
+inline bool wants_block_ep(gmg_handle h, int lpr) { return h->cfg.block_ep != 0 && lpr == 1 && h->cfg.block_rows == 64; }
 
 }  // namespace

@@ -727,32 +727,36 @@ inline SellHost build_transfer_sell(const Compressed& Mrows, const LevelOrdering
     return csr_to_sell(np, ocol.n_pad, st, sort_sigma, lpr);
 }
 
-// Block-CSR of the OFF-BLOCK operator of a blocked level (the specification of setup_kernels.hip.hpp::csr_fill with the
-// off-block filter): the entries of device row r that leave r's block, ascending device column; mid[r] = end of the row
-// (csr_fill writes in-block entries after it when its filter keeps them; here there are none).
+// Block-ordered CSR of part of a blocked level's operator in device numbering (the specification of the device builders
+// setup_kernels.hip.hpp::csr_fill / csr_fill_plain): the kept entries of device row r, ascending device column, at
+// [ptr[r], ptr[r + 1]).  part 2: the entries that LEAVE r's block (device column; mid[r] = end of the row -- csr_fill writes
+// in-block entries after it when its filter keeps them; here there are none).  Parts of the unpadded block sweep:
+// 3 = "explicit" (entries leaving the block + in-block entries with a later device column; device column),
+// 4 = "lower" (in-block entries with an earlier device column; column local to the block).
 struct BlockCsrHost {
     std::vector<int> ptr, mid;      // n_pad + 1, n_pad
     RawVec<int> col;
     RawVec<double> val;
     int max_block_entries = 0;
-    int max_colour_entries = 0;     // `inside` only: most entries of the rows of one colour of one block
 };
 
-// inside = false: the entries that LEAVE the row's block (device column).  inside = true: the entries that stay inside it
-// (column local to the block), the in-block operator of the entry-parallel sweep (setup_kernels.hip.hpp::csr_fill_plain).
-inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& ord, BlockCsrHost& out, bool inside = false) {
+inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& ord, BlockCsrHost& out, int part = 2) {
     const int np = ord.n_pad;
     out.ptr.assign((size_t)np + 1, 0);
     out.mid.assign(np, 0);
     std::vector<int> blk_of(np, 0);
     for (int b = 0; b < ord.n_blocks(); ++b) for (int r = ord.blk_begin[b]; r < ord.blk_begin[b + 1]; ++r) blk_of[r] = b;
+    auto keep = [part](int r, int c, int r0, int r1) {
+        const bool inside = c >= r0 && c < r1;
+        return part == 2 ? !inside : (part == 3 ? (!inside || c > r) : (inside && c < r));
+    };
     parallel_ranges(np, hw_threads(), [&](int lo, int hi, int) {
         for (int r = lo; r < hi; ++r) {
             const int old = ord.new2old[r];
             int n = 0;
             if (old >= 0) {
                 const int b = blk_of[r], r0 = ord.blk_begin[b], r1 = ord.blk_begin[b + 1];
-                for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int c = ord.old2new[A.idx[p]]; n += A.idx[p] != old && ((c < r0 || c >= r1) != inside); }
+                for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int c = ord.old2new[A.idx[p]]; n += A.idx[p] != old && keep(r, c, r0, r1); }
             }
             out.ptr[r + 1] = n;
         }
@@ -770,24 +774,13 @@ inline void build_operator_blockcsr(const Compressed& A, const LevelOrdering& or
                 if (old >= 0) for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) if (A.idx[p] != old) e.emplace_back(ord.old2new[A.idx[p]], A.val[p]);
                 std::stable_sort(e.begin(), e.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
                 int q = out.ptr[r];
-                for (auto& t : e) if ((t.first < r0 || t.first >= r1) != inside) { out.col[q] = inside ? t.first - r0 : t.first; out.val[q] = t.second; ++q; }
+                for (auto& t : e) if (keep(r, t.first, r0, r1)) { out.col[q] = part == 4 ? t.first - r0 : t.first; out.val[q] = t.second; ++q; }
                 out.mid[r] = q;
             }
         }
     }, 64);
     out.max_block_entries = 0;
     for (int b = 0; b < nb; ++b) out.max_block_entries = std::max(out.max_block_entries, out.ptr[ord.blk_begin[b + 1]] - out.ptr[ord.blk_begin[b]]);
-    out.max_colour_entries = 0;
-    if (inside)
-        for (int b = 0; b < nb; ++b) {
-            int run = 0, cur = -1;
-            for (int r = ord.blk_begin[b]; r < ord.blk_begin[b + 1]; ++r) {
-                const int c = ord.row_color[r];
-                if (c != cur) { cur = c; run = 0; }
-                run += out.ptr[r + 1] - out.ptr[r];
-                out.max_colour_entries = std::max(out.max_colour_entries, run);
-            }
-        }
 }
 
 // Rows of U (fine-row major) from its CSC storage, threaded: per-row counts with atomics, prefix sum, scatter.

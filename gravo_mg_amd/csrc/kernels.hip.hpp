@@ -345,34 +345,40 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
 }
 
-// The same sweep, ENTRY-PARALLEL (big blocked levels: 64-row blocks, one wavefront per block).  Both parts of the operator
-// are block-ordered CSR in device numbering (rows of a block are contiguous, so a block's entries are ONE chunk): nothing
-// is padded, a wave's loads are contiguous runs of entries whatever the row lengths are, and -- the point -- the number of
-// 64-lane gathers is ceil(entries / 64) instead of "length of the block's longest row" (the SELL sweeps above iterate to the
-// longest row: 2.96x the real off-block entries and 1.61x the in-block ones on the 506 k-row level, whose sweep moved
-// 200 MB for 103 MB of entries and paid one load -> gather round trip per group of 8 padded columns).
-//   1. every load the block needs is issued up front: off-block entries in kEpOut slots of 64 (column + value), in-block
-//      entries in kEpIn slots of 64 (16-bit local column + value; they stay in registers for the colour loop);
-//   2. off-block couplings (previous iterate): lane l gathers x for ITS ENTRIES, writes the products to LDS in entry order;
-//      then every lane sums the run of products that belongs to its row (CSR row pointers), ascending column order;
-//   3. colour loop: the in-block entries of one colour are one run (rows are colour-sorted inside a block); slot by slot the
-//      lanes holding entries of the current colour write value * x_lds[column] to LDS, and when the colour's run is
-//      complete its rows sum their products and update x in LDS.  Slots are walked with a compile-time index (registers),
-//      colours advance inside a slot (wave-uniform scalar control flow: ballot + readlane give the run boundaries).
-// Blocks with more entries than the register window (kEpIn * 64 in-block, kEpOut * 64 off-block) read the excess from
-// global memory in the same order.  Products are rounded before they are added (no fused multiply-add across lanes), the
-// summation order is that of the other block sweeps: same matrix form x_out = x_in + T^-1 (b - A x_in), tested to 1e-12.
-constexpr int kEpIn = 16, kEpOut = 8;
+// The same sweep for the big blocked levels (64-row blocks, one wavefront per block) on UNPADDED storage.  A block's
+// SELL slice is as wide as its longest row (2.96x the real off-block entries and 1.61x the in-block ones on the 506 k-row
+// level: the SELL sweep moved 200 MB for 103 MB of entries and paid one load -> gather round trip per group of 8 padded
+// columns).  Here the operator is two block-ordered CSRs in device numbering (rows of a block are contiguous, so a block's
+// entries are ONE chunk; a wave's loads are contiguous runs of entries whatever the row lengths are):
+//   E  the entries that multiply the PREVIOUS iterate: everything that leaves the block, and the in-block entries whose
+//      column comes later in the block than the row ("upper").  Handled ENTRY-PARALLEL: lane l gathers x_in for ITS
+//      ENTRIES (ceil(entries / 64) gathers per block instead of one per padded column), writes the products to LDS in
+//      entry order, and every row then sums its run of products (ascending column order).
+//   L  the in-block entries whose column comes earlier than the row ("lower", 16-bit local column): the sequential part.
+//      The slots are transposed through LDS into the row's lane (registers); the colour loop is then gathers from the
+//      block's x in LDS + FMAs only: a row reads updated values exclusively (rows are colour-sorted inside a block, so
+//      "lower" == "of an earlier colour").
+// Every load a block needs is issued before the first use.  Blocks / rows with more entries than the register windows
+// (kEpE * 64 explicit entries, kEpL * 64 lower entries per block, kEpW lower entries per row) read the excess from global
+// memory / LDS in the same order.  Same matrix form as the sweeps above, x_out = x_in + T^-1 (b - A x_in) with T = D +
+// strict lower triangle of the block diagonal in device order; only the summation grouping differs (tested to 1e-12).
+// What bounds it (profiles/README.md): the dependent LDS round trips of one block -- ~0.23 us of kernel time each at
+// 1.6 blocks per resident wave slot -- not LDS or HBM throughput; this formulation has ~25 of them (a first
+// entry-parallel version, which also reduced the in-block products through LDS colour by colour, had ~85 and was slower
+// than the SELL sweep).
+constexpr int kEpE = 12, kEpL = 8, kEpW = 16;
 template <class T, int D>
 __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
-                                                  const unsigned char* __restrict__ row_color, const int* __restrict__ in_ptr,
-                                                  const unsigned short* __restrict__ in_col, const T* __restrict__ in_val,
-                                                  const int* __restrict__ out_ptr, const int* __restrict__ out_col,
-                                                  const T* __restrict__ out_val, const T* __restrict__ diag, const T* __restrict__ b,
-                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap, int n_blocks, int dbg) {
+                                                  const unsigned char* __restrict__ row_color, const int* __restrict__ l_ptr,
+                                                  const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
+                                                  const int* __restrict__ e_ptr, const int* __restrict__ e_col,
+                                                  const T* __restrict__ e_val, const T* __restrict__ diag, const T* __restrict__ b,
+                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks) {
     extern __shared__ unsigned char smem_raw[];
-    T* pbuf = reinterpret_cast<T*>(smem_raw);                          // D x cap products
-    T* xs = pbuf + (size_t)D * cap;                                    // D x 64: the block's x
+    T* xs = reinterpret_cast<T*>(smem_raw);                            // D x 64: the block's new x
+    T* pbuf = xs + D * 64;                                             // cap_e products of one column ...
+    T* sval = pbuf;                                                    // ... later the staged lower entries: cap_l values
+    unsigned short* scol = reinterpret_cast<unsigned short*>(sval + cap_l);      // + cap_l local columns
     // XCD-aware block map: block b runs on XCD b % 8; give every XCD a contiguous run of (spatially neighbouring) blocks
     const int chunk = (int)(gridDim.x >> 3);
     const int blk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3));
@@ -380,128 +386,115 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     const int lane = threadIdx.x;
     const int r0 = blk_begin[blk];                                     // 64 rows (padding rows: no entries, diag 1, b 0, colour 0)
     const int row = r0 + lane;
-    const int e0 = out_ptr[r0], e1 = out_ptr[r0 + 64];
-    const int q0 = in_ptr[r0], q1 = in_ptr[r0 + 64];
-    const int Ein = q1 - q0, Eout = x_in ? e1 - e0 : 0;                // zero iterate: nothing couples in from outside the block
-    // ---- 1. all loads in flight
-    T iv[kEpIn];
-    unsigned ic[kEpIn / 2];
+    const int e0 = e_ptr[r0], e1 = e_ptr[r0 + 64];
+    const int q0 = l_ptr[r0], q1 = l_ptr[r0 + 64];
+    const int nE = x_in ? e1 - e0 : 0;                                 // zero iterate: the explicit part vanishes
+    const int nL = q1 - q0;
+    // ---- all loads in flight
+    int ec[kEpE];
+    T ev[kEpE];
 #pragma unroll
-    for (int m = 0; m < kEpIn / 2; ++m) ic[m] = 0u;
-#pragma unroll
-    for (int m = 0; m < kEpIn; ++m) {
-        iv[m] = (T)0.0;
-        if (64 * m < Ein) {                                            // wave-uniform
-            const int e = q0 + 64 * m + lane;
-            if (e < q1) { iv[m] = __builtin_nontemporal_load(in_val + e); ic[m >> 1] |= (unsigned)__builtin_nontemporal_load(in_col + e) << ((m & 1) * 16); }
-        }
-    }
-    int oc[kEpOut];
-    T ov[kEpOut];
-#pragma unroll
-    for (int k = 0; k < kEpOut; ++k) {
-        oc[k] = row; ov[k] = (T)0.0;
-        if (64 * k < Eout) {
+    for (int k = 0; k < kEpE; ++k) {
+        ec[k] = row; ev[k] = (T)0.0;
+        if (64 * k < nE) {                                             // wave-uniform
             const int e = e0 + 64 * k + lane;
-            if (e < e1) { oc[k] = __builtin_nontemporal_load(out_col + e); ov[k] = __builtin_nontemporal_load(out_val + e); }
+            if (e < e1) { ec[k] = __builtin_nontemporal_load(e_col + e); ev[k] = __builtin_nontemporal_load(e_val + e); }
         }
     }
-    const int ib = in_ptr[row] - q0, ie = in_ptr[row + 1] - q0;
-    const int ob = out_ptr[row] - e0, oe = x_in ? out_ptr[row + 1] - e0 : ob;
+    T lv[kEpL];
+    unsigned short lc[kEpL];
+#pragma unroll
+    for (int m = 0; m < kEpL; ++m) {
+        lv[m] = (T)0.0; lc[m] = 0;
+        if (64 * m < nL) {
+            const int e = q0 + 64 * m + lane;
+            if (e < q1) { lv[m] = __builtin_nontemporal_load(l_val + e); lc[m] = __builtin_nontemporal_load(l_col + e); }
+        }
+    }
+    const int eb = e_ptr[row] - e0, ee = x_in ? e_ptr[row + 1] - e0 : eb;
+    const int lb = l_ptr[row] - q0, nlow = l_ptr[row + 1] - q0 - lb;
     const int mycolor = row_color[row];
     const T dg = (T)1.0 / diag[row];
     T rhs[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) { rhs[c] = b[row + (int64_t)c * ld]; xs[c * 64 + lane] = x_in ? x_in[row + (int64_t)c * ld] : (T)0.0; }
-    // ---- 2. off-block couplings
-    if (Eout > 0 && !(dbg & 2)) {
+    for (int c = 0; c < D; ++c) { rhs[c] = b[row + (int64_t)c * ld]; xs[c * 64 + lane] = (T)0.0; }      // (zero: padded register slots multiply x[0] by 0)
+    // ---- E: explicit part, one right-hand side at a time through the product buffer
+    if (nE > 0) {
 #pragma unroll
-        for (int k = 0; k < kEpOut; ++k)
-            if (64 * k < Eout) {
+        for (int c = 0; c < D; ++c) {
+            const T* xc = x_in + (int64_t)c * ld;
 #pragma unroll
-                for (int c = 0; c < D; ++c) pbuf[c * cap + 64 * k + lane] = ov[k] * x_in[oc[k] + (int64_t)c * ld];
+            for (int k = 0; k < kEpE; ++k)
+                if (64 * k < nE) pbuf[64 * k + lane] = ev[k] * xc[ec[k]];
+            for (int e = 64 * kEpE + lane; e < nE; e += 64) pbuf[e] = e_val[e0 + e] * xc[e_col[e0 + e]];      // beyond the register window (rare)
+            __syncthreads();
+            T acc = (T)0.0;
+            for (int q = eb; q < ee; q += 16) {                        // all reads of a batch in flight, then the adds in stored order
+                T p[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) p[j] = q + j < ee ? pbuf[q + j] : (T)0.0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc += p[j];
             }
-        for (int e = 64 * kEpOut + lane; e < Eout; e += 64) {          // beyond the register window (rare)
-            const T v = out_val[e0 + e];
-            const int cj = out_col[e0 + e];
-#pragma unroll
-            for (int c = 0; c < D; ++c) pbuf[c * cap + e] = v * x_in[cj + (int64_t)c * ld];
+            rhs[c] -= acc;
+            __syncthreads();                                           // the buffer is free again
         }
-        __syncthreads();
-        T acc[D];
-#pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] = (T)0.0;
-        for (int q = ob; q < oe; q += 4) {
-            T p[4][D];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int c = 0; c < D; ++c) p[j][c] = q + j < oe ? pbuf[c * cap + q + j] : (T)0.0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int c = 0; c < D; ++c) acc[c] += p[j][c];
-        }
-#pragma unroll
-        for (int c = 0; c < D; ++c) rhs[c] -= acc[c];
     }
-    __syncthreads();                                                   // xs complete; the product buffer is free again
-    // ---- 3. colour loop over the in-block entries
+    // ---- L: slots -> LDS -> the row's lane
+#pragma unroll
+    for (int m = 0; m < kEpL; ++m)
+        if (64 * m < nL) {
+            const int e = 64 * m + lane;
+            if (e < nL) { sval[e] = lv[m]; scol[e] = lc[m]; }
+        }
+    for (int e = 64 * kEpL + lane; e < nL; e += 64) { sval[e] = l_val[q0 + e]; scol[e] = l_col[q0 + e]; }
+    __syncthreads();
+    T v[kEpW];
+    int cj[kEpW];
+#pragma unroll
+    for (int j = 0; j < kEpW; ++j) {
+        v[j] = (T)0.0; cj[j] = 0;
+        if (j < nlow) { v[j] = sval[lb + j]; cj[j] = scol[lb + j]; }
+    }
     const int nc = blk_ncolors[blk];
-    // first in-block entry of colour cc (block-local): rows are colour-sorted, ib is non-decreasing over the lanes
-    auto colour_start = [&](int cc) -> int {
-        const unsigned long long mask = __ballot(mycolor >= cc);
-        return mask ? __builtin_amdgcn_readlane(ib, (int)__builtin_ctzll(mask)) : Ein;
-    };
-    auto finish_colour = [&](int cc, int qa) {                        // rows of colour cc: sum their run of products, update x
-        __syncthreads();
-        if (mycolor == cc && !(dbg & 4)) {
+    for (int col = 0; col < nc; ++col) {
+        const bool wide = __ballot(mycolor == col && nlow > 8) != 0ull;      // wave-uniform: a row of this colour has more than 8 lower entries
+        if (mycolor == col) {
             T s_[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) s_[c] = (T)0.0;
-            for (int q = ib - qa; q < ie - qa; q += 4) {
-                T p[4][D];
+            {
+                T xv[8][D];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int c = 0; c < D; ++c) p[j][c] = q + j < ie - qa ? pbuf[c * cap + q + j] : (T)0.0;
+                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + cj[j]];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int c = 0; c < D; ++c) s_[c] += p[j][c];
+                    for (int c = 0; c < D; ++c) s_[c] += v[j] * xv[j][c];
+            }
+            if (wide) {
+                T xv[kEpW - 8][D];
+#pragma unroll
+                for (int j = 8; j < kEpW; ++j)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) xv[j - 8][c] = xs[c * 64 + cj[j]];
+#pragma unroll
+                for (int j = 8; j < kEpW; ++j)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) s_[c] += v[j] * xv[j - 8][c];
+                for (int j = kEpW; j < nlow; ++j) {                   // rows with more lower entries than the register window (rare)
+                    const T vj = sval[lb + j];
+                    const int cc = scol[lb + j];
+#pragma unroll
+                    for (int c = 0; c < D; ++c) s_[c] += vj * xs[c * 64 + cc];
+                }
             }
 #pragma unroll
             for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - s_[c]) * dg;
         }
         __syncthreads();
-    };
-    int col = 0, qa = 0, qb = colour_start(1);
-#pragma unroll
-    for (int m = 0; m < kEpIn; ++m) {
-        if (64 * m >= Ein || col >= nc || (dbg & 1)) break;
-        const int e = 64 * m + lane;                                   // the entry this lane holds in slot m
-        const int cj = (ic[m >> 1] >> ((m & 1) * 16)) & 0xffff;
-        while (qa < 64 * m + 64) {                                     // colours with a piece in this slot (or empty ones before it)
-            if (e >= qa && e < qb && !(dbg & 8)) {
-#pragma unroll
-                for (int c = 0; c < D; ++c) pbuf[c * cap + e - qa] = iv[m] * xs[c * 64 + cj];
-            }
-            if (qb > 64 * m + 64) break;                               // the colour continues in the next slot
-            finish_colour(col, qa);
-            if (++col >= nc) break;
-            qa = qb; qb = colour_start(col + 1);
-        }
-    }
-    for (; col < nc && !(dbg & 1); ++col) {                                          // entries beyond the register window, colours without entries
-        const int lo = qa > 64 * kEpIn ? qa : 64 * kEpIn;
-        for (int e = lo + lane; e < qb; e += 64) {
-            const T v = in_val[q0 + e];
-            const int cj = in_col[q0 + e];
-#pragma unroll
-            for (int c = 0; c < D; ++c) pbuf[c * cap + e - qa] = v * xs[c * 64 + cj];
-        }
-        finish_colour(col, qa);
-        qa = qb; qb = colour_start(col + 2);
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];

@@ -12,7 +12,9 @@ namespace gmgs {
 
 constexpr int kMaxRow = 96;          // longest row the device builder sorts in private memory (host fallback beyond)
 
-// mode: 0 = every entry, 1 = only entries whose column lies in the row's block, 2 = only entries leaving the block
+// mode: 0 = every entry, 1 = only entries whose column lies in the row's block, 2 = only entries leaving the block,
+// 3 = "explicit" part of the unpadded block sweep (entries leaving the block + in-block entries with a LATER device column),
+// 4 = "lower" part (in-block entries with an EARLIER device column; local column like mode 1)
 struct RowFilter {
     const int* new2old_row;      // [n_rows_pad]  -1 = padding row
     const int* old2new_col;      // [n_cols]
@@ -28,7 +30,9 @@ __device__ __forceinline__ bool keep_entry(const RowFilter& f, int dev_row, int 
     if (f.mode == 0) { out_col = nc; return true; }
     const bool inside = f.blk_of_row[nc] == f.blk_of_row[dev_row];
     if (f.mode == 1) { out_col = nc - f.blk_begin[f.blk_of_row[dev_row]]; return inside; }
+    if (f.mode == 4) { out_col = nc - f.blk_begin[f.blk_of_row[dev_row]]; return inside && nc < dev_row; }
     out_col = nc;
+    if (f.mode == 3) return !inside || nc > dev_row;
     return !inside;
 }
 
@@ -163,23 +167,6 @@ __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restri
     }
     int q = row_ptr[r];
     for (int e = 0; e < n; ++e, ++q) { col[q] = (ColT)cs[e]; out_val[q] = vs[e]; }
-}
-
-// max over (block, colour) of the in-block entries of that colour's rows (rows are colour-sorted inside a block, padding
-// rows -- colour 0, no entries -- at its end): the product buffer the entry-parallel sweep needs for one colour
-__global__ void block_colour_entry_max(const int* __restrict__ blk_begin, int n_blocks, const unsigned char* __restrict__ row_color,
-                                       const int* __restrict__ row_ptr, int* __restrict__ out_max) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_blocks) return;
-    int best = 0, run = 0, cur = -1;
-    for (int r = blk_begin[b]; r < blk_begin[b + 1]; ++r) {
-        const int len = row_ptr[r + 1] - row_ptr[r];
-        const int c = row_color[r];
-        if (c != cur) { cur = c; run = 0; }
-        run += len;
-        best = run > best ? run : best;
-    }
-    atomicMax(out_max, best);
 }
 
 // max over the blocks of their entry count (LDS capacity the sweep kernel needs)

@@ -1,6 +1,6 @@
 """Level-1 block sweep on the 3 M-vertex bench workload: time per sweep for engine variants / debug modes."""
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gravo_mg_amd import cabi, meshgen
 V, F = meshgen.torus_mesh(1732, 1732)

@@ -34,7 +34,7 @@ def test_device_layout_equals_host_layout(cabi, case, kw):
         nd, cd = dev.level_ordering(k); nh, ch = host.level_ordering(k)
         assert np.array_equal(nd, nh) and np.array_equal(cd, ch)
         blocked = dev.level_blocks(k) is not None
-        for which in ([0, 3, 4] + ([1, 2, 5, 6] if blocked else [])):      # 5 / 6 = block-CSR off-block / in-block operators (big blocked levels), else empty
+        for which in ([0, 3, 4] + ([1, 2, 5, 6, 7] if blocked else [])):      # 5 = block-CSR off-block operator, 6 / 7 = lower / explicit parts of the unpadded block sweep (big blocked levels), else empty
             a, b = dev.debug_sell(k, which), host.debug_sell(k, which)
             assert (a["n_slices"], a["lpr"]) == (b["n_slices"], b["lpr"]), (k, which)
             assert np.array_equal(a["slice_ptr"], b["slice_ptr"]), (k, which)
