@@ -18,7 +18,7 @@ import numpy as np
 import scipy.sparse as sp
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgravomg_hip.so")
+LIB_PATH = os.environ.get("GMG_LIB_PATH") or os.path.join(_HERE, "lib", "libgravomg_hip.so")      # (override: A/B runs of experimental builds)
 
 GMG_OK, GMG_ERR_INVALID, GMG_ERR_NO_DEVICE, GMG_ERR_HIP, GMG_ERR_STATE, GMG_ERR_NUMERIC, GMG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 SMOOTHER_MULTICOLOR_GS, SMOOTHER_JACOBI = 0, 1

@@ -673,7 +673,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     h->timing["setup_h2d"] = ms_h2d;
     (void)tl;
     {
-        int nblk = kNormBlocks;
+        int nblk = std::max(kNormBlocks, grid_for((h->lv[0].n_pad + 63) / 64));        // one partial per four level-0 slices
         if (nblk > h->partial_blocks) {
             if (h->d_partials) (void)dev_free(h->d_partials);
             HIPCHK(dev_malloc((void**)&h->d_partials, sizeof(double) * (size_t)nblk * 8));
@@ -1193,7 +1193,7 @@ int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) try {
                                               l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, sb, se,
                                               h->d_partials + (size_t)c * nblk * 2 * dc));
         }
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0,
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0,
                            (unsigned long long*)nullptr, 0ull);
     }
     HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));

@@ -174,6 +174,24 @@ void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const 
 }
 template <class T>
 void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+    static const int ns_env = [] { const char* e = std::getenv("GMG_RESTRICT_NS"); return e ? std::atoi(e) : 2; }();      // experiment knob: slices per wave
+    if (fine.R.lpr == 4 && ns_env > 1 && fine.R.n_slices >= 4096 && d <= 2) {
+        // big restrictions: several slices per wave (kernels.hip.hpp::restrict_quad)
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            const int waves = (fine.R.n_slices + ns_env - 1) / ns_env;
+            if (ns_env == 4) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::restrict_quad<T, D, 4>), dim3(grid_for(waves)), dim3(gmgk::kBlock), 0, h->stream, fine.R.slice_ptr, fine.R.col,
+                                                  Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad, dst + (size_t)c0 * coarse.n_pad,
+                                                  coarse.n_pad, fine.R.n_slices, 1));
+            } else {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::restrict_quad<T, D, 2>), dim3(grid_for(waves)), dim3(gmgk::kBlock), 0, h->stream, fine.R.slice_ptr, fine.R.col,
+                                                  Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad, dst + (size_t)c0 * coarse.n_pad,
+                                                  coarse.n_pad, fine.R.n_slices, 1));
+            }
+        }
+        return;
+    }
     if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst);
     else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst);
 }
@@ -229,10 +247,10 @@ int wait_norm(gmg_handle h) {
 // the reduction of one group of <= 4 columns: into h_norm + flag when polled, into d_norm (+ a copy later) otherwise
 void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
     if (polled(h))
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->h_norm + 2 * c0,
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->h_norm + 2 * c0,
                            last ? h->h_flag : nullptr, last ? ++h->flag_seq[0] : 0ull);
     else
-        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0,
+        hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0,
                            (unsigned long long*)nullptr, 0ull);
 }
 
@@ -240,13 +258,13 @@ void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
 int launch_norm(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
+    const int nblk = grid_for(l.Aoff.n_slices);          // one slice per wave, like the residual SpMV; one partial per block
     const bool poll = polled(h);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_norm_partials<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                           l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
-                                          l.n_pad, 0, l.Aoff.n_slices, h->d_partials));
+                                          l.n_pad, l.Aoff.n_slices, (float*)nullptr, h->d_partials));
         launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
     }
     if (!poll) HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
@@ -452,11 +470,11 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
 int launch_residual_to_f32(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = std::min(kNormBlocks, (l.Aoff.n_slices + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock);
+    const int nblk = grid_for(l.Aoff.n_slices);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::residual_to_f32_with_norm<D>, dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
-                                          l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, 0, l.Aoff.n_slices,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 1>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
+                                          l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, l.Aoff.n_slices,
                                           l.b32 + (size_t)c0 * l.n_pad, h->d_partials));
         launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
     }

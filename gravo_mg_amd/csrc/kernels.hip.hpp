@@ -450,12 +450,15 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     for (int e = 64 * kEpL + lane; e < nL; e += 64) { sval[e] = l_val[q0 + e]; scol[e] = l_col[q0 + e]; }
     __syncthreads();
     T v[kEpW];
-    int cj[kEpW];
+    unsigned cpk[kEpW / 4];                                            // local columns (< 64), four to a register
+#pragma unroll
+    for (int j = 0; j < kEpW / 4; ++j) cpk[j] = 0u;
 #pragma unroll
     for (int j = 0; j < kEpW; ++j) {
-        v[j] = (T)0.0; cj[j] = 0;
-        if (j < nlow) { v[j] = sval[lb + j]; cj[j] = scol[lb + j]; }
+        v[j] = (T)0.0;
+        if (j < nlow) { v[j] = sval[lb + j]; cpk[j >> 2] |= (unsigned)scol[lb + j] << ((j & 3) * 8); }
     }
+#define GMG_EP_COL(j) ((int)((cpk[(j) >> 2] >> (((j) & 3) * 8)) & 0xffu))
     const int nc = blk_ncolors[blk];
     for (int col = 0; col < nc; ++col) {
         const bool wide = __ballot(mycolor == col && nlow > 8) != 0ull;      // wave-uniform: a row of this colour has more than 8 lower entries
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
-                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + cj[j]];
+                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + GMG_EP_COL(j)];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
 #pragma unroll
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 #pragma unroll
                 for (int j = 8; j < kEpW; ++j)
 #pragma unroll
-                    for (int c = 0; c < D; ++c) xv[j - 8][c] = xs[c * 64 + cj[j]];
+                    for (int c = 0; c < D; ++c) xv[j - 8][c] = xs[c * 64 + GMG_EP_COL(j)];
 #pragma unroll
                 for (int j = 8; j < kEpW; ++j)
 #pragma unroll
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
+#undef GMG_EP_COL
 }
 
 // The same sweep on the QUAD layout (4 lanes per row; blocks of <= 256 rows = 1024 threads).  A colour step is the
@@ -668,15 +672,89 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
     }
 }
 
-// out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of 256 threads, fixed order.
+// Restriction with NS consecutive slices per wave (quad layout).  The plain kernel above is latency-bound on this operator:
+// a slice is 16 rows x ~18 entries = 3.5 KB behind a chain of three dependent memory round trips (slice pointer -> column /
+// value loads -> gathers), 31.6 k waves = 3.9 residency rounds at 3 M vertices, 3.4 TB/s.  Here the loads of all NS slices are
+// issued before the first gather and the gathers before the first use: the same chain carries NS times the bytes.
+// Accumulation order per row is that of the plain kernel (stored order, then the quad reduction): same results bit for bit.
+template <class T, int D, int NS>
+__global__ __launch_bounds__(kBlock) void restrict_quad(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                        const T* __restrict__ val, const int* __restrict__ row_of,
+                                                        const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n_slices,
+                                                        int xcd_swizzle) {
+    constexpr int G = 8;
+    const int s0 = wave_slice(0, xcd_swizzle) * NS;
+    if (s0 >= n_slices) return;
+    const int lane = threadIdx.x & 63;
+    int64_t p[NS];
+    int w[NS];
+    T acc[NS][D];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const bool live = s0 + i < n_slices;                          // wave-uniform
+        p[i] = live ? slice_ptr[s0 + i] : 0;
+        w[i] = live ? (int)((slice_ptr[s0 + i + 1] - p[i]) >> 6) : 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[i][c] = (T)0.0;
+    }
+    for (int g = 0;; g += G) {                                        // groups of G entries per lane; one pass for the usual row lengths
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) any = any || w[i] > g;
+        if (!any) break;
+        int cc[NS][G];
+        T vv[NS][G];
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                cc[i][j] = 0; vv[i][j] = (T)0.0;
+                if (g + j < w[i]) {                                   // wave-uniform
+                    cc[i][j] = __builtin_nontemporal_load(col + p[i] + (int64_t)(g + j) * 64 + lane);
+                    vv[i][j] = __builtin_nontemporal_load(val + p[i] + (int64_t)(g + j) * 64 + lane);
+                }
+            }
+        T xv[NS][G][D];
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (g + j < w[i]) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) xv[i][j][c] = x[cc[i][j] + (int64_t)c * ldx];
+                }
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+#pragma unroll
+            for (int j = 0; j < G; ++j)
+                if (g + j < w[i]) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) acc[i][c] += vv[i][j] * xv[i][j][c];
+                }
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (s0 + i >= n_slices) break;
+        quad_reduce<T, D>(acc[i]);
+        if (lane & 3) continue;
+        const int srow = (s0 + i) * 16 + (lane >> 2);
+        const int row = row_of ? row_of[srow] : srow;
+        if (row < 0) continue;
+#pragma unroll
+        for (int c = 0; c < D; ++c) y[row + (int64_t)c * ldy] = acc[i][c];
+    }
+}
+
+// out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of kReduceBlock threads, fixed order.
+constexpr int kReduceBlock = 1024;
 __device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp, double* __restrict__ out,
                                                       double* red) {
     for (int c = 0; c < ncomp; ++c) {
         double v = 0.0;
-        for (int i = threadIdx.x; i < n_blocks; i += kBlock) v += partials[(int64_t)i * ncomp + c];
+        for (int i = threadIdx.x; i < n_blocks; i += kReduceBlock) v += partials[(int64_t)i * ncomp + c];
         red[threadIdx.x] = v;
         __syncthreads();
-        for (int off = kBlock / 2; off > 0; off >>= 1) {
+        for (int off = kReduceBlock / 2; off > 0; off >>= 1) {
             if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
             __syncthreads();
         }
@@ -687,9 +765,9 @@ __device__ __forceinline__ void block_reduce_partials(const double* __restrict__
 
 // flag != nullptr: `out` is host-visible pinned memory and `seq` is published in *flag after the sums -- the host polls
 // that word instead of paying a copy kernel and a stream synchronisation per residual check.
-__global__ __launch_bounds__(kBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
-                                                          double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
-    __shared__ double red[kBlock];
+__global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
+                                                                double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
+    __shared__ double red[kReduceBlock];
     block_reduce_partials(partials, n_blocks, ncomp, out, red);
     if (flag) {
         __threadfence_system();
@@ -763,22 +841,27 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
     }
 }
 
-// ---- mixed precision (fp32 inner V-cycle inside an fp64 defect-correction loop, BASELINE config 5) ----------------
-// r = b - A x in fp64 (fine operator, fp64 iterate), written as the fp32 right-hand side of the inner cycle, and the
-// partial sums of the residual norms of the SAME residual (so the check costs no second pass over A).
-template <int D>
-__global__ __launch_bounds__(kBlock) void residual_to_f32_with_norm(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                                    const double* __restrict__ val, const double* __restrict__ diag,
-                                                                    const double* __restrict__ b, const double* __restrict__ x,
-                                                                    const double* __restrict__ weight, int ld, int slice_begin, int slice_end,
-                                                                    float* __restrict__ r32, double* __restrict__ partials) {
+// The same sums with the launch geometry of the residual SpMV -- one slice per wave, XCD-aware slice map, one partial per
+// block of four slices (n_slices / 4 of them; reduce_partials adds them in index order, so the result does not depend on
+// which block ran where).  The grid-stride kernel above walks ~6 slices per wave one after the other, each with its own
+// load -> gather round trips: 59 us against 47 us for the SpMV over the same matrix at 3 M vertices.  MODE 1 also writes the
+// residual b - A x as the fp32 right-hand side of the mixed-precision inner cycle (the defect-correction loop of BASELINE config 5).
+template <int D, int MODE>
+__global__ __launch_bounds__(kBlock) void residual_norm_slices(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                               const double* __restrict__ val, const double* __restrict__ diag,
+                                                               const double* __restrict__ b, const double* __restrict__ x,
+                                                               const double* __restrict__ weight, int ld, int n_slices,
+                                                               float* __restrict__ r32, double* __restrict__ partials) {
     __shared__ double red[kWavesPerBlock][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // partial index = the position of this block's four slices in the slice range, not blockIdx (the XCD map permutes blocks)
+    int nblk = gridDim.x, bb = blockIdx.x;
+    if ((nblk & 7) == 0) bb = (bb & 7) * (nblk >> 3) + (bb >> 3);
+    const int s = __builtin_amdgcn_readfirstlane(bb * kWavesPerBlock + wave);
     double sums[2 * D];
 #pragma unroll
     for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
-    for (int s = slice_begin + __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + wave); s < slice_end;
-         s += gridDim.x * kWavesPerBlock) {
+    if (s < n_slices) {
         const int row = s * 64 + lane;
         double acc[D];
         row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
@@ -787,10 +870,11 @@ __global__ __launch_bounds__(kBlock) void residual_to_f32_with_norm(const int64_
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             const double bi = b[row + (int64_t)c * ld];
-            const double r = bi - (acc[c] + dg * x[row + (int64_t)c * ld]);
-            r32[row + (int64_t)c * ld] = (float)r;
-            sums[2 * c] += (r * w) * r;
-            sums[2 * c + 1] += (bi * w) * bi;
+            double r;
+            if (MODE == 1) { r = bi - (acc[c] + dg * x[row + (int64_t)c * ld]); r32[row + (int64_t)c * ld] = (float)r; }
+            else r = acc[c] + dg * x[row + (int64_t)c * ld] - bi;
+            sums[2 * c] = (r * w) * r;
+            sums[2 * c + 1] = (bi * w) * bi;
         }
     }
 #pragma unroll
@@ -805,10 +889,11 @@ __global__ __launch_bounds__(kBlock) void residual_to_f32_with_norm(const int64_
         double v = 0.0;
 #pragma unroll
         for (int w2 = 0; w2 < kWavesPerBlock; ++w2) v += red[w2][threadIdx.x];
-        partials[(int64_t)blockIdx.x * (2 * D) + threadIdx.x] = v;
+        partials[(int64_t)bb * (2 * D) + threadIdx.x] = v;
     }
 }
 
+// ---- mixed precision (fp32 inner V-cycle inside an fp64 defect-correction loop, BASELINE config 5) ----------------
 // x (fp64) += e (fp32): the correction of one inner V-cycle
 __global__ void add_correction(const float* __restrict__ e, double* __restrict__ x, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -11,11 +11,9 @@ variants = [a for a in sys.argv[1:]] or ["", "block_ep=0"]
 for v in variants:
     kw = dict(a.split('=') for a in v.split(',') if a and not a.startswith("DBG"))
     kw = {k: int(x) for k, x in kw.items()}
-    dbgs = [a[3:] for a in v.split(',') if a.startswith("DBG")] or ["0"]
     eng = cabi.Engine(**kw)
     eng.use_hierarchy(H); eng.set_mass(mass); eng.set_system(lhs)
-    for dbg in dbgs:
-        os.environ["GMG_EP_DBG"] = dbg
+    for dbg in ["0"]:
         line = f"{v or 'default':30s} dbg={dbg:3s}"
         for d in (1, 3):
             t_ms, _ = eng.bench_kernel(0, 1, d, 50)
@@ -24,5 +22,4 @@ for v in variants:
             eng.load_problem(rhs, rhs); eng.run_cycles(3, 2)
             t = time.perf_counter(); eng.run_cycles(20, 2); line += f" | cycle {50 * (time.perf_counter() - t):.3f} ms"
         print(line, flush=True)
-    os.environ["GMG_EP_DBG"] = "0"
     eng.close()
