@@ -174,24 +174,6 @@ void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const 
 }
 template <class T>
 void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
-    static const int ns_env = [] { const char* e = std::getenv("GMG_RESTRICT_NS"); return e ? std::atoi(e) : 2; }();      // experiment knob: slices per wave
-    if (fine.R.lpr == 4 && ns_env > 1 && fine.R.n_slices >= 4096 && d <= 2) {
-        // big restrictions: several slices per wave (kernels.hip.hpp::restrict_quad)
-        for (int c0 = 0; c0 < d; c0 += 4) {
-            int dc = std::min(4, d - c0);
-            const int waves = (fine.R.n_slices + ns_env - 1) / ns_env;
-            if (ns_env == 4) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::restrict_quad<T, D, 4>), dim3(grid_for(waves)), dim3(gmgk::kBlock), 0, h->stream, fine.R.slice_ptr, fine.R.col,
-                                                  Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad, dst + (size_t)c0 * coarse.n_pad,
-                                                  coarse.n_pad, fine.R.n_slices, 1));
-            } else {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::restrict_quad<T, D, 2>), dim3(grid_for(waves)), dim3(gmgk::kBlock), 0, h->stream, fine.R.slice_ptr, fine.R.col,
-                                                  Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad, dst + (size_t)c0 * coarse.n_pad,
-                                                  coarse.n_pad, fine.R.n_slices, 1));
-            }
-        }
-        return;
-    }
     if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst);
     else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst);
 }

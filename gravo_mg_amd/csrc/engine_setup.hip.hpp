@@ -378,8 +378,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         }
         phase("R order");
         gmgs::RowFilter fr{c.d_new2old, d_old2new.p, nullptr, nullptr, 0, 0};
-        static const int r_lanes_env = [] { const char* e = std::getenv("GMG_R_LANES"); return e ? std::atoi(e) : 0; }();      // experiment knob
-        const int lpr_r = r_lanes_env == 1 || r_lanes_env == 4 ? r_lanes_env : (h->cfg.block_lanes == 1 ? 1 : 4);
+        const int lpr_r = h->cfg.block_lanes == 1 ? 1 : 4;
         if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) return rc;
         l.R.nnz_real = U.nnz();
         if (sigma > 0) { l.R.row_of = d_order.p; d_order.p = nullptr; }     // the order array becomes the output-row map

@@ -672,79 +672,6 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
     }
 }
 
-// Restriction with NS consecutive slices per wave (quad layout).  The plain kernel above is latency-bound on this operator:
-// a slice is 16 rows x ~18 entries = 3.5 KB behind a chain of three dependent memory round trips (slice pointer -> column /
-// value loads -> gathers), 31.6 k waves = 3.9 residency rounds at 3 M vertices, 3.4 TB/s.  Here the loads of all NS slices are
-// issued before the first gather and the gathers before the first use: the same chain carries NS times the bytes.
-// Accumulation order per row is that of the plain kernel (stored order, then the quad reduction): same results bit for bit.
-template <class T, int D, int NS>
-__global__ __launch_bounds__(kBlock) void restrict_quad(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                        const T* __restrict__ val, const int* __restrict__ row_of,
-                                                        const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int n_slices,
-                                                        int xcd_swizzle) {
-    constexpr int G = 8;
-    const int s0 = wave_slice(0, xcd_swizzle) * NS;
-    if (s0 >= n_slices) return;
-    const int lane = threadIdx.x & 63;
-    int64_t p[NS];
-    int w[NS];
-    T acc[NS][D];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const bool live = s0 + i < n_slices;                          // wave-uniform
-        p[i] = live ? slice_ptr[s0 + i] : 0;
-        w[i] = live ? (int)((slice_ptr[s0 + i + 1] - p[i]) >> 6) : 0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) acc[i][c] = (T)0.0;
-    }
-    for (int g = 0;; g += G) {                                        // groups of G entries per lane; one pass for the usual row lengths
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) any = any || w[i] > g;
-        if (!any) break;
-        int cc[NS][G];
-        T vv[NS][G];
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int j = 0; j < G; ++j) {
-                cc[i][j] = 0; vv[i][j] = (T)0.0;
-                if (g + j < w[i]) {                                   // wave-uniform
-                    cc[i][j] = __builtin_nontemporal_load(col + p[i] + (int64_t)(g + j) * 64 + lane);
-                    vv[i][j] = __builtin_nontemporal_load(val + p[i] + (int64_t)(g + j) * 64 + lane);
-                }
-            }
-        T xv[NS][G][D];
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-                if (g + j < w[i]) {
-#pragma unroll
-                    for (int c = 0; c < D; ++c) xv[i][j][c] = x[cc[i][j] + (int64_t)c * ldx];
-                }
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-#pragma unroll
-            for (int j = 0; j < G; ++j)
-                if (g + j < w[i]) {
-#pragma unroll
-                    for (int c = 0; c < D; ++c) acc[i][c] += vv[i][j] * xv[i][j][c];
-                }
-    }
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        if (s0 + i >= n_slices) break;
-        quad_reduce<T, D>(acc[i]);
-        if (lane & 3) continue;
-        const int srow = (s0 + i) * 16 + (lane >> 2);
-        const int row = row_of ? row_of[srow] : srow;
-        if (row < 0) continue;
-#pragma unroll
-        for (int c = 0; c < D; ++c) y[row + (int64_t)c * ldy] = acc[i][c];
-    }
-}
-
 // out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of kReduceBlock threads, fixed order.
 constexpr int kReduceBlock = 1024;
 __device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp, double* __restrict__ out,
