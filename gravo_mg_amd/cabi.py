@@ -58,7 +58,7 @@ _dp = C.POINTER(C.c_double)
 _vp = C.c_void_p
 
 # name -> (restype, argtypes).  Must list every symbol include/gravomg_hip.h declares
-# (tests/test_cabi_symbols.py checks this table against the header).
+# (tests/test_host.py::test_library_exports_every_declared_symbol checks this table against the header).
 SIGNATURES = {
     "gmg_config_default": (C.c_int, [C.POINTER(GmgConfig)]),
     "gmg_create": (C.c_int, [C.POINTER(GmgConfig), C.POINTER(_vp)]),
@@ -111,6 +111,9 @@ SIGNATURES = {
     "gmg_hierarchy_level_shape": (C.c_int, [_vp, C.c_int, _ip, _ip, _ip]),
     "gmg_hierarchy_get_prolongation": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gmg_hierarchy_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "gmg_hierarchy_get_samples": (C.c_int, [_vp, C.c_int, _ip]),
+    "gmg_hierarchy_get_nearest": (C.c_int, [_vp, C.c_int, _ip]),
+    "gmg_hierarchy_get_points": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
     "gmg_finalize_hierarchy": (C.c_int, [_vp]),
     "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
@@ -236,6 +239,13 @@ class Hierarchy:
             colptr = np.empty(nc.value + 1, np.int32); rowidx = np.empty(nnz.value, np.int32); val = np.empty(nnz.value, np.float64)
             l.gmg_hierarchy_get_prolongation(self._h, k, _pi(colptr), _pi(rowidx), _pd(val))
             self.U.append(sp.csc_matrix((val, rowidx, colptr), shape=(nf.value, nc.value)))
+        # what the reference keeps beside U (multigrid_solver.h:99-104): sample indices, cluster of every point, coarse positions
+        self.samples, self.nearest, self.points = [], [], []
+        for k, u in enumerate(self.U):
+            s_ = np.empty(u.shape[1], np.int32); n_ = np.empty(u.shape[0], np.int32); p_ = np.empty((u.shape[1], 3), np.float64)
+            if l.gmg_hierarchy_get_samples(self._h, k, _pi(s_)) or l.gmg_hierarchy_get_nearest(self._h, k, _pi(n_)) or l.gmg_hierarchy_get_points(self._h, k, _pd(p_)):
+                raise GmgError(GMG_ERR_INVALID, "hierarchy getters failed")
+            self.samples.append(s_); self.nearest.append(n_); self.points.append(p_)
 
     def timing(self, key: str) -> float:
         out = C.c_double()

@@ -10,11 +10,14 @@
 #include <pybind11/stl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "multigrid_solver.h"
 
@@ -54,55 +57,89 @@ MGBS::SparseMatrix to_sparse(const py::object& obj) {
     return m;
 }
 
-// A system matrix mapped in place (no copy): the reference's API receives scipy CSR (gravomg/core.py:74-77) and pybind11
+// A system matrix mapped in place (no copy).  The reference's API receives scipy CSR (gravomg/core.py:74-77) and pybind11
 // converts it to Eigen's column-major storage on every call (core.cpp:68) -- ~100 ms of single-threaded work at 3 M
-// vertices, twice the whole GPU solve.  Here CSC input is mapped as it is, and CSR input of a SYMMETRIC matrix (the
-// only kind the algorithm accepts, multigrid_solver.cpp:1200-1208) is mapped as the CSC of its transpose, i.e. of
-// itself.  Symmetry is spot-checked on a few thousand entries; anything else goes through scipy's conversion.
+// vertices, twice the whole GPU solve.  The engine consumes the OUTER vectors of the compressed storage it is handed as the
+// rows of the operator (for the symmetric matrices the algorithm is defined for, multigrid_solver.cpp:1200-1208, rows and
+// columns coincide).  So: CSR input is mapped as it is -- its outer vectors ARE the rows, for any matrix, and residual() is then
+// exact for unsymmetric input too, like upstream's A*x; CSC input is mapped as it is when it is symmetric -- verified on
+// EVERY entry the first time a matrix content is seen (threaded pass, verdict cached by content digest) -- and converted to
+// CSR otherwise (a matrix unsymmetric in a few rows, e.g. overwritten Dirichlet rows, must not be worked on as its
+// transpose); every other format goes through scipy's conversion to CSR.
 struct MappedSparse {
     MGBS::SparseMatrix m;
     std::vector<py::object> keep;      // the numpy arrays the view points into
 };
 
-bool looks_symmetric(int n, const int* ptr, const int* idx, const double* val) {
+// EVERY entry (i, j) has a partner (j, i) with the same value (to 1e-10 relative): one threaded pass, a binary search per
+// entry (linear where a row's indices are not sorted).  A random probe would pass a matrix that is unsymmetric in a few
+// rows -- Dirichlet rows overwritten without their columns -- and the solver would then work on the transpose.
+bool is_symmetric(int n, const int* ptr, const int* idx, const double* val) {
     const int64_t nnz = ptr[n];
     if (nnz == 0) return true;
-    uint64_t state = 0x9e3779b97f4a7c15ull;
-    for (int s = 0; s < 4096; ++s) {
-        state = state * 6364136223846793005ull + 1442695040888963407ull;
-        const int64_t p = (int64_t)((state >> 11) % (uint64_t)nnz);
-        const int i = (int)(std::upper_bound(ptr, ptr + n + 1, (int)p) - ptr) - 1;     // outer index holding entry p
-        const int j = idx[p];
-        if (j < 0 || j >= n) return false;
-        bool found = false;
-        for (int q = ptr[j]; q < ptr[j + 1]; ++q)
-            if (idx[q] == i) {
-                const double a = val[p], b = val[q];
-                if (std::abs(a - b) > 1e-10 * std::max(std::abs(a), std::abs(b))) return false;
-                found = true;
-                break;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const int T = (int)std::min<int64_t>(hw, nnz / 65536 + 1);
+    std::atomic<bool> ok{true};
+    auto work = [&](int lo, int hi) {
+        for (int i = lo; i < hi && ok.load(std::memory_order_relaxed); ++i)
+            for (int p = ptr[i]; p < ptr[i + 1]; ++p) {
+                const int j = idx[p];
+                if (j < 0 || j >= n) { ok = false; return; }
+                if (j == i) continue;
+                const int* b = idx + ptr[j];
+                const int* e = idx + ptr[j + 1];
+                const int* q = std::lower_bound(b, e, i);
+                if (q == e || *q != i) q = std::find(b, e, i);          // unsorted row: linear
+                if (q == e) { ok = false; return; }
+                const double x = val[p], y = val[q - idx];
+                if (std::abs(x - y) > 1e-10 * std::max(std::abs(x), std::abs(y))) { ok = false; return; }
             }
-        if (!found) return false;
+    };
+    if (T <= 1) work(0, n);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, (int)((int64_t)n * t / T), (int)((int64_t)n * (t + 1) / T));
+        for (auto& t : th) t.join();
     }
-    return true;
+    return ok.load();
 }
 
-MappedSparse map_system_matrix(const py::object& obj) {
+// verdict of the last matrix checked, keyed by its content digest: a repeated solve() on the same lhs pays the check once
+struct SymmetryCache {
+    std::pair<uint64_t, uint64_t> key{0, 0};
+    bool valid = false, symmetric = false;
+};
+
+MappedSparse map_system_matrix(const py::object& obj, SymmetryCache& cache) {
     py::object sp = py::module_::import("scipy.sparse");
     py::object mat = obj;
-    const bool is_csc = sp.attr("isspmatrix_csc")(mat).cast<bool>();
+    bool is_csc = sp.attr("isspmatrix_csc")(mat).cast<bool>();
     const bool is_csr = !is_csc && sp.attr("isspmatrix_csr")(mat).cast<bool>();
-    if (!is_csc && !is_csr) mat = sp.attr("csc_matrix")(mat);
+    if (!is_csc && !is_csr) mat = sp.attr("csr_matrix")(mat);
     for (int attempt = 0; attempt < 2; ++attempt) {
         MappedSparse out;
         auto shape = mat.attr("shape").cast<std::pair<py::ssize_t, py::ssize_t>>();
         auto indptr = mat.attr("indptr").cast<py::array_t<int, py::array::c_style | py::array::forcecast>>();
         auto indices = mat.attr("indices").cast<py::array_t<int, py::array::c_style | py::array::forcecast>>();
         auto data = mat.attr("data").cast<py::array_t<double, py::array::c_style | py::array::forcecast>>();
-        const bool row_major = attempt == 0 && is_csr;
-        if (row_major && (shape.first != shape.second || !looks_symmetric((int)shape.first, indptr.data(), indices.data(), data.data()))) {
-            mat = sp.attr("csc_matrix")(mat);      // not (recognisably) symmetric: the real conversion
-            continue;
+        if (attempt == 0 && is_csc) {
+            bool sym = shape.first == shape.second;
+            if (sym) {
+                MGBS::SparseMatrix view;
+                view.rows_ = (int)shape.first; view.cols_ = (int)shape.second;
+                view.outerView = indptr.data(); view.innerView = indices.data(); view.valuesView = data.data();
+                const auto key = view.digest();
+                if (!(cache.valid && cache.key == key)) {
+                    cache.symmetric = is_symmetric((int)shape.first, indptr.data(), indices.data(), data.data());
+                    cache.key = key; cache.valid = true;
+                }
+                sym = cache.symmetric;
+            }
+            if (!sym) {
+                mat = sp.attr("csr_matrix")(mat);      // columns are not rows here: the real conversion
+                is_csc = false;
+                continue;
+            }
         }
         out.m.rows_ = (int)shape.first; out.m.cols_ = (int)shape.second;
         out.m.outerView = indptr.data(); out.m.innerView = indices.data(); out.m.valuesView = data.data();
@@ -174,7 +211,7 @@ public:
 
     // core.cpp:68-72: x0 = rhs
     py::array_t<double> solve(py::object lhs, DenseIn rhs) {
-        MappedSparse mapped = map_system_matrix(lhs);
+        MappedSparse mapped = map_system_matrix(lhs, symCache);
         MGBS::SparseMatrix& A = mapped.m;
         MGBS::MatrixXd b = to_dense(rhs);
         if (A.rows() != A.cols() || A.rows() != b.rows()) throw std::invalid_argument("lhs must be n x n and rhs n x d");
@@ -190,7 +227,8 @@ public:
         MGBS::MatrixXd b = to_dense(rhs);
         MGBS::MatrixXd x = b;
         solver->clearError();
-        solver->solve(A, b, x, pardiso ? 1 : 0);
+        if (pardiso) throw std::runtime_error("direct_solve(pardiso=True): Pardiso (MKL) is not part of this build; use pardiso=False (sparse LDL^T)");
+        solver->solve(A, b, x, 0);
         check();
         return from_dense(x);
     }
@@ -207,20 +245,27 @@ public:
         solver->U = v;
     }
 
+    // core.cpp:90-116.  samples / nearestSource are filled by every build upstream, levelV only with debug = True; the
+    // remaining debug members (levelE: SIG06 / ablation paths, noTriFoundMap, allTriangles, levelN: debug dumps of the
+    // triangle search) are not produced by this build: asking for them raises instead of returning empty data.
     std::vector<std::vector<int>> sampling_indices() { return solver->samples; }
-    py::list level_points() { return py::list(); }        // debug-only data upstream (filled only when debug=True)
-    py::list level_edges() { return py::list(); }
-    py::list notrimap() { return py::list(); }
-    py::list all_triangles() { return py::list(); }
-    py::list coarse_normals() { return py::list(); }
-    py::list nearest_source() { return py::list(); }
+    std::vector<std::vector<size_t>> nearest_source() { return solver->nearestSource; }
+    py::list level_points() {
+        py::list out;
+        for (const auto& P : solver->levelV) out.append(from_dense(P));
+        return out;
+    }
+    py::list level_edges() { not_produced("level_edges"); return py::list(); }
+    py::list notrimap() { not_produced("notrimap"); return py::list(); }
+    py::list all_triangles() { not_produced("all_triangles"); return py::list(); }
+    py::list coarse_normals() { not_produced("coarse_normals"); return py::list(); }
 
     void write_hierarchy_timing(std::string experiment, std::string file, bool write_headers) { MGBS::writeTiming(solver->hierarchyTiming, experiment, file, write_headers); }
     void write_solver_timing(std::string experiment, std::string file, bool write_headers) { MGBS::writeTiming(solver->solverTiming, experiment, file, write_headers); }
     void write_convergence(std::string file) { MGBS::writeConvergence(solver->convergence, file); }
 
     double residual(py::object lhs, DenseIn rhs, DenseIn solution, int type = 2) {
-        MappedSparse mapped = map_system_matrix(lhs);
+        MappedSparse mapped = map_system_matrix(lhs, symCache);
         MGBS::SparseMatrix& A = mapped.m;
         solver->clearError();
         double r = solver->residualCheck(A, to_dense(rhs), to_dense(solution), type);
@@ -236,6 +281,7 @@ public:
         gmg_config& c = solver->engineConfig;
         if (key == "smoother") c.smoother = (int)value;
         else if (key == "jacobi_omega") c.jacobi_omega = value;
+        else if (key == "gs_omega") c.gs_omega = value;
         else if (key == "coarse_mode") c.coarse_mode = (int)value;
         else if (key == "use_graph") c.use_graph = (int)value;
         else if (key == "block_rows") c.block_rows = (int)value;
@@ -245,6 +291,9 @@ public:
     }
 
 private:
+    static void not_produced(const char* what) {
+        throw std::runtime_error(std::string(what) + ": debug data of the reference's triangle search, not produced by the MI355X hot-path build");
+    }
     // The reference reports problems with printed messages only; the drop-in additionally raises, so that a missing
     // GPU / an unsupported option can never pass silently.
     void check() {
@@ -252,6 +301,7 @@ private:
         if (!now.empty()) throw std::runtime_error(now);
     }
     std::unique_ptr<MGBS::MultigridSolver> solver;
+    SymmetryCache symCache;
 };
 
 PYBIND11_MODULE(gravomg_bindings, m) {

@@ -1341,6 +1341,24 @@ int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out) try
     return GMG_OK;
 } GMG_CATCH_0
 
+int gmg_hierarchy_get_samples(gmg_hierarchy hh, int k, int* out) try {
+    if (!hh || !out || k < 0 || k >= (int)hh->res.samples.size()) return GMG_ERR_INVALID;
+    std::memcpy(out, hh->res.samples[k].data(), sizeof(int) * hh->res.samples[k].size());
+    return GMG_OK;
+} GMG_CATCH_0
+
+int gmg_hierarchy_get_nearest(gmg_hierarchy hh, int k, int* out) try {
+    if (!hh || !out || k < 0 || k >= (int)hh->res.nearest.size()) return GMG_ERR_INVALID;
+    std::memcpy(out, hh->res.nearest[k].data(), sizeof(int) * hh->res.nearest[k].size());
+    return GMG_OK;
+} GMG_CATCH_0
+
+int gmg_hierarchy_get_points(gmg_hierarchy hh, int k, double* out_xyz) try {
+    if (!hh || !out_xyz || k < 0 || k >= (int)hh->res.points.size()) return GMG_ERR_INVALID;
+    std::memcpy(out_xyz, hh->res.points[k].data(), sizeof(double) * hh->res.points[k].size());
+    return GMG_OK;
+} GMG_CATCH_0
+
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) try {
     if (!h || !hh) return GMG_ERR_INVALID;
     int rc = gmg_set_num_levels(h, (int)hh->res.U.size());

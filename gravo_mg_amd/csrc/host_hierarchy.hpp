@@ -48,6 +48,8 @@ struct HierarchyResult {
     std::vector<Compressed> U;               // U[k]: n_k x n_{k+1}, CSC (outer = coarse columns)
     std::vector<int> dof;                    // n_0, n_1, ..., n_L
     std::vector<std::vector<int>> samples;   // per level: fine index of each coarse sample
+    std::vector<std::vector<int>> nearest;   // per level: the coarse sample (cluster) every fine point belongs to (nearestSource, :115,:171)
+    std::vector<std::vector<double>> points; // per level: positions of the coarse points, n_{k+1} x 3 row-major (levelV, :216-241)
     std::map<std::string, double> timing;    // the reference's hierarchyTiming keys
     // per level counts of prolongation row kinds: triangle / edge / fallback / single
     std::vector<std::array<int, 4>> row_kinds;
@@ -342,6 +344,8 @@ public:
             R.U.push_back(from_triplets(nf, nc, trow, tcol, tval));
             R.timing["assemble"] += ms(t6, clk::now());
             R.samples.push_back(std::move(sample));
+            R.nearest.push_back(std::move(nearest));
+            { std::vector<double> xyz((size_t)nc * 3); for (int c = 0; c < nc; ++c) { xyz[3 * (size_t)c] = Pc[c].x; xyz[3 * (size_t)c + 1] = Pc[c].y; xyz[3 * (size_t)c + 2] = Pc[c].z; } R.points.push_back(std::move(xyz)); }
             R.dof.push_back(nc);
             P_own.swap(Pc);
             NB_own.swap(NBc);

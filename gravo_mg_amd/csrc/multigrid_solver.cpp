@@ -112,6 +112,25 @@ void MultigridSolver::buildHierarchy() {
         gmg_hierarchy_get_prolongation(hh, k, u.outer.data(), u.inner.data(), u.values.data());
         DoF.push_back(nc);
     }
+    // what the reference keeps beside U (samples and nearestSource always, levelV with debug only: :128, :171, :241)
+    samples.assign(L, std::vector<int>());
+    nearestSource.assign(L, std::vector<size_t>());
+    levelV.clear();
+    for (int k = 0; k < L; ++k) {
+        const int nf = U[k].rows_, nc = U[k].cols_;
+        samples[k].resize(nc);
+        gmg_hierarchy_get_samples(hh, k, samples[k].data());
+        std::vector<int> near(nf);
+        gmg_hierarchy_get_nearest(hh, k, near.data());
+        nearestSource[k].assign(near.begin(), near.end());
+        if (debug) {
+            std::vector<double> xyz((size_t)nc * 3);
+            gmg_hierarchy_get_points(hh, k, xyz.data());
+            MatrixXd P(nc, 3);
+            for (int c = 0; c < nc; ++c) for (int a = 0; a < 3; ++a) P.data[(size_t)a * nc + c] = xyz[3 * (size_t)c + a];      // column-major n x 3
+            levelV.push_back(P);
+        }
+    }
     for (const char* key : {"hierarchy", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection", "PDS", "levels"}) {
         double v = 0;
         if (gmg_hierarchy_get_timing(hh, key, &v) == GMG_OK) hierarchyTiming[key] = v;

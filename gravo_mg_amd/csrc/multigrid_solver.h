@@ -93,7 +93,9 @@ public:
     SparseMatrix M;
     std::vector<size_t> DoF;
     std::vector<SparseMatrix> U;                 // prolongation operators (what the solver sees)
-    std::vector<std::vector<int>> samples;
+    std::vector<std::vector<int>> samples;       // samples[k]: fine index of every point of level k+1 (multigrid_solver.cpp:128)
+    std::vector<std::vector<size_t>> nearestSource;   // nearestSource[k]: the level-(k+1) point every level-k point clusters to (:171)
+    std::vector<MatrixXd> levelV;                // positions of the points of level k+1 (the reference fills it with debug only, :241)
     int cycleType = 0;                           // 0: V-cycle (1 F / 2 W are rejected: broken upstream)
     bool isSmootherGaussSeidel = false;          // set by the shim (core.cpp:57); solve() does nothing without it
     bool sig06 = false;

@@ -1,156 +1,166 @@
-"""`gravomg.MultigridSolver` -- the reference's Python API (gravomg_bindings/src/gravomg/core.py:7-147) over the
-MI355X-native V-cycle engine.  Same constructor keywords and defaults, same methods and properties; the numerics
-run in libgravomg_hip.so (HIP kernels) through the pybind11 module `gravomg_bindings` next to this package.
+"""`gravomg.MultigridSolver`: the Python class name, constructor keywords, defaults, methods and properties of the
+reference package (the API contract: gravomg_bindings/src/gravomg/core.py:7-147 and the pybind class it wraps,
+gravomg_bindings/src/cpp/core.cpp:142-163) on top of the MI355X-native V-cycle engine.  The numerics run in
+libgravomg_hip.so (HIP kernels, C-ABI in include/gravomg_hip.h) through the pybind11 module `gravomg_bindings` that sits
+next to this package; this file only normalises arguments and forwards.
 
-Differences a user can observe, all deliberate:
-  * only the default hierarchy (Sampling.FASTDISK) and the V-cycle (cycle_type=0) exist; asking for SIG06 / SIG21 /
-    ablation hierarchies, other samplers or F-/W-cycles raises instead of printing a message;
-  * problems (no GPU, unsupported option, singular coarse operator) raise RuntimeError instead of being printed;
-  * the smoother is multicolour Gauss-Seidel (the reference's sweep in a colour-permuted order): iteration counts
-    match the reference's on the tested problems, per-cycle iterates are not bitwise those of lexicographic GS.
+What a user of the reference will notice, all of it deliberate (DESIGN.md sections 2 and 7):
+  * only the default hierarchy (Sampling.FASTDISK) and the V-cycle (cycle_type=0) exist.  SIG06 / SIG21 / ablation
+    hierarchies, the other samplers, F-/W-cycles and Pardiso raise instead of printing a message;
+  * problems (no GPU, unsupported option, singular coarsest operator) raise RuntimeError instead of being printed;
+  * the smoother is a parallel ordering of the reference's Gauss-Seidel: multicolour sweeps on the finest level, over-relaxed
+    by 1.2 (`set_engine_option("gs_omega", 1.0)` gives the reference's update in colour order), block sweeps below.  The
+    iterates are therefore not those of lexicographic Gauss-Seidel cycle by cycle; the stopping test and the solution are the
+    same.  V-cycles to 1e-4 on the 3 M-vertex Poisson problem: 5 (reference algorithm: 6; omega = 1: 7);
+  * `lhs` may be any scipy sparse format.  CSR and symmetric CSC storage are used in place (no conversion, no copy).
 """
 import numpy as np
-from scipy.sparse import csr_matrix
+import scipy.sparse as sp
 
-def _preload_torch_hip_runtime():
-    # torch-ROCm wheels bundle libamdhip64 / libhsa-runtime64 with the system SONAMEs; whichever copy loads first serves
-    # the whole process and torch fails if it is not its own.  Make torch's copy (if torch is installed) the one in use.
-    import ctypes, importlib.util, os
+
+def _use_torch_hip_runtime():
+    """torch-ROCm wheels ship their own libamdhip64 / libhsa-runtime64 under the system SONAMEs; the first copy loaded serves
+    the process and torch refuses to see a GPU if it is not its own.  If torch is installed, load its copy first."""
+    import ctypes
+    import importlib.util
+    import os
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         return
-    if spec is None or not spec.submodule_search_locations:
-        return
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
-        if os.path.exists(path):
-            try:
-                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
-            except OSError:
-                pass
+    roots = list(spec.submodule_search_locations or []) if spec is not None else []
+    for root in roots[:1]:
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(root, "lib", name)
+            if os.path.exists(path):
+                try:
+                    ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+                except OSError:
+                    pass
 
 
-_preload_torch_hip_runtime()
+_use_torch_hip_runtime()
 
-import gravomg_bindings  # noqa: E402
-from gravomg_bindings import Hierarchy, Sampling, Weighting  # noqa: E402
+import gravomg_bindings as _native  # noqa: E402
+from gravomg_bindings import Hierarchy, Sampling, Weighting  # noqa: E402,F401
+
+
+def _sparse(m, what):
+    if not sp.issparse(m):
+        raise TypeError(f"{what} must be a scipy sparse matrix")
+    return m
+
+
+def _points(a, what, cols=None):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a[:, None]
+    if a.ndim != 2 or (cols is not None and a.shape[1] != cols):
+        raise ValueError(f"{what} must be an (n, {cols or 'd'}) array")
+    return a
+
+
+# name -> (kind, docstring).  "call": method forwarding its arguments; "get": read-only property over a native getter.
+_FORWARDED = {
+    "construct_sig21_hierarchy": ("call", "Comparison hierarchy of Liu et al. 2021: out of scope of this build, raises."),
+    "direct_solve": ("call", "direct_solve(lhs, rhs, pardiso=False): sparse LDL^T on the host (comparison helper); pardiso=True raises."),
+    "write_hierarchy_timing": ("call", "write_hierarchy_timing(experiment, file, write_headers=False): the reference's CSV layout."),
+    "write_solver_timing": ("call", "write_solver_timing(experiment, file, write_headers=False): the reference's CSV layout."),
+    "write_convergence": ("call", "write_convergence(file): one 'time,residue' line per V-cycle."),
+    "prolongation_matrices": ("get", "List of the prolongation operators U_k (scipy CSC, n_k x n_{k+1})."),
+    "sampling_indices": ("get", "sampling_indices[k][c]: index on level k of point c of level k + 1."),
+    "nearest_source": ("get", "nearest_source[k][i]: the level-(k+1) point whose cluster contains point i of level k."),
+    "level_points": ("get", "Positions of the points of every coarse level ((n_k, 3) arrays); filled when debug=True, like upstream."),
+    "level_edges": ("get", "Debug data of the SIG06 / ablation paths: not produced by this build, raises."),
+    "notrimap": ("get", "Debug data of the triangle search: not produced by this build, raises."),
+    "all_triangles": ("get", "Debug data of the triangle search: not produced by this build, raises."),
+    "coarse_normals": ("get", "Debug data of the triangle search: not produced by this build, raises."),
+    "solver_timing": ("get", "dict with the reference's solverTiming keys: reduction, coarsest_solve, cycles, solver_total, iterations, residue."),
+    "hierarchy_timing": ("get", "dict with the reference's hierarchyTiming keys."),
+    "convergence": ("get", "[(elapsed_ms, residue), ...] per V-cycle, appended across solves like upstream."),
+}
+# parameter names of the forwarded methods, and their defaults where the reference has some
+_PARAMS = {
+    "construct_sig21_hierarchy": (("faces",), {}),
+    "direct_solve": (("lhs", "rhs", "pardiso"), {"pardiso": False}),
+    "write_hierarchy_timing": (("experiment", "file", "write_headers"), {"write_headers": False}),
+    "write_solver_timing": (("experiment", "file", "write_headers"), {"write_headers": False}),
+    "write_convergence": (("file",), {}),
+}
 
 
 class MultigridSolver(object):
-    def __init__(
-        self, pos, neigh, mass,
-        ratio=8.0, lower_bound=1000, cycle_type=0, tolerance=1e-4, stopping_criteria=2, pre_iters=2, post_iters=2, max_iter=100,
-        check_voronoi=True, nested=False, sampling_strategy=Sampling.FASTDISK, weighting=Weighting.BARYCENTRIC,
-        sig06=False, normals=None, verbose=False, debug=False, ablation=False, ablation_num_points=3, ablation_random=False,
-    ):
-        """Builds the Gravo MG hierarchy for a mesh or point cloud and prepares the solver.
+    """Gravo MG solver for a mesh or point cloud: builds the Graph-Voronoi hierarchy at construction, solves with V-cycles.
 
-        pos: (n, 3) positions.  neigh: (n, K) int neighbour table padded with -1 (see gravomg.util).
-        mass: lumped (diagonal) scipy sparse mass matrix.  The remaining keywords are the reference's
-        (ratio, lower_bound: hierarchy; cycle_type, tolerance, stopping_criteria -- 2 is the M-weighted
-        residual norm --, pre_iters, post_iters, max_iter: solver)."""
-        super().__init__()
-        if not mass.getformat() == 'csr':
-            mass = mass.tocsr()
-        pos = np.asarray(pos, dtype=np.float64)
-        normals = pos if normals is None else normals
-        self.solver = gravomg_bindings.MultigridSolver(
-            pos, np.asarray(neigh, dtype=np.int32), mass,
-            ratio, lower_bound, cycle_type, tolerance, stopping_criteria, pre_iters, post_iters, max_iter,
-            check_voronoi, nested, sampling_strategy, weighting,
-            sig06, normals, verbose, debug, ablation, ablation_num_points, ablation_random,
-        )
-        self.sig21_computed = False
-        self.sig21bary_computed = False
+    pos (n, 3) positions; neigh (n, K) integer neighbour table padded with -1 (gravomg.util); mass: lumped (diagonal) scipy
+    sparse mass matrix.  ratio / lower_bound steer the hierarchy; cycle_type, tolerance, stopping_criteria (2 = M-weighted
+    residual norm), pre_iters, post_iters, max_iter the solver.  Keywords and defaults are the reference's."""
 
-    def construct_sig21_hierarchy(self, faces):
-        """Liu et al. [2021] comparison hierarchy: out of scope here, raises."""
-        self.solver.construct_sig21_hierarchy(faces)
-
-    def toggle_hierarchy(self, hierarchy_type):
-        assert hierarchy_type == Hierarchy.OURS or (hierarchy_type == Hierarchy.SIG21 and self.sig21_computed)
-        self.solver.toggle_hierarchy(hierarchy_type)
+    def __init__(self, pos, neigh, mass,
+                 ratio=8.0, lower_bound=1000, cycle_type=0, tolerance=1e-4, stopping_criteria=2, pre_iters=2, post_iters=2, max_iter=100,
+                 check_voronoi=True, nested=False, sampling_strategy=Sampling.FASTDISK, weighting=Weighting.BARYCENTRIC,
+                 sig06=False, normals=None, verbose=False, debug=False, ablation=False, ablation_num_points=3, ablation_random=False):
+        pos = _points(pos, "pos", 3)
+        neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+        if neigh.ndim != 2 or neigh.shape[0] != pos.shape[0]:
+            raise ValueError("neigh must be an (n, K) integer table with one row per point")
+        self.solver = _native.MultigridSolver(
+            pos, neigh, _sparse(mass, "mass"), float(ratio), int(lower_bound), int(cycle_type), float(tolerance), int(stopping_criteria),
+            int(pre_iters), int(post_iters), int(max_iter), bool(check_voronoi), bool(nested), sampling_strategy, weighting, bool(sig06),
+            pos if normals is None else _points(normals, "normals", 3), bool(verbose), bool(debug), bool(ablation), int(ablation_num_points),
+            bool(ablation_random))
 
     def solve(self, lhs, rhs):
-        """Solves lhs @ x = rhs with V-cycles from the initial guess x0 = rhs; returns x as an (n, d) array."""
-        if not lhs.getformat() == 'csr':
-            print('LHS is not in CSR format, converting to CSR')
-            lhs = lhs.tocsr()
-        return self.solver.solve(lhs, rhs)
-
-    def direct_solve(self, lhs, rhs, pardiso=False):
-        """Direct sparse LDL^T on the host (comparison helper; Pardiso is not available)."""
-        return self.solver.direct_solve(lhs, rhs, pardiso)
-
-    # Getters and setters
-
-    @property
-    def prolongation_matrices(self):
-        return self.solver.prolongation_matrices()
-
-    def set_prolongation_matrices(self, U):
-        self.solver.set_prolongation_matrices(list(U))
-
-    @property
-    def sampling_indices(self):
-        return self.solver.sampling_indices()
-
-    @property
-    def level_points(self):
-        return self.solver.level_points()
-
-    @property
-    def level_edges(self):
-        return self.solver.level_edges()
-
-    @property
-    def notrimap(self):
-        return self.solver.notrimap()
-
-    @property
-    def all_triangles(self):
-        return self.solver.all_triangles()
-
-    @property
-    def coarse_normals(self):
-        return self.solver.coarse_normals()
-
-    @property
-    def nearest_source(self):
-        return self.solver.nearest_source()
-
-    # Timing logs (same CSV layout as the reference's writers)
-
-    def write_hierarchy_timing(self, experiment, file, write_headers=False):
-        return self.solver.write_hierarchy_timing(experiment, file, write_headers)
-
-    def write_solver_timing(self, experiment, file, write_headers=False):
-        return self.solver.write_solver_timing(experiment, file, write_headers)
-
-    def write_convergence(self, file):
-        return self.solver.write_convergence(file)
+        """x with lhs @ x = rhs to the tolerance given at construction, V-cycles from the initial guess x0 = rhs
+        (gravomg_bindings/src/cpp/core.cpp:68-72).  rhs (n,) or (n, d); returns an (n, d) array."""
+        return self.solver.solve(_sparse(lhs, "lhs"), _points(rhs, "rhs"))
 
     def residual(self, lhs, rhs, solution, type=2):
-        return self.solver.residual(lhs, rhs, solution, type)
+        """The reference's residualCheck of `solution`: type 0 ||r||/||b||, 1 M^-1-weighted, 2 M-weighted, 3 ||A X - B||_F."""
+        return self.solver.residual(_sparse(lhs, "lhs"), _points(rhs, "rhs"), _points(solution, "solution"), int(type))
 
-    # Extras of this build (not upstream)
+    def set_prolongation_matrices(self, U):
+        """Replace the hierarchy by the given prolongation operators (scipy sparse, n_k x n_{k+1})."""
+        self.solver.set_prolongation_matrices([_sparse(u, "U[k]") for u in U])
 
-    @property
-    def solver_timing(self):
-        """dict with the reference's solverTiming keys: reduction, coarsest_solve, cycles, solver_total, iterations, residue."""
-        return self.solver.solver_timing()
-
-    @property
-    def hierarchy_timing(self):
-        return self.solver.hierarchy_timing()
-
-    @property
-    def convergence(self):
-        """[(elapsed_ms, residue), ...] per V-cycle (appended across solves, like upstream)."""
-        return self.solver.convergence()
+    def toggle_hierarchy(self, hierarchy_type):
+        """Only Hierarchy.OURS exists in this build; anything else raises."""
+        self.solver.toggle_hierarchy(hierarchy_type)
 
     def set_engine_option(self, key, value):
-        """MI355X engine knobs: smoother (0 multicolour GS, 1 Jacobi), jacobi_omega, coarse_mode (0 host LDL^T, 1 device),
-        use_graph, block_rows, block_from_level, device."""
-        self.solver.set_engine_option(key, float(value))
+        """MI355X engine knobs (not upstream): smoother (0 multicolour Gauss-Seidel, 1 weighted Jacobi), gs_omega, jacobi_omega,
+        coarse_mode (0 host LDL^T, 1 dense inverse applied on the device), use_graph, block_rows, block_from_level, device."""
+        self.solver.set_engine_option(str(key), float(value))
+
+
+def _bind(name, args, kwargs):
+    """Positional argument tuple for the native method `name` from the caller's args / kwargs (reference names and defaults)."""
+    names, defaults = _PARAMS[name]
+    if len(args) > len(names):
+        raise TypeError(f"{name}() takes {len(names)} arguments ({len(args)} given)")
+    bound = dict(defaults)
+    bound.update(zip(names, args))
+    for k, v in kwargs.items():
+        if k not in names or k in names[:len(args)]:
+            raise TypeError(f"{name}() got an unexpected or repeated argument '{k}'")
+        bound[k] = v
+    missing = [n for n in names if n not in bound]
+    if missing:
+        raise TypeError(f"{name}() missing argument(s): {', '.join(missing)}")
+    return tuple(bound[n] for n in names)
+
+
+def _install_forwarders():
+    for name, (kind, doc) in _FORWARDED.items():
+        if kind == "get":
+            setattr(MultigridSolver, name, property(lambda self, _n=name: getattr(self.solver, _n)(), doc=doc))
+            continue
+
+        def method(self, *args, _n=name, **kwargs):
+            return getattr(self.solver, _n)(*_bind(_n, args, kwargs))
+        method.__name__ = method.__qualname__ = name
+        method.__doc__ = doc
+        setattr(MultigridSolver, name, method)
+
+
+_install_forwarders()

@@ -238,6 +238,13 @@ int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coars
 int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val);
 /* hierarchyTiming keys of the reference (multigrid_solver.cpp:21,57,90-97). */
 int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out);
+/* What the reference keeps beside U after buildHierarchy (multigrid_solver.h:99-104; getters of the pybind class,
+ * gravomg_bindings/src/cpp/core.cpp:90-116): samples[k] = fine index of every coarse point of level k+1 (n_{k+1} ints),
+ * nearest[k] = the cluster (coarse point) of every point of level k (n_k ints; `nearestSource`), points[k] = positions of the
+ * coarse points of level k+1 (n_{k+1} x 3, row-major; `levelV`, which the reference only fills with debug = true). */
+int gmg_hierarchy_get_samples(gmg_hierarchy hh, int k, int* out);
+int gmg_hierarchy_get_nearest(gmg_hierarchy hh, int k, int* out);
+int gmg_hierarchy_get_points(gmg_hierarchy hh, int k, double* out_xyz);
 /* Convenience: feed every U_k of a built hierarchy into a solver handle (and finalize it, see below). */
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
 /* Optional, after the last gmg_set_prolongation: build what depends on the hierarchy only (the reference's

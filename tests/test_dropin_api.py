@@ -81,6 +81,25 @@ def test_construction_and_hierarchy_without_gpu(gravomg, tmp_path):
     head, row = f.read_text().strip().split("\n")
     assert head.split(",")[0] == "experiment" and {"hierarchy", "n_vertices", "levels", "sampling", "cluster"} <= set(head.split(","))
     assert row.split(",")[0] == "torus" and len(row.split(",")) == len(head.split(","))
+    # what every build keeps beside U (core.cpp:90-92, 114-116) and the debug-only coarse positions (:94-96)
+    dof = [V.shape[0]] + [u.shape[1] for u in U]
+    samples, nearest = solver.sampling_indices, solver.nearest_source
+    assert len(samples) == len(nearest) == len(U) and solver.level_points == []
+    for k in range(len(U)):
+        assert len(samples[k]) == dof[k + 1] and len(set(samples[k])) == dof[k + 1] and 0 <= min(samples[k]) and max(samples[k]) < dof[k]
+        assert len(nearest[k]) == dof[k] and 0 <= min(nearest[k]) and max(nearest[k]) < dof[k + 1]
+        assert all(nearest[k][samples[k][c]] == c for c in range(0, dof[k + 1], 7))       # a sample belongs to its own cluster
+    dbg = gravomg.MultigridSolver(V, neigh, M, lower_bound=40, debug=True)
+    pts = dbg.level_points
+    assert [p.shape for p in pts] == [(d, 3) for d in dof[1:]]
+    assert np.abs(pts[0]).max() <= np.abs(V).max() * 1.0001                                # cluster centroids stay inside the hull
+    for name in ("level_edges", "notrimap", "all_triangles", "coarse_normals"):
+        with pytest.raises(RuntimeError, match="not produced"):
+            getattr(solver, name)
+    with pytest.raises(RuntimeError, match="Pardiso"):
+        solver.direct_solve((M + 1e-3 * S).tocsr(), M @ V, pardiso=True)
+    with pytest.raises(TypeError):
+        solver.write_convergence()
     with pytest.raises(RuntimeError):
         gravomg.MultigridSolver(V, neigh, M, lower_bound=40, sampling_strategy=gravomg.Sampling.MIS)
     with pytest.raises(RuntimeError):
@@ -140,16 +159,41 @@ def test_reference_call_pattern_smoothing_and_poisson(gravomg, oracle, tmp_path)
 
 @pytest.mark.gpu
 def test_system_matrix_storage_formats_give_the_same_answers(gravomg, oracle):
-    """The shim maps CSC storage in place, maps CSR storage of a symmetric matrix as its own transpose, and converts
-    everything else (COO, ...) like pybind11's Eigen caster would: same results on every route."""
+    """The shim maps CSR storage in place, CSC storage of a symmetric matrix too (verified on every entry), and converts
+    everything else (COO, ...): same results on every route."""
     V, F, S, M, mass = _problem()
     neigh = gravomg.util.neighbors_from_stiffness(S)
     solver = gravomg.MultigridSolver(V, neigh, M, lower_bound=60)
     lhs = sp.csr_matrix(M + 1e-3 * S)
     rhs = M @ V
     x_csr = solver.solve(lhs, rhs)
-    x_csc = solver.solve(sp.csc_matrix(lhs), rhs)          # gravomg.core prints a conversion notice and converts to CSR
+    x_csc = solver.solve(sp.csc_matrix(lhs), rhs)          # mapped in place
     x_coo = solver.solver.solve(sp.coo_matrix(lhs), rhs)    # straight into the pybind11 shim
     assert np.array_equal(x_csr, x_csc) and np.array_equal(x_csr, x_coo)
     assert abs(solver.residual(lhs, rhs, x_csr) - oracle.residual_check(lhs, mass, rhs, x_csr, 2)) <= 1e-9
     assert solver.residual(lhs, rhs, x_csr) == solver.residual(sp.csc_matrix(lhs), rhs, x_csr)
+
+
+@pytest.mark.gpu
+def test_slightly_unsymmetric_csr_is_not_taken_for_its_transpose(gravomg):
+    """The engine works on the outer vectors of the storage it is handed as rows.  CSR storage is therefore used in place for
+    any matrix; CSC storage only when EVERY entry has a symmetric partner (full check, cached by content digest).  Three
+    overwritten entries (the Dirichlet-row pattern) must send a CSC matrix through the real conversion: the residual the
+    shim reports is that of A on every route, not of A^T."""
+    V, F, S, M, mass = _problem()
+    neigh = gravomg.util.neighbors_from_stiffness(S)
+    solver = gravomg.MultigridSolver(V, neigh, M, lower_bound=60)
+    lhs = sp.csr_matrix(M + 1e-3 * S)
+    bad = lhs.copy()
+    for r in (5, 700, 1500):                       # scale one off-diagonal entry of three rows, not its mirror image
+        p = bad.indptr[r] + (1 if bad.indices[bad.indptr[r]] == r else 0)
+        bad.data[p] *= 1.5
+    rhs = M @ V
+    x = np.random.default_rng(3).standard_normal(rhs.shape)
+    for t, want in ((0, None), (3, np.linalg.norm(bad @ x - rhs))):
+        got = solver.residual(bad, rhs, x, t)
+        assert got == solver.residual(sp.csc_matrix(bad), rhs, x, t)             # same route as an explicit conversion
+        if want is not None:
+            assert abs(got - want) <= 1e-12 * want
+            assert abs(got - np.linalg.norm(bad.T @ x - rhs)) > 1e-6 * want       # ... and measurably not the transpose's
+    assert solver.residual(lhs, rhs, x, 3) == solver.residual(sp.csc_matrix(lhs), rhs, x, 3)

@@ -342,3 +342,34 @@ def test_more_than_four_right_hand_sides(cabi, oracle, kw):
     x1, _, _, _ = eng.solve(B[:, 4], tol=1e-10)
     xa, _, _, _ = eng.solve(B, tol=1e-10)
     assert rel(xa[:, 4], x1) <= 1e-7
+
+
+def test_device_coarse_apply_against_the_oracle(setup, cabi, oracle):
+    """GMG_COARSE_DEVICE_INVERSE (dense A_L^-1 applied on the device, no host round trip in the cycle) against the ORACLE,
+    not against the default engine: the coarsest solve itself (multigrid_solver.cpp:1075, 1401) and whole V-cycles through
+    the model assembled from the oracle's operators (tests/vcycle_model.py)."""
+    import scipy.sparse.linalg as spla
+    from tests.vcycle_model import VcycleModel
+    P, _ = setup
+    eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE)
+    eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    AL = eng.level_operator(len(P.U))
+    O = oracle.Hierarchy(P.U, P.mass)
+    O.set_system(P.lhs)
+    rc = np.random.default_rng(4).standard_normal((AL.shape[0], 3))
+    e, eo = eng.coarse_solve(rc), O.coarse_solve(rc)
+    nA = spla.norm(AL)
+    assert np.linalg.norm(AL @ e - rc) <= 1e-11 * (nA * np.linalg.norm(e) + np.linalg.norm(rc))
+    assert np.linalg.norm(AL @ (e - eo)) <= 1e-10 * nA * np.linalg.norm(eo)
+    M = VcycleModel(eng, P.U, P.mass, P.lhs, oracle, eng.gs_omega)
+    x = P.rhs.copy()
+    nL = spla.norm(P.lhs)
+    for cyc in range(2):
+        xg, xm = eng.vcycle(P.rhs, x), M.vcycle(P.rhs, x)
+        assert np.linalg.norm(P.lhs @ (xg - xm)) <= 1e-11 * nL * np.linalg.norm(xm), cyc
+        assert rel(xg, xm) <= (1e-10 if "smoothing" in P.name else 1e-5), cyc
+        x = xm
+    xs, it, res, _ = eng.solve(P.rhs, tol=1e-4)
+    xo, ito, reso, _ = O.solve(P.rhs, tol=1e-4)
+    assert res <= 1e-4 and it <= ito + 2
+    assert abs(oracle.residual_check(P.lhs, P.mass, P.rhs, xs, 2) - res) <= 1e-3 * res + 1e-7
