@@ -48,16 +48,34 @@ def build_workload(n1, n2, order="natural"):
 
 
 def load_pmc_traffic(workload):
-    """HBM bytes per fine-level launch from the committed rocprofv3 --pmc summary (profiles/), if one matches."""
+    """HBM bytes per fine-level launch from the committed rocprofv3 --pmc summary (profiles/), if one matches: (value, source).
+    The counters cannot be read inside this run (rocprofv3 wraps the process), so the figure is STATIC: measured once per
+    build in a separate --pmc pass of this same command and committed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             j = json.load(f)
         if j.get("workload") == workload:
-            return j.get("hbm_bytes_per_launch")
+            return j.get("hbm_bytes_per_launch"), "static: profiles/pmc_traffic.json (" + j.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes") + ")"
     except Exception:
         pass
-    return None
+    return None, None
+
+
+def variant_run(cabi, torch, label, H, mass, lhs, rhs, steps, warmup, **kw):
+    """ms per V-cycle (incl. residual check) + solve-to-1e-4 of another workload / engine variant (never `value`)."""
+    eng = cabi.Engine(**kw)
+    eng.use_hierarchy(H); eng.set_mass(mass)
+    t = time.perf_counter(); eng.set_system(lhs); set_ms = 1e3 * (time.perf_counter() - t)
+    t = time.perf_counter(); x, it, res, conv = eng.solve(rhs, tol=1e-4, stop_type=2, max_iter=100); solve_ms = 1e3 * (time.perf_counter() - t)
+    eng.load_problem(rhs, rhs); eng.run_cycles(warmup, 2)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); eng.run_cycles(steps, 2); torch.cuda.synchronize()
+    out = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps, "iterations_to_1e-4": int(it), "residues": [float(v) for v in conv[:, 1]],
+           "solve_ms": solve_ms, "set_system_ms": set_ms, "n_vertices": int(lhs.shape[0]),
+           "levels": [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)], "colors": [eng.level_info(k)["n_colors"] for k in range(eng.num_levels + 1)]}
+    eng.close()
+    log(f"[bench] variant {label}: {out['ms_per_step']:.3f} ms/cycle, {it} cycles to 1e-4")
+    return out
 
 
 def cpu_quota():
@@ -92,6 +110,7 @@ def cpu_baseline(H, mass, lhs, rhs, cycles):
         "sample": f"{it} V-cycles + residual checks of the full {lhs.shape[0]}-vertex workload (x0=rhs) after the Galerkin setup",
         "setup_ms": {"reduction": O.timing["reduction"], "coarsest_solve": O.timing["coarsest_solve"], "total": 1e3 * setup_s},
         "residues": [float(r) for r in conv[:, 1]],
+        "iterations_to_1e-4": int(next((i + 1 for i, r in enumerate(conv[:, 1]) if r <= 1e-4), -1)),
         "host_cpus": os.cpu_count(), "host_cpu_quota": cpu_quota(),
     }
 
@@ -146,6 +165,7 @@ def main():
     eng.set_system(lhs)
     setup_ms = 1e3 * (time.perf_counter() - t)
     levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
+    eng_omega = eng.gs_omega
     log(f"[bench] set_system {setup_ms:.0f} ms (reduction {eng.timing('reduction'):.0f}, coarsest {eng.timing('coarsest_solve'):.0f}, "
         f"upload {eng.timing('upload'):.0f}); levels {levels}")
 
@@ -176,10 +196,11 @@ def main():
         ms, _ = eng.bench_kernel(kind, 0, 1, args.kernel_reps)
         by = eng.algorithmic_bytes(kind, 0, 1)
         kern[name] = {"ms": ms, "GBps": by / (ms * 1e-3) / 1e9}
+    traffic, traffic_source = load_pmc_traffic(workload)
     roofline = {
-        "bound": "hbm", "kernel": "gmgk::gs_color<1,1> (fine-level multicolour Gauss-Seidel, one launch per colour)",
+        "bound": "hbm", "kernel": "gmgk::gs_color<1,1> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour)",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": load_pmc_traffic(workload),
+        "traffic": traffic, "traffic_source": traffic_source,
         "launch_ms": sweep_ms / launches, "launches_per_sweep": launches,
         "algorithmic_bytes_per_launch": sweep_bytes / launches,
         "other_fine_kernels": kern,
@@ -211,6 +232,19 @@ def main():
                                            "residues_match_host_mode": bool(np.allclose(res2, residues, rtol=1e-6))}
         del eng2
 
+    # ---- informational variants (never `value`): the same problem in random vertex order (SURVEY.md 8d asks for both orderings),
+    # the reference's update without over-relaxation, and BASELINE config 3 (2 M-point kNN Laplacian)
+    if not args.no_variants and args.order == "natural" and (args.n1, args.n2) == (1732, 1732):
+        from gravo_mg_amd import meshgen
+        variants["gs_omega_1"] = variant_run(cabi, torch, "level-0 omega = 1 (the reference's update in colour order)", H, mass, lhs, rhs, args.steps, args.warmup, gs_omega=1.0)
+        Hr, mass_r, lhs_r, rhs_r = build_workload(args.n1, args.n2, "random")
+        variants["random_vertex_order"] = variant_run(cabi, torch, "random vertex order", Hr, mass_r, lhs_r, rhs_r, args.steps, args.warmup)
+        del Hr, mass_r, lhs_r, rhs_r
+        name, pos, S3, mass3, lhs3, rhs3 = meshgen.baseline_config("3")
+        H3 = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S3), ratio=8.0, lower_bound=1000)
+        variants["pointcloud_2M_knn8"] = variant_run(cabi, torch, name, H3, mass3, lhs3, rhs3, args.steps, args.warmup)
+        del H3, pos, S3, mass3, lhs3, rhs3
+
     cpu = cpu_baseline(H, mass, lhs, rhs, args.cpu_cycles) if args.cpu_cycles > 0 else None
 
     out = {
@@ -219,9 +253,13 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
-                   "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": args.graph,
+                   "smoother": f"2+2 sweeps; level 0: multicolour Gauss-Seidel over-relaxed by {eng_omega:g} (SOR, one launch per colour); levels >= 1: "
+                               "block-hybrid Gauss-Seidel (64-row blocks: Gauss-Seidel inside a block, Jacobi between blocks, one launch per sweep)",
+                   "coarse_solve": args.coarse, "hipgraph": args.graph,
                    "tolerance": 1e-4, "stopping_criteria": 2},
-        "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms, "solver_timing_ms": timing,
+        "iterations_to_1e-4": iters, "residue": res, "residues_to_1e-4": [float(v) for v in conv[:, 1]],
+        "iterations_reference_algorithm": cpu["iterations_to_1e-4"] if cpu else None,
+        "solve_ms": solve_ms, "solver_timing_ms": timing,
         "set_system_ms": setup_ms, "set_system_same_pattern_ms": repeat_ms, "set_system_same_pattern_values_only": repeat_values_only,
         "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
         "timed_residues_tail": [float(r) for r in residues[-3:]],

@@ -102,6 +102,14 @@ SIGNATURES = {
     "gmg_dist_norm_all": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_dist_gather": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gmg_dist_scatter": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "gmg_p2p_blob_bytes": (C.c_int, []),
+    "gmg_p2p_prepare": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "gmg_p2p_export": (C.c_int, [_vp, C.c_void_p]),
+    "gmg_p2p_connect": (C.c_int, [_vp, C.c_void_p, C.c_int, C.POINTER(_vp)]),
+    "gmg_p2p_load": (C.c_int, [_vp, _dp, _dp]),
+    "gmg_p2p_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
+    "gmg_p2p_fetch": (C.c_int, [_vp, _dp]),
+    "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
@@ -529,6 +537,52 @@ class Engine:
     def dist_scatter(self, src_ptr: int, pos_ptr: int, idx_ptr: int, n: int, dst_ptr: int):
         """dst[idx[i]] = src[pos[i]] on the engine stream (device pointers)."""
         self._chk(lib().gmg_dist_scatter(self._h, src_ptr, pos_ptr, idx_ptr, int(n), dst_ptr))
+
+
+class P2PCycle:
+    """Engine-driven multi-GPU V-cycle (include/gravomg_hip.h "multi-GPU, engine-driven"): one instance per rank, each over an
+    Engine created with row_align = 64 * world and the system set.  `connect` takes the blobs of all ranks in rank order
+    (gathered by the caller, e.g. with torch.distributed.all_gather_object) -- or, for ranks emulated in one process, the peer
+    P2PCycle objects themselves."""
+
+    def __init__(self, engine: "Engine", rank: int, world: int, d: int = 1):
+        self.eng, self.rank, self.world, self.d = engine, int(rank), int(world), int(d)
+        engine._chk(lib().gmg_p2p_prepare(engine._h, self.rank, self.world, self.d))
+        self._n = engine.level_info(0)["n"]
+
+    def export(self) -> bytes:
+        buf = C.create_string_buffer(lib().gmg_p2p_blob_bytes())
+        self.eng._chk(lib().gmg_p2p_export(self.eng._h, buf))
+        return buf.raw
+
+    def connect(self, blobs=None, peers=None):
+        if peers is not None:                      # same process: handles in rank order
+            arr = (_vp * self.world)(*[p.eng._h for p in peers])
+            self.eng._chk(lib().gmg_p2p_connect(self.eng._h, None, 1, arr))
+        else:
+            blob = b"".join(blobs)
+            assert len(blob) == self.world * lib().gmg_p2p_blob_bytes()
+            self.eng._chk(lib().gmg_p2p_connect(self.eng._h, blob, 0, None))
+
+    def load(self, b, x0):
+        B, X = _f64(b), _f64(x0)
+        assert B.shape == (self._n, self.d) and X.shape == B.shape
+        self.eng._chk(lib().gmg_p2p_load(self.eng._h, _pd(B), _pd(X)))
+
+    def cycles(self, n: int, stop_type: int = 2) -> np.ndarray:
+        res = np.zeros(max(int(n), 1))
+        self.eng._chk(lib().gmg_p2p_cycles(self.eng._h, int(n), int(stop_type), _pd(res)))
+        return res[: int(n)]
+
+    def fetch(self) -> np.ndarray:
+        X = np.empty((self._n, self.d), order="F")
+        self.eng._chk(lib().gmg_p2p_fetch(self.eng._h, _pd(X)))
+        return X
+
+    def stat(self, key: str) -> float:
+        out = C.c_double()
+        self.eng._chk(lib().gmg_p2p_stat(self.eng._h, key.encode(), C.byref(out)))
+        return out.value
 
 
 def host_galerkin(A, U) -> sp.csc_matrix:

@@ -49,6 +49,8 @@ static inline double ms_since(clk::time_point t0) { return std::chrono::duration
 #define GMG_CATCH_0                                              \
     catch (...) { return GMG_ERR_STATE; }
 
+void p2p_release_handle(gmg_handle h);      // engine_dist.hip.hpp
+
 extern "C" {
 
 int gmg_config_default(gmg_config* cfg) try {
@@ -114,6 +116,7 @@ void gmg_destroy(gmg_handle h) {
     if (h->has_device) {
         (void)hipSetDevice(h->cfg.device);
         (void)hipStreamSynchronize(h->stream);
+        p2p_release_handle(h);
         drop_system(h);
         drop_device_transfers(h);
         for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)dev_free(*p);
@@ -1172,12 +1175,10 @@ int gmg_dist_prolong_own(gmg_handle h) try {
     return GMG_OK;
 } GMG_CATCH_H
 
-// sums[2*c] / sums[2*c+1] = this rank's share of sum w r^2 / sum w b^2 for column c (host output; synchronises).
-int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) try {
-    NEED_DEVICE();
+// this rank's share of sum w r^2 / sum w b^2 per column -> h->d_norm[2 * d] (on the stream; no synchronisation)
+static int dist_norm_launch(gmg_handle h, int type) {
     int rc = dist_ready(h);
     if (rc) return rc;
-    if (!sums) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = check_norm_type(h, type))) return rc;
     Level& l = h->lv[0];
     const int d = h->loaded_d;
@@ -1196,6 +1197,16 @@ int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) try {
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0,
                            (unsigned long long*)nullptr, 0ull);
     }
+    return GMG_OK;
+}
+
+// sums[2*c] / sums[2*c+1] = this rank's share of sum w r^2 / sum w b^2 for column c (host output; synchronises).
+int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) try {
+    NEED_DEVICE();
+    if (!sums) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    int rc = dist_norm_launch(h, type);
+    if (rc) return rc;
+    const int d = h->loaded_d;
     HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     std::memcpy(sums, h->h_norm, sizeof(double) * 2 * d);
@@ -1447,3 +1458,5 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
 } GMG_CATCH_0
 
 }  // extern "C"
+
+#include "engine_dist.hip.hpp"

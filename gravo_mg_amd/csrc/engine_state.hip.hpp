@@ -115,8 +115,11 @@ struct gmg_hierarchy_s {
     HierarchyResult res;
 };
 
+struct DistP2P;
+
 struct gmg_solver_s {
     DevPool pool;
+    DistP2P* p2p = nullptr;              // engine-driven multi-GPU cycle (engine_dist.hip.hpp)
     gmg_config cfg;
     std::string err;
     bool has_device = false;

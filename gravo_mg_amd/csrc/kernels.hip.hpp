@@ -713,6 +713,97 @@ __global__ void scatter_entries(const double* __restrict__ src, const int64_t* _
     if (i < n) dst[idx[i]] = src[pos[i]];
 }
 
+// ---- multi-GPU, device-initiated exchange (one process per GPU; engine_dist.hip.hpp) -------------------------------------
+// Every rank owns a MAILBOX (fine-grained device memory, mapped into the other ranks' address spaces through IPC handles)
+// with one region per (source rank, exchange kind) and one 64-bit arrival counter per source rank.  An exchange is ONE small
+// launch on every rank: block j < n_peers PUSHES -- it stores this rank's values for peer j straight into j's mailbox over
+// xGMI, fences at system scope and then publishes the exchange's sequence number in j's counter; block n_peers + j PULLS --
+// lane 0 waits until peer j's sequence number has arrived in the local counter (system-scope acquire), then the block copies
+// j's region into the local vector.  No collective-library call, no host involvement, ~one xGMI round trip of latency.
+// Both directions run every time (with or without payload), so a region is never overwritten before its reader is done with
+// it: a rank pushes exchange s + 1 only after it pulled exchange s from that peer, which the peer sent after its own pull.
+struct P2POp {
+    const int* send_idx;            // local vector entries this rank publishes to the peer (null: contiguous range send_lo ..)
+    int n_send, send_lo;
+    double* remote_box;             // where they go: the peer's mailbox region for (this rank, this kind), peer-mapped
+    unsigned long long* remote_flag;     // the peer's arrival counter for this rank, peer-mapped
+    const int* recv_idx;            // where the peer's values go in the local vector (null: contiguous range recv_lo ..)
+    int n_recv, recv_lo;
+    const double* local_box;        // this rank's mailbox region for (peer, this kind)
+    unsigned long long* local_flag; // this rank's arrival counter for the peer
+};
+
+// vec: D columns with leading dimension ld.  err (device int): set to 1 when a wait timed out (~4 s of wall clock).
+__global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ ops, int n_peers, double* vec, int ld, int D,
+                                                    unsigned long long seq, int* err) {
+    const int j = blockIdx.x < n_peers ? blockIdx.x : blockIdx.x - n_peers;
+    const P2POp op = ops[j];
+    if ((int)blockIdx.x < n_peers) {                                  // ---- push
+        const int64_t total = (int64_t)op.n_send * D;
+        for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+            const int c = (int)(i / op.n_send), k = (int)(i - (int64_t)c * op.n_send);
+            const int src = op.send_idx ? op.send_idx[k] : op.send_lo + k;
+            op.remote_box[i] = vec[src + (int64_t)c * ld];
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {                                                          // ---- pull
+        __shared__ int timed_out;
+        if (threadIdx.x == 0) {
+            timed_out = 0;
+            const unsigned long long t0 = wall_clock64();            // 100 MHz constant clock
+            while (__hip_atomic_load(op.local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 400000000ull) { timed_out = 1; atomicExch(err, 1); break; }
+            }
+        }
+        __syncthreads();
+        if (timed_out) return;
+        const int64_t total = (int64_t)op.n_recv * D;
+        const unsigned long long* box = reinterpret_cast<const unsigned long long*>(op.local_box);
+        for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+            const int c = (int)(i / op.n_recv), k = (int)(i - (int64_t)c * op.n_recv);
+            const int dst = op.recv_idx ? op.recv_idx[k] : op.recv_lo + k;
+            // system-scope loads: the region is rewritten by the peer every exchange, no stale cached copy may be served
+            const unsigned long long bits = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            vec[dst + (int64_t)c * ld] = __longlong_as_double((long long)bits);
+        }
+    }
+}
+
+// All-reduce of a few doubles (the residual-norm sums): every rank pushes its values to every peer, then adds the world
+// contributions in RANK order -- the same sum, bit for bit, on every rank.  One block; peers in ascending rank order.
+__global__ __launch_bounds__(64) void p2p_allreduce_small(const P2POp* __restrict__ ops, int n_peers, int rank, const double* __restrict__ mine,
+                                                          int n, double* __restrict__ out, unsigned long long seq, int* err) {
+    const int t = threadIdx.x;
+    __shared__ int timed_out;
+    if (t == 0) timed_out = 0;
+    for (int j = 0; j < n_peers; ++j)
+        if (t < n) ops[j].remote_box[t] = mine[t];
+    __threadfence_system();
+    __syncthreads();
+    if (t < n_peers) {
+        __hip_atomic_store(ops[t].remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(ops[t].local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 400000000ull) { timed_out = 1; atomicExch(err, 1); break; }
+        }
+    }
+    __syncthreads();
+    if (timed_out) return;
+    if (t < n) {
+        double sum = 0.0;
+        for (int r = 0; r <= n_peers; ++r) {                          // world = n_peers + 1 contributions, rank order
+            if (r == rank) { sum += mine[t]; continue; }
+            const unsigned long long* box = reinterpret_cast<const unsigned long long*>(ops[r < rank ? r : r - 1].local_box);
+            sum += __longlong_as_double((long long)__hip_atomic_load(box + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        }
+        out[t] = sum;
+    }
+}
+
 // n doubles -> host-visible pinned memory, then the sequence word (one block; the coarsest right-hand side)
 __global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restrict__ src, double* __restrict__ dst, int n,
                                                           unsigned long long* flag, unsigned long long seq) {

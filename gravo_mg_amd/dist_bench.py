@@ -95,7 +95,7 @@ def main(args):
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "gmgk::gs_color<1,1> (whole level 0 on one GPU; a rank launches 1/N of it per colour)",
                     "achieved": achieved, "peak": single.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / single.HBM_PEAK_GBS,
-                    "traffic": single.load_pmc_traffic(workload), "launch_ms": sweep_ms / launches, "launches_per_sweep": launches}
+                    "traffic": single.load_pmc_traffic(workload)[0], "traffic_source": single.load_pmc_traffic(workload)[1], "launch_ms": sweep_ms / launches, "launches_per_sweep": launches}
     if rank == 0:
         n0 = lhs.shape[0]
         out = {
@@ -104,7 +104,7 @@ def main(args):
             "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
-                       "smoother": "multicolour Gauss-Seidel 2+2", "coarse_solve": args.coarse, "hipgraph": False,
+                       "smoother": f"2+2 sweeps; level 0: multicolour Gauss-Seidel over-relaxed by {eng.gs_omega:g} (row-partitioned); levels >= 1: block-hybrid Gauss-Seidel (replicated)", "coarse_solve": args.coarse, "hipgraph": False,
                        "partition": (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
                                      f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle"
                                      if halo is not None else

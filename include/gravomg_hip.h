@@ -207,6 +207,26 @@ int gmg_dist_norm_all(gmg_handle h, int type, double* sums);
 int gmg_dist_gather(gmg_handle h, const double* src, const int64_t* idx, int64_t n, double* dst);
 int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const int64_t* idx, int64_t n, double* dst);
 
+/* ---- multi-GPU, engine-driven: one process per GPU, device-initiated peer-to-peer exchanges ----------------------------
+ * The same row-partitioned V-cycle (multigrid_solver.cpp:1059-1088 + the residual check :1228-1277), but orchestrated inside
+ * the library: every exchange is one small kernel that stores this rank's halo values straight into the peers' mailboxes
+ * (fine-grained device memory mapped through hipIpc handles, xGMI stores) and waits for theirs -- no collective-library call
+ * and no host code between the launches of a cycle.  Call order, on every rank: gmg_set_system on a handle created with
+ * row_align = 64 * world -> gmg_p2p_prepare -> gmg_p2p_export -> (the caller gathers the `world` blobs in rank order by any
+ * means: torch.distributed.all_gather_object, MPI, a file) -> gmg_p2p_connect -> gmg_p2p_load -> gmg_p2p_cycles ... ->
+ * gmg_p2p_fetch.  All ranks must run the same sequence of gmg_p2p_cycles / gmg_p2p_fetch calls; a missing peer shows up as
+ * GMG_ERR_STATE after a ~4 s device-side time-out, never as a hang.  Iterates are bitwise those of one GPU. */
+int gmg_p2p_blob_bytes(void);
+int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d);
+int gmg_p2p_export(gmg_handle h, void* blob_out);
+/* blobs: world x gmg_p2p_blob_bytes() bytes in rank order.  same_process != 0 (tests: several "ranks" in one process on one
+ * GPU): blobs may be NULL and peer_handles holds the ranks' handles in rank order (memory is shared directly). */
+int gmg_p2p_connect(gmg_handle h, const void* blobs, int same_process, gmg_handle* peer_handles);
+int gmg_p2p_load(gmg_handle h, const double* b, const double* x0);
+int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
+int gmg_p2p_fetch(gmg_handle h, double* x);
+int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:
  * kind 0 = full smoothing sweep (all colours), 1 = residual r=b-Ax, 2 = restrict, 3 = prolong_add,

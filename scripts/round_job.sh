@@ -1,0 +1,13 @@
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02e; mkdir -p $O; rm -f $R/gpurun_out/fullsize_configs.jsonl
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q --durations=6 > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
+python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json; echo
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof3m -- python $R/bench.py --steps 20 --warmup 3 --cpu-cycles 0 --no-variants > $O/prof3m.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 4 --warmup 1 --cpu-cycles 0 --no-variants --kernel-reps 4 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 4 --warmup 1 --cpu-cycles 0 --no-variants --kernel-reps 4 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof3m_random -- python $R/bench.py --steps 20 --warmup 3 --cpu-cycles 0 --no-variants --order random > $O/prof3m_random.log 2>&1
+python $R/bench.py --n1 2829 --n2 2829 --cpu-cycles 0 --no-variants > $O/bench_8m.json 2> $O/bench_8m.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof8m -- python $R/bench.py --n1 2829 --n2 2829 --steps 20 --warmup 3 --cpu-cycles 0 --no-variants > $O/prof8m.log 2>&1
+python $R/bench.py --n1 4483 --n2 4483 --cpu-cycles 0 --no-variants > $O/bench_20m.json 2> $O/bench_20m.err
+ls $O

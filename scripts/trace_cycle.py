@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
-idx = [i for i, n in enumerate(names) if "residual_norm_partials" in n]
+idx = [i for i, n in enumerate(names) if "residual_norm_partials" in n or "residual_norm_slices" in n]
 # windows between consecutive norm kernels that hold a whole V-cycle (many kernels); take a middle one
 wins = [(idx[i], idx[i + 1]) for i in range(len(idx) - 1) if idx[i + 1] - idx[i] > 20]
 a, b = wins[len(wins) // 2]

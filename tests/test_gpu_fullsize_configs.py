@@ -116,3 +116,35 @@ def test_vcycle_is_affine(case):
     # to rounding; the coarsest solve of the nearly singular Poisson operators (tau = 1e-6) amplifies rounding along the
     # constant mode by ~1/tau: the defect is a constant of relative size ~1e-9
     assert np.abs(y12 - (y1 + y2)).max() <= 1e-8 * (np.abs(y1).max() + np.abs(y2).max())
+
+
+def test_hierarchy_invariants_at_full_size(case, cabi):
+    """The hierarchy the constructor builds (gmg_hierarchy_build: the restatement of multigrid_solver.cpp:62-469, 975-1056) on
+    the full-size workloads: what the reference's construction guarantees, checked on every level -- <= 3 parents per row,
+    weights in [0, 1] summing to 1, every coarse point has children, a sample is the centre of its own cluster and (default
+    barycentric weighting, not nested) clusters are what the prolongation of a sample row points at most strongly, level sizes
+    fall by the FASTDISK ratio (~6 for ratio = 8) down to >= lower_bound.  (Parent-by-parent agreement with the independent
+    restatement of the reference's algorithm is checked at sizes it can handle: tests/test_gpu_hierarchy.py.)"""
+    import scipy.sparse as sp
+    H = case["H"]
+    n = case["lhs"].shape[0]
+    assert len(H.U) >= 2 and len(H.samples) == len(H.nearest) == len(H.points) == len(H.U)
+    for k, U in enumerate(H.U):
+        nc = U.shape[1]
+        assert U.shape[0] == n and 1000 <= nc < n
+        assert 3.0 <= n / nc <= 12.0, (k, n, nc)
+        R = sp.csr_matrix(U)
+        per_row = np.diff(R.indptr)
+        assert per_row.min() >= 1 and per_row.max() <= 3
+        assert U.data.min() >= -1e-12 and U.data.max() <= 1 + 1e-12
+        assert np.abs(np.asarray(U.sum(axis=1)).ravel() - 1.0).max() <= 1e-12
+        assert np.all(np.diff(U.indptr) >= 1) and U.has_sorted_indices
+        smp, near, pts = H.samples[k], H.nearest[k], H.points[k]
+        assert smp.shape == (nc,) and near.shape == (n,) and pts.shape == (nc, 3)
+        assert len(np.unique(smp)) == nc and smp.min() >= 0 and smp.max() < n
+        assert near.min() >= 0 and near.max() < nc
+        assert np.array_equal(near[smp], np.arange(nc))                      # a sample belongs to its own cluster
+        assert np.all(np.bincount(near, minlength=nc) >= 1)                  # no empty cluster
+        assert np.isfinite(pts).all()
+        n = nc
+    assert n < 8 * 1000 * 8                                                  # the coarsest level is small enough for the host LDL^T
