@@ -10,9 +10,10 @@ A "step" is ONE V-cycle followed by the residual check, exactly one trip of the 
 jittered torus 1732 x 1732 = 2 999 824 vertices, cotangent Laplacian, lhs = 1e-6*M + S, rhs = M*y,
 y ~ N(0,1) seed 42, d = 1, x0 = rhs, ratio 8, lower_bound 1000, 2+2 smoothing sweeps, M-norm stop at 1e-4.
 
-For N > 1 the driver launches this file under torch.distributed.run; the finest level is row-partitioned
-and the ranks exchange their slices of x with an RCCL all-gather between colour sweeps
-(gravo_mg_amd/dist.py).  Rank 0 prints ONE JSON line.
+For N > 1 the driver launches this file under torch.distributed.run; the finest level is row-partitioned and after
+every colour sweep each rank stores the halo entries its peers read straight into their mailboxes (device-initiated
+peer-to-peer exchange, gravo_mg_amd/csrc/engine_dist.hip.hpp; RCCL all-gathers as the fallback, gravo_mg_amd/dist.py).
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -132,8 +133,9 @@ def main():
     ap.add_argument("--block-lanes", type=int, default=None)
     ap.add_argument("--no-variants", action="store_true", help="skip the informational device-coarse-apply timing")
     ap.add_argument("--force-dist", action="store_true", help="use the multi-GPU code path even with one rank")
-    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
-                    help="N > 1: publish only the entries other ranks read after a colour sweep (halo) or whole colour segments")
+    ap.add_argument("--exchange", default="p2p", choices=["p2p", "halo", "allgather"],
+                    help="N > 1: p2p = engine-driven cycle, device-initiated stores into the peers' mailboxes (falls back to halo if it "
+                         "cannot be set up); halo = RCCL all-gather of the packed halo entries per colour; allgather = whole colour segments")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -105,10 +105,11 @@ SIGNATURES = {
     "gmg_p2p_blob_bytes": (C.c_int, []),
     "gmg_p2p_prepare": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "gmg_p2p_export": (C.c_int, [_vp, C.c_void_p]),
-    "gmg_p2p_connect": (C.c_int, [_vp, C.c_void_p, C.c_int, C.POINTER(_vp)]),
+    "gmg_p2p_connect": (C.c_int, [_vp, C.c_void_p]),
     "gmg_p2p_load": (C.c_int, [_vp, _dp, _dp]),
     "gmg_p2p_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "gmg_p2p_fetch": (C.c_int, [_vp, _dp]),
+    "gmg_p2p_bench_exchange": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
@@ -542,8 +543,7 @@ class Engine:
 class P2PCycle:
     """Engine-driven multi-GPU V-cycle (include/gravomg_hip.h "multi-GPU, engine-driven"): one instance per rank, each over an
     Engine created with row_align = 64 * world and the system set.  `connect` takes the blobs of all ranks in rank order
-    (gathered by the caller, e.g. with torch.distributed.all_gather_object) -- or, for ranks emulated in one process, the peer
-    P2PCycle objects themselves."""
+    (gathered by the caller, e.g. with torch.distributed.all_gather_object).  Ranks are separate processes."""
 
     def __init__(self, engine: "Engine", rank: int, world: int, d: int = 1):
         self.eng, self.rank, self.world, self.d = engine, int(rank), int(world), int(d)
@@ -555,14 +555,10 @@ class P2PCycle:
         self.eng._chk(lib().gmg_p2p_export(self.eng._h, buf))
         return buf.raw
 
-    def connect(self, blobs=None, peers=None):
-        if peers is not None:                      # same process: handles in rank order
-            arr = (_vp * self.world)(*[p.eng._h for p in peers])
-            self.eng._chk(lib().gmg_p2p_connect(self.eng._h, None, 1, arr))
-        else:
-            blob = b"".join(blobs)
-            assert len(blob) == self.world * lib().gmg_p2p_blob_bytes()
-            self.eng._chk(lib().gmg_p2p_connect(self.eng._h, blob, 0, None))
+    def connect(self, blobs):
+        blob = b"".join(blobs)
+        assert len(blob) == self.world * lib().gmg_p2p_blob_bytes()
+        self.eng._chk(lib().gmg_p2p_connect(self.eng._h, blob))
 
     def load(self, b, x0):
         B, X = _f64(b), _f64(x0)
@@ -578,6 +574,11 @@ class P2PCycle:
         X = np.empty((self._n, self.d), order="F")
         self.eng._chk(lib().gmg_p2p_fetch(self.eng._h, _pd(X)))
         return X
+
+    def bench_exchange(self, reps: int = 100) -> float:
+        out = C.c_double()
+        self.eng._chk(lib().gmg_p2p_bench_exchange(self.eng._h, int(reps), C.byref(out)))
+        return out.value
 
     def stat(self, key: str) -> float:
         out = C.c_double()

@@ -187,12 +187,12 @@ int gmg_p2p_export(gmg_handle h, void* blob_out) try {
 } GMG_CATCH_H
 
 // blobs: `world` blobs in rank order (every rank's gmg_p2p_export output, gathered by the caller -- e.g. torch.distributed
-// all_gather_object, MPI, a file).  same_process != 0: the peers are handles of THIS process (tests: ranks emulated on one
-// GPU), `peer_handles` their gmg_handle values in rank order -- memory is then shared directly instead of through IPC.
-int gmg_p2p_connect(gmg_handle h, const void* blobs, int same_process, gmg_handle* peer_handles) try {
+// all_gather_object, MPI, a file).  (Ranks must be separate PROCESSES: a process's streams share a few hardware queues, and an
+// exchange kernel waiting in front of the kernel it waits for would never be served.)
+int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     NEED_DEVICE();
     DistP2P* p = h->p2p;
-    if (!p || !p->planned || (!blobs && !same_process)) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare first");
+    if (!p || !p->planned || !blobs) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare first");
     const int world = p->world, rank = p->rank, C = h->lv[0].ord.n_colors, nk = p->nk, d = p->d;
     const gmg_p2p_blob* bl = (const gmg_p2p_blob*)blobs;
     p->peers.clear();
@@ -200,14 +200,6 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs, int same_process, gmg_handl
         if (q == rank) continue;
         P2PPeer peer;
         peer.rank = q;
-        if (same_process) {
-            if (!peer_handles || !peer_handles[q] || !peer_handles[q]->p2p) return fail(h, GMG_ERR_INVALID, "peer handle missing");
-            DistP2P* o = peer_handles[q]->p2p;
-            if (o->world != world || o->rank != q || o->d != d || o->box_total[q] != p->box_total[q]) return fail(h, GMG_ERR_INVALID, "peer plans differ");
-            peer.mbox_base = nullptr; peer.flag_base = nullptr;           // not IPC mappings: nothing to close
-            p->peers.push_back(peer);
-            continue;
-        }
         if (bl[q].rank != q || bl[q].world != world || bl[q].d != d || bl[q].n_pad != h->lv[0].n_pad || bl[q].n_colors != C || bl[q].mbox_doubles != p->box_total[q])
             return fail(h, GMG_ERR_INVALID, "peer " + std::to_string(q) + " published a different partition plan (different system / ordering?)");
         HIPCHK(hipIpcOpenMemHandle(&peer.mbox_base, bl[q].mbox, hipIpcMemLazyEnablePeerAccess));
@@ -236,8 +228,8 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs, int same_process, gmg_handl
             for (int j = 0; j < np; ++j) {
                 const int q = p->peers[j].rank;
                 gmgk::P2POp& op = ops[(size_t)(k * 2 + par) * np + j];
-                double* qbox = same_process ? peer_handles[q]->p2p->mbox : (double*)p->peers[j].mbox_base;
-                unsigned long long* qflags = same_process ? peer_handles[q]->p2p->flags : (unsigned long long*)p->peers[j].flag_base;
+                double* qbox = (double*)p->peers[j].mbox_base;
+                unsigned long long* qflags = (unsigned long long*)p->peers[j].flag_base;
                 op.remote_box = qbox + p->box_off[(((size_t)q * world + rank) * nk + k) * 2 + par];
                 op.remote_flag = qflags + 64 * (size_t)rank;                 // one cache line per source rank
                 op.local_box = p->mbox + p->box_off[(((size_t)rank * world + q) * nk + k) * 2 + par];
@@ -376,6 +368,24 @@ int gmg_p2p_fetch(gmg_handle h, double* x) try {
     int rc = p2p_exchange(h, l.ord.n_colors + 1, l.x);
     if (rc) return rc;
     return to_host(h, 0, l.x, p->d, x);
+} GMG_CATCH_H
+
+// Average duration (ms) of one halo exchange of colour 0 (push + wait + pull, one launch), `reps` back to back; collective.
+int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg) try {
+    NEED_DEVICE();
+    DistP2P* p = h->p2p;
+    if (!p || !p->connected || !h->bound || !ms_avg || reps <= 0) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
+    Level& l = h->lv[0];
+    for (int i = 0; i < 3; ++i) (void)p2p_exchange(h, 0, l.x);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < reps; ++i) (void)p2p_exchange(h, 0, l.x);
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_avg = (double)ms / reps;
+    return GMG_OK;
 } GMG_CATCH_H
 
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {

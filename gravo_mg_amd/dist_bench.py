@@ -12,6 +12,7 @@ import time
 
 
 def main(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -50,9 +51,16 @@ def main(args):
     eng.set_mass(mass)
     eng.set_system(lhs)
     levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
+    # ---- exchange engine: "p2p" (default) = the cycle is driven inside the library and every exchange is a device-initiated
+    # store into the peers' mailboxes (gmg_p2p_*, no collective call per colour); "halo" / "allgather" = the RCCL
+    # orchestration of gravo_mg_amd/dist.py.  The peer-to-peer path is taken only if EVERY rank could set it up and its first
+    # cycles reproduce the RCCL path's residues; otherwise all ranks fall back together.
+    p2p, p2p_note = None, None
+    want_p2p = args.exchange == "p2p"
+    cpu_group = dist.new_group(backend="gloo") if (world > 1 and want_p2p) else None
     be = EngineBackend(eng, 1, rank, world, torch.device("cuda", local))
     halo = None
-    if world > 1 and args.exchange == "halo":
+    if world > 1 and args.exchange in ("halo", "p2p"):
         t = time.perf_counter()
         new2old, cb = eng.level_ordering(0)
         A = lhs.tocsr()
@@ -68,11 +76,44 @@ def main(args):
         return out
 
     be.load(rhs, rhs)
-    run(args.warmup)
+    warm = run(max(args.warmup, 2))
     torch.cuda.synchronize()
+    exchange_us = None
+    if want_p2p and world > 1:
+        ok, note = 1, "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
+        try:
+            eng2 = cabi.Engine(device=local, row_align=64 * world, use_graph=False,
+                               coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT)
+            eng2.use_hierarchy(H); eng2.set_mass(mass); eng2.set_system(lhs)
+            cand = cabi.P2PCycle(eng2, rank, world, 1)
+            blobs = [None] * world
+            dist.all_gather_object(blobs, cand.export(), group=cpu_group)
+            cand.connect(blobs)
+            dist.barrier()
+            cand.load(rhs, rhs)
+            got = cand.cycles(len(warm), 2)
+            if not np.allclose(got, warm, rtol=1e-9):
+                ok, note = 0, f"peer-to-peer residues {list(got)} differ from the RCCL path's {warm}"
+        except Exception as e:          # noqa: BLE001
+            ok, note = 0, f"peer-to-peer set-up failed on rank {rank}: {e!r}"
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            p2p, p2p_note = cand, note
+            exchange_us = 1e3 * p2p.bench_exchange(200)
+        else:
+            p2p_note = note if ok == 0 else "another rank could not set up the peer-to-peer path"
+            single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange ({p2p_note})")
     dist.barrier()
     t0 = time.perf_counter()
-    residues = run(args.steps)
+    if p2p is not None:
+        p2p.load(rhs, rhs)
+        p2p.cycles(args.warmup, 2)
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        residues = list(p2p.cycles(args.steps, 2))
+    else:
+        residues = run(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
@@ -83,7 +124,16 @@ def main(args):
 
     be.load(rhs, rhs)
     t = time.perf_counter()
-    iters, res, hist = dv.solve(1e-4, 2, 100)
+    if p2p is not None:
+        p2p.load(rhs, rhs)
+        hist = []
+        while True:
+            hist.append(float(p2p.cycles(1, 2)[0]))
+            if not (hist[-1] > 1e-4 and len(hist) < 100):
+                break
+        iters, res = len(hist), hist[-1]
+    else:
+        iters, res, hist = dv.solve(1e-4, 2, 100)
     torch.cuda.synchronize()
     solve_ms = 1e3 * (time.perf_counter() - t)
 
@@ -105,13 +155,19 @@ def main(args):
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
                        "smoother": f"2+2 sweeps; level 0: multicolour Gauss-Seidel over-relaxed by {eng.gs_omega:g} (row-partitioned); levels >= 1: block-hybrid Gauss-Seidel (replicated)", "coarse_solve": args.coarse, "hipgraph": False,
-                       "partition": (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
+                       "partition": (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep ONE exchange kernel: "
+                                     f"each rank stores the halo entries its peers read into their mailboxes over xGMI ({halo.published_rows} rows in all) and waits "
+                                     "for theirs; r pushed to all peers once per cycle; no collective call in the cycle" if p2p is not None else
+                                     f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
                                      f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle"
                                      if halo is not None else
                                      f"level 0 colour sweeps split {world}-way by rows, everything else replicated; one RCCL all-gather of x per colour sweep"),
                        "tolerance": 1e-4, "stopping_criteria": 2},
             "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms,
-            "collectives_per_cycle": colls / max(args.steps + args.warmup, 1), "collective_backend": backend,
+            "exchange": ("p2p" if p2p is not None else args.exchange if args.exchange != "p2p" else "halo (fallback)"), "exchange_note": p2p_note,
+            "exchange_us": exchange_us,
+            "collectives_per_cycle": (0 if p2p is not None else colls / max(args.steps + max(args.warmup, 2), 1)), "collective_backend": backend,
+            "residues_to_1e-4": [float(v) for v in hist],
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
             "timed_residues_tail": [float(r) for r in residues[-3:]],
             "roofline": roofline, "cpu_baseline": None,

@@ -219,12 +219,13 @@ int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const 
 int gmg_p2p_blob_bytes(void);
 int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d);
 int gmg_p2p_export(gmg_handle h, void* blob_out);
-/* blobs: world x gmg_p2p_blob_bytes() bytes in rank order.  same_process != 0 (tests: several "ranks" in one process on one
- * GPU): blobs may be NULL and peer_handles holds the ranks' handles in rank order (memory is shared directly). */
-int gmg_p2p_connect(gmg_handle h, const void* blobs, int same_process, gmg_handle* peer_handles);
+/* blobs: world x gmg_p2p_blob_bytes() bytes in rank order. */
+int gmg_p2p_connect(gmg_handle h, const void* blobs);
 int gmg_p2p_load(gmg_handle h, const double* b, const double* x0);
 int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
 int gmg_p2p_fetch(gmg_handle h, double* x);
+/* average duration (ms) of one colour-0 halo exchange, `reps` back to back (collective; measurement) */
+int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg);
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
