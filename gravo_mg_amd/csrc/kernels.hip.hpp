@@ -454,9 +454,12 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 #pragma unroll
     for (int j = 0; j < kEpW / 4; ++j) cpk[j] = 0u;
 #pragma unroll
-    for (int j = 0; j < kEpW; ++j) {
-        v[j] = (T)0.0;
-        if (j < nlow) { v[j] = sval[lb + j]; cpk[j >> 2] |= (unsigned)scol[lb + j] << ((j & 3) * 8); }
+    for (int j = 0; j < kEpW; ++j) {                                   // (selects, not branches: LDS reads of slot 0 are always valid, and a
+        const int at = j < nlow ? lb + j : 0;                          // conditional element store makes hipcc copy whole fp32 register tuples)
+        const T t = sval[at];
+        const unsigned cc = scol[at];
+        v[j] = j < nlow ? t : (T)0.0;
+        cpk[j >> 2] |= (j < nlow ? cc : 0u) << ((j & 3) * 8);
     }
 #define GMG_EP_COL(j) ((int)((cpk[(j) >> 2] >> (((j) & 3) * 8)) & 0xffu))
     const int nc = blk_ncolors[blk];
