@@ -240,11 +240,11 @@ void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
 int launch_norm(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = grid_for(l.Aoff.n_slices);          // one slice per wave, like the residual SpMV; one partial per block
+    const int nblk = norm_grid(l.Aoff.n_slices);         // one slice per wave, like the residual SpMV; one partial per block of 16
     const bool poll = polled(h);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream, l.Aoff.slice_ptr,
                                           l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
                                           l.n_pad, l.Aoff.n_slices, (float*)nullptr, h->d_partials));
         launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
@@ -452,10 +452,10 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
 int launch_residual_to_f32(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = grid_for(l.Aoff.n_slices);
+    const int nblk = norm_grid(l.Aoff.n_slices);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 1>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 1>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
                                           l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad, l.Aoff.n_slices,
                                           l.b32 + (size_t)c0 * l.n_pad, h->d_partials));
         launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);

@@ -530,4 +530,9 @@ inline int grid_for(int n_slices) {
     return (g + 7) / 8 * 8;    // multiple of 8 so the XCD swizzle is a bijection
 }
 
+inline int norm_grid(int n_slices) {
+    int g = (n_slices + gmgk::kNormWaves - 1) / gmgk::kNormWaves;
+    return (g + 7) / 8 * 8;
+}
+
 }  // namespace

@@ -863,22 +863,23 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
 }
 
 // The same sums with the launch geometry of the residual SpMV -- one slice per wave, XCD-aware slice map, one partial per
-// block of four slices (n_slices / 4 of them; reduce_partials adds them in index order, so the result does not depend on
+// block of kNormWaves slices (n_slices / 16 of them; reduce_partials adds them in index order, so the result does not depend on
 // which block ran where).  The grid-stride kernel above walks ~6 slices per wave one after the other, each with its own
 // load -> gather round trips: 59 us against 47 us for the SpMV over the same matrix at 3 M vertices.  MODE 1 also writes the
 // residual b - A x as the fp32 right-hand side of the mixed-precision inner cycle (the defect-correction loop of BASELINE config 5).
+constexpr int kNormWaves = 16;      // slices (waves) per block of the norm kernel: 1024 threads, one partial per 16 slices
 template <int D, int MODE>
-__global__ __launch_bounds__(kBlock) void residual_norm_slices(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+__global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                                const double* __restrict__ val, const double* __restrict__ diag,
                                                                const double* __restrict__ b, const double* __restrict__ x,
                                                                const double* __restrict__ weight, int ld, int n_slices,
                                                                float* __restrict__ r32, double* __restrict__ partials) {
-    __shared__ double red[kWavesPerBlock][2 * D];
+    __shared__ double red[kNormWaves][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // partial index = the position of this block's four slices in the slice range, not blockIdx (the XCD map permutes blocks)
+    // partial index = the position of this block's slices in the slice range, not blockIdx (the XCD map permutes blocks)
     int nblk = gridDim.x, bb = blockIdx.x;
     if ((nblk & 7) == 0) bb = (bb & 7) * (nblk >> 3) + (bb >> 3);
-    const int s = __builtin_amdgcn_readfirstlane(bb * kWavesPerBlock + wave);
+    const int s = __builtin_amdgcn_readfirstlane(bb * kNormWaves + wave);
     double sums[2 * D];
 #pragma unroll
     for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void residual_norm_slices(const int64_t* __
     if (threadIdx.x < 2 * D) {
         double v = 0.0;
 #pragma unroll
-        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) v += red[w2][threadIdx.x];
+        for (int w2 = 0; w2 < kNormWaves; ++w2) v += red[w2][threadIdx.x];
         partials[(int64_t)bb * (2 * D) + threadIdx.x] = v;
     }
 }
