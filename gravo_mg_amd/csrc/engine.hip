@@ -13,6 +13,7 @@
 // :1194-1226 (smoother), :1228-1277 (norms), :1387-1419 (solve loop).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <functional>
@@ -76,7 +77,8 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->host_threads = 0;
     cfg->verbose = 0;
     cfg->block_ep = 1;
-    cfg->gs_omega = 1.2;      // measured (profiles/r02/a_iteration_ab.json): 7 -> 5 V-cycles to 1e-4 on the 3 M Poisson problem at the same cost per cycle
+    cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
+                              // problem at the same cost per cycle; centre of the 1.3 - 1.4 plateau on six workloads
     return GMG_OK;
 } GMG_CATCH_0
 
@@ -965,7 +967,21 @@ int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) try
     Level& l = h->lv[0];
     if ((rc = to_device(h, 0, b, d, l.b))) return rc;
     h->timing["load_b"] = ms_since(tl); tl = clk::now();
-    if ((rc = to_device(h, 0, x0, d, l.x))) return rc;
+    // The reference's Python API always starts from x0 = rhs (gravomg_bindings/src/cpp/core.cpp:69): when the initial guess IS
+    // the right-hand side (same buffer, or the same content -- one threaded comparison, far cheaper than a second trip over
+    // PCIe), it is copied on the device instead of being uploaded again.
+    bool same = x0 == b;
+    if (!same) {
+        const size_t cnt = (size_t)l.n * d;
+        std::atomic<bool> differ{false};
+        parallel_ranges((int)std::min<size_t>(cnt >> 12, 1 << 20) + 1, std::min(h->cfg.host_threads, 16), [&](int lo, int hi, int) {
+            const size_t a = (size_t)lo << 12, e = std::min(cnt, (size_t)hi << 12);
+            if (a < e && !differ.load(std::memory_order_relaxed) && std::memcmp(b + a, x0 + a, sizeof(double) * (e - a)) != 0) differ = true;
+        }, 2);
+        same = !differ.load();
+    }
+    if (same) HIPCHK(hipMemcpyAsync(l.x, l.b, sizeof(double) * (size_t)l.n_pad * d, hipMemcpyDeviceToDevice, h->stream));
+    else if ((rc = to_device(h, 0, x0, d, l.x))) return rc;
     h->timing["load_x"] = ms_since(tl); tl = clk::now();
     if (h->cfg.inner_precision && (rc = launch_residual_to_f32(h, d, -1))) return rc;    // defect of the initial guess -> b32
     HIPCHK(hipStreamSynchronize(h->stream));

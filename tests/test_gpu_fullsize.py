@@ -25,7 +25,7 @@ def big(cabi):
 def test_solve_reaches_the_stopping_test_and_the_oracle_agrees(big, oracle):
     eng, lhs, rhs, mass = big["eng"], big["lhs"], big["rhs"], big["mass"]
     x, it, res, conv = eng.solve(rhs, tol=1e-4, stop_type=2, max_iter=100)
-    assert it == 5 and res <= 1e-4                                   # the count DESIGN.md / bench.py quote (level-0 omega = 1.2)
+    assert it == 4 and res <= 1e-4                                   # the count DESIGN.md / bench.py quote (level-0 omega = 1.35)
     assert np.all(np.diff(conv[:, 1]) < 0)                           # monotone contraction
     assert np.all(conv[1:, 1] / conv[:-1, 1] < 0.45)                 # ... at the multigrid rate, every cycle
     chk = oracle.residual_check(lhs, mass, rhs, x, 2)                # one CPU SpMV: the reference's own stopping quantity
@@ -36,7 +36,7 @@ def test_solve_reaches_the_stopping_test_and_the_oracle_agrees(big, oracle):
 
 def test_iteration_counts_against_the_reference_algorithm(big, cabi, oracle):
     """The reference algorithm (1-core oracle, lexicographic Gauss-Seidel) needs 6 V-cycles on this problem, the multicolour
-    sweep with the reference's update (gs_omega = 1) 7, the default engine (level-0 over-relaxation 1.2) 5: recorded side by
+    sweep with the reference's update (gs_omega = 1) 7, the default engine (level-0 over-relaxation 1.35) 4: recorded side by
     side, and the three solutions agree to 20 x tol in the M-norm."""
     lhs, rhs, mass = big["lhs"], big["rhs"], big["mass"]
     O = oracle.Hierarchy(big["H"].U, mass)
@@ -47,7 +47,7 @@ def test_iteration_counts_against_the_reference_algorithm(big, cabi, oracle):
     gs.use_hierarchy(big["H"]); gs.set_mass(mass); gs.set_system(lhs)
     x1, it1, res1, conv1 = gs.solve(rhs, tol=1e-4, stop_type=2, max_iter=100)
     gs.close()
-    assert (ito, it1, it) == (6, 7, 5), (ito, it1, it)
+    assert (ito, it1, it) == (6, 7, 4), (ito, it1, it)
     m = mass[:, None]
     for y in (x, x1):
         assert np.sqrt((m * (y - xo) ** 2).sum() / (m * xo ** 2).sum()) <= 20e-4
