@@ -1,8 +1,16 @@
-"""bench.py --gpus N (N > 1): the same 3 M-vertex Poisson V-cycle, finest level row-partitioned over N ranks
-(gravo_mg_amd/dist.py).  Launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
---gpus N --steps K --warmup W`; also works with N = 1 (WORLD_SIZE=1) to exercise the distributed code path on one GPU.
-Timing: W untimed cycles, barrier + synchronize, K V-cycles each followed by the residual check, synchronize +
-barrier, MAX over ranks.  Rank 0 prints ONE JSON line."""
+"""bench.py --gpus N (N > 1): the same 3 M-vertex Poisson V-cycle, finest level row-partitioned over N ranks.
+Launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W`;
+also works with N = 1 (WORLD_SIZE=1) to exercise the distributed code path on one GPU.
+
+Exchange engines (`--exchange`):
+  p2p (default)  the cycle is driven inside the library (gmg_p2p_*, csrc/engine_dist.hip.hpp): every exchange is a
+                 device-initiated store into the peers' mailboxes, no collective call and no Python per colour.  Taken only if
+                 EVERY rank could set it up and its first cycles reproduce the residues of the plain single-GPU engine
+                 (the iterates do not depend on the number of ranks); otherwise all ranks fall back together to
+  halo           the RCCL orchestration of gravo_mg_amd/dist.py: pack -> all_gather_into_tensor -> unpack per colour
+  allgather      the same with whole colour segments.
+Timing: W untimed cycles, barrier + synchronize, K V-cycles each followed by the residual check, synchronize + barrier,
+MAX over ranks.  Rank 0 prints ONE JSON line."""
 from __future__ import annotations
 
 import json
@@ -32,6 +40,7 @@ def main(args):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # GMG_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that): a functional end-to-end check of the
     # N > 1 path on a 1-GPU box, not a measurement
     backend = os.environ.get("GMG_DIST_BACKEND", "nccl")
@@ -42,132 +51,137 @@ def main(args):
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or args.gpus <= 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    coarse_mode = cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT
 
     workload = f"torus{args.n1}x{args.n2}-poisson-tau1e-6-d1-{args.order}"
     H, mass, lhs, rhs = single.build_workload(args.n1, args.n2, args.order)      # deterministic: every rank builds the same
-    eng = cabi.Engine(device=local, row_align=64 * world, use_graph=False,
-                      coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT)
-    eng.use_hierarchy(H)
-    eng.set_mass(mass)
-    eng.set_system(lhs)
+
+    def new_engine():
+        e = cabi.Engine(device=local, row_align=64 * world, use_graph=False, coarse_mode=coarse_mode)
+        e.use_hierarchy(H); e.set_mass(mass); e.set_system(lhs)
+        return e
+
+    eng = new_engine()
     levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
-    # ---- exchange engine: "p2p" (default) = the cycle is driven inside the library and every exchange is a device-initiated
-    # store into the peers' mailboxes (gmg_p2p_*, no collective call per colour); "halo" / "allgather" = the RCCL
-    # orchestration of gravo_mg_amd/dist.py.  The peer-to-peer path is taken only if EVERY rank could set it up and its first
-    # cycles reproduce the RCCL path's residues; otherwise all ranks fall back together.
-    p2p, p2p_note = None, None
-    want_p2p = args.exchange == "p2p"
-    cpu_group = dist.new_group(backend="gloo") if (world > 1 and want_p2p) else None
-    be = EngineBackend(eng, 1, rank, world, torch.device("cuda", local))
-    halo = None
-    if world > 1 and args.exchange in ("halo", "p2p"):
-        t = time.perf_counter()
-        new2old, cb = eng.level_ordering(0)
-        A = lhs.tocsr()
-        halo = HaloPlan(A.indptr, A.indices, new2old, cb, be.n_pad, world, rank, 1, device=be.device)
-        single.log(f"[bench] rank {rank}: halo plan {halo.published_rows} published rows of {lhs.shape[0]} ({time.perf_counter() - t:.1f}s)")
-    dv = DistVCycle(be, halo=halo)
+    n_warm = max(args.warmup, 2)
+    # what ONE GPU computes (plain engine, same padded layout): the partitioned cycle must reproduce these residues
+    eng.load_problem(rhs, rhs)
+    ref_res = eng.run_cycles(n_warm, 2)
+
+    # ---- peer-to-peer exchange engine
+    p2p, note, exchange_us = None, None, None
+    if args.exchange == "p2p" and world > 1:
+        ok, note = 1, "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
+        cand = None
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+            cand = cabi.P2PCycle(eng, rank, world, 1)
+            blobs = [None] * world
+            dist.all_gather_object(blobs, cand.export(), group=cpu_group)
+            cand.connect(blobs)
+            dist.barrier()
+            cand.load(rhs, rhs)
+            got = cand.cycles(n_warm, 2)
+            if not np.allclose(got, ref_res, rtol=1e-9):
+                ok, note = 0, f"peer-to-peer residues {list(got)} differ from the single-GPU engine's {list(ref_res)}"
+        except Exception as e:          # noqa: BLE001
+            ok, note = 0, f"peer-to-peer set-up failed on rank {rank}: {e!r}"
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            p2p = cand
+            exchange_us = 1e3 * p2p.bench_exchange(200)
+        else:
+            note = note if ok == 0 else "another rank could not set up the peer-to-peer path"
+            single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange ({note})")
+            eng = new_engine()           # the candidate may have left its handle mid-exchange: the fallback starts from a fresh one
+
+    # ---- RCCL orchestration (requested, or the fallback)
+    dv, be, halo = None, None, None
+    if p2p is None:
+        be = EngineBackend(eng, 1, rank, world, torch.device("cuda", local))
+        if world > 1 and args.exchange in ("halo", "p2p"):
+            t = time.perf_counter()
+            new2old, cb = eng.level_ordering(0)
+            A = lhs.tocsr()
+            halo = HaloPlan(A.indptr, A.indices, new2old, cb, be.n_pad, world, rank, 1, device=be.device)
+            single.log(f"[bench] rank {rank}: halo plan {halo.published_rows} published rows of {lhs.shape[0]} ({time.perf_counter() - t:.1f}s)")
+        dv = DistVCycle(be, halo=halo)
 
     def run(k):
+        if p2p is not None:
+            return [float(v) for v in p2p.cycles(k, 2)]
         out = []
         for _ in range(k):
             dv.vcycle()
             out.append(dv.residual_norm(2))
         return out
 
-    be.load(rhs, rhs)
-    warm = run(max(args.warmup, 2))
+    def load():
+        (p2p.load if p2p is not None else be.load)(rhs, rhs)
+
+    load()
+    first = run(n_warm)
+    reproduced = bool(np.allclose(first, ref_res, rtol=1e-9))
+    load()
+    run(args.warmup)
     torch.cuda.synchronize()
-    exchange_us = None
-    if want_p2p and world > 1:
-        ok, note = 1, "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
-        try:
-            eng2 = cabi.Engine(device=local, row_align=64 * world, use_graph=False,
-                               coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT)
-            eng2.use_hierarchy(H); eng2.set_mass(mass); eng2.set_system(lhs)
-            cand = cabi.P2PCycle(eng2, rank, world, 1)
-            blobs = [None] * world
-            dist.all_gather_object(blobs, cand.export(), group=cpu_group)
-            cand.connect(blobs)
-            dist.barrier()
-            cand.load(rhs, rhs)
-            got = cand.cycles(len(warm), 2)
-            if not np.allclose(got, warm, rtol=1e-9):
-                ok, note = 0, f"peer-to-peer residues {list(got)} differ from the RCCL path's {warm}"
-        except Exception as e:          # noqa: BLE001
-            ok, note = 0, f"peer-to-peer set-up failed on rank {rank}: {e!r}"
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            p2p, p2p_note = cand, note
-            exchange_us = 1e3 * p2p.bench_exchange(200)
-        else:
-            p2p_note = note if ok == 0 else "another rank could not set up the peer-to-peer path"
-            single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange ({p2p_note})")
     dist.barrier()
     t0 = time.perf_counter()
-    if p2p is not None:
-        p2p.load(rhs, rhs)
-        p2p.cycles(args.warmup, 2)
-        torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        residues = list(p2p.cycles(args.steps, 2))
-    else:
-        residues = run(args.steps)
+    residues = run(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     t1 = time.perf_counter()
     tmax = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     ms_per_step = 1e3 * float(tmax.item()) / args.steps
-    colls = dv.n_collectives
+    colls_per_cycle = (dv.n_collectives / max(n_warm + args.warmup + args.steps, 1)) if dv is not None else 0
 
-    be.load(rhs, rhs)
+    load()
     t = time.perf_counter()
-    if p2p is not None:
-        p2p.load(rhs, rhs)
-        hist = []
-        while True:
-            hist.append(float(p2p.cycles(1, 2)[0]))
-            if not (hist[-1] > 1e-4 and len(hist) < 100):
-                break
-        iters, res = len(hist), hist[-1]
-    else:
-        iters, res, hist = dv.solve(1e-4, 2, 100)
+    hist = []
+    while True:                               # do { V-cycle; residualCheck } while (res > tol && it < maxIter)   (:1408-1419)
+        hist += run(1)
+        if not (hist[-1] > 1e-4 and len(hist) < 100):
+            break
+    iters, res = len(hist), hist[-1]
     torch.cuda.synchronize()
     solve_ms = 1e3 * (time.perf_counter() - t)
 
     # roofline of the dominant kernel (the fine-level colour sweep, same kernel as on one GPU; measured on the whole level)
     roofline = None
     if rank == 0:
-        sweep_ms, launches = eng.bench_kernel(0, 0, 1, args.kernel_reps)
-        sweep_bytes = eng.algorithmic_bytes(0, 0, 1)
+        probe = eng if p2p is None else new_engine()      # (kernel timing uses the level-0 vectors: not on the live p2p handle)
+        sweep_ms, launches = probe.bench_kernel(0, 0, 1, args.kernel_reps)
+        sweep_bytes = probe.algorithmic_bytes(0, 0, 1)
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
+        traffic, traffic_source = single.load_pmc_traffic(workload)
         roofline = {"bound": "hbm", "kernel": "gmgk::gs_color<1,1> (whole level 0 on one GPU; a rank launches 1/N of it per colour)",
                     "achieved": achieved, "peak": single.HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / single.HBM_PEAK_GBS,
-                    "traffic": single.load_pmc_traffic(workload)[0], "traffic_source": single.load_pmc_traffic(workload)[1], "launch_ms": sweep_ms / launches, "launches_per_sweep": launches}
-    if rank == 0:
+                    "traffic": traffic, "traffic_source": traffic_source, "launch_ms": sweep_ms / launches, "launches_per_sweep": launches}
         n0 = lhs.shape[0]
+        if p2p is not None:
+            partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep ONE exchange "
+                         f"kernel: each rank stores the halo entries its peers read into their mailboxes over xGMI ({int(p2p.stat('halo_rows_published'))} rows "
+                         "published by rank 0) and waits for theirs; r pushed to all peers once per cycle; no collective call in the cycle")
+        elif halo is not None:
+            partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
+                         f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle")
+        else:
+            partition = f"level 0 colour sweeps split {world}-way by rows, everything else replicated; one RCCL all-gather of x per colour sweep"
         out = {
             "metric": "V-cycle wall time (ms per V-cycle incl. residual check) + solve-to-1e-4 iterations, 3M-vertex Poisson",
             "value": ms_per_step, "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
-                       "smoother": f"2+2 sweeps; level 0: multicolour Gauss-Seidel over-relaxed by {eng.gs_omega:g} (row-partitioned); levels >= 1: block-hybrid Gauss-Seidel (replicated)", "coarse_solve": args.coarse, "hipgraph": False,
-                       "partition": (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep ONE exchange kernel: "
-                                     f"each rank stores the halo entries its peers read into their mailboxes over xGMI ({halo.published_rows} rows in all) and waits "
-                                     "for theirs; r pushed to all peers once per cycle; no collective call in the cycle" if p2p is not None else
-                                     f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
-                                     f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle"
-                                     if halo is not None else
-                                     f"level 0 colour sweeps split {world}-way by rows, everything else replicated; one RCCL all-gather of x per colour sweep"),
-                       "tolerance": 1e-4, "stopping_criteria": 2},
-            "iterations_to_1e-4": iters, "residue": res, "solve_ms": solve_ms,
-            "exchange": ("p2p" if p2p is not None else args.exchange if args.exchange != "p2p" else "halo (fallback)"), "exchange_note": p2p_note,
-            "exchange_us": exchange_us,
-            "collectives_per_cycle": (0 if p2p is not None else colls / max(args.steps + max(args.warmup, 2), 1)), "collective_backend": backend,
-            "residues_to_1e-4": [float(v) for v in hist],
+                       "smoother": f"2+2 sweeps; level 0: multicolour Gauss-Seidel over-relaxed by {eng.gs_omega:g} (row-partitioned); levels >= 1: "
+                                   "block-hybrid Gauss-Seidel (replicated)",
+                       "coarse_solve": args.coarse, "hipgraph": False, "partition": partition, "tolerance": 1e-4, "stopping_criteria": 2},
+            "iterations_to_1e-4": iters, "residue": res, "residues_to_1e-4": [float(v) for v in hist], "solve_ms": solve_ms,
+            "exchange": "p2p" if p2p is not None else ("none (one rank)" if world == 1 else args.exchange if args.exchange != "p2p" else "halo (fallback)"),
+            "exchange_note": note, "exchange_us": exchange_us, "single_gpu_residues_reproduced": reproduced,
+            "collectives_per_cycle": colls_per_cycle, "collective_backend": backend,
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
             "timed_residues_tail": [float(r) for r in residues[-3:]],
             "roofline": roofline, "cpu_baseline": None,
