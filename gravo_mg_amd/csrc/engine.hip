@@ -77,6 +77,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->host_threads = 0;
     cfg->verbose = 0;
     cfg->block_ep = 1;
+    cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
                               // problem at the same cost per cycle; centre of the 1.3 - 1.4 plateau on six workloads
     return GMG_OK;
@@ -92,7 +93,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     if (!out) return GMG_ERR_INVALID;
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
-    if (c.sigma < 0 || c.sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
+    if (c.sigma < 0 || c.sigma % 64 || c.restrict_sigma < 0 || c.restrict_sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
         c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
@@ -488,7 +489,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             Level& lk = h->lv[k];
             Compressed Urows = transpose_parallel(h->U[k]);                            // outer = fine rows
             stage[k].sp = build_transfer_sell(Urows, lk.ord, h->lv[k + 1].ord, 0);
-            stage[k].sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, lk.ord, h->cfg.sigma > 0 ? h->cfg.sigma : 0,
+            stage[k].sr = build_transfer_sell(h->U[k], h->lv[k + 1].ord, lk.ord, h->cfg.restrict_sigma > 0 ? h->cfg.restrict_sigma : 0,
                                               h->cfg.block_lanes == 1 ? 1 : 4);       // outer = coarse rows (~18 entries each)
             stage[k].ms_sell += ms_since(t);
         });

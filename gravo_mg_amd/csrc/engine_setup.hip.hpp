@@ -358,7 +358,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     // restriction: rows = coarse points (columns of the CSC U), sorted by length inside windows like the host planner
     {
         const Compressed& U = h->U[k];
-        const int np = c.n_pad, sigma = h->cfg.sigma;
+        const int np = c.n_pad, sigma = h->cfg.restrict_sigma;
         if (sigma > 0 && sigma <= gmgs::kWindowSortMax) {
             int pow2 = 1;
             while (pow2 < sigma) pow2 <<= 1;

@@ -84,6 +84,10 @@ typedef struct {
                               (see gmg_config_default) because the colour ordering smooths a little less per sweep than the
                               reference's lexicographic one (V-cycles to 1e-4 on the 3 M Poisson problem).
                               Must lie in (0, 2): SOR converges for every symmetric positive definite system in that range. */
+    int restrict_sigma;    /* length-sorting window (rows) of the restriction operators U_k^T (multiple of 64; 0 = no sorting; default 64).
+                              Separate from `sigma`: sorting coarse rows by length across wide windows scatters neighbouring rows
+                              (their children are neighbours in the fine vector) and adds an output-row indirection -- 39.5 us with
+                              1024-row windows, 31.1 us with 64-row windows on the 3 M-vertex level (profiles/README.md) */
     int block_ep;          /* 1 (default): big blocked levels (one lane per row, 64-row blocks, block_csr = 1) run the entry-parallel
                               block sweep: in-block and off-block operators as unpadded block-ordered CSR, one 64-lane gather per
                               64 ENTRIES instead of one per padded column of the block's longest row; 0: the SELL / block-CSR sweeps */
