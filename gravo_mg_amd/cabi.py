@@ -282,7 +282,7 @@ class Engine:
     """One gmg_handle: device-resident hierarchy + V-cycle on one HIP stream."""
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
-                 coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=1024, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
+                 coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
                  device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None):
         l = lib()
         cfg = GmgConfig()

@@ -64,7 +64,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->post_iters = 2;
     cfg->coarse_mode = GMG_COARSE_HOST_LDLT;
     cfg->use_graph = 0;      // measured: the cycle is not launch-bound (eager == graph per cycle) and instantiating costs ~5 ms per system
-    cfg->sigma = 1024;
+    cfg->sigma = 0;          // measured: no length sorting inside colour classes beats every window size (irregular meshes; profiles/README.md)
     cfg->row_align = 64;
     cfg->block_rows = 64;
     cfg->block_from_level = 1;

@@ -20,8 +20,8 @@ def _engines(cabi, P, **kw):
 
 @pytest.mark.parametrize("case", ["torus-L3", "random-order", "pointcloud", "smoothing", "bilaplacian"])
 @pytest.mark.parametrize("kw", [dict(), dict(block_lanes=1, block_rows=256), dict(block_lanes=4, block_rows=128), dict(block_rows=0),
-                                dict(block_from_level=0), dict(sigma=0), dict(reorder_fine=1), dict(block_lanes=1), dict(block_lanes=1, block_ep=0), dict(block_lanes=1, block_csr=0)],
-                         ids=["default", "lane1", "quad128", "exact", "blocked-all", "nosort", "cluster-reorder", "entry-parallel", "block-csr", "lane1-sell64"])
+                                dict(block_from_level=0), dict(sigma=1024, restrict_sigma=1024), dict(reorder_fine=1), dict(block_lanes=1), dict(block_lanes=1, block_ep=0), dict(block_lanes=1, block_csr=0)],
+                         ids=["default", "lane1", "quad128", "exact", "blocked-all", "sorted-windows", "cluster-reorder", "entry-parallel", "block-csr", "lane1-sell64"])
 def test_device_layout_equals_host_layout(cabi, case, kw):
     P = {"torus-L3": lambda: problems.torus_problem(96, 80, "poisson", 30),
          "random-order": lambda: problems.torus_problem(48, 40, "poisson", 40, order="random"),
