@@ -387,6 +387,12 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
         }
     }
     __syncthreads();
+    if (PASS == 0) {               // counting pass: the number of occupied slots is all that is needed -- no sort (2.4 -> 1.25 ms on level 1)
+        for (int s = lane; s < kRapSet; s += 64) cnt += keys[s] != 0x7fffffff;
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) c_cnt[p] = cnt;
+        return;
+    }
     // ---- bitonic sort of the 256 slots (empty = INT_MAX sorts to the end)
     for (int k = 2; k <= kRapSet; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -402,10 +408,6 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
         }
     for (int s = lane; s < kRapSet; s += 64) cnt += keys[s] != 0x7fffffff;
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    }
-    if (PASS == 0) {
-        if (lane == 0) c_cnt[p] = cnt;
-        return;
     }
     // ---- step 2: numeric.  Every lane owns up to 4 output columns (cnt <= 256).  The triples of a chunk of children
     // are first gathered IN PARALLEL into LDS as (q, (u_ip a_ij) * u_jq) in the host's walk order -- slot of (child,

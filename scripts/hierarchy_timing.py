@@ -1,6 +1,6 @@
 """Phases of the host hierarchy builder on the bench mesh (the reference's hierarchyTiming keys)."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gravo_mg_amd import cabi, meshgen
 order = sys.argv[1] if len(sys.argv) > 1 else "natural"
 V, F = meshgen.torus_mesh(1732, 1732, order=order)
