@@ -393,21 +393,42 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
         if (lane == 0) c_cnt[p] = cnt;
         return;
     }
-    // ---- bitonic sort of the 256 slots (empty = INT_MAX sorts to the end)
-    for (int k = 2; k <= kRapSet; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int idx = lane; idx < kRapSet; idx += 64) {
-                const int partner = idx ^ j;
-                if (partner > idx) {
-                    const int a = keys[idx], b = keys[partner];
-                    const bool up = (idx & k) == 0;
-                    if ((a > b) == up) { keys[idx] = b; keys[partner] = a; }
-                }
-            }
-            __syncthreads();
+    // ---- compact the occupied slots to the front (ballot ranks), then bitonic-sort only the next power of two >= their number
+    // (a coarse row has ~21 distinct columns: a 32-element sort instead of the 256-slot one)
+    {
+        int kk[kRapSet / 64];
+        int base = 0;
+#pragma unroll
+        for (int g = 0; g < kRapSet / 64; ++g) kk[g] = keys[g * 64 + lane];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < kRapSet / 64; ++g) {
+            const bool occ = kk[g] != 0x7fffffff;
+            const unsigned long long m = __ballot(occ);
+            if (occ) keys[base + __popcll(m & ((1ull << lane) - 1ull))] = kk[g];
+            base += __popcll(m);
         }
-    for (int s = lane; s < kRapSet; s += 64) cnt += keys[s] != 0x7fffffff;
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        cnt = base;
+        int n2 = 2;
+        while (n2 < cnt) n2 <<= 1;
+        __syncthreads();
+        for (int s = cnt + lane; s < n2; s += 64) keys[s] = 0x7fffffff;
+        __syncthreads();
+        for (int k = 2; k <= n2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int idx = lane; idx < n2; idx += 64) {
+                    const int partner = idx ^ j;
+                    if (partner > idx) {
+                        const int a = keys[idx], b = keys[partner];
+                        const bool up = (idx & k) == 0;
+                        if ((a > b) == up) { keys[idx] = b; keys[partner] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int s = n2 + lane; s < kRapSet; s += 64) keys[s] = 0x7fffffff;       // (the numeric step reads keys[g * 64 + lane] only below cnt)
+        __syncthreads();
+    }
     }
     // ---- step 2: numeric.  Every lane owns up to 4 output columns (cnt <= 256).  The triples of a chunk of children
     // are first gathered IN PARALLEL into LDS as (q, (u_ip a_ij) * u_jq) in the host's walk order -- slot of (child,
