@@ -1459,6 +1459,17 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
     std::vector<double> w((size_t)n * d);
     f.solve_multi(b, (size_t)n, x, (size_t)n, d, w.data());
     if (factor_nnz) *factor_nnz = f.factor_nnz();
+    if (const char* reps_env = std::getenv("GMG_LDLT_BENCH")) {        // back-substitution time of the coarsest-level solver (host measurement aid)
+        const int reps = std::max(1, std::atoi(reps_env));
+        std::vector<double> xb((size_t)n);
+        double best = 1e30;
+        for (int batch = 0; batch < 20; ++batch) {                     // minimum over batches: the host may be shared
+            auto t0 = clk::now();
+            for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, xb.data(), (size_t)n, 1, w.data());
+            best = std::min(best, 1e3 * ms_since(t0) / reps);
+        }
+        std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve (best of 20 batches of %d)\n", n, f.factor_nnz(), best, reps);
+    }
     if (std::getenv("GMG_LDLT_CROSSCHECK")) {
         SparseLDLT g;
         if (!g.factor(A)) return GMG_ERR_NUMERIC;

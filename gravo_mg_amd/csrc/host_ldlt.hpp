@@ -535,43 +535,95 @@ private:
         for (; i < m; ++i) s0 += a[i] * b[i];                                                                                    \
         return (s0 + s1) + (s2 + s3);                                                                                            \
     }                                                                                                                            \
-    /* one right-hand side: forward step of a supernode, ys <- L_d^-1 ys (unit lower, w x w), t = L_b ys (r) */                  \
+    /* one right-hand side: forward step of a supernode, ys <- L_d^-1 ys (unit lower, w x w), t = L_b ys (r).  The rectangular   \
+       part takes FOUR columns of the panel per pass over t (one load and one store of t[i] per four columns instead of per      \
+       column); every t[i] still accumulates its columns one after the other in column order -- the results are those of the     \
+       one-column-per-pass loop, bit for bit */                                                                                   \
     ATTR static void sn_forward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, double* t) {                        \
         for (int j = 0; j < w; ++j) {                                                                                            \
             const double* cj = P + (size_t)j * ld;                                                                               \
             const double yj = ys[j];                                                                                             \
             for (int i = j + 1; i < w; ++i) ys[i] -= cj[i] * yj;                                                                 \
         }                                                                                                                        \
-        for (int i = 0; i < r; ++i) t[i] = 0.0;                                                                                  \
-        for (int j = 0; j < w; ++j) {                                                                                            \
+        int j = 0;                                                                                                               \
+        if (w >= 8) {                                                                                                            \
+            const double *c0 = P + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld, *c4 = c3 + ld, *c5 = c4 + ld, *c6 = c5 + ld, *c7 = c6 + ld; \
+            const double y0 = ys[0], y1 = ys[1], y2 = ys[2], y3 = ys[3], y4 = ys[4], y5 = ys[5], y6 = ys[6], y7 = ys[7];        \
+            for (int i = 0; i < r; ++i)                                                                                          \
+                t[i] = (((((((0.0 + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3) + c4[i] * y4) + c5[i] * y5) + c6[i] * y6) + c7[i] * y7; \
+            j = 8;                                                                                                               \
+        } else if (w >= 4) {                                                                                                     \
+            const double *c0 = P + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;                                               \
+            const double y0 = ys[0], y1 = ys[1], y2 = ys[2], y3 = ys[3];                                                         \
+            for (int i = 0; i < r; ++i) t[i] = (((0.0 + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3;                      \
+            j = 4;                                                                                                               \
+        } else {                                                                                                                 \
+            for (int i = 0; i < r; ++i) t[i] = 0.0;                                                                              \
+        }                                                                                                                        \
+        for (; j + 8 <= w; j += 8) {                                                                                             \
+            const double *c0 = P + (size_t)j * ld + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld, *c4 = c3 + ld, *c5 = c4 + ld, *c6 = c5 + ld, *c7 = c6 + ld; \
+            const double y0 = ys[j], y1 = ys[j + 1], y2 = ys[j + 2], y3 = ys[j + 3], y4 = ys[j + 4], y5 = ys[j + 5], y6 = ys[j + 6], y7 = ys[j + 7]; \
+            for (int i = 0; i < r; ++i)                                                                                          \
+                t[i] = (((((((t[i] + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3) + c4[i] * y4) + c5[i] * y5) + c6[i] * y6) + c7[i] * y7; \
+        }                                                                                                                        \
+        for (; j + 4 <= w; j += 4) {                                                                                             \
+            const double *c0 = P + (size_t)j * ld + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;                              \
+            const double y0 = ys[j], y1 = ys[j + 1], y2 = ys[j + 2], y3 = ys[j + 3];                                             \
+            for (int i = 0; i < r; ++i) t[i] = (((t[i] + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3;                     \
+        }                                                                                                                        \
+        for (; j < w; ++j) {                                                                                                     \
             const double* cb = P + (size_t)j * ld + w;                                                                           \
             const double yj = ys[j];                                                                                             \
             for (int i = 0; i < r; ++i) t[i] += cb[i] * yj;                                                                      \
         }                                                                                                                        \
     }                                                                                                                            \
-    /* ... and its backward step: ys <- L_d^-T (ys - L_b^T t) */                                                                 \
+    /* ... and its backward step: ys <- L_d^-T (ys - L_b^T t).  The r-long dot products of four columns share one pass over t;  \
+       each keeps the four interleaved partial sums of dot4 (same association, same bits) */                                     \
     ATTR static void sn_backward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, const double* t) {                 \
-        for (int j = w - 1; j >= 0; --j) {                                                                                       \
+        double bt[kMaxWidth];                                                                                                    \
+        int j = 0;                                                                                                               \
+        for (; j + 4 <= w; j += 4) {                                                                                             \
+            const double *c0 = P + (size_t)j * ld + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;                              \
+            double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};                        \
+            int i = 0;                                                                                                           \
+            for (; i + 4 <= r; i += 4)                                                                                           \
+                for (int k = 0; k < 4; ++k) {                                                                                    \
+                    const double tv = t[i + k];                                                                                  \
+                    a0[k] += c0[i + k] * tv; a1[k] += c1[i + k] * tv; a2[k] += c2[i + k] * tv; a3[k] += c3[i + k] * tv;          \
+                }                                                                                                                \
+            for (; i < r; ++i) { const double tv = t[i]; a0[0] += c0[i] * tv; a1[0] += c1[i] * tv; a2[0] += c2[i] * tv; a3[0] += c3[i] * tv; } \
+            bt[j] = (a0[0] + a0[1]) + (a0[2] + a0[3]); bt[j + 1] = (a1[0] + a1[1]) + (a1[2] + a1[3]);                            \
+            bt[j + 2] = (a2[0] + a2[1]) + (a2[2] + a2[3]); bt[j + 3] = (a3[0] + a3[1]) + (a3[2] + a3[3]);                        \
+        }                                                                                                                        \
+        for (; j < w; ++j) bt[j] = dot4##SUFFIX(P + (size_t)j * ld + w, t, r);                                                   \
+        for (j = w - 1; j >= 0; --j) {                                                                                           \
             const double* cj = P + (size_t)j * ld;                                                                               \
-            ys[j] -= dot4##SUFFIX(cj + w, t, r) + dot4##SUFFIX(cj + j + 1, ys + j + 1, w - 1 - j);                               \
+            ys[j] -= bt[j] + dot4##SUFFIX(cj + j + 1, ys + j + 1, w - 1 - j);                                                    \
         }                                                                                                                        \
     }
     GMG_LDLT_KERNELS(_base, )
     // (this header is host-only code, but engine.hip is also parsed by hipcc's device pass, which knows no x86 features)
 #if defined(__HIP_DEVICE_COMPILE__)
     GMG_LDLT_KERNELS(_avx2, )
+    GMG_LDLT_KERNELS(_avx512, )
     static bool has_avx2() { return false; }
+    static bool has_avx512() { return false; }
 #else
     GMG_LDLT_KERNELS(_avx2, __attribute__((target("avx2,fma"))))
+    GMG_LDLT_KERNELS(_avx512, __attribute__((target("avx512f,avx512dq,avx2,fma"))))
     static bool has_avx2() {
         static const bool v = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"); }();
+        return v;
+    }
+    static bool has_avx512() {
+        static const bool v = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && std::getenv("GMG_NO_AVX512") == nullptr; }();
         return v;
     }
 #endif
 #undef GMG_LDLT_KERNELS
 
     void solve_column(const double* b, double* x, double* y, double* t) const {
-        const bool avx = has_avx2();
+        const bool avx = has_avx2(), avx512 = has_avx512();      // (same source, same order of operations: the three builds give the same bits)
         for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
         for (int s = 0; s < ns_; ++s) {                          // forward: L z = y
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
