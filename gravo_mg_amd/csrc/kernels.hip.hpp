@@ -675,31 +675,45 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
     }
 }
 
-// out[c] = sum over blocks of partials[block][c], c < ncomp.  One block of kReduceBlock threads, fixed order.
+// out[c] = sum over blocks of partials[block][c], c < ncomp <= kReduceMaxComp.  One block of kReduceBlock threads, fixed order
+// (thread-strided sums, wave shuffles, then the 16 wave sums in index order): one pass over the partials and one barrier.
 constexpr int kReduceBlock = 1024;
+constexpr int kReduceMaxComp = 8;
 __device__ __forceinline__ void block_reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp, double* __restrict__ out,
-                                                      double* red) {
-    for (int c = 0; c < ncomp; ++c) {
-        double v = 0.0;
-        for (int i = threadIdx.x; i < n_blocks; i += kReduceBlock) v += partials[(int64_t)i * ncomp + c];
-        red[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = kReduceBlock / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[c] = red[0];
-        __syncthreads();
+                                                      double (*red)[kReduceMaxComp]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double v[kReduceMaxComp];
+#pragma unroll
+    for (int c = 0; c < kReduceMaxComp; ++c) v[c] = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += kReduceBlock)
+#pragma unroll
+        for (int c = 0; c < kReduceMaxComp; ++c)
+            if (c < ncomp) v[c] += partials[(int64_t)i * ncomp + c];
+#pragma unroll
+    for (int c = 0; c < kReduceMaxComp; ++c) {
+        if (c >= ncomp) break;
+        double t = v[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0) red[wave][c] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ncomp) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kReduceBlock / 64; ++w) t += red[w][threadIdx.x];
+        out[threadIdx.x] = t;
     }
 }
 
 // flag != nullptr: `out` is host-visible pinned memory and `seq` is published in *flag after the sums -- the host polls
-// that word instead of paying a copy kernel and a stream synchronisation per residual check.
+// that word instead of paying a copy kernel and a stream synchronisation per residual check.  (The sums are written by the
+// threads of wave 0; lane 0 of that wave releases them: one system-scope fence, not one per thread.)
 __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
                                                                 double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
-    __shared__ double red[kReduceBlock];
+    __shared__ double red[kReduceBlock / 64][kReduceMaxComp];
     block_reduce_partials(partials, n_blocks, ncomp, out, red);
-    if (flag) {
+    if (flag && threadIdx.x < 64) {
         __threadfence_system();
         if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
