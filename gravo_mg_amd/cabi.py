@@ -42,7 +42,7 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int),
     ]
 
 
@@ -110,6 +110,7 @@ SIGNATURES = {
     "gmg_p2p_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "gmg_p2p_fetch": (C.c_int, [_vp, _dp]),
     "gmg_p2p_bench_exchange": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
@@ -283,7 +284,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -299,6 +300,8 @@ class Engine:
             cfg.block_ep = int(bool(block_ep))
         if restrict_sigma is not None:
             cfg.restrict_sigma = int(restrict_sigma)
+        if dist_shard_levels is not None:
+            cfg.dist_shard_levels = int(dist_shard_levels)
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -580,6 +583,13 @@ class P2PCycle:
     def bench_exchange(self, reps: int = 100) -> float:
         out = C.c_double()
         self.eng._chk(lib().gmg_p2p_bench_exchange(self.eng._h, int(reps), C.byref(out)))
+        return out.value
+
+    def bench_kind(self, kind: str, reps: int = 100) -> float:
+        """ms per exchange of the named kind ("color<k>", "halo_all", "rows0", "x1_halo", "rows1", "r0_halo"); collective;
+        overwrites halo entries (load() afterwards)."""
+        out = C.c_double()
+        self.eng._chk(lib().gmg_p2p_bench_kind(self.eng._h, kind.encode(), int(reps), C.byref(out)))
         return out.value
 
     def stat(self, key: str) -> float:

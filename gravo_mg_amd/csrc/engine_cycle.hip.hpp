@@ -83,6 +83,47 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
 }
 
 // block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
+// One block-hybrid sweep in -> out over blocks [b0, b0 + nb) of a blocked level (in == nullptr: the iterate is the zero vector).
+// The kernels find their rows through blk_begin[block]: a sub-range is the same launch on offset block tables.
+template <class T>
+void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out, int b0, int nb, const int* begin_table = nullptr,
+                              const int* ncolors_table = nullptr) {
+    const int ld = l.n_pad;
+    const T* b = Prec<T>::b(l);
+    // (begin_table / ncolors_table: an explicit list of nb blocks instead of a range -- entry-parallel sweep only, which reads
+    // nothing but the first row of its block from the table)
+    const int* blk_begin = begin_table ? begin_table : l.d_blk_begin + b0;
+    const int* blk_ncolors = ncolors_table ? ncolors_table : l.d_blk_ncolors + b0;
+    if (nb <= 0) return;
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        if (l.use_ep) {
+            const int grid = (nb + 7) / 8 * 8;          // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, grid)
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64),
+                                              (size_t)D * 64 * sizeof(T) + std::max((size_t)l.ep_cap_e * sizeof(T), (size_t)l.ep_cap_l * (sizeof(T) + 2)), h->stream,
+                                              blk_begin, blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
+                                              Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb));
+        } else if (l.use_bcsr && d > 1) {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
+                                              (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, blk_begin,
+                                              blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.bc_ptr, l.bc_col,
+                                              Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr), out + (size_t)c0 * ld,
+                                              ld, l.bc_cap));
+        } else if (l.Ain.lpr == 4) {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, blk_begin,
+                                              blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
+                                              l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                              out + (size_t)c0 * ld, ld));
+        } else {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, blk_begin,
+                                              blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
+                                              l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                              out + (size_t)c0 * ld, ld));
+        }
+    }
+}
+
 template <class T>
 void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zero = false) {
     const int ld = l.n_pad;
@@ -91,35 +132,8 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
     // first sweep gets no input vector -- it neither reads x nor gathers the off-block couplings (all zero) -- and the
     // caller skips the memset
     T* in = from_zero ? nullptr : Prec<T>::x(l); T* out = Prec<T>::tmp(l);
-    const T* b = Prec<T>::b(l);
     for (int it = 0; it < iters; ++it) {
-        for (int c0 = 0; c0 < d; c0 += 4) {
-            int dc = std::min(4, d - c0);
-            if (l.use_ep) {
-                const int grid = (nb + 7) / 8 * 8;          // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, grid)
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64),
-                                                  (size_t)D * 64 * sizeof(T) + std::max((size_t)l.ep_cap_e * sizeof(T), (size_t)l.ep_cap_l * (sizeof(T) + 2)), h->stream,
-                                                  l.d_blk_begin, l.d_blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
-                                                  Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                                  out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb));
-            } else if (l.use_bcsr && d > 1) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
-                                                  (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.bc_ptr, l.bc_col,
-                                                  Prec<T>::bcval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr), out + (size_t)c0 * ld,
-                                                  ld, l.bc_cap));
-            } else if (l.Ain.lpr == 4) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
-                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                                  out + (size_t)c0 * ld, ld));
-            } else {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(h->cfg.block_rows), 0, h->stream, l.d_blk_begin,
-                                                  l.d_blk_ncolors, l.d_row_color, l.Ain.slice_ptr, l.ain_col16, Prec<T>::val(l.Ain), l.Aout.slice_ptr,
-                                                  l.Aout.col, Prec<T>::val(l.Aout), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                                  out + (size_t)c0 * ld, ld));
-            }
-        }
+        launch_block_sweep_range<T>(h, l, d, in, out, 0, nb);
         if (it == 0 && from_zero) { in = out; out = Prec<T>::x(l); }      // the result of sweep 1 is in tmp; ping-pong from there
         else std::swap(in, out);
     }

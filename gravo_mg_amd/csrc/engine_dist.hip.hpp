@@ -1,17 +1,24 @@
 // engine_dist.hip.hpp -- part of libgravomg_hip.so's single translation unit (included by engine.hip after engine_cycle).
-// Multi-GPU V-cycle driven by the ENGINE (one process per GPU): level 0 row-partitioned per colour, levels >= 1 replicated,
-// and every exchange a device-initiated store into the peer's mailbox (kernels.hip.hpp::p2p_exchange) -- no collective-library
-// call and no Python between the launches of a cycle.  gravo_mg_amd/dist.py keeps the RCCL orchestration of the same cycle
+// Multi-GPU V-cycle driven by the ENGINE (one process per GPU): level 0 row-partitioned per colour, level 1 partitioned by
+// blocks (cfg.dist_shard_levels >= 2; levels below it replicated), and every exchange a device-initiated store into the peer's
+// mailbox (kernels.hip.hpp::p2p_exchange) -- no collective-library call and no Python between the launches of a cycle.  gravo_mg_amd/dist.py keeps the RCCL orchestration of the same cycle
 // (torch.distributed all-gathers), which remains the fallback and the reference for the tests.
 //
 // Partition (BASELINE.json north_star): the device numbering of level 0 is colour-major, every colour class is
 // padded to 64 * world rows and cut into `world` equal contiguous pieces; rank p owns piece p of every colour.  What moves:
 //   * after every colour of every sweep: the entries of x this rank just updated that rows of ANOTHER rank read (the halo of
 //     that colour; a few thousand values at 3 M vertices) -- per peer, only what that peer reads;
-//   * once per cycle: this rank's rows of the residual, to every peer (the replicated coarse part restricts the whole r);
+//   * once per cycle: the entries of the residual r0 that the restriction rows of another rank read (level 1 partitioned), or
+//     this rank's rows of r0 to every peer (level 1 replicated: the coarse part restricts the whole r);
 //   * after the prolongation: the halo of all colours at once;
 //   * per residual check: 2 d partial sums, added in rank order on every rank (same bits everywhere).
-// The iterates are those of the single-GPU multicolour sweep: bitwise independent of the number of ranks.
+// Level 1 (block-hybrid Gauss-Seidel: exact inside a 64-row block, couplings to other blocks taken from the previous sweep) is
+// partitioned by blocks: a block goes to the rank that owns most of the fine rows its points prolong into, so that the two
+// partitions cover the same part of the mesh and the transfers between them stay local.  A sweep reads the previous iterate at
+// its off-block columns, so ONE exchange per sweep
+// (the x1 entries other ranks' rows -- or their prolongation rows -- read) keeps it exact; the residual r1 is completed on every
+// rank (its rows to all peers: 8 n1 / world bytes per link) for the replicated levels below.
+// The iterates are those of the single-GPU engine: bitwise independent of the number of ranks.
 #pragma once
 
 struct P2PPeer {
@@ -27,7 +34,16 @@ struct gmg_p2p_blob {                                     // what a rank publish
 
 struct DistP2P {
     bool planned = false, connected = false;
-    int rank = 0, world = 1, d = 0, nk = 0;               // nk = exchange kinds: colours 0..C-1, C = halo of all colours, C+1 = residual rows, C+2 = norm sums
+    int rank = 0, world = 1, d = 0, nk = 0;               // nk = exchange kinds: colours 0..C-1, C = halo of all colours, C+1 = level-0 rows, C+2 = norm sums,
+                                                          // C+3 = x1 halo, C+4 = level-1 rows, C+5 = r0 halo of the restriction (the last three: level 1 partitioned)
+    bool shard1 = false;
+    std::vector<int> blk_owner;                           // [block of level 1] -> rank
+    std::vector<std::vector<int>> own_blocks;             // [rank]: its blocks, ascending (block b = device rows 64 b .. 64 b + 63)
+    int* d_l1 = nullptr;                                  // this rank's launch tables, one allocation:
+    int *d_own_begin = nullptr, *d_own_ncolors = nullptr; //   first row / colour count of its blocks (the block sweep's tables)
+    int *d_rsl = nullptr, *d_asl = nullptr, *d_psl = nullptr;   //   slices of U0^T, of A1 and of U1 that hold its rows
+    int n_rsl = 0, n_asl = 0, n_psl = 0;
+    std::vector<std::vector<int>> halo1, halo0r;          // [s * world + t]: x1 entries / r0 entries rank s publishes to rank t, ascending
     // plan: rows (device numbering of level 0) rank s publishes to rank t for halo kind k, ascending
     std::vector<std::vector<int>> halo;                   // [(s * world + t) * (C + 1) + k]
     std::vector<int> own_lo, own_cnt;                     // [colour]: this partition's piece of a colour (same count on every rank)
@@ -40,6 +56,8 @@ struct DistP2P {
     int* d_idx = nullptr;                                 // all index lists, concatenated
     gmgk::P2POp* d_ops = nullptr;                         // [(kind * 2 + parity) * n_peers + j]
     int* d_err = nullptr;
+    unsigned int* d_done = nullptr;                       // push blocks finished, per peer (multi-block exchanges)
+    std::vector<int> kind_blocks;                         // [kind]: blocks per peer and direction of its exchange kernel
     double* d_sums = nullptr;                             // 2 d partial sums of this rank / the reduced sums
     std::vector<unsigned long long> kind_count;           // exchanges done per kind (parity = count & 1)
     unsigned long long seq = 0;                           // exchanges done in all (the arrival counters carry it)
@@ -67,21 +85,32 @@ void p2p_release(gmg_handle h) {
     if (p->d_idx) (void)hipFree(p->d_idx);
     if (p->d_ops) (void)hipFree(p->d_ops);
     if (p->d_err) (void)hipFree(p->d_err);
+    if (p->d_done) (void)hipFree(p->d_done);
     if (p->d_sums) (void)hipFree(p->d_sums);
+    if (p->d_l1) (void)hipFree(p->d_l1);
     delete p;
     h->p2p = nullptr;
 }
 
-// One exchange of kind `kind` on vector `vec` (level-0 layout) -- or nothing with a single rank.
-int p2p_exchange(gmg_handle h, int kind, double* vec) {
+// One exchange of kind `kind` on vector `vec` (leading dimension ld) -- or nothing with a single rank.
+int p2p_exchange(gmg_handle h, int kind, double* vec, int ld) {
     DistP2P* p = h->p2p;
     const int np = (int)p->peers.size();
     if (np == 0) return GMG_OK;
     const int parity = (int)(p->kind_count[kind]++ & 1);
     ++p->seq;
-    hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np), dim3(256), 0, h->stream, p->d_ops + (size_t)(kind * 2 + parity) * np, np, vec, h->lv[0].n_pad, p->d,
-                       p->seq, p->d_err);
+    const int B = p->kind_blocks[kind];
+    hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np * B), dim3(256), 0, h->stream, p->d_ops + (size_t)(kind * 2 + parity) * np, np, vec, ld, p->d,
+                       p->seq, p->d_err, B, p->d_done);
     return GMG_OK;
+}
+
+// the index list rank s publishes to rank t for exchange kind k (null: the kind has no list)
+const std::vector<int>* p2p_list(const DistP2P* p, int C, int s, int t, int k) {
+    if (k <= C) return &p->halo[((size_t)s * p->world + t) * (C + 1) + k];
+    if (k == C + 3 && p->shard1) return &p->halo1[(size_t)s * p->world + t];
+    if (k == C + 5 && p->shard1) return &p->halo0r[(size_t)s * p->world + t];
+    return nullptr;
 }
 
 }  // namespace
@@ -107,12 +136,23 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     Level& l = h->lv[0];
     const LevelOrdering& o = l.ord;
     const int C = o.n_colors;
-    p->nk = C + 3;
+    p->nk = C + 6;
     p->kind_count.assign(p->nk, 0);
     p->own_lo.resize(C); p->own_cnt.resize(C);
     for (int c = 0; c < C; ++c) { p->own_cnt[c] = (o.color_begin[c + 1] - o.color_begin[c]) / world; p->own_lo[c] = o.color_begin[c] + rank * p->own_cnt[c]; }
+    // level 1 is partitioned too when it runs the entry-parallel block sweep (big levels: 64-row blocks, block b = rows 64 b ..) with
+    // replicated levels below it, and the restriction's sorting windows do not straddle blocks
+    p->shard1 = world > 1 && h->cfg.dist_shard_levels >= 2 && h->L >= 2 && h->lv[1].ord.blocked && h->lv[1].use_ep &&
+                h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS && (h->cfg.restrict_sigma == 0 || h->cfg.restrict_sigma == 64);
+    if (p->shard1) {
+        const LevelOrdering& o1 = h->lv[1].ord;
+        for (int b = 0; b <= o1.n_blocks() && p->shard1; ++b) if (o1.blk_begin[b] != 64 * b) p->shard1 = false;
+    }
     // ---- who reads what: for every row r (owner t) and every entry (r, c) with owner(c) = s != t, s publishes c to t
     p->halo.assign((size_t)world * world * (C + 1), std::vector<int>());
+    p->halo1.assign((size_t)world * world, std::vector<int>());
+    p->halo0r.assign((size_t)world * world, std::vector<int>());
+    auto sort_unique = [](std::vector<int>& v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
     if (world > 1) {
         if ((rc = ensure_host_A(h, 0, false))) return rc;
         const Compressed& A = l.A;
@@ -135,11 +175,65 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
                 if (s == t) continue;
                 std::vector<int> all;
                 for (int w = 0; w < T; ++w) { auto& v = part[w][(size_t)s * world + t]; all.insert(all.end(), v.begin(), v.end()); }
-                std::sort(all.begin(), all.end());
-                all.erase(std::unique(all.begin(), all.end()), all.end());
+                sort_unique(all);
                 for (int c : all) p->halo[((size_t)s * world + t) * (C + 1) + colour[c]].push_back(c);
                 p->halo[((size_t)s * world + t) * (C + 1) + C] = all;
             }
+        if (p->shard1) {
+            Level& l1 = h->lv[1];
+            const LevelOrdering& o1 = l1.ord;
+            const Compressed& U0 = h->U[0];                       // CSC: one column per coarse point, rows = fine points
+            const int nb = o1.n_blocks();
+            // block -> the rank that owns most of the fine rows its points prolong into (ties: the lowest rank)
+            std::vector<int> votes((size_t)nb * world, 0);
+            for (int jc = 0; jc < U0.n_outer; ++jc) {
+                const int blk = o1.old2new[jc] >> 6;
+                for (int q = U0.ptr[jc]; q < U0.ptr[jc + 1]; ++q) ++votes[(size_t)blk * world + owner[o.old2new[U0.idx[q]]]];
+            }
+            p->blk_owner.resize(nb);
+            p->own_blocks.assign(world, std::vector<int>());
+            for (int b = 0; b < nb; ++b) {
+                const int* v = &votes[(size_t)b * world];
+                p->blk_owner[b] = (int)(std::max_element(v, v + world) - v);
+                p->own_blocks[p->blk_owner[b]].push_back(b);
+            }
+            auto owner1 = [&](int row) { return p->blk_owner[row >> 6]; };
+            // x1 entries read through A1 (sweeps, residual) or through U0 (prolongation into another rank's fine rows), and r0 entries
+            // read through U0^T (restriction into another rank's coarse rows)
+            if ((rc = ensure_host_A(h, 1, false))) return rc;
+            const Compressed& A1 = l1.A;
+            for (int i = 0; i < l1.n; ++i) {
+                const int tr = owner1(o1.old2new[i]);
+                for (int q = A1.ptr[i]; q < A1.ptr[i + 1]; ++q) {
+                    const int c = o1.old2new[A1.idx[q]], s = owner1(c);
+                    if (s != tr) p->halo1[(size_t)s * world + tr].push_back(c);
+                }
+            }
+            for (int jc = 0; jc < U0.n_outer; ++jc) {
+                const int c = o1.old2new[jc], s1 = owner1(c);
+                for (int q = U0.ptr[jc]; q < U0.ptr[jc + 1]; ++q) {
+                    const int rf = o.old2new[U0.idx[q]], t0 = owner[rf];
+                    if (t0 == s1) continue;
+                    p->halo1[(size_t)s1 * world + t0].push_back(c);       // rank t0 prolongs into fine row rf: reads x1[c]
+                    p->halo0r[(size_t)t0 * world + s1].push_back(rf);     // rank s1 restricts into coarse row c: reads r0[rf]
+                }
+            }
+            for (auto& v : p->halo1) sort_unique(v);
+            for (auto& v : p->halo0r) sort_unique(v);
+            // this rank's launch tables
+            const std::vector<int>& mine = p->own_blocks[rank];
+            const int rps_r = 64 / l.R.lpr, rps_a = 64 / l1.Aoff.lpr, rps_p = 64 / l1.P.lpr;
+            std::vector<int> tab;
+            for (int b : mine) tab.push_back(o1.blk_begin[b]);
+            for (int b : mine) tab.push_back(o1.blk_ncolors[b]);
+            for (int rps : {rps_r, rps_a, rps_p}) for (int b : mine) for (int q = 0; q < 64 / rps; ++q) tab.push_back(b * (64 / rps) + q);
+            HIPCHK(hipMalloc((void**)&p->d_l1, sizeof(int) * std::max<size_t>(tab.size(), 1)));
+            if (!tab.empty()) HIPCHK(hipMemcpy(p->d_l1, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+            const int nm = (int)mine.size();
+            p->d_own_begin = p->d_l1; p->d_own_ncolors = p->d_l1 + nm;
+            p->n_rsl = nm * (64 / rps_r); p->n_asl = nm * (64 / rps_a); p->n_psl = nm * (64 / rps_p);
+            p->d_rsl = p->d_l1 + 2 * nm; p->d_asl = p->d_rsl + p->n_rsl; p->d_psl = p->d_asl + p->n_asl;
+        }
     }
     // ---- mailbox layout of every rank: region (src, kind, parity) in dst's mailbox
     const long long own_rows = (long long)l.n_pad / world;
@@ -150,10 +244,11 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
         for (int src = 0; src < world; ++src)
             for (int k = 0; k < p->nk; ++k)
                 for (int par = 0; par < 2; ++par) {
-                    long long cnt;
-                    if (k <= C) cnt = src == dst ? 0 : (long long)p->halo[((size_t)src * world + dst) * (C + 1) + k].size() * d;
+                    long long cnt = 0;
+                    if (const std::vector<int>* v = p2p_list(p, C, src, dst, k)) cnt = src == dst ? 0 : (long long)v->size() * d;
                     else if (k == C + 1) cnt = src == dst ? 0 : own_rows * d;
-                    else cnt = 2LL * d;                                   // norm sums: a slot for every source, the own one included
+                    else if (k == C + 2) cnt = 2LL * d;                    // norm sums: a slot for every source, the own one included
+                    else if (k == C + 4 && p->shard1) cnt = src == dst ? 0 : 64LL * (long long)p->own_blocks[src].size() * d;
                     p->box_off[(((size_t)dst * world + src) * p->nk + k) * 2 + par] = off;
                     off += (cnt + 7) / 8 * 8;                             // 64-byte aligned regions
                 }
@@ -168,8 +263,12 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     HIPCHK(hipMalloc((void**)&p->d_sums, sizeof(double) * 4 * d));
     HIPCHK(hipStreamSynchronize(h->stream));
     p->planned = true;
-    p->stats["halo_rows_published"] = 0;
-    for (int t = 0; t < world; ++t) if (t != rank) p->stats["halo_rows_published"] += (double)p->halo[((size_t)rank * world + t) * (C + 1) + C].size();
+    auto published = [&](int k) { double n = 0; for (int t = 0; t < world; ++t) if (t != rank) if (const std::vector<int>* v = p2p_list(p, C, rank, t, k)) n += (double)v->size(); return n; };
+    p->stats["halo_rows_published"] = published(C);
+    p->stats["level1_partitioned"] = p->shard1 ? 1.0 : 0.0;
+    p->stats["x1_halo_rows_published"] = published(C + 3);
+    p->stats["r0_halo_rows_published"] = published(C + 5);
+    p->stats["level1_own_rows"] = p->shard1 ? 64.0 * (double)p->own_blocks[rank].size() : (double)h->lv[std::min(1, h->L)].n_pad;
     return GMG_OK;
 } GMG_CATCH_H
 
@@ -182,6 +281,7 @@ int gmg_p2p_export(gmg_handle h, void* blob_out) try {
     HIPCHK(hipIpcGetMemHandle(&b.mbox, p->mbox));
     HIPCHK(hipIpcGetMemHandle(&b.flags, p->flags));
     b.rank = p->rank; b.world = p->world; b.d = p->d; b.n_pad = h->lv[0].n_pad; b.n_colors = h->lv[0].ord.n_colors; b.mbox_doubles = p->box_total[p->rank];
+    b.reserved = p->shard1 ? 1 : 0;
     std::memcpy(blob_out, &b, sizeof(b));
     return GMG_OK;
 } GMG_CATCH_H
@@ -200,29 +300,50 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
         if (q == rank) continue;
         P2PPeer peer;
         peer.rank = q;
-        if (bl[q].rank != q || bl[q].world != world || bl[q].d != d || bl[q].n_pad != h->lv[0].n_pad || bl[q].n_colors != C || bl[q].mbox_doubles != p->box_total[q])
-            return fail(h, GMG_ERR_INVALID, "peer " + std::to_string(q) + " published a different partition plan (different system / ordering?)");
+        if (bl[q].rank != q || bl[q].world != world || bl[q].d != d || bl[q].n_pad != h->lv[0].n_pad || bl[q].n_colors != C || bl[q].mbox_doubles != p->box_total[q] ||
+            bl[q].reserved != (p->shard1 ? 1 : 0))
+            return fail(h, GMG_ERR_INVALID, "peer " + std::to_string(q) + " published a different partition plan (different system / ordering / configuration?)");
         HIPCHK(hipIpcOpenMemHandle(&peer.mbox_base, bl[q].mbox, hipIpcMemLazyEnablePeerAccess));
         HIPCHK(hipIpcOpenMemHandle(&peer.flag_base, bl[q].flags, hipIpcMemLazyEnablePeerAccess));
         p->peers.push_back(peer);
     }
     const int np = (int)p->peers.size();
     if (np == 0) { p->connected = true; return GMG_OK; }
-    // ---- index lists on the device + one op table per (kind, parity)
+    // ---- all index lists in one device array: per (peer, listed kind) the rows sent and the rows received; then the level-0 rows
+    // of every rank (piece s of every colour, in device order)
     std::vector<int> idx;
-    std::vector<size_t> send_at((size_t)np * (C + 1)), recv_at((size_t)np * (C + 1));
+    std::vector<size_t> send_at((size_t)np * nk, 0), recv_at((size_t)np * nk, 0);
     for (int j = 0; j < np; ++j)
-        for (int k = 0; k <= C; ++k) {
-            const auto& sl = p->halo[((size_t)rank * world + p->peers[j].rank) * (C + 1) + k];
-            const auto& rl = p->halo[((size_t)p->peers[j].rank * world + rank) * (C + 1) + k];
-            send_at[(size_t)j * (C + 1) + k] = idx.size(); idx.insert(idx.end(), sl.begin(), sl.end());
-            recv_at[(size_t)j * (C + 1) + k] = idx.size(); idx.insert(idx.end(), rl.begin(), rl.end());
+        for (int k = 0; k < nk; ++k) {
+            const std::vector<int>* sl = p2p_list(p, C, rank, p->peers[j].rank, k);
+            const std::vector<int>* rl = p2p_list(p, C, p->peers[j].rank, rank, k);
+            if (!sl) continue;
+            send_at[(size_t)j * nk + k] = idx.size(); idx.insert(idx.end(), sl->begin(), sl->end());
+            recv_at[(size_t)j * nk + k] = idx.size(); idx.insert(idx.end(), rl->begin(), rl->end());
+        }
+    const int own_rows = h->lv[0].n_pad / world;
+    const size_t rows_at = idx.size();
+    idx.resize(rows_at + (size_t)world * own_rows);
+    for (int s = 0; s < world; ++s) {
+        size_t at = rows_at + (size_t)s * own_rows;
+        for (int c = 0; c < C; ++c) {
+            const int cnt = (h->lv[0].ord.color_begin[c + 1] - h->lv[0].ord.color_begin[c]) / world, lo = h->lv[0].ord.color_begin[c] + s * cnt;
+            for (int i = 0; i < cnt; ++i) idx[at++] = lo + i;
+        }
+    }
+    // ... and the level-1 rows of every rank (its blocks, ascending)
+    std::vector<size_t> rows1_at(world + 1, idx.size());
+    if (p->shard1)
+        for (int s = 0; s < world; ++s) {
+            rows1_at[s] = idx.size();
+            for (int b : p->own_blocks[s]) for (int i = 0; i < 64; ++i) idx.push_back(64 * b + i);
+            rows1_at[s + 1] = idx.size();
         }
     if (p->d_idx) { (void)hipFree(p->d_idx); p->d_idx = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_idx, sizeof(int) * std::max<size_t>(idx.size(), 1)));
-    if (!idx.empty()) HIPCHK(hipMemcpy(p->d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(p->d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    // ---- one op table per (kind, parity)
     std::vector<gmgk::P2POp> ops((size_t)nk * 2 * np);
-    const int own_rows = h->lv[0].n_pad / world;
     for (int k = 0; k < nk; ++k)
         for (int par = 0; par < 2; ++par)
             for (int j = 0; j < np; ++j) {
@@ -235,46 +356,31 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
                 op.local_box = p->mbox + p->box_off[(((size_t)rank * world + q) * nk + k) * 2 + par];
                 op.local_flag = p->flags + 64 * (size_t)q;
                 op.send_idx = op.recv_idx = nullptr; op.n_send = op.n_recv = 0; op.send_lo = op.recv_lo = 0;
-                if (k <= C) {
-                    op.n_send = (int)p->halo[((size_t)rank * world + q) * (C + 1) + k].size();
-                    op.n_recv = (int)p->halo[((size_t)q * world + rank) * (C + 1) + k].size();
-                    op.send_idx = p->d_idx + send_at[(size_t)j * (C + 1) + k];
-                    op.recv_idx = p->d_idx + recv_at[(size_t)j * (C + 1) + k];
+                if (const std::vector<int>* sl = p2p_list(p, C, rank, q, k)) {
+                    op.n_send = (int)sl->size();
+                    op.n_recv = (int)p2p_list(p, C, q, rank, k)->size();
+                    op.send_idx = p->d_idx + send_at[(size_t)j * nk + k];
+                    op.recv_idx = p->d_idx + recv_at[(size_t)j * nk + k];
                 } else if (k == C + 1) {
-                    // residual rows: the pieces of all colours of a rank are NOT contiguous -> one index-free op per colour would be
-                    // C launches; instead the rows travel in device order of the sender's pieces, described by a generated list
+                    // level-0 rows: the pieces of a rank (one per colour) are not contiguous -> the generated lists
                     op.n_send = own_rows; op.n_recv = own_rows;
+                    op.send_idx = p->d_idx + rows_at + (size_t)rank * own_rows;
+                    op.recv_idx = p->d_idx + rows_at + (size_t)q * own_rows;
+                } else if (k == C + 4 && p->shard1) {
+                    op.n_send = 64 * (int)p->own_blocks[rank].size(); op.n_recv = 64 * (int)p->own_blocks[q].size();
+                    op.send_idx = p->d_idx + rows1_at[rank];
+                    op.recv_idx = p->d_idx + rows1_at[q];
                 }
             }
-    // residual rows need explicit lists too (piece p of every colour): append them
-    {
-        std::vector<int> rows((size_t)world * own_rows);
-        for (int s = 0; s < world; ++s) {
-            size_t at = (size_t)s * own_rows;
-            for (int c = 0; c < C; ++c) {
-                const int cnt = (h->lv[0].ord.color_begin[c + 1] - h->lv[0].ord.color_begin[c]) / world, lo = h->lv[0].ord.color_begin[c] + s * cnt;
-                for (int i = 0; i < cnt; ++i) rows[at++] = lo + i;
-            }
-        }
-        int* d_rows = nullptr;
-        const size_t base = idx.size();
-        HIPCHK(hipMalloc((void**)&d_rows, sizeof(int) * (base + rows.size())));
-        if (base) HIPCHK(hipMemcpy(d_rows, p->d_idx, sizeof(int) * base, hipMemcpyDeviceToDevice));
-        HIPCHK(hipMemcpy(d_rows + base, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice));
-        // re-point the lists at the new array
-        for (auto& op : ops) {
-            if (op.send_idx) op.send_idx = d_rows + (op.send_idx - p->d_idx);
-            if (op.recv_idx) op.recv_idx = d_rows + (op.recv_idx - p->d_idx);
-        }
-        (void)hipFree(p->d_idx);
-        p->d_idx = d_rows;
-        for (int par = 0; par < 2; ++par)
-            for (int j = 0; j < np; ++j) {
-                gmgk::P2POp& op = ops[(size_t)((C + 1) * 2 + par) * np + j];
-                op.send_idx = p->d_idx + base + (size_t)rank * own_rows;
-                op.recv_idx = p->d_idx + base + (size_t)p->peers[j].rank * own_rows;
-            }
+    // blocks per peer and direction: one per 4096 values of the largest transfer of the kind (all ranks derive the same number)
+    p->kind_blocks.assign(nk, 1);
+    for (int k = 0; k < nk; ++k) {
+        long long most = 0;
+        for (int par = 0; par < 1; ++par)
+            for (int j = 0; j < np; ++j) { const gmgk::P2POp& op = ops[(size_t)(k * 2 + par) * np + j]; most = std::max<long long>(most, (long long)std::max(op.n_send, op.n_recv) * d); }
+        p->kind_blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 4095) / 4096));
     }
+    if (!p->d_done) { HIPCHK(hipMalloc((void**)&p->d_done, sizeof(unsigned int) * world)); HIPCHK(hipMemset(p->d_done, 0, sizeof(unsigned int) * world)); }
     if (p->d_ops) { (void)hipFree(p->d_ops); p->d_ops = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_ops, sizeof(gmgk::P2POp) * ops.size()));
     HIPCHK(hipMemcpy(p->d_ops, ops.data(), sizeof(gmgk::P2POp) * ops.size(), hipMemcpyHostToDevice));
@@ -305,9 +411,81 @@ int p2p_smooth(gmg_handle h, int iters) {
     for (int it = 0; it < iters; ++it)
         for (int c = 0; c < l.ord.n_colors; ++c) {
             if ((rc = gmg_dist_smooth_color(h, c))) return rc;
-            if ((rc = p2p_exchange(h, c, l.x))) return rc;
+            if ((rc = p2p_exchange(h, c, l.x, l.n_pad))) return rc;
         }
     return GMG_OK;
+}
+
+// `iters` block sweeps on this rank's blocks of level 1, each followed by the x1 halo exchange; the result ends in l1.x
+// (from_zero: the iterate is the zero vector and the first sweep takes no input, like launch_block_sweeps).
+int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero) {
+    DistP2P* p = h->p2p;
+    Level& l1 = h->lv[1];
+    const int C = h->lv[0].ord.n_colors, d = p->d, nb = (int)p->own_blocks[p->rank].size();
+    double* in = from_zero ? nullptr : l1.x;
+    double* out = l1.tmp;
+    int rc;
+    for (int it = 0; it < iters; ++it) {
+        launch_block_sweep_range<double>(h, l1, d, in, out, 0, nb, p->d_own_begin, p->d_own_ncolors);
+        if ((rc = p2p_exchange(h, C + 3, out, l1.n_pad))) return rc;
+        if (it == 0 && from_zero) { in = out; out = l1.x; }
+        else std::swap(in, out);
+    }
+    if (iters > 0 && in != l1.x) HIPCHK(hipMemcpyAsync(l1.x, in, sizeof(double) * (size_t)l1.n_pad * d, hipMemcpyDeviceToDevice, h->stream));
+    return GMG_OK;
+}
+
+// Levels >= 1 with level 1 partitioned by blocks: b1 = U0^T r0 on this rank's rows, sweeps with one halo exchange each, r1
+// completed on every rank, levels >= 2 replicated, and back up to x1 (own rows + halo) for the level-0 prolongation.
+int p2p_coarse_cycle_sharded(gmg_handle h) {
+    DistP2P* p = h->p2p;
+    Level &l0 = h->lv[0], &l1 = h->lv[1];
+    const int C = l0.ord.n_colors, d = p->d;
+    int rc;
+    if ((rc = p2p_exchange(h, C + 5, l0.r, l0.n_pad))) return rc;                      // r0 entries my restriction rows read
+    if (p->n_rsl > 0)                                                                 // :1069 on my rows of level 1
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            if (l0.R.lpr == 4) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer_list<double, D, 0, 4>), dim3(grid_for(p->n_rsl)), dim3(gmgk::kBlock), 0, h->stream, l0.R.slice_ptr,
+                                                  l0.R.col, l0.R.val, l0.R.row_of, l0.r + (size_t)c0 * l0.n_pad, l0.n_pad, l1.b + (size_t)c0 * l1.n_pad, l1.n_pad,
+                                                  p->d_rsl, p->n_rsl));
+            } else {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer_list<double, D, 0, 1>), dim3(grid_for(p->n_rsl)), dim3(gmgk::kBlock), 0, h->stream, l0.R.slice_ptr,
+                                                  l0.R.col, l0.R.val, l0.R.row_of, l0.r + (size_t)c0 * l0.n_pad, l0.n_pad, l1.b + (size_t)c0 * l1.n_pad, l1.n_pad,
+                                                  p->d_rsl, p->n_rsl));
+            }
+        }
+    const bool from_zero = smooth_from_zero_ok(h, l1, h->cfg.pre_iters);
+    if (!from_zero) HIPCHK(hipMemsetAsync(l1.x, 0, sizeof(double) * (size_t)l1.n_pad * d, h->stream));       // :1072-1073
+    if ((rc = p2p_smooth_level1(h, h->cfg.pre_iters, from_zero))) return rc;              // :1063
+    if (p->n_asl > 0)                                                                 // :1066 on my rows
+        for (int c0 = 0; c0 < d; c0 += 4) {
+            int dc = std::min(4, d - c0);
+            if (l1.Aoff.lpr == 4) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full_list<double, D, 1, 4>), dim3(grid_for(p->n_asl)), dim3(gmgk::kBlock), 0, h->stream, l1.Aoff.slice_ptr,
+                                                  l1.Aoff.col, l1.Aoff.val, l1.diag, l1.b + (size_t)c0 * l1.n_pad, l1.x + (size_t)c0 * l1.n_pad,
+                                                  l1.r + (size_t)c0 * l1.n_pad, l1.n_pad, p->d_asl, p->n_asl));
+            } else {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full_list<double, D, 1, 1>), dim3(grid_for(p->n_asl)), dim3(gmgk::kBlock), 0, h->stream, l1.Aoff.slice_ptr,
+                                                  l1.Aoff.col, l1.Aoff.val, l1.diag, l1.b + (size_t)c0 * l1.n_pad, l1.x + (size_t)c0 * l1.n_pad,
+                                                  l1.r + (size_t)c0 * l1.n_pad, l1.n_pad, p->d_asl, p->n_asl));
+            }
+        }
+    if ((rc = p2p_exchange(h, C + 4, l1.r, l1.n_pad))) return rc;                      // everybody's rows -> complete r1 on every rank
+    launch_restrict<double>(h, l1, h->lv[2], d, l1.r, h->lv[2].b);                      // :1069, replicated from here down
+    enqueue_down<double>(h, d, 2);
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
+    else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
+    enqueue_up<double>(h, d, 2);
+    for (int c0 = 0; c0 < d && p->n_psl > 0; c0 += 4) {                               // :1082 into my rows of level 1
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer_list<double, D, 1, 1>), dim3(grid_for(p->n_psl)), dim3(gmgk::kBlock), 0, h->stream, l1.P.slice_ptr, l1.P.col,
+                                          l1.P.val, (const int*)nullptr, h->lv[2].x + (size_t)c0 * h->lv[2].n_pad, h->lv[2].n_pad, l1.x + (size_t)c0 * l1.n_pad,
+                                          l1.n_pad, p->d_psl, p->n_psl));
+    }
+    if ((rc = p2p_exchange(h, C + 3, l1.x, l1.n_pad))) return rc;
+    return p2p_smooth_level1(h, h->cfg.post_iters, false);                            // :1085; leaves x1 current on my rows + halo
 }
 
 int p2p_vcycle(gmg_handle h) {
@@ -316,11 +494,31 @@ int p2p_vcycle(gmg_handle h) {
     int rc;
     if ((rc = p2p_smooth(h, h->cfg.pre_iters))) return rc;                // :1063
     if ((rc = gmg_dist_residual_own(h))) return rc;                       // :1066, own rows
-    if ((rc = p2p_exchange(h, C + 1, l.r))) return rc;                    //        everybody's rows -> complete r on every rank
-    if ((rc = gmg_dist_coarse_cycle(h))) return rc;                       // :1069-1079, replicated
+    if (h->p2p->shard1) {
+        if ((rc = p2p_coarse_cycle_sharded(h))) return rc;
+    } else {
+        if ((rc = p2p_exchange(h, C + 1, l.r, l.n_pad))) return rc;       //        everybody's rows -> complete r on every rank
+        if ((rc = gmg_dist_coarse_cycle(h))) return rc;                   // :1069-1079, replicated
+    }
     if ((rc = gmg_dist_prolong_own(h))) return rc;                        // :1082, own rows
-    if ((rc = p2p_exchange(h, C, l.x))) return rc;                        //        halo of all colours
+    if ((rc = p2p_exchange(h, C, l.x, l.n_pad))) return rc;               //        halo of all colours
     return p2p_smooth(h, h->cfg.post_iters);                              // :1085
+}
+
+// exchange kind by name: "color<k>", "halo_all", "rows0", "x1_halo", "rows1", "r0_halo" -> kind, vector and its leading dimension
+int p2p_kind_by_name(gmg_handle h, const std::string& name, int* kind, double** vec, int* ld) {
+    DistP2P* p = h->p2p;
+    Level& l0 = h->lv[0];
+    const int C = l0.ord.n_colors;
+    *vec = l0.x; *ld = l0.n_pad;
+    if (name.rfind("color", 0) == 0) { *kind = std::atoi(name.c_str() + 5); return *kind >= 0 && *kind < C ? GMG_OK : GMG_ERR_INVALID; }
+    if (name == "halo_all") { *kind = C; return GMG_OK; }
+    if (name == "rows0") { *kind = C + 1; *vec = l0.r; return GMG_OK; }
+    if (!p->shard1) return GMG_ERR_INVALID;
+    if (name == "x1_halo") { *kind = C + 3; *vec = h->lv[1].tmp; *ld = h->lv[1].n_pad; return GMG_OK; }
+    if (name == "rows1") { *kind = C + 4; *vec = h->lv[1].r; *ld = h->lv[1].n_pad; return GMG_OK; }
+    if (name == "r0_halo") { *kind = C + 5; *vec = l0.r; return GMG_OK; }
+    return GMG_ERR_INVALID;
 }
 
 }  // namespace
@@ -364,29 +562,39 @@ int gmg_p2p_fetch(gmg_handle h, double* x) try {
     DistP2P* p = h->p2p;
     if (!p || !p->connected || !h->bound || !x) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
     Level& l = h->lv[0];
-    // the residual-rows exchange moves every rank's own rows of a level-0 vector: reuse it for x
-    int rc = p2p_exchange(h, l.ord.n_colors + 1, l.x);
+    // the level-0 rows exchange moves every rank's own rows of a level-0 vector
+    int rc = p2p_exchange(h, l.ord.n_colors + 1, l.x, l.n_pad);
     if (rc) return rc;
     return to_host(h, 0, l.x, p->d, x);
 } GMG_CATCH_H
 
-// Average duration (ms) of one halo exchange of colour 0 (push + wait + pull, one launch), `reps` back to back; collective.
-int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg) try {
+// Average duration (ms) of one exchange of the named kind (push + wait + pull, one launch), `reps` back to back; collective --
+// every rank calls it with the same arguments.  Kinds: "color<k>" (halo of colour k), "halo_all", "rows0" (every rank's rows of
+// a level-0 vector), and with level 1 partitioned "x1_halo", "rows1", "r0_halo".  The values moved are whatever the vectors
+// hold: call it between problems (gmg_p2p_load afterwards).
+int gmg_p2p_bench_kind(gmg_handle h, const char* kind_name, int reps, double* ms_avg) try {
     NEED_DEVICE();
     DistP2P* p = h->p2p;
-    if (!p || !p->connected || !h->bound || !ms_avg || reps <= 0) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
-    Level& l = h->lv[0];
-    for (int i = 0; i < 3; ++i) (void)p2p_exchange(h, 0, l.x);
+    if (!p || !p->connected || !h->bound || !ms_avg || !kind_name || reps <= 0) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
+    int kind = 0, ld = 0;
+    double* vec = nullptr;
+    if (p2p_kind_by_name(h, kind_name, &kind, &vec, &ld)) return fail(h, GMG_ERR_INVALID, std::string("unknown exchange kind: ") + kind_name);
+    for (int i = 0; i < 3; ++i) (void)p2p_exchange(h, kind, vec, ld);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    for (int i = 0; i < reps; ++i) (void)p2p_exchange(h, 0, l.x);
+    for (int i = 0; i < reps; ++i) (void)p2p_exchange(h, kind, vec, ld);
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *ms_avg = (double)ms / reps;
+    int herr = 0;
+    HIPCHK(hipMemcpy(&herr, p->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) return fail(h, GMG_ERR_STATE, "a peer-to-peer exchange timed out (a rank is missing or ran a different sequence)");
     return GMG_OK;
 } GMG_CATCH_H
+
+int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg) { return gmg_p2p_bench_kind(h, "color0", reps, ms_avg); }
 
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {
     if (!h || !h->p2p || !key || !out) return GMG_ERR_INVALID;

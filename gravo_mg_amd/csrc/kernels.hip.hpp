@@ -628,13 +628,9 @@ __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict
 // MODE 0: y = A x      MODE 1: y = b - A x   (gravomg/src/multigrid_solver.cpp:1066)
 // LPR = lanes per row of the SELL layout (1, or 4 on the coarse levels): slices then hold 64 / LPR rows.
 template <class T, int D, int MODE, int LPR>
-__global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                    const T* __restrict__ val, const T* __restrict__ diag,
-                                                    const T* __restrict__ b, const T* __restrict__ x,
-                                                    T* __restrict__ y, int ld, int slice_begin, int slice_end,
-                                                    int xcd_swizzle) {
-    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
-    if (s >= slice_end) return;
+__device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
+                                                const T* __restrict__ diag, const T* __restrict__ b, const T* __restrict__ x, T* __restrict__ y,
+                                                int ld, int s) {
     const int lane = threadIdx.x & 63;
     const int row = s * (64 / LPR) + lane / LPR;
     T acc[D];
@@ -647,18 +643,34 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
         y[row + (int64_t)c * ld] = MODE == 1 ? b[row + (int64_t)c * ld] - ax : ax;
     }
 }
+template <class T, int D, int MODE, int LPR>
+__global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                    const T* __restrict__ val, const T* __restrict__ diag,
+                                                    const T* __restrict__ b, const T* __restrict__ x,
+                                                    T* __restrict__ y, int ld, int slice_begin, int slice_end,
+                                                    int xcd_swizzle) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
+    if (s >= slice_end) return;
+    spmv_full_slice<T, D, MODE, LPR>(slice_ptr, col, val, diag, b, x, y, ld, s);
+}
+// the same over a LIST of slices (a rank's rows of a level partitioned by blocks: not one contiguous range)
+template <class T, int D, int MODE, int LPR>
+__global__ __launch_bounds__(kBlock) void spmv_full_list(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                         const T* __restrict__ val, const T* __restrict__ diag,
+                                                         const T* __restrict__ b, const T* __restrict__ x,
+                                                         T* __restrict__ y, int ld, const int* __restrict__ slices, int n_list) {
+    const int i = wave_slice(n_list, 1);
+    if (i >= n_list) return;
+    spmv_full_slice<T, D, MODE, LPR>(slice_ptr, col, val, diag, b, x, y, ld, __builtin_amdgcn_readfirstlane(slices[i]));
+}
 
 // Transfer operators.  ADD = 0: y[out_row] = sum val * x[col]   (restriction rc = U^T r, :1069)
 //                       ADD = 1: y[out_row] += sum val * x[col]  (prolongation x += U e, :1082)
 // row_of (may be null) maps the slice row to the output row (-1 = none); ldx/ldy are the leading
 // dimensions of the source / destination level.  LPR as in spmv_full.
 template <class T, int D, int ADD, int LPR>
-__global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
-                                                   const T* __restrict__ val, const int* __restrict__ row_of,
-                                                   const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
-                                                   int slice_begin, int slice_end, int xcd_swizzle) {
-    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
-    if (s >= slice_end) return;
+__device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
+                                               const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s) {
     const int lane = threadIdx.x & 63;
     T acc[D];
     row_dot<T, D>(slice_ptr, col, val, x, ldx, s, lane, acc);
@@ -673,6 +685,24 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
         if (ADD) y[row + (int64_t)c * ldy] += acc[c];
         else y[row + (int64_t)c * ldy] = acc[c];
     }
+}
+template <class T, int D, int ADD, int LPR>
+__global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                   const T* __restrict__ val, const int* __restrict__ row_of,
+                                                   const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                   int slice_begin, int slice_end, int xcd_swizzle) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
+    if (s >= slice_end) return;
+    transfer_slice<T, D, ADD, LPR>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s);
+}
+template <class T, int D, int ADD, int LPR>
+__global__ __launch_bounds__(kBlock) void transfer_list(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                        const T* __restrict__ val, const int* __restrict__ row_of,
+                                                        const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
+                                                        const int* __restrict__ slices, int n_list) {
+    const int i = wave_slice(n_list, 1);
+    if (i >= n_list) return;
+    transfer_slice<T, D, ADD, LPR>(slice_ptr, col, val, row_of, x, ldx, y, ldy, __builtin_amdgcn_readfirstlane(slices[i]));
 }
 
 // out[c] = sum over blocks of partials[block][c], c < ncomp <= kReduceMaxComp.  One block of kReduceBlock threads, fixed order
@@ -751,20 +781,33 @@ struct P2POp {
 };
 
 // vec: D columns with leading dimension ld.  err (device int): set to 1 when a wait timed out (~4 s of wall clock).
+// Grid: 2 * n_peers * B blocks -- per peer B blocks push and B blocks pull, each its strided share of the values (B = 1 for a halo
+// of a few thousand entries; a whole vector moves with tens of blocks: one block's stores do not fill an xGMI link).  The last
+// push block to finish (done[peer], device memory, zero between launches) publishes the sequence number; no block of this
+// launch waits for another block of it, only for the PEER's push.
 __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ ops, int n_peers, double* vec, int ld, int D,
-                                                    unsigned long long seq, int* err) {
-    const int j = blockIdx.x < n_peers ? blockIdx.x : blockIdx.x - n_peers;
+                                                    unsigned long long seq, int* err, int B, unsigned int* done) {
+    const int part = blockIdx.x % B, j = (blockIdx.x / B) % n_peers;
+    const bool push = (int)blockIdx.x < n_peers * B;
     const P2POp op = ops[j];
-    if ((int)blockIdx.x < n_peers) {                                  // ---- push
+    const int64_t stride = (int64_t)B * blockDim.x;
+    if (push) {                                                       // ---- push
         const int64_t total = (int64_t)op.n_send * D;
-        for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        for (int64_t i = (int64_t)part * blockDim.x + threadIdx.x; i < total; i += stride) {
             const int c = (int)(i / op.n_send), k = (int)(i - (int64_t)c * op.n_send);
             const int src = op.send_idx ? op.send_idx[k] : op.send_lo + k;
             op.remote_box[i] = vec[src + (int64_t)c * ld];
         }
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            bool last = true;
+            if (B > 1) {
+                last = __hip_atomic_fetch_add(done + j, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)B - 1;
+                if (last) __hip_atomic_store(done + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (last) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     } else {                                                          // ---- pull
         __shared__ int timed_out;
         if (threadIdx.x == 0) {
@@ -779,7 +822,7 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
         if (timed_out) return;
         const int64_t total = (int64_t)op.n_recv * D;
         const unsigned long long* box = reinterpret_cast<const unsigned long long*>(op.local_box);
-        for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        for (int64_t i = (int64_t)part * blockDim.x + threadIdx.x; i < total; i += stride) {
             const int c = (int)(i / op.n_recv), k = (int)(i - (int64_t)c * op.n_recv);
             const int dst = op.recv_idx ? op.recv_idx[k] : op.recv_lo + k;
             // system-scope loads: the region is rewritten by the peer every exchange, no stale cached copy may be served

@@ -4,7 +4,8 @@ also works with N = 1 (WORLD_SIZE=1) to exercise the distributed code path on on
 
 Exchange engines (`--exchange`):
   p2p (default)  the cycle is driven inside the library (gmg_p2p_*, csrc/engine_dist.hip.hpp): every exchange is a
-                 device-initiated store into the peers' mailboxes, no collective call and no Python per colour.  Taken only if
+                 device-initiated store into the peers' mailboxes, no collective call and no Python per colour.  Level 0 is
+                 partitioned by rows per colour and (--shard-levels 2, default) level 1 by runs of blocks.  Taken only if
                  EVERY rank could set it up and its first cycles reproduce the residues of the plain single-GPU engine
                  (the iterates do not depend on the number of ranks); otherwise all ranks fall back together to
   halo           the RCCL orchestration of gravo_mg_amd/dist.py: pack -> all_gather_into_tensor -> unpack per colour
@@ -57,7 +58,7 @@ def main(args):
     H, mass, lhs, rhs = single.build_workload(args.n1, args.n2, args.order)      # deterministic: every rank builds the same
 
     def new_engine():
-        e = cabi.Engine(device=local, row_align=64 * world, use_graph=False, coarse_mode=coarse_mode)
+        e = cabi.Engine(device=local, row_align=64 * world, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels)
         e.use_hierarchy(H); e.set_mass(mass); e.set_system(lhs)
         return e
 
@@ -90,7 +91,15 @@ def main(args):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             p2p = cand
-            exchange_us = 1e3 * p2p.bench_exchange(200)
+            sharded1 = p2p.stat("level1_partitioned") == 1.0
+            C, pre, post = levels[0]["n_colors"], 2, 2
+            # every exchange of a cycle, timed alone (push + wait + pull in one launch, 200 back to back), and how often a cycle runs it
+            per_cycle = {"color0": None, "halo_all": 1}
+            per_cycle.update({"r0_halo": 1, "x1_halo": pre + post + 1, "rows1": 1} if sharded1 else {"rows0": 1})
+            exchange_us = {k: 1e3 * p2p.bench_kind(k, 200) for k in per_cycle}
+            exchange_us["per_cycle"] = {**{k: v for k, v in per_cycle.items() if v}, "color<k> (each of %d colours)" % C: (pre + post)}
+            exchange_us["sum_per_cycle"] = (sum(exchange_us[k] * n for k, n in per_cycle.items() if n)
+                                            + (pre + post) * sum(1e3 * p2p.bench_kind(f"color{c}", 100) for c in range(C)))
         else:
             note = note if ok == 0 else "another rank could not set up the peer-to-peer path"
             single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange ({note})")
@@ -161,9 +170,15 @@ def main(args):
                     "traffic": traffic, "traffic_source": traffic_source, "launch_ms": sweep_ms / launches, "launches_per_sweep": launches}
         n0 = lhs.shape[0]
         if p2p is not None:
-            partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep ONE exchange "
+            if p2p.stat("level1_partitioned") == 1.0:
+                lower = (f"level 1 split {world}-way by runs of 64-row blocks ({int(p2p.stat('level1_own_rows'))} of {levels[1]['n_pad']} rows on rank 0): "
+                         f"one x1 halo exchange per block sweep ({int(p2p.stat('x1_halo_rows_published'))} rows published by rank 0), r0 halo before the restriction "
+                         f"({int(p2p.stat('r0_halo_rows_published'))} rows), r1 completed on every rank once per cycle; levels >= 2 replicated")
+            else:
+                lower = "levels >= 1 replicated, r0 pushed to all peers once per cycle"
+            partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm); per colour sweep ONE exchange "
                          f"kernel: each rank stores the halo entries its peers read into their mailboxes over xGMI ({int(p2p.stat('halo_rows_published'))} rows "
-                         "published by rank 0) and waits for theirs; r pushed to all peers once per cycle; no collective call in the cycle")
+                         f"published by rank 0) and waits for theirs; {lower}; no collective call in the cycle")
         elif halo is not None:
             partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
                          f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle")

@@ -93,6 +93,8 @@ typedef struct {
     int block_ep;          /* 1 (default): big blocked levels (one lane per row, 64-row blocks, block_csr = 1) run the entry-parallel
                               block sweep: in-block and off-block operators as unpadded block-ordered CSR, one 64-lane gather per
                               64 ENTRIES instead of one per padded column of the block's longest row; 0: the SELL / block-CSR sweeps */
+    int dist_shard_levels; /* multi-GPU (gmg_p2p_*): how many levels are partitioned over the ranks.  2 (default): level 0 by rows per
+                              colour AND level 1 by runs of blocks; 1: level 0 only (levels >= 1 replicated on every rank) */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -232,6 +234,10 @@ int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
 int gmg_p2p_fetch(gmg_handle h, double* x);
 /* average duration (ms) of one colour-0 halo exchange, `reps` back to back (collective; measurement) */
 int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg);
+/* the same for any exchange of the cycle: "color<k>", "halo_all", "rows0" (every rank's level-0 rows: what a cycle with level 1
+ * replicated moves once), and with level 1 partitioned "x1_halo" (after every level-1 sweep), "rows1" (r1 to all, once per
+ * cycle), "r0_halo" (before the restriction, once per cycle).  Overwrites halo entries: gmg_p2p_load afterwards. */
+int gmg_p2p_bench_kind(gmg_handle h, const char* kind, int reps, double* ms_avg);
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */

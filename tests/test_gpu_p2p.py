@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _engine(cabi, P, world):
-    eng = cabi.Engine(row_align=64 * world)
+    # block_lanes=1: the small levels of these problems take the layout of big ones (one lane per row, entry-parallel block sweep),
+    # the layout the level-1 partition is built for
+    eng = cabi.Engine(row_align=64 * world, block_lanes=1)
     eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
     return eng
 
@@ -29,18 +31,28 @@ def _reference(cabi, P, world, cycles):
     return hist, ref.fetch_solution()
 
 
-def _worker(rank, world, port, q, kind):
+def _problem(kind):
+    from tests import problems as pr
+    if kind == "poisson":
+        return pr.torus_problem(96, 80, "poisson", 30)
+    if kind == "poisson-big":
+        return pr.torus_problem(300, 280, "poisson", 100)       # level 1: ~10 k rows, ~165 blocks
+    return pr.torus_problem(64, 60, "smoothing", 60)
+
+
+def _worker(rank, world, port, q, kind, shard):
     try:
         sys.path.insert(0, ROOT)
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
         import torch.distributed as dist
         from gravo_mg_amd import cabi
-        from tests import problems as pr
+        from tests.test_gpu_p2p import _problem
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-        P = pr.torus_problem(96, 80, "poisson", 30) if kind == "poisson" else pr.torus_problem(64, 60, "smoothing", 60)
-        eng = cabi.Engine(row_align=64 * world)
+        P = _problem(kind)
+        eng = cabi.Engine(row_align=64 * world, dist_shard_levels=shard, block_lanes=1)
         eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
         rk = cabi.P2PCycle(eng, rank, world, P.rhs.shape[1])
+        assert rk.stat("level1_partitioned") == (1.0 if shard == 2 else 0.0)
         blobs = [None] * world
         dist.all_gather_object(blobs, rk.export())
         rk.connect(blobs=blobs)
@@ -49,6 +61,9 @@ def _worker(rank, world, port, q, kind):
         hist = rk.cycles(4, 2)
         x = rk.fetch()
         dist.barrier()
+        us = {k: 1e3 * rk.bench_kind(k, 20) for k in (["color0", "halo_all", "rows0"] + (["x1_halo", "rows1", "r0_halo"] if shard == 2 else []))}
+        assert all(v > 0 for v in us.values()), us
+        dist.barrier()
         q.put((rank, hist, x, None))
         dist.destroy_process_group()
     except Exception as e:              # noqa: BLE001
@@ -56,17 +71,19 @@ def _worker(rank, world, port, q, kind):
         q.put((rank, None, None, traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("world,kind", [(2, "poisson"), (3, "poisson"), (4, "smoothing-d3")])
-def test_processes_through_ipc_handles(cabi, world, kind):
+@pytest.mark.parametrize("world,kind,shard", [(2, "poisson", 2), (3, "poisson", 2), (3, "poisson", 1), (4, "smoothing-d3", 2), (4, "poisson-big", 2),
+                                              (2, "poisson-big", 1)])
+def test_processes_through_ipc_handles(cabi, world, kind, shard):
+    """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by runs of blocks (default), 1 = level 0 only."""
     import torch.multiprocessing as mp
-    P = problems.torus_problem(96, 80, "poisson", 30) if kind == "poisson" else problems.torus_problem(64, 60, "smoothing", 60)
+    P = _problem(kind)
     want_hist, want_x = _reference(cabi, P, world, 4)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, shard)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
