@@ -136,6 +136,10 @@ def main():
     ap.add_argument("--exchange", default="p2p", choices=["p2p", "halo", "allgather"],
                     help="N > 1: p2p = engine-driven cycle, device-initiated stores into the peers' mailboxes (falls back to halo if it "
                          "cannot be set up); halo = RCCL all-gather of the packed halo entries per colour; allgather = whole colour segments")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong (default, the BASELINE metric) = the 3 M-vertex problem split over N ranks; weak = --n1 x --n2 vertices PER "
+                         "RANK (a torus of sqrt(N) n1 x sqrt(N) n2 vertices): the weak-scaling point of SURVEY.md 8e.  Every rank still builds the whole "
+                         "hierarchy and set_system (replicated set-up), so the set-up time and memory grow with N")
     ap.add_argument("--shard-levels", type=int, default=2, choices=[1, 2],
                     help="N > 1, p2p: levels partitioned over the ranks (2 = level 0 by rows per colour + level 1 by runs of blocks; 1 = level 0 only)")
     args = ap.parse_args()
