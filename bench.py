@@ -141,7 +141,7 @@ def main():
                          "RANK (a torus of sqrt(N) n1 x sqrt(N) n2 vertices): the weak-scaling point of SURVEY.md 8e.  Every rank still builds the whole "
                          "hierarchy and set_system (replicated set-up), so the set-up time and memory grow with N")
     ap.add_argument("--shard-levels", type=int, default=2, choices=[1, 2],
-                    help="N > 1, p2p: levels partitioned over the ranks (2 = level 0 by rows per colour + level 1 by runs of blocks; 1 = level 0 only)")
+                    help="N > 1, p2p: levels partitioned over the ranks (2 = level 0 by rows per colour + level 1 by blocks; 1 = level 0 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

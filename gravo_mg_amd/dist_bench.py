@@ -5,7 +5,7 @@ also works with N = 1 (WORLD_SIZE=1) to exercise the distributed code path on on
 Exchange engines (`--exchange`):
   p2p (default)  the cycle is driven inside the library (gmg_p2p_*, csrc/engine_dist.hip.hpp): every exchange is a
                  device-initiated store into the peers' mailboxes, no collective call and no Python per colour.  Level 0 is
-                 partitioned by rows per colour and (--shard-levels 2, default) level 1 by runs of blocks.  Taken only if
+                 partitioned by rows per colour and (--shard-levels 2, default) level 1 by blocks.  Taken only if
                  EVERY rank could set it up and its first cycles reproduce the residues of the plain single-GPU engine
                  (the iterates do not depend on the number of ranks); otherwise all ranks fall back together to
   halo           the RCCL orchestration of gravo_mg_amd/dist.py: pack -> all_gather_into_tensor -> unpack per colour
@@ -173,7 +173,7 @@ def main(args):
         n0 = lhs.shape[0]
         if p2p is not None:
             if p2p.stat("level1_partitioned") == 1.0:
-                lower = (f"level 1 split {world}-way by runs of 64-row blocks ({int(p2p.stat('level1_own_rows'))} of {levels[1]['n_pad']} rows on rank 0): "
+                lower = (f"level 1 split {world}-way by 64-row blocks, each owned by the rank holding most of its fine rows ({int(p2p.stat('level1_own_rows'))} of {levels[1]['n_pad']} rows on rank 0): "
                          f"one x1 halo exchange per block sweep ({int(p2p.stat('x1_halo_rows_published'))} rows published by rank 0), r0 halo before the restriction "
                          f"({int(p2p.stat('r0_halo_rows_published'))} rows), r1 completed on every rank once per cycle; levels >= 2 replicated")
             else:

@@ -94,7 +94,7 @@ typedef struct {
                               block sweep: in-block and off-block operators as unpadded block-ordered CSR, one 64-lane gather per
                               64 ENTRIES instead of one per padded column of the block's longest row; 0: the SELL / block-CSR sweeps */
     int dist_shard_levels; /* multi-GPU (gmg_p2p_*): how many levels are partitioned over the ranks.  2 (default): level 0 by rows per
-                              colour AND level 1 by runs of blocks; 1: level 0 only (levels >= 1 replicated on every rank) */
+                              colour AND level 1 by blocks; 1: level 0 only (levels >= 1 replicated on every rank) */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

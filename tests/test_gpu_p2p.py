@@ -74,7 +74,7 @@ def _worker(rank, world, port, q, kind, shard):
 @pytest.mark.parametrize("world,kind,shard", [(2, "poisson", 2), (3, "poisson", 2), (3, "poisson", 1), (4, "smoothing-d3", 2), (4, "poisson-big", 2),
                                               (2, "poisson-big", 1)])
 def test_processes_through_ipc_handles(cabi, world, kind, shard):
-    """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by runs of blocks (default), 1 = level 0 only."""
+    """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by blocks (default), 1 = level 0 only."""
     import torch.multiprocessing as mp
     P = _problem(kind)
     want_hist, want_x = _reference(cabi, P, world, 4)
