@@ -1158,17 +1158,23 @@ int gmg_dist_residual_own(gmg_handle h) try {
 } GMG_CATCH_H
 
 // Replicated coarse part: b1 = U0^T r0 (needs the complete r0), levels 1..L-1 down, coarsest solve, back up to level 1.
-int gmg_dist_coarse_cycle(gmg_handle h) try {
-    NEED_DEVICE();
+// _enqueue leaves the host half of the coarsest solve pending (coarse_host_serve) so that the caller can queue more work first.
+static int dist_coarse_cycle_enqueue(gmg_handle h) {
     int rc = dist_ready(h);
     if (rc) return rc;
     const int d = h->loaded_d;
     launch_restrict<double>(h, h->lv[0], h->lv[1], d, h->lv[0].r, h->lv[1].b);
     enqueue_down<double>(h, d, 1);
     if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
-    else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
+    else if ((rc = coarse_host_begin<double>(h, d))) return rc;
     enqueue_up<double>(h, d, 1);
     return GMG_OK;
+}
+int gmg_dist_coarse_cycle(gmg_handle h) try {
+    NEED_DEVICE();
+    int rc = dist_coarse_cycle_enqueue(h);
+    const int served = coarse_host_serve(h);
+    return rc ? rc : served;
 } GMG_CATCH_H
 
 // x0[own rows] += U0 x1

@@ -312,8 +312,8 @@ int ensure_vectors(gmg_handle h, int d) {
     if (h->h_norm) (void)hipHostFree(h->h_norm);
     HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, kPolledHostFlags));
     if (!h->h_flag) {
-        HIPCHK(hipHostMalloc((void**)&h->h_flag, 128, kPolledHostFlags));
-        std::memset(h->h_flag, 0, 128);
+        HIPCHK(hipHostMalloc((void**)&h->h_flag, 256, kPolledHostFlags));
+        std::memset(h->h_flag, 0, 256);
     }
 
     if (h->d_norm) (void)dev_free(h->d_norm);
@@ -435,9 +435,37 @@ void enqueue_coarse_device(gmg_handle h, int d) {
     if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
 }
 
-// Host coarsest solve (:1075): D2H rc, LDL^T back-substitution per column (fp64), H2D eps.
+// Host coarsest solve (:1075): rc to the host, LDL^T back-substitution per column (fp64), eps back.
+// Polled handles split it in two so that the host's answer releases work that is ALREADY in the queue: coarse_host_begin enqueues
+// the publication of rc, a stream wait on a host-written word (hipStreamWaitValue64) and the fetch of eps; the caller goes on
+// enqueuing the way up (and the residual check); coarse_host_serve then waits for rc, solves, writes eps and the word.  Releasing
+// queued work costs ~3 us after the host's store; launching it after the solve costs ~12 us for the first kernel and ~4 us for
+// each of the next few (scripts/micro/wait_value.hip).
+void coarse_host_solve(gmg_handle h, int d) {
+    Level& c = h->lv[h->L];
+    const size_t cnt = (size_t)c.n_pad * d;
+    double* rc = h->h_pinned;
+    double* e = h->h_pinned + cnt;
+    auto t0 = clk::now();
+    std::memset(e, 0, sizeof(double) * cnt);
+    if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
+    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
+    h->timing["coarse_host_ms"] += ms_since(t0);
+}
+
+// the host part of a pending gate (no-op without one).  The word is written even when waiting for rc failed: the stream must
+// not stay blocked.
+int coarse_host_serve(gmg_handle h) {
+    if (!h->coarse_pending) return GMG_OK;
+    h->coarse_pending = false;
+    const int w = wait_flag(h, 1);
+    if (w == GMG_OK) coarse_host_solve(h, h->coarse_pending_d);
+    __atomic_store_n(h->h_flag + 16, h->flag_seq[2], __ATOMIC_RELEASE);
+    return w;
+}
+
 template <class T = double>
-int coarse_host_roundtrip(gmg_handle h, int d) {
+int coarse_host_begin(gmg_handle h, int d) {
     Level& c = h->lv[h->L];
     const size_t cnt = (size_t)c.n_pad * d;
     double* rc = h->h_pinned;
@@ -445,20 +473,34 @@ int coarse_host_roundtrip(gmg_handle h, int d) {
     if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
     if (polled(h)) {
         hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1]);
+        if (h->gate_ok) {
+            if (hipStreamWaitValue64(h->stream, h->h_flag + 16, ++h->flag_seq[2], hipStreamWaitValueGte, ~0ull) == hipSuccess) {
+                hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
+                                   (const double*)e, c.x, (int)cnt);
+                if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
+                h->coarse_pending = true; h->coarse_pending_d = d;
+                return GMG_OK;
+            }
+            (void)hipGetLastError();
+            h->gate_ok = false; --h->flag_seq[2]; h->timing["gate_disabled"] = 1.0;
+        }
         int w = wait_flag(h, 1);
         if (w) return w;
     } else {
         HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    auto t0 = clk::now();
-    std::memset(e, 0, sizeof(double) * cnt);
-    if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
-    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
-    h->timing["coarse_host_ms"] += ms_since(t0);
+    coarse_host_solve(h, d);
     HIPCHK(hipMemcpyAsync(c.x, e, sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
     if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
     return GMG_OK;
+}
+
+// both halves back to back (callers that have nothing to enqueue in between)
+template <class T = double>
+int coarse_host_roundtrip(gmg_handle h, int d) {
+    int rc = coarse_host_begin<T>(h, d);
+    return rc ? rc : coarse_host_serve(h);
 }
 
 // Mixed precision: fp64 residual of the current iterate -> fp32 right-hand side of the inner cycle, plus the norm sums
@@ -531,13 +573,14 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
         return rc ? rc : err;
     }
     if ((rc = run_graph(h, key_salt + G_DOWN * 10000 + d * 10, [&] { head(); enqueue_down<T>(h, d); }))) return rc;
-    if ((rc = coarse_host_roundtrip<T>(h, d))) return rc;
+    if ((rc = coarse_host_begin<T>(h, d))) return rc;              // (polled: the way up is enqueued behind a gate the host opens in _serve)
     int err = GMG_OK;
     rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
         enqueue_up<T>(h, d);
         tail(err);
     });
-    return rc ? rc : err;
+    const int served = coarse_host_serve(h);
+    return rc ? rc : (served ? served : err);
 }
 
 int vcycle_resident(gmg_handle h, int d, int norm_type) {

@@ -476,7 +476,7 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
     launch_restrict<double>(h, l1, h->lv[2], d, l1.r, h->lv[2].b);                      // :1069, replicated from here down
     enqueue_down<double>(h, d, 2);
     if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
-    else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
+    else if ((rc = coarse_host_begin<double>(h, d))) return rc;       // the host half is served at the end of the cycle's enqueue (p2p_vcycle)
     enqueue_up<double>(h, d, 2);
     for (int c0 = 0; c0 < d && p->n_psl > 0; c0 += 4) {                               // :1082 into my rows of level 1
         int dc = std::min(4, d - c0);
@@ -488,7 +488,7 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
     return p2p_smooth_level1(h, h->cfg.post_iters, false);                            // :1085; leaves x1 current on my rows + halo
 }
 
-int p2p_vcycle(gmg_handle h) {
+int p2p_vcycle_enqueue(gmg_handle h) {
     Level& l = h->lv[0];
     const int C = l.ord.n_colors;
     int rc;
@@ -498,11 +498,18 @@ int p2p_vcycle(gmg_handle h) {
         if ((rc = p2p_coarse_cycle_sharded(h))) return rc;
     } else {
         if ((rc = p2p_exchange(h, C + 1, l.r, l.n_pad))) return rc;       //        everybody's rows -> complete r on every rank
-        if ((rc = gmg_dist_coarse_cycle(h))) return rc;                   // :1069-1079, replicated
+        if ((rc = dist_coarse_cycle_enqueue(h))) return rc;               // :1069-1079, replicated
     }
     if ((rc = gmg_dist_prolong_own(h))) return rc;                        // :1082, own rows
     if ((rc = p2p_exchange(h, C, l.x, l.n_pad))) return rc;               //        halo of all colours
     return p2p_smooth(h, h->cfg.post_iters);                              // :1085
+}
+
+// the whole cycle is queued before the host turns to the coarsest solve: the way up waits in the stream for its answer
+int p2p_vcycle(gmg_handle h) {
+    const int rc = p2p_vcycle_enqueue(h);
+    const int served = coarse_host_serve(h);
+    return rc ? rc : served;
 }
 
 // exchange kind by name: "color<k>", "halo_all", "rows0", "x1_halo", "rows1", "r0_halo" -> kind, vector and its leading dimension

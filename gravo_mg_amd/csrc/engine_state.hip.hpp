@@ -154,7 +154,12 @@ struct gmg_solver_s {
     double* h_norm = nullptr;
     // polled completion (stream launches only): a kernel writes its small result into pinned memory and then a sequence
     // number into h_flag[slot]; the host spins on that word (wait_flag) instead of a copy + hipStreamSynchronize
-    unsigned long long* h_flag = nullptr; unsigned long long flag_seq[2] = {0, 0};
+    unsigned long long* h_flag = nullptr; unsigned long long flag_seq[3] = {0, 0, 0};
+    // h_flag[16]: written by the HOST -- the stream waits on it (hipStreamWaitValue64) in front of the work that needs the host's
+    // coarsest solution, so that work is enqueued before the host solves (engine_cycle.hip.hpp::coarse_host_begin / _serve)
+    bool gate_ok = true;                 // false once hipStreamWaitValue64 was refused: launch after the solve instead
+    bool coarse_pending = false;         // a gate is enqueued and the host has not answered it yet
+    int coarse_pending_d = 0;
     bool poll = true;             // GMG_POLL=0: copy + hipStreamSynchronize instead (the waiting thread then sleeps instead of spinning)
     double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
     std::vector<double> coarse_work;

@@ -873,6 +873,13 @@ __global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restri
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// n doubles from host-visible pinned memory (the host's coarsest solution; the stream was held until the host had written it)
+__global__ __launch_bounds__(kBlock) void fetch_from_host(const double* src, double* __restrict__ dst, int n) {
+    const unsigned long long* s = reinterpret_cast<const unsigned long long*>(src);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock)
+        dst[i] = __longlong_as_double((long long)__hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
 // Residual norms (gravomg/src/multigrid_solver.cpp:1228-1277): per block, partial sums of
 // w_i r_i^2 and w_i b_i^2 for r = A x - b and w = weight ? weight[i] : 1.
 // partials layout: [block][2*D].  Reduced by reduce_partials (deterministic order).
