@@ -278,6 +278,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     std::future<bool> factor_done = std::async(std::launch::async, [&] {
         auto t = clk::now();
         bool ok = h->coarse.factor(h->lv[L].A, true);
+        h->coarse_warm = false;
         if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) coarse_inverse(h, inv);
         ms_factor = ms_since(t);
         return ok;
@@ -566,6 +567,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     factor_done = std::async(std::launch::async, [&] {
         auto t = clk::now();
         bool ok = h->coarse.factor(h->lv[L].A, ord_hit);
+        h->coarse_warm = false;
         if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) coarse_inverse(h, inv);
         ms_factor = ms_since(t);
         return ok;

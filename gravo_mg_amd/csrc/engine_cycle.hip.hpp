@@ -458,6 +458,7 @@ void coarse_host_solve(gmg_handle h, int d) {
 int coarse_host_serve(gmg_handle h) {
     if (!h->coarse_pending) return GMG_OK;
     h->coarse_pending = false;
+    if (!h->coarse_warm) { h->coarse_warm_sink += h->coarse.warm(); h->coarse_warm = true; }      // (the device is busy with the way down)
     const int w = wait_flag(h, 1);
     if (w == GMG_OK) coarse_host_solve(h, h->coarse_pending_d);
     __atomic_store_n(h->h_flag + 16, h->flag_seq[2], __ATOMIC_RELEASE);
@@ -473,7 +474,8 @@ int coarse_host_begin(gmg_handle h, int d) {
     if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
     if (polled(h)) {
         hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1]);
-        if (h->gate_ok) {
+        static const bool gate_off = std::getenv("GMG_NO_STREAM_GATE") != nullptr;      // A/B aid (scripts/coarse_host_time.py)
+        if (h->gate_ok && !gate_off) {
             if (hipStreamWaitValue64(h->stream, h->h_flag + 16, ++h->flag_seq[2], hipStreamWaitValueGte, ~0ull) == hipSuccess) {
                 hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
                                    (const double*)e, c.x, (int)cnt);

@@ -159,6 +159,8 @@ struct gmg_solver_s {
     // coarsest solution, so that work is enqueued before the host solves (engine_cycle.hip.hpp::coarse_host_begin / _serve)
     bool gate_ok = true;                 // false once hipStreamWaitValue64 was refused: launch after the solve instead
     bool coarse_pending = false;         // a gate is enqueued and the host has not answered it yet
+    bool coarse_warm = false;            // the solving thread has read the current factor once (SupernodalLdlt::warm)
+    double coarse_warm_sink = 0.0;
     int coarse_pending_d = 0;
     bool poll = true;             // GMG_POLL=0: copy + hipStreamSynchronize instead (the waiting thread then sleeps instead of spinning)
     double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
