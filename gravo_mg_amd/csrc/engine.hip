@@ -1037,19 +1037,27 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     h->timing["solve_load"] = ms_since(t_all);
     h->timing["coarse_host_ms"] = 0.0;
     auto t0 = clk::now();
-    double residue = 0.0;
+    double residue = 0.0, first_residue = 0.0;
     int it = 0;
     do {
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
         if ((rc = wait_norm(h))) return rc;
         residue = norm_from_sums(h->h_norm, d, stop_type);
+        if (it == 0) first_residue = residue;
         if (conv) { conv[2 * it] = ms_since(t0); conv[2 * it + 1] = residue; }
         ++it;
         if (h->cfg.verbose) std::printf("%d,%f,%.14f \n", it, ms_since(t0), residue);
     } while (residue > tol && it < max_iter);
     h->timing["cycles"] = ms_since(t0);
+    // Diverged: the iteration ended above the tolerance with a residue that is not finite or larger than after the first cycle.
+    // The parallel smoothers are not the reference's lexicographic Gauss-Seidel (block sweeps on the Galerkin levels take the
+    // couplings between blocks from the previous sweep; nothing guarantees their convergence for every SPD matrix), so the
+    // caller is told (timing key "diverged") and keeps its initial guess in x -- it can retry on a handle with block_rows = 0,
+    // gs_omega = 1: Gauss-Seidel in colour order on every level, convergent for every SPD matrix (MultigridSolver::solve does).
+    const bool diverged = !(residue <= tol) && (!std::isfinite(residue) || (it > 1 && residue > first_residue));
+    h->timing["diverged"] = diverged ? 1.0 : 0.0;
     auto t_f = clk::now();
-    if ((rc = gmg_fetch_solution(h, x))) return rc;
+    if (!diverged && (rc = gmg_fetch_solution(h, x))) return rc;
     h->timing["solve_fetch"] = ms_since(t_f);
     h->timing["iterations"] = it;
     h->timing["residue"] = residue;

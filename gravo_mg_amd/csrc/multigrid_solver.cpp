@@ -250,6 +250,23 @@ void MultigridSolver::solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int s
     double residue = std::numeric_limits<double>::max();
     int rc = gmg_solve(engine_, rhs.data.data(), x.data.data(), rhs.cols(), accuracy, stoppingCriteria, maxIter, &iters, &residue, conv.data());
     if (rc != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
+    // The engine's default smoothers (over-relaxed multicolour sweep on level 0, block-hybrid sweeps below) are not the reference's
+    // Gauss-Seidel and carry no convergence guarantee for every SPD matrix.  If they diverged (x still holds the initial guess),
+    // solve again with Gauss-Seidel in colour order on EVERY level -- the reference's update in a permuted order, convergent for
+    // every SPD matrix -- and keep that configuration for this solver object.
+    double diverged = 0;
+    (void)gmg_get_timing(engine_, "diverged", &diverged);
+    solverTiming["fallback_exact_gs"] = 0.0;
+    if (diverged != 0.0 && (engineConfig.block_rows != 0 || engineConfig.gs_omega != 1.0 || engineConfig.smoother != GMG_SMOOTHER_MULTICOLOR_GS)) {
+        if (verbose) std::cout << "the default smoothers diverged (residue " << residue << "): solving again with Gauss-Seidel on every level\n";
+        engineConfig.smoother = GMG_SMOOTHER_MULTICOLOR_GS;
+        engineConfig.block_rows = 0;
+        engineConfig.gs_omega = 1.0;
+        if (ensureSystem(LHS) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return; }
+        rc = gmg_solve(engine_, rhs.data.data(), x.data.data(), rhs.cols(), accuracy, stoppingCriteria, maxIter, &iters, &residue, conv.data());
+        if (rc != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
+        solverTiming["fallback_exact_gs"] = 1.0;
+    }
     for (int i = 0; i < iters; ++i) {
         convergence.push_back({conv[2 * i], conv[2 * i + 1]});          // :1414
         if (verbose) printf("%d,%f,%.14f \n", i + 1, conv[2 * i], conv[2 * i + 1]);

@@ -11,7 +11,9 @@ What a user of the reference will notice, all of it deliberate (DESIGN.md sectio
   * the smoother is a parallel ordering of the reference's Gauss-Seidel: multicolour sweeps on the finest level, over-relaxed
     by 1.35 (`set_engine_option("gs_omega", 1.0)` gives the reference's update in colour order), block sweeps below.  The
     iterates are therefore not those of lexicographic Gauss-Seidel cycle by cycle; the stopping test and the solution are the
-    same.  V-cycles to 1e-4 on the 3 M-vertex Poisson problem: 4 (reference algorithm: 6; omega = 1: 7);
+    same.  V-cycles to 1e-4 on the 3 M-vertex Poisson problem: 4 (reference algorithm: 6; omega = 1: 7).  Should these smoothers
+    diverge on some matrix, solve() repeats the solve with Gauss-Seidel (colour order) on every level and says so in
+    solver_timing["fallback_exact_gs"];
   * `lhs` may be any scipy sparse format.  CSR and symmetric CSC storage are used in place (no conversion, no copy).
 """
 import numpy as np

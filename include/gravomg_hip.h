@@ -167,7 +167,11 @@ int gmg_vcycle(gmg_handle h, const double* b, double* x, int d);
 /* The MG branch of solve(), multigrid_solver.cpp:1408-1419: do { V-cycle; residualCheck } while
  * (residue > tol && it < max_iter).  x arrives holding the initial guess (the binding passes x0 = rhs,
  * gravomg_bindings/src/cpp/core.cpp:69).  conv (optional) receives (elapsed_ms, residue) pairs and must
- * hold 2*max_iter doubles. */
+ * hold 2*max_iter doubles.  If the iteration DIVERGED (it ended above tol with a residue that is not finite or larger than after the
+ * first cycle) x keeps the initial guess and gmg_get_timing(h, "diverged") is 1: the default smoothers are parallel orderings /
+ * block variants of the reference's Gauss-Seidel without its convergence guarantee; a handle created with block_rows = 0 and
+ * gs_omega = 1 runs Gauss-Seidel in colour order on every level (convergent for every SPD matrix) -- the retry the C++ mirror
+ * (MGBS::MultigridSolver::solve) performs by itself. */
 int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter,
               int* iters_out, double* residue_out, double* conv);
 

@@ -158,6 +158,28 @@ def test_reference_call_pattern_smoothing_and_poisson(gravomg, oracle, tmp_path)
 
 
 @pytest.mark.gpu
+def test_diverging_smoother_falls_back_to_gauss_seidel_on_every_level(gravomg):
+    """The engine's default smoothers carry no convergence guarantee for every SPD matrix; solve() must notice a diverging
+    iteration and repeat it with Gauss-Seidel (colour order) on every level.  Provoked here with an over-relaxed Jacobi smoother."""
+    V, F, S, M, mass = _problem()
+    solver = gravomg.MultigridSolver(V, gravomg.neighbors_from_stiffness(S), M, lower_bound=40, tolerance=1e-4, max_iter=30)
+    lhs = (M * 1e-6 + S).tocsr()
+    rhs = M @ np.random.default_rng(1).standard_normal((V.shape[0], 1))
+    x_ok = solver.solve(lhs, rhs)
+    assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.residual(lhs, rhs, x_ok) <= 1e-4
+    solver.set_engine_option("smoother", 1)             # weighted Jacobi ...
+    solver.set_engine_option("jacobi_omega", 1.95)      # ... far beyond its stability limit
+    x = solver.solve(lhs, rhs)
+    t = solver.solver_timing
+    assert t["fallback_exact_gs"] == 1.0
+    assert t["residue"] <= 1e-4 and solver.residual(lhs, rhs, x) <= 1e-4
+    assert np.sqrt((mass[:, None] * (x - x_ok) ** 2).sum() / (mass[:, None] * x_ok ** 2).sum()) <= 1e-2
+    # the safe configuration is kept for later solves of this object
+    solver.solve(lhs, rhs)
+    assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.solver_timing["residue"] <= 1e-4
+
+
+@pytest.mark.gpu
 def test_system_matrix_storage_formats_give_the_same_answers(gravomg, oracle):
     """The shim maps CSR storage in place, CSC storage of a symmetric matrix too (verified on every entry), and converts
     everything else (COO, ...): same results on every route."""

@@ -373,3 +373,18 @@ def test_device_coarse_apply_against_the_oracle(setup, cabi, oracle):
     xo, ito, reso, _ = O.solve(P.rhs, tol=1e-4)
     assert res <= 1e-4 and it <= ito + 2
     assert abs(oracle.residual_check(P.lhs, P.mass, P.rhs, xs, 2) - res) <= 1e-3 * res + 1e-7
+
+
+def test_diverged_solve_keeps_the_initial_guess_and_says_so(cabi):
+    """gmg_solve: an iteration that ends above the tolerance with a residue larger than after its first cycle (or not finite) must not
+    overwrite x, and reports timing key "diverged" = 1 (include/gravomg_hip.h)."""
+    P = problems.torus_problem(64, 60, "poisson", 60)
+    good = cabi.Engine(); good.set_prolongations(P.U); good.set_mass(P.mass); good.set_system(P.lhs)
+    x, it, res, conv = good.solve(P.rhs, tol=1e-4, max_iter=30)
+    assert res <= 1e-4 and good.timing("diverged") == 0.0
+    bad = cabi.Engine(smoother=cabi.SMOOTHER_JACOBI, jacobi_omega=1.95)
+    bad.set_prolongations(P.U); bad.set_mass(P.mass); bad.set_system(P.lhs)
+    xb, itb, resb, convb = bad.solve(P.rhs, tol=1e-4, max_iter=12)
+    assert not (resb <= 1e-4) and bad.timing("diverged") == 1.0 and itb == 12 and len(convb) == 12
+    assert np.array_equal(np.asarray(xb).reshape(-1), np.asarray(P.rhs).reshape(-1))        # x0 = rhs untouched
+
