@@ -1001,6 +1001,7 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     int rc;
     if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
     const int d = h->loaded_d;
+    HelperScope helper_scope(h);
     for (int i = 0; i < n_cycles; ++i) {
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
         if (stop_type >= 0) {
@@ -1033,6 +1034,7 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     if ((rc = check_norm_type(h, stop_type))) return rc;
     if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle (multigrid_solver.cpp:1411-1417)
     auto t_all = clk::now();
+    HelperScope helper_scope(h);
     if ((rc = gmg_load_problem(h, rhs, x, d))) return rc;
     h->timing["solve_load"] = ms_since(t_all);
     h->timing["coarse_host_ms"] = 0.0;
@@ -1485,7 +1487,24 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, xb.data(), (size_t)n, 1, w.data());
             best = std::min(best, 1e3 * ms_since(t0) / reps);
         }
-        std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve (best of 20 batches of %d)\n", n, f.factor_nnz(), best, reps);
+        double best2 = 1e30, diff = 0.0;
+        {
+            SpinHelper helper;
+            helper.arm();
+            std::vector<double> x2((size_t)n);
+            for (int batch = 0; batch < 20; ++batch) {
+                auto t0 = clk::now();
+                for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, x2.data(), (size_t)n, 1, w.data(), &helper);
+                best2 = std::min(best2, 1e3 * ms_since(t0) / reps);
+            }
+            helper.disarm();
+            for (int i = 0; i < n; ++i) diff = std::max(diff, std::fabs(x2[i] - xb[i]));
+        }
+        long part[3];
+        f.split_report(part);
+        std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread, %.2f us with the helper thread (best of 20 batches of %d; "
+                     "panel entries in the two halves / above them: %ld / %ld / %ld; max |difference| %.1e)\n", n, f.factor_nnz(), best, best2, reps, part[0], part[1],
+                     part[2], diff);
     }
     if (std::getenv("GMG_LDLT_CROSSCHECK")) {
         SparseLDLT g;

@@ -449,9 +449,24 @@ void coarse_host_solve(gmg_handle h, int d) {
     auto t0 = clk::now();
     std::memset(e, 0, sizeof(double) * cnt);
     if (h->coarse_work.size() < (size_t)c.n * d) h->coarse_work.resize((size_t)c.n * d);
-    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data());
+    h->coarse.solve_multi(rc, (size_t)c.n_pad, e, (size_t)c.n_pad, d, h->coarse_work.data(), h->coarse_helper.get());
     h->timing["coarse_host_ms"] += ms_since(t0);
 }
+
+// While one of these is alive the helper thread of the coarsest back-substitution spins (a hand-over costs ~0.2 us instead of a
+// wake-up); outside it sleeps and single solves run both halves on the calling thread.  GMG_LDLT_THREADS=1: never start it.
+struct HelperScope {
+    gmg_handle h;
+    explicit HelperScope(gmg_handle hh) : h(hh) {
+        static const bool off = std::getenv("GMG_LDLT_THREADS") && std::atoi(std::getenv("GMG_LDLT_THREADS")) <= 1;
+        if (off || h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT) { h = nullptr; return; }
+        if (!h->coarse_helper) h->coarse_helper.reset(new SpinHelper());
+        h->coarse_helper->arm();
+    }
+    ~HelperScope() { if (h) h->coarse_helper->disarm(); }
+    HelperScope(const HelperScope&) = delete;
+    HelperScope& operator=(const HelperScope&) = delete;
+};
 
 // the host part of a pending gate (no-op without one).  The word is written even when waiting for rc failed: the stream must
 // not stay blocked.

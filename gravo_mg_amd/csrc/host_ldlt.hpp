@@ -10,9 +10,13 @@
 // engine uses: 3-4x faster factorisation and 2x faster back-substitution on the ~21-entries-per-row Galerkin operators).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <iterator>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "host_sparse.hpp"
@@ -321,6 +325,63 @@ private:
     }
 };
 
+// ---- a second thread for the back-substitution of a V-cycle ------------------------------------------------------
+// One job at a time, handed over through two words the threads spin on (a hand-over costs a cache-line transfer, ~0.1-0.2 us; the
+// worker pool's queue + condition variable would cost tens).  The helper spins only while it is ARMED -- for the duration of a
+// solve -- and sleeps on a condition variable otherwise; run() on an unarmed helper executes the job on the caller.
+class SpinHelper {
+public:
+    SpinHelper() : th_([this] { loop(); }) {}
+    ~SpinHelper() {
+        { std::lock_guard<std::mutex> lk(m_); quit_ = true; }
+        cv_.notify_all();
+        th_.join();
+    }
+    SpinHelper(const SpinHelper&) = delete;
+    SpinHelper& operator=(const SpinHelper&) = delete;
+    void arm() { { std::lock_guard<std::mutex> lk(m_); ++armed_; } cv_.notify_all(); }
+    void disarm() { std::lock_guard<std::mutex> lk(m_); --armed_; }
+    bool armed() const { return armed_.load(std::memory_order_acquire) > 0; }
+    // start fn(arg) on the helper (or run it here when the helper sleeps); wait() returns when it is done
+    void run(void (*fn)(void*), void* arg) {
+        if (!armed()) { fn(arg); inline_ = true; return; }
+        inline_ = false;
+        fn_ = fn; arg_ = arg;
+        go_.store(++ticket_, std::memory_order_release);
+    }
+    void wait() {
+        if (inline_) return;
+        while (done_.load(std::memory_order_acquire) != ticket_) __builtin_ia32_pause();
+    }
+
+private:
+    void loop() {
+        unsigned seen = 0;
+        for (;;) {
+            if (armed_.load(std::memory_order_acquire) <= 0) {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return quit_ || armed_.load(std::memory_order_acquire) > 0; });
+                if (quit_) return;
+                continue;
+            }
+            const unsigned g = go_.load(std::memory_order_acquire);
+            if (g != seen) { seen = g; fn_(arg_); done_.store(g, std::memory_order_release); }
+            else __builtin_ia32_pause();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::atomic<int> armed_{0};
+    bool quit_ = false;
+    void (*fn_)(void*) = nullptr;
+    void* arg_ = nullptr;
+    unsigned ticket_ = 0;
+    bool inline_ = true;
+    alignas(64) std::atomic<unsigned> go_{0};
+    alignas(64) std::atomic<unsigned> done_{0};
+    std::thread th_;           // last member: started when everything above exists
+};
+
 // ---- supernodal LDL^T -------------------------------------------------------------------------------------------
 // Same factorisation, organised by supernodes (runs of columns with identical structure below the diagonal, stored as
 // dense column-major panels) and computed left-looking with dense kernels.  The Galerkin coarsest operator has ~21
@@ -360,28 +421,41 @@ public:
         return acc + (double)idx;
     }
 
+    // scratch of one single-column solve: two gather buffers + two accumulators of length n (zero on entry, zero again on exit)
+    size_t scratch_doubles() const { return 2 * ((size_t)max_rows_ + 1) + 2 * (size_t)n; }
+
     void solve(const double* b, double* x, double* work) const {
-        std::vector<double> t((size_t)max_rows_ + 1);       // own scratch: callable concurrently (the dense-inverse build does)
-        solve_column(b, x, work, t.data());
+        std::vector<double> t(scratch_doubles(), 0.0);       // own scratch: callable concurrently (the dense-inverse build does)
+        solve_column(b, x, work, t.data(), nullptr);
     }
 
     // d right-hand sides (columns b + c*ldb -> x + c*ldx); work: n * d doubles.  Every column is an independent
     // single-column solve (so columns cannot interact and a column's result does not depend on d); with more than one
-    // column they run concurrently on the worker pool -- the factor is read-only and shared.
-    void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work) const {
-        const size_t nt = (size_t)max_rows_ + 1;
-        if (scratch_.size() < nt * (size_t)d) scratch_.resize(nt * (size_t)d);
-        if (d == 1) { solve_column(b, x, work, scratch_.data()); return; }
+    // column they run concurrently on the worker pool -- the factor is read-only and shared.  helper (optional): a second
+    // thread that takes one half of the elimination tree of a single-column solve (same arithmetic with or without it).
+    void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work, SpinHelper* helper = nullptr) const {
+        const size_t nt = scratch_doubles();
+        if (scratch_.size() < nt * (size_t)d) scratch_.resize(nt * (size_t)d, 0.0);
+        if (d == 1) { solve_column(b, x, work, scratch_.data(), helper); return; }
         parallel_ranges(d, d, [&](int c0, int c1, int) {
-            for (int c = c0; c < c1; ++c) solve_column(b + (size_t)c * ldb, x + (size_t)c * ldx, work + (size_t)c * n, scratch_.data() + nt * c);
+            for (int c = c0; c < c1; ++c) solve_column(b + (size_t)c * ldb, x + (size_t)c * ldx, work + (size_t)c * n, scratch_.data() + nt * c, nullptr);
         }, 2);
     }
+
+    // share of the factor (panel entries) in the two halves of the elimination tree / in the part above them
+    void split_report(long out[3]) const { out[0] = split_work_[0]; out[1] = split_work_[1]; out[2] = split_work_[2]; }
 
 private:
     static constexpr int kMaxWidth = 48;        // columns per supernode (panel stays in L1/L2)
     bool symbolic_ready_ = false;
     long nnz_l_ = 0;
     int max_rows_ = 0;                           // longest below-diagonal row structure of a supernode
+    // two-way split of the elimination tree for the back-substitution (plan_split): the supernodes of two sets of disjoint
+    // subtrees, and of the part above them ("top": their common ancestors), each ascending
+    std::vector<int> part_sn_[3];                // [0], [1]: the halves; [2]: top
+    std::vector<int> own_rows_;                  // per supernode of a half: leading rows of its structure that lie inside the half
+    std::vector<int> top_cols_;                  // columns of the top supernodes
+    long split_work_[3] = {0, 0, 0};
     mutable std::vector<double> scratch_;        // gathered right-hand-side rows of one supernode (a handle is not thread-safe)
     std::vector<int> inv_;                       // old -> new
     std::vector<int> Cp_, Ci_;                   // upper triangle of P A P^T by columns (pattern)
@@ -504,7 +578,61 @@ private:
         for (int q = 0; q < ns_; ++q) max_rows_ = std::max(max_rows_, rows_ptr_[q + 1] - rows_ptr_[q]);
         pan_.assign(pan_ptr_[ns_], 0.0);
         D_.assign(n, 0.0);
+        plan_split();
         symbolic_ready_ = true;
+    }
+
+    // Two halves of the elimination tree that can be back-substituted independently.  Start from the roots; while one subtree
+    // holds more than 55 % of what is left, move its root to the "top" part and consider its children instead; then deal the
+    // subtrees to two bins, largest first.  (The etree is postordered: a subtree is a run of supernodes, descendants first.)
+    void plan_split() {
+        std::vector<int> parent(ns_, -1);
+        std::vector<long> work(ns_, 0);
+        std::vector<std::vector<int>> kids(ns_);
+        for (int s = 0; s < ns_; ++s) {
+            const int r = rows_ptr_[s + 1] - rows_ptr_[s], w = sn_first_[s + 1] - sn_first_[s];
+            work[s] = (long)(w + r) * w;
+            if (r > 0) parent[s] = sn_of_[rows_[rows_ptr_[s]]];
+        }
+        std::vector<long> sub(work);
+        for (int s = 0; s < ns_; ++s) if (parent[s] >= 0) { sub[parent[s]] += sub[s]; kids[parent[s]].push_back(s); }
+        std::vector<int> cand;
+        for (int s = 0; s < ns_; ++s) if (parent[s] < 0) cand.push_back(s);
+        std::vector<char> in_top(ns_, 0);
+        for (;;) {
+            long total = 0;
+            int big = -1;
+            for (int c : cand) { total += sub[c]; if (big < 0 || sub[c] > sub[big]) big = c; }
+            if (big < 0 || sub[big] * 100 <= total * 55 || kids[big].empty()) break;
+            in_top[big] = 1;
+            cand.erase(std::find(cand.begin(), cand.end(), big));
+            cand.insert(cand.end(), kids[big].begin(), kids[big].end());
+        }
+        std::sort(cand.begin(), cand.end(), [&](int a, int b2) { return sub[a] != sub[b2] ? sub[a] > sub[b2] : a < b2; });
+        std::vector<int> half(ns_, -1);              // supernode -> 0 / 1, -1 = top
+        long load[2] = {0, 0};
+        std::vector<int> root_half(ns_, -1);
+        for (int c : cand) { const int t = load[1] < load[0] ? 1 : 0; root_half[c] = t; load[t] += sub[c]; }
+        for (int s = ns_ - 1; s >= 0; --s) {          // parents before children
+            if (in_top[s]) continue;
+            half[s] = root_half[s] >= 0 ? root_half[s] : half[parent[s]];
+        }
+        for (auto& v : part_sn_) v.clear();
+        scratch_.clear();                            // (its layout follows max_rows_ / n: the accumulators must start from zero)
+        split_work_[0] = split_work_[1] = split_work_[2] = 0;
+        own_rows_.assign(ns_, 0);
+        top_cols_.clear();
+        for (int s = 0; s < ns_; ++s) {
+            const int t = half[s] < 0 ? 2 : half[s];
+            part_sn_[t].push_back(s);
+            split_work_[t] += work[s];
+            const int* R = rows_.data() + rows_ptr_[s];
+            const int r = rows_ptr_[s + 1] - rows_ptr_[s];
+            int k = 0;
+            if (t < 2) while (k < r && half[sn_of_[R[k]]] == t) ++k;     // ancestors inside the half come first (ascending rows)
+            own_rows_[s] = t < 2 ? k : r;
+            if (t == 2) for (int j = sn_first_[s]; j < sn_first_[s + 1]; ++j) top_cols_.push_back(j);
+        }
     }
 
     // dense kernels, compiled for the baseline ISA and for AVX2+FMA
@@ -633,19 +761,26 @@ private:
 #endif
 #undef GMG_LDLT_KERNELS
 
-    void solve_column(const double* b, double* x, double* y, double* t) const {
-        const bool avx = has_avx2(), avx512 = has_avx512();      // (same source, same order of operations: the three builds give the same bits)
-        for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-        for (int s = 0; s < ns_; ++s) {                          // forward: L z = y
+    // forward substitution over the supernodes of one part, ascending.  Rows of the part itself are updated in place; rows above
+    // it (the top part, shared with the other half) go to this half's accumulator.
+    void forward_part(int part, double* y, double* t, double* acc) const {
+        const bool avx = has_avx2();
+        for (int s : part_sn_[part]) {
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
             const int* R = rows_.data() + rows_ptr_[s];
             const int r = rows_ptr_[s + 1] - rows_ptr_[s];
             const double* P = pan_.data() + pan_ptr_[s];
             if (avx) sn_forward1_avx2(P, w + r, w, r, y + f, t); else sn_forward1_base(P, w + r, w, r, y + f, t);
-            for (int i = 0; i < r; ++i) y[R[i]] -= t[i];
+            const int k = own_rows_[s];
+            for (int i = 0; i < k; ++i) y[R[i]] -= t[i];
+            for (int i = k; i < r; ++i) acc[R[i]] += t[i];
         }
-        for (int j = 0; j < n; ++j) y[j] /= D_[j];
-        for (int s = ns_ - 1; s >= 0; --s) {                     // backward: L^T x = z
+    }
+    void backward_part(int part, double* y, double* t) const {
+        const bool avx = has_avx2();
+        const std::vector<int>& list = part_sn_[part];
+        for (size_t q = list.size(); q-- > 0;) {
+            const int s = list[q];
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
             const int* R = rows_.data() + rows_ptr_[s];
             const int r = rows_ptr_[s + 1] - rows_ptr_[s];
@@ -653,6 +788,34 @@ private:
             for (int i = 0; i < r; ++i) t[i] = y[R[i]];
             if (avx) sn_backward1_avx2(P, w + r, w, r, y + f, t); else sn_backward1_base(P, w + r, w, r, y + f, t);
         }
+    }
+
+    // One column.  L z = y runs over the two halves of the elimination tree (independent: a column's structure lies on its path
+    // to the root), whose contributions to the rows above them are accumulated per half and subtracted in a fixed order, then
+    // over the top part; L^T x = z the other way round.  The arithmetic does not depend on whether `helper` executes the second
+    // half concurrently or this thread does both.  t: scratch_doubles() doubles, accumulators zero on entry and on exit.
+    struct HalfJob { const SupernodalLDLT* self; double *y, *t, *acc; bool forward; };
+    static void run_half(void* p) {
+        HalfJob* j = (HalfJob*)p;
+        if (j->forward) j->self->forward_part(1, j->y, j->t, j->acc); else j->self->backward_part(1, j->y, j->t);
+    }
+    void solve_column(const double* b, double* x, double* y, double* t, SpinHelper* helper) const {
+        const size_t nt = (size_t)max_rows_ + 1;
+        double *t0 = t, *t1 = t + nt, *acc0 = t + 2 * nt, *acc1 = acc0 + n;
+        for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+        HalfJob job{this, y, t1, acc1, true};
+        const bool two = helper && !part_sn_[1].empty();
+        if (two) helper->run(run_half, &job); else run_half(&job);
+        forward_part(0, y, t0, acc0);
+        if (two) helper->wait();
+        for (int c : top_cols_) { y[c] = (y[c] - acc0[c]) - acc1[c]; acc0[c] = 0.0; acc1[c] = 0.0; }
+        forward_part(2, y, t0, nullptr);
+        for (int j = 0; j < n; ++j) y[j] /= D_[j];
+        backward_part(2, y, t0);
+        job.forward = false;
+        if (two) helper->run(run_half, &job); else run_half(&job);
+        backward_part(0, y, t0);
+        if (two) helper->wait();
         for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     }
 
