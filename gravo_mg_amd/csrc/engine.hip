@@ -126,6 +126,7 @@ void gmg_destroy(gmg_handle h) {
         for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)dev_free(*p);
         if (h->h_pinned) (void)hipHostFree(h->h_pinned);
         for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]); if (h->h_stage_ev[i]) (void)hipEventDestroy(h->h_stage_ev[i]); }
+        for (hipEvent_t& e : h->h_chunk_ev) if (e) (void)hipEventDestroy(e);
         if (h->h_norm) (void)hipHostFree(h->h_norm);
         if (h->h_flag) (void)hipHostFree(h->h_flag);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -969,21 +970,27 @@ int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) try
     if ((rc = ensure_vectors(h, d))) return rc;
     h->timing["load_vectors"] = ms_since(tl); tl = clk::now();
     Level& l = h->lv[0];
-    if ((rc = to_device(h, 0, b, d, l.b))) return rc;
-    h->timing["load_b"] = ms_since(tl); tl = clk::now();
     // The reference's Python API always starts from x0 = rhs (gravomg_bindings/src/cpp/core.cpp:69): when the initial guess IS
     // the right-hand side (same buffer, or the same content -- one threaded comparison, far cheaper than a second trip over
-    // PCIe), it is copied on the device instead of being uploaded again.
+    // PCIe), it is copied on the device instead of being uploaded again.  The comparison runs beside the upload of b.
     bool same = x0 == b;
+    std::future<bool> compared;
     if (!same) {
         const size_t cnt = (size_t)l.n * d;
-        std::atomic<bool> differ{false};
-        parallel_ranges((int)std::min<size_t>(cnt >> 12, 1 << 20) + 1, std::min(h->cfg.host_threads, 16), [&](int lo, int hi, int) {
-            const size_t a = (size_t)lo << 12, e = std::min(cnt, (size_t)hi << 12);
-            if (a < e && !differ.load(std::memory_order_relaxed) && std::memcmp(b + a, x0 + a, sizeof(double) * (e - a)) != 0) differ = true;
-        }, 2);
-        same = !differ.load();
+        const int threads = std::min(h->cfg.host_threads, 16);
+        compared = std::async(std::launch::async, [b, x0, cnt, threads] {
+            std::atomic<bool> differ{false};
+            parallel_ranges((int)std::min<size_t>(cnt >> 12, 1 << 20) + 1, threads, [&](int lo, int hi, int) {
+                const size_t a = (size_t)lo << 12, e = std::min(cnt, (size_t)hi << 12);
+                if (a < e && !differ.load(std::memory_order_relaxed) && std::memcmp(b + a, x0 + a, sizeof(double) * (e - a)) != 0) differ = true;
+            }, 2);
+            return !differ.load();
+        });
     }
+    rc = to_device(h, 0, b, d, l.b);
+    if (compared.valid()) same = compared.get();          // (joined before any return: the task reads the caller's arrays)
+    if (rc) return rc;
+    h->timing["load_b"] = ms_since(tl); tl = clk::now();
     if (same) HIPCHK(hipMemcpyAsync(l.x, l.b, sizeof(double) * (size_t)l.n_pad * d, hipMemcpyDeviceToDevice, h->stream));
     else if ((rc = to_device(h, 0, x0, d, l.x))) return rc;
     h->timing["load_x"] = ms_since(tl); tl = clk::now();

@@ -356,6 +356,11 @@ inline void threaded_copy(double* dst, const double* src, size_t n, int threads)
     }, 1);
 }
 
+// Vectors cross PCIe in chunks so that the host's copy between the caller's (pageable) array and the pinned staging buffer overlaps
+// the DMA of the neighbouring chunk: 24 MB took ~0.35 ms of copy + ~0.5 ms of DMA one after the other.
+constexpr int kXferChunks = 6;
+inline size_t xfer_chunk(size_t cnt) { return std::max<size_t>((cnt + kXferChunks - 1) / kXferChunks, (size_t)1 << 17); }
+
 // host natural n x d  ->  device numbering (level k) buffer
 int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
     Level& l = h->lv[k];
@@ -366,8 +371,12 @@ int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
     const int f = h->h_stage_flip;
     h->h_stage_flip ^= 1;
     HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));          // the previous DMA out of this staging buffer is done
-    threaded_copy(h->h_stage[f], src, cnt, h->cfg.host_threads);
-    HIPCHK(hipMemcpyAsync(h->d_stage, h->h_stage[f], sizeof(double) * cnt, hipMemcpyHostToDevice, h->stream));
+    const size_t ch = xfer_chunk(cnt);
+    for (size_t off = 0; off < cnt; off += ch) {
+        const size_t len = std::min(ch, cnt - off);
+        threaded_copy(h->h_stage[f] + off, src + off, len, h->cfg.host_threads);
+        HIPCHK(hipMemcpyAsync(h->d_stage + off, h->h_stage[f] + off, sizeof(double) * len, hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(hipEventRecord(h->h_stage_ev[f], h->stream));
     hipLaunchKernelGGL(gmgk::permute_in, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.n, l.d_new2old, dst, l.n_pad, l.n_pad, d);
     // d_stage is reused by the next call: order is guaranteed by the single stream
@@ -384,9 +393,21 @@ int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
     h->h_stage_flip ^= 1;
     HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));
     hipLaunchKernelGGL(gmgk::permute_out, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, src, l.n_pad, l.n_pad, l.d_new2old, h->d_stage, l.n, d);
-    HIPCHK(hipMemcpyAsync(h->h_stage[f], h->d_stage, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
+    const size_t ch = xfer_chunk(cnt);
+    int nch = 0;
+    for (size_t off = 0; off < cnt; off += ch, ++nch) {
+        const size_t len = std::min(ch, cnt - off);
+        if (!h->h_chunk_ev[nch]) HIPCHK(hipEventCreateWithFlags(&h->h_chunk_ev[nch], hipEventDisableTiming));
+        HIPCHK(hipMemcpyAsync(h->h_stage[f] + off, h->d_stage + off, sizeof(double) * len, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->h_chunk_ev[nch], h->stream));
+    }
+    nch = 0;
+    for (size_t off = 0; off < cnt; off += ch, ++nch) {
+        const size_t len = std::min(ch, cnt - off);
+        HIPCHK(hipEventSynchronize(h->h_chunk_ev[nch]));
+        threaded_copy(dst + off, h->h_stage[f] + off, len, h->cfg.host_threads);
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
-    threaded_copy(dst, h->h_stage[f], cnt, h->cfg.host_threads);
     return GMG_OK;
 }
 

@@ -148,6 +148,7 @@ struct gmg_solver_s {
     void* bounce[2] = {nullptr, nullptr};                                  // pinned bounce buffers for the set-up's pageable copies
     hipEvent_t bounce_ev[2] = {nullptr, nullptr}; int bounce_flip = 0;
     hipEvent_t h_stage_ev[2] = {nullptr, nullptr}; int h_stage_flip = 0;
+    hipEvent_t h_chunk_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // per-chunk arrival of a download (to_host)
     double* d_partials = nullptr; int partial_blocks = 0;
     double* d_norm = nullptr;
     double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
