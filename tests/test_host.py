@@ -280,3 +280,32 @@ def test_host_ldlt_many_right_hand_sides_and_galerkin_operator(cabi):
         assert np.array_equal(X[:, c], x1)
         assert np.linalg.norm(X[:, c] - lu.solve(B[:, c])) <= 1e-10 * np.linalg.norm(X[:, c])
     assert nnzL > A.nnz // 2
+
+
+def test_host_ldlt_two_thread_back_substitution_gives_the_same_bits():
+    """The coarsest back-substitution runs the two halves of the elimination tree on two threads inside a solve (SpinHelper); the
+    arithmetic must not depend on whether the helper takes the second half.  The library's timing aid (GMG_LDLT_BENCH) solves both
+    ways and prints the largest difference."""
+    import os
+    import re
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, scipy.sparse as sp\n"
+        "from gravo_mg_amd import cabi\n"
+        "m = 70\n"
+        "T = sp.diags([-1.0, 2.3, -1.0], [-1, 0, 1], shape=(m, m))\n"
+        "A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()\n"
+        "b = np.random.default_rng(3).standard_normal(m * m)\n"
+        "x, nnz = cabi.host_ldlt_solve(A, b)\n"
+        "print('residual', float(np.linalg.norm(A @ x - b) / np.linalg.norm(b)))\n")
+    env = dict(os.environ, GMG_LDLT_BENCH="3")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m1 = re.search(r"two halves / above them: (\d+) / (\d+) / (\d+); max \|difference\| ([0-9.e+-]+)", out.stderr)
+    assert m1, out.stderr[-2000:]
+    a, b2, top, diff = int(m1.group(1)), int(m1.group(2)), int(m1.group(3)), float(m1.group(4))
+    assert diff == 0.0
+    assert a > 0 and b2 > 0 and min(a, b2) >= 0.5 * max(a, b2), (a, b2, top)       # a real split, reasonably balanced
+    assert float(re.search(r"residual ([0-9.e+-]+)", out.stdout).group(1)) <= 1e-10
