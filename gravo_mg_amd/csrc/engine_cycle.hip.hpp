@@ -39,6 +39,24 @@ template <> struct Prec<float> {
     static float* tmp(Level& l) { return l.tmp32; }
 };
 
+// The last colour launch of the cycle's last level-0 sweep also forms its rows' share of the residual check (gs_color_norm) when
+// the cycle being enqueued ends with one (h->fuse_norm_type, set by vcycle_legs): fp64, one group of <= 4 columns, >= 2 colours.
+// Its partial sums go behind the ones the norm kernel will write for the rows of the other colours (launch_norm).
+template <class T>
+bool fold_norm(gmg_handle, Level&, int, bool, int, int) { return false; }
+template <>
+bool fold_norm<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, int se) {
+    if (!last_launch || h->fuse_norm_type < 0 || &l != &h->lv[0] || d > 4 || l.ord.n_colors < 2 || se != l.Aoff.n_slices) return false;
+    const int type = h->fuse_norm_type;
+    const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
+    const int nblk = grid_for(se - sb), first = norm_grid(sb);
+    if ((size_t)(first + nblk) > (size_t)h->partial_blocks) return false;
+    DISPATCH_D(d, hipLaunchKernelGGL((gmgk::gs_color_norm<D>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag,
+                                     l.b, l.x, l.n_pad, sb, se, h->cfg.gs_omega, w, h->d_partials + (size_t)first * 2 * d));
+    h->fuse_norm_blocks = nblk;
+    return true;
+}
+
 template <class T>
 void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
@@ -52,6 +70,7 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
             for (int c = 0; c < l.ord.n_colors; ++c) {
                 int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
                 if (se <= sb) continue;
+                if (fold_norm<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
                 if (fine) {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
@@ -254,14 +273,18 @@ void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
 int launch_norm(gmg_handle h, int d, int type) {
     Level& l = h->lv[0];
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nblk = norm_grid(l.Aoff.n_slices);         // one slice per wave, like the residual SpMV; one partial per block of 16
+    // (rows of the last colour: already summed by the cycle's last colour launch when it was folded in, fold_norm)
+    const int folded = h->fuse_norm_blocks;
+    h->fuse_norm_blocks = 0;
+    const int n_slices = folded ? l.ord.color_begin[l.ord.n_colors - 1] / 64 : l.Aoff.n_slices;
+    const int nblk = norm_grid(n_slices);                // one slice per wave, like the residual SpMV; one partial per block of 16
     const bool poll = polled(h);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream, l.Aoff.slice_ptr,
                                           l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
-                                          l.n_pad, l.Aoff.n_slices, (float*)nullptr, h->d_partials));
-        launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
+                                          l.n_pad, n_slices, (float*)nullptr, h->d_partials));
+        launch_reduce(h, nblk + folded, dc, c0, c0 + 4 >= d);
     }
     if (!poll) HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
     return GMG_OK;
@@ -589,6 +612,9 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
     int rc;
     const int nt = norm_type < 0 ? 9 : norm_type;
     constexpr bool mixed = sizeof(T) == 4;
+    // the residual check's sums over the rows of the last colour come out of the last colour launch of the post-smoothing
+    static const bool no_fold = std::getenv("GMG_NO_NORM_FOLD") != nullptr;      // A/B aid
+    const bool foldable = !mixed && !no_fold && norm_type >= 0 && h->cfg.post_iters > 0 && h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS && !h->lv[0].ord.blocked;
     // mixed precision: the fp32 cycle starts from a zero guess on the defect b32 = b - A x (already in place), its
     // result is added to the fp64 iterate, and the new defect + its norms are formed in one fp64 pass
     auto head = [&] { if (mixed) (void)hipMemsetAsync(h->lv[0].x32, 0, sizeof(float) * (size_t)h->lv[0].n_pad * d, h->stream); };
@@ -605,7 +631,9 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
             head();
             enqueue_down<T>(h, d);
             enqueue_coarse_device<T>(h, d);
+            h->fuse_norm_type = foldable ? norm_type : -1;
             enqueue_up<T>(h, d);
+            h->fuse_norm_type = -1;
             tail(err);
         });
         return rc ? rc : err;
@@ -614,7 +642,9 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
     if ((rc = coarse_host_begin<T>(h, d))) return rc;              // (polled: the way up is enqueued behind a gate the host opens in _serve)
     int err = GMG_OK;
     rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
+        h->fuse_norm_type = foldable ? norm_type : -1;
         enqueue_up<T>(h, d);
+        h->fuse_norm_type = -1;
         tail(err);
     });
     const int served = coarse_host_serve(h);

@@ -115,6 +115,57 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
     }
 }
 
+// The LAST colour launch of a V-cycle's post-smoothing, when a residual check follows: the same update, plus this colour's share of
+// the check's sums.  Right after its update a row's residual needs no second pass over the matrix: the off-diagonal sum is in
+// registers and no later launch changes x before the check, so r_i = sum_{j != i} a_ij x_j + a_ii x_i^new - b_i is exactly the value
+// (same expression, same operands) the norm kernel would compute -- which then only visits the rows of the other colours (a quarter
+// less of its 336 MB at four colours).  (The algebraic shortcut r_i = a_ii (1 - omega)(x_i^GS - x_i^old) is NOT used: near the
+// attainable accuracy it under-reports the residue, 5.9e-8 for a true 6.2e-8 on a 7 680-vertex Poisson problem.)  partials[blockIdx][2 D] = sum w r^2 / sum w b^2 over the block's rows (zeros for blocks
+// beyond the range), added by reduce_partials after the norm kernel's own.
+template <int D>
+__global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                        const double* __restrict__ val, const double* __restrict__ diag,
+                                                        const double* __restrict__ b, double* x, int ld, int slice_begin, int slice_end,
+                                                        double omega, const double* __restrict__ weight, double* __restrict__ partials) {
+    __shared__ double red[kWavesPerBlock][2 * D];
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double sums[2 * D];
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) sums[c] = 0.0;
+    if (s < slice_end) {
+        const int row = s * 64 + lane;
+        double acc[D];
+        row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        const double dg = diag[row];
+        const double w = weight ? weight[row] : 1.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const double bi = b[row + (int64_t)c * ld];
+            const double xi = x[row + (int64_t)c * ld];
+            const double xn = omega == 1.0 ? (bi - acc[c]) / dg : xi + omega * ((bi - acc[c]) / dg - xi);
+            x[row + (int64_t)c * ld] = xn;
+            const double r = acc[c] + dg * xn - bi;                  // the expression of residual_norm_slices, on the same operands
+            sums[2 * c] = (r * w) * r;
+            sums[2 * c + 1] = (bi * w) * bi;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * D; ++c) {
+        double v = sums[c];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][c] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+        double v = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < kWavesPerBlock; ++w2) v += red[w2][threadIdx.x];
+        partials[(int64_t)blockIdx.x * (2 * D) + threadIdx.x] = v;
+    }
+}
+
 // Block-hybrid Gauss-Seidel sweep, ONE launch per sweep (coarse levels, where a launch per colour is
 // latency-bound: 13-18 colours on the Galerkin operators).
 //   * one workgroup (up to 1024 rows = 16 wavefronts) per compact block of rows (host_plan.hpp);
