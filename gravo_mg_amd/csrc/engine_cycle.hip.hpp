@@ -505,6 +505,7 @@ struct HelperScope {
         static const bool off = std::getenv("GMG_LDLT_THREADS") && std::atoi(std::getenv("GMG_LDLT_THREADS")) <= 1;
         if (off || h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT) { h = nullptr; return; }
         if (!h->coarse_helper) h->coarse_helper.reset(new SpinHelper());
+        h->coarse_helper->stay_near_caller();
         h->coarse_helper->arm();
     }
     ~HelperScope() { if (h) h->coarse_helper->disarm(); }
