@@ -503,7 +503,10 @@ struct HelperScope {
     gmg_handle h;
     explicit HelperScope(gmg_handle hh) : h(hh) {
         static const bool off = std::getenv("GMG_LDLT_THREADS") && std::atoi(std::getenv("GMG_LDLT_THREADS")) <= 1;
-        if (off || h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT) { h = nullptr; return; }
+        // (every rank of a multi-GPU job would keep two threads busy -- this one polls -- on the CPUs the job may use: no helper
+        // unless there are at least three per rank, a throttled spinning thread costs far more than it saves)
+        const int ranks = h->dist_ready ? std::max(1, h->world) : 1;
+        if (off || h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT || cpu_budget() < 3 * ranks) { h = nullptr; return; }
         if (!h->coarse_helper) h->coarse_helper.reset(new SpinHelper());
         h->coarse_helper->stay_near_caller();
         h->coarse_helper->arm();
