@@ -57,6 +57,19 @@ bool fold_norm<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, 
     return true;
 }
 
+// ... and the last colour launch of the level-0 PRE-smoothing writes the residual of its rows (gs_color_residual) when the way
+// down asks for it (h->fuse_res_out, set by enqueue_down); launch_spmv then covers the slices in front of that colour only.
+template <class T>
+bool fold_residual(gmg_handle, Level&, int, bool, int, int) { return false; }
+template <>
+bool fold_residual<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, int se) {
+    if (!last_launch || !h->fuse_res_out || &l != &h->lv[0] || d > 4 || l.ord.n_colors < 2 || se != l.Aoff.n_slices || sb <= 0) return false;
+    DISPATCH_D(d, hipLaunchKernelGGL((gmgk::gs_color_residual<D>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col,
+                                     l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega));
+    h->fuse_res_from = sb;
+    return true;
+}
+
 template <class T>
 void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const int ld = l.n_pad;
@@ -71,6 +84,7 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
                 int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
                 if (se <= sb) continue;
                 if (fold_norm<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
+                if (fold_residual<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
                 if (fine) {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
@@ -174,25 +188,26 @@ void launch_smooth(gmg_handle h, Level& l, int d, int iters, bool from_zero = fa
 
 // y = A x (mode 0) or y = b - A x (mode 1)
 template <class T, int LPR>
-void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
+void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y, int n_slices = -1) {
     const int ld = l.n_pad;
+    if (n_slices < 0) n_slices = l.Aoff.n_slices;
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         if (mode == 1) {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
-                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
+                                              y + (size_t)c0 * ld, ld, 0, n_slices, 1));
         } else {
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, LPR>), dim3(grid_for(l.Aoff.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, LPR>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                               l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
-                                              y + (size_t)c0 * ld, ld, 0, l.Aoff.n_slices, 1));
+                                              y + (size_t)c0 * ld, ld, 0, n_slices, 1));
         }
     }
 }
 template <class T>
-void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y) {
-    if (l.Aoff.lpr == 4) launch_spmv_lpr<T, 4>(h, l, d, mode, b, x, y);
-    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y);
+void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y, int n_slices = -1) {
+    if (l.Aoff.lpr == 4) launch_spmv_lpr<T, 4>(h, l, d, mode, b, x, y, n_slices);
+    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y, n_slices);
 }
 
 // coarse.b = U^T fine.r
@@ -443,8 +458,15 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         Level& l = h->lv[k];
         const bool from_zero = k > 0 && smooth_from_zero_ok(h, l, h->cfg.pre_iters);      // eps.setZero (:1072-1073) folded into the first sweep
         if (k > 0 && !from_zero) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);
+        // level 0, fp64: the last colour launch of the pre-smoothing also writes the residual of its rows (fold_residual)
+        static const bool no_fold = std::getenv("GMG_NO_NORM_FOLD") != nullptr;
+        if (k == 0 && sizeof(T) == 8 && !no_fold) h->fuse_res_out = h->lv[0].r;
+        h->fuse_res_from = 0;
         launch_smooth<T>(h, l, d, h->cfg.pre_iters, from_zero);                                     // :1063
-        launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l));                    // :1066
+        h->fuse_res_out = nullptr;
+        const int res_slices = (k == 0 && h->fuse_res_from > 0) ? h->fuse_res_from : -1;
+        h->fuse_res_from = 0;
+        launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices);        // :1066
         launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
     }
 }

@@ -158,6 +158,9 @@ struct gmg_solver_s {
     // residual check folded into the last colour launch of the post-smoothing (engine_cycle.hip.hpp): type of the check the cycle
     // being enqueued ends with (-1: none / not foldable), and the number of partial-sum blocks that launch produced (0: it did not)
     int fuse_norm_type = -1, fuse_norm_blocks = 0;
+    // the same for the residual after the pre-smoothing: where the last colour launch shall write its rows' residual (null: nowhere),
+    // and the first slice it covered (0: it did not)
+    double* fuse_res_out = nullptr; int fuse_res_from = 0;
     unsigned long long* h_flag = nullptr; unsigned long long flag_seq[3] = {0, 0, 0};
     // h_flag[16]: written by the HOST -- the stream waits on it (hipStreamWaitValue64) in front of the work that needs the host's
     // coarsest solution, so that work is enqueued before the host solves (engine_cycle.hip.hpp::coarse_host_begin / _serve)

@@ -166,6 +166,33 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
     }
 }
 
+// The LAST colour launch of the pre-smoothing: the same update, plus the residual r_i = b_i - (sum_{j != i} a_ij x_j + a_ii x_i^new) of
+// its own rows -- the expression of spmv_full<MODE 1> on the same operands (no later launch changes x before the residual), so the
+// residual kernel only visits the rows of the other colours.
+template <int D>
+__global__ __launch_bounds__(kBlock) void gs_color_residual(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+                                                            const double* __restrict__ val, const double* __restrict__ diag,
+                                                            const double* __restrict__ b, double* x, double* __restrict__ r, int ld,
+                                                            int slice_begin, int slice_end, double omega) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
+    if (s >= slice_end) return;
+    const int lane = threadIdx.x & 63;
+    const int row = s * 64 + lane;
+    double acc[D];
+    row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    const double dg = diag[row];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double bi = b[row + (int64_t)c * ld];
+        double xn;
+        if (omega == 1.0) xn = (bi - acc[c]) / dg;
+        else { const double xi = x[row + (int64_t)c * ld]; xn = xi + omega * ((bi - acc[c]) / dg - xi); }
+        x[row + (int64_t)c * ld] = xn;
+        const double ax = acc[c] + dg * xn;
+        r[row + (int64_t)c * ld] = bi - ax;
+    }
+}
+
 // Block-hybrid Gauss-Seidel sweep, ONE launch per sweep (coarse levels, where a launch per colour is
 // latency-bound: 13-18 colours on the Galerkin operators).
 //   * one workgroup (up to 1024 rows = 16 wavefronts) per compact block of rows (host_plan.hpp);
