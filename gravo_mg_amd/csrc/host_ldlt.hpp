@@ -394,8 +394,12 @@ public:
         fn_ = fn; arg_ = arg;
         go_.store(++ticket_, std::memory_order_release);
     }
+    // Whoever claims the job runs it: if the helper has not picked it up by the time the caller is done with its own half (the
+    // helper may have lost its core to another thread for a scheduler tick -- milliseconds), the caller does it itself.
     void wait() {
         if (inline_) return;
+        unsigned expected = ticket_ - 1;
+        if (claim_.compare_exchange_strong(expected, ticket_, std::memory_order_acq_rel)) { fn_(arg_); return; }
         while (done_.load(std::memory_order_acquire) != ticket_) __builtin_ia32_pause();
     }
 
@@ -410,8 +414,11 @@ private:
                 continue;
             }
             const unsigned g = go_.load(std::memory_order_acquire);
-            if (g != seen) { seen = g; fn_(arg_); done_.store(g, std::memory_order_release); }
-            else __builtin_ia32_pause();
+            if (g != seen) {
+                seen = g;
+                unsigned expected = g - 1;
+                if (claim_.compare_exchange_strong(expected, g, std::memory_order_acq_rel)) { fn_(arg_); done_.store(g, std::memory_order_release); }
+            } else __builtin_ia32_pause();
         }
     }
     std::mutex m_;
@@ -425,6 +432,7 @@ private:
     int near_cpu_ = -1;
     alignas(64) std::atomic<unsigned> go_{0};
     alignas(64) std::atomic<unsigned> done_{0};
+    alignas(64) std::atomic<unsigned> claim_{0};
     std::thread th_;           // last member: started when everything above exists
 };
 
