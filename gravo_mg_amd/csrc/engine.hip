@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,7 @@
 #include "host_sparse.hpp"
 #include "kernels.hip.hpp"
 #include "setup_kernels.hip.hpp"
+#include "hierarchy_kernels.hip.hpp"
 
 using namespace gmg;
 using clk = std::chrono::steady_clock;
@@ -1350,6 +1352,92 @@ int gmg_hierarchy_options_default(gmg_hierarchy_options* o) try {
     return GMG_OK;
 } GMG_CATCH_0
 
+// Device stage of the hierarchy builder (HierarchyOptions::device_select): uploads one level's selection inputs, runs
+// gmgh::select_parents, downloads the per-point records.  A hierarchy is built before any handle exists, so the stage keeps its
+// own stream and two pinned bounce buffers (process-wide, created on first use, one build at a time): the big arrays -- positions
+// in, 38 bytes per point out -- cross PCIe in 16 MB pieces with worker threads copying the neighbouring piece between pageable
+// memory and the bounce buffer (threaded first touch of the 110 MB result included).  Returns false (the host loop does the level)
+// on any HIP failure.
+namespace {
+struct HierarchyXfer {
+    std::mutex m;
+    hipStream_t st = nullptr;
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ok = false, tried = false;
+    bool ready() {
+        if (tried) return ok;
+        tried = true;
+        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipHostMalloc(&buf[i], kBounceBytes, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        return ok;
+    }
+    bool up(void* dst, const void* src, size_t bytes, int threads) {
+        int f = 0;
+        for (size_t off = 0; off < bytes; off += kBounceBytes, f ^= 1) {
+            const size_t len = std::min(kBounceBytes, bytes - off);
+            if (hipEventSynchronize(ev[f]) != hipSuccess) return false;
+            threaded_copy_bytes(buf[f], (const char*)src + off, len, threads);
+            if (hipMemcpyAsync((char*)dst + off, buf[f], len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(ev[f], st) != hipSuccess) return false;
+        }
+        return true;
+    }
+    bool down(void* dst, const void* src, size_t bytes, int threads) {
+        const size_t nchunk = (bytes + kBounceBytes - 1) / kBounceBytes;
+        auto issue = [&](size_t c) {
+            const int f = (int)(c & 1);
+            const size_t off = c * kBounceBytes, len = std::min(kBounceBytes, bytes - off);
+            return hipMemcpyAsync(buf[f], (const char*)src + off, len, hipMemcpyDeviceToHost, st) == hipSuccess && hipEventRecord(ev[f], st) == hipSuccess;
+        };
+        if (hipEventSynchronize(ev[0]) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess) return false;
+        if (nchunk && !issue(0)) return false;
+        for (size_t c = 0; c < nchunk; ++c) {
+            if (c + 1 < nchunk && !issue(c + 1)) return false;
+            const int f = (int)(c & 1);
+            const size_t off = c * kBounceBytes, len = std::min(kBounceBytes, bytes - off);
+            if (hipEventSynchronize(ev[f]) != hipSuccess) return false;
+            threaded_copy_bytes((char*)dst + off, buf[f], len, threads);
+        }
+        return true;
+    }
+};
+HierarchyXfer& hierarchy_xfer() { static HierarchyXfer* x = new HierarchyXfer(); return *x; }      // (leaked: no destruction order problems at exit)
+}  // namespace
+
+static bool hierarchy_select_on_device(const HierarchyOptions::SelectJob& j) {
+    HierarchyXfer& X = hierarchy_xfer();
+    std::lock_guard<std::mutex> lock(X.m);
+    if (!X.ready()) return false;
+    const int threads = std::min(hw_threads(), 16);
+    // one device allocation for the whole job, carved into 256-byte aligned pieces
+    const size_t nf = (size_t)j.nf, nc = (size_t)j.nc;
+    const size_t sizes[14] = {sizeof(double) * 3 * nf, sizeof(double) * 3 * nc, sizeof(int) * nf, j.nested ? sizeof(int) * nc : 0, sizeof(int) * (nc + 1),
+                              sizeof(int) * (size_t)j.cadj_ptr[nc], sizeof(int) * 3 * (size_t)j.ntri, sizeof(int) * (nc + 1), sizeof(int) * (size_t)j.tof_ptr[nc],
+                              sizeof(int) * nc * (size_t)j.Kc, nf, nf, sizeof(int) * 3 * nf, sizeof(double) * 3 * nf};
+    size_t offs[15] = {0};
+    for (int i = 0; i < 14; ++i) offs[i + 1] = offs[i] + (sizes[i] + 255) / 256 * 256;
+    char* arena = nullptr;
+    if (hipMalloc((void**)&arena, std::max<size_t>(offs[14], 256)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const void* srcs[10] = {j.P, j.Pc, j.nearest, j.sample, j.cadj_ptr, j.cadj, j.tris, j.tof_ptr, j.tof, j.NBc};
+    bool ok = true;
+    for (int i = 0; i < 10 && ok; ++i) ok = sizes[i] == 0 || X.up(arena + offs[i], srcs[i], sizes[i], threads);
+    if (ok) {
+        hipLaunchKernelGGL(gmgh::select_parents, dim3((unsigned)((nf + 127) / 128)), dim3(128), 0, X.st, j.nf, j.Kc, j.weighting, j.nested,
+                           (const double*)(arena + offs[0]), (const double*)(arena + offs[1]), (const int*)(arena + offs[2]), (const int*)(arena + offs[3]),
+                           (const int*)(arena + offs[4]), (const int*)(arena + offs[5]), (const int*)(arena + offs[6]), (const int*)(arena + offs[7]),
+                           (const int*)(arena + offs[8]), (const int*)(arena + offs[9]), (unsigned char*)(arena + offs[10]), (unsigned char*)(arena + offs[11]),
+                           (int*)(arena + offs[12]), (double*)(arena + offs[13]));
+        ok = hipGetLastError() == hipSuccess && X.down(j.cnt, arena + offs[10], nf, threads) && X.down(j.kind, arena + offs[11], nf, threads) &&
+             X.down(j.col, arena + offs[12], sizeof(int) * 3 * nf, threads) && X.down(j.w, arena + offs[13], sizeof(double) * 3 * nf, threads);
+    }
+    (void)hipStreamSynchronize(X.st);          // nothing of this job may still be in flight when its buffers go
+    (void)hipFree(arena);
+    if (!ok) (void)hipGetLastError();
+    return ok;
+}
+
 int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt, gmg_hierarchy* out) try {
     if (!pos || !neigh || n <= 0 || K <= 0 || !out) return GMG_ERR_INVALID;
     gmg_hierarchy_options o;
@@ -1359,8 +1447,30 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     for (size_t i = 0; i < (size_t)n * K; ++i) if (neigh[i] >= n) return GMG_ERR_INVALID;
     HierarchyOptions ho;
     ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting;
+    // the per-point selection stage runs on the GPU when there is one (same bits as the host loop; GMG_HIERARCHY_DEVICE=0: host only)
+    {
+        const char* env = std::getenv("GMG_HIERARCHY_DEVICE");
+        int ndev = 0;
+        if (!(env && std::atoi(env) == 0) && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ho.device_select = hierarchy_select_on_device;
+        else (void)hipGetLastError();
+    }
+    // first use in a process: runtime start-up, code object load and the pinned buffers (~80 ms) happen beside the sequential
+    // sampling / clustering sweeps of the first level instead of in front of the device stage
+    std::future<void> device_warm;
+    if (ho.device_select)
+        device_warm = std::async(std::launch::async, [] {
+            HierarchyXfer& X = hierarchy_xfer();
+            std::lock_guard<std::mutex> lock(X.m);
+            if (!X.ready()) return;
+            hipLaunchKernelGGL(gmgh::select_parents, dim3(1), dim3(128), 0, X.st, 0, 0, 0, 0, (const double*)nullptr, (const double*)nullptr, (const int*)nullptr,
+                               (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                               (const int*)nullptr, (const int*)nullptr, (unsigned char*)nullptr, (unsigned char*)nullptr, (int*)nullptr, (double*)nullptr);
+            (void)hipStreamSynchronize(X.st);
+            (void)hipGetLastError();
+        });
     gmg_hierarchy hh = new gmg_hierarchy_s();
     hh->res = HierarchyBuilder::build(pos, n, neigh, K, ho);
+    if (device_warm.valid()) device_warm.get();
     *out = hh;
     return GMG_OK;
 } GMG_CATCH_0

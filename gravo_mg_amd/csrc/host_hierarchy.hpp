@@ -42,6 +42,29 @@ struct HierarchyOptions {
     bool check_voronoi = true;
     bool nested = false;
     int weighting = 0;           // 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST (multigrid_solver.h:48-52)
+    // Optional accelerator for the per-point parent selection (:291-452) of a level: every fine point is independent there.  Host
+    // pointers in, per-point results out; returns false when it did not run (the host loop does the level then).  A point it
+    // could not handle comes back with cnt = 255 and is redone by the host routine.  Must produce the host routine's bits.
+    struct SelectJob {
+        int nf = 0, nc = 0, Kc = 0, ntri = 0, weighting = 0, nested = 0;
+        const double* P = nullptr;            // nf x 3 (row-major)
+        const double* Pc = nullptr;           // nc x 3
+        const int* nearest = nullptr;         // nf
+        const int* sample = nullptr;          // nc
+        const int* cadj_ptr = nullptr;        // nc + 1
+        const int* cadj = nullptr;            // sorted neighbour cells of every cell
+        const int* tris = nullptr;            // ntri x 3
+        const double* tri_normal = nullptr;   // ntri x 3
+        const int* tof_ptr = nullptr;         // nc + 1
+        const int* tof = nullptr;             // triangles of every cell, ascending
+        const int* NBc = nullptr;             // nc x Kc
+        unsigned char* cnt = nullptr;         // nf: entries of the row (1..3), 255 = not handled
+        unsigned char* kind = nullptr;        // nf: 0 triangle, 1 edge, 2 closest three, 3 single / one neighbour, 4 nested sample
+        int* col = nullptr;                   // 3 nf
+        double* w = nullptr;                  // 3 nf
+    };
+    bool (*device_select)(const SelectJob&) = nullptr;
+    int device_select_min_points = 200000;    // smaller levels stay on the host (transfer set-up costs more than the loop)
 };
 
 struct HierarchyResult {
@@ -108,7 +131,7 @@ public:
         HierarchyResult R;
         auto t_all = clk::now();
         for (const char* key : {"PDS", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection",
-                                "prepare", "edge_length", "assemble"}) R.timing[key] = 0.0;      // the last three: not in the reference's list
+                                "prepare", "edge_length", "assemble", "selection_on_device"}) R.timing[key] = 0.0;      // the last four: not in the reference's list
         R.timing["n_vertices"] = n;
         std::vector<V3> P_own;                 // storage of the coarser levels; level 0 reads the caller's arrays in place
         std::vector<int> NB_own;
@@ -252,6 +275,29 @@ public:
             const int chunk_len = (nf + nchunk - 1) / nchunk;
             struct Chunk { IndexVec row, col; ValueVec val; std::array<int, 4> kinds{0, 0, 0, 0}; };
             std::vector<Chunk> chunks(nchunk);
+            // Big levels: the selection runs on the GPU when the caller supplied one (same bits); what comes back is one record
+            // per point, turned into the same per-chunk triplet lists below.
+            std::unique_ptr<unsigned char[]> dev_cnt, dev_kind;
+            std::unique_ptr<int[]> dev_col;
+            std::unique_ptr<double[]> dev_w;
+            bool on_device = false;
+            if (opt.device_select && nf >= opt.device_select_min_points) {
+                std::vector<int> cadj_ptr((size_t)nc + 1, 0), cadj_flat;
+                for (int c = 0; c < nc; ++c) cadj_ptr[c + 1] = cadj_ptr[c] + (int)cadj[c].size();
+                cadj_flat.resize(cadj_ptr[nc]);
+                parallel_ranges(nc, T, [&](int lo, int hi, int) { for (int c = lo; c < hi; ++c) std::copy(cadj[c].begin(), cadj[c].end(), cadj_flat.begin() + cadj_ptr[c]); }, 4096);
+                dev_cnt.reset(new unsigned char[nf]); dev_kind.reset(new unsigned char[nf]);
+                dev_col.reset(new int[3 * (size_t)nf]); dev_w.reset(new double[3 * (size_t)nf]);
+                HierarchyOptions::SelectJob job;
+                job.nf = nf; job.nc = nc; job.Kc = Kc; job.ntri = ntri; job.weighting = opt.weighting; job.nested = opt.nested ? 1 : 0;
+                job.P = reinterpret_cast<const double*>(P.data()); job.Pc = reinterpret_cast<const double*>(Pc.data());
+                job.nearest = nearest.data(); job.sample = sample.data(); job.cadj_ptr = cadj_ptr.data(); job.cadj = cadj_flat.data();
+                job.tris = reinterpret_cast<const int*>(tris.data()); job.tri_normal = reinterpret_cast<const double*>(tri_normal.data());
+                job.tof_ptr = tof_ptr.data(); job.tof = tof.data(); job.NBc = NBc.data();
+                job.cnt = dev_cnt.get(); job.kind = dev_kind.get(); job.col = dev_col.get(); job.w = dev_w.get();
+                on_device = opt.device_select(job);
+            }
+            R.timing["selection_on_device"] += on_device ? 1.0 : 0.0;
             parallel_ranges(nchunk, nchunk, [&](int q0, int q1, int) {
             for (int q = q0; q < q1; ++q) {
             Chunk& ck = chunks[q];
@@ -262,61 +308,12 @@ public:
             auto emit = [&](int f, int c, double w) { trow.push_back(f); tcol.push_back(c); tval.push_back(w); };
             detail::SmallIntFloatMap inside_edge;
             for (int f = f_lo; f < f_hi; ++f) {
-                const V3 p = P[f];
-                const int c = nearest[f];
-                const V3 pc = Pc[c];
-                if (opt.nested && sample[c] == f) { emit(f, c, 1.0); continue; }
-                if (cadj[c].empty()) { emit(f, c, 1.0); ++kinds[3]; continue; }
-                if (cadj[c].size() == 1) {
-                    int nb = cadj[c][0];
-                    emit_edge(f, c, nb, p, pc, Pc, opt.weighting, emit);
-                    ++kinds[3];
+                if (on_device && dev_cnt[f] != 255) {
+                    for (int j = 0; j < dev_cnt[f]; ++j) emit(f, dev_col[3 * (size_t)f + j], dev_w[3 * (size_t)f + j]);
+                    if (dev_kind[f] < 4) ++kinds[dev_kind[f]];
                     continue;
                 }
-                inside_edge.clear();
-                bool found = false;
-                std::array<int, 3> best{0, 0, 0};
-                double bary[3] = {0, 0, 0};
-                for (int tq = tof_ptr[c]; tq < tof_ptr[c + 1]; ++tq) {
-                    const int t = tof[tq];
-                    std::array<int, 3> tri = tris[t];
-                    while (tri[0] != c) std::rotate(tri.begin(), tri.begin() + 1, tri.end());
-                    double b[3];
-                    double dist = in_triangle(p, tri, tri_normal[t], Pc, b, inside_edge);
-                    if (dist >= 0.0) { found = true; best = tri; bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2]; break; }
-                }
-                if (found) {
-                    ++kinds[0];
-                    double w[3];
-                    if (opt.weighting == 0) { w[0] = bary[0]; w[1] = bary[1]; w[2] = bary[2]; }
-                    else if (opt.weighting == 1) { w[0] = w[1] = w[2] = 1.0 / 3; }
-                    else inv_dist_weights(Pc, p, best.data(), 3, w);
-                    for (int j = 0; j < 3; ++j) emit(f, best[j], w[j]);
-                    continue;
-                }
-                int edge_to = -1;
-                for (const auto& kv : inside_edge)
-                    if (kv.second >= 0.f) { edge_to = kv.first; break; }              // :375-383
-                if (edge_to >= 0) {
-                    ++kinds[1];
-                    emit_edge(f, c, edge_to, p, pc, Pc, opt.weighting, emit);
-                    continue;
-                }
-                // closest three (:415-435): the cell itself + its two nearest table neighbours, inverse distance
-                ++kinds[2];
-                std::vector<std::pair<double, int>> cand;
-                for (int j = 0; j < Kc; ++j) {
-                    int nb = NBc[(size_t)c * Kc + j];
-                    if (nb < 0 || nb == c) continue;
-                    cand.emplace_back(detail::norm(p - Pc[nb]), nb);
-                }
-                std::sort(cand.begin(), cand.end());
-                int from[3] = {c, -1, -1};
-                int cnt = 1;
-                for (size_t j = 0; j < cand.size() && cnt < 3; ++j) from[cnt++] = cand[j].second;
-                double w[3];
-                inv_dist_weights(Pc, p, from, cnt, w);
-                for (int j = 0; j < cnt; ++j) emit(f, from[j], w[j]);
+                select_point(f, P, Pc, nearest, sample, cadj, tof_ptr, tof, tris, tri_normal, NBc, Kc, opt, inside_edge, emit, kinds);
             }
             }
             }, 1);
@@ -439,6 +436,70 @@ private:
 
     // :471-507  barycentric test of the projection of p onto the triangle's plane; returns |distance to plane|
     // when inside, -1 otherwise, and records the "inside edge" bookkeeping.
+    // Parents and weights of ONE fine point (:291-452): the containing candidate triangle of its cell, else the edge it projects
+    // into, else the cell and its two nearest table neighbours.  emit(f, coarse, weight) in the order the row is stored.
+    template <class PosView, class Emit>
+    static void select_point(int f, const PosView& P, const std::vector<V3>& Pc, const std::vector<int>& nearest, const std::vector<int>& sample,
+                             const std::vector<std::vector<int>>& cadj, const std::vector<int>& tof_ptr, const std::vector<int>& tof,
+                             const std::vector<std::array<int, 3>>& tris, const std::vector<V3>& tri_normal, const std::vector<int>& NBc, int Kc,
+                             const HierarchyOptions& opt, detail::SmallIntFloatMap& inside_edge, Emit& emit, std::array<int, 4>& kinds) {
+        const V3 p = P[f];
+        const int c = nearest[f];
+        const V3 pc = Pc[c];
+        if (opt.nested && sample[c] == f) { emit(f, c, 1.0); return; }
+        if (cadj[c].empty()) { emit(f, c, 1.0); ++kinds[3]; return; }
+        if (cadj[c].size() == 1) {
+            int nb = cadj[c][0];
+            emit_edge(f, c, nb, p, pc, Pc, opt.weighting, emit);
+            ++kinds[3];
+            return;
+        }
+        inside_edge.clear();
+        bool found = false;
+        std::array<int, 3> best{0, 0, 0};
+        double bary[3] = {0, 0, 0};
+        for (int tq = tof_ptr[c]; tq < tof_ptr[c + 1]; ++tq) {
+            const int t = tof[tq];
+            std::array<int, 3> tri = tris[t];
+            while (tri[0] != c) std::rotate(tri.begin(), tri.begin() + 1, tri.end());
+            double b[3];
+            double dist = in_triangle(p, tri, tri_normal[t], Pc, b, inside_edge);
+            if (dist >= 0.0) { found = true; best = tri; bary[0] = b[0]; bary[1] = b[1]; bary[2] = b[2]; break; }
+        }
+        if (found) {
+            ++kinds[0];
+            double w[3];
+            if (opt.weighting == 0) { w[0] = bary[0]; w[1] = bary[1]; w[2] = bary[2]; }
+            else if (opt.weighting == 1) { w[0] = w[1] = w[2] = 1.0 / 3; }
+            else inv_dist_weights(Pc, p, best.data(), 3, w);
+            for (int j = 0; j < 3; ++j) emit(f, best[j], w[j]);
+            return;
+        }
+        int edge_to = -1;
+        for (const auto& kv : inside_edge)
+            if (kv.second >= 0.f) { edge_to = kv.first; break; }              // :375-383
+        if (edge_to >= 0) {
+            ++kinds[1];
+            emit_edge(f, c, edge_to, p, pc, Pc, opt.weighting, emit);
+            return;
+        }
+        // closest three (:415-435): the cell itself + its two nearest table neighbours, inverse distance
+        ++kinds[2];
+        std::vector<std::pair<double, int>> cand;
+        for (int j = 0; j < Kc; ++j) {
+            int nb = NBc[(size_t)c * Kc + j];
+            if (nb < 0 || nb == c) continue;
+            cand.emplace_back(detail::norm(p - Pc[nb]), nb);
+        }
+        std::sort(cand.begin(), cand.end());
+        int from[3] = {c, -1, -1};
+        int cnt = 1;
+        for (size_t j = 0; j < cand.size() && cnt < 3; ++j) from[cnt++] = cand[j].second;
+        double w[3];
+        inv_dist_weights(Pc, p, from, cnt, w);
+        for (int j = 0; j < cnt; ++j) emit(f, from[j], w[j]);
+    }
+
     static double in_triangle(V3 p, const std::array<int, 3>& tri, V3 nrm, const std::vector<V3>& pos, double bary[3],
                               detail::SmallIntFloatMap& inside_edge) {
         const V3 v1 = pos[tri[0]], v2 = pos[tri[1]], v3 = pos[tri[2]];

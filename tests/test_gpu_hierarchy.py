@@ -53,3 +53,41 @@ def test_builder_matches_restatement_and_engine_consumes_it(cabi, oracle, kind):
     assert res <= tol and reso <= tol and it <= ito + 2
     m = mass[:, None]
     assert np.sqrt((m * (x - xo) ** 2).sum() / (m * xo ** 2).sum()) <= 20 * tol
+
+
+@pytest.mark.parametrize("kind,weighting,nested", [("torus", 0, False), ("torus-random", 0, False), ("sphere", 0, False), ("pointcloud", 0, False),
+                                                    ("torus", 2, False), ("torus", 1, True)])
+def test_device_selection_stage_gives_the_host_bits(cabi, kind, weighting, nested):
+    """The per-point parent selection (multigrid_solver.cpp:291-452) runs on the GPU for levels of >= 200 k points
+    (csrc/hierarchy_kernels.hip.hpp); U must be bit-identical to the host loop's (GMG_HIERARCHY_DEVICE=0), whatever the mesh."""
+    import os
+    from gravo_mg_amd import meshgen
+    if kind.startswith("torus"):
+        V, F = meshgen.torus_mesh(520, 500, order="random" if kind.endswith("random") else "natural")
+        S, _ = meshgen.cotan_laplacian(V, F)
+        neigh = meshgen.neighbors_from_stiffness(S)
+    elif kind == "sphere":
+        V, F = meshgen.sphere_mesh(230_000)
+        S, _ = meshgen.cotan_laplacian(V, F)
+        neigh = meshgen.neighbors_from_stiffness(S)
+    else:
+        V = meshgen.torus_points(240_000, noise=0.002)
+        S, _ = meshgen.knn_graph_laplacian(V, 8)
+        neigh = meshgen.neighbors_from_stiffness(S)
+    old = os.environ.get("GMG_HIERARCHY_DEVICE")
+    try:
+        os.environ["GMG_HIERARCHY_DEVICE"] = "0"
+        Hh = cabi.Hierarchy(V, neigh, weighting=weighting, nested=nested)
+        os.environ["GMG_HIERARCHY_DEVICE"] = "1"
+        Hd = cabi.Hierarchy(V, neigh, weighting=weighting, nested=nested)
+    finally:
+        if old is None:
+            os.environ.pop("GMG_HIERARCHY_DEVICE", None)
+        else:
+            os.environ["GMG_HIERARCHY_DEVICE"] = old
+    assert Hh.timing("selection_on_device") == 0.0 and Hd.timing("selection_on_device") >= 1.0
+    assert len(Hh.U) == len(Hd.U) >= 2
+    for a, b in zip(Hh.U, Hd.U):
+        assert a.shape == b.shape
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+        assert np.array_equal(a.data, b.data)            # bitwise
