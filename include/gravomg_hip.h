@@ -266,7 +266,8 @@ typedef struct {
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o);
 /* Replaces MGBS::MultigridSolver::buildHierarchy / constructProlongation
  * (gravomg/src/multigrid_solver.cpp:43-60, 62-469).  pos: n x 3 row-major; neigh: n x K row-major,
- * padded with -1 (gravomg_bindings/src/cpp/core.cpp:15-18). */
+ * padded with -1 (gravomg_bindings/src/cpp/core.cpp:15-18).  Works without a GPU; with one, the per-point parent selection
+ * (:291-452) of levels with >= 200 000 points runs on it -- same prolongations, bit for bit (GMG_HIERARCHY_DEVICE=0: host only). */
 int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt,
                         gmg_hierarchy* out);
 void gmg_hierarchy_destroy(gmg_hierarchy hh);
