@@ -434,8 +434,6 @@ private:
         }
     }
 
-    // :471-507  barycentric test of the projection of p onto the triangle's plane; returns |distance to plane|
-    // when inside, -1 otherwise, and records the "inside edge" bookkeeping.
     // Parents and weights of ONE fine point (:291-452): the containing candidate triangle of its cell, else the edge it projects
     // into, else the cell and its two nearest table neighbours.  emit(f, coarse, weight) in the order the row is stored.
     template <class PosView, class Emit>
@@ -500,6 +498,8 @@ private:
         for (int j = 0; j < cnt; ++j) emit(f, from[j], w[j]);
     }
 
+    // :471-507  barycentric test of the projection of p onto the triangle's plane; returns |distance to plane|
+    // when inside, -1 otherwise, and records the "inside edge" bookkeeping.
     static double in_triangle(V3 p, const std::array<int, 3>& tri, V3 nrm, const std::vector<V3>& pos, double bary[3],
                               detail::SmallIntFloatMap& inside_edge) {
         const V3 v1 = pos[tri[0]], v2 = pos[tri[1]], v3 = pos[tri[2]];
