@@ -5,6 +5,9 @@
 // pybind11's Eigen casters are not usable (no Eigen), so scipy sparse matrices are unpacked by hand the way
 // pybind11/eigen/matrix.h does it (obj -> csc_matrix -> indptr / indices / data) and numpy arrays are taken
 // column-major (forcecast), i.e. all arguments are copied in and results copied out, like upstream.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -29,8 +32,9 @@ namespace {
 
 MGBS::MatrixXd to_dense(const DenseIn& a) {
     if (a.ndim() != 1 && a.ndim() != 2) throw std::invalid_argument("expected a 1-D or 2-D float array");
-    MGBS::MatrixXd m((int)a.shape(0), a.ndim() == 2 ? (int)a.shape(1) : 1);
-    std::memcpy(m.data.data(), a.data(), sizeof(double) * m.data.size());
+    MGBS::MatrixXd m;
+    m.rows_ = (int)a.shape(0); m.cols_ = a.ndim() == 2 ? (int)a.shape(1) : 1;
+    m.data.assign(a.data(), a.data() + (size_t)m.rows_ * m.cols_);        // one pass (no zero fill first)
     return m;
 }
 
@@ -174,11 +178,22 @@ public:
                     int stopping_criteria, int pre_iters, int post_iters, int max_iter, bool check_voronoi, bool nested,
                     Sampling sampling_strategy, Weighting weighting, bool sig06, DenseIn normals, bool verbose, bool debug, bool ablation,
                     int ablation_num_points, bool ablation_random) {
+        const bool trace = std::getenv("GMG_CTOR_TRACE") != nullptr;      // phases of the construction on stderr
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!trace) return;
+            auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[gravomg ctor] %-28s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t0).count());
+            t0 = now;
+        };
         MGBS::MatrixXd V = to_dense(positions);
+        lap("positions");
         MGBS::MatrixXi N = to_int(neighbors);
+        lap("neighbours");
         MGBS::SparseMatrix M = to_sparse(mass);
+        lap("mass");
         if (V.cols() != 3 || N.rows() != V.rows() || M.rows() != V.rows()) throw std::invalid_argument("positions must be n x 3, neighbors n x K, mass n x n");
-        solver.reset(new MGBS::MultigridSolver(V, N, M));
+        solver.reset(new MGBS::MultigridSolver(std::move(V), std::move(N), std::move(M)));
         solver->checkVoronoi = check_voronoi;
         solver->nested = nested;
         solver->samplingStrategy = sampling_strategy;
@@ -188,12 +203,14 @@ public:
         solver->ablation = ablation;
         solver->ablationNumPoints = ablation_num_points;
         solver->ablationRandom = ablation_random;
-        solver->normals = to_dense(normals);
+        if (sig06) solver->normals = to_dense(normals);      // only the (out-of-scope) SIG06 hierarchy reads them: no 72 MB copy otherwise
         solver->verbose = verbose;
         solver->debug = debug;
         solver->ratio = ratio;
         solver->lowBound = low_bound;
+        lap("solver object");
         solver->buildHierarchy();
+        lap("buildHierarchy");
         if (solver->U.empty() && *solver->lastError()) throw std::runtime_error(solver->lastError());
         solver->cycleType = cycle_type;
         solver->accuracy = tolerance;
@@ -202,6 +219,7 @@ public:
         solver->postIters = post_iters;
         solver->isSmootherGaussSeidel = true;
         (void)solver->prepareEngine();       // hierarchy -> device now (part of the construction phase); errors resurface in solve()
+        lap("prepareEngine");
     }
 
     void construct_sig21_hierarchy(py::object) { throw std::runtime_error("the SIG21 comparison hierarchy is out of scope of the MI355X hot-path build"); }

@@ -160,10 +160,23 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
     if (h->L < 0) return fail(h, GMG_ERR_STATE, "call gmg_set_num_levels first");
     if (k < 0 || k >= h->L || n_fine <= 0 || n_coarse <= 0 || !colptr || !rowidx || !val) return fail(h, GMG_ERR_INVALID, "bad prolongation arguments");
     for (int j = 0; j < n_coarse; ++j) if (colptr[j + 1] < colptr[j]) return fail(h, GMG_ERR_INVALID, "colptr not monotone");
-    for (int p = 0; p < colptr[n_coarse]; ++p) if (rowidx[p] < 0 || rowidx[p] >= n_fine) return fail(h, GMG_ERR_INVALID, "row index out of range in U");
+    {
+        std::atomic<bool> bad{false};
+        parallel_ranges(colptr[n_coarse], h->cfg.host_threads, [&](int lo, int hi, int) {
+            for (int p = lo; p < hi; ++p) if (rowidx[p] < 0 || rowidx[p] >= n_fine) { bad = true; return; }
+        }, 1 << 18);
+        if (bad) return fail(h, GMG_ERR_INVALID, "row index out of range in U");
+    }
     if (h->has_device) { drop_system(h); drop_device_transfers(h); }
     h->patches.clear(); h->patches_ready = false;
-    h->U[k].assign(n_coarse, n_fine, colptr, rowidx, val);
+    {   // (default-initialised vectors filled on all cores: 108 MB of first touches at 3 M vertices)
+        Compressed& u = h->U[k];
+        u.n_outer = n_coarse; u.n_inner = n_fine;
+        u.ptr.assign(colptr, colptr + n_coarse + 1);
+        u.idx.resize((size_t)colptr[n_coarse]); u.val.resize((size_t)colptr[n_coarse]);
+        threaded_copy_bytes(u.idx.data(), rowidx, sizeof(int) * u.idx.size(), h->cfg.host_threads);
+        threaded_copy_bytes(u.val.data(), val, sizeof(double) * u.val.size(), h->cfg.host_threads);
+    }
     h->U_set[k] = 1;
     h->ord_cache_valid = false;
     return GMG_OK;
@@ -1491,9 +1504,10 @@ int gmg_hierarchy_level_shape(gmg_hierarchy hh, int k, int* n_fine, int* n_coars
 int gmg_hierarchy_get_prolongation(gmg_hierarchy hh, int k, int* colptr, int* rowidx, double* val) try {
     if (!hh || k < 0 || k >= (int)hh->res.U.size()) return GMG_ERR_INVALID;
     const Compressed& u = hh->res.U[k];
-    if (colptr) std::memcpy(colptr, u.ptr.data(), sizeof(int) * (u.n_outer + 1));
-    if (rowidx) std::memcpy(rowidx, u.idx.data(), sizeof(int) * u.nnz());
-    if (val) std::memcpy(val, u.val.data(), sizeof(double) * u.nnz());
+    // (threaded: the destinations are usually fresh arrays -- 108 MB of first touches at 3 M vertices)
+    if (colptr) threaded_copy_bytes(colptr, u.ptr.data(), sizeof(int) * (size_t)(u.n_outer + 1), hw_threads());
+    if (rowidx) threaded_copy_bytes(rowidx, u.idx.data(), sizeof(int) * (size_t)u.nnz(), hw_threads());
+    if (val) threaded_copy_bytes(val, u.val.data(), sizeof(double) * (size_t)u.nnz(), hw_threads());
     return GMG_OK;
 } GMG_CATCH_0
 
@@ -1513,7 +1527,7 @@ int gmg_hierarchy_get_samples(gmg_hierarchy hh, int k, int* out) try {
 
 int gmg_hierarchy_get_nearest(gmg_hierarchy hh, int k, int* out) try {
     if (!hh || !out || k < 0 || k >= (int)hh->res.nearest.size()) return GMG_ERR_INVALID;
-    std::memcpy(out, hh->res.nearest[k].data(), sizeof(int) * hh->res.nearest[k].size());
+    threaded_copy_bytes(out, hh->res.nearest[k].data(), sizeof(int) * hh->res.nearest[k].size(), hw_threads());
     return GMG_OK;
 } GMG_CATCH_0
 

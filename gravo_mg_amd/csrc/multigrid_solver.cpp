@@ -2,15 +2,33 @@
 #include "multigrid_solver.h"
 
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
 #include <limits>
+#include <memory>
+#include <algorithm>
+#include <vector>
 #include <thread>
 
 namespace MGBS {
 
 namespace {
+// [0, n) cut into contiguous ranges run on up to 16 threads (plain std::thread: these loops run once per hierarchy, over 10^6..10^7
+// items each touching fresh memory -- page faults and strided reads that one core takes tens of milliseconds for)
+template <class F>
+void parallelRanges(int n, F&& f) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    const int T = std::max(1, std::min({16, hw > 0 ? hw : 1, n / 65536 + 1}));
+    if (T == 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back([&, t] { f((int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); });
+    f(0, (int)((long long)n / T));
+    for (auto& x : th) x.join();
+}
+
 bool configEqual(const gmg_config& a, const gmg_config& b) { return std::memcmp(&a, &b, sizeof(gmg_config)) == 0; }
 
 // FNV-1a style digest of a byte range taken 8 bytes at a time, in up to 16 chunks hashed concurrently and combined in
@@ -68,6 +86,12 @@ MultigridSolver::MultigridSolver(MatrixXd& V_, MatrixXi& neigh_, SparseMatrix& M
     std::memset(&createdWith_, 0, sizeof(createdWith_));
 }
 
+MultigridSolver::MultigridSolver(MatrixXd&& V_, MatrixXi&& neigh_, SparseMatrix&& M_) : V(std::move(V_)), neigh(std::move(neigh_)), M(std::move(M_)) {
+    hierarchyTiming["n_vertices"] = V.rows();
+    gmg_config_default(&engineConfig);
+    std::memset(&createdWith_, 0, sizeof(createdWith_));
+}
+
 MultigridSolver::~MultigridSolver() {
     if (engine_) gmg_destroy(engine_);
 }
@@ -89,16 +113,28 @@ void MultigridSolver::buildHierarchy() {
     opt.sampling = (int)samplingStrategy; opt.weighting = (int)weightingScheme;
     // positions: column-major n x 3 -> row-major
     const int n = V.rows();
-    std::vector<double> pos((size_t)n * 3);
-    for (int i = 0; i < n; ++i) for (int c = 0; c < 3; ++c) pos[(size_t)i * 3 + c] = V(i, c);
+    std::unique_ptr<double[]> pos(new double[(size_t)n * 3]);             // (not value-initialised: every entry is written below, on all cores)
+    parallelRanges(n, [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i) for (int c = 0; c < 3; ++c) pos[(size_t)i * 3 + c] = V(i, c);
+    });
+    const bool trace = std::getenv("GMG_CTOR_TRACE") != nullptr;
+    auto tt = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gravomg ctor]   %-26s %.1f ms\n", what, std::chrono::duration<double, std::milli>(now - tt).count());
+        tt = now;
+    };
+    lap("row-major positions");
     gmg_hierarchy hh = nullptr;
-    int rc = gmg_hierarchy_build(pos.data(), n, neigh.data.data(), neigh.cols(), &opt, &hh);
+    int rc = gmg_hierarchy_build(pos.get(), n, neigh.data.data(), neigh.cols(), &opt, &hh);
     if (rc != GMG_OK) {
         err_ = rc == GMG_ERR_UNSUPPORTED ? "only Sampling::FASTDISK is supported by the MI355X hot-path build" : "gmg_hierarchy_build failed";
         std::cout << "ERROR! " << err_ << std::endl;
         U.clear();
         return;
     }
+    lap("gmg_hierarchy_build");
     const int L = gmg_hierarchy_num_levels(hh);
     U.assign(L, SparseMatrix());
     DoF.clear();
@@ -112,6 +148,7 @@ void MultigridSolver::buildHierarchy() {
         gmg_hierarchy_get_prolongation(hh, k, u.outer.data(), u.inner.data(), u.values.data());
         DoF.push_back(nc);
     }
+    lap("fetch U");
     // what the reference keeps beside U (samples and nearestSource always, levelV with debug only: :128, :171, :241)
     samples.assign(L, std::vector<int>());
     nearestSource.assign(L, std::vector<size_t>());
@@ -120,9 +157,10 @@ void MultigridSolver::buildHierarchy() {
         const int nf = U[k].rows_, nc = U[k].cols_;
         samples[k].resize(nc);
         gmg_hierarchy_get_samples(hh, k, samples[k].data());
-        std::vector<int> near(nf);
-        gmg_hierarchy_get_nearest(hh, k, near.data());
-        nearestSource[k].assign(near.begin(), near.end());
+        std::unique_ptr<int[]> near(new int[(size_t)nf]);
+        gmg_hierarchy_get_nearest(hh, k, near.get());
+        nearestSource[k].resize(nf);
+        parallelRanges(nf, [&](int lo, int hi) { for (int i = lo; i < hi; ++i) nearestSource[k][i] = (size_t)near[i]; });
         if (debug) {
             std::vector<double> xyz((size_t)nc * 3);
             gmg_hierarchy_get_points(hh, k, xyz.data());
@@ -135,7 +173,9 @@ void MultigridSolver::buildHierarchy() {
         double v = 0;
         if (gmg_hierarchy_get_timing(hh, key, &v) == GMG_OK) hierarchyTiming[key] = v;
     }
+    lap("samples / nearest / timing");
     gmg_hierarchy_destroy(hh);
+    lap("destroy");
 }
 
 int MultigridSolver::ensureEngine() {

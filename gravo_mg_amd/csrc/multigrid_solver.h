@@ -70,6 +70,8 @@ class MultigridSolver {
 public:
     // gravomg/include/gravomg/multigrid_solver.h:58; M is the (diagonal) mass matrix
     MultigridSolver(MatrixXd& V, MatrixXi& neigh, SparseMatrix& M);
+    // the same, taking over the caller's storage (the pybind shim's converted copies: 160 MB at 3 M vertices)
+    MultigridSolver(MatrixXd&& V, MatrixXi&& neigh, SparseMatrix&& M);
     ~MultigridSolver();
     MultigridSolver(const MultigridSolver&) = delete;
     MultigridSolver& operator=(const MultigridSolver&) = delete;
