@@ -296,6 +296,14 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     const int world = p->world, rank = p->rank, C = h->lv[0].ord.n_colors, nk = p->nk, d = p->d;
     const gmg_p2p_blob* bl = (const gmg_p2p_blob*)blobs;
     p->peers.clear();
+    {   // peer access to every other visible device (the IPC mapping below enables it lazily as well; "already enabled" and "not
+        // supported" are both fine here -- an unreachable peer shows up in hipIpcOpenMemHandle)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess)
+            for (int dev = 0; dev < ndev; ++dev)
+                if (dev != h->cfg.device) { int can = 0; if (hipDeviceCanAccessPeer(&can, h->cfg.device, dev) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(dev, 0); }
+        (void)hipGetLastError();
+    }
     for (int q = 0; q < world; ++q) {
         if (q == rank) continue;
         P2PPeer peer;

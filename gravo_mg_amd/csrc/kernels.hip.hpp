@@ -891,7 +891,9 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
         if (threadIdx.x == 0) {
             timed_out = 0;
             const unsigned long long t0 = wall_clock64();            // 100 MHz constant clock
-            while (__hip_atomic_load(op.local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            // (an exchange that already timed out means the peer is gone: the launches still queued behind it give up at once)
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = 1;
+            while (!timed_out && __hip_atomic_load(op.local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
                 __builtin_amdgcn_s_sleep(8);
                 if (wall_clock64() - t0 > 400000000ull) { timed_out = 1; atomicExch(err, 1); break; }
             }
@@ -924,7 +926,8 @@ __global__ __launch_bounds__(64) void p2p_allreduce_small(const P2POp* __restric
     if (t < n_peers) {
         __hip_atomic_store(ops[t].remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(ops[t].local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = 1;
+        while (!timed_out && __hip_atomic_load(ops[t].local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 400000000ull) { timed_out = 1; atomicExch(err, 1); break; }
         }
