@@ -93,3 +93,59 @@ def test_processes_through_ipc_handles(cabi, world, kind, shard):
         assert err is None, err
         np.testing.assert_allclose(hist, want_hist, rtol=1e-12)
         assert np.array_equal(x, want_x), rank
+
+
+def _absent_peer_worker(rank, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        import time
+        import torch.distributed as dist
+        from gravo_mg_amd import cabi
+        from tests.test_gpu_p2p import _problem
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+        P = _problem("poisson")
+        eng = cabi.Engine(row_align=128, block_lanes=1)
+        eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+        rk = cabi.P2PCycle(eng, rank, 2, 1)
+        blobs = [None, None]
+        dist.all_gather_object(blobs, rk.export())
+        rk.connect(blobs=blobs)
+        dist.barrier()
+        rk.load(P.rhs, P.rhs)
+        if rank == 0:
+            t = time.perf_counter()
+            try:
+                rk.cycles(2, 2)
+                q.put((rank, "no error", time.perf_counter() - t))
+            except cabi.GmgError as e:
+                q.put((rank, str(e), time.perf_counter() - t))
+        else:
+            time.sleep(9.0)            # connected, mailboxes mapped -- but never takes part in a cycle
+            q.put((rank, "absent", 0.0))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:              # noqa: BLE001
+        import traceback
+        q.put((rank, "worker failed: " + traceback.format_exc() + repr(e), 0.0))
+
+
+def test_a_missing_peer_is_an_error_not_a_hang(cabi):
+    """A rank that never runs its share of the cycle: the device-side wait of the first exchange gives up after ~4 s, every launch
+    queued behind it returns at once, and gmg_p2p_cycles reports GMG_ERR_STATE."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_absent_peer_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (msg, dt)) for r, msg, dt in [q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(60)
+    assert got[1][0] == "absent", got
+    msg, dt = got[0]
+    assert "timed out" in msg, got
+    assert 3.0 <= dt <= 8.5, dt          # one 4 s wait, not one per queued exchange
