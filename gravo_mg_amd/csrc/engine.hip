@@ -1378,10 +1378,13 @@ struct HierarchyXfer {
     void* buf[2] = {nullptr, nullptr};
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool ok = false, tried = false;
-    bool ready() {
-        if (tried) return ok;
+    int device = -1;                  // the stream's device: the calling thread's current device at first use
+    // dev: the device the caller's allocations and launches go to; a process that later builds on another device keeps the host loop
+    bool ready(int dev) {
+        if (tried) return ok && dev == device;
         tried = true;
-        ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        device = dev;
+        ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
         for (int i = 0; i < 2 && ok; ++i)
             ok = hipHostMalloc(&buf[i], kBounceBytes, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) (void)hipGetLastError();
@@ -1422,7 +1425,8 @@ HierarchyXfer& hierarchy_xfer() { static HierarchyXfer* x = new HierarchyXfer();
 static bool hierarchy_select_on_device(const HierarchyOptions::SelectJob& j) {
     HierarchyXfer& X = hierarchy_xfer();
     std::lock_guard<std::mutex> lock(X.m);
-    if (!X.ready()) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || !X.ready(dev)) { (void)hipGetLastError(); return false; }
     const int threads = std::min(hw_threads(), 16);
     // one device allocation for the whole job, carved into 256-byte aligned pieces
     const size_t nf = (size_t)j.nf, nc = (size_t)j.nc;
@@ -1470,11 +1474,13 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     // first use in a process: runtime start-up, code object load and the pinned buffers (~80 ms) happen beside the sequential
     // sampling / clustering sweeps of the first level instead of in front of the device stage
     std::future<void> device_warm;
+    int caller_device = 0;
+    if (ho.device_select && hipGetDevice(&caller_device) != hipSuccess) { (void)hipGetLastError(); ho.device_select = nullptr; }
     if (ho.device_select)
-        device_warm = std::async(std::launch::async, [] {
+        device_warm = std::async(std::launch::async, [caller_device] {
             HierarchyXfer& X = hierarchy_xfer();
             std::lock_guard<std::mutex> lock(X.m);
-            if (!X.ready()) return;
+            if (hipSetDevice(caller_device) != hipSuccess || !X.ready(caller_device)) { (void)hipGetLastError(); return; }
             hipLaunchKernelGGL(gmgh::select_parents, dim3(1), dim3(128), 0, X.st, 0, 0, 0, 0, (const double*)nullptr, (const double*)nullptr, (const int*)nullptr,
                                (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
                                (const int*)nullptr, (const int*)nullptr, (unsigned char*)nullptr, (unsigned char*)nullptr, (int*)nullptr, (double*)nullptr);
