@@ -1425,8 +1425,9 @@ HierarchyXfer& hierarchy_xfer() { static HierarchyXfer* x = new HierarchyXfer();
 static bool hierarchy_select_on_device(const HierarchyOptions::SelectJob& j) {
     HierarchyXfer& X = hierarchy_xfer();
     std::lock_guard<std::mutex> lock(X.m);
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || !X.ready(dev)) { (void)hipGetLastError(); return false; }
+    // (the builder runs this stage on a task thread: the device to use travels in the job)
+    int dev = j.device;
+    if ((dev < 0 && hipGetDevice(&dev) != hipSuccess) || hipSetDevice(dev) != hipSuccess || !X.ready(dev)) { (void)hipGetLastError(); return false; }
     const int threads = std::min(hw_threads(), 16);
     // one device allocation for the whole job, carved into 256-byte aligned pieces
     const size_t nf = (size_t)j.nf, nc = (size_t)j.nc;
@@ -1476,6 +1477,7 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     std::future<void> device_warm;
     int caller_device = 0;
     if (ho.device_select && hipGetDevice(&caller_device) != hipSuccess) { (void)hipGetLastError(); ho.device_select = nullptr; }
+    ho.device = caller_device;
     if (ho.device_select)
         device_warm = std::async(std::launch::async, [caller_device] {
             HierarchyXfer& X = hierarchy_xfer();

@@ -46,7 +46,7 @@ struct HierarchyOptions {
     // pointers in, per-point results out; returns false when it did not run (the host loop does the level then).  A point it
     // could not handle comes back with cnt = 255 and is redone by the host routine.  Must produce the host routine's bits.
     struct SelectJob {
-        int nf = 0, nc = 0, Kc = 0, ntri = 0, weighting = 0, nested = 0;
+        int nf = 0, nc = 0, Kc = 0, ntri = 0, weighting = 0, nested = 0, device = -1;
         const double* P = nullptr;            // nf x 3 (row-major)
         const double* Pc = nullptr;           // nc x 3
         const int* nearest = nullptr;         // nf
@@ -64,6 +64,7 @@ struct HierarchyOptions {
         double* w = nullptr;                  // 3 nf
     };
     bool (*device_select)(const SelectJob&) = nullptr;
+    int device = -1;                          // the HIP device the hook shall use (the builder itself knows no devices)
     int device_select_min_points = 200000;    // smaller levels stay on the host (transfer set-up costs more than the loop)
 };
 
@@ -133,8 +134,19 @@ public:
         for (const char* key : {"PDS", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection",
                                 "prepare", "edge_length", "assemble", "selection_on_device"}) R.timing[key] = 0.0;      // the last four: not in the reference's list
         R.timing["n_vertices"] = n;
-        std::vector<V3> P_own;                 // storage of the coarser levels; level 0 reads the caller's arrays in place
-        std::vector<int> NB_own;
+        // Storage of the coarser levels (level 0 reads the caller's arrays in place).  Shared: the last stage of a level -- parent
+        // selection + assembly of U_k -- runs as a task beside the sequential stages of the next levels and reads them too.
+        std::shared_ptr<std::vector<V3>> P_hold;
+        std::shared_ptr<std::vector<int>> NB_hold;
+        struct Work {                          // what the last stage of one level reads (and the level's by-products)
+            std::vector<int> nearest, sample, tof_ptr, tof;
+            std::vector<std::vector<int>> cadj;
+            std::vector<std::array<int, 3>> tris;
+            std::vector<V3> tri_normal;
+        };
+        struct LevelOut { Compressed U; std::array<int, 4> kinds{0, 0, 0, 0}; double ms_select = 0, ms_assemble = 0, on_device = 0; };
+        std::vector<std::shared_ptr<Work>> works;
+        std::vector<std::future<LevelOut>> pending;
         detail::View<V3> P(reinterpret_cast<const V3*>(pos), (size_t)n);
         detail::View<int> NB(neigh, (size_t)n * K);
         int nbK = K;
@@ -148,9 +160,12 @@ public:
             const double radius = std::cbrt(opt.ratio) * average_edge_length(P, NB, nbK, EL);   // :104
             R.timing["edge_length"] += ms(te, clk::now());
             std::vector<double> D(nf, std::numeric_limits<double>::max());
-            std::vector<int> nearest(nf, 0);
+            auto W = std::make_shared<Work>();
+            std::vector<int>& nearest = W->nearest;
+            nearest.assign(nf, 0);
             auto t0 = clk::now();
-            std::vector<int> sample = fast_disk_sample(P, NB, nbK, radius, D, nearest, EL);     // :128
+            std::vector<int>& sample = W->sample;
+            sample = fast_disk_sample(P, NB, nbK, radius, D, nearest, EL);                  // :128
             if ((int)sample.size() < opt.lower_bound) break;                                // :156-159
             const int nc = (int)sample.size();
             auto t1 = clk::now();
@@ -162,7 +177,8 @@ public:
             // coarse adjacency: clusters that touch through a fine edge (:178-187); sorted unique lists
             // (the lists are SETS -- sorted, unique -- so they can be collected cluster by cluster on all cores: the fine
             // points of every cluster first, by a counting sort of `nearest`)
-            std::vector<std::vector<int>> cadj(nc);
+            std::vector<std::vector<int>>& cadj = W->cadj;
+            cadj.assign(nc, std::vector<int>());
             std::vector<int> mem_ptr((size_t)nc + 1, 0), members(nf);
             for (int f = 0; f < nf; ++f) mem_ptr[nearest[f] + 1]++;
             for (int c = 0; c < nc; ++c) mem_ptr[c + 1] += mem_ptr[c];
@@ -190,7 +206,8 @@ public:
             int max_nb = 0;
             for (auto& a : cadj) max_nb = std::max(max_nb, (int)a.size());
             // homogeneous table for the next level (:196-205): self first, then at most max_nb-1 neighbours
-            std::vector<int> NBc((size_t)nc * std::max(max_nb, 1), -1);
+            auto NBc_sp = std::make_shared<std::vector<int>>((size_t)nc * std::max(max_nb, 1), -1);
+            std::vector<int>& NBc = *NBc_sp;
             const int Kc = std::max(max_nb, 1);
             if (max_nb > 0)
                 for (int i = 0; i < nc; ++i) {
@@ -206,7 +223,8 @@ public:
             R.timing["next_neighborhood"] += ms(t2, t3);
 
             // coarse positions (:216-240)
-            std::vector<V3> Pc(nc, V3{0, 0, 0});
+            auto Pc_sp = std::make_shared<std::vector<V3>>(nc, V3{0, 0, 0});
+            std::vector<V3>& Pc = *Pc_sp;
             if (opt.nested) {
                 for (int c = 0; c < nc; ++c) Pc[c] = P[sample[c]];
             } else {
@@ -247,8 +265,10 @@ public:
             std::vector<int> tri_first((size_t)nc + 1, 0);
             for (int c = 0; c < nc; ++c) tri_first[c + 1] = tri_first[c] + (int)local[c].size();
             const int ntri = tri_first[nc];
-            std::vector<std::array<int, 3>> tris(ntri);
-            std::vector<V3> tri_normal(ntri);
+            std::vector<std::array<int, 3>>& tris = W->tris;
+            tris.assign(ntri, std::array<int, 3>{0, 0, 0});
+            std::vector<V3>& tri_normal = W->tri_normal;
+            tri_normal.assign(ntri, V3{0, 0, 0});
             parallel_ranges(nc, T, [&](int lo, int hi, int) {
                 for (int c = lo; c < hi; ++c)
                     for (size_t q = 0; q < local[c].size(); ++q) {
@@ -257,10 +277,12 @@ public:
                         tri_normal[tri_first[c] + q] = detail::normalized(detail::cross(Pc[tr[1]] - Pc[tr[0]], Pc[tr[2]] - Pc[tr[0]]));
                     }
             }, 256);
-            std::vector<int> tof_ptr((size_t)nc + 1, 0);
+            std::vector<int>& tof_ptr = W->tof_ptr;
+            tof_ptr.assign((size_t)nc + 1, 0);
             for (int t = 0; t < ntri; ++t) for (int q = 0; q < 3; ++q) tof_ptr[tris[t][q] + 1]++;
             for (int c = 0; c < nc; ++c) tof_ptr[c + 1] += tof_ptr[c];
-            std::vector<int> tof(tof_ptr[nc]);
+            std::vector<int>& tof = W->tof;
+            tof.assign(tof_ptr[nc], 0);
             {
                 std::vector<int> fillp(tof_ptr.begin(), tof_ptr.end() - 1);
                 for (int t = 0; t < ntri; ++t) for (int q = 0; q < 3; ++q) tof[fillp[tris[t][q]]++] = t;
@@ -268,6 +290,22 @@ public:
             auto t5 = clk::now();
             R.timing["triangle_finding"] += ms(t4, t5);
 
+            // ---- last stage of the level, as a task: it needs nothing the next levels change and nothing they need waits for it
+            auto P_keep = P_hold;                                  // (keeps this level's positions alive; null on level 0)
+            const detail::View<V3> Pv = P;
+            const HierarchyOptions optc = opt;
+            auto finish = [W, Pc_sp, NBc_sp, P_keep, Pv, optc, nf, nc, Kc, ntri, T]() -> LevelOut {
+            auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            LevelOut out;
+            auto t5s = clk::now();
+            const HierarchyOptions& opt = optc;
+            const detail::View<V3>& P = Pv;
+            const std::vector<V3>& Pc = *Pc_sp;
+            const std::vector<int>& NBc = *NBc_sp;
+            const std::vector<int>&nearest = W->nearest, &sample = W->sample, &tof_ptr = W->tof_ptr, &tof = W->tof;
+            const std::vector<std::vector<int>>& cadj = W->cadj;
+            const std::vector<std::array<int, 3>>& tris = W->tris;
+            const std::vector<V3>& tri_normal = W->tri_normal;
             // per fine point: pick coarse parents and weights (:291-452)
             // Every fine point is independent: chunks of points on all cores, each with its own triplet list, concatenated in
             // chunk order afterwards (= the sequential emission order).
@@ -289,7 +327,7 @@ public:
                 dev_cnt.reset(new unsigned char[nf]); dev_kind.reset(new unsigned char[nf]);
                 dev_col.reset(new int[3 * (size_t)nf]); dev_w.reset(new double[3 * (size_t)nf]);
                 HierarchyOptions::SelectJob job;
-                job.nf = nf; job.nc = nc; job.Kc = Kc; job.ntri = ntri; job.weighting = opt.weighting; job.nested = opt.nested ? 1 : 0;
+                job.nf = nf; job.nc = nc; job.Kc = Kc; job.ntri = ntri; job.weighting = opt.weighting; job.nested = opt.nested ? 1 : 0; job.device = opt.device;
                 job.P = reinterpret_cast<const double*>(P.data()); job.Pc = reinterpret_cast<const double*>(Pc.data());
                 job.nearest = nearest.data(); job.sample = sample.data(); job.cadj_ptr = cadj_ptr.data(); job.cadj = cadj_flat.data();
                 job.tris = reinterpret_cast<const int*>(tris.data()); job.tri_normal = reinterpret_cast<const double*>(tri_normal.data());
@@ -297,7 +335,7 @@ public:
                 job.cnt = dev_cnt.get(); job.kind = dev_kind.get(); job.col = dev_col.get(); job.w = dev_w.get();
                 on_device = opt.device_select(job);
             }
-            R.timing["selection_on_device"] += on_device ? 1.0 : 0.0;
+            out.on_device = on_device ? 1.0 : 0.0;
             parallel_ranges(nchunk, nchunk, [&](int q0, int q1, int) {
             for (int q = q0; q < q1; ++q) {
             Chunk& ck = chunks[q];
@@ -335,21 +373,34 @@ public:
                 for (auto& ck : chunks) for (int z = 0; z < 4; ++z) kinds[z] += ck.kinds[z];
             }
             auto t6 = clk::now();
-            R.timing["triangle_selection"] += ms(t5, t6);
-            R.row_kinds.push_back(kinds);
-
-            R.U.push_back(from_triplets(nf, nc, trow, tcol, tval));
-            R.timing["assemble"] += ms(t6, clk::now());
-            R.samples.push_back(std::move(sample));
-            R.nearest.push_back(std::move(nearest));
+            out.ms_select = ms(t5s, t6);
+            out.kinds = kinds;
+            out.U = from_triplets(nf, nc, trow, tcol, tval);
+            out.ms_assemble = ms(t6, clk::now());
+            return out;
+            };
+            // big levels: beside the next levels' sequential sweeps; small ones: right here
+            works.push_back(W);
+            if (nf >= 100000) pending.push_back(std::async(std::launch::async, finish));
+            else { std::promise<LevelOut> done; done.set_value(finish()); pending.push_back(done.get_future()); }
             { std::vector<double> xyz((size_t)nc * 3); for (int c = 0; c < nc; ++c) { xyz[3 * (size_t)c] = Pc[c].x; xyz[3 * (size_t)c + 1] = Pc[c].y; xyz[3 * (size_t)c + 2] = Pc[c].z; } R.points.push_back(std::move(xyz)); }
             R.dof.push_back(nc);
-            P_own.swap(Pc);
-            NB_own.swap(NBc);
-            P = detail::View<V3>(P_own);
-            NB = detail::View<int>(NB_own);
+            P_hold = Pc_sp;
+            NB_hold = NBc_sp;
+            P = detail::View<V3>(*P_hold);
+            NB = detail::View<int>(*NB_hold);
             nbK = Kc;
             ++level;
+        }
+        for (size_t k = 0; k < pending.size(); ++k) {               // collect the levels' last stages, in order
+            LevelOut out = pending[k].get();
+            R.U.push_back(std::move(out.U));
+            R.row_kinds.push_back(out.kinds);
+            R.timing["triangle_selection"] += out.ms_select;
+            R.timing["assemble"] += out.ms_assemble;
+            R.timing["selection_on_device"] += out.on_device;
+            R.samples.push_back(std::move(works[k]->sample));
+            R.nearest.push_back(std::move(works[k]->nearest));
         }
         R.timing["levels"] = (double)R.U.size();
         R.timing["hierarchy"] = ms(t_all, clk::now());
