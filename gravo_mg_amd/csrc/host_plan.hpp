@@ -305,15 +305,24 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     }, 1);
     std::vector<int> count(o.n_colors, 0);
     for (int q = 0; q < nchunk; ++q) for (int c = 0; c < o.n_colors; ++c) count[c] += hist[q][c];
+    // Device order of the colour classes: ascending size (stable, so classes of equal size -- a regular mesh -- keep the order the
+    // greedy colouring gave them).  Any order of the classes is a Gauss-Seidel ordering; this one ends every sweep with the largest
+    // class, whose launch also produces its rows' residual / residual-check sums (engine_cycle.hip.hpp::fold_residual, fold_norm), and
+    // gets the stragglers an irregular graph leaves behind (two classes of < 2 000 rows on an 8 M-vertex torus) out of the way first.
+    std::vector<int> colour_at(o.n_colors), slot_of(o.n_colors);
+    std::iota(colour_at.begin(), colour_at.end(), 0);
+    std::stable_sort(colour_at.begin(), colour_at.end(), [&](int a, int b) { return count[a] < count[b]; });
+    for (int sl = 0; sl < o.n_colors; ++sl) slot_of[colour_at[sl]] = sl;
     o.color_begin.assign(o.n_colors + 1, 0);
-    for (int c = 0; c < o.n_colors; ++c) o.color_begin[c + 1] = o.color_begin[c] + round_up(count[c], row_align);
+    for (int sl = 0; sl < o.n_colors; ++sl) o.color_begin[sl + 1] = o.color_begin[sl] + round_up(count[colour_at[sl]], row_align);
     o.n_pad = o.n_colors ? o.color_begin[o.n_colors] : 0;
     if (o.n_pad == 0) o.n_pad = row_align;
     prefill.wait();
     if (o.n_pad <= n_pad_max) o.new2old.resize((size_t)o.n_pad);       // shrinks: no reallocation
     else o.new2old.assign((size_t)o.n_pad, -1);
     {
-        std::vector<int> run(o.color_begin.begin(), o.color_begin.end() - (o.n_colors ? 1 : 0));
+        std::vector<int> run(o.n_colors);
+        for (int c = 0; c < o.n_colors; ++c) run[c] = o.color_begin[slot_of[c]];
         for (int q = 0; q < nchunk; ++q) for (int c = 0; c < o.n_colors; ++c) { const int h = hist[q][c]; hist[q][c] = run[c]; run[c] += h; }
     }
     parallel_ranges(nchunk, nchunk, [&](int lo, int hi, int) {
@@ -326,8 +335,8 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     phase("bucket");
     if (sigma > 0) {
         std::vector<std::pair<int, int>> windows;
-        for (int c = 0; c < o.n_colors; ++c) {
-            const int lo = o.color_begin[c], hi = lo + count[c];
+        for (int sl = 0; sl < o.n_colors; ++sl) {
+            const int lo = o.color_begin[sl], hi = lo + count[colour_at[sl]];
             for (int w = lo; w < hi; w += sigma) windows.emplace_back(w, std::min(hi, w + sigma));
         }
         parallel_ranges((int)windows.size(), T, [&](int lo, int hi, int) {
