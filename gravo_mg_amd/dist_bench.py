@@ -60,7 +60,8 @@ def main(args):
     H, mass, lhs, rhs = single.build_workload(n1, n2, args.order)                # deterministic: every rank builds the same
 
     def new_engine():
-        e = cabi.Engine(device=local, row_align=64 * world, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels)
+        kw = {} if args.block_lanes is None else {"block_lanes": args.block_lanes}
+        e = cabi.Engine(device=local, row_align=64 * world, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels, **kw)
         e.use_hierarchy(H); e.set_mass(mass); e.set_system(lhs)
         return e
 

@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02o; mkdir -p $O; rm -f $R/gpurun_out/fullsize_configs.jsonl
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02p; mkdir -p $O; rm -f $R/gpurun_out/fullsize_configs.jsonl
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q --durations=6 > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json; echo

@@ -25,9 +25,34 @@ def test_bench_two_gpus_with_rccl(cabi, exchange):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["collective_backend"] == "nccl"
+    _check_line(line, exchange)
+
+
+def _check_line(line, exchange):
     assert line["residue"] <= 1e-4 and 3 <= line["iterations_to_1e-4"] <= 8
+    assert line["single_gpu_residues_reproduced"] is True
     if exchange == "p2p":
         assert line["exchange"] == "p2p", line.get("exchange_note")
-        assert line["collectives_per_cycle"] == 0 and line["exchange_us"] > 0
+        us = line["exchange_us"]
+        assert line["collectives_per_cycle"] == 0 and us["color0"] > 0 and us["halo_all"] > 0 and us["sum_per_cycle"] > 0
+        assert ("x1_halo" in us) == ("level 1 split" in line["config"]["partition"])
     else:
         assert line["collectives_per_cycle"] > 0
+
+
+@pytest.mark.parametrize("exchange,shard", [("p2p", 2), ("p2p", 1), ("halo", 2)])
+def test_bench_two_ranks_on_one_gpu(cabi, exchange, shard):
+    """The same launch with two ranks SHARING the one GPU of the test box (gloo for the bootstrap and the fallback's collectives: RCCL
+    refuses two ranks on one device): the whole `bench.py --gpus 2` path -- partition, peer-to-peer set-up through IPC handles,
+    validation against the single-GPU residues, per-exchange timings, the JSON line -- runs in the suite."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GMG_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--n1", "600", "--n2", "600", "--exchange", exchange,
+           "--shard-levels", str(shard), "--kernel-reps", "5", "--block-lanes", "1"]      # (one lane per row: the 60 k-row level 1 takes the big levels' layout)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["collective_backend"] == "gloo" and line["scaling"] == "strong"
+    _check_line(line, exchange)
+    if exchange == "p2p":
+        assert ("level 1 split" in line["config"]["partition"]) == (shard == 2)
