@@ -76,20 +76,47 @@ def main(args):
     p2p, note, exchange_us = None, None, None
     if args.exchange == "p2p" and world > 1:
         ok, note = 1, "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
-        cand = None
+        cand, blob = None, None
+        cpu_group = dist.new_group(backend="gloo")
+
+        def agreed(local_ok):
+            """MIN over the ranks: every step below is collective, so a rank that failed locally still takes part in the next
+            agreement (contributing 0) instead of leaving the others waiting in a collective it never enters."""
+            flags = [None] * world
+            dist.all_gather_object(flags, int(local_ok), group=cpu_group)
+            return min(flags) == 1
+
+        # step 1 (local): plan + mailbox; step 2 (collective): everybody's IPC blobs, None from a rank that failed
         try:
-            cpu_group = dist.new_group(backend="gloo")
+            if os.environ.get("GMG_P2P_SELFTEST_FAIL") and rank == world - 1:      # test hook: one rank cannot set the path up
+                raise RuntimeError("forced by GMG_P2P_SELFTEST_FAIL")
             cand = cabi.P2PCycle(eng, rank, world, 1)
-            blobs = [None] * world
-            dist.all_gather_object(blobs, cand.export(), group=cpu_group)
-            cand.connect(blobs)
-            dist.barrier()
-            cand.load(rhs, rhs)
-            got = cand.cycles(n_warm, 2)
-            if not np.allclose(got, ref_res, rtol=1e-9):
-                ok, note = 0, f"peer-to-peer residues {list(got)} differ from the single-GPU engine's {list(ref_res)}"
+            blob = cand.export()
         except Exception as e:          # noqa: BLE001
             ok, note = 0, f"peer-to-peer set-up failed on rank {rank}: {e!r}"
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob, group=cpu_group)
+        if ok and any(b is None for b in blobs):
+            ok, note = 0, f"rank {[i for i, b in enumerate(blobs) if b is None]} could not set up the peer-to-peer path"
+        # step 3 (local): map the peers' mailboxes
+        if ok:
+            try:
+                cand.connect(blobs)
+            except Exception as e:      # noqa: BLE001
+                ok, note = 0, f"peer-to-peer connect failed on rank {rank}: {e!r}"
+        if not agreed(ok):
+            if ok:
+                ok, note = 0, "another rank could not map the mailboxes"
+        else:
+            # step 4 (collective on the devices): the first cycles must reproduce the single-GPU residues; a rank that fails here
+            # shows up on the others as a device-side time-out (an error, not a hang)
+            try:
+                cand.load(rhs, rhs)
+                got = cand.cycles(n_warm, 2)
+                if not np.allclose(got, ref_res, rtol=1e-9):
+                    ok, note = 0, f"peer-to-peer residues {list(got)} differ from the single-GPU engine's {list(ref_res)}"
+            except Exception as e:      # noqa: BLE001
+                ok, note = 0, f"peer-to-peer cycles failed on rank {rank}: {e!r}"
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:

@@ -21,7 +21,7 @@ def test_bench_two_gpus_with_rccl(cabi, exchange):
     env.pop("GMG_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--n1", "600", "--n2", "600", "--exchange", exchange]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["collective_backend"] == "nccl"
@@ -49,10 +49,25 @@ def test_bench_two_ranks_on_one_gpu(cabi, exchange, shard):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29543",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--n1", "600", "--n2", "600", "--exchange", exchange,
            "--shard-levels", str(shard), "--kernel-reps", "5", "--block-lanes", "1"]      # (one lane per row: the 60 k-row level 1 takes the big levels' layout)
-    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["collective_backend"] == "gloo" and line["scaling"] == "strong"
     _check_line(line, exchange)
     if exchange == "p2p":
         assert ("level 1 split" in line["config"]["partition"]) == (shard == 2)
+
+
+def test_a_rank_that_cannot_set_up_peer_to_peer_takes_every_rank_to_the_fallback(cabi):
+    """bench.py --gpus N decides together: if one rank fails to set the peer-to-peer path up, all ranks run the collective (RCCL / here gloo)
+    orchestration and the line says so."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GMG_DIST_BACKEND="gloo", GMG_P2P_SELFTEST_FAIL="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29545",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--n1", "400", "--n2", "400", "--kernel-reps", "5"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["exchange"] == "halo (fallback)" and "could not set up" in line["exchange_note"] or "forced" in line["exchange_note"]
+    assert line["collectives_per_cycle"] > 0 and line["single_gpu_residues_reproduced"] is True
+    assert line["residue"] <= 1e-4 and 3 <= line["iterations_to_1e-4"] <= 8
+
