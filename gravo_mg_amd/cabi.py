@@ -21,6 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GMG_LIB_PATH") or os.path.join(_HERE, "lib", "libgravomg_hip.so")      # (override: A/B runs of experimental builds)
 
 GMG_OK, GMG_ERR_INVALID, GMG_ERR_NO_DEVICE, GMG_ERR_HIP, GMG_ERR_STATE, GMG_ERR_NUMERIC, GMG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
+DIVERGED = 1          # gmg_solve only, not an error: the iteration did not contract
 SMOOTHER_MULTICOLOR_GS, SMOOTHER_JACOBI = 0, 1
 COARSE_HOST_LDLT, COARSE_DEVICE_INVERSE = 0, 1
 
@@ -467,8 +468,11 @@ class Engine:
         X = B.copy(order="F") if x0 is None else _f64(x0).copy(order="F")
         iters, res = C.c_int(), C.c_double()
         conv = np.zeros(2 * max(int(max_iter), 1))
-        self._chk(lib().gmg_solve(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
-                                  C.byref(iters), C.byref(res), _pd(conv)))
+        rc = lib().gmg_solve(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
+                             C.byref(iters), C.byref(res), _pd(conv))
+        self.diverged = rc == DIVERGED       # not an error: the iteration did not contract, X holds the last iterate (include/gravomg_hip.h)
+        if not self.diverged:
+            self._chk(rc)
         return self._shape_like(X, rhs), iters.value, res.value, conv[: 2 * iters.value].reshape(-1, 2)
 
     def load_problem(self, b, x0):

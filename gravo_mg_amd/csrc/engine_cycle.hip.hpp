@@ -560,7 +560,10 @@ int coarse_host_begin(gmg_handle h, int d) {
     if (polled(h)) {
         hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1]);
         static const bool gate_off = std::getenv("GMG_NO_STREAM_GATE") != nullptr;      // A/B aid (scripts/coarse_host_time.py)
-        if (h->gate_ok && !gate_off) {
+        // The gate is only used once this handle has SEEN a published right-hand side arrive while its stream was still busy: wait_flag's
+        // safety net (an idle stream implies visible data) cannot fire behind a gate the host itself has to open, so on a host that does
+        // not see in-flight device writes a gated first contact would spin for ever.  The first coarse solve of a handle is ungated.
+        if (h->gate_ok && h->gate_proven && !gate_off) {
             if (hipStreamWaitValue64(h->stream, h->h_flag + 16, ++h->flag_seq[2], hipStreamWaitValueGte, ~0ull) == hipSuccess) {
                 hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
                                    (const double*)e, c.x, (int)cnt);
@@ -573,6 +576,8 @@ int coarse_host_begin(gmg_handle h, int d) {
         }
         int w = wait_flag(h, 1);
         if (w) return w;
+        if (h->poll) h->gate_proven = true;        // the flag showed up by itself (wait_flag clears h->poll otherwise)
+        if (!polled(h)) HIPCHK(hipStreamSynchronize(h->stream));
     } else {
         HIPCHK(hipMemcpyAsync(rc, c.b, sizeof(double) * cnt, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

@@ -260,6 +260,10 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     HIPCHK(hipMemsetAsync(p->flags, 0, sizeof(unsigned long long) * 64 * (size_t)world, h->stream));
     HIPCHK(hipMalloc((void**)&p->d_err, sizeof(int)));
     HIPCHK(hipMemsetAsync(p->d_err, 0, sizeof(int), h->stream));
+    if (const char* ts = std::getenv("GMG_P2P_TIMEOUT_S")) {
+        const double sec = std::atof(ts);
+        if (sec > 0.0) { const unsigned long long ticks = (unsigned long long)(sec * 1e8); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gmgk::g_p2p_timeout_ticks), &ticks, sizeof(ticks))); }
+    }
     HIPCHK(hipMalloc((void**)&p->d_sums, sizeof(double) * 4 * d));
     HIPCHK(hipStreamSynchronize(h->stream));
     p->planned = true;
@@ -295,7 +299,15 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     if (!p || !p->planned || !blobs) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare first");
     const int world = p->world, rank = p->rank, C = h->lv[0].ord.n_colors, nk = p->nk, d = p->d;
     const gmg_p2p_blob* bl = (const gmg_p2p_blob*)blobs;
+    // (a second connect: the mappings of the first one are closed, not dropped -- re-opening a handle that is still mapped can fail)
+    auto close_peer = [](P2PPeer& peer) {
+        if (peer.mbox_base) (void)hipIpcCloseMemHandle(peer.mbox_base);
+        if (peer.flag_base) (void)hipIpcCloseMemHandle(peer.flag_base);
+        peer.mbox_base = peer.flag_base = nullptr;
+    };
+    for (auto& peer : p->peers) close_peer(peer);
     p->peers.clear();
+    p->connected = false;
     {   // peer access to every other visible device (the IPC mapping below enables it lazily as well; "already enabled" and "not
         // supported" are both fine here -- an unreachable peer shows up in hipIpcOpenMemHandle)
         int ndev = 0;
@@ -311,8 +323,16 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
         if (bl[q].rank != q || bl[q].world != world || bl[q].d != d || bl[q].n_pad != h->lv[0].n_pad || bl[q].n_colors != C || bl[q].mbox_doubles != p->box_total[q] ||
             bl[q].reserved != (p->shard1 ? 1 : 0))
             return fail(h, GMG_ERR_INVALID, "peer " + std::to_string(q) + " published a different partition plan (different system / ordering / configuration?)");
-        HIPCHK(hipIpcOpenMemHandle(&peer.mbox_base, bl[q].mbox, hipIpcMemLazyEnablePeerAccess));
-        HIPCHK(hipIpcOpenMemHandle(&peer.flag_base, bl[q].flags, hipIpcMemLazyEnablePeerAccess));
+        // (every mapping that was opened is in p->peers -- or closed -- before an error leaves this function: p2p_release sees it)
+        if (hipIpcOpenMemHandle(&peer.mbox_base, bl[q].mbox, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, GMG_ERR_HIP, "hipIpcOpenMemHandle failed for the mailbox of rank " + std::to_string(q));
+        }
+        if (hipIpcOpenMemHandle(&peer.flag_base, bl[q].flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+            (void)hipGetLastError();
+            close_peer(peer);
+            return fail(h, GMG_ERR_HIP, "hipIpcOpenMemHandle failed for the arrival counters of rank " + std::to_string(q));
+        }
         p->peers.push_back(peer);
     }
     const int np = (int)p->peers.size();
@@ -402,6 +422,9 @@ int gmg_p2p_load(gmg_handle h, const double* b, const double* x0) try {
     DistP2P* p = h->p2p;
     if (!p || !p->connected) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare / gmg_p2p_connect first");
     unbind_level0(h);
+    // a time-out of an earlier problem (rank skew at first use, a peer that came late) must not poison this one: the exchange
+    // kernels give up at once while the word is set
+    HIPCHK(hipMemsetAsync(p->d_err, 0, sizeof(int), h->stream));
     int rc = gmg_load_problem(h, b, x0, p->d);
     if (rc) return rc;
     // the distributed steps address the level-0 vectors through the `bound` state of the gmg_dist_* entry points
@@ -581,6 +604,10 @@ int gmg_p2p_fetch(gmg_handle h, double* x) try {
     // the level-0 rows exchange moves every rank's own rows of a level-0 vector
     int rc = p2p_exchange(h, l.ord.n_colors + 1, l.x, l.n_pad);
     if (rc) return rc;
+    int herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, p->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (herr) return fail(h, GMG_ERR_STATE, "a peer-to-peer exchange timed out (a rank is missing or ran a different sequence): x is incomplete");
     return to_host(h, 0, l.x, p->d, x);
 } GMG_CATCH_H
 

@@ -165,6 +165,7 @@ struct gmg_solver_s {
     // h_flag[16]: written by the HOST -- the stream waits on it (hipStreamWaitValue64) in front of the work that needs the host's
     // coarsest solution, so that work is enqueued before the host solves (engine_cycle.hip.hpp::coarse_host_begin / _serve)
     bool gate_ok = true;                 // false once hipStreamWaitValue64 was refused: launch after the solve instead
+    bool gate_proven = false;            // true once a published right-hand side was seen by the polling host while the stream was busy (ungated)
     bool coarse_pending = false;         // a gate is enqueued and the host has not answered it yet
     bool coarse_warm = false;            // the solving thread has read the current factor once (SupernodalLdlt::warm)
     double coarse_warm_sink = 0.0;

@@ -858,7 +858,11 @@ struct P2POp {
     unsigned long long* local_flag; // this rank's arrival counter for the peer
 };
 
-// vec: D columns with leading dimension ld.  err (device int): set to 1 when a wait timed out (~4 s of wall clock).
+// How long a pull waits for its peer, in ticks of the 100 MHz wall clock (default 4 s; engine_dist.hip.hpp sets it from
+// GMG_P2P_TIMEOUT_S at gmg_p2p_prepare: first-use code-object loads, paging or a debugger can skew ranks by more than that).
+__device__ unsigned long long g_p2p_timeout_ticks = 400000000ull;
+
+// vec: D columns with leading dimension ld.  err (device int): set to 1 when a wait timed out (g_p2p_timeout_ticks of wall clock).
 // Grid: 2 * n_peers * B blocks -- per peer B blocks push and B blocks pull, each its strided share of the values (B = 1 for a halo
 // of a few thousand entries; a whole vector moves with tens of blocks: one block's stores do not fill an xGMI link).  The last
 // push block to finish (done[peer], device memory, zero between launches) publishes the sequence number; no block of this
@@ -895,7 +899,7 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = 1;
             while (!timed_out && __hip_atomic_load(op.local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
                 __builtin_amdgcn_s_sleep(8);
-                if (wall_clock64() - t0 > 400000000ull) { timed_out = 1; atomicExch(err, 1); break; }
+                if (wall_clock64() - t0 > g_p2p_timeout_ticks) { timed_out = 1; atomicExch(err, 1); break; }
             }
         }
         __syncthreads();
@@ -929,7 +933,7 @@ __global__ __launch_bounds__(64) void p2p_allreduce_small(const P2POp* __restric
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = 1;
         while (!timed_out && __hip_atomic_load(ops[t].local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 400000000ull) { timed_out = 1; atomicExch(err, 1); break; }
+            if (wall_clock64() - t0 > g_p2p_timeout_ticks) { timed_out = 1; atomicExch(err, 1); break; }
         }
     }
     __syncthreads();

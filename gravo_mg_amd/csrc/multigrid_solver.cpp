@@ -2,6 +2,7 @@
 #include "multigrid_solver.h"
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -181,6 +182,7 @@ void MultigridSolver::buildHierarchy() {
 int MultigridSolver::ensureEngine() {
     gmg_config want = engineConfig;
     want.pre_iters = preIters; want.post_iters = postIters; want.verbose = 0;
+    if (exactGsActive_) { want.smoother = GMG_SMOOTHER_MULTICOLOR_GS; want.block_rows = 0; want.gs_omega = 1.0; }      // scoped fallback, see solve()
     if (engine_ && !configEqual(want, createdWith_)) { gmg_destroy(engine_); engine_ = nullptr; }
     if (!engine_) {
         int rc = gmg_create(&want, &engine_);
@@ -216,6 +218,10 @@ int MultigridSolver::ensureSystem(const SparseMatrix& LHS) {
     int rc = prepareEngine();
     if (rc) return rc;
     const std::pair<uint64_t, uint64_t> digLHS = LHS.digest();
+    if (exactGsActive_ && digLHS != exactGsFor_) {       // another system: back to the configured engine
+        exactGsActive_ = false;
+        if ((rc = prepareEngine())) return rc;
+    }
     if (!systemReady_ || uploadedLHS_ != digLHS) {
         // mass diagonal for the M / M^-1 norms (multigrid_solver.cpp:1248-1264)
         std::vector<double> md(M.cols(), 0.0);
@@ -288,24 +294,47 @@ void MultigridSolver::solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int s
     std::vector<double> conv(2 * (size_t)std::max(maxIter, 1));
     int iters = 0;
     double residue = std::numeric_limits<double>::max();
+    // The initial guess, in case the solve has to be repeated (gmg_solve overwrites x with the last iterate, as the reference does).
+    // The reference's binding always passes x0 = rhs (core.cpp:69): a sampled comparison recognises that without a pass over the
+    // vectors; any other guess is copied.
+    bool x0IsRhs = x.data.size() == rhs.data.size();
+    if (x0IsRhs) {
+        const size_t cnt = x.data.size(), step = std::max<size_t>(1, cnt / 4096);
+        for (size_t i = 0; i < cnt && x0IsRhs; i += step) x0IsRhs = x.data[i] == rhs.data[i];
+        if (cnt) x0IsRhs = x0IsRhs && x.data[cnt - 1] == rhs.data[cnt - 1];
+    }
+    std::vector<double> x0;
+    if (!x0IsRhs) x0 = x.data;
     int rc = gmg_solve(engine_, rhs.data.data(), x.data.data(), rhs.cols(), accuracy, stoppingCriteria, maxIter, &iters, &residue, conv.data());
-    if (rc != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
+    if (rc != GMG_OK && rc != GMG_DIVERGED) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
     // The engine's default smoothers (over-relaxed multicolour sweep on level 0, block-hybrid sweeps below) are not the reference's
-    // Gauss-Seidel and carry no convergence guarantee for every SPD matrix.  If they diverged (x still holds the initial guess),
-    // solve again with Gauss-Seidel in colour order on EVERY level -- the reference's update in a permuted order, convergent for
-    // every SPD matrix -- and keep that configuration for this solver object.
-    double diverged = 0;
-    (void)gmg_get_timing(engine_, "diverged", &diverged);
-    solverTiming["fallback_exact_gs"] = 0.0;
-    if (diverged != 0.0 && (engineConfig.block_rows != 0 || engineConfig.gs_omega != 1.0 || engineConfig.smoother != GMG_SMOOTHER_MULTICOLOR_GS)) {
-        if (verbose) std::cout << "the default smoothers diverged (residue " << residue << "): solving again with Gauss-Seidel on every level\n";
-        engineConfig.smoother = GMG_SMOOTHER_MULTICOLOR_GS;
-        engineConfig.block_rows = 0;
-        engineConfig.gs_omega = 1.0;
+    // Gauss-Seidel and carry no convergence guarantee for every SPD matrix.  If the iteration did not contract (GMG_DIVERGED), solve
+    // again from the same initial guess with Gauss-Seidel in colour order on EVERY level -- the reference's update in a permuted
+    // order, convergent for every SPD matrix.  The switch is scoped to THIS system (keyed by its content digest: the next solve on
+    // another matrix runs the configured engine again), never overrides a smoother the caller chose (weighted Jacobi), never touches
+    // the public `engineConfig`, and is always reported (message + solverTiming["fallback_exact_gs"]).
+    solverTiming["fallback_exact_gs"] = exactGsActive_ ? 1.0 : 0.0;
+    solverTiming["diverged"] = 0.0;
+    const bool canFallBack = !exactGsActive_ && engineConfig.smoother == GMG_SMOOTHER_MULTICOLOR_GS && (engineConfig.block_rows != 0 || engineConfig.gs_omega != 1.0);
+    if (rc == GMG_DIVERGED && canFallBack) {
+        std::cout << "gravomg: the default smoothers did not contract on this system (residue " << residue << " after " << iters
+                  << " cycles): solving again with Gauss-Seidel in colour order on every level" << std::endl;
+        exactGsActive_ = true;
+        exactGsFor_ = uploadedLHS_;
+        if (x0IsRhs) x.data = rhs.data; else x.data = x0;
         if (ensureSystem(LHS) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return; }
         rc = gmg_solve(engine_, rhs.data.data(), x.data.data(), rhs.cols(), accuracy, stoppingCriteria, maxIter, &iters, &residue, conv.data());
-        if (rc != GMG_OK) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
+        if (rc != GMG_OK && rc != GMG_DIVERGED) { err_ = gmg_last_error(engine_); std::cout << "ERROR! " << err_ << std::endl; return; }
         solverTiming["fallback_exact_gs"] = 1.0;
+    }
+    if (rc == GMG_DIVERGED) {
+        // the reference would hand back its last iterate without a word; so does this, with a word -- unless the iteration blew up
+        // (residue not finite or 1e4 x the smallest one seen: the engine stopped it), which no caller can use
+        solverTiming["diverged"] = 1.0;
+        std::cout << "gravomg: the V-cycle iteration did not contract (residue " << residue << " after " << iters << " cycles); x holds the last iterate" << std::endl;
+        double blown = 0;
+        (void)gmg_get_timing(engine_, "blown_up", &blown);
+        if (blown != 0.0 || !std::isfinite(residue)) { err_ = "the V-cycle iteration diverged (residue " + std::to_string(residue) + ")"; std::cout << "ERROR! " << err_ << std::endl; }
     }
     for (int i = 0; i < iters; ++i) {
         convergence.push_back({conv[2 * i], conv[2 * i + 1]});          // :1414

@@ -137,6 +137,8 @@ private:
     std::vector<std::pair<uint64_t, uint64_t>> uploadedU_;     // digests of what the engine holds
     std::pair<uint64_t, uint64_t> uploadedLHS_{0, 0};
     bool systemReady_ = false;
+    bool exactGsActive_ = false;                               // Gauss-Seidel on every level instead of the configured smoothers ...
+    std::pair<uint64_t, uint64_t> exactGsFor_{0, 0};           // ... for the system with this digest only (solve())
     gmg_config createdWith_;
     std::string err_;
 };

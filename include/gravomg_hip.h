@@ -40,7 +40,8 @@ typedef enum {
     GMG_ERR_HIP = -3,          /* a HIP runtime call failed */
     GMG_ERR_STATE = -4,        /* call order: hierarchy / system not set */
     GMG_ERR_NUMERIC = -5,      /* zero/missing diagonal, singular coarsest operator */
-    GMG_ERR_UNSUPPORTED = -6   /* option outside the hot-path scope (F/W-cycle, SIG06, ...) */
+    GMG_ERR_UNSUPPORTED = -6,  /* option outside the hot-path scope (F/W-cycle, SIG06, ...) */
+    GMG_DIVERGED = 1           /* gmg_solve only, NOT an error: the iteration did not contract (see gmg_solve); x holds the last iterate */
 } gmg_status;
 
 enum { GMG_SMOOTHER_MULTICOLOR_GS = 0, GMG_SMOOTHER_JACOBI = 1 };
@@ -167,11 +168,15 @@ int gmg_vcycle(gmg_handle h, const double* b, double* x, int d);
 /* The MG branch of solve(), multigrid_solver.cpp:1408-1419: do { V-cycle; residualCheck } while
  * (residue > tol && it < max_iter).  x arrives holding the initial guess (the binding passes x0 = rhs,
  * gravomg_bindings/src/cpp/core.cpp:69).  conv (optional) receives (elapsed_ms, residue) pairs and must
- * hold 2*max_iter doubles.  If the iteration DIVERGED (it ended above tol with a residue that is not finite or larger than after the
- * first cycle) x keeps the initial guess and gmg_get_timing(h, "diverged") is 1: the default smoothers are parallel orderings /
- * block variants of the reference's Gauss-Seidel without its convergence guarantee; a handle created with block_rows = 0 and
- * gs_omega = 1 runs Gauss-Seidel in colour order on every level (convergent for every SPD matrix) -- the retry the C++ mirror
- * (MGBS::MultigridSolver::solve) performs by itself. */
+ * hold 2*max_iter doubles.  Like the reference, x ALWAYS receives the last iterate.  The return value tells a caller what the
+ * reference leaves it to find out: GMG_OK when the loop ended the way the reference's does (residue <= tol, or max_iter reached while
+ * the residue was at or below the one after the first cycle), GMG_DIVERGED (= 1, not an error; gmg_get_timing(h, "diverged") is 1 too)
+ * when it ended above tol with a residue that is not finite or larger than after the first cycle.  The loop also stops early -- it
+ * cannot recover -- at the first non-finite residue and once the residue exceeds 1e4 x the smallest one seen (iters_out then is
+ * < max_iter).  The default smoothers are parallel orderings / block variants of the reference's Gauss-Seidel without its
+ * convergence guarantee; a handle created with block_rows = 0 and gs_omega = 1 runs Gauss-Seidel in colour order on every level
+ * (convergent for every SPD matrix) -- the retry the C++ mirror (MGBS::MultigridSolver::solve) performs by itself from the same
+ * initial guess. */
 int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter,
               int* iters_out, double* residue_out, double* conv);
 

@@ -158,25 +158,42 @@ def test_reference_call_pattern_smoothing_and_poisson(gravomg, oracle, tmp_path)
 
 
 @pytest.mark.gpu
-def test_diverging_smoother_falls_back_to_gauss_seidel_on_every_level(gravomg):
-    """The engine's default smoothers carry no convergence guarantee for every SPD matrix; solve() must notice a diverging
-    iteration and repeat it with Gauss-Seidel (colour order) on every level.  Provoked here with an over-relaxed Jacobi smoother."""
+def test_diverging_smoother_falls_back_to_gauss_seidel_on_every_level(gravomg, capfd):
+    """The engine's default smoothers carry no convergence guarantee for every SPD matrix; solve() must notice an iteration that
+    does not contract and repeat it, from the same initial guess, with Gauss-Seidel (colour order) on every level -- for THAT
+    system only, with a message, without touching the caller's engine options.  Provoked with the engine's test aid
+    GMG_TEST_FORCE_DIVERGED (every configuration but Gauss-Seidel on every level then reports GMG_DIVERGED): no SPD system here
+    makes the default smoothers fail."""
     V, F, S, M, mass = _problem()
     solver = gravomg.MultigridSolver(V, gravomg.neighbors_from_stiffness(S), M, lower_bound=40, tolerance=1e-4, max_iter=30)
     lhs = (M * 1e-6 + S).tocsr()
     rhs = M @ np.random.default_rng(1).standard_normal((V.shape[0], 1))
     x_ok = solver.solve(lhs, rhs)
     assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.residual(lhs, rhs, x_ok) <= 1e-4
-    solver.set_engine_option("smoother", 1)             # weighted Jacobi ...
-    solver.set_engine_option("jacobi_omega", 1.95)      # ... far beyond its stability limit
-    x = solver.solve(lhs, rhs)
+    capfd.readouterr()
+    os.environ["GMG_TEST_FORCE_DIVERGED"] = "1"
+    try:
+        x = solver.solve(lhs, rhs)
+    finally:
+        del os.environ["GMG_TEST_FORCE_DIVERGED"]
     t = solver.solver_timing
-    assert t["fallback_exact_gs"] == 1.0
+    assert "Gauss-Seidel in colour order on every level" in capfd.readouterr().out        # said so without `verbose`
+    assert t["fallback_exact_gs"] == 1.0 and t["diverged"] == 0.0
     assert t["residue"] <= 1e-4 and solver.residual(lhs, rhs, x) <= 1e-4
     assert np.sqrt((mass[:, None] * (x - x_ok) ** 2).sum() / (mass[:, None] * x_ok ** 2).sum()) <= 1e-2
-    # the safe configuration is kept for later solves of this object
+    # the safe configuration stays for THIS system (no second failed attempt) ...
     solver.solve(lhs, rhs)
-    assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.solver_timing["residue"] <= 1e-4
+    assert solver.solver_timing["fallback_exact_gs"] == 1.0 and solver.solver_timing["residue"] <= 1e-4
+    # ... and only for it: another matrix runs the configured engine again
+    lhs2 = (M * 1e-3 + S).tocsr()
+    x2 = solver.solve(lhs2, rhs)
+    assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.residual(lhs2, rhs, x2) <= 1e-4
+    # a smoother the caller chose is never replaced: weighted Jacobi far beyond its stability limit blows up, and solve() says so
+    solver.set_engine_option("smoother", 1)
+    solver.set_engine_option("jacobi_omega", 1.95)
+    with pytest.raises(RuntimeError, match="diverged"):
+        solver.solve(lhs2, rhs)
+    assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.solver_timing["diverged"] == 1.0
 
 
 @pytest.mark.gpu

@@ -375,16 +375,24 @@ def test_device_coarse_apply_against_the_oracle(setup, cabi, oracle):
     assert abs(oracle.residual_check(P.lhs, P.mass, P.rhs, xs, 2) - res) <= 1e-3 * res + 1e-7
 
 
-def test_diverged_solve_keeps_the_initial_guess_and_says_so(cabi):
-    """gmg_solve: an iteration that ends above the tolerance with a residue larger than after its first cycle (or not finite) must not
-    overwrite x, and reports timing key "diverged" = 1 (include/gravomg_hip.h)."""
+def test_diverged_solve_returns_the_last_iterate_and_says_so(cabi):
+    """gmg_solve: like the reference, x always receives the last iterate; an iteration that ends above the tolerance with a residue
+    larger than after its first cycle (or not finite) returns GMG_DIVERGED (not an error) and timing key "diverged" = 1, and stops
+    as soon as the residue is not finite or 1e4 x the smallest one seen (include/gravomg_hip.h)."""
     P = problems.torus_problem(64, 60, "poisson", 60)
     good = cabi.Engine(); good.set_prolongations(P.U); good.set_mass(P.mass); good.set_system(P.lhs)
     x, it, res, conv = good.solve(P.rhs, tol=1e-4, max_iter=30)
-    assert res <= 1e-4 and good.timing("diverged") == 0.0
+    assert res <= 1e-4 and good.timing("diverged") == 0.0 and not good.diverged
+    # a solve that merely runs out of cycles while contracting is NOT "diverged"
+    x2, it2, res2, conv2 = good.solve(P.rhs, tol=1e-30, max_iter=2)
+    assert it2 == 2 and res2 > 1e-30 and not good.diverged and good.timing("diverged") == 0.0
+    assert np.array_equal(conv2[:, 1], conv[:2, 1])
     bad = cabi.Engine(smoother=cabi.SMOOTHER_JACOBI, jacobi_omega=1.95)
     bad.set_prolongations(P.U); bad.set_mass(P.mass); bad.set_system(P.lhs)
-    xb, itb, resb, convb = bad.solve(P.rhs, tol=1e-4, max_iter=12)
-    assert not (resb <= 1e-4) and bad.timing("diverged") == 1.0 and itb == 12 and len(convb) == 12
-    assert np.array_equal(np.asarray(xb).reshape(-1), np.asarray(P.rhs).reshape(-1))        # x0 = rhs untouched
-
+    xb, itb, resb, convb = bad.solve(P.rhs, tol=1e-4, max_iter=40)
+    assert not (resb <= 1e-4) and bad.diverged and bad.timing("diverged") == 1.0 and len(convb) == itb
+    assert 3 <= itb < 40 and convb[-1, 1] > 1e4 * convb[:, 1].min()           # stopped early: blown up
+    # the last iterate, not the initial guess: running the same number of cycles on the resident problem gives the same vector
+    bad.load_problem(P.rhs, P.rhs); bad.run_cycles(itb, 2)
+    assert np.array_equal(np.asarray(xb).reshape(-1), bad.fetch_solution().reshape(-1))
+    assert not np.array_equal(np.asarray(xb).reshape(-1), np.asarray(P.rhs).reshape(-1))
