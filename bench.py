@@ -48,6 +48,15 @@ def build_workload(n1, n2, order="natural"):
     return H, mass, lhs, rhs
 
 
+def build_config(cfg):
+    """Another BASELINE config as the main workload (profiling aid; the driver's line is the default workload)."""
+    from gravo_mg_amd import cabi, meshgen
+    name, pos, S, mass, lhs, rhs = meshgen.baseline_config(cfg)
+    H = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S), ratio=8.0, lower_bound=1000)
+    log(f"[bench] {name}: n={lhs.shape[0]} nnz={lhs.nnz} d={rhs.shape[1]}")
+    return name, H, mass, lhs, rhs
+
+
 def load_pmc_traffic(workload):
     """HBM bytes per fine-level launch from the committed rocprofv3 --pmc summary (profiles/), if one matches: (value, source).
     The counters cannot be read inside this run (rocprofv3 wraps the process), so the figure is STATIC: measured once per
@@ -124,6 +133,8 @@ def main():
     ap.add_argument("--n1", type=int, default=1732)
     ap.add_argument("--n2", type=int, default=1732)
     ap.add_argument("--order", default="natural", choices=["natural", "random"])
+    ap.add_argument("--config", default=None, choices=["1", "2", "3", "4", "4r", "5", "5b", "6"],
+                    help="profiling aid: another BASELINE config (meshgen.baseline_config) as the main workload instead of the torus --n1 x --n2")
     ap.add_argument("--cpu-cycles", type=int, default=25, help="V-cycles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--coarse", default="host", choices=["host", "device"])
     ap.add_argument("--graph", action="store_true", help="replay the cycle legs from hipGraphs (same cycle time, ~5 ms instantiation per system)")
@@ -155,8 +166,13 @@ def main():
 
     assert torch.cuda.is_available() and cabi.device_count() > 0, "bench.py needs a HIP device (no CPU fallback)"
     workload = f"torus{args.n1}x{args.n2}-poisson-tau1e-6-d1-{args.order}"
-    H, mass, lhs, rhs = build_workload(args.n1, args.n2, args.order)
+    if args.config:
+        workload, H, mass, lhs, rhs = build_config(args.config)
+        args.no_variants = True
+    else:
+        H, mass, lhs, rhs = build_workload(args.n1, args.n2, args.order)
     n0 = lhs.shape[0]
+    d0 = int(rhs.shape[1])
 
     kw = {}
     if args.block_rows is not None:
@@ -200,13 +216,13 @@ def main():
     ms_per_step = 1e3 * (t1 - t0) / args.steps
 
     # ---- roofline of the dominant kernel: fine-level Gauss-Seidel colour launches (gs_color<1,1>) --------
-    sweep_ms, launches = eng.bench_kernel(0, 0, 1, args.kernel_reps)
-    sweep_bytes = eng.algorithmic_bytes(0, 0, 1)
+    sweep_ms, launches = eng.bench_kernel(0, 0, d0, args.kernel_reps)
+    sweep_bytes = eng.algorithmic_bytes(0, 0, d0)
     achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
     kern = {}
     for name, kind in (("residual", 1), ("restrict", 2), ("prolong_add", 3), ("norm", 4)):
-        ms, _ = eng.bench_kernel(kind, 0, 1, args.kernel_reps)
-        by = eng.algorithmic_bytes(kind, 0, 1)
+        ms, _ = eng.bench_kernel(kind, 0, d0, args.kernel_reps)
+        by = eng.algorithmic_bytes(kind, 0, d0)
         kern[name] = {"ms": ms, "GBps": by / (ms * 1e-3) / 1e9}
     traffic, traffic_source = load_pmc_traffic(workload)
     roofline = {

@@ -1634,24 +1634,31 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, xb.data(), (size_t)n, 1, w.data());
             best = std::min(best, 1e3 * ms_since(t0) / reps);
         }
-        double best2 = 1e30, diff = 0.0;
-        {
-            SpinHelper helper;
-            helper.arm();
+        long part[3];
+        f.split_report(part);
+        std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread (best of 20 batches of %d); %d parts of the elimination "
+                     "tree, panel entries in the lightest / heaviest part / above them: %ld / %ld / %ld\n", n, f.factor_nnz(), best, reps, f.parts(), part[0], part[1], part[2]);
+        for (int threads = 2; threads <= std::min(8, f.parts()); threads += threads < 4 ? 1 : 2) {
+            double best2 = 1e30, diff = 0.0;
+            SpinTeam team(threads - 1);
+            team.arm();
             std::vector<double> x2((size_t)n);
             for (int batch = 0; batch < 20; ++batch) {
                 auto t0 = clk::now();
-                for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, x2.data(), (size_t)n, 1, w.data(), &helper);
+                for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, x2.data(), (size_t)n, 1, w.data(), &team);
                 best2 = std::min(best2, 1e3 * ms_since(t0) / reps);
             }
-            helper.disarm();
+            team.disarm();
             for (int i = 0; i < n; ++i) diff = std::max(diff, std::fabs(x2[i] - xb[i]));
+            double ph[6];
+            team.arm();
+            f.profile(b, w.data(), &team, reps, ph);
+            team.disarm();
+            std::fprintf(stderr, "[gmg ldlt] %d threads: %.2f us per solve; max |difference| to the one-thread solve %.1e  (phases: parts down %.1f, top down %.1f, top up %.1f, "
+                         "parts up %.1f us; %d top supernodes)\n", threads, best2, diff, ph[0], ph[1], ph[2], ph[3], (int)ph[4]);
         }
-        long part[3];
-        f.split_report(part);
-        std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread, %.2f us with the helper thread (best of 20 batches of %d; "
-                     "panel entries in the two halves / above them: %ld / %ld / %ld; max |difference| %.1e)\n", n, f.factor_nnz(), best, best2, reps, part[0], part[1],
-                     part[2], diff);
+        { double ph[6]; f.profile(b, w.data(), nullptr, reps, ph);
+          std::fprintf(stderr, "[gmg ldlt] 1 thread phases: parts down %.1f, top down %.1f, top up %.1f, parts up %.1f us\n", ph[0], ph[1], ph[2], ph[3]); }
     }
     if (std::getenv("GMG_LDLT_CROSSCHECK")) {
         SparseLDLT g;

@@ -519,17 +519,21 @@ void coarse_host_solve(gmg_handle h, int d) {
     h->timing["coarse_host_ms"] += ms_since(t0);
 }
 
-// While one of these is alive the helper thread of the coarsest back-substitution spins (a hand-over costs ~0.2 us instead of a
-// wake-up); outside it sleeps and single solves run both halves on the calling thread.  GMG_LDLT_THREADS=1: never start it.
+// While one of these is alive the helper threads of the coarsest back-substitution spin (a hand-over costs ~0.2 us instead of a
+// wake-up); outside they sleep and single solves run every part of the elimination tree on the calling thread.
+// GMG_LDLT_THREADS = threads of a solve including the caller (default: as many as the factor has parts, at most 8); 1: no team.
 struct HelperScope {
     gmg_handle h;
     explicit HelperScope(gmg_handle hh) : h(hh) {
-        static const bool off = std::getenv("GMG_LDLT_THREADS") && std::atoi(std::getenv("GMG_LDLT_THREADS")) <= 1;
-        // (every rank of a multi-GPU job would keep two threads busy -- this one polls -- on the CPUs the job may use: no helper
-        // unless there are at least three per rank, a throttled spinning thread costs far more than it saves)
+        static const int env_threads = std::getenv("GMG_LDLT_THREADS") ? std::atoi(std::getenv("GMG_LDLT_THREADS")) : 0;
+        // (every rank of a multi-GPU job keeps its team busy -- and this thread polls -- on the CPUs the job may use: a rank's team
+        // is sized to its share of them minus one CPU of slack, a throttled spinning thread costs far more than it saves)
         const int ranks = h->dist_ready ? std::max(1, h->world) : 1;
-        if (off || h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT || cpu_budget() < 3 * ranks) { h = nullptr; return; }
-        if (!h->coarse_helper) h->coarse_helper.reset(new SpinHelper());
+        const int share = cpu_budget() / ranks;
+        int threads = std::min(std::min(h->coarse.parts(), 8), share - 1);
+        if (env_threads > 0) threads = std::min(threads, env_threads);
+        if (h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT || threads < 2) { h = nullptr; return; }
+        if (!h->coarse_helper || h->coarse_helper->helpers() != threads - 1) h->coarse_helper.reset(new SpinTeam(threads - 1));
         h->coarse_helper->stay_near_caller();
         h->coarse_helper->arm();
     }

@@ -173,7 +173,7 @@ struct gmg_solver_s {
     bool poll = true;             // GMG_POLL=0: copy + hipStreamSynchronize instead (the waiting thread then sleeps instead of spinning)
     double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
     std::vector<double> coarse_work;
-    std::unique_ptr<SpinHelper> coarse_helper;      // second thread of the coarsest back-substitution, armed for the duration of a solve (HelperScope)
+    std::unique_ptr<SpinTeam> coarse_helper;        // the other threads of the coarsest back-substitution, armed for the duration of a solve (HelperScope)
     std::map<std::string, double> timing;
     std::map<int, hipGraphExec_t> graphs;
     int loaded_d = 0;

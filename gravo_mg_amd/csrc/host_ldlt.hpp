@@ -332,24 +332,32 @@ private:
 };
 
 // ---- a second thread for the back-substitution of a V-cycle ------------------------------------------------------
-// One job at a time, handed over through two words the threads spin on (a hand-over costs a cache-line transfer, ~0.1-0.2 us; the
-// worker pool's queue + condition variable would cost tens).  The helper spins only while it is ARMED -- for the duration of a
-// solve -- and sleeps on a condition variable otherwise; run() on an unarmed helper executes the job on the caller.
-class SpinHelper {
+// A small team of spinning threads for the coarsest back-substitution.  A batch of independent jobs is handed over through two
+// words the threads spin on (a hand-over costs a cache-line transfer, ~0.1-0.2 us; the worker pool's queue + condition variable
+// would cost tens).  The helpers spin only while the team is ARMED -- for the duration of a solve -- and sleep on a condition
+// variable otherwise; run() on an unarmed team executes every job on the caller.  Whoever claims a job runs it (the caller takes
+// part): a helper that lost its core to another thread for a scheduler tick -- milliseconds -- costs nothing, the others and the
+// caller do its share.  Results never depend on who ran what (the jobs are independent and the caller combines them in job order).
+class SpinTeam {
 public:
-    SpinHelper() : th_([this] { loop(); }) {}
-    ~SpinHelper() {
+    explicit SpinTeam(int helpers = 1) {
+        helpers = std::max(1, std::min(helpers, 15));
+        th_.reserve((size_t)helpers);
+        for (int i = 0; i < helpers; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~SpinTeam() {
         { std::lock_guard<std::mutex> lk(m_); quit_ = true; }
         cv_.notify_all();
-        th_.join();
+        for (auto& t : th_) t.join();
     }
-    SpinHelper(const SpinHelper&) = delete;
-    SpinHelper& operator=(const SpinHelper&) = delete;
+    SpinTeam(const SpinTeam&) = delete;
+    SpinTeam& operator=(const SpinTeam&) = delete;
+    int helpers() const { return (int)th_.size(); }
     void arm() { { std::lock_guard<std::mutex> lk(m_); ++armed_; } cv_.notify_all(); }
     void disarm() { std::lock_guard<std::mutex> lk(m_); --armed_; }
     bool armed() const { return armed_.load(std::memory_order_acquire) > 0; }
-    // Keep the helper on a core that shares its last-level cache with the CALLING thread (not the same core): the two threads
-    // hand ~200 cache lines of the solution vector back and forth per solve, which costs several times more across L3 domains
+    // Keep the helpers on cores that share their last-level cache with the CALLING thread (not the same core): the threads hand
+    // a few hundred cache lines of the solution vector back and forth per solve, which costs several times more across L3 domains
     // (measured: 52 us per solve with the helper next door, 74 us across CCDs of an EPYC 9575F).  Best effort: topology from
     // sysfs, silently skipped where it is not readable or the affinity call is refused.
     void stay_near_caller() {
@@ -385,25 +393,39 @@ public:
         int n = 0;
         for (int c : l3)
             if (c != cpu && std::find(sib.begin(), sib.end(), c) == sib.end() && c < CPU_SETSIZE) { CPU_SET(c, &set); ++n; }
-        if (n > 0) (void)pthread_setaffinity_np(th_.native_handle(), sizeof set, &set);
+        if (n >= (int)th_.size())          // (fewer cores next door than helpers: leave the placement to the scheduler)
+            for (auto& t : th_) (void)pthread_setaffinity_np(t.native_handle(), sizeof set, &set);
     }
-    // start fn(arg) on the helper (or run it here when the helper sleeps); wait() returns when it is done
-    void run(void (*fn)(void*), void* arg) {
-        if (!armed()) { fn(arg); inline_ = true; return; }
-        inline_ = false;
-        fn_ = fn; arg_ = arg;
-        go_.store(++ticket_, std::memory_order_release);
-    }
-    // Whoever claims the job runs it: if the helper has not picked it up by the time the caller is done with its own half (the
-    // helper may have lost its core to another thread for a scheduler tick -- milliseconds), the caller does it itself.
-    void wait() {
-        if (inline_) return;
-        unsigned expected = ticket_ - 1;
-        if (claim_.compare_exchange_strong(expected, ticket_, std::memory_order_acq_rel)) { fn_(arg_); return; }
-        while (done_.load(std::memory_order_acquire) != ticket_) __builtin_ia32_pause();
+    // fn(arg, j) for j = 0 .. njobs - 1, each exactly once, on the helpers and the calling thread; returns when all are done
+    void run(void (*fn)(void*, int), void* arg, int njobs) {
+        if (njobs <= 0) return;
+        if (!armed() || njobs == 1) { for (int j = 0; j < njobs; ++j) fn(arg, j); return; }
+        fn_ = fn; arg_ = arg; njobs_ = (unsigned)njobs;
+        const uint64_t tk = (uint64_t)(++ticket_) << 32;
+        done_.store(tk, std::memory_order_relaxed);
+        claim_.store(tk, std::memory_order_release);          // publishes fn_ / arg_ / njobs_ with the ticket
+        work(ticket_);
+        while (done_.load(std::memory_order_acquire) != (tk | (unsigned)njobs)) __builtin_ia32_pause();
+        // close the batch: a late helper that still holds an old value of the claim word must fail its exchange once the next
+        // batch's description (fn_ / arg_ / njobs_) is being written
+        claim_.store(tk | 0xffffffffu, std::memory_order_release);
     }
 
 private:
+    // claim and run jobs of ticket `tk` until none is left (or a newer ticket shows up: then this thread is late, not needed)
+    void work(unsigned tk) {
+        uint64_t v = claim_.load(std::memory_order_acquire);
+        for (;;) {
+            if ((unsigned)(v >> 32) != tk) return;
+            const unsigned j = (unsigned)v;
+            if (j >= njobs_) return;                           // (njobs_ belongs to ticket tk: read after the acquire that showed tk)
+            if (claim_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) {
+                fn_(arg_, (int)j);
+                done_.fetch_add(1, std::memory_order_release);
+                v = claim_.load(std::memory_order_acquire);
+            }
+        }
+    }
     void loop() {
         unsigned seen = 0;
         for (;;) {
@@ -413,28 +435,25 @@ private:
                 if (quit_) return;
                 continue;
             }
-            const unsigned g = go_.load(std::memory_order_acquire);
-            if (g != seen) {
-                seen = g;
-                unsigned expected = g - 1;
-                if (claim_.compare_exchange_strong(expected, g, std::memory_order_acq_rel)) { fn_(arg_); done_.store(g, std::memory_order_release); }
-            } else __builtin_ia32_pause();
+            const unsigned tk = (unsigned)(claim_.load(std::memory_order_acquire) >> 32);
+            if (tk != seen) { seen = tk; work(tk); }
+            else __builtin_ia32_pause();
         }
     }
     std::mutex m_;
     std::condition_variable cv_;
     std::atomic<int> armed_{0};
     bool quit_ = false;
-    void (*fn_)(void*) = nullptr;
+    void (*fn_)(void*, int) = nullptr;
     void* arg_ = nullptr;
+    unsigned njobs_ = 0;
     unsigned ticket_ = 0;
-    bool inline_ = true;
     int near_cpu_ = -1;
-    alignas(64) std::atomic<unsigned> go_{0};
-    alignas(64) std::atomic<unsigned> done_{0};
-    alignas(64) std::atomic<unsigned> claim_{0};
-    std::thread th_;           // last member: started when everything above exists
+    alignas(64) std::atomic<uint64_t> claim_{0};      // (ticket << 32) | next unclaimed job
+    alignas(64) std::atomic<uint64_t> done_{0};       // (ticket << 32) | finished jobs
+    std::vector<std::thread> th_;                     // last member: started when everything above exists
 };
+using SpinHelper = SpinTeam;      // (the two-way version's name)
 
 // ---- supernodal LDL^T -------------------------------------------------------------------------------------------
 // Same factorisation, organised by supernodes (runs of columns with identical structure below the diagonal, stored as
@@ -475,8 +494,9 @@ public:
         return acc + (double)idx;
     }
 
-    // scratch of one single-column solve: two gather buffers + two accumulators of length n (zero on entry, zero again on exit)
-    size_t scratch_doubles() const { return 2 * ((size_t)max_rows_ + 1) + 2 * (size_t)n; }
+    // scratch of one single-column solve: per part of the elimination tree (+ the top) a gather buffer, per part an accumulator of
+    // length n (zero on entry, zero again on exit)
+    size_t scratch_doubles() const { return (size_t)(parts_ + 1) * ((size_t)max_rows_ + 1) + (size_t)parts_ * (size_t)n; }
 
     void solve(const double* b, double* x, double* work) const {
         std::vector<double> t(scratch_doubles(), 0.0);       // own scratch: callable concurrently (the dense-inverse build does)
@@ -485,9 +505,10 @@ public:
 
     // d right-hand sides (columns b + c*ldb -> x + c*ldx); work: n * d doubles.  Every column is an independent
     // single-column solve (so columns cannot interact and a column's result does not depend on d); with more than one
-    // column they run concurrently on the worker pool -- the factor is read-only and shared.  helper (optional): a second
-    // thread that takes one half of the elimination tree of a single-column solve (same arithmetic with or without it).
-    void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work, SpinHelper* helper = nullptr) const {
+    // column they run concurrently on the worker pool -- the factor is read-only and shared.  helper (optional): a team of
+    // spinning threads that shares the parts of the elimination tree of a single-column solve with the caller (same arithmetic
+    // with or without it, whatever its size).
+    void solve_multi(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work, SpinTeam* helper = nullptr) const {
         const size_t nt = scratch_doubles();
         if (scratch_.size() < nt * (size_t)d) scratch_.resize(nt * (size_t)d, 0.0);
         if (d == 1) { solve_column(b, x, work, scratch_.data(), helper); return; }
@@ -496,20 +517,56 @@ public:
         }, 2);
     }
 
-    // share of the factor (panel entries) in the two halves of the elimination tree / in the part above them
-    void split_report(long out[3]) const { out[0] = split_work_[0]; out[1] = split_work_[1]; out[2] = split_work_[2]; }
+    // share of the factor (panel entries) in the lightest / the heaviest part of the elimination tree / in the part above them
+    void split_report(long out[3]) const {
+        out[0] = out[1] = split_work_.empty() ? 0 : split_work_[0];
+        for (int t = 0; t < parts_; ++t) { out[0] = std::min(out[0], split_work_[t]); out[1] = std::max(out[1], split_work_[t]); }
+        out[2] = split_work_.empty() ? 0 : split_work_[parts_];
+    }
+    int parts() const { return parts_; }
+    // measurement aid: microseconds of the four phases of one single-column solve (parts down, top down, top up, parts up) and
+    // the number of top supernodes
+    void profile(const double* b, double* y, SpinTeam* team, int reps, double out[6]) const {
+        using clk = std::chrono::steady_clock;
+        auto us = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
+        const size_t nt = (size_t)max_rows_ + 1;
+        std::vector<double> tt(scratch_doubles(), 0.0);
+        double* t = tt.data();
+        double* ttop = t + nt * (size_t)parts_;
+        for (int k = 0; k < 6; ++k) out[k] = 0.0;
+        for (int rep = 0; rep < reps; ++rep) {
+            for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+            PartJob job{this, y, t, true};
+            auto t0 = clk::now();
+            if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
+            out[0] += us(t0); t0 = clk::now();
+            for (int c : top_cols_) { double v = y[c]; for (int q = 0; q < parts_; ++q) { double* a = t + nt * (size_t)(parts_ + 1) + (size_t)n * q; v -= a[c]; a[c] = 0.0; } y[c] = v; }
+            forward_part(parts_, y, ttop, nullptr);
+            out[1] += us(t0); t0 = clk::now();
+            for (int j = 0; j < n; ++j) y[j] /= D_[j];
+            backward_part(parts_, y, ttop);
+            out[2] += us(t0); t0 = clk::now();
+            job.forward = false;
+            if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
+            out[3] += us(t0);
+        }
+        for (int k = 0; k < 4; ++k) out[k] /= reps;
+        out[4] = (double)part_sn_[parts_].size();
+    }
 
 private:
     static constexpr int kMaxWidth = 48;        // columns per supernode (panel stays in L1/L2)
     bool symbolic_ready_ = false;
     long nnz_l_ = 0;
     int max_rows_ = 0;                           // longest below-diagonal row structure of a supernode
-    // two-way split of the elimination tree for the back-substitution (plan_split): the supernodes of two sets of disjoint
-    // subtrees, and of the part above them ("top": their common ancestors), each ascending
-    std::vector<int> part_sn_[3];                // [0], [1]: the halves; [2]: top
-    std::vector<int> own_rows_;                  // per supernode of a half: leading rows of its structure that lie inside the half
+    // split of the elimination tree for the back-substitution (plan_split): parts_ sets of disjoint subtrees, and the part above
+    // them ("top": their common ancestors), supernodes ascending in each.  parts_ follows from the factor alone (never from the
+    // machine), so the arithmetic -- which subtree's contributions are subtracted in which order -- is the same everywhere
+    int parts_ = 2;
+    std::vector<std::vector<int>> part_sn_;      // [0 .. parts_): the parts; [parts_]: top
+    std::vector<int> own_rows_;                  // per supernode of a part: leading rows of its structure that lie inside the part
     std::vector<int> top_cols_;                  // columns of the top supernodes
-    long split_work_[3] = {0, 0, 0};
+    std::vector<long> split_work_;               // panel entries per part, [parts_]: top
     mutable std::vector<double> scratch_;        // gathered right-hand-side rows of one supernode (a handle is not thread-safe)
     std::vector<int> inv_;                       // old -> new
     std::vector<int> Cp_, Ci_;                   // upper triangle of P A P^T by columns (pattern)
@@ -636,18 +693,25 @@ private:
         symbolic_ready_ = true;
     }
 
-    // Two halves of the elimination tree that can be back-substituted independently.  Start from the roots; while one subtree
-    // holds more than 55 % of what is left, move its root to the "top" part and consider its children instead; then deal the
-    // subtrees to two bins, largest first.  (The etree is postordered: a subtree is a run of supernodes, descendants first.)
+    // Parts of the elimination tree that can be back-substituted independently: sets of disjoint subtrees.  Start from the roots;
+    // while one subtree holds more than 1.1 / parts_ of what is left, move its root to the "top" part and consider its children
+    // instead; then deal the subtrees to parts_ bins, largest first.  (The etree is postordered: a subtree is a run of supernodes,
+    // descendants first.)  parts_: one per ~kPartWork panel entries, 2 .. kMaxParts.
+    static constexpr long kPartWork = 60000;
+    static constexpr int kMaxParts = 8;
     void plan_split() {
         std::vector<int> parent(ns_, -1);
         std::vector<long> work(ns_, 0);
         std::vector<std::vector<int>> kids(ns_);
+        long all = 0;
         for (int s = 0; s < ns_; ++s) {
             const int r = rows_ptr_[s + 1] - rows_ptr_[s], w = sn_first_[s + 1] - sn_first_[s];
             work[s] = (long)(w + r) * w;
+            all += work[s];
             if (r > 0) parent[s] = sn_of_[rows_[rows_ptr_[s]]];
         }
+        parts_ = (int)std::max<long>(2, std::min<long>(kMaxParts, (all + kPartWork / 2) / kPartWork));
+        if (const char* e = std::getenv("GMG_LDLT_PARTS")) parts_ = std::max(2, std::min(kMaxParts, std::atoi(e)));      // measurement aid
         std::vector<long> sub(work);
         for (int s = 0; s < ns_; ++s) if (parent[s] >= 0) { sub[parent[s]] += sub[s]; kids[parent[s]].push_back(s); }
         std::vector<int> cand;
@@ -657,35 +721,39 @@ private:
             long total = 0;
             int big = -1;
             for (int c : cand) { total += sub[c]; if (big < 0 || sub[c] > sub[big]) big = c; }
-            if (big < 0 || sub[big] * 100 <= total * 55 || kids[big].empty()) break;
+            if (big < 0 || sub[big] * 100 * parts_ <= total * 110 || kids[big].empty()) break;
             in_top[big] = 1;
             cand.erase(std::find(cand.begin(), cand.end(), big));
             cand.insert(cand.end(), kids[big].begin(), kids[big].end());
         }
         std::sort(cand.begin(), cand.end(), [&](int a, int b2) { return sub[a] != sub[b2] ? sub[a] > sub[b2] : a < b2; });
-        std::vector<int> half(ns_, -1);              // supernode -> 0 / 1, -1 = top
-        long load[2] = {0, 0};
+        std::vector<int> half(ns_, -1);              // supernode -> part, -1 = top
+        std::vector<long> load(parts_, 0);
         std::vector<int> root_half(ns_, -1);
-        for (int c : cand) { const int t = load[1] < load[0] ? 1 : 0; root_half[c] = t; load[t] += sub[c]; }
+        for (int c : cand) {
+            int t = 0;
+            for (int q = 1; q < parts_; ++q) if (load[q] < load[t]) t = q;
+            root_half[c] = t; load[t] += sub[c];
+        }
         for (int s = ns_ - 1; s >= 0; --s) {          // parents before children
             if (in_top[s]) continue;
             half[s] = root_half[s] >= 0 ? root_half[s] : half[parent[s]];
         }
-        for (auto& v : part_sn_) v.clear();
-        scratch_.clear();                            // (its layout follows max_rows_ / n: the accumulators must start from zero)
-        split_work_[0] = split_work_[1] = split_work_[2] = 0;
+        part_sn_.assign((size_t)parts_ + 1, std::vector<int>());
+        scratch_.clear();                            // (its layout follows max_rows_ / n / parts_: the accumulators must start from zero)
+        split_work_.assign((size_t)parts_ + 1, 0);
         own_rows_.assign(ns_, 0);
         top_cols_.clear();
         for (int s = 0; s < ns_; ++s) {
-            const int t = half[s] < 0 ? 2 : half[s];
+            const int t = half[s] < 0 ? parts_ : half[s];
             part_sn_[t].push_back(s);
             split_work_[t] += work[s];
             const int* R = rows_.data() + rows_ptr_[s];
             const int r = rows_ptr_[s + 1] - rows_ptr_[s];
             int k = 0;
-            if (t < 2) while (k < r && half[sn_of_[R[k]]] == t) ++k;     // ancestors inside the half come first (ascending rows)
-            own_rows_[s] = t < 2 ? k : r;
-            if (t == 2) for (int j = sn_first_[s]; j < sn_first_[s + 1]; ++j) top_cols_.push_back(j);
+            if (t < parts_) while (k < r && half[sn_of_[R[k]]] == t) ++k;     // ancestors inside the part come first (ascending rows)
+            own_rows_[s] = t < parts_ ? k : r;
+            if (t == parts_) for (int j = sn_first_[s]; j < sn_first_[s + 1]; ++j) top_cols_.push_back(j);
         }
     }
 
@@ -728,54 +796,62 @@ private:
         for (; i < m; ++i) s0 += a[i] * b[i];                                                                                    \
         return (s0 + s1) + (s2 + s3);                                                                                            \
     }                                                                                                                            \
-    /* one right-hand side: forward step of a supernode, ys <- L_d^-1 ys (unit lower, w x w), t = L_b ys (r).  The rectangular   \
-       part takes FOUR columns of the panel per pass over t (one load and one store of t[i] per four columns instead of per      \
-       column); every t[i] still accumulates its columns one after the other in column order -- the results are those of the     \
-       one-column-per-pass loop, bit for bit */                                                                                   \
-    ATTR static void sn_forward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, double* t) {                        \
+    /* one right-hand side: forward step of a supernode, ys <- L_d^-1 ys (unit lower, w x w), t = L_b ys (r), in two pieces so that   \
+       the rows of a big panel can be shared between threads.  The rectangular part takes EIGHT / FOUR columns of the panel per     \
+       pass over t (one load and one store of t[i] per group instead of per column); every t[i] still accumulates its columns one   \
+       after the other in column order -- the results are those of the one-column-per-pass loop, bit for bit, and a row's value     \
+       does not depend on which range of rows it is computed with */                                                               \
+    ATTR static void sn_forward_tri##SUFFIX(const double* P, int ld, int w, double* ys) {                                       \
         for (int j = 0; j < w; ++j) {                                                                                            \
             const double* cj = P + (size_t)j * ld;                                                                               \
             const double yj = ys[j];                                                                                             \
             for (int i = j + 1; i < w; ++i) ys[i] -= cj[i] * yj;                                                                 \
         }                                                                                                                        \
+    }                                                                                                                            \
+    /* rows [r0, r1) of t = L_b ys */                                                                                              \
+    ATTR static void sn_forward_rect##SUFFIX(const double* P, int ld, int w, int r0, int r1, const double* ys, double* t) {     \
         int j = 0;                                                                                                               \
         if (w >= 8) {                                                                                                            \
             const double *c0 = P + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld, *c4 = c3 + ld, *c5 = c4 + ld, *c6 = c5 + ld, *c7 = c6 + ld; \
             const double y0 = ys[0], y1 = ys[1], y2 = ys[2], y3 = ys[3], y4 = ys[4], y5 = ys[5], y6 = ys[6], y7 = ys[7];        \
-            for (int i = 0; i < r; ++i)                                                                                          \
+            for (int i = r0; i < r1; ++i)                                                                                        \
                 t[i] = (((((((0.0 + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3) + c4[i] * y4) + c5[i] * y5) + c6[i] * y6) + c7[i] * y7; \
             j = 8;                                                                                                               \
         } else if (w >= 4) {                                                                                                     \
             const double *c0 = P + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;                                               \
             const double y0 = ys[0], y1 = ys[1], y2 = ys[2], y3 = ys[3];                                                         \
-            for (int i = 0; i < r; ++i) t[i] = (((0.0 + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3;                      \
+            for (int i = r0; i < r1; ++i) t[i] = (((0.0 + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3;                    \
             j = 4;                                                                                                               \
         } else {                                                                                                                 \
-            for (int i = 0; i < r; ++i) t[i] = 0.0;                                                                              \
+            for (int i = r0; i < r1; ++i) t[i] = 0.0;                                                                            \
         }                                                                                                                        \
         for (; j + 8 <= w; j += 8) {                                                                                             \
             const double *c0 = P + (size_t)j * ld + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld, *c4 = c3 + ld, *c5 = c4 + ld, *c6 = c5 + ld, *c7 = c6 + ld; \
             const double y0 = ys[j], y1 = ys[j + 1], y2 = ys[j + 2], y3 = ys[j + 3], y4 = ys[j + 4], y5 = ys[j + 5], y6 = ys[j + 6], y7 = ys[j + 7]; \
-            for (int i = 0; i < r; ++i)                                                                                          \
+            for (int i = r0; i < r1; ++i)                                                                                        \
                 t[i] = (((((((t[i] + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3) + c4[i] * y4) + c5[i] * y5) + c6[i] * y6) + c7[i] * y7; \
         }                                                                                                                        \
         for (; j + 4 <= w; j += 4) {                                                                                             \
             const double *c0 = P + (size_t)j * ld + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;                              \
             const double y0 = ys[j], y1 = ys[j + 1], y2 = ys[j + 2], y3 = ys[j + 3];                                             \
-            for (int i = 0; i < r; ++i) t[i] = (((t[i] + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3;                     \
+            for (int i = r0; i < r1; ++i) t[i] = (((t[i] + c0[i] * y0) + c1[i] * y1) + c2[i] * y2) + c3[i] * y3;                   \
         }                                                                                                                        \
         for (; j < w; ++j) {                                                                                                     \
             const double* cb = P + (size_t)j * ld + w;                                                                           \
             const double yj = ys[j];                                                                                             \
-            for (int i = 0; i < r; ++i) t[i] += cb[i] * yj;                                                                      \
+            for (int i = r0; i < r1; ++i) t[i] += cb[i] * yj;                                                                    \
         }                                                                                                                        \
     }                                                                                                                            \
-    /* ... and its backward step: ys <- L_d^-T (ys - L_b^T t).  The r-long dot products of four columns share one pass over t;  \
-       each keeps the four interleaved partial sums of dot4 (same association, same bits) */                                     \
-    ATTR static void sn_backward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, const double* t) {                 \
-        double bt[kMaxWidth];                                                                                                    \
-        int j = 0;                                                                                                               \
-        for (; j + 4 <= w; j += 4) {                                                                                             \
+    ATTR static void sn_forward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, double* t) {                        \
+        sn_forward_tri##SUFFIX(P, ld, w, ys);                                                                                    \
+        sn_forward_rect##SUFFIX(P, ld, w, 0, r, ys, t);                                                                          \
+    }                                                                                                                            \
+    /* ... and its backward step: ys <- L_d^-T (ys - L_b^T t), again in two pieces.  bt[j] = column j of L_b . t for the columns    \
+       [j0, j1) (j0 a multiple of 4): the r-long dot products of four columns share one pass over t; each keeps the four           \
+       interleaved partial sums of dot4 (same association, same bits whatever the column range) */                                  \
+    ATTR static void sn_backward_rect##SUFFIX(const double* P, int ld, int w, int r, int j0, int j1, const double* t, double* bt) { \
+        int j = j0;                                                                                                              \
+        for (; j + 4 <= j1; j += 4) {                                                                                            \
             const double *c0 = P + (size_t)j * ld + w, *c1 = c0 + ld, *c2 = c1 + ld, *c3 = c2 + ld;                              \
             double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0}, a3[4] = {0, 0, 0, 0};                        \
             int i = 0;                                                                                                           \
@@ -788,11 +864,18 @@ private:
             bt[j] = (a0[0] + a0[1]) + (a0[2] + a0[3]); bt[j + 1] = (a1[0] + a1[1]) + (a1[2] + a1[3]);                            \
             bt[j + 2] = (a2[0] + a2[1]) + (a2[2] + a2[3]); bt[j + 3] = (a3[0] + a3[1]) + (a3[2] + a3[3]);                        \
         }                                                                                                                        \
-        for (; j < w; ++j) bt[j] = dot4##SUFFIX(P + (size_t)j * ld + w, t, r);                                                   \
-        for (j = w - 1; j >= 0; --j) {                                                                                           \
+        for (; j < j1; ++j) bt[j] = dot4##SUFFIX(P + (size_t)j * ld + w, t, r);                                                  \
+    }                                                                                                                            \
+    ATTR static void sn_backward_tri##SUFFIX(const double* P, int ld, int w, double* ys, const double* bt) {                    \
+        for (int j = w - 1; j >= 0; --j) {                                                                                       \
             const double* cj = P + (size_t)j * ld;                                                                               \
             ys[j] -= bt[j] + dot4##SUFFIX(cj + j + 1, ys + j + 1, w - 1 - j);                                                    \
         }                                                                                                                        \
+    }                                                                                                                            \
+    ATTR static void sn_backward1##SUFFIX(const double* P, int ld, int w, int r, double* ys, const double* t) {                 \
+        double bt[kMaxWidth];                                                                                                    \
+        sn_backward_rect##SUFFIX(P, ld, w, r, 0, w, t, bt);                                                                      \
+        sn_backward_tri##SUFFIX(P, ld, w, ys, bt);                                                                               \
     }
     GMG_LDLT_KERNELS(_base, )
     // (this header is host-only code, but engine.hip is also parsed by hipcc's device pass, which knows no x86 features)
@@ -844,32 +927,39 @@ private:
         }
     }
 
-    // One column.  L z = y runs over the two halves of the elimination tree (independent: a column's structure lies on its path
-    // to the root), whose contributions to the rows above them are accumulated per half and subtracted in a fixed order, then
-    // over the top part; L^T x = z the other way round.  The arithmetic does not depend on whether `helper` executes the second
-    // half concurrently or this thread does both.  t: scratch_doubles() doubles, accumulators zero on entry and on exit.
-    struct HalfJob { const SupernodalLDLT* self; double *y, *t, *acc; bool forward; };
-    static void run_half(void* p) {
-        HalfJob* j = (HalfJob*)p;
-        if (j->forward) j->self->forward_part(1, j->y, j->t, j->acc); else j->self->backward_part(1, j->y, j->t);
+    // One column.  L z = y runs over the parts of the elimination tree (independent: a column's structure lies on its path to the
+    // root), whose contributions to the rows above them are accumulated per part and subtracted in part order, then over the top
+    // part; L^T x = z the other way round.  The arithmetic does not depend on whether / how many threads of `team` share the parts
+    // with this one.  t: scratch_doubles() doubles, accumulators zero on entry and on exit.
+    struct PartJob { const SupernodalLDLT* self; double *y, *t; bool forward; };
+    static void run_part(void* p, int part) {
+        PartJob* j = (PartJob*)p;
+        const SupernodalLDLT* S = j->self;
+        const size_t nt = (size_t)S->max_rows_ + 1;
+        double* tp = j->t + nt * (size_t)part;
+        double* acc = j->t + nt * (size_t)(S->parts_ + 1) + (size_t)S->n * (size_t)part;
+        if (j->forward) S->forward_part(part, j->y, tp, acc); else S->backward_part(part, j->y, tp);
     }
-    void solve_column(const double* b, double* x, double* y, double* t, SpinHelper* helper) const {
+    void solve_column(const double* b, double* x, double* y, double* t, SpinTeam* team) const {
         const size_t nt = (size_t)max_rows_ + 1;
-        double *t0 = t, *t1 = t + nt, *acc0 = t + 2 * nt, *acc1 = acc0 + n;
+        double* ttop = t + nt * (size_t)parts_;
+        double* acc0 = t + nt * (size_t)(parts_ + 1);
         for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-        HalfJob job{this, y, t1, acc1, true};
-        const bool two = helper && !part_sn_[1].empty();
-        if (two) helper->run(run_half, &job); else run_half(&job);
-        forward_part(0, y, t0, acc0);
-        if (two) helper->wait();
-        for (int c : top_cols_) { y[c] = (y[c] - acc0[c]) - acc1[c]; acc0[c] = 0.0; acc1[c] = 0.0; }
-        forward_part(2, y, t0, nullptr);
+        PartJob job{this, y, t, true};
+        if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
+        for (int c : top_cols_) {
+            double v = y[c];
+            for (int q = 0; q < parts_; ++q) { double* a = acc0 + (size_t)n * q; v -= a[c]; a[c] = 0.0; }
+            y[c] = v;
+        }
+        // (the top part is a chain of the factor's biggest panels.  Sharing the rows / columns of a panel with the team was built
+        // and measured on the GPU box's EPYC 9575F: 41 + 59 us on one thread became 107 + 113 us with eight -- a hand-over per
+        // panel and the panel's cache lines travelling cost more than the 3 us a panel takes; it runs on the calling thread)
+        forward_part(parts_, y, ttop, nullptr);
         for (int j = 0; j < n; ++j) y[j] /= D_[j];
-        backward_part(2, y, t0);
+        backward_part(parts_, y, ttop);
         job.forward = false;
-        if (two) helper->run(run_half, &job); else run_half(&job);
-        backward_part(0, y, t0);
-        if (two) helper->wait();
+        if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
         for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     }
 

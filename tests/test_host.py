@@ -282,10 +282,10 @@ def test_host_ldlt_many_right_hand_sides_and_galerkin_operator(cabi):
     assert nnzL > A.nnz // 2
 
 
-def test_host_ldlt_two_thread_back_substitution_gives_the_same_bits():
-    """The coarsest back-substitution runs the two halves of the elimination tree on two threads inside a solve (SpinHelper); the
-    arithmetic must not depend on whether the helper takes the second half.  The library's timing aid (GMG_LDLT_BENCH) solves both
-    ways and prints the largest difference."""
+def test_host_ldlt_team_back_substitution_gives_the_same_bits():
+    """The coarsest back-substitution runs the parts of the elimination tree (2 .. 8 sets of disjoint subtrees, by the size of the
+    factor) on a team of spinning threads inside a solve (SpinTeam); the arithmetic must not depend on how many threads share the
+    parts.  The library's timing aid (GMG_LDLT_BENCH) solves with 1, 2, 3, ... threads and prints the largest difference."""
     import os
     import re
     import subprocess
@@ -293,7 +293,7 @@ def test_host_ldlt_two_thread_back_substitution_gives_the_same_bits():
     code = (
         "import numpy as np, scipy.sparse as sp\n"
         "from gravo_mg_amd import cabi\n"
-        "m = 70\n"
+        "m = 90\n"
         "T = sp.diags([-1.0, 2.3, -1.0], [-1, 0, 1], shape=(m, m))\n"
         "A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()\n"
         "b = np.random.default_rng(3).standard_normal(m * m)\n"
@@ -303,9 +303,10 @@ def test_host_ldlt_two_thread_back_substitution_gives_the_same_bits():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
-    m1 = re.search(r"two halves / above them: (\d+) / (\d+) / (\d+); max \|difference\| ([0-9.e+-]+)", out.stderr)
+    m1 = re.search(r"(\d+) parts of the elimination tree, panel entries in the lightest / heaviest part / above them: (\d+) / (\d+) / (\d+)", out.stderr)
     assert m1, out.stderr[-2000:]
-    a, b2, top, diff = int(m1.group(1)), int(m1.group(2)), int(m1.group(3)), float(m1.group(4))
-    assert diff == 0.0
-    assert a > 0 and b2 > 0 and min(a, b2) >= 0.5 * max(a, b2), (a, b2, top)       # a real split, reasonably balanced
+    parts, lo, hi, top = (int(m1.group(k)) for k in (1, 2, 3, 4))
+    assert parts >= 3 and lo > 0 and lo >= 0.5 * hi, (parts, lo, hi, top)          # a real split, reasonably balanced
+    diffs = re.findall(r"(\d+) threads: .* max \|difference\| to the one-thread solve ([0-9.e+-]+)", out.stderr)
+    assert len(diffs) >= 2 and all(float(d) == 0.0 for _, d in diffs), out.stderr[-2000:]
     assert float(re.search(r"residual ([0-9.e+-]+)", out.stdout).group(1)) <= 1e-10
