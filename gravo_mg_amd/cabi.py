@@ -125,6 +125,8 @@ SIGNATURES = {
     "gmg_hierarchy_get_samples": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_hierarchy_get_nearest": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_hierarchy_get_points": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_hierarchy_get_fine_order": (C.c_int, [_vp, _ip, _ip]),
+    "gmg_set_fine_order": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
     "gmg_finalize_hierarchy": (C.c_int, [_vp]),
     "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
@@ -257,6 +259,13 @@ class Hierarchy:
             if l.gmg_hierarchy_get_samples(self._h, k, _pi(s_)) or l.gmg_hierarchy_get_nearest(self._h, k, _pi(n_)) or l.gmg_hierarchy_get_points(self._h, k, _pd(p_)):
                 raise GmgError(GMG_ERR_INVALID, "hierarchy getters failed")
             self.samples.append(s_); self.nearest.append(n_); self.points.append(p_)
+        # breadth-first order of the points (only made for inputs without locality; None otherwise)
+        cnt = C.c_int()
+        l.gmg_hierarchy_get_fine_order(self._h, None, C.byref(cnt))
+        self.fine_order = None
+        if cnt.value:
+            self.fine_order = np.empty(cnt.value, np.int32)
+            l.gmg_hierarchy_get_fine_order(self._h, _pi(self.fine_order), C.byref(cnt))
 
     def timing(self, key: str) -> float:
         out = C.c_double()
@@ -329,7 +338,8 @@ class Engine:
             pass
 
     # -- hierarchy input
-    def set_prolongations(self, U: Sequence, finalize: bool = True):
+    def set_prolongations(self, U: Sequence, finalize: bool = True, fine_order=None):
+        """fine_order: optional locality order of the level-0 points (gmg_set_fine_order), e.g. Hierarchy.fine_order."""
         l = lib()
         self._chk(l.gmg_set_num_levels(self._h, len(U)))
         self._sizes = []
@@ -339,6 +349,9 @@ class Engine:
             if k == 0:
                 self._sizes.append(u.shape[0])
             self._sizes.append(u.shape[1])
+        if fine_order is not None and len(U):
+            fo = np.ascontiguousarray(fine_order, dtype=np.int32)
+            self._chk(l.gmg_set_fine_order(self._h, fo.shape[0], _pi(fo)))
         if finalize and len(U):
             self._chk(l.gmg_finalize_hierarchy(self._h))
 

@@ -147,6 +147,7 @@ int gmg_set_num_levels(gmg_handle h, int L) try {
     PoolScope pool_scope_(&h->pool);
     if (h->has_device) { drop_system(h); drop_device_transfers(h); }
     h->patches.clear(); h->patches_ready = false;
+    h->bfs_order.clear();
     h->L = L;
     h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
@@ -446,7 +447,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             }
             else if (k == 0) {
                 if (reorder0 && patches_done.valid()) patches_done.wait();
-                const std::vector<int>* base = reorder0 && (int)h->cluster_order.size() == n ? &h->cluster_order : nullptr;
+                const std::vector<int>* base = reorder0 && (int)base_order(h).size() == n ? &base_order(h) : nullptr;
                 if (permuted0 && base) {
                     // colour the LHS pattern in cluster order (made on the device, see device_permute_pattern), then map back
                     LevelOrdering c = make_ordering(PatternView{n, h->reo_ptr.data(), h->reo_idx.data()}, mc, h->cfg.row_align, h->cfg.sigma, 0);
@@ -529,9 +530,24 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     const bool blocked0 = mc && h->cfg.block_rows > 0 && h->cfg.block_from_level <= 0 && L > 0;
     reorder0 = mc && !ord_hit && !blocked0 && wants_locality_reorder(PatternView{n, colptr, rowidx}, h->cfg.reorder_fine);
     bool A0_uploaded = false;
-    if (reorder0 && device_setup && h->cfg.device_rap && h->patches_ready && (int)h->cluster_order.size() == n) {
+    // (h->cluster_order is only read once the patches are ready: build_patches may still be writing it)
+    const bool have_bfs = (int)h->bfs_order.size() == n, have_cluster = h->patches_ready && (int)h->cluster_order.size() == n;
+    h->base_order_choice = (reorder0 && h->patches_ready && have_bfs && !have_cluster) ? 1 : 0;
+    if (reorder0 && have_bfs && have_cluster && !(device_setup && h->cfg.device_rap)) {
+        // host-planner path: the same decision from the host twin of the device score (choose_base_order)
+        unsigned long long sc[2], sb[2];
+        order_gather_score_host(PatternView{n, colptr, rowidx}, h->cluster_order, 4096, sc);
+        order_gather_score_host(PatternView{n, colptr, rowidx}, h->bfs_order, 4096, sb);
+        if (const char* e = std::getenv("GMG_BASE_ORDER")) h->base_order_choice = std::atoi(e) == 1 ? 1 : 0;
+        else h->base_order_choice = (sc[1] && sb[1] && (double)sb[0] / (double)sb[1] < (double)sc[0] / (double)sc[1]) ? 1 : 0;
+        h->timing["base_order_score_cluster"] = sc[1] ? (double)sc[0] / (double)sc[1] : 0.0;
+        h->timing["base_order_score_bfs"] = sb[1] ? (double)sb[0] / (double)sb[1] : 0.0;
+        h->timing["base_order_choice"] = h->base_order_choice;
+    }
+    if (reorder0 && device_setup && h->cfg.device_rap && (have_cluster || (h->patches_ready && have_bfs))) {
         int rc = upload_csr_raw(h, h->lv[0].dA, n, colptr, rowidx, val);
-        if (rc == GMG_OK) { A0_uploaded = true; rc = device_permute_pattern(h, h->lv[0].dA, n, colptr[n]); }
+        if (rc == GMG_OK) { A0_uploaded = true; rc = choose_base_order(h, h->lv[0].dA, n); }
+        if (rc == GMG_OK) rc = device_permute_pattern(h, h->lv[0].dA, n, colptr[n]);
         if (rc != GMG_OK) { join_tasks(); return rc; }
         permuted0 = true;
         mark("permuted_pattern");
@@ -1498,7 +1514,14 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
             (void)hipGetLastError();
         });
     gmg_hierarchy hh = new gmg_hierarchy_s();
+    // A breadth-first order of the points over `neigh`, for inputs whose numbering has no locality (randomly ordered scans, point
+    // clouds): one of the two base orders gmg_set_system may give the finest level (choose_base_order).  A sequential sweep of the
+    // whole graph (~60 ms at 3 M points) on its own thread, beside the construction.
+    std::future<std::vector<int>> fine_order;
+    if (n > 65536 && mean_index_distance_table(neigh, n, K) > std::max(32768.0, n / 32.0))
+        fine_order = std::async(std::launch::async, [neigh, n, K] { return bfs_point_order(neigh, n, K); });
     hh->res = HierarchyBuilder::build(pos, n, neigh, K, ho);
+    if (fine_order.valid()) hh->fine_order = fine_order.get();
     if (device_warm.valid()) device_warm.get();
     *out = hh;
     return GMG_OK;
@@ -1553,6 +1576,30 @@ int gmg_hierarchy_get_points(gmg_hierarchy hh, int k, double* out_xyz) try {
     return GMG_OK;
 } GMG_CATCH_0
 
+int gmg_hierarchy_get_fine_order(gmg_hierarchy hh, int* out, int* count) try {
+    if (!hh || !count) return GMG_ERR_INVALID;
+    *count = (int)hh->fine_order.size();
+    if (out && !hh->fine_order.empty()) std::memcpy(out, hh->fine_order.data(), sizeof(int) * hh->fine_order.size());
+    return GMG_OK;
+} GMG_CATCH_0
+
+int gmg_set_fine_order(gmg_handle h, int n, const int* order) try {
+    if (!h || n < 0 || (n > 0 && !order)) return GMG_ERR_INVALID;
+    if (n > 0) {
+        if (h->L <= 0 || !h->U_set[0] || h->U[0].n_inner != n) return fail(h, GMG_ERR_STATE, "set the prolongations first: the order must have one entry per level-0 point");
+        std::vector<unsigned char> seen((size_t)n, 0);
+        for (int i = 0; i < n; ++i) {
+            if (order[i] < 0 || order[i] >= n || seen[order[i]]) return fail(h, GMG_ERR_INVALID, "the fine order is not a permutation of the level-0 points");
+            seen[order[i]] = 1;
+        }
+    }
+    h->bfs_order.assign(order, order + n);
+    if (h->d_bfs_order) { (void)dev_free(h->d_bfs_order); h->d_bfs_order = nullptr; }
+    if (h->d_bfs_inv) { (void)dev_free(h->d_bfs_inv); h->d_bfs_inv = nullptr; }
+    h->ord_cache_valid = false;        // cached orderings were built on another base order
+    return GMG_OK;
+} GMG_CATCH_H
+
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) try {
     if (!h || !hh) return GMG_ERR_INVALID;
     int rc = gmg_set_num_levels(h, (int)hh->res.U.size());
@@ -1561,6 +1608,7 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) try {
         const Compressed& u = hh->res.U[k];
         if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
     }
+    if (!hh->res.U.empty() && (rc = gmg_set_fine_order(h, (int)hh->fine_order.size(), hh->fine_order.data()))) return rc;
     return gmg_finalize_hierarchy(h);
 } GMG_CATCH_H
 

@@ -126,23 +126,63 @@ int ensure_device_transfers(gmg_handle h) {
     return GMG_OK;
 }
 
-// LHS pattern in the hierarchy's cluster order (h->cluster_order), made on the device from the uploaded LHS and copied
-// to h->reo_ptr / h->reo_idx: the level-0 colouring then walks a locally ordered graph instead of chasing pointers
-// through a randomly numbered one (3 M vertices in random order: 450 ms -> 20 ms).
+// The base order of a reordered level 0 in use (gmg_set_system decides per system, choose_base_order): new -> old.
+inline const std::vector<int>& base_order(gmg_handle h) { return h->base_order_choice == 1 ? h->bfs_order : h->cluster_order; }
+
+static int ensure_device_order(gmg_handle h, const std::vector<int>& ord, int** d_ord, int** d_inv) {
+    if (*d_ord) return GMG_OK;
+    const int n = (int)ord.size();
+    std::vector<int> inv(n);
+    parallel_ranges(n, std::min(h->cfg.host_threads, 32), [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) inv[ord[r]] = r; });
+    int rc;
+    if ((rc = upload(h, d_ord, ord)) || (rc = upload(h, d_inv, inv))) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+}
+
+// Which locality order serves THIS matrix better -- the hierarchy's cluster order (points grouped by parent, level by level:
+// compact 2-D patches) or the breadth-first order over the point graph (wavefronts; only when the caller / the hierarchy object
+// supplied one, gmg_set_fine_order)?  Both are scored on the uploaded pattern by the number of distinct cache lines the j-th
+// gathers of 64 consecutive rows touch (gmgs::order_gather_score, 4 096 sampled windows, < 0.1 ms): a triangle mesh scores
+// 0.27 lines per entry in breadth-first order and 0.37 in cluster order, a kNN point cloud 0.46 / 0.37, and the kernels follow
+// (fine-level residual 49 / 72 us and 93 / 83 us).  Ties go to the cluster order.  Sets h->base_order_choice.
+int choose_base_order(gmg_handle h, const DevCsr& dA, int n) {
+    h->base_order_choice = 0;
+    h->timing["base_order_score_cluster"] = h->timing["base_order_score_bfs"] = h->timing["base_order_choice"] = 0.0;
+    if ((int)h->bfs_order.size() != n || (int)h->cluster_order.size() != n) { h->base_order_choice = (int)h->bfs_order.size() == n ? 1 : 0; return GMG_OK; }
+    if (const char* e = std::getenv("GMG_BASE_ORDER")) { h->base_order_choice = std::atoi(e) == 1 ? 1 : 0; return GMG_OK; }      // A/B aid
+    int rc;
+    if ((rc = ensure_device_order(h, h->cluster_order, &h->d_cluster_order, &h->d_cluster_inv)) || (rc = ensure_device_order(h, h->bfs_order, &h->d_bfs_order, &h->d_bfs_inv))) return rc;
+    DevTmp<unsigned long long> acc;
+    if ((rc = acc.alloc(h, 4))) return rc;
+    HIPCHK(hipMemsetAsync(acc.p, 0, sizeof(unsigned long long) * 4, h->stream));
+    const int n_win = 4096;
+    hipLaunchKernelGGL(gmgs::order_gather_score, dim3(n_win / 4), dim3(256), 0, h->stream, dA.ptr, dA.idx, h->d_cluster_order, h->d_cluster_inv, n, n_win, acc.p);
+    hipLaunchKernelGGL(gmgs::order_gather_score, dim3(n_win / 4), dim3(256), 0, h->stream, dA.ptr, dA.idx, h->d_bfs_order, h->d_bfs_inv, n, n_win, acc.p + 2);
+    unsigned long long host[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(host, acc.p, sizeof host, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const double sc = host[1] ? (double)host[0] / (double)host[1] : 0.0, sb = host[3] ? (double)host[2] / (double)host[3] : 0.0;
+    h->timing["base_order_score_cluster"] = sc; h->timing["base_order_score_bfs"] = sb;
+    h->base_order_choice = sb < sc ? 1 : 0;
+    h->timing["base_order_choice"] = h->base_order_choice;
+    return GMG_OK;
+}
+
+// LHS pattern in the chosen base order (base_order(h)), made on the device from the uploaded LHS and copied to h->reo_ptr /
+// h->reo_idx: the level-0 colouring then walks a locally ordered graph instead of chasing pointers through a randomly numbered
+// one (3 M vertices in random order: 450 ms -> 20 ms).
 int device_permute_pattern(gmg_handle h, const DevCsr& dA, int n, int64_t nnz) {
     int rc;
-    if (!h->d_cluster_order) {
-        std::vector<int> inv(n);
-        const std::vector<int>& ord = h->cluster_order;
-        parallel_ranges(n, std::min(h->cfg.host_threads, 32), [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) inv[ord[r]] = r; });
-        if ((rc = upload(h, &h->d_cluster_order, ord)) || (rc = upload(h, &h->d_cluster_inv, inv))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
+    const bool bfs = h->base_order_choice == 1;
+    int** d_ord = bfs ? &h->d_bfs_order : &h->d_cluster_order;
+    int** d_inv = bfs ? &h->d_bfs_inv : &h->d_cluster_inv;
+    if ((rc = ensure_device_order(h, base_order(h), d_ord, d_inv))) return rc;
     DevTmp<int> len, pptr, pidx;
     if ((rc = len.alloc(h, n)) || (rc = pptr.alloc(h, (size_t)n + 1)) || (rc = pidx.alloc(h, (size_t)nnz))) return rc;
-    hipLaunchKernelGGL(gmgs::perm_row_lengths, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, h->d_cluster_order, n, len.p);
+    hipLaunchKernelGGL(gmgs::perm_row_lengths, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, *d_ord, n, len.p);
     if ((rc = device_scan<int, int>(h, len.p, n, pptr.p, nullptr))) return rc;
-    hipLaunchKernelGGL(gmgs::perm_fill, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.idx, h->d_cluster_order, h->d_cluster_inv, pptr.p, n, pidx.p);
+    hipLaunchKernelGGL(gmgs::perm_fill, dim3((n + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.idx, *d_ord, *d_inv, pptr.p, n, pidx.p);
     h->reo_ptr.resize((size_t)n + 1);
     h->reo_idx.resize((size_t)nnz);
     if ((rc = d2h(h, h->reo_ptr.data(), pptr.p, sizeof(int) * ((size_t)n + 1))) || (rc = d2h(h, h->reo_idx.data(), pidx.p, sizeof(int) * (size_t)nnz))) return rc;

@@ -113,6 +113,7 @@ struct Level {
 
 struct gmg_hierarchy_s {
     HierarchyResult res;
+    std::vector<int> fine_order;         // breadth-first order of the level-0 points over `neigh` (new -> old); empty when the input order is local already
 };
 
 struct DistP2P;
@@ -134,6 +135,9 @@ struct gmg_solver_s {
     std::vector<PatchSet> patches;
     std::vector<int> cluster_order;       // locality-preserving order of the level-0 points derived from U (new -> old)
     int *d_cluster_order = nullptr, *d_cluster_inv = nullptr;      // device copies (order, and old -> new position)
+    std::vector<int> bfs_order;           // ... and the breadth-first order over the point graph, when the caller / the hierarchy object supplied one (gmg_set_fine_order)
+    int *d_bfs_order = nullptr, *d_bfs_inv = nullptr;
+    int base_order_choice = 0;            // what the last reordered set-up used: 0 cluster order, 1 breadth-first order
     RawVec<int> reo_ptr, reo_idx;         // LHS pattern permuted into cluster order (staging for the level-0 colouring)
     bool patches_ready = false;
     bool dU_flagged = false;              // ell3_from_csc found a U row with more than 3 entries (host paths only)
@@ -349,6 +353,8 @@ void free_ell3(DevEll3& e) {
 void drop_device_transfers(gmg_handle h) {
     if (h->d_cluster_order) { (void)dev_free(h->d_cluster_order); h->d_cluster_order = nullptr; }
     if (h->d_cluster_inv) { (void)dev_free(h->d_cluster_inv); h->d_cluster_inv = nullptr; }
+    if (h->d_bfs_order) { (void)dev_free(h->d_bfs_order); h->d_bfs_order = nullptr; }
+    if (h->d_bfs_inv) { (void)dev_free(h->d_bfs_inv); h->d_bfs_inv = nullptr; }
     for (auto& m : h->dU) free_csr(m);
     for (auto& e : h->dE3) free_ell3(e);
     h->dU.clear(); h->dE3.clear();
@@ -441,7 +447,9 @@ void drop_system(gmg_handle h) {
     if (h->d_ainv) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
 }
 
-constexpr int kQuadLevelRows = 262144;  // blocked levels smaller than this use 4 lanes per row
+// blocked levels smaller than this use 4 lanes per row (GMG_QUAD_LEVEL_ROWS: measurement aid)
+inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 262144; return v; }
+#define kQuadLevelRows quad_level_rows()
 constexpr int kEpMaxBlockEntries = 6144;        // largest explicit / lower chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
 constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)
 inline bool wants_block_csr(gmg_handle h, int lpr) { return h->cfg.block_csr != 0 && lpr == 1 && h->cfg.block_rows == 64; }

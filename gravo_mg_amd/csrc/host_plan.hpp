@@ -542,6 +542,77 @@ inline std::vector<int> cluster_order(const std::vector<Compressed>& Urows, cons
     return order;
 }
 
+// Breadth-first order of the points of a neighbour table (n x K, rows padded with -1, as the reference's `neigh`): the order in
+// which a sequential breadth-first search from point 0 (restarting at the lowest unvisited index) takes them out of its queue.
+// Consecutive points lie next to each other on a wavefront and their neighbours next to each other on the wavefronts before and
+// after it, so the j-th gathers of 64 consecutive rows fall into a few cache lines: on a randomly numbered 3 M-vertex mesh the
+// fine-level residual runs at 49 us with this base order, 72 us with the hierarchy's cluster order (gathers scattered over a 2-D
+// patch) -- a kNN point-cloud graph, whose wavefronts are thick and ragged, is the other way round (93 / 83 us), which is why
+// gmg_set_system scores both on the actual matrix (engine_setup.hip.hpp::choose_base_order).  Sequential by definition; the rows
+// of the queue's next entries are prefetched.  Returns new -> old.
+inline std::vector<int> bfs_point_order(const int* neigh, int n, int K) {
+    std::vector<int> order;
+    order.reserve((size_t)n);
+    std::vector<unsigned char> seen((size_t)n, 0);
+    for (int s = 0; s < n; ++s) {
+        if (seen[s]) continue;
+        seen[s] = 1; order.push_back(s);
+        for (size_t h = order.size() - 1; h < order.size(); ++h) {
+            if (h + 8 < order.size()) __builtin_prefetch(neigh + (size_t)order[h + 8] * K);
+            const int* row = neigh + (size_t)order[h] * K;
+            for (int j = 0; j < K; ++j) {
+                const int w = row[j];
+                if (w < 0) break;
+                if (!seen[w]) { seen[w] = 1; order.push_back(w); }
+            }
+        }
+    }
+    return order;
+}
+
+// Host twin of gmgs::order_gather_score (setup_kernels.hip.hpp; the specification of the score): distinct 128-byte lines touched
+// by the j-th gathers of 64 rows taken at every fourth position of `order`, summed over n_win sampled windows, and the number of
+// entries.  Integer sums: the same numbers as the device kernel's.
+template <class Mat>
+inline void order_gather_score_host(const Mat& A, const std::vector<int>& order, int n_win, unsigned long long out[2]) {
+    const int n = A.n_outer;
+    out[0] = out[1] = 0;
+    if (n < 512) return;
+    std::vector<int> inv((size_t)n);
+    for (int r = 0; r < n; ++r) inv[order[r]] = r;
+    constexpr int kMaxRow = 32;
+    std::vector<int> p((size_t)64 * kMaxRow), len(64);
+    for (int w = 0; w < n_win; ++w) {
+        const int start = (int)((long long)w * (n - 256) / n_win);
+        int maxlen = 0;
+        for (int l = 0; l < 64; ++l) {
+            const int v = order[start + 4 * l], b = A.ptr[v];
+            len[l] = std::min(A.ptr[v + 1] - b, kMaxRow);
+            for (int q = 0; q < len[l]; ++q) p[(size_t)l * kMaxRow + q] = inv[A.idx[b + q]];
+            std::sort(p.begin() + (size_t)l * kMaxRow, p.begin() + (size_t)l * kMaxRow + len[l]);
+            maxlen = std::max(maxlen, len[l]);
+        }
+        for (int j = 0; j < maxlen; ++j)
+            for (int l = 0; l < 64; ++l) {
+                if (j >= len[l]) continue;
+                ++out[1];
+                const int line = p[(size_t)l * kMaxRow + j] >> 4;
+                bool first = true;
+                for (int m = 0; m < l && first; ++m) first = !(j < len[m] && (p[(size_t)m * kMaxRow + j] >> 4) == line);
+                out[0] += first ? 1 : 0;
+            }
+    }
+}
+
+// mean |i - neighbour| of a neighbour table (sampled): the same locality measure as mean_index_distance
+inline double mean_index_distance_table(const int* neigh, int n, int K) {
+    const int step = std::max(1, n / 65536);
+    double sum = 0.0; long cnt = 0;
+    for (int i = 0; i < n; i += step)
+        for (int j = 0; j < K && neigh[(size_t)i * K + j] >= 0; ++j) { sum += std::abs(neigh[(size_t)i * K + j] - i); ++cnt; }
+    return cnt ? sum / cnt : 0.0;
+}
+
 inline LevelOrdering identity_ordering(int n) {
     LevelOrdering o;
     o.n = n; o.n_pad = round_up(std::max(n, 1), kSlice); o.n_colors = 1;

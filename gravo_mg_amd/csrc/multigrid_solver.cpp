@@ -175,6 +175,14 @@ void MultigridSolver::buildHierarchy() {
         if (gmg_hierarchy_get_timing(hh, key, &v) == GMG_OK) hierarchyTiming[key] = v;
     }
     lap("samples / nearest / timing");
+    {   // by-product of the construction for the engine (not in the reference): breadth-first order of the points, made for inputs
+        // whose numbering has no locality -- belongs to the `U` built here (prepareEngine drops it when `U` was replaced)
+        int cnt = 0;
+        fineOrder_.clear();
+        if (gmg_hierarchy_get_fine_order(hh, nullptr, &cnt) == GMG_OK && cnt > 0) { fineOrder_.resize((size_t)cnt); gmg_hierarchy_get_fine_order(hh, fineOrder_.data(), &cnt); }
+        fineOrderFor_.clear();
+        for (size_t k = 0; k < U.size(); ++k) fineOrderFor_.push_back(U[k].digest());
+    }
     gmg_hierarchy_destroy(hh);
     lap("destroy");
 }
@@ -207,6 +215,8 @@ int MultigridSolver::prepareEngine() {
                 err_ = gmg_last_error(engine_);
                 return rc;
             }
+        if (!U.empty() && !fineOrder_.empty() && digU == fineOrderFor_ && (int)fineOrder_.size() == U[0].rows())
+            (void)gmg_set_fine_order(engine_, (int)fineOrder_.size(), fineOrder_.data());       // (optional: a refusal only costs locality)
         if (!U.empty() && (rc = gmg_finalize_hierarchy(engine_))) { err_ = gmg_last_error(engine_); return rc; }
         uploadedU_ = digU;
         systemReady_ = false;

@@ -135,6 +135,8 @@ private:
     int ensureSystem(const SparseMatrix& LHS);
     gmg_handle engine_ = nullptr;
     std::vector<std::pair<uint64_t, uint64_t>> uploadedU_;     // digests of what the engine holds
+    std::vector<int> fineOrder_;                               // breadth-first order of the points from buildHierarchy (may be empty) ...
+    std::vector<std::pair<uint64_t, uint64_t>> fineOrderFor_;  // ... and the digests of the U it belongs to
     std::pair<uint64_t, uint64_t> uploadedLHS_{0, 0};
     bool systemReady_ = false;
     bool exactGsActive_ = false;                               // Gauss-Seidel on every level instead of the configured smoothers ...

@@ -290,6 +290,49 @@ __global__ void perm_fill(const int* __restrict__ ptr, const int* __restrict__ i
     for (int q = b; q < e; ++q) pidx[o + (q - b)] = inv[idx[q]];
 }
 
+// How well do the x-gathers of 64 consecutive rows coalesce under a candidate base order of the level-0 points?  One wavefront per
+// sampled window: lane l stands for the point at position start + 4 l of the order (every fourth one: the rows of one colour
+// class), sorts the positions of its row's columns, and for every entry slot j the wave counts the distinct 128-byte lines
+// (16 doubles) its 64 j-th gathers touch -- what a gather instruction of the sweep / residual kernels pays in the vector cache.
+// out[0] += distinct lines, out[1] += entries (integers: the sums do not depend on the order of the atomics).
+constexpr int kScoreMaxRow = 32;
+__global__ __launch_bounds__(256) void order_gather_score(const int* __restrict__ ptr, const int* __restrict__ idx, const int* __restrict__ order,
+                                                          const int* __restrict__ inv, int n, int n_win, unsigned long long* __restrict__ out) {
+    __shared__ int lines[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= n_win || n < 512) return;
+    const int start = (int)((long long)w * (n - 256) / n_win);
+    const int v = order[start + 4 * lane];
+    const int b = ptr[v];
+    const int len = min(ptr[v + 1] - b, kScoreMaxRow);
+    int p[kScoreMaxRow];
+    for (int q = 0; q < len; ++q) {                        // insertion sort of the column positions
+        const int c = inv[idx[b + q]];
+        int k = q;
+        while (k > 0 && p[k - 1] > c) { p[k] = p[k - 1]; --k; }
+        p[k] = c;
+    }
+    int maxlen = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off, 64));
+    unsigned distinct = 0, entries = 0;
+    for (int j = 0; j < maxlen; ++j) {
+        const bool has = j < len;
+        const int line = has ? p[j] >> 4 : -1;
+        lines[wave][lane] = line;
+        __builtin_amdgcn_wave_barrier();
+        bool first = has;
+        for (int m = 0; m < lane && first; ++m) first = lines[wave][m] != line;
+        __builtin_amdgcn_wave_barrier();
+        distinct += first ? 1u : 0u;
+        entries += has ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { distinct += __shfl_xor(distinct, off, 64); entries += __shfl_xor(entries, off, 64); }
+    if (lane == 0) { atomicAdd(out, (unsigned long long)distinct); atomicAdd(out + 1, (unsigned long long)entries); }
+}
+
 // row -> block map of a blocked ordering (blk_begin: n_blocks + 1 device rows)
 __global__ void block_of_rows(const int* __restrict__ blk_begin, int n_blocks, int* __restrict__ blk_of_row) {
     const int b = blockIdx.x;

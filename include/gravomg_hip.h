@@ -288,6 +288,16 @@ int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out);
 int gmg_hierarchy_get_samples(gmg_hierarchy hh, int k, int* out);
 int gmg_hierarchy_get_nearest(gmg_hierarchy hh, int k, int* out);
 int gmg_hierarchy_get_points(gmg_hierarchy hh, int k, double* out_xyz);
+/* A breadth-first order of the level-0 points over `neigh` (new -> old), made beside the construction when the input numbering
+ * has no locality (randomly ordered scans, point clouds); *count = 0 otherwise.  out may be NULL (size query).  Not in the
+ * reference: a by-product the MI355X engine uses to number the finest level (gmg_set_fine_order). */
+int gmg_hierarchy_get_fine_order(gmg_hierarchy hh, int* out, int* count);
+/* Optional, after the prolongations and before gmg_finalize_hierarchy / gmg_set_system: a locality-preserving order of the
+ * level-0 points (a permutation, new -> old; n = 0 clears it).  When the system's numbering has no locality the engine
+ * renumbers its finest level; with this order at hand it scores it against the order it derives from the hierarchy on the
+ * actual matrix and uses the better one (results do not depend on the numbering beyond rounding).  gmg_use_hierarchy passes
+ * the hierarchy object's order by itself. */
+int gmg_set_fine_order(gmg_handle h, int n, const int* order);
 /* Convenience: feed every U_k of a built hierarchy into a solver handle (and finalize it, see below). */
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
 /* Optional, after the last gmg_set_prolongation: build what depends on the hierarchy only (the reference's

@@ -296,3 +296,45 @@ def test_prolongation_rows_with_more_than_three_entries_use_the_host_builders(ca
 
 def rel(a, b):
     return np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(np.asarray(b)), 1e-300)
+
+
+def test_base_order_of_a_reordered_level_follows_the_gather_score(cabi):
+    """Inputs without locality get their finest level renumbered; with the hierarchy object's breadth-first order at hand the
+    engine scores it against the cluster order on the actual matrix (distinct cache lines per gather of 64 rows) and takes the
+    better one: breadth-first on a triangle mesh, cluster order on a kNN point cloud.  Device score and host twin decide alike
+    (same orderings from the device builder and the host planner), and the solve agrees with the oracle either way."""
+    from gravo_mg_amd import meshgen
+    from oracle import oracle
+    V, F = meshgen.torus_mesh(340, 340, order="random")
+    S, mass = meshgen.cotan_laplacian(V, F)
+    H = cabi.Hierarchy(V, meshgen.neighbors_from_stiffness(S), lower_bound=2000)
+    lhs, rhs = meshgen.poisson_system(S, mass)
+    assert H.fine_order is not None
+    engs = []
+    for dev in (True, False):
+        e = cabi.Engine(device_setup=dev)
+        e.use_hierarchy(H); e.set_mass(mass); e.set_system(lhs)
+        assert e.timing("base_order_choice") == 1.0 and 0 < e.timing("base_order_score_bfs") < e.timing("base_order_score_cluster")
+        engs.append(e)
+    assert engs[0].timing("base_order_score_bfs") == engs[1].timing("base_order_score_bfs")
+    assert engs[0].timing("base_order_score_cluster") == engs[1].timing("base_order_score_cluster")
+    for a, b in zip(engs[0].level_ordering(0), engs[1].level_ordering(0)):
+        assert np.array_equal(a, b)
+    x, it, res, _ = engs[0].solve(rhs, tol=1e-4)
+    O = oracle.Hierarchy(H.U, mass); O.set_system(lhs)
+    xo, ito, reso, _ = O.solve(rhs, tol=1e-4)
+    assert res <= 1e-4 and it <= ito + 1
+    assert np.sqrt((mass[:, None] * (x - xo) ** 2).sum() / (mass[:, None] * xo ** 2).sum()) <= 20 * 1e-4
+    n_col_bfs = engs[0].level_info(0)["n_colors"]
+    # the cluster order alone (no fine order handed over): more colour classes on the same mesh
+    e2 = cabi.Engine(); e2.set_prolongations(H.U); e2.set_mass(mass); e2.set_system(lhs)
+    assert e2.timing("base_order_choice") == 0.0 and n_col_bfs <= e2.level_info(0)["n_colors"]
+    x2, it2, res2, _ = e2.solve(rhs, tol=1e-4)
+    assert res2 <= 1e-4 and np.sqrt((mass[:, None] * (x - x2) ** 2).sum() / (mass[:, None] * x2 ** 2).sum()) <= 20 * 1e-4
+    # a kNN point cloud: thick, ragged wavefronts -- the cluster order scores better
+    P = meshgen.torus_points(120_000, noise=0.0005)
+    Sp, mp = meshgen.knn_graph_laplacian(P, 8)
+    Hp = cabi.Hierarchy(P, meshgen.neighbors_from_stiffness(Sp), lower_bound=2000)
+    assert Hp.fine_order is not None
+    ep = cabi.Engine(); ep.use_hierarchy(Hp); ep.set_mass(mp); ep.set_system(meshgen.poisson_system(Sp, mp)[0])
+    assert ep.timing("base_order_choice") == 0.0 and ep.timing("base_order_score_cluster") < ep.timing("base_order_score_bfs")

@@ -37,3 +37,32 @@ def test_cpp_builder_matches_python_restatement(cabi, kind, lower_bound, ratio):
         for cnt in np.diff(sp.csr_matrix(a).indptr):
             kinds[int(cnt)] += 1
     assert kinds[3] > 0 and kinds[2] > 0          # triangle rows and edge/two-parent rows both occur
+
+
+def test_fine_order_is_the_breadth_first_order_of_the_point_graph(cabi):
+    """gmg_hierarchy_build's by-product for inputs without locality (gmg_hierarchy_get_fine_order): the order in which a sequential
+    breadth-first search over `neigh` from point 0 dequeues the points -- checked against a plain Python BFS; a locally numbered
+    input gets none."""
+    V, F = meshgen.torus_mesh(340, 340, order="random")
+    S, _ = meshgen.cotan_laplacian(V, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    H = cabi.Hierarchy(V, neigh, lower_bound=4000)
+    fo = H.fine_order
+    n = V.shape[0]
+    assert fo is not None and fo.shape == (n,)
+    seen = np.zeros(n, bool); want = []
+    for s0 in range(n):
+        if seen[s0]:
+            continue
+        seen[s0] = True; want.append(s0); h = len(want) - 1
+        while h < len(want):
+            for w in neigh[want[h]]:
+                if w < 0:
+                    break
+                if not seen[w]:
+                    seen[w] = True; want.append(int(w))
+            h += 1
+    assert np.array_equal(fo, np.array(want, dtype=np.int32))
+    V2, F2 = meshgen.torus_mesh(300, 300)
+    S2, _ = meshgen.cotan_laplacian(V2, F2)
+    assert cabi.Hierarchy(V2, meshgen.neighbors_from_stiffness(S2), lower_bound=4000).fine_order is None
