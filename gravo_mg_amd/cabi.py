@@ -86,6 +86,7 @@ SIGNATURES = {
     "gmg_coarse_solve": (C.c_int, [_vp, _dp, C.c_int, _dp]),
     "gmg_residual_norm": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_int, _dp]),
     "gmg_vcycle": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "gmg_smooth_residual": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_solve": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _ip, _dp, _dp]),
     "gmg_load_problem": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "gmg_run_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
@@ -432,6 +433,14 @@ class Engine:
         B, X = _f64(b), _f64(x).copy(order="F")
         self._chk(lib().gmg_smooth(self._h, k, _pd(B), _pd(X), B.shape[1], int(iters)))
         return self._shape_like(X, x)
+
+    def smooth_residual(self, k, b, x, iters, from_zero=False):
+        """(x after `iters` sweeps, b - A x as the way down forms it) -- gmg_smooth_residual"""
+        B = _f64(b)
+        X = np.zeros_like(B, order="F") if x is None else _f64(x).copy(order="F")
+        R = np.empty_like(B, order="F")
+        self._chk(lib().gmg_smooth_residual(self._h, k, _pd(B), _pd(X), B.shape[1], int(iters), int(bool(from_zero)), _pd(R)))
+        return self._shape_like(X, b), self._shape_like(R, b)
 
     def residual(self, k, b, x):
         B, X = _f64(b), _f64(x)

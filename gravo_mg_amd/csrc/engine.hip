@@ -905,6 +905,27 @@ int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters
     return to_host(h, k, l.x, d, x);
 } GMG_CATCH_H
 
+int gmg_smooth_residual(gmg_handle h, int k, const double* b, double* x, int d, int iters, int from_zero, double* r) try {
+    NEED_DEVICE();
+    int rc = check_level(h, k, false);
+    if (rc) return rc;
+    if (!b || !x || !r || d <= 0 || iters < 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = ensure_vectors(h, d))) return rc;
+    Level& l = h->lv[k];
+    if ((rc = to_device(h, k, b, d, l.b))) return rc;
+    const bool zero = from_zero != 0 && k > 0 && smooth_from_zero_ok(h, l, iters);
+    if (from_zero) HIPCHK(hipMemsetAsync(l.x, 0, sizeof(double) * (size_t)l.n_pad * d, h->stream));
+    else if ((rc = to_device(h, k, x, d, l.x))) return rc;
+    h->sweep_prev_valid = false;
+    launch_smooth<double>(h, l, d, iters, zero);
+    const bool delta = k > 0 && launch_residual_delta<double>(h, l, d, l.r);        // exactly what enqueue_down does
+    if (!delta) launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r);
+    h->timing["residual_from_sweep"] = delta ? 1.0 : 0.0;
+    h->loaded_d = 0;
+    if ((rc = to_host(h, k, l.x, d, x))) return rc;
+    return to_host(h, k, l.r, d, r);
+} GMG_CATCH_H
+
 int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, double* r) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);

@@ -126,6 +126,7 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
     // (begin_table / ncolors_table: an explicit list of nb blocks instead of a range -- entry-parallel sweep only, which reads
     // nothing but the first row of its block from the table)
     const int* blk_begin = begin_table ? begin_table : l.d_blk_begin + b0;
+    static const bool table_always = std::getenv("GMG_EP_BLOCK_TABLE") != nullptr;      // A/B aid
     const int* blk_ncolors = ncolors_table ? ncolors_table : l.d_blk_ncolors + b0;
     if (nb <= 0) return;
     for (int c0 = 0; c0 < d; c0 += 4) {
@@ -134,9 +135,9 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
             const int grid = (nb + 7) / 8 * 8;          // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, grid)
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64),
                                               (size_t)D * 64 * sizeof(T) + std::max((size_t)l.ep_cap_e * sizeof(T), (size_t)l.ep_cap_l * (sizeof(T) + 2)), h->stream,
-                                              blk_begin, blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
+                                              ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
                                               Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb));
+                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0));
         } else if (l.use_bcsr && d > 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                               (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, blk_begin,
@@ -165,12 +166,40 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
     // first sweep gets no input vector -- it neither reads x nor gathers the off-block couplings (all zero) -- and the
     // caller skips the memset
     T* in = from_zero ? nullptr : Prec<T>::x(l); T* out = Prec<T>::tmp(l);
+    const T* before_last = nullptr;      // the iterate the last sweep started from (nullptr: the zero vector)
+    bool last_known = false;
     for (int it = 0; it < iters; ++it) {
         launch_block_sweep_range<T>(h, l, d, in, out, 0, nb);
+        before_last = in; last_known = true;
         if (it == 0 && from_zero) { in = out; out = Prec<T>::x(l); }      // the result of sweep 1 is in tmp; ping-pong from there
         else std::swap(in, out);
     }
     if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
+    // what residual_delta_ep needs: the last sweep went before_last -> x (the copy above, if any, does not touch before_last)
+    h->sweep_prev_valid = last_known && before_last != (const T*)Prec<T>::x(l);
+    h->sweep_prev = (const void*)before_last;
+}
+
+// r = b - A x of a blocked level with the unpadded block storage, straight after its block sweeps (h->sweep_prev: the iterate the
+// last sweep started from): the sweep's explicit part applied to x_old - x_new (kernels.hip.hpp::residual_delta_ep)
+// (begin_table / nb_list: an explicit list of blocks -- a rank's blocks of a partitioned level -- instead of all of them)
+template <class T>
+bool launch_residual_delta(gmg_handle h, Level& l, int d, T* r, const int* begin_table = nullptr, int nb_list = 0) {
+    static const bool off = std::getenv("GMG_NO_DELTA_RESIDUAL") != nullptr;      // A/B aid
+    if (off || !l.use_ep || !h->sweep_prev_valid || h->cfg.smoother == GMG_SMOOTHER_JACOBI) return false;
+    h->sweep_prev_valid = false;
+    const int ld = l.n_pad, nb = begin_table ? nb_list : l.ord.n_blocks();
+    if (nb <= 0) return true;
+    const int grid = (nb + 7) / 8 * 8;
+    const T* x_old = (const T*)h->sweep_prev;
+    const T* x_new = Prec<T>::x(l);
+    for (int c0 = 0; c0 < d; c0 += 4) {
+        int dc = std::min(4, d - c0);
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_delta_ep<T, D>), dim3(grid), dim3(64), (size_t)std::max(l.ep_cap_e, 64) * sizeof(T), h->stream, begin_table,
+                                          l.ee_ptr, l.ee_col, Prec<T>::eeval(l), (x_old ? x_old + (size_t)c0 * ld : nullptr), x_new + (size_t)c0 * ld,
+                                          r + (size_t)c0 * ld, ld, nb));
+    }
+    return true;
 }
 
 // true when smoothing level l from a zero iterate needs no materialised zero vector (block sweeps, at least one of them)
@@ -462,11 +491,14 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         static const bool no_fold = std::getenv("GMG_NO_NORM_FOLD") != nullptr;
         if (k == 0 && sizeof(T) == 8 && !no_fold) h->fuse_res_out = h->lv[0].r;
         h->fuse_res_from = 0;
+        h->sweep_prev_valid = false;
         launch_smooth<T>(h, l, d, h->cfg.pre_iters, from_zero);                                     // :1063
         h->fuse_res_out = nullptr;
         const int res_slices = (k == 0 && h->fuse_res_from > 0) ? h->fuse_res_from : -1;
         h->fuse_res_from = 0;
-        launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices);        // :1066
+        // :1066.  Straight after block sweeps on the unpadded block storage the residual comes from the sweep's explicit part alone
+        if (!(k > 0 && launch_residual_delta<T>(h, l, d, Prec<T>::r(l))))
+            launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices);
         launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
     }
 }

@@ -456,13 +456,19 @@ int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero) {
     double* in = from_zero ? nullptr : l1.x;
     double* out = l1.tmp;
     int rc;
+    const double* before_last = nullptr;
     for (int it = 0; it < iters; ++it) {
         launch_block_sweep_range<double>(h, l1, d, in, out, 0, nb, p->d_own_begin, p->d_own_ncolors);
         if ((rc = p2p_exchange(h, C + 3, out, l1.n_pad))) return rc;
+        before_last = in;
         if (it == 0 && from_zero) { in = out; out = l1.x; }
         else std::swap(in, out);
     }
     if (iters > 0 && in != l1.x) HIPCHK(hipMemcpyAsync(l1.x, in, sizeof(double) * (size_t)l1.n_pad * d, hipMemcpyDeviceToDevice, h->stream));
+    // (both buffers carry the halo entries this rank's rows read: each was exchanged right after the sweep that wrote it -- what the
+    // residual from the sweep's explicit part needs, launch_residual_delta, exactly as the single-GPU engine forms it)
+    h->sweep_prev_valid = iters > 0 && before_last != l1.x;
+    h->sweep_prev = (const void*)before_last;
     return GMG_OK;
 }
 
@@ -490,7 +496,8 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
     const bool from_zero = smooth_from_zero_ok(h, l1, h->cfg.pre_iters);
     if (!from_zero) HIPCHK(hipMemsetAsync(l1.x, 0, sizeof(double) * (size_t)l1.n_pad * d, h->stream));       // :1072-1073
     if ((rc = p2p_smooth_level1(h, h->cfg.pre_iters, from_zero))) return rc;              // :1063
-    if (p->n_asl > 0)                                                                 // :1066 on my rows
+    const bool from_sweep = launch_residual_delta<double>(h, l1, d, l1.r, p->d_own_begin, (int)p->own_blocks[p->rank].size());      // :1066 on my rows ...
+    if (!from_sweep && p->n_asl > 0)                                                  // ... or with the residual SpMV
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             if (l1.Aoff.lpr == 4) {

@@ -168,6 +168,8 @@ struct gmg_solver_s {
     unsigned long long* h_flag = nullptr; unsigned long long flag_seq[3] = {0, 0, 0};
     // h_flag[16]: written by the HOST -- the stream waits on it (hipStreamWaitValue64) in front of the work that needs the host's
     // coarsest solution, so that work is enqueued before the host solves (engine_cycle.hip.hpp::coarse_host_begin / _serve)
+    const void* sweep_prev = nullptr;    // the iterate the last block sweep of launch_block_sweeps started from (nullptr: zero) ...
+    bool sweep_prev_valid = false;       // ... valid until the next launch touches the level (enqueue_down consumes it: residual_delta_ep)
     bool gate_ok = true;                 // false once hipStreamWaitValue64 was refused: launch after the solve instead
     bool gate_proven = false;            // true once a published right-hand side was seen by the polling host while the stream was busy (ungated)
     bool coarse_pending = false;         // a gate is enqueued and the host has not answered it yet
@@ -448,7 +450,7 @@ void drop_system(gmg_handle h) {
 }
 
 // blocked levels smaller than this use 4 lanes per row (GMG_QUAD_LEVEL_ROWS: measurement aid)
-inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 262144; return v; }
+inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 131072; return v; }
 #define kQuadLevelRows quad_level_rows()
 constexpr int kEpMaxBlockEntries = 6144;        // largest explicit / lower chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
 constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)

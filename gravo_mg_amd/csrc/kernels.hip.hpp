@@ -451,7 +451,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
                                                   const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
                                                   const int* __restrict__ e_ptr, const int* __restrict__ e_col,
                                                   const T* __restrict__ e_val, const T* __restrict__ diag, const T* __restrict__ b,
-                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks) {
+                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks, int blk0) {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                            // D x 64: the block's new x
     T* pbuf = xs + D * 64;                                             // cap_e products of one column ...
@@ -462,7 +462,9 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     const int blk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3));
     if (blk >= n_blocks) return;
     const int lane = threadIdx.x;
-    const int r0 = blk_begin[blk];                                     // 64 rows (padding rows: no entries, diag 1, b 0, colour 0)
+    // 64 rows (padding rows: no entries, diag 1, b 0, colour 0).  Without a block table the blocks are the level's own, in order:
+    // block b starts at row 64 (blk0 + b) -- one dependent load less in front of everything else the wave does
+    const int r0 = blk_begin ? blk_begin[blk] : (blk0 + blk) << 6;
     const int row = r0 + lane;
     const int e0 = e_ptr[r0], e1 = e_ptr[r0 + 64];
     const int q0 = l_ptr[r0], q1 = l_ptr[r0 + 64];
@@ -583,6 +585,70 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 #pragma unroll
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
 #undef GMG_EP_COL
+}
+
+// Residual of a blocked level RIGHT AFTER a block-hybrid sweep x_old -> x_new, from the sweep's own explicit part: the sweep solved
+//   a_ii x_new_i + sum_{L(i)} a_ij x_new_j + sum_{E(i)} a_ij x_old_j = b_i        (L: earlier rows of the block, E: everything else)
+// for every row, so  r_i = b_i - (A x_new)_i = sum_{E(i)} a_ij (x_old_j - x_new_j):  the residual needs neither b nor the diagonal
+// nor the lower entries -- 55 % of the operator's entries on the 506 k-row level of the 3 M-vertex torus, on the UNPADDED E storage
+// (the residual SpMV reads the merged SELL operator, 25-29 % padding: 31 us; this: see profiles/).  The value differs from
+// b - A x_new by the rounding of the sweep's last division, |a_ii x_i| eps -- the size of the rounding error of evaluating b - A x
+// itself.  x_old == nullptr: the sweep started from the zero vector.  Launch geometry and entry-parallel reduction as in gs_block_ep.
+template <class T, int D>
+__global__ __launch_bounds__(64) void residual_delta_ep(const int* __restrict__ blk_begin, const int* __restrict__ e_ptr, const int* __restrict__ e_col,
+                                                        const T* __restrict__ e_val, const T* __restrict__ x_old, const T* __restrict__ x_new,
+                                                        T* __restrict__ r, int ld, int n_blocks) {
+    extern __shared__ unsigned char smem_raw[];
+    T* pbuf = reinterpret_cast<T*>(smem_raw);
+    const int chunk = (int)(gridDim.x >> 3);
+    const int blk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3));
+    if (blk >= n_blocks) return;
+    const int lane = threadIdx.x;
+    const int r0 = blk_begin ? blk_begin[blk] : blk << 6;          // a block table (a rank's blocks), or the level's own blocks in order
+    const int row = r0 + lane;
+    const int e0 = e_ptr[r0], e1 = e_ptr[r0 + 64];
+    const int nE = e1 - e0;
+    int ec[kEpE];
+    T ev[kEpE];
+#pragma unroll
+    for (int k = 0; k < kEpE; ++k) {
+        ec[k] = row; ev[k] = (T)0.0;
+        if (64 * k < nE) {
+            const int e = e0 + 64 * k + lane;
+            if (e < e1) { ec[k] = __builtin_nontemporal_load(e_col + e); ev[k] = __builtin_nontemporal_load(e_val + e); }
+        }
+    }
+    const int eb = e_ptr[row] - e0, ee = e_ptr[row + 1] - e0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const T* xn = x_new + (int64_t)c * ld;
+        if (x_old) {
+            const T* xo = x_old + (int64_t)c * ld;
+            T dx[kEpE];
+#pragma unroll
+            for (int k = 0; k < kEpE; ++k) dx[k] = 64 * k < nE ? xo[ec[k]] - xn[ec[k]] : (T)0.0;
+#pragma unroll
+            for (int k = 0; k < kEpE; ++k)
+                if (64 * k < nE) pbuf[64 * k + lane] = ev[k] * dx[k];
+            for (int e = 64 * kEpE + lane; e < nE; e += 64) { const int cj = e_col[e0 + e]; pbuf[e] = e_val[e0 + e] * (xo[cj] - xn[cj]); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kEpE; ++k)
+                if (64 * k < nE) pbuf[64 * k + lane] = -(ev[k] * xn[ec[k]]);
+            for (int e = 64 * kEpE + lane; e < nE; e += 64) pbuf[e] = -(e_val[e0 + e] * xn[e_col[e0 + e]]);
+        }
+        __syncthreads();
+        T acc = (T)0.0;
+        for (int q = eb; q < ee; q += 16) {
+            T p[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) p[j] = q + j < ee ? pbuf[q + j] : (T)0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc += p[j];
+        }
+        r[row + (int64_t)c * ld] = acc;
+        __syncthreads();
+    }
 }
 
 // The same sweep on the QUAD layout (4 lanes per row; blocks of <= 256 rows = 1024 threads).  A colour step is the

@@ -149,6 +149,12 @@ int gmg_get_timing(gmg_handle h, const char* key, double* out);
 /* ---- operators (host in / host out; natural numbering).  Used by the parity tests -------------- */
 /* `iters` smoothing sweeps on level k: replaces GaussSeidelSmoother, multigrid_solver.cpp:1194-1226. */
 int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters);
+/* The first half of the way down on level k as the cycle runs it: `iters` smoothing sweeps (multigrid_solver.cpp:1063; from_zero
+ * != 0: from the zero vector, :1072-1073, x is output only) followed by res = b - A x (:1066).  On a level with the unpadded block
+ * storage the residual comes out of the last sweep's explicit part (r_i = sum_E a_ij (x_old_j - x_new_j), csrc/kernels.hip.hpp::
+ * residual_delta_ep; timing key "residual_from_sweep" = 1), otherwise from the residual SpMV: the entry point of the parity test
+ * of that shortcut against b - A x. */
+int gmg_smooth_residual(gmg_handle h, int k, const double* b, double* x, int d, int iters, int from_zero, double* r);
 /* r = b - A_k x : multigrid_solver.cpp:1066. */
 int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, double* r);
 /* y = A_k x. */

@@ -107,6 +107,33 @@ def test_block_hybrid_sweep_of_the_big_level_kernels(setup, cabi, oracle):
         _check_block_sweeps(P, eng, oracle)
 
 
+def test_residual_from_the_sweeps_explicit_part_equals_b_minus_Ax(setup, cabi, oracle):
+    """On the way down, a level with the unpadded block storage takes its residual from the last sweep's explicit part,
+    r_i = sum_E a_ij (x_old_j - x_new_j) (kernels.hip.hpp::residual_delta_ep), instead of a pass over the whole operator.  Against
+    the oracle's b - A x of the same iterate, to the rounding of evaluating b - A x: |difference| <= 1e-13 (|A||x| + |b|)."""
+    P, _ = setup
+    eng = cabi.Engine(block_lanes=1)          # the big-level kernels on every blocked level
+    eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    rng = np.random.default_rng(11)
+    used = 0
+    for k in range(1, len(P.U)):
+        A = eng.level_operator(k)
+        absA = abs(A)
+        for d in (1, 3):
+            b = rng.standard_normal((A.shape[0], d)); x0 = rng.standard_normal((A.shape[0], d))
+            for iters in (1, 2, 3):
+                for from_zero in (False, True):
+                    x, r = eng.smooth_residual(k, b, None if from_zero else x0, iters, from_zero=from_zero)
+                    shortcut = eng.timing("residual_from_sweep") == 1.0
+                    # (a sweep count whose result lands in the other buffer is copied over x -- which was x_old -- and falls back to the SpMV)
+                    assert shortcut == (iters % 2 == 0 or (from_zero and iters == 1))
+                    used += shortcut
+                    assert np.array_equal(x, eng.smooth(k, b, np.zeros_like(b) if from_zero else x0, iters))
+                    scale = absA @ abs(x) + abs(b)
+                    assert np.abs(r - oracle.residual(A, b, x)).max() <= 1e-13 * scale.max(), (k, d, iters, from_zero)
+    assert used > 0 or len(P.U) == 1
+
+
 def _check_block_sweeps(P, eng, oracle):
     import scipy.sparse.linalg as spla
     rng = np.random.default_rng(7)
