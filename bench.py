@@ -72,8 +72,9 @@ def load_pmc_traffic(workload):
     return None, None
 
 
-def variant_run(cabi, torch, label, H, mass, lhs, rhs, steps, warmup, **kw):
-    """ms per V-cycle (incl. residual check) + solve-to-1e-4 of another workload / engine variant (never `value`)."""
+def variant_run(cabi, torch, label, H, mass, lhs, rhs, steps, warmup, kernels=False, **kw):
+    """ms per V-cycle (incl. residual check) + solve-to-1e-4 of another workload / engine variant (never `value`).
+    kernels: also the fine-level kernels one by one (HIP events) with their algorithmic GB/s for this right-hand-side width."""
     eng = cabi.Engine(**kw)
     eng.use_hierarchy(H); eng.set_mass(mass)
     t = time.perf_counter(); eng.set_system(lhs); set_ms = 1e3 * (time.perf_counter() - t)
@@ -83,6 +84,20 @@ def variant_run(cabi, torch, label, H, mass, lhs, rhs, steps, warmup, **kw):
     out = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps, "iterations_to_1e-4": int(it), "residues": [float(v) for v in conv[:, 1]],
            "solve_ms": solve_ms, "set_system_ms": set_ms, "n_vertices": int(lhs.shape[0]),
            "levels": [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)], "colors": [eng.level_info(k)["n_colors"] for k in range(eng.num_levels + 1)]}
+    d = int(rhs.shape[1])
+    cyc_bytes = cycle_algorithmic_bytes(eng, d)
+    out["cycle_algorithmic_GB"] = cyc_bytes / 1e9
+    out["cycle_frac_of_peak"] = cyc_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if kernels:
+        kk = {}
+        for name, kind, k in (("fine_sweep", 0, 0), ("fine_residual", 1, 0), ("fine_restrict", 2, 0), ("fine_prolong_add", 3, 0), ("fine_norm", 4, 0),
+                              ("level1_sweep", 0, 1), ("level1_residual", 1, 1)):
+            if k >= eng.num_levels:
+                continue
+            ms, launches = eng.bench_kernel(kind, k, d, 30)
+            by = eng.algorithmic_bytes(kind, k, d)
+            kk[name] = {"ms": ms, "launches": launches, "algorithmic_MB": by / 1e6, "GBps": by / (ms * 1e-3) / 1e9}
+        out["kernels"] = kk
     eng.close()
     log(f"[bench] variant {label}: {out['ms_per_step']:.3f} ms/cycle, {it} cycles to 1e-4")
     return out
@@ -103,9 +118,19 @@ def cpu_quota():
         return None
 
 
+def cycle_algorithmic_bytes(eng, d):
+    """one V-cycle incl. residual check = sum over the smoothed levels of (pre + post sweeps + residual) sweeps +
+    restriction + prolongation, + the check on level 0 -- each array counted once per kernel."""
+    total = 0.0
+    for k in range(eng.num_levels):
+        total += (eng.pre_iters + eng.post_iters + 1) * eng.algorithmic_bytes(0, k, d) + eng.algorithmic_bytes(2, k, d) + eng.algorithmic_bytes(3, k, d)
+    return total + eng.algorithmic_bytes(4, 0, d)
+
+
 def cpu_baseline(H, mass, lhs, rhs, cycles):
     """The oracle (line-by-line CPU restatement, 1 thread as the reference pins omp_set_num_threads(1),
     multigrid_solver.cpp:86-87) on the SAME workload: Galerkin setup + `cycles` V-cycles with residual check."""
+    import numpy as np
     from oracle import oracle
     oracle.build()
     O = oracle.Hierarchy(H.U, mass)
@@ -115,14 +140,31 @@ def cpu_baseline(H, mass, lhs, rhs, cycles):
     t = time.perf_counter()
     x, it, res, conv = O.solve(rhs, tol=0.0, stop_type=2, max_iter=cycles)     # tol 0 => exactly `cycles` trips
     cyc_s = time.perf_counter() - t
-    return {
+    out = {
         "value": 1e3 * cyc_s / it, "unit": "ms per V-cycle (incl. residual check)", "cores": 1, "kind": "port",
+        "flags": "-O3 -DNDEBUG (the reference's Release build, gravomg_bindings/setup.py:38,47: no -march)",
         "sample": f"{it} V-cycles + residual checks of the full {lhs.shape[0]}-vertex workload (x0=rhs) after the Galerkin setup",
         "setup_ms": {"reduction": O.timing["reduction"], "coarsest_solve": O.timing["coarsest_solve"], "total": 1e3 * setup_s},
         "residues": [float(r) for r in conv[:, 1]],
         "iterations_to_1e-4": int(next((i + 1 for i, r in enumerate(conv[:, 1]) if r <= 1e-4), -1)),
         "host_cpus": os.cpu_count(), "host_cpu_quota": cpu_quota(),
     }
+    del O
+    # the same port with -march=native, built on THIS host (a third of the cycles: it is the second baseline)
+    try:
+        n_cyc = max(3, cycles // 3)
+        On = oracle.Hierarchy(H.U, mass, native=True)
+        t = time.perf_counter(); On.set_system(lhs); nat_setup = time.perf_counter() - t
+        t = time.perf_counter(); _, itn, _, convn = On.solve(rhs, tol=0.0, stop_type=2, max_iter=n_cyc); nat_s = time.perf_counter() - t
+        out["march_native"] = {"value": 1e3 * nat_s / itn, "cycles": int(itn), "setup_ms_total": 1e3 * nat_setup,
+                               "same_residues": bool(np.allclose(convn[:, 1], conv[:itn, 1], rtol=1e-6))}
+        del On
+    except Exception as e:
+        out["march_native"] = {"value": None, "reason": f"{type(e).__name__}: {e}"}
+    # the reference's own Eigen expressions, where this host has Eigen (oracle/eigen_baseline.cpp)
+    eig, why = oracle.eigen_baseline(H.U, mass, lhs, rhs, max(3, cycles // 3))
+    out["eigen"] = eig if eig is not None else {"value": None, "reason": why}
+    return out
 
 
 def main():
@@ -132,7 +174,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n1", type=int, default=1732)
     ap.add_argument("--n2", type=int, default=1732)
-    ap.add_argument("--order", default="natural", choices=["natural", "random"])
+    ap.add_argument("--order", default="natural", choices=["natural", "random", "chunks"])
     ap.add_argument("--config", default=None, choices=["1", "2", "3", "4", "4r", "5", "5b", "6"],
                     help="profiling aid: another BASELINE config (meshgen.baseline_config) as the main workload instead of the torus --n1 x --n2")
     ap.add_argument("--cpu-cycles", type=int, default=25, help="V-cycles timed on the CPU oracle (0 = skip)")
@@ -233,6 +275,11 @@ def main():
         "algorithmic_bytes_per_launch": sweep_bytes / launches,
         "other_fine_kernels": kern,
     }
+    # ... and of the whole step (the honest companion of the dominant-kernel figure): algorithmic bytes of one V-cycle + check
+    cyc_bytes = cycle_algorithmic_bytes(eng, d0)
+    roofline["cycle"] = {"algorithmic_bytes": cyc_bytes, "achieved": cyc_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": cyc_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "whole V-cycle + residual check (every level, launch boundaries and the host coarsest solve included) over ms_per_step"}
 
     # ---- informational: the same matrix pattern with new values (the demos' new-tau-per-frame usage) only refreshes values
     lhs_b = lhs.copy()
@@ -268,6 +315,18 @@ def main():
         Hr, mass_r, lhs_r, rhs_r = build_workload(args.n1, args.n2, "random")
         variants["random_vertex_order"] = variant_run(cabi, torch, "random vertex order", Hr, mass_r, lhs_r, rhs_r, args.steps, args.warmup)
         del Hr, mass_r, lhs_r, rhs_r
+        # an ordering in between: 65 536-vertex runs of the natural order, shuffled -- local inside a run, below the reordering trigger
+        Hc, mass_c, lhs_c, rhs_c = build_workload(args.n1, args.n2, "chunks")
+        variants["chunk_shuffled_order"] = variant_run(cabi, torch, "natural order in shuffled runs of 65 536 vertices (not renumbered)", Hc, mass_c, lhs_c, rhs_c, args.steps, args.warmup)
+        del Hc, mass_c, lhs_c, rhs_c
+        # the reference's real call pattern (demos/smoothing.py:47-50, conformal_flow.py:58): n x 3 right-hand side, lhs = M + 1e-3 S,
+        # on the same 3 M-vertex mesh and hierarchy; byte model 160 B per fine row and sweep instead of 112
+        Vs, Fs = meshgen.torus_mesh(args.n1, args.n2)
+        Ss, mass_s = meshgen.cotan_laplacian(Vs, Fs)
+        lhs_s, rhs_s = meshgen.smoothing_system(Ss, mass_s, Vs)
+        variants["smoothing_d3_3M"] = variant_run(cabi, torch, "smoothing M + 1e-3 S, d = 3", H, mass, lhs_s, rhs_s, args.steps, args.warmup, kernels=True)
+        variants["smoothing_d3_3M"]["ratio_to_d1_cycle"] = variants["smoothing_d3_3M"]["ms_per_step"] / ms_per_step
+        del Vs, Fs, Ss, mass_s, lhs_s, rhs_s
         name, pos, S3, mass3, lhs3, rhs3 = meshgen.baseline_config("3")
         H3 = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S3), ratio=8.0, lower_bound=1000)
         variants["pointcloud_2M_knn8"] = variant_run(cabi, torch, name, H3, mass3, lhs3, rhs3, args.steps, args.warmup)

@@ -126,6 +126,7 @@ SIGNATURES = {
     "gmg_hierarchy_get_samples": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_hierarchy_get_nearest": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_hierarchy_get_points": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_host_threads": (C.c_int, []),
     "gmg_hierarchy_get_fine_order": (C.c_int, [_vp, _ip, _ip]),
     "gmg_set_fine_order": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
@@ -638,6 +639,11 @@ def host_galerkin(A, U) -> sp.csc_matrix:
     lib().gmg_host_galerkin(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), nc, _pi(u.indptr), _pi(u.indices), _pd(u.data),
                             _pi(colptr), _pi(rowidx), _pd(val))
     return sp.csc_matrix((val, rowidx, colptr), shape=(nc, nc))
+
+
+def default_host_threads() -> int:
+    """Host threads a handle uses by default: the CPUs this process may use (affinity, cgroup quota) divided by LOCAL_WORLD_SIZE."""
+    return int(lib().gmg_host_threads())
 
 
 def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024, row_align: int = 64) -> dict:

@@ -86,6 +86,8 @@ int gmg_config_default(gmg_config* cfg) try {
     return GMG_OK;
 } GMG_CATCH_0
 
+int gmg_host_threads(void) try { return hw_threads(); } GMG_CATCH_0
+
 int gmg_device_count(void) try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -559,8 +559,9 @@ struct HelperScope {
     explicit HelperScope(gmg_handle hh) : h(hh) {
         static const int env_threads = std::getenv("GMG_LDLT_THREADS") ? std::atoi(std::getenv("GMG_LDLT_THREADS")) : 0;
         // (every rank of a multi-GPU job keeps its team busy -- and this thread polls -- on the CPUs the job may use: a rank's team
-        // is sized to its share of them minus one CPU of slack, a throttled spinning thread costs far more than it saves)
-        const int ranks = h->dist_ready ? std::max(1, h->world) : 1;
+        // is sized to its share of them (cpu_budget() divides by LOCAL_WORLD_SIZE) minus one CPU of slack, a throttled spinning
+        // thread costs far more than it saves; ranks started without that variable are counted through the handle's world size)
+        const int ranks = (h->dist_ready && !std::getenv("LOCAL_WORLD_SIZE")) ? std::max(1, h->world) : 1;
         const int share = cpu_budget() / ranks;
         int threads = std::min(std::min(h->coarse.parts(), 8), share - 1);
         if (env_threads > 0) threads = std::min(threads, env_threads);

@@ -124,6 +124,10 @@ inline int cpu_budget() {
         long long quota = 0, period = 0;                                 // cgroup v1
         if (read_ll("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", quota) && read_ll("/sys/fs/cgroup/cpu/cpu.cfs_period_us", period) && quota > 0 && period > 0)
             t = std::min<long>(t, (long)std::max<long long>(1, (quota + period - 1) / period));
+        // one process per GPU: the ranks of a node share its CPUs (torchrun exports LOCAL_WORLD_SIZE); every rank sizes its worker
+        // pool, its staging threads and its back-substitution team to ITS share -- 8 ranks x 16 threads on a 16-CPU quota is the
+        // throttling case above
+        if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) { const int lw = std::atoi(e); if (lw > 1) t = std::max<long>(1, t / lw); }
         if (const char* e = std::getenv("GMG_HOST_THREADS")) { const int o = std::atoi(e); if (o > 0) t = o; }
         return (int)std::max<long>(1, t);
     }();

@@ -176,6 +176,40 @@ def main(args):
     ms_per_step = 1e3 * float(tmax.item()) / args.steps
     colls_per_cycle = (dv.n_collectives / max(n_warm + args.warmup + args.steps, 1)) if dv is not None else 0
 
+    # ---- variant (never `value`): the north star's collective -- RCCL all-gather of the packed x halo per colour sweep -- timed for a
+    # few cycles beside the peer-to-peer default, so that the named exchange has a number on every node the driver measures.
+    # Every step that could fail on one rank is followed by a collective agreement before the ranks enter a collective together.
+    variants = {}
+    if p2p is not None and world > 1 and not os.environ.get("GMG_BENCH_NO_HALO_VARIANT"):
+        okv, dv2, be2, why = 1, None, None, None
+        try:
+            eng_h = new_engine()
+            be2 = EngineBackend(eng_h, 1, rank, world, torch.device("cuda", local))
+            new2old, cb = eng_h.level_ordering(0)
+            A = lhs.tocsr()
+            halo2 = HaloPlan(A.indptr, A.indices, new2old, cb, be2.n_pad, world, rank, 1, device=be2.device)
+            dv2 = DistVCycle(be2, halo=halo2)
+            be2.load(rhs, rhs)
+        except Exception as e:          # noqa: BLE001
+            okv, why = 0, repr(e)
+        if agreed(okv):
+            k = max(1, min(args.steps, 10))
+            warm = []
+            for _ in range(n_warm):
+                dv2.vcycle(); warm.append(dv2.residual_norm(2))
+            torch.cuda.synchronize(); dist.barrier()
+            th0 = time.perf_counter()
+            for _ in range(k):
+                dv2.vcycle(); dv2.residual_norm(2)
+            torch.cuda.synchronize(); dist.barrier()
+            th = torch.tensor([time.perf_counter() - th0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+            variants["rccl_halo_allgather"] = {"ms_per_step": 1e3 * float(th.item()) / k, "steps": k, "collectives_per_cycle": dv2.n_collectives / (n_warm + k),
+                                               "residues_match_single_gpu": bool(np.allclose(warm, ref_res, rtol=1e-9)),
+                                               "what": "level 0 row-partitioned, levels >= 1 replicated; pack -> all_gather_into_tensor -> unpack per colour sweep (gravo_mg_amd/dist.py)"}
+        else:
+            variants["rccl_halo_allgather"] = {"ms_per_step": None, "reason": why or "another rank could not set the RCCL orchestration up"}
+
     load()
     t = time.perf_counter()
     hist = []
@@ -230,7 +264,11 @@ def main(args):
             "collectives_per_cycle": colls_per_cycle, "collective_backend": backend,
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
             "timed_residues_tail": [float(r) for r in residues[-3:]],
-            "roofline": roofline, "cpu_baseline": None,
+            "variants": variants,
+            "host_threads_per_rank": cabi.default_host_threads(),
+            "roofline": roofline,
+            "cpu_baseline": {"value": None, "unit": "ms per V-cycle (incl. residual check)", "cores": 1, "kind": "port",
+                             "see": "timed on rank 0 at N = 1 only (bench.py without --gpus, the driver's BENCH line of the same build): the 1-core oracle on the same workload"},
         }
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

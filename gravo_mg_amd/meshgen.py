@@ -24,7 +24,9 @@ def torus_mesh(n1: int, n2: int, R: float = 1.0, r: float = 0.4, jitter: float =
     The (u, v) parameters are jittered by `jitter` cell widths so that no two edges have identical
     length (the hierarchy's Dijkstra then has no exact ties).  Returns (V [n,3] float64, F [m,3] int32),
     area-normalised and centred like gravomg.util.normalize_area (gravomg_bindings/src/gravomg/util.py:52-55).
-    order: "natural" (row-major grid order, banded matrix) or "random" (worst-case permutation)."""
+    order: "natural" (row-major grid order, banded matrix), "random" (worst-case permutation) or "chunks" (runs of 65 536
+    consecutive vertices of the natural order, the runs themselves shuffled: local inside a run, far jumps at its borders --
+    an ordering with SOME locality, below the engine's reordering trigger of mean |row - column| > n / 32)."""
     rng = np.random.default_rng(seed)
     i, j = np.meshgrid(np.arange(n1), np.arange(n2), indexing="ij")
     u = (i + jitter * (rng.random((n1, n2)) - 0.5)) * (2 * np.pi / n1)
@@ -41,8 +43,13 @@ def torus_mesh(n1: int, n2: int, R: float = 1.0, r: float = 0.4, jitter: float =
         np.stack([idx.ravel(), ip.ravel(), ipjp.ravel()], axis=1),
         np.stack([idx.ravel(), ipjp.ravel(), jp.ravel()], axis=1),
     ]).astype(np.int32)
-    if order == "random":
-        perm = rng.permutation(V.shape[0])            # new -> old
+    if order in ("random", "chunks"):
+        if order == "random":
+            perm = rng.permutation(V.shape[0])            # new -> old
+        else:
+            run = 65536
+            starts = np.arange(0, V.shape[0], run)
+            perm = np.concatenate([np.arange(s0, min(s0 + run, V.shape[0])) for s0 in starts[rng.permutation(len(starts))]])
         inv = np.empty_like(perm)
         inv[perm] = np.arange(perm.shape[0])
         V = V[perm]
@@ -165,6 +172,39 @@ def bilaplacian(S, mass):
     B = (S @ sp.diags(1.0 / mass) @ S).tocsc()
     B.sort_indices()
     return B
+
+
+def open_cylinder_mesh(n1: int, n2: int, radius: float = 1.0, height: float = 2.0, jitter: float = 0.25, seed: int = 5):
+    """A surface WITH BOUNDARY: n1 (around, periodic) x n2 (along the axis, open at both ends) grid on a cylinder, two triangles
+    per quad.  The two rims are boundary loops (valence-4 rows with no Dirichlet condition: the cotangent Laplacian's natural
+    boundary), everything else is valence 6.  Area-normalised and centred like the torus meshes."""
+    rng = np.random.default_rng(seed)
+    i, j = np.meshgrid(np.arange(n1), np.arange(n2), indexing="ij")
+    u = (i + jitter * (rng.random((n1, n2)) - 0.5)) * (2 * np.pi / n1)
+    t = (j + jitter * (rng.random((n1, n2)) - 0.5) * ((j > 0) & (j < n2 - 1))) * (height / (n2 - 1))
+    V = np.stack([(radius * np.cos(u)).ravel(), (radius * np.sin(u)).ravel(), t.ravel()], axis=1)
+    ii, jj = np.meshgrid(np.arange(n1), np.arange(n2 - 1), indexing="ij")
+    a = (ii * n2 + jj).ravel(); b = (((ii + 1) % n1) * n2 + jj).ravel(); c = (((ii + 1) % n1) * n2 + jj + 1).ravel(); d = (ii * n2 + jj + 1).ravel()
+    F = np.concatenate([np.stack([a, b, c], axis=1), np.stack([a, c, d], axis=1)]).astype(np.int32)
+    return normalize_area(V, F), F
+
+
+def sheared_torus_mesh(n1: int, n2: int, shear: float = 2.5, **kw):
+    """A torus mesh with BADLY SHAPED triangles: the grid of torus_mesh with its quads split along the LONG diagonal of a sheared
+    parameter lattice, which makes every triangle obtuse (largest angle ~ atan-dependent on `shear`; 2.5 gives ~130 degrees).
+    Obtuse angles have negative cotangents, so the stiffness matrix S = -cotmatrix gets POSITIVE off-diagonal entries: it stays
+    symmetric positive semi-definite but is no longer an M-matrix -- the class for which over-relaxed and block-hybrid sweeps
+    have no textbook guarantee."""
+    V, F = torus_mesh(n1, n2, **kw)
+    # re-triangulate: vertex (i, j) connects to (i+1, j + s) instead of (i+1, j): a lattice sheared by s cells
+    s_cells = int(round(shear))
+    i, j = np.meshgrid(np.arange(n1), np.arange(n2), indexing="ij")
+    idx = (i * n2 + j).ravel()
+    right = (((i + 1) % n1) * n2 + (j + s_cells) % n2).ravel()
+    up = (i * n2 + (j + 1) % n2).ravel()
+    right_up = (((i + 1) % n1) * n2 + (j + s_cells + 1) % n2).ravel()
+    F2 = np.concatenate([np.stack([idx, right, right_up], axis=1), np.stack([idx, right_up, up], axis=1)]).astype(np.int32)
+    return normalize_area(V, F2), F2
 
 
 def sphere_mesh(n: int, seed: int = 3, order: str = "spatial"):

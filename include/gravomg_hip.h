@@ -106,6 +106,10 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out);
 void gmg_destroy(gmg_handle h);
 const char* gmg_last_error(gmg_handle h);
 /* Number of usable HIP devices (0 on a CPU-only box); never fails. */
+/* Host threads a handle uses unless gmg_config::host_threads says otherwise: the CPUs this PROCESS may use (hardware threads,
+ * affinity mask, cgroup v1/v2 quota; GMG_HOST_THREADS overrides) divided by LOCAL_WORLD_SIZE when one process per GPU shares a
+ * node -- worker pool, staging copies and the coarsest back-substitution's team are sized by it. */
+int gmg_host_threads(void);
 int gmg_device_count(void);
 
 /* ---- hierarchy input ------------------------------------------------------------------------ */

@@ -53,6 +53,23 @@ def test_iteration_counts_against_the_reference_algorithm(big, cabi, oracle):
         assert np.sqrt((m * (y - xo) ** 2).sum() / (m * xo ** 2).sum()) <= 20e-4
 
 
+def test_one_cycle_matches_the_model_at_full_size(big, oracle):
+    """Per-cycle parity AT FULL SIZE: one V-cycle of the default engine from x0 = rhs against the model of the same iteration
+    assembled from the oracle's operators and the device's orderings (tests/vcycle_model.py; ~20 oracle residuals at 3 M
+    vertices).  Same bounds as at 109 k vertices (tests/test_gpu_cycle_model.py): backward error <= 1e-12 ||A|| ||x||, forward
+    1e-6 (the Poisson operator's condition number is ~1/tau = 1e6 x that of the mesh)."""
+    import scipy.sparse.linalg as spla
+    from tests.vcycle_model import VcycleModel
+    eng, lhs, rhs, mass = big["eng"], big["lhs"], big["rhs"], big["mass"]
+    M = VcycleModel(eng, big["H"].U, mass, lhs, oracle, eng.gs_omega)
+    xg = eng.vcycle(rhs, rhs)
+    xm = M.vcycle(rhs, rhs.copy())
+    d = np.linalg.norm(xg - xm) / np.linalg.norm(xm)
+    assert np.linalg.norm(lhs @ (xg - xm)) <= 1e-12 * spla.norm(lhs) * np.linalg.norm(xm), d
+    assert d <= 1e-6, d
+    assert abs(eng.residual_norm(rhs, xg, 2) - oracle.residual_check(lhs, mass, rhs, xm, 2)) <= 1e-7
+
+
 def test_vcycle_is_affine_and_columns_do_not_interact(big):
     eng, rhs = big["eng"], big["rhs"]
     n = rhs.shape[0]
