@@ -52,14 +52,14 @@ int device_scan(gmg_handle h, const TIn* in, int n, TOut* out, TOut* total_host)
 // col16: write 16-bit columns into *col16_out (in-block part of a blocked level) instead of out.col.
 int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pend, const int* idx, const double* val, gmgs::RowFilter f,
                       const int* d_order, int n_rows_pad, int lpr, unsigned short** col16_out, double* d_diag, int* d_err, bool refill = false) {
+    auto fill = [&]() {
+        const dim3 grid((n_rows_pad + 255) / 256);
+        if (col16_out) hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, grid, dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
+        else hipLaunchKernelGGL(gmgs::sell_fill<int>, grid, dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad, out.slice_ptr, out.col, out.val, d_diag, d_err);
+    };
     if (refill) {        // same pattern as the matrix this layout was built from: slice pointers stand, entries are rewritten
         if (!out.slice_ptr || !out.val) return fail(h, GMG_ERR_STATE, "refill of a layout that was never built");
-        if (col16_out)
-            hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
-                               n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
-        else
-            hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
-                               out.slice_ptr, out.col, out.val, d_diag, d_err);
+        fill();
         return GMG_OK;
     }
     free_sell(out);
@@ -81,13 +81,8 @@ int device_build_sell(gmg_handle h, DevSell& out, const int* pbeg, const int* pe
     if (col16_out) {
         if (*col16_out) { (void)dev_free(*col16_out); *col16_out = nullptr; }
         HIPCHK(dev_malloc((void**)col16_out, std::max<int64_t>(out.stored, 1) * sizeof(unsigned short)));
-        hipLaunchKernelGGL(gmgs::sell_fill<unsigned short>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr,
-                           n_rows_pad, out.slice_ptr, *col16_out, out.val, d_diag, d_err);
-    } else {
-        HIPCHK(dev_malloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
-        hipLaunchKernelGGL(gmgs::sell_fill<int>, dim3((n_rows_pad + 255) / 256), dim3(256), 0, h->stream, pbeg, pend, idx, val, f, d_order, lpr, n_rows_pad,
-                           out.slice_ptr, out.col, out.val, d_diag, d_err);
-    }
+    } else HIPCHK(dev_malloc((void**)&out.col, std::max<int64_t>(out.stored, 1) * sizeof(int)));
+    fill();
     return GMG_OK;
 }
 
@@ -276,6 +271,17 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
     return GMG_OK;
 }
 
+// the block-CSR fills of a blocked level
+void launch_csr_fill_plain(gmg_handle h, Level& l, const DevCsr& dA, const gmgs::RowFilter& fe, const gmgs::RowFilter& fl, int* d_err) {
+    const dim3 gr((l.n_pad + 255) / 256);
+    hipLaunchKernelGGL(gmgs::csr_fill_plain<int>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fe, l.n_pad, l.ee_ptr, l.ee_col, l.ee_val, d_err);
+    hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fl, l.n_pad, l.ep_ptr, l.ep_col, l.ep_val, d_err);
+}
+void launch_csr_fill(gmg_handle h, Level& l, const DevCsr& dA, const gmgs::RowFilter& fout, const int* d_blk_of_row, int* d_err) {
+    const dim3 gr((l.n_pad + 255) / 256);
+    hipLaunchKernelGGL(gmgs::csr_fill, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, d_blk_of_row, l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
+}
+
 // Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device from Level::dA and the
 // device copies of U_k.  A row longer than gmgs::kMaxRow or a prolongation row with more than 3 entries raises *d_err:
 // the caller then falls back to the host planner.
@@ -347,9 +353,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
                 HIPCHK(dev_malloc((void**)&l.ee_val, sizeof(double) * (size_t)std::max(nnz_e, 1)));
                 HIPCHK(dev_malloc((void**)&l.ep_col, sizeof(unsigned short) * (size_t)std::max(nnz_l, 1)));
                 HIPCHK(dev_malloc((void**)&l.ep_val, sizeof(double) * (size_t)std::max(nnz_l, 1)));
-                hipLaunchKernelGGL(gmgs::csr_fill_plain<int>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fe, l.n_pad, l.ee_ptr, l.ee_col, l.ee_val, d_err);
-                hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fl, l.n_pad, l.ep_ptr, l.ep_col,
-                                   l.ep_val, d_err);
+                launch_csr_fill_plain(h, l, dA, fe, fl, d_err);
             } else {
                 (void)dev_free(l.ee_ptr); l.ee_ptr = nullptr;
                 (void)dev_free(l.ep_ptr); l.ep_ptr = nullptr;
@@ -375,8 +379,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
                 HIPCHK(dev_malloc((void**)&l.bc_mid, sizeof(int) * (size_t)l.n_pad));
                 HIPCHK(dev_malloc((void**)&l.bc_col, sizeof(int) * (size_t)std::max(nnz, 1)));
                 HIPCHK(dev_malloc((void**)&l.bc_val, sizeof(double) * (size_t)std::max(nnz, 1)));
-                hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, d_blk_of_row.p,
-                                   l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
+                launch_csr_fill(h, l, dA, fout, d_blk_of_row.p, d_err);
             } else { (void)dev_free(l.bc_ptr); l.bc_ptr = nullptr; }
         }
         if (!l.use_ep) {
@@ -455,14 +458,10 @@ int device_refill_level(gmg_handle h, int k, int* d_err) {
             gmgs::RowFilter fe{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 3, 1};
             gmgs::RowFilter fl{l.d_new2old, l.d_old2new, l.d_blk_of_row, l.d_blk_begin, 4, 1};
             const dim3 gr((l.n_pad + 255) / 256);
-            hipLaunchKernelGGL(gmgs::csr_fill_plain<int>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fe, l.n_pad, l.ee_ptr, l.ee_col, l.ee_val, d_err);
-            hipLaunchKernelGGL(gmgs::csr_fill_plain<unsigned short>, gr, dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fl, l.n_pad, l.ep_ptr, l.ep_col, l.ep_val,
-                               d_err);
+            launch_csr_fill_plain(h, l, dA, fe, fl, d_err);
             return GMG_OK;
         }
-        if (l.use_bcsr)
-            hipLaunchKernelGGL(gmgs::csr_fill, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, l.d_blk_of_row,
-                               l.d_blk_begin, l.n_pad, l.bc_ptr, l.bc_mid, l.bc_col, l.bc_val, d_err);
+        if (l.use_bcsr) launch_csr_fill(h, l, dA, fout, l.d_blk_of_row, d_err);
         if ((rc = device_build_sell(h, l.Ain, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fin, nullptr, l.n_pad, l.Ain.lpr, &l.ain_col16, nullptr, d_err, true)) ||
             (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
     }

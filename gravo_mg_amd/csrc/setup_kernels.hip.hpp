@@ -10,7 +10,7 @@
 
 namespace gmgs {
 
-constexpr int kMaxRow = 96;          // longest row the device builder sorts in private memory (host fallback beyond)
+constexpr int kMaxRow = 96;          // longest row (kept entries) the device builder takes: host planner beyond
 
 // mode: 0 = every entry, 1 = only entries whose column lies in the row's block, 2 = only entries leaving the block,
 // 3 = "explicit" part of the unpadded block sweep (entries leaving the block + in-block entries with a LATER device column),
@@ -62,111 +62,188 @@ __global__ void slice_widths(const int* __restrict__ len, int lpr, int n_slices,
     widths[s] = (int64_t)w * 64;
 }
 
-// One thread per slice row position: gather the kept entries, sort them by device column, write them (and the
-// padding) into the slice.  diag (optional) receives the dropped diagonal entry (1.0 for padding rows).
+// ---- a row's kept entries, in device-column order ---------------------------------------------------------------------------
+// The fill kernels below give one thread a row: gather the kept entries, put them in device-column order, write them out.  The
+// first version kept them in a private array of kMaxRow entries and insertion-sorted it: 1 152 bytes of scratch per thread that
+// no cache holds for 3 M threads -- `sell_fill` moved 5.2 GB for a 252 MB matrix (rocprofv3 FETCH_SIZE / WRITE_SIZE,
+// profiles/r02).  Now nothing is sorted and nothing leaves the registers: pass 1 collects the kept DEVICE COLUMNS of the row in
+// RowCols<CAP> (append = a chain of selects with compile-time indices: no dynamic register indexing, so no scratch); pass 2 walks
+// the row again (its index / map entries are in the cache) and writes every kept entry straight to its place, its RANK = the number
+// of collected columns smaller than its own (CAP compares, unrolled).  CAP in {8, 32, 96} is chosen per WAVEFRONT by its longest
+// stored row (wave-uniform branch).  Same entries at the same places as before: the output is bit-identical.
+template <int CAP>
+struct RowCols {
+    int c[CAP];
+    int n;
+};
+
+template <int CAP>
+__device__ __forceinline__ void cols_append(RowCols<CAP>& R, int col) {
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) R.c[j] = R.n == j ? col : R.c[j];
+    ++R.n;
+}
+
+// pass 1: the kept device columns of natural row `old` (device row r); dg / has_diag: the dropped diagonal entry.  false (and the
+// error flag) when the row keeps more than CAP entries (CAP = kMaxRow only: the caller picked CAP >= the stored length otherwise).
+template <int CAP>
+__device__ __forceinline__ bool cols_gather(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
+                                            const double* __restrict__ val, const RowFilter& f, int r, int old, RowCols<CAP>& R, double& dg,
+                                            bool& has_diag, int* __restrict__ err_flag) {
+    R.n = 0;
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) R.c[j] = 0x7fffffff;        // unused slots: larger than every column, never counted by a rank
+    if (old < 0) return true;
+    for (int p = pbeg[old]; p < pend[old]; ++p) {
+        const int oc = idx[p];
+        if (f.drop_diag && oc == old) { dg = val[p]; has_diag = true; continue; }
+        int c;
+        if (!keep_entry(f, r, old, oc, c)) continue;
+        if (R.n >= CAP) { atomicExch(err_flag, 1); return false; }
+        cols_append<CAP>(R, c);
+    }
+    return true;
+}
+
+template <int CAP>
+__device__ __forceinline__ int cols_rank(const RowCols<CAP>& R, int col) {
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) k += R.c[j] < col ? 1 : 0;
+    return k;
+}
+
+// longest stored row of the wavefront (an upper bound of the kept entries): picks the register capacity
+__device__ __forceinline__ int wave_max_raw_len(const int* __restrict__ pbeg, const int* __restrict__ pend, int old) {
+    int len = old >= 0 ? pend[old] - pbeg[old] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, 64));
+    return len;
+}
+
+// One thread per slice row position: the kept entries in device-column order into the slice, padding behind them.
+// diag (optional) receives the dropped diagonal entry (1.0 for padding rows).
+template <class ColT, int CAP>
+__device__ __forceinline__ void sell_fill_row(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
+                                              const double* __restrict__ val, const RowFilter& f, int lpr, int r, int old, int s, int l,
+                                              const int64_t* __restrict__ slice_ptr, ColT* __restrict__ col, double* __restrict__ out_val,
+                                              double* __restrict__ diag, int* __restrict__ err_flag) {
+    RowCols<CAP> R;
+    double dg = 1.0;
+    bool has_diag = old < 0;
+    const bool ok = cols_gather<CAP>(pbeg, pend, idx, val, f, r, old, R, dg, has_diag, err_flag);
+    if (diag) {
+        if (ok && f.drop_diag && (!has_diag || dg == 0.0)) atomicExch(err_flag, 2);      // missing / zero diagonal
+        diag[r] = dg;
+    }
+    const int64_t base = slice_ptr[s];
+    const int w = (int)((slice_ptr[s + 1] - base) >> 6);
+    auto at = [&](int e) { return base + (int64_t)(e / lpr) * 64 + l * lpr + (e % lpr); };
+    if (old >= 0 && ok)
+        for (int p = pbeg[old]; p < pend[old]; ++p) {
+            const int oc = idx[p];
+            if (f.drop_diag && oc == old) continue;
+            int c;
+            if (!keep_entry(f, r, old, oc, c)) continue;
+            const int64_t q = at(cols_rank<CAP>(R, c));
+            col[q] = (ColT)c; out_val[q] = val[p];
+        }
+    for (int e = ok ? R.n : 0; e < w * lpr; ++e) { const int64_t q = at(e); col[q] = (ColT)0; out_val[q] = 0.0; }
+}
+
 template <class ColT>
 __global__ void sell_fill(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
                           const double* __restrict__ val, RowFilter f,
                           const int* __restrict__ order, int lpr, int n_rows_pad, const int64_t* __restrict__ slice_ptr,
                           ColT* __restrict__ col, double* __restrict__ out_val, double* __restrict__ diag, int* __restrict__ err_flag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_rows_pad) return;
+    const bool live = i < n_rows_pad;
     const int rps = 64 / lpr;
-    const int s = i / rps, l = i % rps;
-    const int r = order ? order[i] : i;
-    const int old = f.new2old_row[r];
-    int cs[kMaxRow];
-    double vs[kMaxRow];
-    int n = 0;
-    double dg = 1.0;
-    bool has_diag = old < 0;
-    if (old >= 0) {
-        for (int p = pbeg[old]; p < pend[old]; ++p) {
-            const int oc = idx[p];
-            if (f.drop_diag && oc == old) { dg = val[p]; has_diag = true; continue; }
-            int c;
-            if (!keep_entry(f, r, old, oc, c)) continue;
-            if (n >= kMaxRow) { atomicExch(err_flag, 1); break; }
-            // insertion sort by device column (rows are short; stable, deterministic)
-            int q = n;
-            const double v = val[p];
-            while (q > 0 && cs[q - 1] > c) { cs[q] = cs[q - 1]; vs[q] = vs[q - 1]; --q; }
-            cs[q] = c; vs[q] = v;
-            ++n;
-        }
-    }
-    if (diag) {
-        if (f.drop_diag && (!has_diag || dg == 0.0)) atomicExch(err_flag, 2);      // missing / zero diagonal
-        diag[r] = dg;
-    }
-    const int64_t base = slice_ptr[s];
-    const int w = (int)((slice_ptr[s + 1] - base) >> 6);
-    for (int e = 0; e < w * lpr; ++e) {
-        const int64_t q = base + (int64_t)(e / lpr) * 64 + l * lpr + (e % lpr);
-        if (e < n) { col[q] = (ColT)cs[e]; out_val[q] = vs[e]; }
-        else { col[q] = (ColT)0; out_val[q] = 0.0; }
-    }
+    const int s = live ? i / rps : 0, l = live ? i % rps : 0;
+    const int r = live ? (order ? order[i] : i) : 0;
+    const int old = live ? f.new2old_row[r] : -1;
+    const int wmax = wave_max_raw_len(pbeg, pend, old);          // (all lanes take part in the shuffles)
+    if (!live) return;
+    if (wmax <= 8) sell_fill_row<ColT, 8>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag);
+    else if (wmax <= 32) sell_fill_row<ColT, 32>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag);
+    else sell_fill_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag);
 }
 
 // Block-CSR of a big blocked level (kernels.hip.hpp::gs_blockcsr): off-diagonal entries of device row r at
 // [row_ptr[r], row_ptr[r + 1]), device column numbers, the entries that leave the row's block first (ascending column),
 // then the in-block ones (ascending column) from row_mid[r] on.  row_ptr comes from row_lengths (mode 0) + a prefix sum.
+template <int CAP>
+__device__ __forceinline__ void csr_fill_row(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
+                                             const double* __restrict__ val, const RowFilter& f, int r, int old, int r0, int r1,
+                                             const int* __restrict__ row_ptr, int* __restrict__ row_mid, int* __restrict__ col,
+                                             double* __restrict__ out_val, int* __restrict__ err_flag) {
+    RowCols<CAP> R;
+    double dg = 1.0; bool hd = false;
+    const int q0 = row_ptr[r];
+    if (!cols_gather<CAP>(pbeg, pend, idx, val, f, r, old, R, dg, hd, err_flag)) { row_mid[r] = q0; return; }
+    int n_out = 0;                                              // entries that leave the block: they come first
+#pragma unroll
+    for (int j = 0; j < CAP; ++j) n_out += (j < R.n && (R.c[j] < r0 || R.c[j] >= r1)) ? 1 : 0;
+    row_mid[r] = q0 + n_out;
+    if (old < 0) return;
+    for (int p = pbeg[old]; p < pend[old]; ++p) {
+        int c;
+        if (!keep_entry(f, r, old, idx[p], c)) continue;
+        const bool inside = c >= r0 && c < r1;
+        int k = 0;                                              // rank among the entries of its own group
+#pragma unroll
+        for (int j = 0; j < CAP; ++j) k += (R.c[j] < c && ((R.c[j] >= r0 && R.c[j] < r1) == inside)) ? 1 : 0;
+        const int q = q0 + (inside ? n_out : 0) + k;
+        col[q] = c; out_val[q] = val[p];
+    }
+}
+
 __global__ void csr_fill(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx, const double* __restrict__ val,
                          RowFilter f, const int* __restrict__ blk_of_row, const int* __restrict__ blk_begin, int n_rows_pad,
                          const int* __restrict__ row_ptr, int* __restrict__ row_mid, int* __restrict__ col, double* __restrict__ out_val,
                          int* __restrict__ err_flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows_pad) return;
-    const int old = f.new2old_row[r];
-    int cs[kMaxRow];
-    double vs[kMaxRow];
-    int n = 0;
-    if (old >= 0) {
-        for (int p = pbeg[old]; p < pend[old]; ++p) {
-            const int oc = idx[p];
-            int c;
-            if (!keep_entry(f, r, old, oc, c)) continue;
-            if (n >= kMaxRow) { atomicExch(err_flag, 1); break; }
-            int q = n;
-            const double v = val[p];
-            while (q > 0 && cs[q - 1] > c) { cs[q] = cs[q - 1]; vs[q] = vs[q - 1]; --q; }
-            cs[q] = c; vs[q] = v;
-            ++n;
-        }
-    }
+    const bool live = r < n_rows_pad;
+    const int old = live ? f.new2old_row[r] : -1;
+    const int wmax = wave_max_raw_len(pbeg, pend, old);
+    if (!live) return;
     const int b = blk_of_row[r];
     const int r0 = blk_begin[b], r1 = blk_begin[b + 1];
-    int q = row_ptr[r];
-    for (int e = 0; e < n; ++e) if (cs[e] < r0 || cs[e] >= r1) { col[q] = cs[e]; out_val[q] = vs[e]; ++q; }
-    row_mid[r] = q;
-    for (int e = 0; e < n; ++e) if (cs[e] >= r0 && cs[e] < r1) { col[q] = cs[e]; out_val[q] = vs[e]; ++q; }
+    if (wmax <= 8) csr_fill_row<8>(pbeg, pend, idx, val, f, r, old, r0, r1, row_ptr, row_mid, col, out_val, err_flag);
+    else if (wmax <= 32) csr_fill_row<32>(pbeg, pend, idx, val, f, r, old, r0, r1, row_ptr, row_mid, col, out_val, err_flag);
+    else csr_fill_row<kMaxRow>(pbeg, pend, idx, val, f, r, old, r0, r1, row_ptr, row_mid, col, out_val, err_flag);
 }
 
 // Plain block-ordered CSR of the entries the filter keeps (the in-block operator of the entry-parallel sweep, 16-bit local
 // columns): row r's kept entries, ascending column, at [row_ptr[r], row_ptr[r + 1]).
+template <class ColT, int CAP>
+__device__ __forceinline__ void csr_fill_plain_row(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
+                                                   const double* __restrict__ val, const RowFilter& f, int r, int old, const int* __restrict__ row_ptr,
+                                                   ColT* __restrict__ col, double* __restrict__ out_val, int* __restrict__ err_flag) {
+    RowCols<CAP> R;
+    double dg = 1.0; bool hd = false;
+    if (!cols_gather<CAP>(pbeg, pend, idx, val, f, r, old, R, dg, hd, err_flag)) return;
+    const int q0 = row_ptr[r];
+    for (int p = pbeg[old]; p < pend[old]; ++p) {
+        int c;
+        if (!keep_entry(f, r, old, idx[p], c)) continue;
+        const int q = q0 + cols_rank<CAP>(R, c);
+        col[q] = (ColT)c; out_val[q] = val[p];
+    }
+}
+
 template <class ColT>
 __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx, const double* __restrict__ val,
                                RowFilter f, int n_rows_pad, const int* __restrict__ row_ptr, ColT* __restrict__ col, double* __restrict__ out_val,
                                int* __restrict__ err_flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows_pad) return;
-    const int old = f.new2old_row[r];
-    if (old < 0) return;
-    int cs[kMaxRow];
-    double vs[kMaxRow];
-    int n = 0;
-    for (int p = pbeg[old]; p < pend[old]; ++p) {
-        int c;
-        if (!keep_entry(f, r, old, idx[p], c)) continue;
-        if (n >= kMaxRow) { atomicExch(err_flag, 1); break; }
-        int q = n;
-        const double v = val[p];
-        while (q > 0 && cs[q - 1] > c) { cs[q] = cs[q - 1]; vs[q] = vs[q - 1]; --q; }
-        cs[q] = c; vs[q] = v;
-        ++n;
-    }
-    int q = row_ptr[r];
-    for (int e = 0; e < n; ++e, ++q) { col[q] = (ColT)cs[e]; out_val[q] = vs[e]; }
+    const bool live = r < n_rows_pad;
+    const int old = live ? f.new2old_row[r] : -1;
+    const int wmax = wave_max_raw_len(pbeg, pend, old);
+    if (!live || old < 0) return;
+    if (wmax <= 8) csr_fill_plain_row<ColT, 8>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
+    else if (wmax <= 32) csr_fill_plain_row<ColT, 32>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
+    else csr_fill_plain_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
 }
 
 // max over the blocks of their entry count (LDS capacity the sweep kernel needs)
@@ -477,8 +554,8 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
     // are first gathered IN PARALLEL into LDS as (q, (u_ip a_ij) * u_jq) in the host's walk order -- slot of (child,
     // entry, s) = 3 * (entries of the earlier children + entry) + s -- then every lane runs down the list once and adds
     // the products of its columns: the same additions in the same order as the host, at LDS-broadcast cost.
-    __shared__ int sq[kRapSlots];
-    __shared__ double sv[kRapSlots];
+    __shared__ __attribute__((aligned(16))) int sq[kRapSlots];
+    __shared__ __attribute__((aligned(16))) double sv[kRapSlots];
     __shared__ int c_incl[64], c_beg[64];
     __shared__ double c_uip[64];
     const int out0 = c_ptr[p];
@@ -534,9 +611,20 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
         __syncthreads();
         const int slots = 3 * pairs;
         if (groups == 1) {
+            // (four slots per step through 128-bit LDS reads; the additions stay one after the other in slot order)
             double a0 = acc[0];
             const int m0 = mine[0];
-            for (int x = 0; x < slots; ++x) if (sq[x] == m0) a0 = a0 + sv[x];
+            int x = 0;
+            for (; x + 4 <= slots; x += 4) {
+                const int4 q4 = *reinterpret_cast<const int4*>(&sq[x]);
+                const double2 v01 = *reinterpret_cast<const double2*>(&sv[x]);
+                const double2 v23 = *reinterpret_cast<const double2*>(&sv[x + 2]);
+                if (q4.x == m0) a0 = a0 + v01.x;
+                if (q4.y == m0) a0 = a0 + v01.y;
+                if (q4.z == m0) a0 = a0 + v23.x;
+                if (q4.w == m0) a0 = a0 + v23.y;
+            }
+            for (; x < slots; ++x) if (sq[x] == m0) a0 = a0 + sv[x];
             acc[0] = a0;
         } else {
             for (int x = 0; x < slots; ++x) {
