@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--n1", type=int, default=1732)
     ap.add_argument("--n2", type=int, default=1732)
     ap.add_argument("--order", default="natural", choices=["natural", "random", "chunks"])
-    ap.add_argument("--config", default=None, choices=["1", "2", "3", "4", "4r", "5", "5b", "6"],
+    ap.add_argument("--config", default=None, choices=["1", "2", "3", "4", "4r", "4s", "5", "5b", "6"],
                     help="profiling aid: another BASELINE config (meshgen.baseline_config) as the main workload instead of the torus --n1 x --n2")
     ap.add_argument("--cpu-cycles", type=int, default=25, help="V-cycles timed on the CPU oracle (0 = skip)")
     ap.add_argument("--coarse", default="host", choices=["host", "device"])

@@ -1705,6 +1705,7 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, xb.data(), (size_t)n, 1, w.data());
             best = std::min(best, 1e3 * ms_since(t0) / reps);
         }
+        std::fprintf(stderr, "[gmg ldlt] factorisation: ordering %.2f ms, symbolic %.2f ms, numeric %.2f ms\n", f.phase_ms[0], f.phase_ms[1], f.phase_ms[2]);
         long part[3];
         f.split_report(part);
         std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread (best of 20 batches of %d); %d parts of the elimination "

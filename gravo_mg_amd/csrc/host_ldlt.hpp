@@ -468,16 +468,25 @@ public:
     bool ok = false;
     std::vector<int> perm;              // new -> old
 
+    double phase_ms[3] = {0, 0, 0};     // ordering / symbolic / numeric of the last factor() (measurement aid)
     bool factor(const Compressed& A, bool reuse_perm = false) {
+        using clk = std::chrono::steady_clock;
+        auto ms = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
         ok = false;
+        phase_ms[0] = phase_ms[1] = 0.0;
         if (!(reuse_perm && n == A.n_outer && (int)perm.size() == n && symbolic_ready_)) {
+            auto t0 = clk::now();
             SparseLDLT ord;
             ord.compute_ordering(A);
             perm = ord.perm;
             n = A.n_outer;
+            phase_ms[0] = ms(t0); t0 = clk::now();
             symbolic(A);
+            phase_ms[1] = ms(t0);
         }
+        auto t1 = clk::now();
         numeric(A);
+        phase_ms[2] = ms(t1);
         return ok;
     }
 
@@ -512,9 +521,17 @@ public:
         const size_t nt = scratch_doubles();
         if (scratch_.size() < nt * (size_t)d) scratch_.resize(nt * (size_t)d, 0.0);
         if (d == 1) { solve_column(b, x, work, scratch_.data(), helper); return; }
-        parallel_ranges(d, d, [&](int c0, int c1, int) {
-            for (int c = c0; c < c1; ++c) solve_column(b + (size_t)c * ldb, x + (size_t)c * ldx, work + (size_t)c * n, scratch_.data() + nt * c, nullptr);
-        }, 2);
+        // several columns: one job per column.  With an armed team (inside a V-cycle solve) the columns go to its spinning threads -- a
+        // hand-over costs a cache line, where waking worker-pool threads costs tens of microseconds per solve (d = 3 at n = 1929:
+        // 125 us per cycle through the pool); otherwise through the worker pool.  Each column is the one-thread solve either way.
+        struct ColJob { const SupernodalLDLT* self; const double* b; size_t ldb; double* x; size_t ldx; double* work; double* scratch; size_t nt; };
+        ColJob job{this, b, ldb, x, ldx, work, scratch_.data(), nt};
+        auto run = [](void* p, int c) {
+            const ColJob* j = (const ColJob*)p;
+            j->self->solve_column(j->b + (size_t)c * j->ldb, j->x + (size_t)c * j->ldx, j->work + (size_t)c * j->self->n, j->scratch + j->nt * (size_t)c, nullptr);
+        };
+        if (helper && helper->armed()) { helper->run(run, &job, d); return; }
+        parallel_ranges(d, d, [&](int c0, int c1, int) { for (int c = c0; c < c1; ++c) run(&job, c); }, 2);
     }
 
     // share of the factor (panel entries) in the lightest / the heaviest part of the elimination tree / in the part above them

@@ -53,7 +53,10 @@ __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const 
 // acc[c] = sum_j val[j] * x[col[j] + c*ld] over this lane's row of slice s.  The slice width is wave-uniform, so
 // the dispatch on it is a scalar branch: full groups of 8, then one width-specialised tail (no serialized
 // remainder loop -- with 6-7 entries per mesh row and 3 per prolongation row the tail IS the row).
-template <class T, int D, int G = 8>
+// (G entries per group: 8 with one or two right-hand sides; 4 with three or four -- 8 x D gathered values in flight cost 100 VGPRs
+// at D = 3, i.e. 4 wavefronts per SIMD instead of 8)
+template <int D> struct DotGroup { static constexpr int value = D >= 3 ? 4 : 8; };
+template <class T, int D, int G = DotGroup<D>::value>
 __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                         const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                         T (&acc)[D]) {
@@ -549,27 +552,33 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
             T s_[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) s_[c] = (T)0.0;
-            {
-                T xv[8][D];
+            // (gathers of a chunk in flight together; chunks of 8 entries with one right-hand side, of 4 with more: registers)
+            constexpr int CH = D == 1 ? 8 : 4;
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+            for (int j0 = 0; j0 < 8; j0 += CH) {
+                T xv[CH][D];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + GMG_EP_COL(j)];
+                for (int j = 0; j < CH; ++j)
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + GMG_EP_COL(j0 + j)];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) s_[c] += v[j] * xv[j][c];
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
             }
             if (wide) {
-                T xv[kEpW - 8][D];
 #pragma unroll
-                for (int j = 8; j < kEpW; ++j)
+                for (int j0 = 8; j0 < kEpW; j0 += CH) {
+                    T xv[CH][D];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) xv[j - 8][c] = xs[c * 64 + GMG_EP_COL(j)];
+                    for (int j = 0; j < CH; ++j)
 #pragma unroll
-                for (int j = 8; j < kEpW; ++j)
+                        for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + GMG_EP_COL(j0 + j)];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) s_[c] += v[j] * xv[j - 8][c];
+                    for (int j = 0; j < CH; ++j)
+#pragma unroll
+                        for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
+                }
                 for (int j = kEpW; j < nlow; ++j) {                   // rows with more lower entries than the register window (rare)
                     const T vj = sval[lb + j];
                     const int cc = scol[lb + j];

@@ -259,6 +259,11 @@ def baseline_config(cfg: str):
         S, mass = cotan_laplacian(V, F)
         lhs, rhs = poisson_system(S, mass)
         return f"cfg4 torus 1732x1732 Poisson d=1 ({'random' if cfg == '4r' else 'natural'} vertex order)", V, S, mass, lhs, rhs
+    if cfg == "4s":     # the reference's real call pattern at the headline size: smoothing M + 1e-3 S, rhs = M V (n x 3), on the 3 M mesh
+        V, F = torus_mesh(1732, 1732)
+        S, mass = cotan_laplacian(V, F)
+        lhs, rhs = smoothing_system(S, mass, V)
+        return "cfg4s torus 1732x1732 smoothing d=3", V, S, mass, lhs, rhs
     if cfg in ("5", "5b"):   # Bilaplacian data smoothing M + tau S M^-1 S on the ~3 M mesh (mixed precision: fp32 inner V-cycle)
         tau = 1e-3 if cfg == "5" else 1e-9
         V, F = torus_mesh(1732, 1732)
