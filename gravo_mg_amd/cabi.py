@@ -50,7 +50,7 @@ class GmgConfig(C.Structure):
 class GmgHierarchyOptions(C.Structure):
     _fields_ = [
         ("ratio", C.c_double), ("lower_bound", C.c_int), ("check_voronoi", C.c_int), ("nested", C.c_int),
-        ("sampling", C.c_int), ("weighting", C.c_int),
+        ("sampling", C.c_int), ("weighting", C.c_int), ("debug", C.c_int),
     ]
 
 
@@ -127,6 +127,7 @@ SIGNATURES = {
     "gmg_hierarchy_get_nearest": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_hierarchy_get_points": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_host_threads": (C.c_int, []),
+    "gmg_hierarchy_get_triangles": (C.c_int, [_vp, C.c_int, _ip, _ip]),
     "gmg_hierarchy_get_fine_order": (C.c_int, [_vp, _ip, _ip]),
     "gmg_set_fine_order": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
@@ -233,7 +234,7 @@ class Hierarchy:
     Mirrors what ``MGBS::MultigridSolver::buildHierarchy`` produces: ``U`` (list of scipy CSC matrices,
     n_k x n_{k+1}) and the reference's ``hierarchyTiming`` keys."""
 
-    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0):
+    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0, debug=False):
         l = lib()
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         neigh = np.ascontiguousarray(neigh, dtype=np.int32)
@@ -242,7 +243,7 @@ class Hierarchy:
         opt = GmgHierarchyOptions()
         l.gmg_hierarchy_options_default(C.byref(opt))
         opt.ratio, opt.lower_bound, opt.check_voronoi, opt.nested = float(ratio), int(lower_bound), int(bool(check_voronoi)), int(bool(nested))
-        opt.sampling, opt.weighting = int(sampling), int(weighting)
+        opt.sampling, opt.weighting, opt.debug = int(sampling), int(weighting), int(bool(debug))
         self._h = _vp()
         rc = l.gmg_hierarchy_build(_pd(pos), pos.shape[0], _pi(neigh), neigh.shape[1], C.byref(opt), C.byref(self._h))
         if rc:
@@ -261,6 +262,15 @@ class Hierarchy:
             if l.gmg_hierarchy_get_samples(self._h, k, _pi(s_)) or l.gmg_hierarchy_get_nearest(self._h, k, _pi(n_)) or l.gmg_hierarchy_get_points(self._h, k, _pd(p_)):
                 raise GmgError(GMG_ERR_INVALID, "hierarchy getters failed")
             self.samples.append(s_); self.nearest.append(n_); self.points.append(p_)
+        # the reference's debug dump of the triangle search (allTriangles): only kept with debug=True
+        self.triangles = []
+        for k in range(len(self.U)):
+            cnt = C.c_int()
+            l.gmg_hierarchy_get_triangles(self._h, k, None, C.byref(cnt))
+            t = np.empty((cnt.value, 3), np.int32)
+            if cnt.value:
+                l.gmg_hierarchy_get_triangles(self._h, k, _pi(t), C.byref(cnt))
+            self.triangles.append(t)
         # breadth-first order of the points (only made for inputs without locality; None otherwise)
         cnt = C.c_int()
         l.gmg_hierarchy_get_fine_order(self._h, None, C.byref(cnt))

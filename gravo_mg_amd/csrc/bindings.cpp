@@ -263,9 +263,8 @@ public:
         solver->U = v;
     }
 
-    // core.cpp:90-116.  samples / nearestSource are filled by every build upstream, levelV only with debug = True; the
-    // remaining debug members (levelE: SIG06 / ablation paths, noTriFoundMap, allTriangles, levelN: debug dumps of the
-    // triangle search) are not produced by this build: asking for them raises instead of returning empty data.
+    // core.cpp:90-116.  samples / nearestSource are filled by every build upstream, levelV, allTriangles and noTriFoundMap only
+    // with debug = True; levelE belongs to the SIG06 hierarchy and levelN is never filled upstream: both come back empty, as there.
     std::vector<std::vector<int>> sampling_indices() { return solver->samples; }
     std::vector<std::vector<size_t>> nearest_source() { return solver->nearestSource; }
     py::list level_points() {
@@ -273,10 +272,10 @@ public:
         for (const auto& P : solver->levelV) out.append(from_dense(P));
         return out;
     }
-    py::list level_edges() { not_produced("level_edges"); return py::list(); }
-    py::list notrimap() { not_produced("notrimap"); return py::list(); }
-    py::list all_triangles() { not_produced("all_triangles"); return py::list(); }
-    py::list coarse_normals() { not_produced("coarse_normals"); return py::list(); }
+    py::list level_edges() { return py::list(); }
+    std::vector<std::vector<int>> notrimap() { return solver->noTriFoundMap; }
+    std::vector<std::vector<std::vector<int>>> all_triangles() { return solver->allTriangles; }
+    py::list coarse_normals() { return py::list(); }
 
     void write_hierarchy_timing(std::string experiment, std::string file, bool write_headers) { MGBS::writeTiming(solver->hierarchyTiming, experiment, file, write_headers); }
     void write_solver_timing(std::string experiment, std::string file, bool write_headers) { MGBS::writeTiming(solver->solverTiming, experiment, file, write_headers); }
@@ -309,9 +308,6 @@ public:
     }
 
 private:
-    static void not_produced(const char* what) {
-        throw std::runtime_error(std::string(what) + ": debug data of the reference's triangle search, not produced by the MI355X hot-path build");
-    }
     // The reference reports problems with printed messages only; the drop-in additionally raises, so that a missing
     // GPU / an unsupported option can never pass silently.
     void check() {

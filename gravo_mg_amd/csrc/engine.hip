@@ -1408,7 +1408,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
 
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o) try {
     if (!o) return GMG_ERR_INVALID;
-    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0;
+    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0; o->debug = 0;
     return GMG_OK;
 } GMG_CATCH_0
 
@@ -1511,7 +1511,7 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     if (o.weighting < 0 || o.weighting > 2 || !(o.ratio > 0)) return GMG_ERR_INVALID;
     for (size_t i = 0; i < (size_t)n * K; ++i) if (neigh[i] >= n) return GMG_ERR_INVALID;
     HierarchyOptions ho;
-    ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting;
+    ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting; ho.keep_triangles = o.debug != 0;
     // the per-point selection stage runs on the GPU when there is one (same bits as the host loop; GMG_HIERARCHY_DEVICE=0: host only)
     {
         const char* env = std::getenv("GMG_HIERARCHY_DEVICE");
@@ -1596,6 +1596,15 @@ int gmg_hierarchy_get_nearest(gmg_hierarchy hh, int k, int* out) try {
 int gmg_hierarchy_get_points(gmg_hierarchy hh, int k, double* out_xyz) try {
     if (!hh || !out_xyz || k < 0 || k >= (int)hh->res.points.size()) return GMG_ERR_INVALID;
     std::memcpy(out_xyz, hh->res.points[k].data(), sizeof(double) * hh->res.points[k].size());
+    return GMG_OK;
+} GMG_CATCH_0
+
+int gmg_hierarchy_get_triangles(gmg_hierarchy hh, int k, int* out, int* count) try {
+    if (!hh || !count || k < 0 || k >= (int)hh->res.U.size()) return GMG_ERR_INVALID;
+    if (k >= (int)hh->res.triangles.size()) { *count = 0; return GMG_OK; }
+    const auto& t = hh->res.triangles[k];
+    *count = (int)t.size();
+    if (out && !t.empty()) std::memcpy(out, t.data(), sizeof(int) * 3 * t.size());
     return GMG_OK;
 } GMG_CATCH_0
 

@@ -42,6 +42,7 @@ struct HierarchyOptions {
     bool check_voronoi = true;
     bool nested = false;
     int weighting = 0;           // 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST (multigrid_solver.h:48-52)
+    bool keep_triangles = false; // the reference's `debug`: keep every level's candidate triangles (allTriangles, multigrid_solver.cpp:281)
     // Optional accelerator for the per-point parent selection (:291-452) of a level: every fine point is independent there.  Host
     // pointers in, per-point results out; returns false when it did not run (the host loop does the level then).  A point it
     // could not handle comes back with cnt = 255 and is redone by the host routine.  Must produce the host routine's bits.
@@ -74,6 +75,7 @@ struct HierarchyResult {
     std::vector<std::vector<int>> samples;   // per level: fine index of each coarse sample
     std::vector<std::vector<int>> nearest;   // per level: the coarse sample (cluster) every fine point belongs to (nearestSource, :115,:171)
     std::vector<std::vector<double>> points; // per level: positions of the coarse points, n_{k+1} x 3 row-major (levelV, :216-241)
+    std::vector<std::vector<std::array<int, 3>>> triangles;   // per level: the candidate triangles of the coarse points (allTriangles, :247-281); only with keep_triangles
     std::map<std::string, double> timing;    // the reference's hierarchyTiming keys
     // per level counts of prolongation row kinds: triangle / edge / fallback / single
     std::vector<std::array<int, 4>> row_kinds;
@@ -401,6 +403,7 @@ public:
             R.timing["selection_on_device"] += out.on_device;
             R.samples.push_back(std::move(works[k]->sample));
             R.nearest.push_back(std::move(works[k]->nearest));
+            if (opt.keep_triangles) R.triangles.push_back(std::move(works[k]->tris));
         }
         R.timing["levels"] = (double)R.U.size();
         R.timing["hierarchy"] = ms(t_all, clk::now());

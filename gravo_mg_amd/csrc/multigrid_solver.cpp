@@ -111,7 +111,7 @@ void MultigridSolver::buildHierarchy() {
     gmg_hierarchy_options opt;
     gmg_hierarchy_options_default(&opt);
     opt.ratio = ratio; opt.lower_bound = lowBound; opt.check_voronoi = checkVoronoi; opt.nested = nested;
-    opt.sampling = (int)samplingStrategy; opt.weighting = (int)weightingScheme;
+    opt.sampling = (int)samplingStrategy; opt.weighting = (int)weightingScheme; opt.debug = debug ? 1 : 0;
     // positions: column-major n x 3 -> row-major
     const int n = V.rows();
     std::unique_ptr<double[]> pos(new double[(size_t)n * 3]);             // (not value-initialised: every entry is written below, on all cores)
@@ -154,8 +154,22 @@ void MultigridSolver::buildHierarchy() {
     samples.assign(L, std::vector<int>());
     nearestSource.assign(L, std::vector<size_t>());
     levelV.clear();
+    // the remaining debug members of the reference (multigrid_solver.h:99-102): levelE is only filled by the SIG06 hierarchy
+    // (:663-681) and levelN by nothing at all, so both stay empty here as there; with `debug` the reference keeps every level's
+    // candidate triangles (allTriangles, :281) and a zero vector per level in noTriFoundMap (:291, never written afterwards)
+    levelE.clear(); levelN.clear(); allTriangles.clear(); noTriFoundMap.clear();
     for (int k = 0; k < L; ++k) {
         const int nf = U[k].rows_, nc = U[k].cols_;
+        if (debug) {
+            int cnt = 0;
+            gmg_hierarchy_get_triangles(hh, k, nullptr, &cnt);
+            std::vector<int> flat((size_t)cnt * 3);
+            if (cnt > 0) gmg_hierarchy_get_triangles(hh, k, flat.data(), &cnt);
+            std::vector<std::vector<int>> tris((size_t)cnt);
+            for (int t = 0; t < cnt; ++t) tris[t] = {flat[3 * (size_t)t], flat[3 * (size_t)t + 1], flat[3 * (size_t)t + 2]};
+            allTriangles.push_back(std::move(tris));
+            noTriFoundMap.push_back(std::vector<int>((size_t)nf, 0));
+        }
         samples[k].resize(nc);
         gmg_hierarchy_get_samples(hh, k, samples[k].data());
         std::unique_ptr<int[]> near(new int[(size_t)nf]);

@@ -98,6 +98,10 @@ public:
     std::vector<std::vector<int>> samples;       // samples[k]: fine index of every point of level k+1 (multigrid_solver.cpp:128)
     std::vector<std::vector<size_t>> nearestSource;   // nearestSource[k]: the level-(k+1) point every level-k point clusters to (:171)
     std::vector<MatrixXd> levelV;                // positions of the points of level k+1 (the reference fills it with debug only, :241)
+    std::vector<MatrixXi> levelE;                // (multigrid_solver.h:99) filled by the SIG06 hierarchy only upstream: always empty here
+    std::vector<std::vector<int>> noTriFoundMap; // (:100) with debug: one zero vector per level, as upstream (:291 is its only write)
+    std::vector<std::vector<std::vector<int>>> allTriangles;   // (:101) with debug: the candidate triangles of every level (:281)
+    std::vector<MatrixXd> levelN;                // (:102) never filled upstream: always empty
     int cycleType = 0;                           // 0: V-cycle (1 F / 2 W are rejected: broken upstream)
     bool isSmootherGaussSeidel = false;          // set by the shim (core.cpp:57); solve() does nothing without it
     bool sig06 = false;

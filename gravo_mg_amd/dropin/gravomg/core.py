@@ -73,10 +73,10 @@ _FORWARDED = {
     "sampling_indices": ("get", "sampling_indices[k][c]: index on level k of point c of level k + 1."),
     "nearest_source": ("get", "nearest_source[k][i]: the level-(k+1) point whose cluster contains point i of level k."),
     "level_points": ("get", "Positions of the points of every coarse level ((n_k, 3) arrays); filled when debug=True, like upstream."),
-    "level_edges": ("get", "Debug data of the SIG06 / ablation paths: not produced by this build, raises."),
-    "notrimap": ("get", "Debug data of the triangle search: not produced by this build, raises."),
-    "all_triangles": ("get", "Debug data of the triangle search: not produced by this build, raises."),
-    "coarse_normals": ("get", "Debug data of the triangle search: not produced by this build, raises."),
+    "level_edges": ("get", "Edges of the SIG06 hierarchy's levels: empty for the default hierarchy, as upstream."),
+    "notrimap": ("get", "With debug=True one zero vector per level (upstream never writes anything else into it); empty otherwise."),
+    "all_triangles": ("get", "With debug=True the candidate triangles of every level's coarse points; empty otherwise."),
+    "coarse_normals": ("get", "Never filled upstream: always empty."),
     "solver_timing": ("get", "dict with the reference's solverTiming keys: reduction, coarsest_solve, cycles, solver_total, iterations, residue."),
     "hierarchy_timing": ("get", "dict with the reference's hierarchyTiming keys."),
     "convergence": ("get", "[(elapsed_ms, residue), ...] per V-cycle, appended across solves like upstream."),

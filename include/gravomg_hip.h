@@ -276,6 +276,7 @@ typedef struct {
     int nested;            /* 0 */
     int sampling;          /* Sampling enum (multigrid_solver.h:40-46); only 0 = FASTDISK is supported */
     int weighting;         /* Weighting enum (multigrid_solver.h:48-52): 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST */
+    int debug;             /* the reference's `debug` member: keep every level's candidate triangles (allTriangles, multigrid_solver.cpp:281) */
 } gmg_hierarchy_options;
 
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o);
@@ -298,6 +299,9 @@ int gmg_hierarchy_get_timing(gmg_hierarchy hh, const char* key, double* out);
 int gmg_hierarchy_get_samples(gmg_hierarchy hh, int k, int* out);
 int gmg_hierarchy_get_nearest(gmg_hierarchy hh, int k, int* out);
 int gmg_hierarchy_get_points(gmg_hierarchy hh, int k, double* out_xyz);
+/* allTriangles[k] (multigrid_solver.h:101; only kept when the hierarchy was built with debug != 0): the candidate triangles of the
+ * coarse points of level k+1, *count triples of coarse indices, in construction order.  out may be NULL (size query). */
+int gmg_hierarchy_get_triangles(gmg_hierarchy hh, int k, int* out, int* count);
 /* A breadth-first order of the level-0 points over `neigh` (new -> old), made beside the construction when the input numbering
  * has no locality (randomly ordered scans, point clouds); *count = 0 otherwise.  out may be NULL (size query).  Not in the
  * reference: a by-product the MI355X engine uses to number the finest level (gmg_set_fine_order). */

@@ -93,9 +93,18 @@ def test_construction_and_hierarchy_without_gpu(gravomg, tmp_path):
     pts = dbg.level_points
     assert [p.shape for p in pts] == [(d, 3) for d in dof[1:]]
     assert np.abs(pts[0]).max() <= np.abs(V).max() * 1.0001                                # cluster centroids stay inside the hull
-    for name in ("level_edges", "notrimap", "all_triangles", "coarse_normals"):
-        with pytest.raises(RuntimeError, match="not produced"):
-            getattr(solver, name)
+    # the reference's remaining debug members: levelE (SIG06 hierarchy only) and levelN (never filled) are empty upstream too;
+    # allTriangles / noTriFoundMap exist with debug=True only (multigrid_solver.cpp:281, 291)
+    for s_ in (solver, dbg):
+        assert list(s_.level_edges) == [] and list(s_.coarse_normals) == []
+    assert list(solver.all_triangles) == [] and list(solver.notrimap) == []
+    tris, ntm = dbg.all_triangles, dbg.notrimap
+    assert len(tris) == len(ntm) == len(U)
+    for k in range(len(U)):
+        t = np.asarray(tris[k])
+        assert t.ndim == 2 and t.shape[1] == 3 and t.shape[0] >= dof[k + 1] // 2 and t.min() >= 0 and t.max() < dof[k + 1]
+        assert np.all(t[:, 0] != t[:, 1]) and np.all(t[:, 1] != t[:, 2]) and np.all(t[:, 0] != t[:, 2])
+        assert len(ntm[k]) == dof[k] and not np.any(ntm[k])
     with pytest.raises(RuntimeError, match="Pardiso"):
         solver.direct_solve((M + 1e-3 * S).tocsr(), M @ V, pardiso=True)
     with pytest.raises(TypeError):
