@@ -318,6 +318,23 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     HIPCHK(dev_malloc((void**)&l.diag, sizeof(double) * l.n_pad));
     if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) return rc;
     l.Aoff.nnz_real = l.nnz - l.n;
+    // 16-bit column codes for the fine-level kernels (GMG_NO_COL16: A/B aid): 2 of the 12 bytes of an entry less to read per launch
+    h->timing["col16_l0"] = 0.0;
+    if (k == 0 && !l.ord.blocked && lpr == 1 && l.Aoff.stored > 0 && !std::getenv("GMG_NO_COL16")) {
+        DevTmp<int> d_fail;
+        int failed = 0;
+        if ((rc = d_fail.alloc(h, 1))) return rc;
+        HIPCHK(hipMemsetAsync(d_fail.p, 0, sizeof(int), h->stream));
+        HIPCHK(dev_malloc((void**)&l.Aoff.col16, sizeof(unsigned) * (size_t)l.Aoff.stored));
+        HIPCHK(dev_malloc((void**)&l.Aoff.win_base, sizeof(int) * (size_t)l.Aoff.n_slices * 8));
+        hipLaunchKernelGGL(gmgs::compress_cols, dim3((l.Aoff.n_slices + 3) / 4), dim3(256), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, dA.ptr, l.d_new2old,
+                           l.Aoff.n_slices, l.Aoff.col16, l.Aoff.win_base, d_fail.p);
+        HIPCHK(hipMemcpyAsync(&failed, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->timing["col16_failed_slices_l0"] = failed;
+        if (failed) { (void)dev_free(l.Aoff.col16); (void)dev_free(l.Aoff.win_base); l.Aoff.col16 = nullptr; l.Aoff.win_base = nullptr; }
+        else h->timing["col16_l0"] = 1.0;
+    }
     phase("A");
     if (l.ord.blocked) {
         if ((rc = d_blk_of_row.alloc(h, l.n_pad)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||

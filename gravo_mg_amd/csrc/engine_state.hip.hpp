@@ -54,6 +54,8 @@ struct DevSell {
     double* val = nullptr;
     float* val32 = nullptr;       // fp32 copy of val (mixed-precision inner cycle); shares slice_ptr / col / row_of
     int* row_of = nullptr;
+    unsigned* col16 = nullptr;         // level 0: 16-bit column codes, two to a word, indexed like col (the first half of every slice's region is used)
+    int* win_base = nullptr;           //          + the 8 window bases of every slice (gmgs::compress_cols); null = the kernels read col
 };
 
 // natural-numbering compressed matrix on the device (A_k, U_k by coarse column)
@@ -324,6 +326,8 @@ void free_sell(DevSell& s) {
     if (s.val) (void)dev_free(s.val);
     if (s.val32) (void)dev_free(s.val32);
     if (s.row_of) (void)dev_free(s.row_of);
+    if (s.col16) (void)dev_free(s.col16);
+    if (s.win_base) (void)dev_free(s.win_base);
     s = DevSell();
 }
 

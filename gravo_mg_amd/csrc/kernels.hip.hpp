@@ -79,6 +79,71 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
     }
 }
 
+// ---- 16-bit column codes (level 0; setup_kernels.hip.hpp::compress_cols) ------------------------------------------------------------
+// The fine-level kernels run at the HBM limit for the bytes they move, so the way to a faster launch is fewer bytes: a column index is
+// 4 of the 12 bytes of an entry.  The columns of the 64 rows of a slice are the neighbours of 64 consecutive rows: a few short ranges
+// (one or two per colour class).  Every slice gets up to 8 "windows" [base_k, base_k + 8192) that cover its columns;
+// code = k << 13 | (column - base_k), two codes to a 32-bit word (entries 2 q and 2 q + 1 of a row share word q of the slice's region),
+// and the 8 bases of the slice sit in lanes 0..7 of one register, picked per entry by ds_bpermute.  Same columns in the same order: the
+// results are bit-identical to the 32-bit path.  A level with a slice that 8 windows cannot cover keeps its 32-bit indices.
+constexpr int kColWinBits = 3, kColDeltaBits = 13, kColWins = 1 << kColWinBits;
+
+template <class T, int D, int W>
+__device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp, const T* __restrict__ vp, const T* x, int ld, int basev, T (&acc)[D]) {
+    unsigned pk[(W + 1) / 2];
+    T v[W];
+#pragma unroll
+    for (int q = 0; q < (W + 1) / 2; ++q) pk[q] = __builtin_nontemporal_load(cp + q * 64);
+#pragma unroll
+    for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(vp + j * 64);
+    int c[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        const unsigned u = (j & 1) ? pk[j >> 1] >> 16 : pk[j >> 1] & 0xffffu;
+        c[j] = __builtin_amdgcn_ds_bpermute((int)((u >> (kColDeltaBits - 2)) & ((kColWins - 1) << 2)), basev) + (int)(u & ((1u << kColDeltaBits) - 1u));
+    }
+    T xv[W][D];
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) xv[j][d] = x[c[j] + (int64_t)d * ld];
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] += v[j] * xv[j][d];
+}
+
+// row_dot with the columns read from the codes (G is even: a group's codes are whole words)
+template <class T, int D, int G = DotGroup<D>::value>
+__device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr, const unsigned* __restrict__ col16, const int* __restrict__ win_base,
+                                          const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
+    const int basev = win_base[(int64_t)s * kColWins + (lane & (kColWins - 1))];
+    const int64_t p0 = slice_ptr[s];
+    int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+    const unsigned* cp = col16 + p0 + lane;
+    const T* vp = val + p0 + lane;
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0;
+    for (; w >= G; w -= G, cp += (G / 2) * 64, vp += G * 64) row_dot_group16<T, D, G>(cp, vp, x, ld, basev, acc);
+    switch (w) {
+        case 1: row_dot_group16<T, D, 1>(cp, vp, x, ld, basev, acc); break;
+        case 2: row_dot_group16<T, D, 2>(cp, vp, x, ld, basev, acc); break;
+        case 3: row_dot_group16<T, D, 3>(cp, vp, x, ld, basev, acc); break;
+        case 4: if (G > 4) row_dot_group16<T, D, 4>(cp, vp, x, ld, basev, acc); break;
+        case 5: if (G > 4) row_dot_group16<T, D, 5>(cp, vp, x, ld, basev, acc); break;
+        case 6: if (G > 4) row_dot_group16<T, D, 6>(cp, vp, x, ld, basev, acc); break;
+        case 7: if (G > 4) row_dot_group16<T, D, 7>(cp, vp, x, ld, basev, acc); break;
+        default: break;
+    }
+}
+
+template <class T, int D, int C16>
+__device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
+                                            const int* __restrict__ win_base, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
+    if constexpr (C16 != 0) row_dot16<T, D>(slice_ptr, col16, win_base, val, x, ld, s, lane, acc);
+    else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+}
+
 // Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
 template <class T, int D>
 __device__ __forceinline__ void quad_reduce(T (&acc)[D]) {
@@ -98,13 +163,14 @@ template <class T, int D, int FINE>
 __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const T* __restrict__ val, const T* __restrict__ diag,
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
-                                                   int slice_end, int xcd_swizzle, T omega) {
+                                                   int slice_end, int xcd_swizzle, T omega, const unsigned* __restrict__ col16 = nullptr,
+                                                   const int* __restrict__ win_base = nullptr) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     T acc[D];
-    row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    row_dot_sel<T, D, FINE == 2>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);      // FINE 2: level 0 with 16-bit column codes
     const T dg = diag[row];
     if (omega == (T)1.0) {                 // kernel argument: a scalar branch.  The reference's update, no read of x_i
 #pragma unroll
@@ -125,11 +191,12 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
 // less of its 336 MB at four colours).  (The algebraic shortcut r_i = a_ii (1 - omega)(x_i^GS - x_i^old) is NOT used: near the
 // attainable accuracy it under-reports the residue, 5.9e-8 for a true 6.2e-8 on a 7 680-vertex Poisson problem.)  partials[blockIdx][2 D] = sum w r^2 / sum w b^2 over the block's rows (zeros for blocks
 // beyond the range), added by reduce_partials after the norm kernel's own.
-template <int D>
+template <int D, int C16 = 0>
 __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                         const double* __restrict__ val, const double* __restrict__ diag,
                                                         const double* __restrict__ b, double* x, int ld, int slice_begin, int slice_end,
-                                                        double omega, const double* __restrict__ weight, double* __restrict__ partials) {
+                                                        double omega, const double* __restrict__ weight, double* __restrict__ partials,
+                                                        const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
     __shared__ double red[kWavesPerBlock][2 * D];
     const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -139,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
     if (s < slice_end) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll
@@ -172,17 +239,18 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
 // The LAST colour launch of the pre-smoothing: the same update, plus the residual r_i = b_i - (sum_{j != i} a_ij x_j + a_ii x_i^new) of
 // its own rows -- the expression of spmv_full<MODE 1> on the same operands (no later launch changes x before the residual), so the
 // residual kernel only visits the rows of the other colours.
-template <int D>
+template <int D, int C16 = 0>
 __global__ __launch_bounds__(kBlock) void gs_color_residual(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                             const double* __restrict__ val, const double* __restrict__ diag,
                                                             const double* __restrict__ b, double* x, double* __restrict__ r, int ld,
-                                                            int slice_begin, int slice_end, double omega) {
+                                                            int slice_begin, int slice_end, double omega, const unsigned* __restrict__ col16 = nullptr,
+                                                            const int* __restrict__ win_base = nullptr) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     double acc[D];
-    row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
     const double dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -780,14 +848,14 @@ __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict
 
 // MODE 0: y = A x      MODE 1: y = b - A x   (gravomg/src/multigrid_solver.cpp:1066)
 // LPR = lanes per row of the SELL layout (1, or 4 on the coarse levels): slices then hold 64 / LPR rows.
-template <class T, int D, int MODE, int LPR>
+template <class T, int D, int MODE, int LPR, int C16 = 0>
 __device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ diag, const T* __restrict__ b, const T* __restrict__ x, T* __restrict__ y,
-                                                int ld, int s) {
+                                                int ld, int s, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = s * (64 / LPR) + lane / LPR;
     T acc[D];
-    row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const T dg = diag[row];
 #pragma unroll
@@ -796,15 +864,15 @@ __device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slic
         y[row + (int64_t)c * ld] = MODE == 1 ? b[row + (int64_t)c * ld] - ax : ax;
     }
 }
-template <class T, int D, int MODE, int LPR>
+template <class T, int D, int MODE, int LPR, int C16 = 0>
 __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                     const T* __restrict__ val, const T* __restrict__ diag,
                                                     const T* __restrict__ b, const T* __restrict__ x,
                                                     T* __restrict__ y, int ld, int slice_begin, int slice_end,
-                                                    int xcd_swizzle) {
+                                                    int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    spmv_full_slice<T, D, MODE, LPR>(slice_ptr, col, val, diag, b, x, y, ld, s);
+    spmv_full_slice<T, D, MODE, LPR, C16>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base);
 }
 // the same over a LIST of slices (a rank's rows of a level partitioned by blocks: not one contiguous range)
 template <class T, int D, int MODE, int LPR>
@@ -1092,12 +1160,13 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
 // load -> gather round trips: 59 us against 47 us for the SpMV over the same matrix at 3 M vertices.  MODE 1 also writes the
 // residual b - A x as the fp32 right-hand side of the mixed-precision inner cycle (the defect-correction loop of BASELINE config 5).
 constexpr int kNormWaves = 16;      // slices (waves) per block of the norm kernel: 1024 threads, one partial per 16 slices
-template <int D, int MODE>
+template <int D, int MODE, int C16 = 0>
 __global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                                const double* __restrict__ val, const double* __restrict__ diag,
                                                                const double* __restrict__ b, const double* __restrict__ x,
                                                                const double* __restrict__ weight, int ld, int n_slices,
-                                                               float* __restrict__ r32, double* __restrict__ partials) {
+                                                               float* __restrict__ r32, double* __restrict__ partials,
+                                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
     __shared__ double red[kNormWaves][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // partial index = the position of this block's slices in the slice range, not blockIdx (the XCD map permutes blocks)
@@ -1110,7 +1179,7 @@ __global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const in
     if (s < n_slices) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot<double, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll

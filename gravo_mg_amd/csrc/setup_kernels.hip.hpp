@@ -246,6 +246,66 @@ __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restri
     else csr_fill_plain_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
 }
 
+// 16-bit column codes of a SELL operator (kernels.hip.hpp, "16-bit column codes"): one wavefront per slice.  The windows of a slice are
+// chosen greedily in ascending order (base_0 = the smallest column, base_k = the smallest column at or beyond base_{k-1} + 8192), which
+// covers any column set with the fewest windows of that length; padding entries (entry j of a row is padding when j >= the row's stored
+// off-diagonal entries, known from the source matrix -- never judged by a value, which a values-only refresh may change) get code 0 =
+// the slice's first base, a valid index that is multiplied by 0 like column 0 before.  *fail counts the slices 8 windows do not cover.
+__global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const int* __restrict__ a_ptr,
+                                                     const int* __restrict__ new2old, int n_slices, unsigned* __restrict__ col16,
+                                                     int* __restrict__ win_base, int* __restrict__ fail) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (s >= n_slices) return;
+    const int64_t p0 = slice_ptr[s];
+    const int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+    const int old = new2old[s * 64 + lane];
+    const int len = old >= 0 ? a_ptr[old + 1] - a_ptr[old] - 1 : 0;
+    constexpr int kNone = 0x7fffffff;
+    int base[8];
+    int lo = 0;                                                  // columns below lo are covered
+    bool more = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int m = kNone;
+        if (more)
+            for (int j = 0; j < w; ++j) {
+                const int c = col[p0 + (int64_t)j * 64 + lane];
+                if (j < len && c >= lo && c < m) m = c;
+            }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, 64));
+        if (m == kNone) { more = false; base[k] = k ? base[k - 1] : 0; }
+        else { base[k] = m; lo = m + 8192; }
+    }
+    bool bad = false;
+    unsigned word = 0;
+    for (int j = 0; j < w; ++j) {
+        const int c = col[p0 + (int64_t)j * 64 + lane];
+        unsigned code = 0;
+        if (j < len) {
+            int k = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) k += (base[q] > base[q - 1] && c >= base[q]) ? 1 : 0;
+            int b = base[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) b = k == q ? base[q] : b;
+            const int delta = c - b;
+            if (delta < 0 || delta >= 8192) bad = true;
+            code = ((unsigned)k << 13) | ((unsigned)delta & 8191u);
+        }
+        word = (j & 1) ? (word | (code << 16)) : code;
+        if ((j & 1) || j == w - 1) col16[p0 + (int64_t)(j >> 1) * 64 + lane] = word;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicAdd(fail, 1);
+    if (lane < 8) {
+        int b = base[0];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) b = lane == q ? base[q] : b;
+        win_base[(int64_t)s * 8 + lane] = b;
+    }
+}
+
 // max over the blocks of their entry count (LDS capacity the sweep kernel needs)
 __global__ void block_entry_max(const int* __restrict__ blk_begin, int n_blocks, const int* __restrict__ row_ptr, int* __restrict__ out_max) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -338,3 +338,42 @@ def test_base_order_of_a_reordered_level_follows_the_gather_score(cabi):
     assert Hp.fine_order is not None
     ep = cabi.Engine(); ep.use_hierarchy(Hp); ep.set_mass(mp); ep.set_system(meshgen.poisson_system(Sp, mp)[0])
     assert ep.timing("base_order_choice") == 0.0 and ep.timing("base_order_score_cluster") < ep.timing("base_order_score_bfs")
+
+
+@pytest.mark.parametrize("case", ["torus", "random-order", "pointcloud", "smoothing-d3"])
+def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi, case):
+    """Level 0 stores its column indices a second time as 16-bit codes (window of the slice + offset inside it, gmgs::compress_cols)
+    and the fine-level kernels read those: the same columns in the same order, so every iterate is bit-identical to the 32-bit path
+    (GMG_NO_COL16), also after a values-only refresh, for d = 3 and in the fp32 inner cycle."""
+    import os
+    P = {"torus": lambda: problems.torus_problem(96, 80, "poisson", 30),
+         "random-order": lambda: problems.torus_problem(64, 60, "poisson", 40, order="random"),
+         "pointcloud": lambda: problems.pointcloud_problem(3000),
+         "smoothing-d3": lambda: problems.torus_problem(64, 60, "smoothing", 60)}[case]()
+
+    def run(no16):
+        if no16:
+            os.environ["GMG_NO_COL16"] = "1"
+        try:
+            e = cabi.Engine()
+            e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
+        finally:
+            os.environ.pop("GMG_NO_COL16", None)
+        return e
+    a, b = run(False), run(True)
+    assert b.timing("col16_l0") == 0.0
+    assert a.timing("col16_l0") == 1.0 and a.timing("col16_failed_slices_l0") == 0.0     # small meshes: 8 windows of 8 192 cover any slice
+    for e in (a, b):
+        e.load_problem(P.rhs, P.rhs)
+    ha, hb = a.run_cycles(4, 2), b.run_cycles(4, 2)
+    assert np.array_equal(ha, hb) and np.array_equal(a.fetch_solution(), b.fetch_solution())
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(P.rhs.shape)
+    assert np.array_equal(a.residual(0, P.rhs, x), b.residual(0, P.rhs, x)) and np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
+    for t in (0, 1, 2, 3):
+        assert a.residual_norm(P.rhs, x, t) == b.residual_norm(P.rhs, x, t)
+    lhs2 = P.lhs.copy(); lhs2.data = lhs2.data * (1.0 + 0.1 * rng.random(lhs2.nnz))
+    lhs2 = (lhs2 + lhs2.T) * 0.5                                        # same pattern, new (symmetric) values: refreshed in place
+    a.set_system(lhs2); b.set_system(lhs2)
+    assert a.timing("setup_values_only") == 1.0
+    assert np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
