@@ -267,12 +267,22 @@ def main():
         by = eng.algorithmic_bytes(kind, 0, d0)
         kern[name] = {"ms": ms, "GBps": by / (ms * 1e-3) / 1e9}
     traffic, traffic_source = load_pmc_traffic(workload)
+    # level 0 stores its column indices as 16-bit codes when every slice's columns fit 8 windows: the kernel then MOVES
+    # 2 bytes less per entry than the CSR figure SURVEY.md 8(d) defines as algorithmic (value + int32 index), plus 32 B of bases per
+    # 64-row slice.  `achieved` / `frac` stay on the algorithmic definition; `stored_format_*` is the same launch on the bytes of the
+    # stored format, i.e. how close the kernel is to the limit for what it actually has to read.
+    col16 = bool(eng.timing("col16_l0"))
+    info0 = eng.level_info(0)
+    stored_bytes = sweep_bytes - (2.0 * (info0["nnz"] - info0["n"]) - 32.0 * info0["n_pad"] / 64 if col16 else 0.0)
     roofline = {
-        "bound": "hbm", "kernel": "gmgk::gs_color<1,1> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour)",
+        "bound": "hbm", "kernel": "gmgk::gs_color<1,%d> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour%s)" % (2 if col16 else 1, "; 16-bit column codes" if col16 else ""),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_source,
         "launch_ms": sweep_ms / launches, "launches_per_sweep": launches,
         "algorithmic_bytes_per_launch": sweep_bytes / launches,
+        "index_format": "16-bit window codes (2 B per entry + 32 B per slice)" if col16 else "int32",
+        "stored_format_bytes_per_launch": stored_bytes / launches,
+        "stored_format_frac": stored_bytes / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "other_fine_kernels": kern,
     }
     # ... and of the whole step (the honest companion of the dominant-kernel figure): algorithmic bytes of one V-cycle + check

@@ -264,9 +264,9 @@ template <class T, int LPR>
 void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                          fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
-                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1));
+        DISPATCH_D(dc, DISPATCH_C16(fine.R.col16 != nullptr, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
+                                          h->stream, fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
+                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1, fine.R.col16, fine.R.win_base)));
     }
 }
 template <class T>
@@ -280,9 +280,9 @@ template <class T>
 void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                          fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
-                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1));
+        DISPATCH_D(dc, DISPATCH_C16(fine.P.col16 != nullptr, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
+                                          h->stream, fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
+                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1, fine.P.col16, fine.P.win_base)));
     }
 }
 

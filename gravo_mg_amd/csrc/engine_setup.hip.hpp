@@ -318,23 +318,6 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     HIPCHK(dev_malloc((void**)&l.diag, sizeof(double) * l.n_pad));
     if ((rc = device_build_sell(h, l.Aoff, dA.ptr, dA.ptr + 1, dA.idx, dA.val, f, nullptr, l.n_pad, lpr, nullptr, l.diag, d_err))) return rc;
     l.Aoff.nnz_real = l.nnz - l.n;
-    // 16-bit column codes for the fine-level kernels (GMG_NO_COL16: A/B aid): 2 of the 12 bytes of an entry less to read per launch
-    h->timing["col16_l0"] = 0.0;
-    if (k == 0 && !l.ord.blocked && lpr == 1 && l.Aoff.stored > 0 && !std::getenv("GMG_NO_COL16")) {
-        DevTmp<int> d_fail;
-        int failed = 0;
-        if ((rc = d_fail.alloc(h, 1))) return rc;
-        HIPCHK(hipMemsetAsync(d_fail.p, 0, sizeof(int), h->stream));
-        HIPCHK(dev_malloc((void**)&l.Aoff.col16, sizeof(unsigned) * (size_t)l.Aoff.stored));
-        HIPCHK(dev_malloc((void**)&l.Aoff.win_base, sizeof(int) * (size_t)l.Aoff.n_slices * 8));
-        hipLaunchKernelGGL(gmgs::compress_cols, dim3((l.Aoff.n_slices + 3) / 4), dim3(256), 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, dA.ptr, l.d_new2old,
-                           l.Aoff.n_slices, l.Aoff.col16, l.Aoff.win_base, d_fail.p);
-        HIPCHK(hipMemcpyAsync(&failed, d_fail.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->timing["col16_failed_slices_l0"] = failed;
-        if (failed) { (void)dev_free(l.Aoff.col16); (void)dev_free(l.Aoff.win_base); l.Aoff.col16 = nullptr; l.Aoff.win_base = nullptr; }
-        else h->timing["col16_l0"] = 1.0;
-    }
     phase("A");
     if (l.ord.blocked) {
         if ((rc = d_blk_of_row.alloc(h, l.n_pad)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
@@ -453,7 +436,36 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) return rc;
         l.P.nnz_real = h->U[k].nnz();
     }
+    // ---- 16-bit column codes of level 0's operator and transfers for the fine-level kernels (kernels.hip.hpp; GMG_NO_COL16: A/B aid): 2 of
+    // the 12 bytes of an entry less to read per launch.  An operator with a slice that 8 windows do not cover keeps its 32-bit indices.
+    DevSell* c16_ops[3] = {&l.Aoff, &l.R, &l.P};
+    const char* c16_keys[3] = {"col16_l0", "col16_R_l0", "col16_P_l0"};
+    int c16_failed[3] = {0, 0, 0};
+    DevTmp<int> d_c16;
+    const bool c16 = k == 0 && !l.ord.blocked && !std::getenv("GMG_NO_COL16");
+    if (k == 0) for (const char* key : c16_keys) h->timing[key] = 0.0;
+    if (c16) {
+        if ((rc = d_c16.alloc(h, 3))) return rc;
+        HIPCHK(hipMemsetAsync(d_c16.p, 0, 3 * sizeof(int), h->stream));
+        for (int i = 0; i < 3; ++i) {
+            DevSell& op = *c16_ops[i];
+            if (op.stored <= 0 || op.n_slices <= 0 || (i == 0 && op.lpr != 1)) continue;
+            HIPCHK(dev_malloc((void**)&op.col16, sizeof(unsigned) * (size_t)op.stored));
+            HIPCHK(dev_malloc((void**)&op.win_base, sizeof(int) * (size_t)op.n_slices * 8));
+            hipLaunchKernelGGL(gmgs::compress_cols, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, i == 0 ? dA.ptr : (const int*)nullptr,
+                               i == 0 ? l.d_new2old : (const int*)nullptr, op.val, op.n_slices, op.col16, op.win_base, d_c16.p + i);
+        }
+        HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
     HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
+    if (c16)
+        for (int i = 0; i < 3; ++i) {
+            DevSell& op = *c16_ops[i];
+            h->timing[std::string(c16_keys[i]) + "_failed_slices"] = c16_failed[i];
+            if (!op.col16) continue;
+            if (c16_failed[i]) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; }
+            else h->timing[c16_keys[i]] = 1.0;
+        }
     phase("P");
     return GMG_OK;
 }

@@ -889,12 +889,13 @@ __global__ __launch_bounds__(kBlock) void spmv_full_list(const int64_t* __restri
 //                       ADD = 1: y[out_row] += sum val * x[col]  (prolongation x += U e, :1082)
 // row_of (may be null) maps the slice row to the output row (-1 = none); ldx/ldy are the leading
 // dimensions of the source / destination level.  LPR as in spmv_full.
-template <class T, int D, int ADD, int LPR>
+template <class T, int D, int ADD, int LPR, int C16 = 0>
 __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
-                                               const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s) {
+                                               const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s,
+                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
     const int lane = threadIdx.x & 63;
     T acc[D];
-    row_dot<T, D>(slice_ptr, col, val, x, ldx, s, lane, acc);
+    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, val, x, ldx, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const int srow = s * (64 / LPR) + lane / LPR;
     // ADD = 1 is a read-modify-write of y: only safe when every output row is produced by exactly one slice row, so that
@@ -907,14 +908,15 @@ __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice
         else y[row + (int64_t)c * ldy] = acc[c];
     }
 }
-template <class T, int D, int ADD, int LPR>
+template <class T, int D, int ADD, int LPR, int C16 = 0>
 __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const T* __restrict__ val, const int* __restrict__ row_of,
                                                    const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
-                                                   int slice_begin, int slice_end, int xcd_swizzle) {
+                                                   int slice_begin, int slice_end, int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr,
+                                                   const int* __restrict__ win_base = nullptr) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    transfer_slice<T, D, ADD, LPR>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s);
+    transfer_slice<T, D, ADD, LPR, C16>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base);
 }
 template <class T, int D, int ADD, int LPR>
 __global__ __launch_bounds__(kBlock) void transfer_list(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,

@@ -248,19 +248,22 @@ __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restri
 
 // 16-bit column codes of a SELL operator (kernels.hip.hpp, "16-bit column codes"): one wavefront per slice.  The windows of a slice are
 // chosen greedily in ascending order (base_0 = the smallest column, base_k = the smallest column at or beyond base_{k-1} + 8192), which
-// covers any column set with the fewest windows of that length; padding entries (entry j of a row is padding when j >= the row's stored
-// off-diagonal entries, known from the source matrix -- never judged by a value, which a values-only refresh may change) get code 0 =
-// the slice's first base, a valid index that is multiplied by 0 like column 0 before.  *fail counts the slices 8 windows do not cover.
+// covers any column set with the fewest windows of that length; padding entries get code 0 = the slice's first base, a valid index that
+// is multiplied by 0 like column 0 before.  What is padding: for the operator (a_ptr != null) entry j of a row when j >= the row's stored
+// off-diagonal entries, known from the source matrix -- never judged by a value, which a values-only refresh may change; for a transfer
+// (a_ptr == null; its values never change after the layout) an entry whose value is 0, which contributes 0 wherever it points.
+// *fail counts the slices 8 windows do not cover.
 __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const int* __restrict__ a_ptr,
-                                                     const int* __restrict__ new2old, int n_slices, unsigned* __restrict__ col16,
-                                                     int* __restrict__ win_base, int* __restrict__ fail) {
+                                                     const int* __restrict__ new2old, const double* __restrict__ val, int n_slices,
+                                                     unsigned* __restrict__ col16, int* __restrict__ win_base, int* __restrict__ fail) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (s >= n_slices) return;
     const int64_t p0 = slice_ptr[s];
     const int w = (int)((slice_ptr[s + 1] - p0) >> 6);
-    const int old = new2old[s * 64 + lane];
-    const int len = old >= 0 ? a_ptr[old + 1] - a_ptr[old] - 1 : 0;
+    int len = 0;
+    if (a_ptr) { const int old = new2old[s * 64 + lane]; len = old >= 0 ? a_ptr[old + 1] - a_ptr[old] - 1 : 0; }
+    auto real = [&](int j) { return a_ptr ? j < len : val[p0 + (int64_t)j * 64 + lane] != 0.0; };
     constexpr int kNone = 0x7fffffff;
     int base[8];
     int lo = 0;                                                  // columns below lo are covered
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__
         if (more)
             for (int j = 0; j < w; ++j) {
                 const int c = col[p0 + (int64_t)j * 64 + lane];
-                if (j < len && c >= lo && c < m) m = c;
+                if (c >= lo && c < m && real(j)) m = c;
             }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, 64));
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__
     for (int j = 0; j < w; ++j) {
         const int c = col[p0 + (int64_t)j * 64 + lane];
         unsigned code = 0;
-        if (j < len) {
+        if (real(j)) {
             int k = 0;
 #pragma unroll
             for (int q = 1; q < 8; ++q) k += (base[q] > base[q - 1] && c >= base[q]) ? 1 : 0;

@@ -362,7 +362,9 @@ def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi
         return e
     a, b = run(False), run(True)
     assert b.timing("col16_l0") == 0.0
-    assert a.timing("col16_l0") == 1.0 and a.timing("col16_failed_slices_l0") == 0.0     # small meshes: 8 windows of 8 192 cover any slice
+    assert b.timing("col16_R_l0") == 0.0 and b.timing("col16_P_l0") == 0.0
+    for key in ("col16_l0", "col16_R_l0", "col16_P_l0"):               # the operator and both transfers of level 0
+        assert a.timing(key) == 1.0 and a.timing(key + "_failed_slices") == 0.0     # small meshes: 8 windows of 8 192 cover any slice
     for e in (a, b):
         e.load_problem(P.rhs, P.rhs)
     ha, hb = a.run_cycles(4, 2), b.run_cycles(4, 2)
