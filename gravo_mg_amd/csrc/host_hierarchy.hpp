@@ -65,6 +65,14 @@ struct HierarchyOptions {
         double* w = nullptr;                  // 3 nf
     };
     bool (*device_select)(const SelectJob&) = nullptr;
+    // Optional accelerator for the Graph-Voronoi clustering (:1015-1056) of a big level.  begin (called before the sequential sampling
+    // sweep, which it runs beside) may start moving the level's positions and neighbour table; finish gets the sampler's results
+    // (sample, seeded distances, seeded owners in `nearest`) and overwrites `nearest` with the clustering's owners -- the host sweep's,
+    // point for point, up to exact distance ties between predecessors (hierarchy_kernels.hip.hpp).  finish(ctx, nullptr, ...) abandons
+    // the job; false = nothing was written, the host sweep does the level.
+    void* (*device_cluster_begin)(const double* P, const int* NB, int n, int K, int device) = nullptr;
+    bool (*device_cluster_finish)(void* ctx, const int* sample, int ns, const double* Dseed, int* nearest) = nullptr;
+    int device_cluster_min_points = 200000;   // smaller levels stay on the host (a few milliseconds either way)
     int device = -1;                          // the HIP device the hook shall use (the builder itself knows no devices)
     int device_select_min_points = 200000;    // smaller levels stay on the host (transfer set-up costs more than the loop)
 };
@@ -134,7 +142,7 @@ public:
         HierarchyResult R;
         auto t_all = clk::now();
         for (const char* key : {"PDS", "sampling", "cluster", "next_neighborhood", "next_positions", "triangle_finding", "triangle_selection",
-                                "prepare", "edge_length", "assemble", "selection_on_device"}) R.timing[key] = 0.0;      // the last four: not in the reference's list
+                                "prepare", "edge_length", "assemble", "selection_on_device", "cluster_on_device"}) R.timing[key] = 0.0;      // the last four: not in the reference's list
         R.timing["n_vertices"] = n;
         // Storage of the coarser levels (level 0 reads the caller's arrays in place).  Shared: the last stage of a level -- parent
         // selection + assembly of U_k -- runs as a task beside the sequential stages of the next levels and reads them too.
@@ -167,12 +175,19 @@ public:
             nearest.assign(nf, 0);
             auto t0 = clk::now();
             std::vector<int>& sample = W->sample;
+            void* cluster_ctx = (opt.device_cluster_begin && opt.device_cluster_finish && nf >= opt.device_cluster_min_points)
+                                    ? opt.device_cluster_begin(reinterpret_cast<const double*>(P.data()), NB.data(), nf, nbK, opt.device) : nullptr;
             sample = fast_disk_sample(P, NB, nbK, radius, D, nearest, EL);                  // :128
-            if ((int)sample.size() < opt.lower_bound) break;                                // :156-159
+            if ((int)sample.size() < opt.lower_bound) {                                     // :156-159
+                if (cluster_ctx) (void)opt.device_cluster_finish(cluster_ctx, nullptr, 0, nullptr, nullptr);
+                break;
+            }
             const int nc = (int)sample.size();
             auto t1 = clk::now();
             R.timing["sampling"] += ms(t0, t1);
-            voronoi_dijkstra(P, sample, NB, nbK, D, nearest, EL);                           // :170
+            const bool clustered_on_device = cluster_ctx && opt.device_cluster_finish(cluster_ctx, sample.data(), nc, D.data(), nearest.data());
+            if (!clustered_on_device) voronoi_dijkstra(P, sample, NB, nbK, D, nearest, EL);  // :170
+            else R.timing["cluster_on_device"] += 1.0;
             auto t2 = clk::now();
             R.timing["cluster"] += ms(t1, t2);
 
