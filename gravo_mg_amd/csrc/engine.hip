@@ -1508,103 +1508,6 @@ static bool hierarchy_select_on_device(const HierarchyOptions::SelectJob& j) {
     return ok;
 }
 
-// Device stage of the Graph-Voronoi clustering (HierarchyOptions::device_cluster_begin / _finish; kernels and the argument why the result
-// is the host sweep's: hierarchy_kernels.hip.hpp).  begin runs on its own thread beside the sequential sampling sweep: positions and the
-// neighbour table cross PCIe (156 MB at 3 M points) and the edge lengths are formed on the device meanwhile; finish uploads what the
-// sampler produced (seeded distances and owners, 36 MB), relaxes to the fixed point (one launch + a 4-byte read per round, ~10 rounds),
-// resolves the owners and downloads them.  Its own stream and bounce buffers: the selection stage of the previous level may be running.
-namespace {
-HierarchyXfer& cluster_xfer() { static HierarchyXfer* x = new HierarchyXfer(); return *x; }
-struct ClusterCtx {
-    int n = 0, K = 0, dev = 0;
-    char* arena = nullptr;
-    size_t offs[12] = {0};
-    std::future<bool> prefetch;
-};
-enum { CL_P, CL_NB, CL_EL, CL_D, CL_SEED, CL_NEAR, CL_BEST, CL_PRED, CL_SAMPLE, CL_FLAGS, CL_END };
-}  // namespace
-
-static void* hierarchy_cluster_begin(const double* P, const int* NB, int n, int K, int device) {
-    ClusterCtx* c = new ClusterCtx();
-    c->n = n; c->K = K; c->dev = device;
-    c->prefetch = std::async(std::launch::async, [c, P, NB] {
-        HierarchyXfer& X = cluster_xfer();
-        std::lock_guard<std::mutex> lock(X.m);
-        if (hipSetDevice(c->dev) != hipSuccess || !X.ready(c->dev)) { (void)hipGetLastError(); return false; }
-        const size_t n = (size_t)c->n, K = (size_t)c->K;
-        const size_t sizes[CL_END] = {sizeof(double) * 3 * n, sizeof(int) * n * K, sizeof(double) * n * K, sizeof(double) * n, sizeof(double) * n, sizeof(int) * n,
-                                      sizeof(unsigned long long) * n, sizeof(int) * n, sizeof(int) * n, 3 * n + 256};
-        for (int i = 0; i < CL_END; ++i) c->offs[i + 1] = c->offs[i] + (sizes[i] + 255) / 256 * 256;
-        if (hipMalloc((void**)&c->arena, c->offs[CL_END]) != hipSuccess) { (void)hipGetLastError(); c->arena = nullptr; return false; }
-        const int threads = std::min(hw_threads(), 8);
-        bool ok = X.up(c->arena + c->offs[CL_P], P, sizes[CL_P], threads) && X.up(c->arena + c->offs[CL_NB], NB, sizes[CL_NB], threads);
-        if (ok) {
-            hipLaunchKernelGGL(gmgh::cluster_edge_lengths, dim3((unsigned)((n * K + 255) / 256)), dim3(256), 0, X.st, c->n, c->K, (const double*)(c->arena + c->offs[CL_P]),
-                               (const int*)(c->arena + c->offs[CL_NB]), (double*)(c->arena + c->offs[CL_EL]));
-            ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(X.st) == hipSuccess;
-        }
-        if (!ok) (void)hipGetLastError();
-        return ok;
-    });
-    return c;
-}
-
-static bool hierarchy_cluster_finish(void* ctx, const int* sample, int ns, const double* Dseed, int* nearest) {
-    ClusterCtx* c = (ClusterCtx*)ctx;
-    bool ok = c->prefetch.get();
-    HierarchyXfer& X = cluster_xfer();
-    std::lock_guard<std::mutex> lock(X.m);
-    if (ok && sample) ok = hipSetDevice(c->dev) == hipSuccess;
-    if (ok && sample) {
-        const int n = c->n, K = c->K;
-        const int threads = std::min(hw_threads(), 16);
-        auto at = [&](int i) { return c->arena + c->offs[i]; };
-        double* D = (double*)at(CL_D); double* seed = (double*)at(CL_SEED); int* d_near = (int*)at(CL_NEAR);
-        unsigned long long* best = (unsigned long long*)at(CL_BEST); int* pred = (int*)at(CL_PRED); int* d_sample = (int*)at(CL_SAMPLE);
-        unsigned char* flags = (unsigned char*)at(CL_FLAGS);          // is_src | changed A | changed B | any (int, 256-aligned tail)
-        unsigned char* is_src = flags; unsigned char* ch[2] = {flags + n, flags + 2 * (size_t)n};
-        int* any = (int*)(flags + (3 * (size_t)n + 3) / 4 * 4);             // [0] progress of a round, [1] error
-        const dim3 gn((unsigned)((n + 255) / 256)), b256(256);
-        ok = X.up(D, Dseed, sizeof(double) * n, threads) && X.up(d_near, nearest, sizeof(int) * n, threads) && X.up(d_sample, sample, sizeof(int) * ns, threads) &&
-             hipMemcpyAsync(seed, D, sizeof(double) * n, hipMemcpyDeviceToDevice, X.st) == hipSuccess &&
-             hipMemsetAsync(flags, 0, 3 * (size_t)n + 256, X.st) == hipSuccess && hipMemsetAsync(best, 0xff, sizeof(unsigned long long) * n, X.st) == hipSuccess &&
-             hipMemsetAsync(pred, 0x7f, sizeof(int) * n, X.st) == hipSuccess;
-        if (ok) hipLaunchKernelGGL(gmgh::cluster_init, dim3((unsigned)((ns + 255) / 256)), b256, 0, X.st, ns, d_sample, D, d_near, is_src, ch[0]);
-        int h_any = 1, rounds = 0, h_flags[2] = {1, 0};
-        for (; ok && h_any && rounds < 4096; ++rounds) {
-            const int in = rounds & 1;
-            ok = hipMemsetAsync(ch[in ^ 1], 0, n, X.st) == hipSuccess && hipMemsetAsync(any, 0, sizeof(int), X.st) == hipSuccess;
-            if (!ok) break;
-            hipLaunchKernelGGL(gmgh::cluster_relax, gn, b256, 0, X.st, n, K, (const int*)at(CL_NB), (const double*)at(CL_EL), D, ch[in], ch[in ^ 1], any);
-            ok = hipMemcpyAsync(&h_any, any, sizeof(int), hipMemcpyDeviceToHost, X.st) == hipSuccess && hipStreamSynchronize(X.st) == hipSuccess;
-        }
-        if (ok && h_any) ok = false;                                   // no fixed point within the round limit: leave it to the host sweep
-        if (ok) {
-            for (int pass = 0; pass < 2; ++pass)
-                hipLaunchKernelGGL(gmgh::cluster_pred, gn, b256, 0, X.st, n, K, pass, (const int*)at(CL_NB), (const double*)at(CL_EL), D, seed, is_src, best, pred);
-            for (int it = 0; ok && h_flags[0] && it < 64; ++it) {
-                ok = hipMemsetAsync(any, 0, 2 * sizeof(int), X.st) == hipSuccess;
-                hipLaunchKernelGGL(gmgh::cluster_jump, gn, b256, 0, X.st, n, D, seed, is_src, pred, any);
-                ok = ok && hipMemcpyAsync(h_flags, any, 2 * sizeof(int), hipMemcpyDeviceToHost, X.st) == hipSuccess && hipStreamSynchronize(X.st) == hipSuccess;
-                if (ok && h_flags[1]) ok = false;                      // a point without a tight predecessor (cannot happen at a fixed point)
-            }
-            if (ok && h_flags[0]) ok = false;
-        }
-        if (ok) {
-            hipLaunchKernelGGL(gmgh::cluster_owner, gn, b256, 0, X.st, n, D, seed, is_src, pred, d_near);
-            std::vector<int> out((size_t)n);                           // the caller's array is only overwritten by a complete result
-            ok = hipGetLastError() == hipSuccess && X.down(out.data(), d_near, sizeof(int) * n, threads) && hipStreamSynchronize(X.st) == hipSuccess;
-            if (ok) std::memcpy(nearest, out.data(), sizeof(int) * (size_t)n);
-        }
-        if (std::getenv("GMG_SETUP_TRACE")) std::fprintf(stderr, "[gmg hierarchy] clustering on the device: n=%d, %d relaxation rounds, ok=%d\n", n, rounds, (int)ok);
-    }
-    if (c->arena) { (void)hipStreamSynchronize(X.st); (void)hipFree(c->arena); }
-    if (!ok) (void)hipGetLastError();
-    const bool done = ok && sample != nullptr;
-    delete c;
-    return done;
-}
-
 int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt, gmg_hierarchy* out) try {
     if (!pos || !neigh || n <= 0 || K <= 0 || !out) return GMG_ERR_INVALID;
     gmg_hierarchy_options o;
@@ -1618,17 +1521,14 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     {
         const char* env = std::getenv("GMG_HIERARCHY_DEVICE");
         int ndev = 0;
-        if (!(env && std::atoi(env) == 0) && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
-            ho.device_select = hierarchy_select_on_device;
-            if (const char* hc = std::getenv("GMG_HIERARCHY_HOST_CLUSTER"); !(hc && std::atoi(hc) != 0)) { ho.device_cluster_begin = hierarchy_cluster_begin; ho.device_cluster_finish = hierarchy_cluster_finish; }
-            if (const char* e = std::getenv("GMG_CLUSTER_DEVICE_MIN_POINTS")) ho.device_cluster_min_points = std::max(1, std::atoi(e));
-        } else (void)hipGetLastError();
+        if (!(env && std::atoi(env) == 0) && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ho.device_select = hierarchy_select_on_device;
+        else (void)hipGetLastError();
     }
     // first use in a process: runtime start-up, code object load and the pinned buffers (~80 ms) happen beside the sequential
     // sampling / clustering sweeps of the first level instead of in front of the device stage
     std::future<void> device_warm;
     int caller_device = 0;
-    if (ho.device_select && hipGetDevice(&caller_device) != hipSuccess) { (void)hipGetLastError(); ho.device_select = nullptr; ho.device_cluster_begin = nullptr; }
+    if (ho.device_select && hipGetDevice(&caller_device) != hipSuccess) { (void)hipGetLastError(); ho.device_select = nullptr; }
     ho.device = caller_device;
     if (ho.device_select)
         device_warm = std::async(std::launch::async, [caller_device] {

@@ -159,90 +159,4 @@ __global__ __launch_bounds__(128) void select_parents(int nf, int Kc, int weight
     out_cnt[f] = (unsigned char)cnt; out_kind[f] = 2;
 }
 
-// ---- Graph-Voronoi clustering (gravomg/src/multigrid_solver.cpp:1015-1056; host routine: HierarchyBuilder::voronoi_dijkstra) -------------
-// The reference runs a multi-source Dijkstra over `neigh` on distances the sampler PRE-SEEDED (every point within two rings and the
-// radius of a sample holds that path's length and that sample), pushing only what it improves.  So a point relaxes its neighbours iff
-// it is a source or ended below its seed ("active"), and the result is the greatest fixed point of
-//     D[g] = min(seed[g], min over active u with g in neigh(u) of fl(D[u] + |p_u - p_g|)),        D[source] = 0,
-// which label-correcting relaxations reach from above whatever their order: a candidate formed from a not-yet-final D[u] is never
-// below the one formed from the final value (fl(a + w) is monotone in a), and every final value is re-relaxed after it is reached.
-// The sums are the reference's (one rounding per edge, lengths sqrt(dx^2 + dy^2 + dz^2) in that order, no contraction), positive doubles
-// order like their bit patterns, so D comes out bit-identical with 64-bit atomic minima.  Owners afterwards: Dijkstra gives g the owner
-// of the FIRST popped point whose candidate equals the final D[g] -- the tight predecessor with the smallest distance.  Only when two
-// tight predecessors have exactly the same distance does the reference's answer depend on the internal order of its binary heap; the
-// rule here is then the smaller point index (tests/test_gpu_hierarchy.py compares the owners point by point with the host sweep).
-__device__ __forceinline__ unsigned long long dbits(double v) { return (unsigned long long)__double_as_longlong(v); }
-
-__global__ __launch_bounds__(256) void cluster_edge_lengths(int n, int K, const double* __restrict__ P, const int* __restrict__ NB, double* __restrict__ EL) {
-    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (q >= (size_t)n * K) return;
-    const int i = (int)(q / K);
-    const int g = NB[q];
-    EL[q] = g < 0 ? 0.0 : norm(sub(load3(P, i), load3(P, g)));
-}
-
-// sources: distance 0, owner = their index in the sample, first frontier
-__global__ __launch_bounds__(256) void cluster_init(int ns, const int* __restrict__ sample, double* __restrict__ D, int* __restrict__ nearest,
-                                                    unsigned char* __restrict__ is_src, unsigned char* __restrict__ changed) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ns) return;
-    const int s = sample[i];
-    D[s] = 0.0; nearest[s] = i; is_src[s] = 1; changed[s] = 1;
-}
-
-// one round: every point whose distance fell in the last round offers its neighbours D[u] + length
-__global__ __launch_bounds__(256) void cluster_relax(int n, int K, const int* __restrict__ NB, const double* __restrict__ EL, double* D,
-                                                     const unsigned char* __restrict__ changed_in, unsigned char* __restrict__ changed_out, int* __restrict__ any) {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= n || !changed_in[u]) return;
-    const double du = __longlong_as_double((long long)atomicAdd((unsigned long long*)&D[u], 0ull));
-    bool lowered = false;
-    for (int j = 0; j < K; ++j) {
-        const int g = NB[(size_t)u * K + j];
-        if (g < 0) continue;
-        const unsigned long long cand = dbits(du + EL[(size_t)u * K + j]);
-        if (cand < dbits(D[g])) {
-            const unsigned long long old = atomicMin((unsigned long long*)&D[g], cand);
-            if (cand < old) { changed_out[g] = 1; lowered = true; }
-        }
-    }
-    if (lowered) *any = 1;
-}
-
-// tight predecessors: pass 0 -> the smallest distance among them, pass 1 -> the smallest index among those
-__global__ __launch_bounds__(256) void cluster_pred(int n, int K, int pass, const int* __restrict__ NB, const double* __restrict__ EL, const double* __restrict__ D,
-                                                    const double* __restrict__ seed, const unsigned char* __restrict__ is_src,
-                                                    unsigned long long* __restrict__ best, int* __restrict__ pred) {
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= n) return;
-    const double du = D[u];
-    if (!is_src[u] && !(du < seed[u])) return;                 // not active: never pushed, never a predecessor
-    for (int j = 0; j < K; ++j) {
-        const int g = NB[(size_t)u * K + j];
-        if (g < 0 || is_src[g]) continue;
-        const double dg = D[g];
-        if (!(dg < seed[g]) || dbits(du + EL[(size_t)u * K + j]) != dbits(dg)) continue;
-        if (pass == 0) atomicMin(&best[g], dbits(du));
-        else if (dbits(du) == best[g]) atomicMin(&pred[g], u);
-    }
-}
-
-// owners along the predecessor chains (every chain ends in a source): pointer doubling, then the source's sample index
-__global__ __launch_bounds__(256) void cluster_jump(int n, const double* __restrict__ D, const double* __restrict__ seed, const unsigned char* __restrict__ is_src,
-                                                    int* pred, int* __restrict__ any) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n || is_src[g] || !(D[g] < seed[g])) return;
-    const int p = pred[g];
-    if (p < 0 || p >= n) { any[1] = 1; return; }              // no tight predecessor: cannot happen at a fixed point
-    if (is_src[p]) return;
-    pred[g] = pred[p];
-    any[0] = 1;
-}
-__global__ __launch_bounds__(256) void cluster_owner(int n, const double* __restrict__ D, const double* __restrict__ seed, const unsigned char* __restrict__ is_src,
-                                                     const int* __restrict__ pred, int* nearest) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n || is_src[g] || !(D[g] < seed[g])) return;
-    nearest[g] = nearest[pred[g]];                            // (a source's entry is its sample index and is never written here)
-}
-
 }  // namespace gmgh

@@ -66,3 +66,57 @@ def test_fine_order_is_the_breadth_first_order_of_the_point_graph(cabi):
     V2, F2 = meshgen.torus_mesh(300, 300)
     S2, _ = meshgen.cotan_laplacian(V2, F2)
     assert cabi.Hierarchy(V2, meshgen.neighbors_from_stiffness(S2), lower_bound=4000).fine_order is None
+
+
+@pytest.mark.parametrize("kind,ratio", [("torus", 8.0), ("torus-random", 8.0), ("sphere", 8.0), ("pointcloud", 8.0), ("open-cylinder", 8.0),
+                                        ("sphere", 1.3), ("pointcloud", 1.3), ("torus", 27.0)])
+def test_clustering_sweep_after_the_disk_sampler_only_resets_the_samples(cabi, kind, ratio):
+    """multigrid_solver.cpp:1015-1056 after :975-1013: the multi-source Dijkstra starts from distances the sampler seeded with
+    exactly the candidates the sweep would offer, so it cannot lower anything (argument in host_hierarchy.hpp::voronoi_dijkstra) and
+    the builder skips the heap.  GMG_HIERARCHY_FULL_DIJKSTRA=1 runs the sweep as the reference writes it: same owners for every
+    point of every level, same hierarchy bit for bit -- on regular, randomly numbered, irregular, open and point-cloud inputs, with
+    small and large sampling radii."""
+    import os
+    if kind.startswith("torus"):
+        V, F = meshgen.torus_mesh(150, 140, order="random" if kind.endswith("random") else "natural")
+    elif kind == "sphere":
+        V, F = meshgen.sphere_mesh(20_000)
+    elif kind == "open-cylinder":
+        V, F = meshgen.open_cylinder_mesh(150, 130)
+    if kind == "pointcloud":
+        V = meshgen.torus_points(20_000, noise=0.002)
+        S, _ = meshgen.knn_graph_laplacian(V, 8)
+    else:
+        S, _ = meshgen.cotan_laplacian(V, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    try:
+        os.environ["GMG_HIERARCHY_FULL_DIJKSTRA"] = "1"
+        Hf = cabi.Hierarchy(V, neigh, ratio=ratio, lower_bound=50)
+    finally:
+        os.environ.pop("GMG_HIERARCHY_FULL_DIJKSTRA", None)
+    Hs = cabi.Hierarchy(V, neigh, ratio=ratio, lower_bound=50)
+    assert len(Hf.U) == len(Hs.U) >= 2
+    for a, b in zip(Hf.nearest, Hs.nearest):
+        assert np.array_equal(a, b)
+    for a, b in zip(Hf.U, Hs.U):
+        assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+
+
+def test_a_neighbour_behind_a_gap_in_a_table_row_makes_the_full_sweep_run(cabi):
+    """The sampler stops at a row's first -1, the Dijkstra sweep skips over it: with such a row the shortcut's argument does not hold,
+    and the builder must fall back to the sweep (same result as forcing it)."""
+    import os
+    V, neigh = _inputs("torus")
+    neigh = np.ascontiguousarray(np.concatenate([neigh[:, :2], -np.ones((len(neigh), 1), neigh.dtype), neigh[:, 2:]], axis=1))
+    try:
+        os.environ["GMG_HIERARCHY_FULL_DIJKSTRA"] = "1"
+        Hf = cabi.Hierarchy(V, neigh, lower_bound=15)
+    finally:
+        os.environ.pop("GMG_HIERARCHY_FULL_DIJKSTRA", None)
+    Hs = cabi.Hierarchy(V, neigh, lower_bound=15)
+    assert len(Hf.U) == len(Hs.U) >= 1
+    for a, b in zip(Hf.nearest, Hs.nearest):
+        assert np.array_equal(a, b)
+    # (with the gap the sweep does real work: points reached only through the hidden neighbours change owner)
+    V0, n0 = _inputs("torus")
+    assert not np.array_equal(cabi.Hierarchy(V0, n0, lower_bound=15).nearest[0], Hs.nearest[0])
