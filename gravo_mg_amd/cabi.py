@@ -111,6 +111,7 @@ SIGNATURES = {
     "gmg_p2p_load": (C.c_int, [_vp, _dp, _dp]),
     "gmg_p2p_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "gmg_p2p_fetch": (C.c_int, [_vp, _dp]),
+    "gmg_p2p_solve": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "gmg_p2p_bench_exchange": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
@@ -333,6 +334,19 @@ class Engine:
         self.pre_iters, self.post_iters = int(pre_iters), int(post_iters)
         self.gs_omega = float(cfg.gs_omega)       # relaxation factor of the level-0 sweep (engine default unless given)
 
+    @classmethod
+    def borrow(cls, handle: int) -> "Engine":
+        """View of a gmg_handle somebody else owns (e.g. the one inside gravomg.MultigridSolver, prepare_system()): never destroyed
+        from here."""
+        self = cls.__new__(cls)
+        self._h = _vp(int(handle))
+        self._borrowed = True
+        self._n0 = None
+        self._sizes = []
+        self.pre_iters = self.post_iters = None
+        self.gs_omega = None
+        return self
+
     # -- plumbing
     def _chk(self, rc: int):
         if rc:
@@ -340,7 +354,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().gmg_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                lib().gmg_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -616,6 +631,15 @@ class P2PCycle:
         X = np.empty((self._n, self.d), order="F")
         self.eng._chk(lib().gmg_p2p_fetch(self.eng._h, _pd(X)))
         return X
+
+    def solve(self, b, x0, tol=1e-4, stop_type=2, max_iter=100):
+        """gmg_p2p_solve: (x, iterations, residue); collective."""
+        B = _f64(b)
+        X = np.array(_f64(x0), order="F", copy=True)
+        assert B.shape == (self._n, self.d) and X.shape == B.shape
+        it, res = C.c_int(), C.c_double()
+        self.eng._chk(lib().gmg_p2p_solve(self.eng._h, _pd(B), _pd(X), float(tol), int(stop_type), int(max_iter), C.byref(it), C.byref(res)))
+        return X, it.value, res.value
 
     def bench_exchange(self, reps: int = 100) -> float:
         out = C.c_double()

@@ -294,6 +294,16 @@ public:
     std::map<std::string, double> solver_timing() { return solver->solverTiming; }
     std::map<std::string, double> hierarchy_timing() { return solver->hierarchyTiming; }
     std::vector<std::tuple<double, double>> convergence() { return solver->convergence; }
+    // multi-GPU hook (not upstream; gravomg.MultigridSolver.enable_distributed): system set on this rank's engine, no solve.
+    // Returns (C-ABI handle of the engine as an integer -- owned by this object --, layout generation).
+    std::tuple<uintptr_t, long> prepare_system(py::object lhs) {
+        MappedSparse mapped = map_system_matrix(lhs, symCache);
+        gmg_handle h = nullptr;
+        long gen = 0;
+        solver->clearError();
+        if (solver->prepareSystem(mapped.m, &h, &gen) != GMG_OK) { check(); throw std::runtime_error("prepare_system failed"); }
+        return std::make_tuple((uintptr_t)h, gen);
+    }
     void set_engine_option(const std::string& key, double value) {
         gmg_config& c = solver->engineConfig;
         if (key == "smoother") c.smoother = (int)value;
@@ -304,6 +314,9 @@ public:
         else if (key == "block_rows") c.block_rows = (int)value;
         else if (key == "block_from_level") c.block_from_level = (int)value;
         else if (key == "device") c.device = (int)value;
+        else if (key == "row_align") c.row_align = (int)value;
+        else if (key == "block_lanes") c.block_lanes = (int)value;
+        else if (key == "dist_shard_levels") c.dist_shard_levels = (int)value;
         else throw std::invalid_argument("unknown engine option: " + key);
     }
 
@@ -347,5 +360,6 @@ PYBIND11_MODULE(gravomg_bindings, m) {
         .def("solver_timing", &MultigridSolver::solver_timing)
         .def("hierarchy_timing", &MultigridSolver::hierarchy_timing)
         .def("convergence", &MultigridSolver::convergence)
+        .def("prepare_system", &MultigridSolver::prepare_system, py::arg("lhs"))
         .def("set_engine_option", &MultigridSolver::set_engine_option, py::arg("key"), py::arg("value"));
 }

@@ -618,6 +618,25 @@ int gmg_p2p_fetch(gmg_handle h, double* x) try {
     return to_host(h, 0, l.x, p->d, x);
 } GMG_CATCH_H
 
+// gmg_solve over the ranks: x0 in, solution out (complete on every rank).  The reference's loop, multigrid_solver.cpp:1408-1419:
+// do { V-cycle; residualCheck } while (residue > tol && it < maxIter) -- every rank sees the same residues (the norm sums are
+// all-reduced in rank order), so every rank leaves the loop in the same iteration.  Collective.
+int gmg_p2p_solve(gmg_handle h, const double* b, double* x, double tol, int stop_type, int max_iter, int* iters_out, double* residue_out) try {
+    if (!h) return GMG_ERR_INVALID;
+    if (!b || !x || max_iter < 1) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    int rc = gmg_p2p_load(h, b, x);
+    if (rc) return rc;
+    int it = 0;
+    double residue = 0.0;
+    do {
+        if ((rc = gmg_p2p_cycles(h, 1, stop_type, &residue))) return rc;
+        ++it;
+    } while (residue > tol && it < max_iter);
+    if (iters_out) *iters_out = it;
+    if (residue_out) *residue_out = residue;
+    return gmg_p2p_fetch(h, x);
+} GMG_CATCH_H
+
 // Average duration (ms) of one exchange of the named kind (push + wait + pull, one launch), `reps` back to back; collective --
 // every rank calls it with the same arguments.  Kinds: "color<k>" (halo of colour k), "halo_all", "rows0" (every rank's rows of
 // a level-0 vector), and with level 1 partitioned "x1_halo", "rows1", "r0_halo".  The values moved are whatever the vectors

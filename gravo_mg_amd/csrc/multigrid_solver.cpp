@@ -255,7 +255,17 @@ int MultigridSolver::ensureSystem(const SparseMatrix& LHS) {
         if ((rc = gmg_set_system(engine_, LHS.rows(), LHS.outerPtr(), LHS.innerPtr(), LHS.valuePtr()))) { err_ = gmg_last_error(engine_); systemReady_ = false; return rc; }
         uploadedLHS_ = digLHS;
         systemReady_ = true;
+        ++systemGeneration_;
     }
+    return GMG_OK;
+}
+
+int MultigridSolver::prepareSystem(const SparseMatrix& LHS, gmg_handle* handle, long* generation) {
+    if (U.empty()) { err_ = "the hierarchy has no levels (mesh smaller than lower_bound?)"; return GMG_ERR_STATE; }
+    int rc = ensureSystem(LHS);
+    if (rc) return rc;
+    if (handle) *handle = engine_;
+    if (generation) *generation = systemGeneration_;
     return GMG_OK;
 }
 

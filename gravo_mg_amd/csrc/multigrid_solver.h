@@ -133,6 +133,10 @@ public:
     int prepareEngine();
     const char* lastError() const;
     void clearError() { err_.clear(); }
+    /* Multi-GPU hook (not in the reference): brings the engine to "system set" for LHS without solving and hands out the engine's
+       C-ABI handle (owned by this object) and a counter that changes whenever the device layout was rebuilt, so that a caller can
+       drive the engine-driven multi-GPU cycle (gmg_p2p_*, include/gravomg_hip.h) on it.  Returns a gmg status. */
+    int prepareSystem(const SparseMatrix& LHS, gmg_handle* handle, long* generation);
 
 private:
     int ensureEngine();
@@ -143,6 +147,7 @@ private:
     std::vector<std::pair<uint64_t, uint64_t>> fineOrderFor_;  // ... and the digests of the U it belongs to
     std::pair<uint64_t, uint64_t> uploadedLHS_{0, 0};
     bool systemReady_ = false;
+    long systemGeneration_ = 0;                                // bumped by every gmg_set_system (prepareSystem)
     bool exactGsActive_ = false;                               // Gauss-Seidel on every level instead of the configured smoothers ...
     std::pair<uint64_t, uint64_t> exactGsFor_{0, 0};           // ... for the system with this digest only (solve())
     gmg_config createdWith_;

@@ -112,10 +112,59 @@ class MultigridSolver(object):
             pos if normals is None else _points(normals, "normals", 3), bool(verbose), bool(debug), bool(ablation), int(ablation_num_points),
             bool(ablation_random))
 
+        self._solve_args = (float(tolerance), int(stopping_criteria), int(max_iter))
+        self._dist = None
+
     def solve(self, lhs, rhs):
         """x with lhs @ x = rhs to the tolerance given at construction, V-cycles from the initial guess x0 = rhs
-        (gravomg_bindings/src/cpp/core.cpp:68-72).  rhs (n,) or (n, d); returns an (n, d) array."""
+        (gravomg_bindings/src/cpp/core.cpp:68-72).  rhs (n,) or (n, d); returns an (n, d) array.  After enable_distributed() the
+        V-cycles run row-partitioned over the ranks (same iterates, same result on every rank)."""
+        if self._dist is not None:
+            return self._solve_distributed(_sparse(lhs, "lhs"), _points(rhs, "rhs"))
         return self.solver.solve(_sparse(lhs, "lhs"), _points(rhs, "rhs"))
+
+    # ---- one process per GPU (not upstream) -------------------------------------------------------------------------------------------
+    def enable_distributed(self, rank, world, all_gather, device=None, shard_levels=2):
+        """Make solve() a COLLECTIVE over `world` processes (one per GPU), each holding a MultigridSolver built from the same inputs:
+        level 0 is partitioned by rows per colour (levels >= 1 by blocks / replicated, `shard_levels`), exchanges are device-initiated
+        stores into the peers' mailboxes (include/gravomg_hip.h, "multi-GPU, engine-driven").  The colours are
+        global, so the iterates -- and the returned x, on every rank -- are those of the single-GPU solve.
+
+        all_gather(obj) -> list with every rank's obj in rank order, e.g.
+            def all_gather(o): out = [None] * world; torch.distributed.all_gather_object(out, o); return out
+        (the only thing the ranks exchange through the caller: 1 KB connection records, once per system layout).
+        device: HIP device of this rank (default: rank).  Call before the first solve()."""
+        rank, world = int(rank), int(world)
+        if not (0 <= rank < world):
+            raise ValueError("rank must be in [0, world)")
+        if world > 1:
+            self.solver.set_engine_option("row_align", 64 * world)
+            self.solver.set_engine_option("dist_shard_levels", int(shard_levels))
+            self.solver.set_engine_option("device", rank if device is None else int(device))
+            self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None}
+        else:
+            self._dist = None
+
+    def _solve_distributed(self, lhs, rhs):
+        import os
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+        if root not in sys.path:
+            sys.path.insert(0, root)
+        from gravo_mg_amd import cabi                     # ctypes view of the same libgravomg_hip.so
+        D = self._dist
+        tol, stop_type, max_iter = self._solve_args
+        handle, generation = self.solver.prepare_system(lhs)
+        key = (handle, generation, rhs.shape[1])
+        if D["key"] != key:                               # new layout (or another d): partition, export, connect
+            eng = cabi.Engine.borrow(handle)
+            cyc = cabi.P2PCycle(eng, D["rank"], D["world"], rhs.shape[1])
+            cyc.connect(D["all_gather"](cyc.export()))
+            D["cycle"], D["key"] = cyc, key
+        # x0 = rhs, as the binding does; then gmg_p2p_solve: do { V-cycle; residualCheck } while (residue > tol && it < maxIter)
+        x, it, residue = D["cycle"].solve(rhs, rhs, tol=tol, stop_type=stop_type, max_iter=max_iter)
+        self.distributed_info = {"iterations": it, "residue": residue, "world": D["world"]}
+        return np.ascontiguousarray(x)
 
     def residual(self, lhs, rhs, solution, type=2):
         """The reference's residualCheck of `solution`: type 0 ||r||/||b||, 1 M^-1-weighted, 2 M-weighted, 3 ||A X - B||_F."""

@@ -251,6 +251,11 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs);
 int gmg_p2p_load(gmg_handle h, const double* b, const double* x0);
 int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
 int gmg_p2p_fetch(gmg_handle h, double* x);
+/* gmg_solve as a collective: load (x = initial guess, n x d column-major like b), the reference's do-while loop
+ * (multigrid_solver.cpp:1408-1419) of gmg_p2p_cycles(1) until residue <= tol or max_iter cycles, fetch into x.  The residues are
+ * identical on all ranks, so all ranks stop in the same iteration.  This is what gravomg.MultigridSolver.solve() runs after
+ * enable_distributed() (gravo_mg_amd/dropin/gravomg/core.py). */
+int gmg_p2p_solve(gmg_handle h, const double* b, double* x, double tol, int stop_type, int max_iter, int* iters_out, double* residue_out);
 /* average duration (ms) of one colour-0 halo exchange, `reps` back to back (collective; measurement) */
 int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg);
 /* the same for any exchange of the cycle: "color<k>", "halo_all", "rows0" (every rank's level-0 rows: what a cycle with level 1

@@ -149,3 +149,70 @@ def test_a_missing_peer_is_an_error_not_a_hang(cabi):
     msg, dt = got[0]
     assert "timed out" in msg, got
     assert 3.0 <= dt <= 8.5, dt          # one 4 s wait, not one per queued exchange
+
+
+def _dropin_inputs():
+    from gravo_mg_amd import meshgen
+    V, F = meshgen.torus_mesh(150, 140)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    lhs, rhs = meshgen.smoothing_system(S, mass, V)           # the demos' call: n x 3 right-hand side
+    return V, meshgen.neighbors_from_stiffness(S), mass, lhs, rhs
+
+
+def _dropin_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "gravo_mg_amd", "dropin"))
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        import scipy.sparse as sp
+        import torch.distributed as dist
+        import gravomg
+        from tests.test_gpu_p2p import _dropin_inputs
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        V, neigh, mass, lhs, rhs = _dropin_inputs()
+        solver = gravomg.MultigridSolver(V, neigh, sp.diags(mass).tocsc(), lower_bound=100, tolerance=1e-6)
+
+        def all_gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        solver.enable_distributed(rank, world, all_gather, device=0)           # every rank on the one GPU of the test box
+        x = solver.solve(lhs, rhs)
+        x2 = solver.solve(lhs, 2.0 * rhs)                                      # same layout: no second connect
+        dist.barrier()
+        q.put((rank, x, x2, dict(solver.distributed_info), None))
+        dist.destroy_process_group()
+    except Exception as e:              # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, None, traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multigridsolver_solve_as_a_collective_over_ranks(cabi, world):
+    """gravomg.MultigridSolver.enable_distributed(): solve() of the drop-in class runs the engine-driven multi-GPU cycle on the engine
+    it already owns (`prepare_system` hands out its C-ABI handle) -- here `world` processes on one GPU.  Same number of V-cycles and,
+    bit for bit, the single-process solution on every rank (global colours: the partition does not change the iterates)."""
+    import scipy.sparse as sp
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "gravo_mg_amd", "dropin"))
+    import gravomg
+    V, neigh, mass, lhs, rhs = _dropin_inputs()
+    single = gravomg.MultigridSolver(V, neigh, sp.diags(mass).tocsc(), lower_bound=100, tolerance=1e-6)
+    want = single.solve(lhs, rhs)
+    want_iters = int(single.solver_timing["iterations"])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dropin_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, x, x2, info, err in got:
+        assert err is None, err
+        assert info["iterations"] == want_iters and info["residue"] <= 1e-6 and info["world"] == world
+        assert np.array_equal(x, want), (rank, np.abs(x - want).max())
+        np.testing.assert_allclose(x2, 2.0 * want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
