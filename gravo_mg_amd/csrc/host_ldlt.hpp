@@ -23,9 +23,16 @@
 #include <sched.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <future>
+#include <memory>
+#include <new>
 #include <string>
 
 #include "host_sparse.hpp"
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 
 namespace gmg {
 
@@ -188,103 +195,137 @@ private:
     // Nested dissection with breadth-first level-set separators: O(E log n), fill O(n log n) on mesh-like graphs.
     // A region is split by the middle level of a BFS started at a pseudo-peripheral vertex (edges of a BFS only join
     // equal or adjacent levels, so a whole level separates); the two halves are ordered first, the separator last.
+    // order(region) = order(a) ++ order(b) ++ separator: every region owns a contiguous slice of perm, so the two halves are ordered by
+    // independent tasks (the first split walks the whole graph on one thread, the rest runs on up to 16); the result does not depend
+    // on how the work was spread.
+    struct NdShared {
+        const Compressed* A;
+        std::unique_ptr<std::atomic<int>[]> region;       // vertex -> id of the region it currently belongs to (-1: in a separator)
+        std::vector<int> level;                           // BFS levels (entries of a region are only touched by the task that owns it)
+        std::atomic<int> next_region{1};
+        int* perm;
+    };
     void nested_dissection(const Compressed& A) {
-        perm.clear(); perm.reserve(n);
-        std::vector<int> region(n, 0), level(n, -1), queue;
-        int next_region = 1;
-        struct Task { std::vector<int> nodes; int id; };
-        // explicit stack; a task's separator is emitted AFTER its two halves, so push a marker task holding it
-        struct Item { std::vector<int> nodes; int id; bool emit; };
-        std::vector<Item> stack;
-        { std::vector<int> all(n); for (int i = 0; i < n; ++i) all[i] = i; stack.push_back({std::move(all), 0, false}); }
-        std::vector<int> out_rev;      // built in reverse (separators first), reversed at the end
-        out_rev.reserve(n);
-        while (!stack.empty()) {
-            Item it = std::move(stack.back());
-            stack.pop_back();
-            if (it.emit) { for (auto r = it.nodes.rbegin(); r != it.nodes.rend(); ++r) out_rev.push_back(*r); continue; }
-            if ((int)it.nodes.size() <= kLeaf) {      // leaf region: exact minimum degree on its own subgraph
-                std::vector<int> ord = leaf_min_degree(A, it.nodes, region, it.id);
-                for (auto r = ord.rbegin(); r != ord.rend(); ++r) out_rev.push_back(*r);
-                continue;
-            }
-            const int id = it.id;
-            auto bfs = [&](int start) {      // levels inside region `id`; returns the visit order in `queue`
-                queue.clear(); queue.push_back(start); level[start] = 0;
-                for (size_t h = 0; h < queue.size(); ++h) {
-                    int v = queue[h];
-                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { int w = A.idx[p]; if (region[w] == id && level[w] < 0) { level[w] = level[v] + 1; queue.push_back(w); } }
-                }
-            };
-            for (int v : it.nodes) level[v] = -1;
-            bfs(it.nodes[0]);
-            if (queue.size() < it.nodes.size()) {
-                // disconnected region: peel this component off and handle both parts independently
-                std::vector<int> comp(queue), rest;
-                const int idc = next_region++, idr = next_region++;
-                for (int v : comp) region[v] = idc;
-                for (int v : it.nodes) if (level[v] < 0) { rest.push_back(v); region[v] = idr; }
-                stack.push_back({std::move(rest), idr, false});
-                stack.push_back({std::move(comp), idc, false});
-                continue;
-            }
-            const int far = queue.back();
-            for (int v : it.nodes) level[v] = -1;
-            bfs(far);
-            const int depth = level[queue.back()];
-            if (depth < 2) { for (auto r = it.nodes.rbegin(); r != it.nodes.rend(); ++r) out_rev.push_back(*r); continue; }   // clique-like: no separator
-            // middle level by vertex count
-            std::vector<int> cnt(depth + 1, 0);
-            for (int v : queue) cnt[level[v]]++;
-            int mid = 1, acc = cnt[0];
-            while (mid < depth - 1 && acc + cnt[mid] < (int)queue.size() / 2) { acc += cnt[mid]; ++mid; }
-            std::vector<int> a, b, sep;
-            const int ida = next_region++, idb = next_region++;
-            for (int v : queue) {
-                if (level[v] < mid) { a.push_back(v); region[v] = ida; }
-                else if (level[v] > mid) { b.push_back(v); region[v] = idb; }
-                else { sep.push_back(v); region[v] = -1; }
-            }
-            // processing order (stack, reversed output): separator is emitted first into out_rev => eliminated last
-            stack.push_back({std::move(a), ida, false});
-            stack.push_back({std::move(b), idb, false});
-            stack.push_back({std::move(sep), -1, true});
+        perm.assign(n, 0);
+        NdShared S;
+        S.A = &A;
+        S.region.reset(new std::atomic<int>[(size_t)std::max(n, 1)]);
+        for (int i = 0; i < n; ++i) S.region[i].store(0, std::memory_order_relaxed);
+        S.level.assign(n, -1);
+        S.perm = perm.data();
+        std::vector<int> all(n);
+        for (int i = 0; i < n; ++i) all[i] = i;
+        nd_order(S, std::move(all), 0, 0, 0);
+    }
+    static void nd_order(NdShared& S, std::vector<int> nodes, int id, int off, int depth) {
+        const Compressed& A = *S.A;
+        int* out = S.perm + off;
+        auto in_region = [&](int w, int rid) { return S.region[w].load(std::memory_order_relaxed) == rid; };
+        if ((int)nodes.size() <= kLeaf) {      // leaf region: exact minimum degree on its own subgraph
+            const std::vector<int> ord = leaf_min_degree(A, nodes, S.region.get(), id);
+            std::copy(ord.begin(), ord.end(), out);
+            return;
         }
-        perm.assign(out_rev.rbegin(), out_rev.rend());
+        std::vector<int> queue;
+        queue.reserve(nodes.size());
+        auto bfs = [&](int start) {      // levels inside region `id`; the visit order ends up in `queue`
+            queue.clear(); queue.push_back(start); S.level[start] = 0;
+            for (size_t h = 0; h < queue.size(); ++h) {
+                const int v = queue[h];
+                for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { const int w = A.idx[p]; if (in_region(w, id) && S.level[w] < 0) { S.level[w] = S.level[v] + 1; queue.push_back(w); } }
+            }
+        };
+        // two halves: the first on another thread while the region is big and the tree of tasks still narrow
+        auto both = [&](std::vector<int>&& first, int id1, int off1, std::vector<int>&& second, int id2, int off2) {
+            if (depth < 4 && first.size() > 600 && second.size() > 600) {
+                auto other = std::async(std::launch::async, [&S, id1, off1, depth, f = std::move(first)]() mutable { nd_order(S, std::move(f), id1, off1, depth + 1); });
+                nd_order(S, std::move(second), id2, off2, depth + 1);
+                other.get();
+            } else {
+                nd_order(S, std::move(first), id1, off1, depth + 1);
+                nd_order(S, std::move(second), id2, off2, depth + 1);
+            }
+        };
+        for (int v : nodes) S.level[v] = -1;
+        bfs(nodes[0]);
+        if (queue.size() < nodes.size()) {
+            // disconnected region: peel this component off and handle both parts independently (order: the rest, then the component)
+            std::vector<int> comp(queue), rest;
+            const int idc = S.next_region.fetch_add(2), idr = idc + 1;
+            for (int v : comp) S.region[v].store(idc, std::memory_order_relaxed);
+            for (int v : nodes) if (S.level[v] < 0) { rest.push_back(v); S.region[v].store(idr, std::memory_order_relaxed); }
+            const int nrest = (int)rest.size();
+            both(std::move(rest), idr, off, std::move(comp), idc, off + nrest);
+            return;
+        }
+        const int far = queue.back();
+        for (int v : nodes) S.level[v] = -1;
+        bfs(far);
+        const int deep = S.level[queue.back()];
+        if (deep < 2) { std::copy(nodes.begin(), nodes.end(), out); return; }   // clique-like: no separator
+        // middle level by vertex count
+        std::vector<int> cnt(deep + 1, 0);
+        for (int v : queue) cnt[S.level[v]]++;
+        int mid = 1, acc = cnt[0];
+        while (mid < deep - 1 && acc + cnt[mid] < (int)queue.size() / 2) { acc += cnt[mid]; ++mid; }
+        std::vector<int> a, b, sep;
+        const int ida = S.next_region.fetch_add(2), idb = ida + 1;
+        for (int v : queue) {
+            if (S.level[v] < mid) { a.push_back(v); S.region[v].store(ida, std::memory_order_relaxed); }
+            else if (S.level[v] > mid) { b.push_back(v); S.region[v].store(idb, std::memory_order_relaxed); }
+            else { sep.push_back(v); S.region[v].store(-1, std::memory_order_relaxed); }
+        }
+        const int na = (int)a.size(), nb = (int)b.size();
+        std::copy(sep.begin(), sep.end(), out + na + nb);        // the separator is eliminated last
+        both(std::move(a), ida, off, std::move(b), idb, off + na);
     }
 
     // Exact minimum degree restricted to the vertices of one region (ids local to `nodes`).
-    static std::vector<int> leaf_min_degree(const Compressed& A, const std::vector<int>& nodes, const std::vector<int>& region, int id) {
+    // (adjacency as bit rows over the region's own vertices, <= kLeaf / 64 words each, like min_degree below: eliminating v ORs its
+    // row into each neighbour's.  Ties go to the vertex that comes first in `nodes`.  The sorted-list version this replaces spent
+    // 1-3 ms per leaf in set unions; the orderings are the same.)
+    __attribute__((target("popcnt"))) static std::vector<int> leaf_min_degree(const Compressed& A, const std::vector<int>& nodes, const std::atomic<int>* region, int id) {
         const int m = (int)nodes.size();
-        std::vector<int> local(m);
+        const int W = (m + 63) / 64;
         std::vector<std::pair<int, int>> key(m);
         for (int i = 0; i < m; ++i) key[i] = {nodes[i], i};
         std::sort(key.begin(), key.end());
         auto find = [&](int g) { auto it = std::lower_bound(key.begin(), key.end(), std::make_pair(g, -1)); return it->second; };
-        std::vector<std::vector<int>> adj(m);
+        std::vector<uint64_t> bits((size_t)m * W, 0);
+        auto row = [&](int v) { return bits.data() + (size_t)v * W; };
         for (int i = 0; i < m; ++i) {
             const int g = nodes[i];
-            for (int p = A.ptr[g]; p < A.ptr[g + 1]; ++p) { int w = A.idx[p]; if (w != g && region[w] == id) adj[i].push_back(find(w)); }
-            std::sort(adj[i].begin(), adj[i].end());
-            adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+            for (int p = A.ptr[g]; p < A.ptr[g + 1]; ++p) {
+                const int w = A.idx[p];
+                if (w != g && region[w].load(std::memory_order_relaxed) == id) { const int j = find(w); row(i)[j >> 6] |= 1ull << (j & 63); row(j)[i >> 6] |= 1ull << (i & 63); }
+            }
         }
+        std::vector<int> deg(m, 0), out;
+        for (int v = 0; v < m; ++v) { const uint64_t* r = row(v); for (int q = 0; q < W; ++q) deg[v] += __builtin_popcountll(r[q]); }
         std::vector<char> done(m, 0);
-        std::vector<int> out, merged;
         out.reserve(m);
         for (int step = 0; step < m; ++step) {
-            int v = -1; size_t best = ~(size_t)0;
-            for (int j = 0; j < m; ++j) if (!done[j] && adj[j].size() < best) { best = adj[j].size(); v = j; }
+            int v = -1, best = m + 1;
+            for (int j = 0; j < m; ++j) if (!done[j] && deg[j] < best) { best = deg[j]; v = j; }
             done[v] = 1;
             out.push_back(nodes[v]);
-            const std::vector<int>& nv = adj[v];
-            for (int u : nv) {
-                merged.clear();
-                std::set_union(adj[u].begin(), adj[u].end(), nv.begin(), nv.end(), std::back_inserter(merged));
-                std::vector<int>& au = adj[u];
-                au.clear();
-                for (int w : merged) if (w != u && w != v) au.push_back(w);
+            const uint64_t* rv = row(v);
+            for (int wq = 0; wq < W; ++wq) {
+                uint64_t mask = rv[wq];
+                while (mask) {
+                    const int u = (wq << 6) + __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    uint64_t* ru = row(u);                   // adj[u] = (adj[u] | adj[v]) \ {u, v}
+                    int d = deg[u];
+                    for (int q = 0; q < W; ++q) {
+                        const uint64_t add = rv[q] & ~ru[q];
+                        if (add) { d += __builtin_popcountll(add); ru[q] |= add; }
+                    }
+                    ru[u >> 6] &= ~(1ull << (u & 63));
+                    ru[v >> 6] &= ~(1ull << (v & 63));
+                    deg[u] = d - 2;
+                }
             }
-            adj[v].clear();
         }
         return out;
     }
@@ -481,8 +522,10 @@ public:
             perm = ord.perm;
             n = A.n_outer;
             phase_ms[0] = ms(t0); t0 = clk::now();
+            structure_error_ = false;
             symbolic(A);
             phase_ms[1] = ms(t0);
+            if (structure_error_) return false;
         }
         auto t1 = clk::now();
         numeric(A);
@@ -574,6 +617,7 @@ public:
 private:
     static constexpr int kMaxWidth = 48;        // columns per supernode (panel stays in L1/L2)
     bool symbolic_ready_ = false;
+    bool structure_error_ = false;              // symbolic(): a supernode's row list did not match its column count (never seen)
     long nnz_l_ = 0;
     int max_rows_ = 0;                           // longest below-diagonal row structure of a supernode
     // split of the elimination tree for the back-substitution (plan_split): parts_ sets of disjoint subtrees, and the part above
@@ -592,11 +636,26 @@ private:
     std::vector<int> sn_of_;                     // column -> supernode
     std::vector<int> rows_ptr_, rows_;           // below-diagonal row structure of each supernode (sorted)
     std::vector<size_t> pan_ptr_;                // offset of each panel in pan_
-    std::vector<double> pan_;                    // panels: (w + r) x w column-major, ld = w + r
+    // panels: (w + r) x w column-major, ld = w + r.  Storage from calloc: a new block is zero without being touched, so the first
+    // factorisation faults its pages in once, while it fills them; a re-factorisation zeroes it on all threads first (a std::vector
+    // touched the 8 MB of the n = 6 608 factor twice on one thread before any use: 4.5 of the 12 ms of the symbolic phase)
+    struct PanelStore {
+        double* p = nullptr; size_t n = 0;
+        PanelStore() = default;
+        PanelStore(const PanelStore& o) { *this = o; }
+        PanelStore& operator=(const PanelStore& o) { if (this != &o) { resize_uninitialised(o.n); if (n) std::memcpy(p, o.p, n * sizeof(double)); fresh = false; } return *this; }
+        ~PanelStore() { std::free(p); }
+        bool fresh = false;      // just allocated with calloc: all zero without having been touched (big blocks come straight from the kernel)
+        void resize_uninitialised(size_t m) { if (m != n) { std::free(p); p = m ? (double*)std::calloc(m, sizeof(double)) : nullptr; if (m && !p) throw std::bad_alloc(); n = m; fresh = true; } }
+        double* data() { return p; } const double* data() const { return p; }
+        size_t size() const { return n; }
+        double operator[](size_t i) const { return p[i]; }
+    };
+    PanelStore pan_;
     std::vector<double> D_;
 
     // upper triangle of P A P^T by columns (row indices only) + elimination tree + column counts of L
-    void upper_and_etree(const Compressed& A, std::vector<int>& parent, std::vector<int>& lnz) {
+    void upper_and_etree(const Compressed& A, std::vector<int>& parent, std::vector<int>& lnz, bool counts = true) {
         inv_.assign(n, 0);
         for (int i = 0; i < n; ++i) inv_[perm[i]] = i;
         Cp_.assign(n + 1, 0);
@@ -612,19 +671,83 @@ private:
             for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) { const int i = inv_[A.idx[p]]; if (i <= k) Ci_[q++] = i; }
         }
         parent.assign(n, -1); lnz.assign(n, 0);
-        std::vector<int> flag(n, -1);
-        for (int k = 0; k < n; ++k) {
-            flag[k] = k;
-            for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
-                int i = Ci_[p];
-                while (i < k && flag[i] != k) { if (parent[i] < 0) parent[i] = k; lnz[i]++; flag[i] = k; i = parent[i]; }
+        if (!counts) {
+            // the tree alone (what the postorder needs): ancestors with path compression, O(nnz(A) alpha) instead of the O(nnz(L)) walk
+            std::vector<int> anc(n, -1);
+            for (int k = 0; k < n; ++k)
+                for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
+                    int i = Ci_[p];
+                    while (i < k) {
+                        const int next = anc[i];
+                        anc[i] = k;
+                        if (next < 0) { parent[i] = k; break; }
+                        if (next == k) break;
+                        i = next;
+                    }
+                }
+            return;
+        }
+        {   // the tree as above ...
+            std::vector<int> anc(n, -1);
+            for (int k = 0; k < n; ++k)
+                for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
+                    int i = Ci_[p];
+                    while (i < k) {
+                        const int next = anc[i];
+                        anc[i] = k;
+                        if (next < 0) { parent[i] = k; break; }
+                        if (next == k) break;
+                        i = next;
+                    }
+                }
+        }
+        // ... and the column counts of L without visiting its entries (Gilbert, Ng, Peyton 1994), valid because the numbering is a
+        // postorder of the tree (every subtree is an interval [first[j], j]).  Row i of L is the subtree T_i spanned by the nonzeros of
+        // row i of A below the diagonal; column j's count is the number of T_i that contain j.  Give +1 to every leaf of T_i, -1 to the
+        // lowest common ancestor of consecutive leaves and -1 to parent(i): the weights inside subtree(j) then sum to 1 exactly when j
+        // is in T_i.  Walking the columns in order, j is a leaf of T_i iff the previous nonzero of row i lies before first[j], and the
+        // common ancestor with the previous leaf is the root of its set in a union-find in which finished columns hang below their
+        // parents.  O(nnz(A) alpha(n)) instead of the O(nnz(L)) row-subtree walk (GMG_LDLT_CHECK_COUNTS=1 runs that walk beside it).
+        std::vector<int> first(n), delta(n, 0), prevnz(n, -1), prevleaf(n, -1), uf(n);
+        for (int j = 0; j < n; ++j) { first[j] = j; uf[j] = j; }
+        for (int j = 0; j < n; ++j) if (parent[j] >= 0 && first[j] < first[parent[j]]) first[parent[j]] = first[j];
+        auto find = [&](int v) { int r = v; while (uf[r] != r) r = uf[r]; while (uf[v] != r) { const int nx = uf[v]; uf[v] = r; v = nx; } return r; };
+        for (int j = 0; j < n; ++j) {
+            const int old = perm[j];
+            for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) {
+                const int i = inv_[A.idx[p]];
+                if (i <= j) continue;
+                if (prevnz[i] < first[j]) {                       // j is a leaf of T_i
+                    delta[j]++;
+                    if (prevleaf[i] >= 0) delta[find(prevleaf[i])]--;
+                    prevleaf[i] = j;
+                }
+                prevnz[i] = j;
             }
+            if (parent[j] >= 0) uf[j] = parent[j];
+        }
+        for (int i = 0; i < n; ++i) {
+            if (prevnz[i] < 0) delta[i]++;                        // no nonzero below the diagonal in row i: T_i = {i}
+            if (parent[i] >= 0) delta[parent[i]]--;
+        }
+        for (int j = 0; j < n; ++j) if (parent[j] >= 0) delta[parent[j]] += delta[j];
+        for (int j = 0; j < n; ++j) lnz[j] = delta[j] - 1;
+        if (std::getenv("GMG_LDLT_CHECK_COUNTS")) {
+            std::vector<int> flag(n, -1), ref(n, 0), par2(n, -1);
+            for (int k = 0; k < n; ++k) {
+                flag[k] = k;
+                for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
+                    int i = Ci_[p];
+                    while (i < k && flag[i] != k) { if (par2[i] < 0) par2[i] = k; ref[i]++; flag[i] = k; i = par2[i]; }
+                }
+            }
+            if (ref != lnz || par2 != parent) { std::fprintf(stderr, "[gmg ldlt] column counts / tree differ from the row-subtree walk\n"); std::abort(); }
         }
     }
 
     void symbolic(const Compressed& A) {
         std::vector<int> parent, lnz;
-        upper_and_etree(A, parent, lnz);
+        upper_and_etree(A, parent, lnz, false);
         {   // postorder the elimination tree (same fill; makes every subtree, hence every supernode, a run of columns)
             std::vector<int> head(n, -1), nxt(n, -1), post, stack;
             for (int j = n - 1; j >= 0; --j) if (parent[j] >= 0) { nxt[j] = head[parent[j]]; head[parent[j]] = j; }
@@ -644,17 +767,8 @@ private:
             perm.swap(p2);
             upper_and_etree(A, parent, lnz);
         }
-        // column structures of L (rows ascending: filled row by row)
-        std::vector<int> Lp(n + 1, 0), fill(n, 0), flag(n, -1);
-        for (int k = 0; k < n; ++k) Lp[k + 1] = Lp[k] + lnz[k];
-        std::vector<int> Li(Lp[n]);
-        for (int k = 0; k < n; ++k) {
-            flag[k] = k;
-            for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
-                int i = Ci_[p];
-                while (i < k && flag[i] != k) { Li[Lp[i] + fill[i]++] = k; flag[i] = k; i = parent[i]; }
-            }
-        }
+        long nnz_l = 0;
+        for (int k = 0; k < n; ++k) nnz_l += lnz[k];
         // fundamental supernodes: column j + 1 joins j's supernode when it is j's parent and has the same structure
         std::vector<int> first;
         int start = 0;
@@ -696,15 +810,38 @@ private:
         }
         rows_.resize(rows_ptr_[ns_]);
         pan_ptr_.assign(ns_ + 1, 0);
-        nnz_l_ = Lp[n];
-        for (int s = 0; s < ns_; ++s) {
-            const int l = sn_first_[s + 1] - 1, w = sn_first_[s + 1] - sn_first_[s];
-            std::copy(Li.begin() + Lp[l], Li.begin() + Lp[l + 1], rows_.begin() + rows_ptr_[s]);
-            pan_ptr_[s + 1] = pan_ptr_[s] + (size_t)(w + lnz[l]) * w;
+        nnz_l_ = nnz_l;
+        // Row structure of every supernode = structure of its last column l: the entries of A below l in the supernode's columns and
+        // what its children hand up (a child of a column of the supernode that lies outside it is the LAST column of its own supernode,
+        // so its structure is that supernode's row list).  Every list is read once by its parent: O(sum of the lists) instead of the
+        // O(nnz(L)) column-by-column fill this replaces; the count must come out as lnz[l].
+        {
+            std::vector<int> kid_head(ns_, -1), kid_next(ns_, -1), mark(n, -1);
+            for (int s = ns_ - 1; s >= 0; --s) {
+                const int l = sn_first_[s + 1] - 1;
+                if (parent[l] >= 0) { const int t = sn_of_[parent[l]]; kid_next[s] = kid_head[t]; kid_head[t] = s; }
+            }
+            for (int s = 0; s < ns_; ++s) {
+                const int f = sn_first_[s], l = sn_first_[s + 1] - 1, w = l - f + 1;
+                int* out = rows_.data() + rows_ptr_[s];
+                const int cap = rows_ptr_[s + 1] - rows_ptr_[s];
+                int cnt = 0;
+                bool over = false;
+                auto add = [&](int i) { if (i > l && mark[i] != s) { mark[i] = s; if (cnt < cap) out[cnt++] = i; else over = true; } };
+                for (int j = f; j <= l; ++j) {
+                    const int old = perm[j];
+                    for (int p = A.ptr[old]; p < A.ptr[old + 1]; ++p) add(inv_[A.idx[p]]);
+                }
+                for (int c = kid_head[s]; c >= 0; c = kid_next[c])
+                    for (int q = rows_ptr_[c]; q < rows_ptr_[c + 1]; ++q) add(rows_[q]);
+                if (over || cnt != cap) { symbolic_ready_ = false; ok = false; structure_error_ = true; return; }
+                std::sort(out, out + cnt);
+                pan_ptr_[s + 1] = pan_ptr_[s] + (size_t)(w + lnz[l]) * w;
+            }
         }
         max_rows_ = 0;
         for (int q = 0; q < ns_; ++q) max_rows_ = std::max(max_rows_, rows_ptr_[q + 1] - rows_ptr_[q]);
-        pan_.assign(pan_ptr_[ns_], 0.0);
+        pan_.resize_uninitialised(pan_ptr_[ns_]);
         D_.assign(n, 0.0);
         plan_split();
         symbolic_ready_ = true;
@@ -915,6 +1052,59 @@ private:
 #endif
 #undef GMG_LDLT_KERNELS
 
+    // panel_update as a register-blocked product (AVX2 + FMA): 8 rows x 4 columns of U per pass over the w columns of the descendant's
+    // panel, instead of one axpy per (column of U, column of the panel) -- the panel is read k1 / 4 times instead of k1 times and U is
+    // written once.  Every entry of U is still ONE accumulator summed over the panel's columns in order with one fused multiply-add
+    // each, the arithmetic the axpy version compiles to.  Rows above a column's diagonal inside a 4-column block are computed too
+    // (into unused storage of U).
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __attribute__((target("avx2,fma"))) static void panel_update_blocked(const double* Lk, int ld, int k, int k1, int w, const double* d, double* U, double* F) {
+        for (int c = 0; c < w; ++c) for (int j = 0; j < k1; ++j) F[(size_t)c * k1 + j] = Lk[(size_t)c * ld + j] * d[c];
+        for (int j0 = 0; j0 < k1; j0 += 4) {
+            const int jn = std::min(4, k1 - j0);
+            int i0 = j0;
+            for (; i0 + 8 <= k; i0 += 8) {
+                __m256d a00 = _mm256_setzero_pd(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00, a30 = a00, a31 = a00;
+                const double* lp = Lk + i0;
+                const double* fp = F + j0;
+                if (jn == 4) {
+                    for (int c = 0; c < w; ++c, lp += ld, fp += k1) {
+                        const __m256d x0 = _mm256_loadu_pd(lp), x1 = _mm256_loadu_pd(lp + 4);
+                        const __m256d b0 = _mm256_broadcast_sd(fp), b1 = _mm256_broadcast_sd(fp + 1), b2 = _mm256_broadcast_sd(fp + 2), b3 = _mm256_broadcast_sd(fp + 3);
+                        a00 = _mm256_fmadd_pd(x0, b0, a00); a01 = _mm256_fmadd_pd(x1, b0, a01);
+                        a10 = _mm256_fmadd_pd(x0, b1, a10); a11 = _mm256_fmadd_pd(x1, b1, a11);
+                        a20 = _mm256_fmadd_pd(x0, b2, a20); a21 = _mm256_fmadd_pd(x1, b2, a21);
+                        a30 = _mm256_fmadd_pd(x0, b3, a30); a31 = _mm256_fmadd_pd(x1, b3, a31);
+                    }
+                    double* u = U + (size_t)j0 * k + i0;
+                    _mm256_storeu_pd(u, a00); _mm256_storeu_pd(u + 4, a01);
+                    _mm256_storeu_pd(u + k, a10); _mm256_storeu_pd(u + k + 4, a11);
+                    _mm256_storeu_pd(u + 2 * (size_t)k, a20); _mm256_storeu_pd(u + 2 * (size_t)k + 4, a21);
+                    _mm256_storeu_pd(u + 3 * (size_t)k, a30); _mm256_storeu_pd(u + 3 * (size_t)k + 4, a31);
+                } else {
+                    for (int jj = 0; jj < jn; ++jj) {
+                        __m256d s0 = _mm256_setzero_pd(), s1 = s0;
+                        const double* l2 = Lk + i0;
+                        for (int c = 0; c < w; ++c, l2 += ld) {
+                            const __m256d b = _mm256_broadcast_sd(F + (size_t)c * k1 + j0 + jj);
+                            s0 = _mm256_fmadd_pd(_mm256_loadu_pd(l2), b, s0); s1 = _mm256_fmadd_pd(_mm256_loadu_pd(l2 + 4), b, s1);
+                        }
+                        _mm256_storeu_pd(U + (size_t)(j0 + jj) * k + i0, s0); _mm256_storeu_pd(U + (size_t)(j0 + jj) * k + i0 + 4, s1);
+                    }
+                }
+            }
+            for (; i0 < k; ++i0)                                   // the last rows, one at a time (same accumulation)
+                for (int jj = 0; jj < jn; ++jj) {
+                    double acc = 0.0;
+                    for (int c = 0; c < w; ++c) acc = __builtin_fma(Lk[(size_t)c * ld + i0], F[(size_t)c * k1 + j0 + jj], acc);
+                    U[(size_t)(j0 + jj) * k + i0] = acc;
+                }
+        }
+    }
+#else
+    static void panel_update_blocked(const double*, int, int, int, int, const double*, double*, double*) {}
+#endif
+
     // forward substitution over the supernodes of one part, ascending.  Rows of the part itself are updated in place; rows above
     // it (the top part, shared with the other half) go to this half's accumulator.
     void forward_part(int part, double* y, double* t, double* acc) const {
@@ -981,11 +1171,18 @@ private:
     }
 
     void numeric(const Compressed& A) {
-        std::fill(pan_.begin(), pan_.end(), 0.0);
+        if (pan_.fresh) pan_.fresh = false;       // first factorisation into this storage: zero already, pages not yet touched
+        else {
+            const size_t chunk = (size_t)1 << 16, nch = (pan_.size() + chunk - 1) / chunk;
+            parallel_ranges((int)nch, hw_threads(), [&](int lo, int hi, int) {
+                const size_t a = (size_t)lo * chunk, e = std::min(pan_.size(), (size_t)hi * chunk);
+                if (a < e) std::memset(pan_.data() + a, 0, (e - a) * sizeof(double));
+            }, 8);
+        }
         const bool avx = has_avx2();
         std::vector<int> relpos(n, -1);          // row -> row index inside the current panel
         std::vector<int> head(ns_, -1), next(ns_, -1), pos(ns_, 0);      // pending descendants of each supernode, their progress
-        std::vector<double> U;
+        std::vector<double> U, Fbuf;
         for (int s = 0; s < ns_; ++s) {
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
             const int* R = rows_.data() + rows_ptr_[s];
@@ -1008,7 +1205,7 @@ private:
                 const int k = rd - p0;
                 const double* Lk = pan_.data() + pan_ptr_[dd] + wd + p0;
                 U.resize((size_t)k * k1);
-                if (avx) panel_update_avx2(Lk, ldd, k, k1, wd, D_.data() + fd, U.data());
+                if (avx) { Fbuf.resize((size_t)wd * k1); panel_update_blocked(Lk, ldd, k, k1, wd, D_.data() + fd, U.data(), Fbuf.data()); }
                 else panel_update_base(Lk, ldd, k, k1, wd, D_.data() + fd, U.data());
                 for (int j = 0; j < k1; ++j) {
                     double* tc = P + (size_t)(Rd[p0 + j] - f) * ld;
