@@ -1741,7 +1741,7 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             f.profile(b, w.data(), &team, reps, ph);
             team.disarm();
             std::fprintf(stderr, "[gmg ldlt] %d threads: %.2f us per solve; max |difference| to the one-thread solve %.1e  (phases: parts down %.1f, top down %.1f, top up %.1f, "
-                         "parts up %.1f us; %d top supernodes)\n", threads, best2, diff, ph[0], ph[1], ph[2], ph[3], (int)ph[4]);
+                         "parts up %.1f us; %d top supernodes in %d chains)\n", threads, best2, diff, ph[0], ph[1], ph[2], ph[3], (int)ph[4], (int)ph[5]);
         }
         { double ph[6]; f.profile(b, w.data(), nullptr, reps, ph);
           std::fprintf(stderr, "[gmg ldlt] 1 thread phases: parts down %.1f, top down %.1f, top up %.1f, parts up %.1f us\n", ph[0], ph[1], ph[2], ph[3]); }

@@ -548,7 +548,7 @@ public:
 
     // scratch of one single-column solve: per part of the elimination tree (+ the top) a gather buffer, per part an accumulator of
     // length n (zero on entry, zero again on exit)
-    size_t scratch_doubles() const { return (size_t)(parts_ + 1) * ((size_t)max_rows_ + 1) + (size_t)parts_ * (size_t)n; }
+    size_t scratch_doubles() const { return (size_t)groups_ * ((size_t)max_rows_ + 1 + (size_t)n); }
 
     void solve(const double* b, double* x, double* work) const {
         std::vector<double> t(scratch_doubles(), 0.0);       // own scratch: callable concurrently (the dense-inverse build does)
@@ -581,7 +581,8 @@ public:
     void split_report(long out[3]) const {
         out[0] = out[1] = split_work_.empty() ? 0 : split_work_[0];
         for (int t = 0; t < parts_; ++t) { out[0] = std::min(out[0], split_work_[t]); out[1] = std::max(out[1], split_work_[t]); }
-        out[2] = split_work_.empty() ? 0 : split_work_[parts_];
+        out[2] = 0;
+        for (int g = parts_; g < groups_ && g < (int)split_work_.size(); ++g) out[2] += split_work_[g];
     }
     int parts() const { return parts_; }
     // measurement aid: microseconds of the four phases of one single-column solve (parts down, top down, top up, parts up) and
@@ -589,29 +590,28 @@ public:
     void profile(const double* b, double* y, SpinTeam* team, int reps, double out[6]) const {
         using clk = std::chrono::steady_clock;
         auto us = [](clk::time_point a) { return std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
-        const size_t nt = (size_t)max_rows_ + 1;
         std::vector<double> tt(scratch_doubles(), 0.0);
         double* t = tt.data();
-        double* ttop = t + nt * (size_t)parts_;
+        const int S = (int)stage_groups_.size();
         for (int k = 0; k < 6; ++k) out[k] = 0.0;
         for (int rep = 0; rep < reps; ++rep) {
             for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-            PartJob job{this, y, t, true};
             auto t0 = clk::now();
-            if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
+            run_stage(0, y, t, true, team);
             out[0] += us(t0); t0 = clk::now();
-            for (int c : top_cols_) { double v = y[c]; for (int q = 0; q < parts_; ++q) { double* a = t + nt * (size_t)(parts_ + 1) + (size_t)n * q; v -= a[c]; a[c] = 0.0; } y[c] = v; }
-            forward_part(parts_, y, ttop, nullptr);
+            for (int st = 1; st < S; ++st) run_stage(st, y, t, true, team);
             out[1] += us(t0); t0 = clk::now();
             for (int j = 0; j < n; ++j) y[j] /= D_[j];
-            backward_part(parts_, y, ttop);
+            for (int st = S - 1; st >= 1; --st) run_stage(st, y, t, false, team);
             out[2] += us(t0); t0 = clk::now();
-            job.forward = false;
-            if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
+            run_stage(0, y, t, false, team);
             out[3] += us(t0);
         }
         for (int k = 0; k < 4; ++k) out[k] /= reps;
-        out[4] = (double)part_sn_[parts_].size();
+        size_t top_sn = 0;
+        for (int g = parts_; g < groups_; ++g) top_sn += part_sn_[g].size();
+        out[4] = (double)top_sn;
+        out[5] = (double)(groups_ - parts_);
     }
 
 private:
@@ -623,11 +623,18 @@ private:
     // split of the elimination tree for the back-substitution (plan_split): parts_ sets of disjoint subtrees, and the part above
     // them ("top": their common ancestors), supernodes ascending in each.  parts_ follows from the factor alone (never from the
     // machine), so the arithmetic -- which subtree's contributions are subtracted in which order -- is the same everywhere
+    // The top is a tree of CHAINS (a separator = a run of supernodes each with one child in the top); chains at the same depth below the
+    // root chain are independent of each other exactly like the parts are, so the way down runs: the parts, then the deepest chains, ...,
+    // then the root chain -- one hand-over per stage, what a group sends to rows above itself goes through its accumulator -- and the
+    // way up the reverse.  At n = 6 608 (8 parts, 7 chains) the longest path through the top is 3 chains of its 7.
     int parts_ = 2;
-    std::vector<std::vector<int>> part_sn_;      // [0 .. parts_): the parts; [parts_]: top
-    std::vector<int> own_rows_;                  // per supernode of a part: leading rows of its structure that lie inside the part
-    std::vector<int> top_cols_;                  // columns of the top supernodes
-    std::vector<long> split_work_;               // panel entries per part, [parts_]: top
+    int groups_ = 3;                             // parts + chains of the top
+    std::vector<std::vector<int>> part_sn_;      // supernodes of every group, ascending: [0 .. parts_) the parts, [parts_ .. groups_) the top's chains
+    std::vector<std::vector<int>> stage_groups_; // groups that run side by side, in the order of the way down: [0] = the parts, ..., last = root chain(s)
+    std::vector<std::vector<int>> group_cols_;   // columns of a chain
+    std::vector<std::vector<int>> group_feeds_;  // groups of earlier stages (whose accumulators a chain takes in), in the order they are subtracted
+    std::vector<int> own_rows_;                  // per supernode: leading rows of its structure that lie inside its own group
+    std::vector<long> split_work_;               // panel entries per group
     mutable std::vector<double> scratch_;        // gathered right-hand-side rows of one supernode (a handle is not thread-safe)
     std::vector<int> inv_;                       // old -> new
     std::vector<int> Cp_, Ci_;                   // upper triangle of P A P^T by columns (pattern)
@@ -893,21 +900,43 @@ private:
             if (in_top[s]) continue;
             half[s] = root_half[s] >= 0 ? root_half[s] : half[parent[s]];
         }
-        part_sn_.assign((size_t)parts_ + 1, std::vector<int>());
-        scratch_.clear();                            // (its layout follows max_rows_ / n / parts_: the accumulators must start from zero)
-        split_work_.assign((size_t)parts_ + 1, 0);
+        // chains of the top: a top supernode continues its parent's chain when it is the parent's only child in the top, else it
+        // starts a chain one level deeper (parents before children: descending order)
+        std::vector<int> top_kids(ns_, 0), chain_depth;
+        for (int s = 0; s < ns_; ++s) if (in_top[s] && parent[s] >= 0 && in_top[parent[s]]) top_kids[parent[s]]++;
+        for (int s = ns_ - 1; s >= 0; --s) {
+            if (!in_top[s]) continue;
+            const int p = parent[s];
+            if (p >= 0 && in_top[p] && top_kids[p] == 1) { half[s] = half[p]; continue; }
+            half[s] = parts_ + (int)chain_depth.size();
+            chain_depth.push_back((p >= 0 && in_top[p]) ? chain_depth[half[p] - parts_] + 1 : 0);
+        }
+        groups_ = parts_ + (int)chain_depth.size();
+        int deepest = -1;
+        for (int d : chain_depth) deepest = std::max(deepest, d);
+        stage_groups_.assign((size_t)deepest + 2, std::vector<int>());
+        for (int q = 0; q < parts_; ++q) stage_groups_[0].push_back(q);
+        for (int g = parts_; g < groups_; ++g) stage_groups_[(size_t)(deepest - chain_depth[g - parts_]) + 1].push_back(g);      // deepest chains first
+        for (auto& st : stage_groups_) std::sort(st.begin(), st.end());
+        part_sn_.assign((size_t)groups_, std::vector<int>());
+        group_cols_.assign((size_t)groups_, std::vector<int>());
+        group_feeds_.assign((size_t)groups_, std::vector<int>());
+        for (size_t st = 1; st < stage_groups_.size(); ++st)
+            for (int g : stage_groups_[st])
+                for (size_t e = 0; e < st; ++e) group_feeds_[g].insert(group_feeds_[g].end(), stage_groups_[e].begin(), stage_groups_[e].end());
+        scratch_.clear();                            // (its layout follows max_rows_ / n / groups_: the accumulators must start from zero)
+        split_work_.assign((size_t)groups_, 0);
         own_rows_.assign(ns_, 0);
-        top_cols_.clear();
         for (int s = 0; s < ns_; ++s) {
-            const int t = half[s] < 0 ? parts_ : half[s];
+            const int t = half[s];
             part_sn_[t].push_back(s);
             split_work_[t] += work[s];
             const int* R = rows_.data() + rows_ptr_[s];
             const int r = rows_ptr_[s + 1] - rows_ptr_[s];
             int k = 0;
-            if (t < parts_) while (k < r && half[sn_of_[R[k]]] == t) ++k;     // ancestors inside the part come first (ascending rows)
-            own_rows_[s] = t < parts_ ? k : r;
-            if (t == parts_) for (int j = sn_first_[s]; j < sn_first_[s + 1]; ++j) top_cols_.push_back(j);
+            while (k < r && half[sn_of_[R[k]]] == t) ++k;     // ancestors inside the group come first (ascending rows = the path to the root)
+            own_rows_[s] = k;
+            if (t >= parts_) for (int j = sn_first_[s]; j < sn_first_[s + 1]; ++j) group_cols_[t].push_back(j);
         }
     }
 
@@ -1134,39 +1163,41 @@ private:
         }
     }
 
-    // One column.  L z = y runs over the parts of the elimination tree (independent: a column's structure lies on its path to the
-    // root), whose contributions to the rows above them are accumulated per part and subtracted in part order, then over the top
-    // part; L^T x = z the other way round.  The arithmetic does not depend on whether / how many threads of `team` share the parts
-    // with this one.  t: scratch_doubles() doubles, accumulators zero on entry and on exit.
-    struct PartJob { const SupernodalLDLT* self; double *y, *t; bool forward; };
-    static void run_part(void* p, int part) {
+    struct PartJob { const SupernodalLDLT* self; double *y, *t; bool forward; const int* groups; };
+    double* group_buffer(double* t, int g) const { return t + ((size_t)max_rows_ + 1) * (size_t)g; }
+    double* group_acc(double* t, int g) const { return t + ((size_t)max_rows_ + 1) * (size_t)groups_ + (size_t)n * (size_t)g; }
+    static void run_part(void* p, int idx) {
         PartJob* j = (PartJob*)p;
         const SupernodalLDLT* S = j->self;
-        const size_t nt = (size_t)S->max_rows_ + 1;
-        double* tp = j->t + nt * (size_t)part;
-        double* acc = j->t + nt * (size_t)(S->parts_ + 1) + (size_t)S->n * (size_t)part;
-        if (j->forward) S->forward_part(part, j->y, tp, acc); else S->backward_part(part, j->y, tp);
-    }
-    void solve_column(const double* b, double* x, double* y, double* t, SpinTeam* team) const {
-        const size_t nt = (size_t)max_rows_ + 1;
-        double* ttop = t + nt * (size_t)parts_;
-        double* acc0 = t + nt * (size_t)(parts_ + 1);
-        for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
-        PartJob job{this, y, t, true};
-        if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
-        for (int c : top_cols_) {
-            double v = y[c];
-            for (int q = 0; q < parts_; ++q) { double* a = acc0 + (size_t)n * q; v -= a[c]; a[c] = 0.0; }
-            y[c] = v;
+        const int g = j->groups[idx];
+        if (!j->forward) { S->backward_part(g, j->y, S->group_buffer(j->t, g)); return; }
+        // a chain first takes in what the groups of the earlier stages sent to its columns, in a fixed order (and leaves their
+        // accumulators zero)
+        for (int c : S->group_cols_[g]) {
+            double v = j->y[c];
+            for (int f : S->group_feeds_[g]) { double* a = S->group_acc(j->t, f); v -= a[c]; a[c] = 0.0; }
+            j->y[c] = v;
         }
-        // (the top part is a chain of the factor's biggest panels.  Sharing the rows / columns of a panel with the team was built
-        // and measured on the GPU box's EPYC 9575F: 41 + 59 us on one thread became 107 + 113 us with eight -- a hand-over per
-        // panel and the panel's cache lines travelling cost more than the 3 us a panel takes; it runs on the calling thread)
-        forward_part(parts_, y, ttop, nullptr);
+        S->forward_part(g, j->y, S->group_buffer(j->t, g), S->group_acc(j->t, g));
+    }
+    void run_stage(int st, double* y, double* t, bool forward, SpinTeam* team) const {
+        const std::vector<int>& gs = stage_groups_[st];
+        PartJob job{this, y, t, forward, gs.data()};
+        if (team) team->run(run_part, &job, (int)gs.size()); else for (int q = 0; q < (int)gs.size(); ++q) run_part(&job, q);
+    }
+    // One column.  L z = y runs stage by stage from the leaves of the elimination tree to its root (the parts, then the chains of the
+    // top by depth): the groups of a stage are independent -- a column's structure lies on its path to the root -- and what they send
+    // to rows above themselves is accumulated per group and subtracted in a fixed order by the chain that owns the row; L^T x = z the
+    // other way round.  The arithmetic does not depend on whether / how many threads of `team` share the groups with this one.
+    // t: scratch_doubles() doubles, accumulators zero on entry and on exit.
+    // (Sharing the rows / columns of single panels with the team was built and measured on the GPU box's EPYC 9575F: 41 + 59 us of
+    // the then sequential top became 107 + 113 us -- a hand-over per panel costs more than the 3 us a panel takes.)
+    void solve_column(const double* b, double* x, double* y, double* t, SpinTeam* team) const {
+        const int S = (int)stage_groups_.size();
+        for (int i = 0; i < n; ++i) y[i] = b[perm[i]];
+        for (int st = 0; st < S; ++st) run_stage(st, y, t, true, team);
         for (int j = 0; j < n; ++j) y[j] /= D_[j];
-        backward_part(parts_, y, ttop);
-        job.forward = false;
-        if (team) team->run(run_part, &job, parts_); else for (int q = 0; q < parts_; ++q) run_part(&job, q);
+        for (int st = S - 1; st >= 0; --st) run_stage(st, y, t, false, team);
         for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     }
 
