@@ -1213,7 +1213,7 @@ int gmg_dist_smooth_color(gmg_handle h, int c) try {
             if (l.Aoff.col16) {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 2>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                                   l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega,
-                                                  l.Aoff.col16, l.Aoff.win_base));
+                                                  l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from));
             } else {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                                   l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega));
@@ -1237,7 +1237,7 @@ int gmg_dist_residual_own(gmg_handle h) try {
             int dc = std::min(4, d - c0);
             DISPATCH_D(dc, DISPATCH_C16(l.Aoff.col16 != nullptr, hipLaunchKernelGGL((gmgk::spmv_full<double, D, 1, 1, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0,
                                               h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld,
-                                              l.r + (size_t)c0 * ld, ld, sb, se, 1, l.Aoff.col16, l.Aoff.win_base)));
+                                              l.r + (size_t)c0 * ld, ld, sb, se, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from)));
         }
     }
     return GMG_OK;

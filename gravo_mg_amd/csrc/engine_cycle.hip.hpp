@@ -57,7 +57,7 @@ bool fold_norm<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, 
     if ((size_t)(first + nblk) > (size_t)h->partial_blocks) return false;
     DISPATCH_D(d, DISPATCH_C16(l.Aoff.col16 != nullptr, hipLaunchKernelGGL((gmgk::gs_color_norm<D, C16>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                      l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, l.n_pad, sb, se, h->cfg.gs_omega, w, h->d_partials + (size_t)first * 2 * d,
-                                     l.Aoff.col16, l.Aoff.win_base)));
+                                     l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from)));
     h->fuse_norm_blocks = nblk;
     return true;
 }
@@ -71,7 +71,7 @@ bool fold_residual<double>(gmg_handle h, Level& l, int d, bool last_launch, int 
     if (!last_launch || !h->fuse_res_out || &l != &h->lv[0] || d > 4 || l.ord.n_colors < 2 || se != l.Aoff.n_slices || sb <= 0) return false;
     DISPATCH_D(d, DISPATCH_C16(l.Aoff.col16 != nullptr, hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                      l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega,
-                                     l.Aoff.col16, l.Aoff.win_base)));
+                                     l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from)));
     h->fuse_res_from = sb;
     return true;
 }
@@ -94,7 +94,7 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
                 if (fine && l.Aoff.col16) {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 2>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base));
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from));
                 } else if (fine) {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
@@ -236,11 +236,11 @@ void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const 
             if (mode == 1) {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, 1>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                                   l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
-                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base));
+                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from));
             } else {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, 1, 1>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                                   l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
-                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base));
+                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from));
             }
         } else if (mode == 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
@@ -266,7 +266,7 @@ void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const 
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, DISPATCH_C16(fine.R.col16 != nullptr, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
                                           h->stream, fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
-                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1, fine.R.col16, fine.R.win_base)));
+                                          dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1, fine.R.col16, fine.R.win_base, fine.R.c16_from)));
     }
 }
 template <class T>
@@ -282,7 +282,7 @@ void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, DISPATCH_C16(fine.P.col16 != nullptr, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
                                           h->stream, fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
-                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1, fine.P.col16, fine.P.win_base)));
+                                          coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1, fine.P.col16, fine.P.win_base, fine.P.c16_from)));
     }
 }
 
@@ -347,7 +347,7 @@ int launch_norm(gmg_handle h, int d, int type) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, DISPATCH_C16(l.Aoff.col16 != nullptr, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0, C16>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream,
                                           l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
-                                          l.n_pad, n_slices, (float*)nullptr, h->d_partials, l.Aoff.col16, l.Aoff.win_base)));
+                                          l.n_pad, n_slices, (float*)nullptr, h->d_partials, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from)));
         launch_reduce(h, nblk + folded, dc, c0, c0 + 4 >= d);
     }
     if (!poll) HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));
@@ -662,7 +662,7 @@ int launch_residual_to_f32(gmg_handle h, int d, int type) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, DISPATCH_C16(l.Aoff.col16 != nullptr, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 1, C16>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream,
                                           l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad,
-                                          l.Aoff.n_slices, l.b32 + (size_t)c0 * l.n_pad, h->d_partials, l.Aoff.col16, l.Aoff.win_base)));
+                                          l.Aoff.n_slices, l.b32 + (size_t)c0 * l.n_pad, h->d_partials, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_from)));
         launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);
     }
     if (!polled(h)) HIPCHK(hipMemcpyAsync(h->h_norm, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, h->stream));

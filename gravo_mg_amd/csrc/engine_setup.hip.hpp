@@ -440,30 +440,34 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     // the 12 bytes of an entry less to read per launch.  An operator with a slice that 8 windows do not cover keeps its 32-bit indices.
     DevSell* c16_ops[3] = {&l.Aoff, &l.R, &l.P};
     const char* c16_keys[3] = {"col16_l0", "col16_R_l0", "col16_P_l0"};
-    int c16_failed[3] = {0, 0, 0};
+    int c16_failed[6] = {0, 0, 0, 0, 0, 0};      // per operator: slices that 8 windows do not cover, 1 + index of the last of them
     DevTmp<int> d_c16;
     const bool c16 = k == 0 && !l.ord.blocked && !std::getenv("GMG_NO_COL16");
     if (k == 0) for (const char* key : c16_keys) h->timing[key] = 0.0;
     if (c16) {
-        if ((rc = d_c16.alloc(h, 3))) return rc;
-        HIPCHK(hipMemsetAsync(d_c16.p, 0, 3 * sizeof(int), h->stream));
+        if ((rc = d_c16.alloc(h, 6))) return rc;
+        HIPCHK(hipMemsetAsync(d_c16.p, 0, 6 * sizeof(int), h->stream));
         for (int i = 0; i < 3; ++i) {
             DevSell& op = *c16_ops[i];
             if (op.stored <= 0 || op.n_slices <= 0 || (i == 0 && op.lpr != 1)) continue;
             HIPCHK(dev_malloc((void**)&op.col16, sizeof(unsigned) * (size_t)op.stored));
             HIPCHK(dev_malloc((void**)&op.win_base, sizeof(int) * (size_t)op.n_slices * 8));
             hipLaunchKernelGGL(gmgs::compress_cols, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, i == 0 ? dA.ptr : (const int*)nullptr,
-                               i == 0 ? l.d_new2old : (const int*)nullptr, op.val, op.n_slices, op.col16, op.win_base, d_c16.p + i);
+                               i == 0 ? l.d_new2old : (const int*)nullptr, op.val, op.n_slices, op.col16, op.win_base, d_c16.p + 2 * i);
         }
-        HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 3 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
     if (c16)
         for (int i = 0; i < 3; ++i) {
             DevSell& op = *c16_ops[i];
-            h->timing[std::string(c16_keys[i]) + "_failed_slices"] = c16_failed[i];
+            h->timing[std::string(c16_keys[i]) + "_failed_slices"] = c16_failed[2 * i];
+            h->timing[std::string(c16_keys[i]) + "_from_slice"] = c16_failed[2 * i + 1];
             if (!op.col16) continue;
-            if (c16_failed[i]) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; }
+            // the kernels read the codes from the slice behind the last uncovered one (rows of tiny colour classes, scattered over the mesh,
+            // sit at the front of the colour-major numbering); an operator whose uncovered slices reach into its second quarter keeps int32
+            op.c16_from = c16_failed[2 * i + 1];
+            if (op.c16_from > op.n_slices / 4) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; op.c16_from = 0; }
             else h->timing[c16_keys[i]] = 1.0;
         }
     phase("P");

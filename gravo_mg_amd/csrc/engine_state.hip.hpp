@@ -56,6 +56,7 @@ struct DevSell {
     int* row_of = nullptr;
     unsigned* col16 = nullptr;         // level 0: 16-bit column codes, two to a word, indexed like col (the first half of every slice's region is used)
     int* win_base = nullptr;           //          + the 8 window bases of every slice (gmgs::compress_cols); null = the kernels read col
+    int c16_from = 0;                  //          slices below this index keep their 32-bit indices (8 windows did not cover one of them)
 };
 
 // natural-numbering compressed matrix on the device (A_k, U_k by coarse column)

@@ -139,9 +139,14 @@ __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr,
 
 template <class T, int D, int C16>
 __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
-                                            const int* __restrict__ win_base, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
-    if constexpr (C16 != 0) row_dot16<T, D>(slice_ptr, col16, win_base, val, x, ld, s, lane, acc);
-    else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+                                            const int* __restrict__ win_base, int c16_from, const T* __restrict__ val, const T* x, int ld, int s, int lane,
+                                            T (&acc)[D]) {
+    // slices below c16_from (a kernel argument, s is wave-uniform: a scalar branch with nothing to wait for) keep their 32-bit indices:
+    // the few slices that 8 windows cannot cover -- rows of tiny colour classes, scattered over the mesh -- sit at the front
+    if constexpr (C16 != 0) {
+        if (s >= c16_from) row_dot16<T, D>(slice_ptr, col16, win_base, val, x, ld, s, lane, acc);
+        else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    } else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 
 // Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
@@ -164,13 +169,13 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
                                                    const T* __restrict__ val, const T* __restrict__ diag,
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
                                                    int slice_end, int xcd_swizzle, T omega, const unsigned* __restrict__ col16 = nullptr,
-                                                   const int* __restrict__ win_base = nullptr) {
+                                                   const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     T acc[D];
-    row_dot_sel<T, D, FINE == 2>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);      // FINE 2: level 0 with 16-bit column codes
+    row_dot_sel<T, D, FINE == 2>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);      // FINE 2: level 0 with 16-bit column codes
     const T dg = diag[row];
     if (omega == (T)1.0) {                 // kernel argument: a scalar branch.  The reference's update, no read of x_i
 #pragma unroll
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
                                                         const double* __restrict__ val, const double* __restrict__ diag,
                                                         const double* __restrict__ b, double* x, int ld, int slice_begin, int slice_end,
                                                         double omega, const double* __restrict__ weight, double* __restrict__ partials,
-                                                        const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
+                                                        const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     __shared__ double red[kWavesPerBlock][2 * D];
     const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
     if (s < slice_end) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
+        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll
@@ -244,13 +249,13 @@ __global__ __launch_bounds__(kBlock) void gs_color_residual(const int64_t* __res
                                                             const double* __restrict__ val, const double* __restrict__ diag,
                                                             const double* __restrict__ b, double* x, double* __restrict__ r, int ld,
                                                             int slice_begin, int slice_end, double omega, const unsigned* __restrict__ col16 = nullptr,
-                                                            const int* __restrict__ win_base = nullptr) {
+                                                            const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     double acc[D];
-    row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
+    row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
     const double dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -851,11 +856,11 @@ __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict
 template <class T, int D, int MODE, int LPR, int C16 = 0>
 __device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ diag, const T* __restrict__ b, const T* __restrict__ x, T* __restrict__ y,
-                                                int ld, int s, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
+                                                int ld, int s, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     const int lane = threadIdx.x & 63;
     const int row = s * (64 / LPR) + lane / LPR;
     T acc[D];
-    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
+    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const T dg = diag[row];
 #pragma unroll
@@ -869,10 +874,10 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
                                                     const T* __restrict__ val, const T* __restrict__ diag,
                                                     const T* __restrict__ b, const T* __restrict__ x,
                                                     T* __restrict__ y, int ld, int slice_begin, int slice_end,
-                                                    int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
+                                                    int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    spmv_full_slice<T, D, MODE, LPR, C16>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base);
+    spmv_full_slice<T, D, MODE, LPR, C16>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base, c16_from);
 }
 // the same over a LIST of slices (a rank's rows of a level partitioned by blocks: not one contiguous range)
 template <class T, int D, int MODE, int LPR>
@@ -892,10 +897,10 @@ __global__ __launch_bounds__(kBlock) void spmv_full_list(const int64_t* __restri
 template <class T, int D, int ADD, int LPR, int C16 = 0>
 __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s,
-                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
+                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     const int lane = threadIdx.x & 63;
     T acc[D];
-    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, val, x, ldx, s, lane, acc);
+    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ldx, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const int srow = s * (64 / LPR) + lane / LPR;
     // ADD = 1 is a read-modify-write of y: only safe when every output row is produced by exactly one slice row, so that
@@ -913,10 +918,10 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
                                                    const T* __restrict__ val, const int* __restrict__ row_of,
                                                    const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                    int slice_begin, int slice_end, int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr,
-                                                   const int* __restrict__ win_base = nullptr) {
+                                                   const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    transfer_slice<T, D, ADD, LPR, C16>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base);
+    transfer_slice<T, D, ADD, LPR, C16>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base, c16_from);
 }
 template <class T, int D, int ADD, int LPR>
 __global__ __launch_bounds__(kBlock) void transfer_list(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
@@ -1168,7 +1173,7 @@ __global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const in
                                                                const double* __restrict__ b, const double* __restrict__ x,
                                                                const double* __restrict__ weight, int ld, int n_slices,
                                                                float* __restrict__ r32, double* __restrict__ partials,
-                                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr) {
+                                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
     __shared__ double red[kNormWaves][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // partial index = the position of this block's slices in the slice range, not blockIdx (the XCD map permutes blocks)
@@ -1181,7 +1186,7 @@ __global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const in
     if (s < n_slices) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, val, x, ld, s, lane, acc);
+        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll

@@ -252,7 +252,7 @@ __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restri
 // is multiplied by 0 like column 0 before.  What is padding: for the operator (a_ptr != null) entry j of a row when j >= the row's stored
 // off-diagonal entries, known from the source matrix -- never judged by a value, which a values-only refresh may change; for a transfer
 // (a_ptr == null; its values never change after the layout) an entry whose value is 0, which contributes 0 wherever it points.
-// *fail counts the slices 8 windows do not cover.
+// fail[0] counts the slices 8 windows do not cover, fail[1] = 1 + the index of the last of them (the kernels use the codes from there on).
 __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const int* __restrict__ a_ptr,
                                                      const int* __restrict__ new2old, const double* __restrict__ val, int n_slices,
                                                      unsigned* __restrict__ col16, int* __restrict__ win_base, int* __restrict__ fail) {
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__
         word = (j & 1) ? (word | (code << 16)) : code;
         if ((j & 1) || j == w - 1) col16[p0 + (int64_t)(j >> 1) * 64 + lane] = word;
     }
-    if (__ballot(bad) != 0ull && lane == 0) atomicAdd(fail, 1);
+    if (__ballot(bad) != 0ull && lane == 0) { atomicAdd(fail, 1); atomicMax(fail + 1, s + 1); }      // how many, and the end of the last one
     if (lane < 8) {
         int b = base[0];
 #pragma unroll
