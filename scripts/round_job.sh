@@ -6,6 +6,8 @@ cd $R
 timeout 1800 python -m pytest tests -m gpu -q --durations=6 > $O/pytest_gpu.log 2>&1; tail -12 $O/pytest_gpu.log
 cp gpurun_out/fullsize_configs.jsonl $O/ 2>/dev/null; cp gpurun_out/sor_default.jsonl $O/ 2>/dev/null
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json; echo
+python bench.py --n1 2829 --n2 2829 --cpu-cycles 0 --no-variants > $O/bench_8m.json 2> $O/bench_8m.err
+python bench.py --n1 4483 --n2 4483 --cpu-cycles 0 --no-variants > $O/bench_20m.json 2> $O/bench_20m.err
 cd /tmp; export TMPDIR=/tmp
 prof() {   # name, bench args...
   N=$1; shift
@@ -25,8 +27,6 @@ pmc fetch_pointcloud FETCH_SIZE --config 3; pmc write_pointcloud WRITE_SIZE --co
 pmc tcc_3m "TCC_HIT_sum TCC_MISS_sum"; pmc tcc_3m_random "TCC_HIT_sum TCC_MISS_sum" --config 4r; pmc tcc_pointcloud "TCC_HIT_sum TCC_MISS_sum" --config 3
 cat $O/pmc_fetch_3m.txt $O/pmc_write_3m.txt > $O/pmc_fetch_write_summary.txt
 cd $R
-python bench.py --n1 2829 --n2 2829 --cpu-cycles 0 --no-variants > $O/bench_8m.json 2> $O/bench_8m.err
-python bench.py --n1 4483 --n2 4483 --cpu-cycles 0 --no-variants > $O/bench_20m.json 2> $O/bench_20m.err
 for S in 2 1; do GMG_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 2 --shard-levels $S 2>$O/dist_shard$S.err | tail -1 > $O/bench_2ranks_1gpu_shard$S.json; done
 python scripts/setup_breakdown.py 2>&1 | grep -A3 "^set_system" > $O/setup_breakdown_natural.txt
 python scripts/setup_breakdown.py random 2>&1 | grep -A3 "^set_system" > $O/setup_breakdown_random.txt

@@ -3,7 +3,8 @@ sys.path.insert(0, '.')
 import bench
 from gravo_mg_amd import cabi
 order = sys.argv[1] if len(sys.argv) > 1 else "natural"
-H, mass, lhs, rhs = bench.build_workload(1732, 1732, order)
+N1 = int(sys.argv[2]) if len(sys.argv) > 2 else 1732
+H, mass, lhs, rhs = bench.build_workload(N1, N1, order)
 keys = ("reduction", "coarsest_solve", "upload", "setup_ordering", "setup_ordering_l0", "setup_ordering_l1", "setup_wait_ordering",
         "setup_device_layout", "setup_total", "setup_ordering_cached")
 eng = cabi.Engine()
