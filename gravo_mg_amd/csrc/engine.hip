@@ -26,6 +26,12 @@
 #include <string>
 #include <vector>
 
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+#endif
+
 #include "../../include/gravomg_hip.h"
 #include "host_hierarchy.hpp"
 #include "host_ldlt.hpp"
@@ -38,6 +44,31 @@
 using namespace gmg;
 using clk = std::chrono::steady_clock;
 static inline double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// Debugging aid: GMG_SEGV_BACKTRACE=1 makes a fatal signal inside the process print the native call stack of the faulting thread
+// (symbol + offset; `addr2line -e libgravomg_hip.so` resolves them) before the default action takes over.
+namespace {
+void gmg_fatal_signal(int sig) {
+    void* frames[48];
+    const int nf = backtrace(frames, 48);
+    const char msg[] = "[gmg] fatal signal, native stack of the faulting thread:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, nf, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct GmgSignalAid {
+    GmgSignalAid() {
+        if (!std::getenv("GMG_SEGV_BACKTRACE")) return;
+        struct sigaction sa;
+        std::memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = gmg_fatal_signal;
+        sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr); sigaction(SIGFPE, &sa, nullptr);
+    }
+} gmg_signal_aid;
+}  // namespace
+#endif
 
 #include "engine_state.hip.hpp"
 #include "engine_setup.hip.hpp"
@@ -469,6 +500,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     spawn_level_ops = [&](int k) {
         op_done[k] = std::async(std::launch::async, [&, k] {
             ord_done[k].wait();
+            if (k == 0) wait_lhs();      // level 0 is ordered from the caller's arrays, but laid out from the host copy: that copy must be complete
             auto t = clk::now();
             Level& lk = h->lv[k];
             LevelStage& st = stage[k];

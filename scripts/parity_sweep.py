@@ -74,7 +74,7 @@ def main():
             rec = {"problem": name, "n": int(V.shape[0]), "levels": len(H.U), "variant": vname, "tolerance": tol,
                    "gpu_iterations": int(it), "oracle_iterations": int(ito), "gpu_residue": float(res), "oracle_residue": float(reso),
                    "oracle_check_of_gpu_solution": chk, "solution_distance_M_rel": dist, "oracle_seconds": t_oracle,
-                   "ok": bool(chk <= tol * 1.0001 and abs(chk - res) <= 1e-3 * max(chk, 1e-300) + 1e-9 and dist <= 30 * tol and (jac or abs(it - ito) <= max(2, ito // 3)))}
+                   "ok": bool(chk <= tol * 1.0001 and abs(chk - res) <= 1e-3 * max(chk, 1e-300) + 1e-9 and dist <= 30 * tol and (jac or it <= ito + max(2, ito // 3)))}      # (fewer cycles than the reference algorithm is what the over-relaxed level-0 sweep is for)
             worst = max(worst, dist / tol)
             out.append(rec)
             print(json.dumps(rec), flush=True)

@@ -1,4 +1,4 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03z; mkdir -p $O; cd $R
-for i in 1 2; do python bench.py --n1 2829 --n2 2829 --cpu-cycles 0 --no-variants 2>$O/err$i.txt | python -c "
-import sys,json; j=json.loads(sys.stdin.read()); print(j['set_system_ms'], j['solver_timing_ms'])"; grep "set_system" $O/err$i.txt | cut -c1-300; done
-python scripts/setup_breakdown.py natural 2829 2>&1 | grep -A1 "^set_system" | head -2 | cut -c1-700
+ulimit -c 0
+for i in 1 2 3 4 5 6; do GMG_SEGV_BACKTRACE=1 timeout 600 python scripts/r03_repro.py > $O/rp$i.out 2> $O/rp$i.err; echo "run $i rc=$? $(tail -1 $O/rp$i.out)"; done
+for i in 1 2 3 4; do timeout 600 python scripts/parity_sweep.py > $O/ps$i.out 2> $O/ps$i.err; echo "sweep $i rc=$? $(tail -1 $O/ps$i.out | cut -c1-60)"; done

@@ -48,3 +48,25 @@ def test_one_handle_many_systems(cabi, oracle):
             free_after_warmup = _free_device_bytes()
     # the pool parks blocks for reuse but must not grow without bound: two more rounds cost (almost) no extra device memory
     assert free_after_warmup - _free_device_bytes() < 64 << 20
+
+
+def test_host_planner_set_system_repeated_on_a_small_mesh(cabi):
+    """Regression (round 3): with device_setup=False level 0 is ORDERED from the caller's arrays but LAID OUT from the engine's host
+    copy of the LHS, which is made by a background task -- on a small mesh the ordering used to finish first and the layout task read a
+    half-made copy (a segmentation fault in about one of three runs of scripts/parity_sweep.py).  Many set-ups in a row, each checked."""
+    from gravo_mg_amd import meshgen
+    V, F = meshgen.torus_mesh(180, 150)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    lhs, rhs = meshgen.poisson_system(S, mass)
+    H = cabi.Hierarchy(V, meshgen.neighbors_from_stiffness(S), lower_bound=1000)
+    ref = None
+    for rep in range(40):
+        eng = cabi.Engine(device_setup=False)
+        eng.use_hierarchy(H); eng.set_mass(mass); eng.set_system(lhs)
+        x, it, res, _ = eng.solve(rhs, tol=1e-4, max_iter=100)
+        assert res <= 1e-4
+        if ref is None:
+            ref = (x, it)
+        else:
+            assert it == ref[1] and np.array_equal(x, ref[0])
+        del eng
