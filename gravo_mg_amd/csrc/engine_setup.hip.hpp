@@ -437,39 +437,62 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         l.P.nnz_real = h->U[k].nnz();
     }
     // ---- 16-bit column codes of level 0's operator and transfers for the fine-level kernels (kernels.hip.hpp; GMG_NO_COL16: A/B aid): 2 of
-    // the 12 bytes of an entry less to read per launch.  An operator with a slice that 8 windows do not cover keeps its 32-bit indices.
+    // the 12 bytes of an entry less to read per launch.  First with 8 windows of 8 192 columns per slice (meshes); an operator that
+    // leaves more than an eighth of its slices uncovered that way (kNN graphs: the 64 rows of a slice reach into every colour class)
+    // is coded again with 32 windows of 2 048, and keeps its 32-bit indices alone if that does not cover it either.
     DevSell* c16_ops[3] = {&l.Aoff, &l.R, &l.P};
     const char* c16_keys[3] = {"col16_l0", "col16_R_l0", "col16_P_l0"};
-    int c16_failed[6] = {0, 0, 0, 0, 0, 0};      // per operator: slices that 8 windows do not cover, 1 + index of the last of them
+    int c16_failed[6] = {0, 0, 0, 0, 0, 0};      // per operator: uncovered slices, 1 + index of the last of them
     DevTmp<int> d_c16;
     const bool c16 = k == 0 && !l.ord.blocked && !std::getenv("GMG_NO_COL16");
+    const int c16_test_fail = std::getenv("GMG_COL16_TEST_FAIL") ? std::atoi(std::getenv("GMG_COL16_TEST_FAIL")) : 0;      // tests: N > 0 every N-th slice "uncovered", N < 0 the first -N
+    auto c16_launch = [&](int i, int nw) -> int {
+        DevSell& op = *c16_ops[i];
+        if (op.win_base) { (void)dev_free(op.win_base); op.win_base = nullptr; }
+        if (!op.col16) HIPCHK(dev_malloc((void**)&op.col16, sizeof(unsigned) * (size_t)op.stored));
+        HIPCHK(dev_malloc((void**)&op.win_base, sizeof(int) * (size_t)op.n_slices * nw));
+        HIPCHK(hipMemsetAsync(d_c16.p + 2 * i, 0, 2 * sizeof(int), h->stream));
+        const int* a_ptr = i == 0 ? dA.ptr : (const int*)nullptr;
+        const int* n2o = i == 0 ? l.d_new2old : (const int*)nullptr;
+        if (nw == 8) hipLaunchKernelGGL(gmgs::compress_cols<8>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i);
+        else hipLaunchKernelGGL(gmgs::compress_cols<32>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i);
+        op.c16_dbits = nw == 8 ? 13 : 11;
+        return GMG_OK;
+    };
+    // usable as it is?  uncovered slices all within the first 1/16 of the numbering (tiny colour classes come first): codes from the slice
+    // behind them on, no per-slice test in the kernels (mode 1); else at most 1/8 of the slices uncovered: flagged one by one (mode 2)
+    auto c16_mode_of = [&](int i) { const DevSell& op = *c16_ops[i]; return c16_failed[2 * i + 1] <= op.n_slices / 16 ? 1 : (c16_failed[2 * i] <= op.n_slices / 8 ? 2 : 0); };
     if (k == 0) for (const char* key : c16_keys) h->timing[key] = 0.0;
     if (c16) {
         if ((rc = d_c16.alloc(h, 6))) return rc;
-        HIPCHK(hipMemsetAsync(d_c16.p, 0, 6 * sizeof(int), h->stream));
         for (int i = 0; i < 3; ++i) {
             DevSell& op = *c16_ops[i];
             if (op.stored <= 0 || op.n_slices <= 0 || (i == 0 && op.lpr != 1)) continue;
-            HIPCHK(dev_malloc((void**)&op.col16, sizeof(unsigned) * (size_t)op.stored));
-            HIPCHK(dev_malloc((void**)&op.win_base, sizeof(int) * (size_t)op.n_slices * 8));
-            hipLaunchKernelGGL(gmgs::compress_cols, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, i == 0 ? dA.ptr : (const int*)nullptr,
-                               i == 0 ? l.d_new2old : (const int*)nullptr, op.val, op.n_slices, op.col16, op.win_base, d_c16.p + 2 * i);
+            if ((rc = c16_launch(i, 8))) return rc;
         }
         HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
-    if (c16)
+    if (c16) {
+        bool again = false;
+        for (int i = 0; i < 3; ++i)
+            if (c16_ops[i]->col16 && c16_mode_of(i) == 0) { if ((rc = c16_launch(i, 32))) return rc; again = true; }
+        if (again) {
+            HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
         for (int i = 0; i < 3; ++i) {
             DevSell& op = *c16_ops[i];
             h->timing[std::string(c16_keys[i]) + "_failed_slices"] = c16_failed[2 * i];
-            h->timing[std::string(c16_keys[i]) + "_from_slice"] = c16_failed[2 * i + 1];
-            if (!op.col16) continue;
-            // the kernels read the codes from the slice behind the last uncovered one (rows of tiny colour classes, scattered over the mesh,
-            // sit at the front of the colour-major numbering); an operator whose uncovered slices reach into its second quarter keeps int32
+            if (!op.col16) { h->timing[std::string(c16_keys[i]) + "_windows"] = 0; continue; }
+            op.c16_mode = c16_mode_of(i);
             op.c16_from = c16_failed[2 * i + 1];
-            if (op.c16_from > op.n_slices / 4) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; op.c16_from = 0; }
+            if (op.c16_mode == 0) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; op.c16_dbits = 13; op.c16_from = 0; }
             else h->timing[c16_keys[i]] = 1.0;
+            h->timing[std::string(c16_keys[i]) + "_windows"] = op.col16 ? (op.c16_dbits == 13 ? 8 : 32) : 0;
+            h->timing[std::string(c16_keys[i]) + "_mode"] = op.c16_mode;
         }
+    }
     phase("P");
     return GMG_OK;
 }

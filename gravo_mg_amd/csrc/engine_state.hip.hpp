@@ -55,8 +55,11 @@ struct DevSell {
     float* val32 = nullptr;       // fp32 copy of val (mixed-precision inner cycle); shares slice_ptr / col / row_of
     int* row_of = nullptr;
     unsigned* col16 = nullptr;         // level 0: 16-bit column codes, two to a word, indexed like col (the first half of every slice's region is used)
-    int* win_base = nullptr;           //          + the 8 window bases of every slice (gmgs::compress_cols); null = the kernels read col
-    int c16_from = 0;                  //          slices below this index keep their 32-bit indices (8 windows did not cover one of them)
+    int* win_base = nullptr;           //          + the window bases of every slice, first one -1 = slice on 32-bit indices (gmgs::compress_cols); null = the kernels read col
+    int c16_dbits = 13;                //          offset bits of a code: 13 = 8 windows of 8 192 columns per slice, 11 = 32 windows of 2 048
+    int c16_mode = 0;                  //          0 none, 1 codes from slice c16_from on (uncovered slices are a short prefix), 2 uncovered slices flagged one by one
+    int c16_from = 0;
+    int c16_arg() const { return (c16_mode == 1 ? c16_from : 0) | (c16_dbits == 11 ? 1 << 30 : 0); }      // the kernels' c16_arg (kernels.hip.hpp::row_dot_sel)
 };
 
 // natural-numbering compressed matrix on the device (A_k, U_k by coarse column)

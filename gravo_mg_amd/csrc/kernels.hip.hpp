@@ -82,25 +82,34 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
 // ---- 16-bit column codes (level 0; setup_kernels.hip.hpp::compress_cols) ------------------------------------------------------------
 // The fine-level kernels run at the HBM limit for the bytes they move, so the way to a faster launch is fewer bytes: a column index is
 // 4 of the 12 bytes of an entry.  The columns of the 64 rows of a slice are the neighbours of 64 consecutive rows: a few short ranges
-// (one or two per colour class).  Every slice gets up to 8 "windows" [base_k, base_k + 8192) that cover its columns;
-// code = k << 13 | (column - base_k), two codes to a 32-bit word (entries 2 q and 2 q + 1 of a row share word q of the slice's region),
-// and the 8 bases of the slice sit in lanes 0..7 of one register, picked per entry by ds_bpermute.  Same columns in the same order: the
-// results are bit-identical to the 32-bit path.  A level with a slice that 8 windows cannot cover keeps its 32-bit indices.
-constexpr int kColWinBits = 3, kColDeltaBits = 13, kColWins = 1 << kColWinBits;
-
-template <class T, int D, int W>
-__device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp, const T* __restrict__ vp, const T* x, int ld, int basev, T (&acc)[D]) {
+// (one or two per colour class).  Every slice gets up to NW "windows" [base_k, base_k + 2^dbits) that cover its columns -- 8 windows of
+// 8 192 columns (dbits = 13) for meshes, 32 windows of 2 048 (dbits = 11) for kNN graphs, whose 64 rows reach into every colour class --;
+// code = k << dbits | (column - base_k), two codes to a 32-bit word (entries 2 q and 2 q + 1 of a row share word q of the slice's
+// region), and the bases of the slice sit in lanes 0 .. NW-1 of one register, picked per entry by ds_bpermute.  Same columns in the same
+// order: the results are bit-identical to the 32-bit path.  A slice that NW windows cannot cover (rows of tiny colour classes,
+// scattered over the mesh) carries -1 as its first base and is read through the 32-bit indices: the wave learns that from the base
+// register AFTER it has issued its first group of loads, so the other slices never wait for the answer.
+template <class T, int D, int W, bool FLAGS>
+__device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp, const int* __restrict__ cp32, const T* __restrict__ vp, const T* x, int ld,
+                                                int basev, int dbits, int& fallback, T (&acc)[D]) {
     unsigned pk[(W + 1) / 2];
     T v[W];
 #pragma unroll
     for (int q = 0; q < (W + 1) / 2; ++q) pk[q] = __builtin_nontemporal_load(cp + q * 64);
 #pragma unroll
     for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(vp + j * 64);
+    if constexpr (FLAGS) { if (fallback < 0) fallback = __builtin_amdgcn_readfirstlane(basev) < 0 ? 1 : 0; }
     int c[W];
+    if (FLAGS && fallback) {
 #pragma unroll
-    for (int j = 0; j < W; ++j) {
-        const unsigned u = (j & 1) ? pk[j >> 1] >> 16 : pk[j >> 1] & 0xffffu;
-        c[j] = __builtin_amdgcn_ds_bpermute((int)((u >> (kColDeltaBits - 2)) & ((kColWins - 1) << 2)), basev) + (int)(u & ((1u << kColDeltaBits) - 1u));
+        for (int j = 0; j < W; ++j) c[j] = __builtin_nontemporal_load(cp32 + j * 64);
+    } else {
+        const unsigned mask = (1u << dbits) - 1u;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned u = (j & 1) ? pk[j >> 1] >> 16 : pk[j >> 1] & 0xffffu;
+            c[j] = __builtin_amdgcn_ds_bpermute((int)((u >> dbits) << 2), basev) + (int)(u & mask);
+        }
     }
     T xv[W][D];
 #pragma unroll
@@ -114,38 +123,45 @@ __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp,
 }
 
 // row_dot with the columns read from the codes (G is even: a group's codes are whole words)
-template <class T, int D, int G = DotGroup<D>::value>
-__device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr, const unsigned* __restrict__ col16, const int* __restrict__ win_base,
-                                          const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
-    const int basev = win_base[(int64_t)s * kColWins + (lane & (kColWins - 1))];
+template <class T, int D, bool FLAGS, int G = DotGroup<D>::value>
+__device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
+                                          const int* __restrict__ win_base, int dbits, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
+    const int wshift = 16 - dbits;                                        // windows per slice = 1 << wshift
+    const int basev = win_base[((int64_t)s << wshift) + (lane & ((1 << wshift) - 1))];
     const int64_t p0 = slice_ptr[s];
     int w = (int)((slice_ptr[s + 1] - p0) >> 6);
     const unsigned* cp = col16 + p0 + lane;
+    const int* cp32 = col + p0 + lane;
     const T* vp = val + p0 + lane;
+    int fallback = -1;                                                    // not known yet
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (; w >= G; w -= G, cp += (G / 2) * 64, vp += G * 64) row_dot_group16<T, D, G>(cp, vp, x, ld, basev, acc);
+    for (; w >= G; w -= G, cp += (G / 2) * 64, cp32 += G * 64, vp += G * 64) row_dot_group16<T, D, G, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc);
     switch (w) {
-        case 1: row_dot_group16<T, D, 1>(cp, vp, x, ld, basev, acc); break;
-        case 2: row_dot_group16<T, D, 2>(cp, vp, x, ld, basev, acc); break;
-        case 3: row_dot_group16<T, D, 3>(cp, vp, x, ld, basev, acc); break;
-        case 4: if (G > 4) row_dot_group16<T, D, 4>(cp, vp, x, ld, basev, acc); break;
-        case 5: if (G > 4) row_dot_group16<T, D, 5>(cp, vp, x, ld, basev, acc); break;
-        case 6: if (G > 4) row_dot_group16<T, D, 6>(cp, vp, x, ld, basev, acc); break;
-        case 7: if (G > 4) row_dot_group16<T, D, 7>(cp, vp, x, ld, basev, acc); break;
+        case 1: row_dot_group16<T, D, 1, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 2: row_dot_group16<T, D, 2, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 3: row_dot_group16<T, D, 3, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 4: if (G > 4) row_dot_group16<T, D, 4, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 5: if (G > 4) row_dot_group16<T, D, 5, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 6: if (G > 4) row_dot_group16<T, D, 6, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 7: if (G > 4) row_dot_group16<T, D, 7, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
         default: break;
     }
 }
 
+// C16 = 0: 32-bit indices.  C16 = 1: codes from slice `from` on (the uncovered slices are a short prefix of the numbering -- tiny colour
+// classes come first -- and the branch on the wave-uniform slice number has nothing to wait for).  C16 = 2: uncovered slices anywhere,
+// found through their flag.  c16_arg = from | format << 30 (format 0: 13 offset bits / 8 windows, 1: 11 offset bits / 32 windows).
 template <class T, int D, int C16>
 __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
-                                            const int* __restrict__ win_base, int c16_from, const T* __restrict__ val, const T* x, int ld, int s, int lane,
+                                            const int* __restrict__ win_base, int c16_arg, const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                             T (&acc)[D]) {
-    // slices below c16_from (a kernel argument, s is wave-uniform: a scalar branch with nothing to wait for) keep their 32-bit indices:
-    // the few slices that 8 windows cannot cover -- rows of tiny colour classes, scattered over the mesh -- sit at the front
-    if constexpr (C16 != 0) {
-        if (s >= c16_from) row_dot16<T, D>(slice_ptr, col16, win_base, val, x, ld, s, lane, acc);
+    if constexpr (C16 == 1) {
+        const int dbits = (c16_arg >> 30) & 1 ? 11 : 13;
+        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
         else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+    } else if constexpr (C16 == 2) {
+        row_dot16<T, D, true>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
     } else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 
@@ -169,13 +185,13 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
                                                    const T* __restrict__ val, const T* __restrict__ diag,
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
                                                    int slice_end, int xcd_swizzle, T omega, const unsigned* __restrict__ col16 = nullptr,
-                                                   const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                   const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     T acc[D];
-    row_dot_sel<T, D, FINE == 2>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);      // FINE 2: level 0 with 16-bit column codes
+    row_dot_sel<T, D, (FINE >= 2 ? FINE - 1 : 0)>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);      // FINE 2 / 3: level 0 with 16-bit column codes (row_dot_sel mode 1 / 2)
     const T dg = diag[row];
     if (omega == (T)1.0) {                 // kernel argument: a scalar branch.  The reference's update, no read of x_i
 #pragma unroll
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
                                                         const double* __restrict__ val, const double* __restrict__ diag,
                                                         const double* __restrict__ b, double* x, int ld, int slice_begin, int slice_end,
                                                         double omega, const double* __restrict__ weight, double* __restrict__ partials,
-                                                        const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                        const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     __shared__ double red[kWavesPerBlock][2 * D];
     const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
     if (s < slice_end) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
+        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll
@@ -249,13 +265,13 @@ __global__ __launch_bounds__(kBlock) void gs_color_residual(const int64_t* __res
                                                             const double* __restrict__ val, const double* __restrict__ diag,
                                                             const double* __restrict__ b, double* x, double* __restrict__ r, int ld,
                                                             int slice_begin, int slice_end, double omega, const unsigned* __restrict__ col16 = nullptr,
-                                                            const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                            const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     double acc[D];
-    row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
+    row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);
     const double dg = diag[row];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -856,11 +872,11 @@ __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict
 template <class T, int D, int MODE, int LPR, int C16 = 0>
 __device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ diag, const T* __restrict__ b, const T* __restrict__ x, T* __restrict__ y,
-                                                int ld, int s, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                int ld, int s, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int lane = threadIdx.x & 63;
     const int row = s * (64 / LPR) + lane / LPR;
     T acc[D];
-    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
+    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const T dg = diag[row];
 #pragma unroll
@@ -874,10 +890,10 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
                                                     const T* __restrict__ val, const T* __restrict__ diag,
                                                     const T* __restrict__ b, const T* __restrict__ x,
                                                     T* __restrict__ y, int ld, int slice_begin, int slice_end,
-                                                    int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                    int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    spmv_full_slice<T, D, MODE, LPR, C16>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base, c16_from);
+    spmv_full_slice<T, D, MODE, LPR, C16>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base, c16_arg);
 }
 // the same over a LIST of slices (a rank's rows of a level partitioned by blocks: not one contiguous range)
 template <class T, int D, int MODE, int LPR>
@@ -897,10 +913,10 @@ __global__ __launch_bounds__(kBlock) void spmv_full_list(const int64_t* __restri
 template <class T, int D, int ADD, int LPR, int C16 = 0>
 __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s,
-                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int lane = threadIdx.x & 63;
     T acc[D];
-    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ldx, s, lane, acc);
+    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_arg, val, x, ldx, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const int srow = s * (64 / LPR) + lane / LPR;
     // ADD = 1 is a read-modify-write of y: only safe when every output row is produced by exactly one slice row, so that
@@ -918,10 +934,10 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
                                                    const T* __restrict__ val, const int* __restrict__ row_of,
                                                    const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
                                                    int slice_begin, int slice_end, int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr,
-                                                   const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                   const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    transfer_slice<T, D, ADD, LPR, C16>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base, c16_from);
+    transfer_slice<T, D, ADD, LPR, C16>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base, c16_arg);
 }
 template <class T, int D, int ADD, int LPR>
 __global__ __launch_bounds__(kBlock) void transfer_list(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
@@ -1173,7 +1189,7 @@ __global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const in
                                                                const double* __restrict__ b, const double* __restrict__ x,
                                                                const double* __restrict__ weight, int ld, int n_slices,
                                                                float* __restrict__ r32, double* __restrict__ partials,
-                                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_from = 0) {
+                                                               const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     __shared__ double red[kNormWaves][2 * D];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // partial index = the position of this block's slices in the slice range, not blockIdx (the XCD map permutes blocks)
@@ -1186,7 +1202,7 @@ __global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const in
     if (s < n_slices) {
         const int row = s * 64 + lane;
         double acc[D];
-        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_from, val, x, ld, s, lane, acc);
+        row_dot_sel<double, D, C16>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);
         const double dg = diag[row];
         const double w = weight ? weight[row] : 1.0;
 #pragma unroll

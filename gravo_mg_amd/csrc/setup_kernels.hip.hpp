@@ -246,16 +246,21 @@ __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restri
     else csr_fill_plain_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
 }
 
-// 16-bit column codes of a SELL operator (kernels.hip.hpp, "16-bit column codes"): one wavefront per slice.  The windows of a slice are
-// chosen greedily in ascending order (base_0 = the smallest column, base_k = the smallest column at or beyond base_{k-1} + 8192), which
-// covers any column set with the fewest windows of that length; padding entries get code 0 = the slice's first base, a valid index that
-// is multiplied by 0 like column 0 before.  What is padding: for the operator (a_ptr != null) entry j of a row when j >= the row's stored
-// off-diagonal entries, known from the source matrix -- never judged by a value, which a values-only refresh may change; for a transfer
-// (a_ptr == null; its values never change after the layout) an entry whose value is 0, which contributes 0 wherever it points.
-// fail[0] counts the slices 8 windows do not cover, fail[1] = 1 + the index of the last of them (the kernels use the codes from there on).
+// 16-bit column codes of a SELL operator (kernels.hip.hpp, "16-bit column codes"): one wavefront per slice, NW windows of 65536 / NW
+// columns.  The windows of a slice are chosen greedily in ascending order (base_0 = the smallest column, base_k = the smallest column
+// at or beyond base_{k-1} + span), which covers any column set with the fewest windows of that length; padding entries get code 0 = the
+// slice's first base, a valid index that is multiplied by 0 like column 0 before.  What is padding: for the operator (a_ptr != null)
+// entry j of a row when j >= the row's stored off-diagonal entries, known from the source matrix -- never judged by a value, which a
+// values-only refresh may change; for a transfer (a_ptr == null; its values never change after the layout) an entry whose value is 0,
+// which contributes 0 wherever it points.  A slice that needs more than NW windows (tests: also every test_fail-th slice, or the first -test_fail slices) gets -1 as its
+// first base -- the kernels then read its 32-bit indices -- and is counted in fail[0]; fail[1] = 1 + the index of the last such slice.
+template <int NW>
 __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const int* __restrict__ a_ptr,
-                                                     const int* __restrict__ new2old, const double* __restrict__ val, int n_slices,
+                                                     const int* __restrict__ new2old, const double* __restrict__ val, int n_slices, int test_fail,
                                                      unsigned* __restrict__ col16, int* __restrict__ win_base, int* __restrict__ fail) {
+    constexpr int kSpan = 65536 / NW;
+    constexpr int kDbits = NW == 8 ? 13 : 11;
+    static_assert(NW == 8 || NW == 32, "8 windows of 8192 or 32 windows of 2048");
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (s >= n_slices) return;
@@ -265,11 +270,11 @@ __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__
     if (a_ptr) { const int old = new2old[s * 64 + lane]; len = old >= 0 ? a_ptr[old + 1] - a_ptr[old] - 1 : 0; }
     auto real = [&](int j) { return a_ptr ? j < len : val[p0 + (int64_t)j * 64 + lane] != 0.0; };
     constexpr int kNone = 0x7fffffff;
-    int base[8];
+    int base[NW];
     int lo = 0;                                                  // columns below lo are covered
     bool more = true;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < NW; ++k) {
         int m = kNone;
         if (more)
             for (int j = 0; j < w; ++j) {
@@ -279,33 +284,35 @@ __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = min(m, __shfl_xor(m, off, 64));
         if (m == kNone) { more = false; base[k] = k ? base[k - 1] : 0; }
-        else { base[k] = m; lo = m + 8192; }
+        else { base[k] = m; lo = m + kSpan; }
     }
+    // anything left beyond the last window?
     bool bad = false;
+    if (more)
+        for (int j = 0; j < w; ++j) { const int c = col[p0 + (int64_t)j * 64 + lane]; if (c >= lo && real(j)) bad = true; }
+    bad = __ballot(bad) != 0ull || (test_fail > 0 && s % test_fail == 1) || (test_fail < 0 && s < -test_fail);
     unsigned word = 0;
     for (int j = 0; j < w; ++j) {
         const int c = col[p0 + (int64_t)j * 64 + lane];
         unsigned code = 0;
-        if (real(j)) {
+        if (real(j) && !bad) {
             int k = 0;
 #pragma unroll
-            for (int q = 1; q < 8; ++q) k += (base[q] > base[q - 1] && c >= base[q]) ? 1 : 0;
+            for (int q = 1; q < NW; ++q) k += (base[q] > base[q - 1] && c >= base[q]) ? 1 : 0;
             int b = base[0];
 #pragma unroll
-            for (int q = 1; q < 8; ++q) b = k == q ? base[q] : b;
-            const int delta = c - b;
-            if (delta < 0 || delta >= 8192) bad = true;
-            code = ((unsigned)k << 13) | ((unsigned)delta & 8191u);
+            for (int q = 1; q < NW; ++q) b = k == q ? base[q] : b;
+            code = ((unsigned)k << kDbits) | ((unsigned)(c - b) & (unsigned)(kSpan - 1));
         }
         word = (j & 1) ? (word | (code << 16)) : code;
         if ((j & 1) || j == w - 1) col16[p0 + (int64_t)(j >> 1) * 64 + lane] = word;
     }
-    if (__ballot(bad) != 0ull && lane == 0) { atomicAdd(fail, 1); atomicMax(fail + 1, s + 1); }      // how many, and the end of the last one
-    if (lane < 8) {
+    if (bad && lane == 0) { atomicAdd(fail, 1); atomicMax(fail + 1, s + 1); }      // how many, and the end of the last one
+    if (lane < NW) {
         int b = base[0];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) b = lane == q ? base[q] : b;
-        win_base[(int64_t)s * 8 + lane] = b;
+        for (int q = 1; q < NW; ++q) b = lane == q ? base[q] : b;
+        win_base[(int64_t)s * NW + lane] = (bad && lane == 0) ? -1 : b;
     }
 }
 

@@ -1,5 +1,5 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03y; mkdir -p $O; cd $R
-timeout 900 python -m pytest tests/test_gpu_setup.py -m gpu -q -x -k "16_bit" 2>&1 | tail -2
+timeout 900 python -m pytest tests/test_gpu_setup.py -m gpu -q -x -k "16_bit" 2>&1 | tail -12
 python - <<PY 2>&1 | grep -v amdgpu.ids | tee $O/col16_from.txt
 import sys, os, time; sys.path.insert(0, '.')
 import numpy as np
@@ -13,7 +13,7 @@ def run(tag, H, mass, lhs, rhs):
         os.environ.pop("GMG_NO_COL16", None)
         keys = ("col16_l0", "col16_R_l0", "col16_P_l0")
         out = {"case": tag, "A/R/P": [eng.timing(k) for k in keys]}
-        if not no16: out["failed"] = [eng.timing(k + "_failed_slices") for k in keys]; out["from"] = [eng.timing(k + "_from_slice") for k in keys]; out["slices"] = eng.level_info(0)["n_pad"] // 64
+        if not no16: out["failed"] = [eng.timing(k + "_failed_slices") for k in keys]; out["windows"] = [eng.timing(k + "_windows") for k in keys]; out["mode"] = [eng.timing(k + "_mode") if eng.timing(k) else 0 for k in keys]; out["slices"] = eng.level_info(0)["n_pad"] // 64
         d = rhs.shape[1]
         for name, kind in (("sweep", 0), ("residual", 1), ("restrict", 2), ("prolong", 3), ("norm", 4)):
             ms, launches = eng.bench_kernel(kind, 0, d, 100)

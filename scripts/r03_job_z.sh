@@ -1,4 +1,3 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03z; mkdir -p $O; cd $R
-ulimit -c 0
-for i in 1 2 3 4 5 6; do GMG_SEGV_BACKTRACE=1 timeout 600 python scripts/r03_repro.py > $O/rp$i.out 2> $O/rp$i.err; echo "run $i rc=$? $(tail -1 $O/rp$i.out)"; done
-for i in 1 2 3 4; do timeout 600 python scripts/parity_sweep.py > $O/ps$i.out 2> $O/ps$i.err; echo "sweep $i rc=$? $(tail -1 $O/ps$i.out | cut -c1-60)"; done
+timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+( for c in 4 4r 3 4s 5; do python scripts/ab_cycle.py --config $c --label "codes"; done ) 2>/dev/null | cut -c1-330 | tee $O/ab_codes.jsonl

@@ -340,8 +340,9 @@ def test_base_order_of_a_reordered_level_follows_the_gather_score(cabi):
     assert ep.timing("base_order_choice") == 0.0 and ep.timing("base_order_score_cluster") < ep.timing("base_order_score_bfs")
 
 
-@pytest.mark.parametrize("case", ["torus", "random-order", "pointcloud", "smoothing-d3"])
-def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi, case):
+@pytest.mark.parametrize("case,test_fail", [("torus", 0), ("random-order", 0), ("pointcloud", 0), ("smoothing-d3", 0), ("torus", 9), ("pointcloud", 11),
+                                            ("smoothing-d3", 10), ("torus", -3), ("random-order", -2)])
+def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi, case, test_fail):
     """Level 0 stores its column indices a second time as 16-bit codes (window of the slice + offset inside it, gmgs::compress_cols)
     and the fine-level kernels read those: the same columns in the same order, so every iterate is bit-identical to the 32-bit path
     (GMG_NO_COL16), also after a values-only refresh, for d = 3 and in the fp32 inner cycle."""
@@ -354,17 +355,25 @@ def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi
     def run(no16):
         if no16:
             os.environ["GMG_NO_COL16"] = "1"
+        elif test_fail:                          # pretend slices are not covered by their windows: every N-th (flagged one by one), or the first -N (prefix)
+            os.environ["GMG_COL16_TEST_FAIL"] = str(test_fail)
         try:
             e = cabi.Engine()
             e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
         finally:
-            os.environ.pop("GMG_NO_COL16", None)
+            os.environ.pop("GMG_NO_COL16", None); os.environ.pop("GMG_COL16_TEST_FAIL", None)
         return e
     a, b = run(False), run(True)
     assert b.timing("col16_l0") == 0.0
     assert b.timing("col16_R_l0") == 0.0 and b.timing("col16_P_l0") == 0.0
     for key in ("col16_l0", "col16_R_l0", "col16_P_l0"):               # the operator and both transfers of level 0
-        assert a.timing(key) == 1.0 and a.timing(key + "_failed_slices") == 0.0     # small meshes: 8 windows of 8 192 cover any slice
+        assert a.timing(key) == 1.0
+        if test_fail == 0:
+            assert a.timing(key + "_failed_slices") == 0.0 and a.timing(key + "_mode") == 1.0     # small meshes: 8 windows of 8 192 cover any slice
+        elif test_fail > 0:                                            # uncovered slices all over the numbering: found through their flags
+            assert a.timing(key + "_failed_slices") > 0 and a.timing(key + "_mode") == 2.0
+        else:                                                          # a short prefix of uncovered slices: codes from the slice behind it
+            assert a.timing(key + "_failed_slices") == -test_fail and a.timing(key + "_mode") == 1.0
     for e in (a, b):
         e.load_problem(P.rhs, P.rhs)
     ha, hb = a.run_cycles(4, 2), b.run_cycles(4, 2)
