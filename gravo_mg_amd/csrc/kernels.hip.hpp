@@ -1184,7 +1184,9 @@ __global__ __launch_bounds__(kBlock) void residual_norm_partials(const int64_t* 
 // residual b - A x as the fp32 right-hand side of the mixed-precision inner cycle (the defect-correction loop of BASELINE config 5).
 constexpr int kNormWaves = 16;      // slices (waves) per block of the norm kernel: 1024 threads, one partial per 16 slices
 template <int D, int MODE, int C16 = 0>
-__global__ __launch_bounds__(kNormWaves * 64) void residual_norm_slices(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
+// (second launch bound: 8 waves per SIMD, i.e. TWO of these 1024-thread blocks per CU -- the d = 3 instantiation with the 16-bit codes
+// took 66 registers without it, one block per CU, 94 -> 116 us)
+__global__ __launch_bounds__(kNormWaves * 64, 8) void residual_norm_slices(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                                const double* __restrict__ val, const double* __restrict__ diag,
                                                                const double* __restrict__ b, const double* __restrict__ x,
                                                                const double* __restrict__ weight, int ld, int n_slices,
