@@ -24,7 +24,8 @@ def run(tag, H, mass, lhs, rhs):
         if no16 == 0: ref = (hist, x)
         else: out["bitwise_equal"] = bool(np.array_equal(hist, ref[0]) and np.array_equal(x, ref[1]))
         print(out, flush=True)
-for cfg in ("4s", "5"):
+run("3M", *bench.build_workload(1732, 1732, "natural"))
+for cfg in ("4s",):
     name, H, mass, lhs, rhs = bench.build_config(cfg)
     run(cfg, H, mass, lhs, rhs)
 PY

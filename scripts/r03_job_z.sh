@@ -1,3 +1,3 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03z; mkdir -p $O; cd $R
-timeout 1800 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
-( for c in 4 4r 3 4s 5; do python scripts/ab_cycle.py --config $c --label "codes"; done ) 2>/dev/null | cut -c1-330 | tee $O/ab_codes.jsonl
+for rep in 1 2; do for v in plain bound; do GMG_LIB_PATH=$R/scripts/micro/ab/lib_$v.so python scripts/ab_cycle.py --config 4 --label "$v" 2>/dev/null | cut -c1-200; done; done
+for v in plain bound; do GMG_LIB_PATH=$R/scripts/micro/ab/lib_$v.so python scripts/ab_cycle.py --config 4s --label "$v" 2>/dev/null | cut -c1-200; GMG_LIB_PATH=$R/scripts/micro/ab/lib_$v.so python scripts/ab_cycle.py --config 3 --label "$v" 2>/dev/null | cut -c1-200; done
