@@ -25,7 +25,8 @@ def run(tag, H, mass, lhs, rhs):
         else: out["bitwise_equal"] = bool(np.array_equal(hist, ref[0]) and np.array_equal(x, ref[1]))
         print(out, flush=True)
 run("3M", *bench.build_workload(1732, 1732, "natural"))
-for cfg in ("4s",):
+run("8M", *bench.build_workload(2829, 2829, "natural"))
+for cfg in ("4r", "3", "4s", "5"):
     name, H, mass, lhs, rhs = bench.build_config(cfg)
     run(cfg, H, mass, lhs, rhs)
 PY
