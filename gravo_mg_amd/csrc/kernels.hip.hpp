@@ -5,8 +5,12 @@
 // val[] 512 contiguous bytes (perfectly coalesced streams); the only irregular access is the gather of
 // x[col].  Each lane accumulates its row sequentially in stored (ascending device column) order, so the
 // result is deterministic and independent of the launch geometry.  These are HBM-bound irregular sparse
-// contractions (0.17-0.25 flop/byte): no MFMA, no LDS -- the slice pointer is wave-uniform (scalar
-// loads), x lives in L2 / Infinity Cache (24 MB at 3 M unknowns), matrices stream once per launch.
+// contractions (0.17-0.25 flop/byte): no MFMA -- the slice pointer is wave-uniform (scalar loads), x lives in
+// L2 / Infinity Cache (24 MB at 3 M unknowns), matrices stream once per launch.  Staging x tiles of the fine level in LDS
+// (the north star's suggestion) was measured not to pay: PMC shows HBM traffic within 5-16 % of the compulsory bytes in
+// every vertex ordering -- the gathers are served by L2, what separates orderings is cache lines per gather instruction,
+// which a staging pass would touch just the same (profiles/README.md, round 3).  What did pay on the fine level is FEWER
+// bytes: 16-bit column codes, below.  LDS is used where rows of a block depend on each other (block sweeps, levels >= 1).
 //
 // Dense multi-vectors: column-major, leading dimension ld (= padded level size), D columns.
 #pragma once
