@@ -88,6 +88,7 @@ SIGNATURES = {
     "gmg_vcycle": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "gmg_smooth_residual": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_solve": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _ip, _dp, _dp]),
+    "gmg_solve_x0_rhs": (C.c_int, [_vp, _dp, _dp, C.c_int, C.c_double, C.c_int, C.c_int, _ip, _dp, _dp]),
     "gmg_load_problem": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "gmg_run_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "gmg_fetch_solution": (C.c_int, [_vp, _dp]),
@@ -513,11 +514,16 @@ class Engine:
         """Returns (x, iterations, residue, convergence[(ms, residue), ...]).  x0 defaults to rhs
         (gravomg_bindings/src/cpp/core.cpp:69)."""
         B = _f64(rhs)
-        X = B.copy(order="F") if x0 is None else _f64(x0).copy(order="F")
         iters, res = C.c_int(), C.c_double()
         conv = np.zeros(2 * max(int(max_iter), 1))
-        rc = lib().gmg_solve(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
-                             C.byref(iters), C.byref(res), _pd(conv))
+        if x0 is None:                       # gmg_solve_x0_rhs: x is output only (no copy of rhs made here, none uploaded)
+            X = np.empty(B.shape, order="F")
+            rc = lib().gmg_solve_x0_rhs(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
+                                        C.byref(iters), C.byref(res), _pd(conv))
+        else:
+            X = _f64(x0).copy(order="F")
+            rc = lib().gmg_solve(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
+                                 C.byref(iters), C.byref(res), _pd(conv))
         self.diverged = rc == DIVERGED       # not an error: the iteration did not contract, X holds the last iterate (include/gravomg_hip.h)
         if not self.diverged:
             self._chk(rc)

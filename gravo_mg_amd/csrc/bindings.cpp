@@ -233,9 +233,13 @@ public:
         MGBS::SparseMatrix& A = mapped.m;
         MGBS::MatrixXd b = to_dense(rhs);
         if (A.rows() != A.cols() || A.rows() != b.rows()) throw std::invalid_argument("lhs must be n x n and rhs n x d");
-        MGBS::MatrixXd x = b;
+        MGBS::MatrixXd x;                                   // x0 = rhs, formed on the device: no host copy of b here (24 MB per column set at 3 M)
+        x.rows_ = b.rows_; x.cols_ = b.cols_;
+        x.data.resize(b.data.size());
         solver->clearError();
+        solver->initialGuessIsRhs = true;
         solver->solve(A, b, x, 2);
+        solver->initialGuessIsRhs = false;
         check();
         return from_dense(x);
     }

@@ -1119,15 +1119,17 @@ int gmg_vcycle(gmg_handle h, const double* b, double* x, int d) try {
     return gmg_fetch_solution(h, x);
 } GMG_CATCH_H
 
-int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter, int* iters_out,
-              double* residue_out, double* conv) try {
+// x0: the initial guess (may be rhs itself: then it is copied on the device, not uploaded); x: receives the last iterate
+static int solve_common(gmg_handle h, const double* rhs, const double* x0, double* x, int d, double tol, int stop_type, int max_iter, int* iters_out,
+                        double* residue_out, double* conv) {
     NEED_DEVICE();
     int rc;
+    if (!rhs || !x0 || !x) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = check_norm_type(h, stop_type))) return rc;
     if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle (multigrid_solver.cpp:1411-1417)
     auto t_all = clk::now();
     HelperScope helper_scope(h);
-    if ((rc = gmg_load_problem(h, rhs, x, d))) return rc;
+    if ((rc = gmg_load_problem(h, rhs, x0, d))) return rc;
     h->timing["solve_load"] = ms_since(t_all);
     h->timing["coarse_host_ms"] = 0.0;
     auto t0 = clk::now();
@@ -1168,6 +1170,18 @@ int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int
     if (iters_out) *iters_out = it;
     if (residue_out) *residue_out = residue;
     return diverged ? GMG_DIVERGED : GMG_OK;
+}
+
+int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter, int* iters_out,
+              double* residue_out, double* conv) try {
+    return solve_common(h, rhs, x, x, d, tol, stop_type, max_iter, iters_out, residue_out, conv);
+} GMG_CATCH_H
+
+// The reference's binding always starts from x0 = rhs (gravomg_bindings/src/cpp/core.cpp:69): this entry point says so, and the
+// caller neither fills x with a copy of rhs nor pays for the comparison gmg_solve makes to find that out.  x is output only.
+int gmg_solve_x0_rhs(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter, int* iters_out,
+                     double* residue_out, double* conv) try {
+    return solve_common(h, rhs, rhs, x, d, tol, stop_type, max_iter, iters_out, residue_out, conv);
 } GMG_CATCH_H
 
 // ---- multi-GPU: one process per GPU, level 0 row-partitioned per colour, levels >= 1 replicated ---------------

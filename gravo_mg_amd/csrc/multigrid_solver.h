@@ -129,6 +129,9 @@ public:
 
     /* MI355X engine knobs (not in the reference) */
     gmg_config engineConfig;
+    /* Set by a caller that KNOWS the initial guess of the next solve() is the right-hand side (the binding: core.cpp:69): x is then
+       output only -- it need not hold a copy of rhs -- and the engine copies rhs to x on the device (gmg_solve_x0_rhs). */
+    bool initialGuessIsRhs = false;
     /* Creates the device engine and hands it the hierarchy (`U`) now rather than inside the first solve(); optional. */
     int prepareEngine();
     const char* lastError() const;

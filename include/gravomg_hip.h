@@ -189,6 +189,10 @@ int gmg_vcycle(gmg_handle h, const double* b, double* x, int d);
  * initial guess. */
 int gmg_solve(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter,
               int* iters_out, double* residue_out, double* conv);
+/* The same with the initial guess x0 = rhs, the only one the reference's Python binding ever passes (core.cpp:69): x is OUTPUT only --
+ * the caller does not fill it with a copy of rhs, and the engine copies rhs to x on the device instead of comparing and uploading. */
+int gmg_solve_x0_rhs(gmg_handle h, const double* rhs, double* x, int d, double tol, int stop_type, int max_iter,
+                     int* iters_out, double* residue_out, double* conv);
 
 /* ---- resident problem (device-resident b / x; what gmg_solve and bench.py are built from) ---------- */
 /* Upload rhs and the initial guess (natural numbering, n_0 x d) and keep them resident. */
