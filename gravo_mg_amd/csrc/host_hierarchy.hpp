@@ -231,17 +231,22 @@ public:
             if (opt.nested) {
                 for (int c = 0; c < nc; ++c) Pc[c] = P[sample[c]];
             } else {
-                std::vector<int> csize(nc, 0);
-                for (int f = 0; f < nf; ++f) { Pc[nearest[f]] = Pc[nearest[f]] + P[f]; ++csize[nearest[f]]; }
-                for (int c = 0; c < nc; ++c) {
-                    if (csize[c] == 1) {
-                        V3 s = P[sample[c]];
-                        for (int nb : cadj[c]) s = s + P[sample[nb]];
-                        Pc[c] = (1.0 / (cadj[c].size() + 1.0)) * s;
-                    } else {
-                        Pc[c] = (1.0 / csize[c]) * Pc[c];
+                // (cell by cell on all threads: `members` lists a cell's points in ascending index, the order in which the reference's
+                // single loop over the fine points adds them -- the sums have the same bits)
+                parallel_ranges(nc, T, [&](int lo, int hi, int) {
+                    for (int c = lo; c < hi; ++c) {
+                        V3 acc{0, 0, 0};
+                        for (int m = mem_ptr[c]; m < mem_ptr[c + 1]; ++m) acc = acc + P[members[m]];
+                        const int csize = mem_ptr[c + 1] - mem_ptr[c];
+                        if (csize == 1) {
+                            V3 s = P[sample[c]];
+                            for (int nb : cadj[c]) s = s + P[sample[nb]];
+                            Pc[c] = (1.0 / (cadj[c].size() + 1.0)) * s;
+                        } else {
+                            Pc[c] = (1.0 / csize) * acc;
+                        }
                     }
-                }
+                }, 1024);
             }
             auto t4 = clk::now();
             R.timing["next_positions"] += ms(t3, t4);

@@ -1,5 +1,3 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03z; mkdir -p $O; cd $R
-timeout 1500 python -m pytest tests/test_dropin_api.py tests/test_gpu_parity.py tests/test_gpu_p2p.py -m gpu -q -x 2>&1 | tail -2
-python bench.py --cpu-cycles 0 --no-variants 2>/dev/null | python -c "
-import sys,json; j=json.loads(sys.stdin.read()); print('solve_ms', j['solve_ms'], j['solver_timing_ms'], j['value'])"
-python scripts/dropin_timing.py 2>&1 | tail -6
+timeout 1200 python -m pytest tests/test_gpu_hierarchy.py tests/test_gpu_fullsize.py -m gpu -q -x 2>&1 | tail -2
+( python scripts/hierarchy_timing.py 2>&1 | grep -E "^natural"; python scripts/hierarchy_timing.py 2>&1 | grep -E "^natural" ) | cut -c1-330 | tee $O/hierarchy_timing.txt
