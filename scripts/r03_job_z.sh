@@ -1,3 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03z; mkdir -p $O; cd $R
-timeout 1200 python -m pytest tests/test_gpu_hierarchy.py tests/test_gpu_fullsize.py -m gpu -q -x 2>&1 | tail -2
-( python scripts/hierarchy_timing.py 2>&1 | grep -E "^natural"; python scripts/hierarchy_timing.py 2>&1 | grep -E "^natural" ) | cut -c1-330 | tee $O/hierarchy_timing.txt
+R=$GRAFT_REPO_ROOT; cd $R
+for i in 1 2 3; do timeout 1800 python -m pytest tests -m gpu -q -x -p no:cacheprovider 2>&1 | tail -1; done
+for i in 1 2 3; do timeout 600 python scripts/parity_sweep.py 2>/dev/null | tail -1 | cut -c1-60; done
+timeout 900 python scripts/soak.py 2>&1 | tail -1 | cut -c1-80
