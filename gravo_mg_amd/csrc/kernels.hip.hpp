@@ -156,17 +156,17 @@ __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr,
 // C16 = 0: 32-bit indices.  C16 = 1: codes from slice `from` on (the uncovered slices are a short prefix of the numbering -- tiny colour
 // classes come first -- and the branch on the wave-uniform slice number has nothing to wait for).  C16 = 2: uncovered slices anywhere,
 // found through their flag.  c16_arg = from | format << 30 (format 0: 13 offset bits / 8 windows, 1: 11 offset bits / 32 windows).
-template <class T, int D, int C16>
+template <class T, int D, int C16, int G = DotGroup<D>::value>
 __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
                                             const int* __restrict__ win_base, int c16_arg, const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                             T (&acc)[D]) {
     if constexpr (C16 == 1) {
         const int dbits = (c16_arg >> 30) & 1 ? 11 : 13;
-        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
-        else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false, G>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
+        else row_dot<T, D, G>(slice_ptr, col, val, x, ld, s, lane, acc);
     } else if constexpr (C16 == 2) {
-        row_dot16<T, D, true>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
-    } else row_dot<T, D>(slice_ptr, col, val, x, ld, s, lane, acc);
+        row_dot16<T, D, true, G>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
+    } else row_dot<T, D, G>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 
 // Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
@@ -919,10 +919,11 @@ __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice
                                                const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s,
                                                const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int lane = threadIdx.x & 63;
-    T acc[D];
-    row_dot_sel<T, D, C16>(slice_ptr, col, col16, win_base, c16_arg, val, x, ldx, s, lane, acc);
-    if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     const int srow = s * (64 / LPR) + lane / LPR;
+    T acc[D];
+    // (quad layout = restrictions: a lane holds 4-5 of a row's ~18 entries -- one group of 8 in flight instead of 4 + a dependent tail)
+    row_dot_sel<T, D, C16, (LPR == 4 ? 8 : DotGroup<D>::value)>(slice_ptr, col, col16, win_base, c16_arg, val, x, ldx, s, lane, acc);
+    if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     // ADD = 1 is a read-modify-write of y: only safe when every output row is produced by exactly one slice row, so that
     // instantiation never takes an output-row map (slice row == output row: unique by construction)
     const int row = (!ADD && row_of) ? row_of[srow] : srow;
