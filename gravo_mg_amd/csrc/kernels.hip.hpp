@@ -57,9 +57,9 @@ __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const 
 // acc[c] = sum_j val[j] * x[col[j] + c*ld] over this lane's row of slice s.  The slice width is wave-uniform, so
 // the dispatch on it is a scalar branch: full groups of 8, then one width-specialised tail (no serialized
 // remainder loop -- with 6-7 entries per mesh row and 3 per prolongation row the tail IS the row).
-// (G entries per group: 8 with one or two right-hand sides; 4 with three or four -- 8 x D gathered values in flight cost 100 VGPRs
-// at D = 3, i.e. 4 wavefronts per SIMD instead of 8)
-template <int D> struct DotGroup { static constexpr int value = D >= 3 ? 4 : 8; };
+// (G entries per group: 8 with one or two right-hand sides; 6 with three -- a mesh row's six entries are one group, 90 VGPRs, 5 wavefronts
+// per SIMD: 22.9 us per colour launch against 23.5 with groups of 4 and 8 wavefronts --; 4 with four)
+template <int D> struct DotGroup { static constexpr int value = D >= 4 ? 4 : (D == 3 ? 6 : 8); };
 template <class T, int D, int G = DotGroup<D>::value>
 __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                         const T* __restrict__ val, const T* x, int ld, int s, int lane,
