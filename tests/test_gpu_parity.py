@@ -303,6 +303,9 @@ def test_solve_reaches_tolerance_and_matches_reference_solution(setup, oracle):
     assert res2 <= tight and reso2 <= tight and it2 <= ito2 + 2       # (the over-relaxed level-0 sweep usually needs fewer cycles)
     dx2 = np.sqrt((m * (x2 - xo2) ** 2).sum()) / np.sqrt((m * xo2 ** 2).sum())
     assert dx2 <= 100 * tight
+    # gmg_solve_x0_rhs (no x0 given: x is output only, rhs copied to x on the device) and gmg_solve from an explicit copy of rhs: the same bits
+    x3, it3, res3, _ = eng.solve(P.rhs, x0=np.array(P.rhs, copy=True), tol=tol, stop_type=2, max_iter=100)
+    assert it3 == it and res3 == res and np.array_equal(x3, x)
 
 
 @pytest.mark.parametrize("variant", ["jacobi", "device_coarse", "graph", "exact_gs", "blocked_all", "small_blocks", "lane_per_row_blocks"])
