@@ -140,6 +140,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
         hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) == hipSuccess) {
         h->has_device = true;
         h->own_stream = h->stream;
+        { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0) h->n_cus = cus; else (void)hipGetLastError(); }
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
         if (const char* e = std::getenv("GMG_POLL")) h->poll = std::atoi(e) != 0;

@@ -133,6 +133,16 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
     if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
 }
 
+// Launch geometry of the entry-parallel block sweep (kernels.hip.hpp::gs_block_ep): persistent workgroups -- `waves_per_cu` per compute
+// unit, each sweeping several blocks -- when the level has more blocks than that; one block per workgroup otherwise.
+// GMG_EP_WAVES_PER_CU: A/B aid (0 = always one block per workgroup, the launch of rounds 2 and 3).
+inline int ep_persistent_grid(gmg_handle h, int vgrid) {
+    static const int env_wpc = std::getenv("GMG_EP_WAVES_PER_CU") ? std::atoi(std::getenv("GMG_EP_WAVES_PER_CU")) : -1;
+    const int wpc = env_wpc >= 0 ? env_wpc : 0;
+    if (wpc > 0 && vgrid > wpc * h->n_cus) return std::max(8, wpc * h->n_cus / 8 * 8);
+    return vgrid;
+}
+
 // block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
 // One block-hybrid sweep in -> out over blocks [b0, b0 + nb) of a blocked level (in == nullptr: the iterate is the zero vector).
 // The kernels find their rows through blk_begin[block]: a sub-range is the same launch on offset block tables.
@@ -150,12 +160,12 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         if (l.use_ep) {
-            const int grid = (nb + 7) / 8 * 8;          // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, grid)
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64),
-                                              (size_t)D * 64 * sizeof(T) + std::max((size_t)l.ep_cap_e * sizeof(T), (size_t)l.ep_cap_l * (sizeof(T) + 2)), h->stream,
+            const int vgrid = (nb + 7) / 8 * 8;         // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, vgrid)
+            const int grid = ep_persistent_grid(h, vgrid);
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
                                               ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
                                               Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0));
+                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid));
         } else if (l.use_bcsr && d > 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                               (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, blk_begin,

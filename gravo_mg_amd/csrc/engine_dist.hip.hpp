@@ -620,21 +620,42 @@ int gmg_p2p_fetch(gmg_handle h, double* x) try {
 
 // gmg_solve over the ranks: x0 in, solution out (complete on every rank).  The reference's loop, multigrid_solver.cpp:1408-1419:
 // do { V-cycle; residualCheck } while (residue > tol && it < maxIter) -- every rank sees the same residues (the norm sums are
-// all-reduced in rank order), so every rank leaves the loop in the same iteration.  Collective.
+// all-reduced in rank order), so every rank leaves the loop in the same iteration and takes the same decision below.  Collective.
+// The safeguards of the single-GPU solve (engine.hip::solve_common) apply unchanged: the loop stops at a residue that is not
+// finite or 1e4 x the smallest seen; an iteration that ends above the tolerance with such a residue, or with one larger than
+// after its first cycle, returns GMG_DIVERGED (x still receives the last iterate, as in the reference) and the caller can repeat
+// the solve with Gauss-Seidel in colour order on every level (block_rows = 0, gs_omega = 1).  Timing keys as in gmg_solve.
 int gmg_p2p_solve(gmg_handle h, const double* b, double* x, double tol, int stop_type, int max_iter, int* iters_out, double* residue_out) try {
     if (!h) return GMG_ERR_INVALID;
-    if (!b || !x || max_iter < 1) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if (!b || !x) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle
+    auto t_all = clk::now();
     int rc = gmg_p2p_load(h, b, x);
     if (rc) return rc;
+    h->timing["solve_load"] = ms_since(t_all);
+    auto t0 = clk::now();
     int it = 0;
-    double residue = 0.0;
+    double residue = 0.0, first_residue = 0.0, least_residue = 0.0;
+    bool blown = false;
     do {
         if ((rc = gmg_p2p_cycles(h, 1, stop_type, &residue))) return rc;
+        if (it == 0) first_residue = least_residue = residue;
+        if (residue < least_residue) least_residue = residue;
         ++it;
-    } while (residue > tol && it < max_iter);
+        blown = !std::isfinite(residue) || (it >= 3 && residue > 1e4 * least_residue);
+    } while (residue > tol && it < max_iter && !blown);
+    h->timing["cycles"] = ms_since(t0);
+    const bool diverged = !(residue <= tol) && (blown || (it > 1 && residue > first_residue));
+    h->timing["diverged"] = diverged ? 1.0 : 0.0;
+    h->timing["blown_up"] = blown ? 1.0 : 0.0;
+    h->timing["iterations"] = it;
+    h->timing["residue"] = residue;
     if (iters_out) *iters_out = it;
     if (residue_out) *residue_out = residue;
-    return gmg_p2p_fetch(h, x);
+    rc = gmg_p2p_fetch(h, x);
+    h->timing["solve_call"] = ms_since(t_all);
+    if (rc) return rc;
+    return diverged ? GMG_DIVERGED : GMG_OK;
 } GMG_CATCH_H
 
 // Average duration (ms) of one exchange of the named kind (push + wait + pull, one launch), `reps` back to back; collective --

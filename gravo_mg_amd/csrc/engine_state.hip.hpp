@@ -130,6 +130,7 @@ struct gmg_solver_s {
     gmg_config cfg;
     std::string err;
     bool has_device = false;
+    int n_cus = 256;                      // compute units of the device (launch geometry of the persistent kernels)
     hipStream_t stream = nullptr;
     int L = -1;
     std::vector<Compressed> U;

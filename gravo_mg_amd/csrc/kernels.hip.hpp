@@ -541,52 +541,90 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
 // entry-parallel version, which also reduced the in-block products through LDS colour by colour, had ~85 and was slower
 // than the SELL sweep).
 constexpr int kEpE = 12, kEpL = 8, kEpW = 16;
+constexpr int kEpZero = 16;                                            // zero slots in LDS (see ep_lds_bytes)
+
+// Raw buffer access to a wave-uniform chunk (base pointer and byte count in SGPRs): ONE instruction per load, no per-lane bounds
+// test and no 64-bit address arithmetic -- reads past `bytes` return zero without touching memory.  (gfx950 buffer resource, word 3 =
+// 0x00020000: raw 32-bit data format, bounds checking on.)  `NT`: streamed once (matrix arrays).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ep_chunk(const void* base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+template <class T, bool NT> __device__ __forceinline__ T ep_load(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    static_assert(sizeof(T) == 8 || sizeof(T) == 4 || sizeof(T) == 2, "");
+    constexpr int aux = NT ? 2 : 0;
+    T out;
+    if constexpr (sizeof(T) == 8) { auto w = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, aux); __builtin_memcpy(&out, &w, 8); }
+    else if constexpr (sizeof(T) == 4) { auto w = __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, aux); __builtin_memcpy(&out, &w, 4); }
+    else { auto w = __builtin_amdgcn_raw_buffer_load_b16(r, byte_off, 0, aux); __builtin_memcpy(&out, &w, 2); }
+    return out;
+}
+
+// dynamic LDS of gs_block_ep: the block's x (D x 64), kEpZero zero slots, and the staging region -- first the products of the explicit
+// entries (at least the register window's 64 kEpE, so that no slot needs a guard), then the lower entries (values + 16-bit columns)
+template <class T> inline size_t ep_lds_bytes(int D, int cap_e, int cap_l) {
+    const size_t pe = (size_t)(cap_e > 64 * kEpE ? cap_e : 64 * kEpE), sl = (size_t)(cap_l > 64 * kEpL ? cap_l : 64 * kEpL);
+    const size_t stage = pe * sizeof(T) > sl * (sizeof(T) + 2) ? pe * sizeof(T) : sl * (sizeof(T) + 2);
+    return ((size_t)D * 64 + kEpZero) * sizeof(T) + stage;
+}
+
+// Round 4: the sweep is bound by the INSTRUCTIONS a wave issues -- a SIMD retires one block every ~3.2 us whether four or five
+// waves share it (persistent launches with 8 ... 20 workgroups per compute unit: 12 us per block and wave up to 4 waves per SIMD,
+// 16.5 us with 5; profiles/README.md round 4), 1 375 instructions per block at ~5.5 cycles each, of which the guarded loads (a
+// scalar branch, a lane mask and 64-bit address arithmetic per slot), the selects of the row sums and of the transposition were
+// more than half.  This version issues about half as many: chunk loads through buffer resources (above), no guards at all on
+// the register window (LDS is sized for the whole window; unused slots read zeros and multiply x[0] by zero), out-of-run reads
+// redirected to a zero region of LDS by ONE address select instead of value selects.  Same operations in the same order: the
+// results are bitwise those of the round-2 kernel.
+// `vgrid` > gridDim.x: persistent workgroups -- workgroup w sweeps the virtual blocks w, w + gridDim.x, ... (the XCD-aware map is
+// applied to the virtual index, so a workgroup's blocks stay on its XCD's part of the level).
 template <class T, int D>
 __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
                                                   const unsigned char* __restrict__ row_color, const int* __restrict__ l_ptr,
                                                   const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
                                                   const int* __restrict__ e_ptr, const int* __restrict__ e_col,
                                                   const T* __restrict__ e_val, const T* __restrict__ diag, const T* __restrict__ b,
-                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks, int blk0) {
+                                                  const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks, int blk0,
+                                                  int vgrid) {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                            // D x 64: the block's new x
-    T* pbuf = xs + D * 64;                                             // cap_e products of one column ...
-    T* sval = pbuf;                                                    // ... later the staged lower entries: cap_l values
-    unsigned short* scol = reinterpret_cast<unsigned short*>(sval + cap_l);      // + cap_l local columns
-    // XCD-aware block map: block b runs on XCD b % 8; give every XCD a contiguous run of (spatially neighbouring) blocks
-    const int chunk = (int)(gridDim.x >> 3);
-    const int blk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3));
-    if (blk >= n_blocks) return;
+    T* zeroT = xs + D * 64;                                            // kEpZero zeros: where reads beyond a row's run go
+    const unsigned short* zero16 = reinterpret_cast<const unsigned short*>(zeroT);
+    T* pbuf = zeroT + kEpZero;                                         // products of one column's explicit entries ...
+    T* sval = pbuf;                                                    // ... later the staged lower entries: values
+    unsigned short* scol = reinterpret_cast<unsigned short*>(sval + (cap_l > 64 * kEpL ? cap_l : 64 * kEpL));      // and local columns
+    const int chunk = vgrid >> 3;
     const int lane = threadIdx.x;
+    if (lane < kEpZero) zeroT[lane] = (T)0.0;
+  for (int vb = (int)blockIdx.x; vb < vgrid; vb += (int)gridDim.x) {
+    // XCD-aware block map: workgroup w runs on XCD w % 8; every XCD gets a contiguous run of (spatially neighbouring) blocks
+    const int blk = __builtin_amdgcn_readfirstlane((vb & 7) * chunk + (vb >> 3));
+    if (blk >= n_blocks) continue;
     // 64 rows (padding rows: no entries, diag 1, b 0, colour 0).  Without a block table the blocks are the level's own, in order:
     // block b starts at row 64 (blk0 + b) -- one dependent load less in front of everything else the wave does
-    const int r0 = blk_begin ? blk_begin[blk] : (blk0 + blk) << 6;
+    const int r0 = __builtin_amdgcn_readfirstlane(blk_begin ? blk_begin[blk] : (blk0 + blk) << 6);
     const int row = r0 + lane;
     const int e0 = e_ptr[r0], e1 = e_ptr[r0 + 64];
     const int q0 = l_ptr[r0], q1 = l_ptr[r0 + 64];
     const int nE = x_in ? e1 - e0 : 0;                                 // zero iterate: the explicit part vanishes
     const int nL = q1 - q0;
-    // ---- all loads in flight
+    int lane_b = lane;                                                 // (opaque per block: keeps the slot offsets in the loads' immediate fields instead of in hoisted registers)
+    asm volatile("" : "+v"(lane_b));
+    // ---- all loads in flight (register windows: 64 kEpE explicit, 64 kEpL lower entries; what a block has beyond them is read later)
+    const __amdgpu_buffer_rsrc_t rc = ep_chunk(e_col + e0, nE * 4), rv = ep_chunk(e_val + e0, nE * (int)sizeof(T));
+    const __amdgpu_buffer_rsrc_t rlv = ep_chunk(l_val + q0, nL * (int)sizeof(T)), rlc = ep_chunk(l_col + q0, nL * 2);
     int ec[kEpE];
     T ev[kEpE];
+    if (nE > 0) {
 #pragma unroll
-    for (int k = 0; k < kEpE; ++k) {
-        ec[k] = row; ev[k] = (T)0.0;
-        if (64 * k < nE) {                                             // wave-uniform
-            const int e = e0 + 64 * k + lane;
-            if (e < e1) { ec[k] = __builtin_nontemporal_load(e_col + e); ev[k] = __builtin_nontemporal_load(e_val + e); }
-        }
+        for (int k = 0; k < kEpE; ++k) { ec[k] = ep_load<int, true>(rc, lane_b * 4 + 256 * k); ev[k] = ep_load<T, true>(rv, lane_b * (int)sizeof(T) + 64 * k * (int)sizeof(T)); }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kEpE; ++k) { ec[k] = 0; ev[k] = (T)0.0; }
     }
     T lv[kEpL];
     unsigned short lc[kEpL];
 #pragma unroll
-    for (int m = 0; m < kEpL; ++m) {
-        lv[m] = (T)0.0; lc[m] = 0;
-        if (64 * m < nL) {
-            const int e = q0 + 64 * m + lane;
-            if (e < q1) { lv[m] = __builtin_nontemporal_load(l_val + e); lc[m] = __builtin_nontemporal_load(l_col + e); }
-        }
-    }
+    for (int m = 0; m < kEpL; ++m) { lv[m] = ep_load<T, true>(rlv, lane_b * (int)sizeof(T) + 64 * m * (int)sizeof(T)); lc[m] = ep_load<unsigned short, true>(rlc, lane_b * 2 + 128 * m); }
     const int eb = e_ptr[row] - e0, ee = x_in ? e_ptr[row + 1] - e0 : eb;
     const int lb = l_ptr[row] - q0, nlow = l_ptr[row + 1] - q0 - lb;
     const int mycolor = row_color[row];
@@ -598,19 +636,28 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     if (nE > 0) {
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const T* xc = x_in + (int64_t)c * ld;
+            const __amdgpu_buffer_rsrc_t rx = ep_chunk(x_in + (int64_t)c * ld, ld * (int)sizeof(T));
+            T xg[kEpE];
 #pragma unroll
-            for (int k = 0; k < kEpE; ++k)
-                if (64 * k < nE) pbuf[64 * k + lane] = ev[k] * xc[ec[k]];
-            for (int e = 64 * kEpE + lane; e < nE; e += 64) pbuf[e] = e_val[e0 + e] * xc[e_col[e0 + e]];      // beyond the register window (rare)
+            for (int k = 0; k < kEpE; ++k) xg[k] = ep_load<T, false>(rx, ec[k] * (int)sizeof(T));
+#pragma unroll
+            for (int k = 0; k < kEpE; ++k) pbuf[64 * k + lane] = ev[k] * xg[k];
+            if (nE > 64 * kEpE) {                                      // beyond the register window (rare)
+                const T* xc = x_in + (int64_t)c * ld;
+                for (int e = 64 * kEpE + lane; e < nE; e += 64) pbuf[e] = e_val[e0 + e] * xc[e_col[e0 + e]];
+            }
             __syncthreads();
+            // every row sums its run in stored order, eight reads in flight; reads beyond the run hit the zero slots
             T acc = (T)0.0;
-            for (int q = eb; q < ee; q += 16) {                        // all reads of a batch in flight, then the adds in stored order
-                T p[16];
+            const T* pa = pbuf + eb;
+            int rem = ee - eb;
+            while (__builtin_amdgcn_ballot_w64(rem > 0)) {
+                T p[8];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) p[j] = q + j < ee ? pbuf[q + j] : (T)0.0;
+                for (int j = 0; j < 8; ++j) p[j] = (rem > j ? pa : zeroT)[j];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc += p[j];
+                for (int j = 0; j < 8; ++j) acc += p[j];
+                pa += 8; rem -= 8;
             }
             rhs[c] -= acc;
             __syncthreads();                                           // the buffer is free again
@@ -618,29 +665,25 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     }
     // ---- L: slots -> LDS -> the row's lane
 #pragma unroll
-    for (int m = 0; m < kEpL; ++m)
-        if (64 * m < nL) {
-            const int e = 64 * m + lane;
-            if (e < nL) { sval[e] = lv[m]; scol[e] = lc[m]; }
-        }
-    for (int e = 64 * kEpL + lane; e < nL; e += 64) { sval[e] = l_val[q0 + e]; scol[e] = l_col[q0 + e]; }
+    for (int m = 0; m < kEpL; ++m) { sval[64 * m + lane] = lv[m]; scol[64 * m + lane] = lc[m]; }
+    if (nL > 64 * kEpL)
+        for (int e = 64 * kEpL + lane; e < nL; e += 64) { sval[e] = l_val[q0 + e]; scol[e] = l_col[q0 + e]; }
     __syncthreads();
     T v[kEpW];
-    unsigned cpk[kEpW / 4];                                            // local columns (< 64), four to a register
+    int xa[kEpW];                                                      // local columns (< 64)
+    {
+        const T* va = sval + lb;
+        const unsigned short* ca = scol + lb;
 #pragma unroll
-    for (int j = 0; j < kEpW / 4; ++j) cpk[j] = 0u;
-#pragma unroll
-    for (int j = 0; j < kEpW; ++j) {                                   // (selects, not branches: LDS reads of slot 0 are always valid, and a
-        const int at = j < nlow ? lb + j : 0;                          // conditional element store makes hipcc copy whole fp32 register tuples)
-        const T t = sval[at];
-        const unsigned cc = scol[at];
-        v[j] = j < nlow ? t : (T)0.0;
-        cpk[j >> 2] |= (j < nlow ? cc : 0u) << ((j & 3) * 8);
+        for (int j = 0; j < kEpW; ++j) {                               // (one select of the ADDRESS per array: slots beyond the row's run read zeros)
+            v[j] = (j < nlow ? va : (const T*)zeroT)[j];
+            xa[j] = (j < nlow ? ca : zero16)[j];
+        }
     }
-#define GMG_EP_COL(j) ((int)((cpk[(j) >> 2] >> (((j) & 3) * 8)) & 0xffu))
+    const bool longrow = nlow > 8;
     const int nc = blk_ncolors[blk];
     for (int col = 0; col < nc; ++col) {
-        const bool wide = __ballot(mycolor == col && nlow > 8) != 0ull;      // wave-uniform: a row of this colour has more than 8 lower entries
+        const bool wide = __builtin_amdgcn_ballot_w64(mycolor == col && longrow) != 0ull;      // wave-uniform: a row of this colour has more than 8 lower entries
         if (mycolor == col) {
             T s_[D];
 #pragma unroll
@@ -653,7 +696,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
 #pragma unroll
-                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + GMG_EP_COL(j0 + j)];
+                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + xa[j0 + j]];
 #pragma unroll
                 for (int j = 0; j < CH; ++j)
 #pragma unroll
@@ -666,7 +709,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 #pragma unroll
                     for (int j = 0; j < CH; ++j)
 #pragma unroll
-                        for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + GMG_EP_COL(j0 + j)];
+                        for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + xa[j0 + j]];
 #pragma unroll
                     for (int j = 0; j < CH; ++j)
 #pragma unroll
@@ -686,7 +729,8 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
-#undef GMG_EP_COL
+    __syncthreads();                                                   // xs and the staging area are free for the next block
+  }
 }
 
 // Residual of a blocked level RIGHT AFTER a block-hybrid sweep x_old -> x_new, from the sweep's own explicit part: the sweep solved
