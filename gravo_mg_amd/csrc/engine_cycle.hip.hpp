@@ -223,7 +223,7 @@ bool launch_residual_delta(gmg_handle h, Level& l, int d, T* r, const int* begin
     const T* x_new = Prec<T>::x(l);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_delta_ep<T, D>), dim3(grid), dim3(64), (size_t)std::max(l.ep_cap_e, 64) * sizeof(T), h->stream, begin_table,
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_delta_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(0, l.ep_cap_e, 0), h->stream, begin_table,
                                           l.ee_ptr, l.ee_col, Prec<T>::eeval(l), (x_old ? x_old + (size_t)c0 * ld : nullptr), x_new + (size_t)c0 * ld,
                                           r + (size_t)c0 * ld, ld, nb));
     }

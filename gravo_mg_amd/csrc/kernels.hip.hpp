@@ -541,7 +541,11 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
 // entry-parallel version, which also reduced the in-block products through LDS colour by colour, had ~85 and was slower
 // than the SELL sweep).
 constexpr int kEpE = 12, kEpL = 8, kEpW = 16;
-constexpr int kEpZero = 16;                                            // zero slots in LDS (see ep_lds_bytes)
+constexpr int kEpZeroBytes = 256;                                      // zero region in LDS: 16 staged records / 32 doubles (see ep_lds_bytes)
+// a staged lower entry: value + byte offset of its column inside the block's x, read back with ONE LDS instruction
+template <class T> struct EpRec;
+template <> struct EpRec<double> { typedef int type __attribute__((ext_vector_type(4))); };
+template <> struct EpRec<float> { typedef int type __attribute__((ext_vector_type(2))); };
 
 // Raw buffer access to a wave-uniform chunk (base pointer and byte count in SGPRs): ONE instruction per load, no per-lane bounds
 // test and no 64-bit address arithmetic -- reads past `bytes` return zero without touching memory.  (gfx950 buffer resource, word 3 =
@@ -559,12 +563,12 @@ template <class T, bool NT> __device__ __forceinline__ T ep_load(__amdgpu_buffer
     return out;
 }
 
-// dynamic LDS of gs_block_ep: the block's x (D x 64), kEpZero zero slots, and the staging region -- first the products of the explicit
-// entries (at least the register window's 64 kEpE, so that no slot needs a guard), then the lower entries (values + 16-bit columns)
+// dynamic LDS of gs_block_ep: the block's x (D x 64), the zero region, and the staging region -- first the products of the explicit
+// entries (at least the register window's 64 kEpE, so that no slot needs a guard), then the lower entries as records
 template <class T> inline size_t ep_lds_bytes(int D, int cap_e, int cap_l) {
     const size_t pe = (size_t)(cap_e > 64 * kEpE ? cap_e : 64 * kEpE), sl = (size_t)(cap_l > 64 * kEpL ? cap_l : 64 * kEpL);
-    const size_t stage = pe * sizeof(T) > sl * (sizeof(T) + 2) ? pe * sizeof(T) : sl * (sizeof(T) + 2);
-    return ((size_t)D * 64 + kEpZero) * sizeof(T) + stage;
+    const size_t stage = pe * sizeof(T) > sl * sizeof(typename EpRec<T>::type) ? pe * sizeof(T) : sl * sizeof(typename EpRec<T>::type);
+    return (size_t)D * 64 * sizeof(T) + kEpZeroBytes + stage;
 }
 
 // Round 4: the sweep is bound by the INSTRUCTIONS a wave issues -- a SIMD retires one block every ~3.2 us whether four or five
@@ -587,14 +591,14 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
                                                   int vgrid) {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                            // D x 64: the block's new x
-    T* zeroT = xs + D * 64;                                            // kEpZero zeros: where reads beyond a row's run go
-    const unsigned short* zero16 = reinterpret_cast<const unsigned short*>(zeroT);
-    T* pbuf = zeroT + kEpZero;                                         // products of one column's explicit entries ...
-    T* sval = pbuf;                                                    // ... later the staged lower entries: values
-    unsigned short* scol = reinterpret_cast<unsigned short*>(sval + (cap_l > 64 * kEpL ? cap_l : 64 * kEpL));      // and local columns
+    typedef typename EpRec<T>::type Rec;
+    T* zeroT = xs + D * 64;                                            // the zero region: where reads beyond a row's run go
+    const Rec* zeroR = reinterpret_cast<const Rec*>(zeroT);
+    T* pbuf = zeroT + kEpZeroBytes / sizeof(T);                        // products of one column's explicit entries ...
+    Rec* srec = reinterpret_cast<Rec*>(pbuf);                          // ... later the staged lower entries
     const int chunk = vgrid >> 3;
     const int lane = threadIdx.x;
-    if (lane < kEpZero) zeroT[lane] = (T)0.0;
+    reinterpret_cast<int*>(zeroT)[lane] = 0;                           // kEpZeroBytes = 64 x 4
   for (int vb = (int)blockIdx.x; vb < vgrid; vb += (int)gridDim.x) {
     // XCD-aware block map: workgroup w runs on XCD w % 8; every XCD gets a contiguous run of (spatially neighbouring) blocks
     const int blk = __builtin_amdgcn_readfirstlane((vb & 7) * chunk + (vb >> 3));
@@ -663,63 +667,76 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
             __syncthreads();                                           // the buffer is free again
         }
     }
-    // ---- L: slots -> LDS -> the row's lane
+    // ---- L: slots -> LDS (records: value, byte offset of the column in xs) -> the row's lane
+    auto make_rec = [](T val, unsigned short col) {
+        Rec rr;
+        if constexpr (sizeof(T) == 8) { long long bits; __builtin_memcpy(&bits, &val, 8); rr.x = (int)bits; rr.y = (int)(bits >> 32); rr.z = (int)col * 8; rr.w = 0; }
+        else { int bits; __builtin_memcpy(&bits, &val, 4); rr.x = bits; rr.y = (int)col * 4; }
+        return rr;
+    };
 #pragma unroll
-    for (int m = 0; m < kEpL; ++m) { sval[64 * m + lane] = lv[m]; scol[64 * m + lane] = lc[m]; }
+    for (int m = 0; m < kEpL; ++m) srec[64 * m + lane] = make_rec(lv[m], lc[m]);
     if (nL > 64 * kEpL)
-        for (int e = 64 * kEpL + lane; e < nL; e += 64) { sval[e] = l_val[q0 + e]; scol[e] = l_col[q0 + e]; }
+        for (int e = 64 * kEpL + lane; e < nL; e += 64) srec[e] = make_rec(l_val[q0 + e], l_col[q0 + e]);
     __syncthreads();
     T v[kEpW];
-    int xa[kEpW];                                                      // local columns (< 64)
+    int xa[kEpW];                                                      // byte offsets of the columns inside xs (column 0 of a multi-vector)
     {
-        const T* va = sval + lb;
-        const unsigned short* ca = scol + lb;
+        const Rec* ra = srec + lb;
 #pragma unroll
-        for (int j = 0; j < kEpW; ++j) {                               // (one select of the ADDRESS per array: slots beyond the row's run read zeros)
-            v[j] = (j < nlow ? va : (const T*)zeroT)[j];
-            xa[j] = (j < nlow ? ca : zero16)[j];
+        for (int j = 0; j < kEpW; ++j) {                               // (one select of the ADDRESS: slots beyond the row's run read a zero record)
+            const Rec rr = (j < nlow ? ra : zeroR)[j];
+            if constexpr (sizeof(T) == 8) { const long long bits = ((long long)(unsigned)rr.x) | ((long long)rr.y << 32); __builtin_memcpy(&v[j], &bits, 8); xa[j] = rr.z; }
+            else { const int bits = rr.x; __builtin_memcpy(&v[j], &bits, 4); xa[j] = rr.y; }
         }
     }
-    const bool longrow = nlow > 8;
     const int nc = blk_ncolors[blk];
-    for (int col = 0; col < nc; ++col) {
-        const bool wide = __builtin_amdgcn_ballot_w64(mycolor == col && longrow) != 0ull;      // wave-uniform: a row of this colour has more than 8 lower entries
+    // four lower entries of this lane's row: all gathers in flight, then the FMAs in stored order
+    auto chunk4 = [&](int j0, T (&s_)[D]) {
+        T xv[4][D];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < D; ++c) xv[j][c] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(xs + c * 64) + xa[j0 + j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
+    };
+    int col0 = 0;
+    // rows of the first colour have no lower entries (rows of one colour do not couple): their update is rhs / diag, written by every lane
+    // at once -- the other lanes' values are overwritten when their colour comes (nothing reads them before: a row's lower entries
+    // point at earlier colours only)
+    if (!__builtin_amdgcn_ballot_w64(mycolor == 0 && nlow > 0)) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - (T)0.0) * dg;
+        col0 = 1;
+        __syncthreads();
+    }
+    for (int col = col0; col < nc; ++col) {
         if (mycolor == col) {
             T s_[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) s_[c] = (T)0.0;
-            // (gathers of a chunk in flight together; chunks of 8 entries with one right-hand side, of 4 with more: registers)
-            constexpr int CH = D == 1 ? 8 : 4;
+            // (wave-uniform tests: most rows of the early colours have few lower entries)
+            if (__builtin_amdgcn_ballot_w64(nlow > 0)) {
+                chunk4(0, s_);
+                if (__builtin_amdgcn_ballot_w64(nlow > 4)) {
+                    chunk4(4, s_);
+                    if (__builtin_amdgcn_ballot_w64(nlow > 8)) {
+                        chunk4(8, s_);
+                        if (__builtin_amdgcn_ballot_w64(nlow > 12)) {
+                            chunk4(12, s_);
+                            for (int j = kEpW; j < nlow; ++j) {       // rows with more lower entries than the register window (rare)
+                                const Rec rr = srec[lb + j];
+                                T vj; int cb;
+                                if constexpr (sizeof(T) == 8) { const long long bits = ((long long)(unsigned)rr.x) | ((long long)rr.y << 32); __builtin_memcpy(&vj, &bits, 8); cb = rr.z; }
+                                else { const int bits = rr.x; __builtin_memcpy(&vj, &bits, 4); cb = rr.y; }
 #pragma unroll
-            for (int j0 = 0; j0 < 8; j0 += CH) {
-                T xv[CH][D];
-#pragma unroll
-                for (int j = 0; j < CH; ++j)
-#pragma unroll
-                    for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + xa[j0 + j]];
-#pragma unroll
-                for (int j = 0; j < CH; ++j)
-#pragma unroll
-                    for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
-            }
-            if (wide) {
-#pragma unroll
-                for (int j0 = 8; j0 < kEpW; j0 += CH) {
-                    T xv[CH][D];
-#pragma unroll
-                    for (int j = 0; j < CH; ++j)
-#pragma unroll
-                        for (int c = 0; c < D; ++c) xv[j][c] = xs[c * 64 + xa[j0 + j]];
-#pragma unroll
-                    for (int j = 0; j < CH; ++j)
-#pragma unroll
-                        for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
-                }
-                for (int j = kEpW; j < nlow; ++j) {                   // rows with more lower entries than the register window (rare)
-                    const T vj = sval[lb + j];
-                    const int cc = scol[lb + j];
-#pragma unroll
-                    for (int c = 0; c < D; ++c) s_[c] += vj * xs[c * 64 + cc];
+                                for (int c = 0; c < D; ++c) s_[c] += vj * *reinterpret_cast<const T*>(reinterpret_cast<const char*>(xs + c * 64) + cb);
+                            }
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -745,52 +762,58 @@ __global__ __launch_bounds__(64) void residual_delta_ep(const int* __restrict__ 
                                                         const T* __restrict__ e_val, const T* __restrict__ x_old, const T* __restrict__ x_new,
                                                         T* __restrict__ r, int ld, int n_blocks) {
     extern __shared__ unsigned char smem_raw[];
-    T* pbuf = reinterpret_cast<T*>(smem_raw);
+    T* zeroT = reinterpret_cast<T*>(smem_raw);                         // the zero region, then the products (ep_lds_bytes(0, cap_e, 0))
+    T* pbuf = zeroT + kEpZeroBytes / sizeof(T);
     const int chunk = (int)(gridDim.x >> 3);
     const int blk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3));
     if (blk >= n_blocks) return;
     const int lane = threadIdx.x;
-    const int r0 = blk_begin ? blk_begin[blk] : blk << 6;          // a block table (a rank's blocks), or the level's own blocks in order
+    reinterpret_cast<int*>(zeroT)[lane] = 0;
+    const int r0 = __builtin_amdgcn_readfirstlane(blk_begin ? blk_begin[blk] : blk << 6);          // a block table (a rank's blocks), or the level's own blocks in order
     const int row = r0 + lane;
     const int e0 = e_ptr[r0], e1 = e_ptr[r0 + 64];
     const int nE = e1 - e0;
+    // (chunk loads through buffer resources, unguarded register window, zero-slot reads: as in gs_block_ep)
+    const __amdgpu_buffer_rsrc_t rc = ep_chunk(e_col + e0, nE * 4), rv = ep_chunk(e_val + e0, nE * (int)sizeof(T));
     int ec[kEpE];
     T ev[kEpE];
 #pragma unroll
-    for (int k = 0; k < kEpE; ++k) {
-        ec[k] = row; ev[k] = (T)0.0;
-        if (64 * k < nE) {
-            const int e = e0 + 64 * k + lane;
-            if (e < e1) { ec[k] = __builtin_nontemporal_load(e_col + e); ev[k] = __builtin_nontemporal_load(e_val + e); }
-        }
-    }
+    for (int k = 0; k < kEpE; ++k) { ec[k] = ep_load<int, true>(rc, lane * 4 + 256 * k); ev[k] = ep_load<T, true>(rv, lane * (int)sizeof(T) + 64 * k * (int)sizeof(T)); }
     const int eb = e_ptr[row] - e0, ee = e_ptr[row + 1] - e0;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         const T* xn = x_new + (int64_t)c * ld;
+        const __amdgpu_buffer_rsrc_t rn = ep_chunk(xn, ld * (int)sizeof(T));
         if (x_old) {
             const T* xo = x_old + (int64_t)c * ld;
-            T dx[kEpE];
+            const __amdgpu_buffer_rsrc_t ro = ep_chunk(xo, ld * (int)sizeof(T));
+            T go[kEpE], gn[kEpE];
 #pragma unroll
-            for (int k = 0; k < kEpE; ++k) dx[k] = 64 * k < nE ? xo[ec[k]] - xn[ec[k]] : (T)0.0;
+            for (int k = 0; k < kEpE; ++k) { go[k] = ep_load<T, false>(ro, ec[k] * (int)sizeof(T)); gn[k] = ep_load<T, false>(rn, ec[k] * (int)sizeof(T)); }
 #pragma unroll
-            for (int k = 0; k < kEpE; ++k)
-                if (64 * k < nE) pbuf[64 * k + lane] = ev[k] * dx[k];
-            for (int e = 64 * kEpE + lane; e < nE; e += 64) { const int cj = e_col[e0 + e]; pbuf[e] = e_val[e0 + e] * (xo[cj] - xn[cj]); }
+            for (int k = 0; k < kEpE; ++k) pbuf[64 * k + lane] = ev[k] * (go[k] - gn[k]);
+            if (nE > 64 * kEpE)
+                for (int e = 64 * kEpE + lane; e < nE; e += 64) { const int cj = e_col[e0 + e]; pbuf[e] = e_val[e0 + e] * (xo[cj] - xn[cj]); }
         } else {
+            T gn[kEpE];
 #pragma unroll
-            for (int k = 0; k < kEpE; ++k)
-                if (64 * k < nE) pbuf[64 * k + lane] = -(ev[k] * xn[ec[k]]);
-            for (int e = 64 * kEpE + lane; e < nE; e += 64) pbuf[e] = -(e_val[e0 + e] * xn[e_col[e0 + e]]);
+            for (int k = 0; k < kEpE; ++k) gn[k] = ep_load<T, false>(rn, ec[k] * (int)sizeof(T));
+#pragma unroll
+            for (int k = 0; k < kEpE; ++k) pbuf[64 * k + lane] = -(ev[k] * gn[k]);
+            if (nE > 64 * kEpE)
+                for (int e = 64 * kEpE + lane; e < nE; e += 64) pbuf[e] = -(e_val[e0 + e] * xn[e_col[e0 + e]]);
         }
         __syncthreads();
         T acc = (T)0.0;
-        for (int q = eb; q < ee; q += 16) {
-            T p[16];
+        const T* pa = pbuf + eb;
+        int rem = ee - eb;
+        while (__builtin_amdgcn_ballot_w64(rem > 0)) {
+            T p[8];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) p[j] = q + j < ee ? pbuf[q + j] : (T)0.0;
+            for (int j = 0; j < 8; ++j) p[j] = (rem > j ? pa : zeroT)[j];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc += p[j];
+            for (int j = 0; j < 8; ++j) acc += p[j];
+            pa += 8; rem -= 8;
         }
         r[row + (int64_t)c * ld] = acc;
         __syncthreads();
