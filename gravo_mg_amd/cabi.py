@@ -117,6 +117,7 @@ SIGNATURES = {
     "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
+    "gmg_profile_cycle": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
     "gmg_hierarchy_build": (C.c_int, [_dp, C.c_int, _ip, C.c_int, C.POINTER(GmgHierarchyOptions), C.POINTER(_vp)]),
@@ -549,6 +550,12 @@ class Engine:
         ms, launches = C.c_double(), C.c_int()
         self._chk(lib().gmg_bench_kernel(self._h, int(kind), int(k), int(d), int(reps), C.byref(ms), C.byref(launches)))
         return ms.value, launches.value
+
+    def profile_cycle(self, stop_type: int = 2, reps: int = 10) -> np.ndarray:
+        """ms per leg of a V-cycle + residual check on the resident problem: levels 0 .. L-1, the coarsest solve, the check."""
+        out = np.zeros(self.num_levels + 2)
+        self._chk(lib().gmg_profile_cycle(self._h, int(stop_type), int(reps), _pd(out), out.size))
+        return out
 
     def algorithmic_bytes(self, kind: int, k: int, d: int) -> float:
         out = C.c_double()

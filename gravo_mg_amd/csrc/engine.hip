@@ -168,6 +168,7 @@ void gmg_destroy(gmg_handle h) {
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
+        for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(h->own_stream);
         h->pool.trim();
     }
@@ -1103,6 +1104,38 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
         }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    return GMG_OK;
+} GMG_CATCH_H
+
+// Where the time of a cycle goes, leg by leg: `reps` V-cycles + residual checks on the resident problem with an event at every leg boundary.
+// ms_out[k], k < L: level k (way down: pre-smoothing, residual, restriction; way up: prolongation, post-smoothing); ms_out[L]: the coarsest
+// solve (publication of the right-hand side, host back-substitution, fetch: GPU idle time included); ms_out[L + 1]: the residual check.
+// The events cost a little (the sum is reported against the unprofiled cycle by the caller).
+int gmg_profile_cycle(gmg_handle h, int stop_type, int reps, double* ms_out, int n_out) try {
+    NEED_DEVICE();
+    if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
+    const int L = h->L;
+    if (!ms_out || n_out < L + 2 || reps <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments (ms_out needs levels + 2 entries)");
+    if (h->cfg.use_graph) return fail(h, GMG_ERR_UNSUPPORTED, "leg profiling needs stream launches (use_graph = 0)");
+    int rc;
+    if ((rc = check_norm_type(h, stop_type))) return rc;
+    const int d = h->loaded_d;
+    HelperScope helper_scope(h);
+    std::vector<double> acc((size_t)L + 2, 0.0);
+    for (int i = 0; i < reps; ++i) {
+        h->prof_on = true; h->prof_n = 0;
+        rc = vcycle_resident(h, d, stop_type);
+        h->prof_on = false;
+        if (rc) return rc;
+        if ((rc = wait_norm(h))) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->prof_n != 2 * L + 3) return fail(h, GMG_ERR_STATE, "unexpected number of leg boundaries");
+        auto span = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, h->prof_ev[a], h->prof_ev[b]); return (double)ms; };
+        for (int k = 0; k < L; ++k) acc[k] += span(k, k + 1) + span(L + 1 + (L - 1 - k), L + 2 + (L - 1 - k));
+        acc[L] += span(L, L + 1);
+        acc[L + 1] += span(2 * L + 1, 2 * L + 2);
+    }
+    for (int k = 0; k < L + 2; ++k) ms_out[k] = acc[k] / reps;
     return GMG_OK;
 } GMG_CATCH_H
 

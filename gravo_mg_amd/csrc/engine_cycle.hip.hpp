@@ -476,23 +476,28 @@ inline void threaded_copy(double* dst, const double* src, size_t n, int threads)
 constexpr int kXferChunks = 6;
 inline size_t xfer_chunk(size_t cnt) { return std::max<size_t>((cnt + kXferChunks - 1) / kXferChunks, (size_t)1 << 17); }
 
+// The pinned staging holds ONE column (n doubles per buffer, two buffers): an n x d block crosses column by column, alternating the buffers, so
+// a first n x 3 solve pays no page-locking of a bigger staging area (16-40 ms at 3 M vertices: the demos' call, core.cpp:68-72) and the
+// host copy of column c + 1 overlaps the DMA of column c.
 // host natural n x d  ->  device numbering (level k) buffer
 int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
     Level& l = h->lv[k];
-    const size_t cnt = (size_t)l.n * d;
+    const size_t n = (size_t)l.n, cnt = n * d;
     int rc = ensure_stage(h, cnt);
     if (rc) return rc;
-    if ((rc = ensure_host_stage(h, cnt))) return rc;
-    const int f = h->h_stage_flip;
-    h->h_stage_flip ^= 1;
-    HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));          // the previous DMA out of this staging buffer is done
-    const size_t ch = xfer_chunk(cnt);
-    for (size_t off = 0; off < cnt; off += ch) {
-        const size_t len = std::min(ch, cnt - off);
-        threaded_copy(h->h_stage[f] + off, src + off, len, h->cfg.host_threads);
-        HIPCHK(hipMemcpyAsync(h->d_stage + off, h->h_stage[f] + off, sizeof(double) * len, hipMemcpyHostToDevice, h->stream));
+    if ((rc = ensure_host_stage(h, n))) return rc;
+    const size_t ch = xfer_chunk(n);
+    for (int c = 0; c < d; ++c) {
+        const int f = h->h_stage_flip;
+        h->h_stage_flip ^= 1;
+        HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));          // the previous DMA out of this staging buffer is done
+        for (size_t off = 0; off < n; off += ch) {
+            const size_t len = std::min(ch, n - off);
+            threaded_copy(h->h_stage[f] + off, src + c * n + off, len, h->cfg.host_threads);
+            HIPCHK(hipMemcpyAsync(h->d_stage + c * n + off, h->h_stage[f] + off, sizeof(double) * len, hipMemcpyHostToDevice, h->stream));
+        }
+        HIPCHK(hipEventRecord(h->h_stage_ev[f], h->stream));
     }
-    HIPCHK(hipEventRecord(h->h_stage_ev[f], h->stream));
     hipLaunchKernelGGL(gmgk::permute_in, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, h->d_stage, l.n, l.d_new2old, dst, l.n_pad, l.n_pad, d);
     // d_stage is reused by the next call: order is guaranteed by the single stream
     return GMG_OK;
@@ -500,27 +505,38 @@ int to_device(gmg_handle h, int k, const double* src, int d, double* dst) {
 
 int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
     Level& l = h->lv[k];
-    const size_t cnt = (size_t)l.n * d;
+    const size_t n = (size_t)l.n, cnt = n * d;
     int rc = ensure_stage(h, cnt);
     if (rc) return rc;
-    if ((rc = ensure_host_stage(h, cnt))) return rc;
-    const int f = h->h_stage_flip;
-    h->h_stage_flip ^= 1;
-    HIPCHK(hipEventSynchronize(h->h_stage_ev[f]));
+    if ((rc = ensure_host_stage(h, n))) return rc;
+    HIPCHK(hipEventSynchronize(h->h_stage_ev[0]));
+    HIPCHK(hipEventSynchronize(h->h_stage_ev[1]));
     hipLaunchKernelGGL(gmgk::permute_out, dim3((l.n_pad + 255) / 256), dim3(256), 0, h->stream, src, l.n_pad, l.n_pad, l.d_new2old, h->d_stage, l.n, d);
-    const size_t ch = xfer_chunk(cnt);
-    int nch = 0;
-    for (size_t off = 0; off < cnt; off += ch, ++nch) {
-        const size_t len = std::min(ch, cnt - off);
-        if (!h->h_chunk_ev[nch]) HIPCHK(hipEventCreateWithFlags(&h->h_chunk_ev[nch], hipEventDisableTiming));
-        HIPCHK(hipMemcpyAsync(h->h_stage[f] + off, h->d_stage + off, sizeof(double) * len, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipEventRecord(h->h_chunk_ev[nch], h->stream));
-    }
-    nch = 0;
-    for (size_t off = 0; off < cnt; off += ch, ++nch) {
-        const size_t len = std::min(ch, cnt - off);
-        HIPCHK(hipEventSynchronize(h->h_chunk_ev[nch]));
-        threaded_copy(dst + off, h->h_stage[f] + off, len, h->cfg.host_threads);
+    const size_t ch = xfer_chunk(n);
+    constexpr int kEvPerBuf = (int)(sizeof(h->h_chunk_ev) / sizeof(h->h_chunk_ev[0])) / 2;
+    static_assert(kEvPerBuf >= kXferChunks, "one event per chunk and staging buffer");
+    auto issue = [&](int c) -> int {                             // column c on the wire, into buffer c & 1, an event behind every chunk
+        const int f = c & 1;
+        int nch = 0;
+        for (size_t off = 0; off < n; off += ch, ++nch) {
+            const size_t len = std::min(ch, n - off);
+            hipEvent_t& ev = h->h_chunk_ev[f * kEvPerBuf + nch];
+            if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            HIPCHK(hipMemcpyAsync(h->h_stage[f] + off, h->d_stage + c * n + off, sizeof(double) * len, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipEventRecord(ev, h->stream));
+        }
+        return GMG_OK;
+    };
+    if ((rc = issue(0))) return rc;
+    for (int c = 0; c < d; ++c) {
+        if (c + 1 < d && (rc = issue(c + 1))) return rc;         // (its buffer was copied out two columns ago)
+        const int f = c & 1;
+        int nch = 0;
+        for (size_t off = 0; off < n; off += ch, ++nch) {
+            const size_t len = std::min(ch, n - off);
+            HIPCHK(hipEventSynchronize(h->h_chunk_ev[f * kEvPerBuf + nch]));
+            threaded_copy(dst + c * n + off, h->h_stage[f] + off, len, h->cfg.host_threads);
+        }
     }
     HIPCHK(hipStreamSynchronize(h->stream));
     return GMG_OK;
@@ -528,11 +544,20 @@ int to_host(gmg_handle h, int k, const double* src, int d, double* dst) {
 
 // ---- V-cycle legs --------------------------------------------------------------------------------------
 
+// gmg_profile_cycle: an event at every boundary between the legs of a cycle (2 L + 3 of them: before each level's way down, after the
+// last one, at the start of the way up, after each level's way up, after the residual check)
+inline void prof_mark(gmg_handle h) {
+    if (!h->prof_on) return;
+    if ((size_t)h->prof_n >= h->prof_ev.size()) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) return; h->prof_ev.push_back(e); }
+    (void)hipEventRecord(h->prof_ev[h->prof_n++], h->stream);
+}
+
 template <class T = double>
 void enqueue_down(gmg_handle h, int d, int k0 = 0) {
     const int L = h->L;
     for (int k = k0; k < L; ++k) {
         Level& l = h->lv[k];
+        prof_mark(h);
         const bool from_zero = k > 0 && smooth_from_zero_ok(h, l, h->cfg.pre_iters);      // eps.setZero (:1072-1073) folded into the first sweep
         if (k > 0 && !from_zero) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);
         // level 0, fp64: the last colour launch of the pre-smoothing also writes the residual of its rows (fold_residual)
@@ -549,14 +574,17 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
             launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices);
         launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
     }
+    prof_mark(h);
 }
 
 template <class T = double>
 void enqueue_up(gmg_handle h, int d, int k0 = 0) {
+    prof_mark(h);
     for (int k = h->L - 1; k >= k0; --k) {
         Level& l = h->lv[k];
         launch_prolong_add<T>(h, l, h->lv[k + 1], d, Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l));     // :1082
         launch_smooth<T>(h, l, d, h->cfg.post_iters);                                                // :1085
+        prof_mark(h);
     }
 }
 
@@ -740,6 +768,7 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
             hipLaunchKernelGGL(gmgk::add_correction, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->lv[0].x32, h->lv[0].x, (int64_t)cnt);
             err = launch_residual_to_f32(h, d, norm_type);
         } else if (norm_type >= 0) err = launch_norm(h, d, norm_type);
+        prof_mark(h);
     };
     if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
         int err = GMG_OK;

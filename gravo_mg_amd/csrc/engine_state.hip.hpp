@@ -159,7 +159,7 @@ struct gmg_solver_s {
     void* bounce[2] = {nullptr, nullptr};                                  // pinned bounce buffers for the set-up's pageable copies
     hipEvent_t bounce_ev[2] = {nullptr, nullptr}; int bounce_flip = 0;
     hipEvent_t h_stage_ev[2] = {nullptr, nullptr}; int h_stage_flip = 0;
-    hipEvent_t h_chunk_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // per-chunk arrival of a download (to_host)
+    hipEvent_t h_chunk_ev[16] = {};      // per-chunk arrival of a download (to_host): 8 per staging buffer
     double* d_partials = nullptr; int partial_blocks = 0;
     double* d_norm = nullptr;
     double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
@@ -191,6 +191,8 @@ struct gmg_solver_s {
     std::map<int, hipGraphExec_t> graphs;
     int loaded_d = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> prof_ev;     // gmg_profile_cycle: events at the boundaries of a cycle's legs (prof_on: record them)
+    bool prof_on = false; int prof_n = 0;
     // multi-GPU (one process per GPU): this rank's share of level 0, externally owned level-0 vectors
     hipStream_t own_stream = nullptr;
     int rank = 0, world = 1;
@@ -459,7 +461,7 @@ void drop_system(gmg_handle h) {
 }
 
 // blocked levels smaller than this use 4 lanes per row (GMG_QUAD_LEVEL_ROWS: measurement aid)
-inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 131072; return v; }
+inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 65536; return v; }
 #define kQuadLevelRows quad_level_rows()
 constexpr int kEpMaxBlockEntries = 6144;        // largest explicit / lower chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
 constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)

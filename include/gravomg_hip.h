@@ -274,6 +274,10 @@ int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
  * 4 = residual-norm kernels.  The repetitions are enqueued back to back between two events (the way the
  * V-cycle issues them); launches_out = kernel launches per repetition (colours for the sweep). */
 int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out);
+/* Leg-by-leg time of a V-cycle + residual check on the resident problem (HIP events at the leg boundaries, average over `reps` cycles):
+ * ms_out[k], k < levels: level k's share (multigrid_solver.cpp:1063-1069 on the way down, :1082-1085 on the way up); ms_out[levels]: the
+ * coarsest solve (:1075) with its host round trip; ms_out[levels + 1]: the residual check (:1228-1277).  n_out >= levels + 2. */
+int gmg_profile_cycle(gmg_handle h, int stop_type, int reps, double* ms_out, int n_out);
 /* Algorithmic (compulsory) bytes of the same unit of work, SURVEY.md 8(d). */
 int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out);
 
