@@ -116,6 +116,7 @@ SIGNATURES = {
     "gmg_p2p_bench_exchange": (C.c_int, [_vp, C.c_int, _dp]),
     "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
+    "gmg_p2p_set_smoother": (C.c_int, [_vp, C.c_int]),
     "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
     "gmg_profile_cycle": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
@@ -651,7 +652,10 @@ class P2PCycle:
         X = np.array(_f64(x0), order="F", copy=True)
         assert B.shape == (self._n, self.d) and X.shape == B.shape
         it, res = C.c_int(), C.c_double()
-        self.eng._chk(lib().gmg_p2p_solve(self.eng._h, _pd(B), _pd(X), float(tol), int(stop_type), int(max_iter), C.byref(it), C.byref(res)))
+        rc = lib().gmg_p2p_solve(self.eng._h, _pd(B), _pd(X), float(tol), int(stop_type), int(max_iter), C.byref(it), C.byref(res))
+        self.diverged = rc == DIVERGED       # not an error: the iteration did not contract on any rank (same residues everywhere), X = last iterate
+        if not self.diverged:
+            self.eng._chk(rc)
         return X, it.value, res.value
 
     def bench_exchange(self, reps: int = 100) -> float:
@@ -665,6 +669,10 @@ class P2PCycle:
         out = C.c_double()
         self.eng._chk(lib().gmg_p2p_bench_kind(self.eng._h, kind.encode(), int(reps), C.byref(out)))
         return out.value
+
+    def set_smoother(self, hybrid: bool):
+        """False: exact multicolour GS, an exchange per colour (default); True: hybrid GS (GS inside a rank, Jacobi across ranks), one per sweep."""
+        self.eng._chk(lib().gmg_p2p_set_smoother(self.eng._h, int(bool(hybrid))))
 
     def stat(self, key: str) -> float:
         out = C.c_double()

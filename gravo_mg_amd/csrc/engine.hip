@@ -49,22 +49,26 @@ static inline double ms_since(clk::time_point t0) { return std::chrono::duration
 // Debugging aid: GMG_SEGV_BACKTRACE=1 makes a fatal signal inside the process print the native call stack of the faulting thread
 // (symbol + offset; `addr2line -e libgravomg_hip.so` resolves them) before the default action takes over.
 namespace {
+struct sigaction gmg_prev_action[32];
 void gmg_fatal_signal(int sig) {
     void* frames[48];
-    const int nf = backtrace(frames, 48);
+    const int nf = backtrace(frames, 48);          // (libgcc's unwinder was loaded at install time: no first-use allocation in here)
     const char msg[] = "[gmg] fatal signal, native stack of the faulting thread:\n";
     (void)!write(2, msg, sizeof(msg) - 1);
     backtrace_symbols_fd(frames, nf, 2);
-    signal(sig, SIG_DFL);
+    // hand over to whoever was installed before us (the host application's handler, or the default action)
+    if (sig > 0 && sig < 32) sigaction(sig, &gmg_prev_action[sig], nullptr); else signal(sig, SIG_DFL);
     raise(sig);
 }
 struct GmgSignalAid {
     GmgSignalAid() {
         if (!std::getenv("GMG_SEGV_BACKTRACE")) return;
+        void* warm[4];
+        (void)backtrace(warm, 4);                  // first use loads libgcc_s (dlopen + malloc): not something to do inside a signal handler
         struct sigaction sa;
         std::memset(&sa, 0, sizeof(sa));
         sa.sa_handler = gmg_fatal_signal;
-        sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr); sigaction(SIGFPE, &sa, nullptr);
+        for (int sig : {SIGSEGV, SIGBUS, SIGABRT, SIGFPE}) sigaction(sig, &sa, &gmg_prev_action[sig]);
     }
 } gmg_signal_aid;
 }  // namespace

@@ -37,6 +37,7 @@ struct DistP2P {
     int rank = 0, world = 1, d = 0, nk = 0;               // nk = exchange kinds: colours 0..C-1, C = halo of all colours, C+1 = level-0 rows, C+2 = norm sums,
                                                           // C+3 = x1 halo, C+4 = level-1 rows, C+5 = r0 halo of the restriction (the last three: level 1 partitioned)
     bool shard1 = false;
+    bool hybrid = false;                                  // gmg_p2p_set_smoother: Gauss-Seidel inside a rank, Jacobi across ranks (one exchange per sweep)
     std::vector<int> blk_owner;                           // [block of level 1] -> rank
     std::vector<std::vector<int>> own_blocks;             // [rank]: its blocks, ascending (block b = device rows 64 b .. 64 b + 63)
     int* d_l1 = nullptr;                                  // this rank's launch tables, one allocation:
@@ -436,14 +437,21 @@ int gmg_p2p_load(gmg_handle h, const double* b, const double* x0) try {
 
 namespace {
 
+// Level-0 sweeps on this rank's rows.  Default: an exchange after every colour -- colours are global, so the iterates are those of the
+// single-GPU engine whatever the number of ranks is.  Hybrid (gmg_p2p_set_smoother): the colours of a sweep run back to
+// back on the rank's rows with the peers' values of the PREVIOUS sweep, then ONE exchange of the halo of all colours -- Gauss-Seidel
+// inside a rank, Jacobi across ranks: a quarter of the exchanges at four colours, iterates (and possibly the cycle count) depend on P.
 int p2p_smooth(gmg_handle h, int iters) {
     Level& l = h->lv[0];
+    const bool hybrid = h->p2p->hybrid;
     int rc;
-    for (int it = 0; it < iters; ++it)
+    for (int it = 0; it < iters; ++it) {
         for (int c = 0; c < l.ord.n_colors; ++c) {
             if ((rc = gmg_dist_smooth_color(h, c))) return rc;
-            if ((rc = p2p_exchange(h, c, l.x, l.n_pad))) return rc;
+            if (!hybrid && (rc = p2p_exchange(h, c, l.x, l.n_pad))) return rc;
         }
+        if (hybrid && (rc = p2p_exchange(h, l.ord.n_colors, l.x, l.n_pad))) return rc;
+    }
     return GMG_OK;
 }
 
@@ -685,6 +693,15 @@ int gmg_p2p_bench_kind(gmg_handle h, const char* kind_name, int reps, double* ms
 } GMG_CATCH_H
 
 int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg) { return gmg_p2p_bench_kind(h, "color0", reps, ms_avg); }
+
+// 0 (default): exact multicolour Gauss-Seidel on level 0, one exchange per colour (iterates independent of the rank count);
+// 1: hybrid -- Gauss-Seidel inside a rank, Jacobi across ranks, ONE exchange per sweep.  Collective in the sense that every rank must choose the same.
+int gmg_p2p_set_smoother(gmg_handle h, int hybrid) try {
+    if (!h || !h->p2p) return h ? fail(h, GMG_ERR_STATE, "no distributed plan (gmg_p2p_prepare)") : GMG_ERR_INVALID;
+    if (hybrid != 0 && hybrid != 1) return fail(h, GMG_ERR_INVALID, "smoother must be 0 (exact) or 1 (hybrid)");
+    h->p2p->hybrid = hybrid != 0;
+    return GMG_OK;
+} GMG_CATCH_H
 
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {
     if (!h || !h->p2p || !key || !out) return GMG_ERR_INVALID;

@@ -441,7 +441,7 @@ public:
     void run(void (*fn)(void*, int), void* arg, int njobs) {
         if (njobs <= 0) return;
         if (!armed() || njobs == 1) { for (int j = 0; j < njobs; ++j) fn(arg, j); return; }
-        fn_ = fn; arg_ = arg; njobs_ = (unsigned)njobs;
+        fn_.store(fn, std::memory_order_relaxed); arg_.store(arg, std::memory_order_relaxed); njobs_.store((unsigned)njobs, std::memory_order_relaxed);
         const uint64_t tk = (uint64_t)(++ticket_) << 32;
         done_.store(tk, std::memory_order_relaxed);
         claim_.store(tk, std::memory_order_release);          // publishes fn_ / arg_ / njobs_ with the ticket
@@ -459,9 +459,14 @@ private:
         for (;;) {
             if ((unsigned)(v >> 32) != tk) return;
             const unsigned j = (unsigned)v;
-            if (j >= njobs_) return;                           // (njobs_ belongs to ticket tk: read after the acquire that showed tk)
+            // the batch's description is read through relaxed atomics (a late helper may look at it while run() writes the next one: that
+            // read is then discarded, because its exchange on the closed claim word fails) and used only after a successful claim
+            const unsigned nj = njobs_.load(std::memory_order_relaxed);
+            void (*const fn)(void*, int) = fn_.load(std::memory_order_relaxed);
+            void* const arg = arg_.load(std::memory_order_relaxed);
+            if (j >= nj) return;                               // (njobs_ belongs to ticket tk: read after the acquire that showed tk)
             if (claim_.compare_exchange_weak(v, v + 1, std::memory_order_acq_rel, std::memory_order_acquire)) {
-                fn_(arg_, (int)j);
+                fn(arg, (int)j);
                 done_.fetch_add(1, std::memory_order_release);
                 v = claim_.load(std::memory_order_acquire);
             }
@@ -485,9 +490,9 @@ private:
     std::condition_variable cv_;
     std::atomic<int> armed_{0};
     bool quit_ = false;
-    void (*fn_)(void*, int) = nullptr;
-    void* arg_ = nullptr;
-    unsigned njobs_ = 0;
+    std::atomic<void (*)(void*, int)> fn_{nullptr};
+    std::atomic<void*> arg_{nullptr};
+    std::atomic<unsigned> njobs_{0};
     unsigned ticket_ = 0;
     int near_cpu_ = -1;
     alignas(64) std::atomic<uint64_t> claim_{0};      // (ticket << 32) | next unclaimed job

@@ -95,6 +95,7 @@ MultigridSolver::MultigridSolver(MatrixXd&& V_, MatrixXi&& neigh_, SparseMatrix&
 
 MultigridSolver::~MultigridSolver() {
     if (engine_) gmg_destroy(engine_);
+    if (parked_.engine) gmg_destroy(parked_.engine);
 }
 
 const char* MultigridSolver::lastError() const { return err_.c_str(); }
@@ -201,11 +202,23 @@ void MultigridSolver::buildHierarchy() {
     lap("destroy");
 }
 
+void MultigridSolver::swapParked() {
+    std::swap(engine_, parked_.engine);
+    std::swap(createdWith_, parked_.createdWith);
+    std::swap(uploadedU_, parked_.uploadedU);
+    std::swap(uploadedLHS_, parked_.uploadedLHS);
+    std::swap(systemReady_, parked_.systemReady);
+}
+
 int MultigridSolver::ensureEngine() {
     gmg_config want = engineConfig;
     want.pre_iters = preIters; want.post_iters = postIters; want.verbose = 0;
     if (exactGsActive_) { want.smoother = GMG_SMOOTHER_MULTICOLOR_GS; want.block_rows = 0; want.gs_omega = 1.0; }      // scoped fallback, see solve()
-    if (engine_ && !configEqual(want, createdWith_)) { gmg_destroy(engine_); engine_ = nullptr; }
+    if (engine_ && !configEqual(want, createdWith_)) {
+        // the other configuration may still be alive (fallback <-> configured engine): switch; otherwise park this one in its place
+        if (parked_.engine && !configEqual(want, parked_.createdWith)) { gmg_destroy(parked_.engine); parked_ = ParkedEngine(); }
+        swapParked();
+    }
     if (!engine_) {
         int rc = gmg_create(&want, &engine_);
         if (rc != GMG_OK) { engine_ = nullptr; err_ = "gmg_create failed (invalid engine configuration)"; return rc; }
@@ -244,6 +257,11 @@ int MultigridSolver::ensureSystem(const SparseMatrix& LHS) {
     const std::pair<uint64_t, uint64_t> digLHS = LHS.digest();
     if (exactGsActive_ && digLHS != exactGsFor_) {       // another system: back to the configured engine
         exactGsActive_ = false;
+        if ((rc = prepareEngine())) return rc;
+    }
+    if (!exactGsActive_ && needsExactGs_.count(digLHS)) {      // known not to contract with the default smoothers: no second attempt
+        exactGsActive_ = true;
+        exactGsFor_ = digLHS;
         if ((rc = prepareEngine())) return rc;
     }
     if (!systemReady_ || uploadedLHS_ != digLHS) {
@@ -329,15 +347,12 @@ void MultigridSolver::solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int s
     int iters = 0;
     double residue = std::numeric_limits<double>::max();
     // The initial guess, in case the solve has to be repeated (gmg_solve overwrites x with the last iterate, as the reference does).
-    // The reference's binding always passes x0 = rhs (core.cpp:69): a sampled comparison recognises that without a pass over the
-    // vectors; any other guess is copied.
+    // The reference's binding always passes x0 = rhs (core.cpp:69; initialGuessIsRhs says so and costs nothing); any other caller's guess is
+    // compared in full (a guess that differs from rhs in a few entries only -- a point source, a local perturbation -- must survive a retry)
+    // and copied when it differs.
     bool x0IsRhs = x.data.size() == rhs.data.size();
     const bool knownRhs = initialGuessIsRhs && x0IsRhs;        // the caller says so: x is output only
-    if (x0IsRhs && !knownRhs) {
-        const size_t cnt = x.data.size(), step = std::max<size_t>(1, cnt / 4096);
-        for (size_t i = 0; i < cnt && x0IsRhs; i += step) x0IsRhs = x.data[i] == rhs.data[i];
-        if (cnt) x0IsRhs = x0IsRhs && x.data[cnt - 1] == rhs.data[cnt - 1];
-    }
+    if (x0IsRhs && !knownRhs) x0IsRhs = std::memcmp(x.data.data(), rhs.data.data(), sizeof(double) * x.data.size()) == 0;
     std::vector<double> x0;
     if (!x0IsRhs) x0 = x.data;
     auto run = [&]() {
@@ -360,6 +375,7 @@ void MultigridSolver::solve(SparseMatrix& LHS, MatrixXd& rhs, MatrixXd& x, int s
                   << " cycles): solving again with Gauss-Seidel in colour order on every level" << std::endl;
         exactGsActive_ = true;
         exactGsFor_ = uploadedLHS_;
+        needsExactGs_.insert(uploadedLHS_);
         if (!knownRhs) { if (x0IsRhs) x.data = rhs.data; else x.data = x0; }
         if (ensureSystem(LHS) != GMG_OK) { std::cout << "ERROR! " << err_ << std::endl; return; }
         rc = run();

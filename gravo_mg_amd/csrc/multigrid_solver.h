@@ -11,6 +11,7 @@
 #ifndef GRAVOMG_AMD_MULTIGRID_SOLVER_H
 #define GRAVOMG_AMD_MULTIGRID_SOLVER_H
 
+#include <set>
 #include <cstdint>
 #include <map>
 #include <string>
@@ -154,6 +155,17 @@ private:
     bool exactGsActive_ = false;                               // Gauss-Seidel on every level instead of the configured smoothers ...
     std::pair<uint64_t, uint64_t> exactGsFor_{0, 0};           // ... for the system with this digest only (solve())
     gmg_config createdWith_;
+    // The engine that is NOT in use -- the exact-GS one while the configured one runs, or the other way round -- with its state: an
+    // application that alternates between a system needing the fallback and others switches engines instead of rebuilding them.
+    struct ParkedEngine {
+        gmg_handle engine = nullptr;
+        gmg_config createdWith;
+        std::vector<std::pair<uint64_t, uint64_t>> uploadedU;
+        std::pair<uint64_t, uint64_t> uploadedLHS{0, 0};
+        bool systemReady = false;
+    } parked_;
+    void swapParked();
+    std::set<std::pair<uint64_t, uint64_t>> needsExactGs_;     // systems (content digests) whose default iteration did not contract: straight to the fallback next time
     std::string err_;
 };
 

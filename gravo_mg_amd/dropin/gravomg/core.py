@@ -163,7 +163,15 @@ class MultigridSolver(object):
             D["cycle"], D["key"] = cyc, key
         # x0 = rhs, as the binding does; then gmg_p2p_solve: do { V-cycle; residualCheck } while (residue > tol && it < maxIter)
         x, it, residue = D["cycle"].solve(rhs, rhs, tol=tol, stop_type=stop_type, max_iter=max_iter)
-        self.distributed_info = {"iterations": it, "residue": residue, "world": D["world"]}
+        diverged = bool(D["cycle"].diverged)
+        self.distributed_info = {"iterations": it, "residue": residue, "world": D["world"], "diverged": diverged}
+        if diverged:
+            # every rank sees the same residues, so every rank lands here together.  The single-GPU path would repeat the solve with Gauss-Seidel
+            # on every level; here the caller is told (as the reference would not be) and a blown-up iteration is an error, never a result
+            print(f"gravomg: the V-cycle iteration did not contract over {D['world']} ranks (residue {residue} after {it} cycles); x holds the last iterate; "
+                  "set_engine_option('block_rows', 0) and ('gs_omega', 1.0) select Gauss-Seidel in colour order on every level", flush=True)
+            if not np.isfinite(residue) or D["cycle"].eng.timing("blown_up"):
+                raise RuntimeError(f"the V-cycle iteration diverged (residue {residue})")
         return np.ascontiguousarray(x)
 
     def residual(self, lhs, rhs, solution, type=2):

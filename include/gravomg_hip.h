@@ -267,6 +267,11 @@ int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg);
  * cycle), "r0_halo" (before the restriction, once per cycle).  Overwrites halo entries: gmg_p2p_load afterwards. */
 int gmg_p2p_bench_kind(gmg_handle h, const char* kind, int reps, double* ms_avg);
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
+/* Level-0 smoother of the partitioned cycle (multigrid_solver.cpp:1194-1226 split over ranks).  0 (default): multicolour
+ * Gauss-Seidel with an exchange after every colour -- the single-GPU iterates bit for bit, (pre + post) x colours exchanges per cycle;
+ * 1: hybrid -- Gauss-Seidel inside a rank, Jacobi across ranks, ONE exchange per sweep (pre + post per cycle); the iterates then depend
+ * on the number of ranks.  Every rank must make the same choice. */
+int gmg_p2p_set_smoother(gmg_handle h, int hybrid);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:

@@ -1,4 +1,4 @@
-"""Multi-rank orchestration (gravo_mg_amd/dist.py) on CPU: world_size 2 and 3 with the gloo backend and a numpy
+"""Multi-rank orchestration (gravo_mg_amd/dist.py) on CPU: world_size 2, 3 and 8 with the gloo backend and a numpy
 backend for the local steps.  Checks that the row-partitioned V-cycle with an all-gather after every colour gives
 the SAME iterates as the single-process multicolour V-cycle (the colours are global, so the result must not depend
 on the number of ranks), and the same residual norms / iteration count.  CPU only."""
@@ -179,7 +179,8 @@ def _single(kind):
 
 
 @pytest.mark.parametrize("world,kind,mode", [(2, "poisson", "replicate"), (3, "smoothing", "replicate"), (2, "poisson", "partitioned"),
-                                             (3, "smoothing", "partitioned"), (2, "poisson", "halo"), (3, "smoothing", "halo")])
+                                             (3, "smoothing", "partitioned"), (2, "poisson", "halo"), (3, "smoothing", "halo"),
+                                             (8, "poisson", "halo"), (8, "smoothing", "partitioned")])      # the target's P = 8
 def test_row_partitioned_vcycle_is_independent_of_world_size(world, kind, mode, tmp_path, cabi, oracle):
     import torch.multiprocessing as mp
     P, x3, hist, it, res, x = _single(kind)

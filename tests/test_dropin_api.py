@@ -197,6 +197,14 @@ def test_diverging_smoother_falls_back_to_gauss_seidel_on_every_level(gravomg, c
     lhs2 = (M * 1e-3 + S).tocsr()
     x2 = solver.solve(lhs2, rhs)
     assert solver.solver_timing["fallback_exact_gs"] == 0.0 and solver.residual(lhs2, rhs, x2) <= 1e-4
+    # back to the first system: it is remembered as one that needs the fallback (no second failed attempt, no message), and the engine
+    # that solved it was parked, not destroyed
+    capfd.readouterr()
+    x_again = solver.solve(lhs, rhs)
+    assert "did not contract" not in capfd.readouterr().out
+    assert solver.solver_timing["fallback_exact_gs"] == 1.0 and np.array_equal(x_again, x)
+    x2_again = solver.solve(lhs2, rhs)
+    assert solver.solver_timing["fallback_exact_gs"] == 0.0 and np.array_equal(x2_again, x2)
     # a smoother the caller chose is never replaced: weighted Jacobi far beyond its stability limit blows up, and solve() says so
     solver.set_engine_option("smoother", 1)
     solver.set_engine_option("jacobi_omega", 1.95)

@@ -1,5 +1,5 @@
 """Engine-driven multi-GPU cycle (gmg_p2p_*: device-initiated peer-to-peer exchanges, no collective call per colour) on ONE
-MI355X: 2 / 3 / 4 ranks as separate PROCESSES that map each other's mailboxes through hipIpc handles -- the mechanism real
+MI355X: 2 / 3 / 4 / 8 ranks as separate PROCESSES that map each other's mailboxes through hipIpc handles -- the mechanism real
 multi-GPU runs use, here with all ranks on the same device (the blobs travel over a gloo process group).  In every case the solution must equal the single-engine one bit for bit -- the partition must not
 change the iterates (colours are global) -- and the residual history to rounding (the norm sums are formed per rank and then
 added in rank order, identically on every rank)."""
@@ -40,15 +40,17 @@ def _problem(kind):
     return pr.torus_problem(64, 60, "smoothing", 60)
 
 
-def _worker(rank, world, port, q, kind, shard):
+def _worker(rank, world, port, q, kind, shard, budget):
     try:
         sys.path.insert(0, ROOT)
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ["LOCAL_WORLD_SIZE"] = str(world)          # what torch.distributed.run sets: a rank's host threads are its share of the CPUs
         import torch.distributed as dist
         from gravo_mg_amd import cabi
         from tests.test_gpu_p2p import _problem
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         P = _problem(kind)
+        assert cabi.default_host_threads() == max(1, budget // world), (cabi.default_host_threads(), budget, world)
         eng = cabi.Engine(row_align=64 * world, dist_shard_levels=shard, block_lanes=1)
         eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
         rk = cabi.P2PCycle(eng, rank, world, P.rhs.shape[1])
@@ -60,6 +62,13 @@ def _worker(rank, world, port, q, kind, shard):
         rk.load(P.rhs, P.rhs)
         hist = rk.cycles(4, 2)
         x = rk.fetch()
+        xs, its, ress = rk.solve(P.rhs, P.rhs, tol=1e-4, stop_type=2, max_iter=50)      # the collective solve loop completes on this budget
+        assert ress <= 1e-4 and its >= 1 and eng.timing("diverged") == 0.0
+        # hybrid Gauss-Seidel (one exchange per sweep): another convergent iteration -- same solution to the tolerance, a few cycles more at most
+        rk.set_smoother(True)
+        xh, ith, resh = rk.solve(P.rhs, P.rhs, tol=1e-4, stop_type=2, max_iter=50)
+        rk.set_smoother(False)
+        assert resh <= 1e-4 and ith <= its + 3, (ith, its, resh)
         dist.barrier()
         us = {k: 1e3 * rk.bench_kind(k, 20) for k in (["color0", "halo_all", "rows0"] + (["x1_halo", "rows1", "r0_halo"] if shard == 2 else []))}
         assert all(v > 0 for v in us.values()), us
@@ -72,7 +81,7 @@ def _worker(rank, world, port, q, kind, shard):
 
 
 @pytest.mark.parametrize("world,kind,shard", [(2, "poisson", 2), (3, "poisson", 2), (3, "poisson", 1), (4, "smoothing-d3", 2), (4, "poisson-big", 2),
-                                              (2, "poisson-big", 1)])
+                                              (2, "poisson-big", 1), (8, "poisson-big", 2), (8, "smoothing-d3", 1)])      # 8: the target's rank count
 def test_processes_through_ipc_handles(cabi, world, kind, shard):
     """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by blocks (default), 1 = level 0 only."""
     import torch.multiprocessing as mp
@@ -83,7 +92,8 @@ def test_processes_through_ipc_handles(cabi, world, kind, shard):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, shard)) for r in range(world)]
+    budget = cabi.default_host_threads()             # this process has no LOCAL_WORLD_SIZE: the CPUs it may use
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, shard, budget)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(world)]
