@@ -1471,12 +1471,17 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
     int launches = 1;
+    static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
+    const bool il = k == 0 && d > 1 && d <= 4 && !no_il && l.Aoff.lpr == 1;
+    const bool il_p = il && h->L >= 2 && h->lv[1].ord.blocked && h->lv[1].use_ep && h->cfg.post_iters > 0 && h->cfg.smoother != GMG_SMOOTHER_JACOBI;
     auto body = [&]() {
         switch (kind) {
             case 0: launch_smooth<double>(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors; break;
-            case 1: launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r); break;
-            case 2: launch_restrict<double>(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b); break;
-            case 3: launch_prolong_add<double>(h, l, h->lv[k + 1], d, h->lv[k + 1].x, l.x); break;
+            // (level 0 with 2 .. 4 right-hand sides: the variants the cycle runs -- residual written / gathered as an interleaved multi-vector,
+            // prolongation from the interleaved copy of level 1's x: engine_cycle.hip.hpp::enqueue_down / enqueue_up)
+            case 1: launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r, -1, il); break;
+            case 2: launch_restrict<double>(h, l, h->lv[k + 1], d, l.r, h->lv[k + 1].b, il); break;
+            case 3: launch_prolong_add<double>(h, l, h->lv[k + 1], d, il_p ? h->lv[k + 1].r : h->lv[k + 1].x, l.x, il_p); break;
             case 4: (void)launch_norm(h, d, 0); launches = 2; break;
             default: break;
         }

@@ -73,9 +73,15 @@ bool fold_residual(gmg_handle, Level&, int, bool, int, int) { return false; }
 template <>
 bool fold_residual<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, int se) {
     if (!last_launch || !h->fuse_res_out || &l != &h->lv[0] || d > 4 || l.ord.n_colors < 2 || se != l.Aoff.n_slices || sb <= 0) return false;
-    DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                     l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega,
-                                     l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
+    if (h->il_r0 && d > 1) {
+        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16, (D > 1)>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                         l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega,
+                                         l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
+    } else {
+        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                         l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega,
+                                         l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
+    }
     h->fuse_res_from = sb;
     return true;
 }
@@ -148,7 +154,7 @@ inline int ep_persistent_grid(gmg_handle h, int vgrid) {
 // The kernels find their rows through blk_begin[block]: a sub-range is the same launch on offset block tables.
 template <class T>
 void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out, int b0, int nb, const int* begin_table = nullptr,
-                              const int* ncolors_table = nullptr) {
+                              const int* ncolors_table = nullptr, T* out_il = nullptr) {
     const int ld = l.n_pad;
     const T* b = Prec<T>::b(l);
     // (begin_table / ncolors_table: an explicit list of nb blocks instead of a range -- entry-parallel sweep only, which reads
@@ -165,7 +171,7 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
                                               ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
                                               Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid));
+                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid, out_il));
         } else if (l.use_bcsr && d > 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                               (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, blk_begin,
@@ -196,8 +202,12 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
     T* in = from_zero ? nullptr : Prec<T>::x(l); T* out = Prec<T>::tmp(l);
     const T* before_last = nullptr;      // the iterate the last sweep started from (nullptr: the zero vector)
     bool last_known = false;
+    T* il = (T*)h->il_sweep_out;          // (enqueue_up: the last sweep also writes the level's x as an interleaved multi-vector)
+    h->il_sweep_out = nullptr; h->il_sweep_done = false;
     for (int it = 0; it < iters; ++it) {
-        launch_block_sweep_range<T>(h, l, d, in, out, 0, nb);
+        const bool with_il = il && it == iters - 1 && l.use_ep && d > 1 && d <= 4;
+        launch_block_sweep_range<T>(h, l, d, in, out, 0, nb, nullptr, nullptr, with_il ? il : nullptr);
+        if (with_il) h->il_sweep_done = true;
         before_last = in; last_known = true;
         if (it == 0 && from_zero) { in = out; out = Prec<T>::x(l); }      // the result of sweep 1 is in tmp; ping-pong from there
         else std::swap(in, out);
@@ -245,9 +255,14 @@ void launch_smooth(gmg_handle h, Level& l, int d, int iters, bool from_zero = fa
 
 // y = A x (mode 0) or y = b - A x (mode 1)
 template <class T, int LPR>
-void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y, int n_slices = -1) {
+void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y, int n_slices = -1, bool y_il = false) {
     const int ld = l.n_pad;
     if (n_slices < 0) n_slices = l.Aoff.n_slices;
+    if (y_il && mode == 1 && LPR == 1 && d > 1 && d <= 4) {        // residual as an interleaved multi-vector (level 0, d > 1: what the restriction gathers from)
+        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, C16, (D > 1)>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                                         l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b, x, y, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
+        return;
+    }
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         if (LPR == 1 && l.Aoff.c16_mode == 1) {           // level 0 with 16-bit column codes
@@ -282,14 +297,20 @@ void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const 
     }
 }
 template <class T>
-void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y, int n_slices = -1) {
+void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x, T* y, int n_slices = -1, bool y_il = false) {
     if (l.Aoff.lpr == 4) launch_spmv_lpr<T, 4>(h, l, d, mode, b, x, y, n_slices);
-    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y, n_slices);
+    else launch_spmv_lpr<T, 1>(h, l, d, mode, b, x, y, n_slices, y_il);
 }
 
 // coarse.b = U^T fine.r
 template <class T, int LPR>
-void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst, bool src_il = false) {
+    if (src_il && d > 1 && d <= 4) {
+        DISPATCH_D(d, DISPATCH_C16(fine.R.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16, (D > 1)>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
+                                         h->stream, fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src, fine.n_pad, dst, coarse.n_pad, 0, fine.R.n_slices, 1,
+                                         fine.R.col16, fine.R.win_base, fine.R.c16_arg())));
+        return;
+    }
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, DISPATCH_C16(fine.R.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
@@ -298,14 +319,20 @@ void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const 
     }
 }
 template <class T>
-void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
-    if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst);
-    else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst);
+void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst, bool src_il = false) {
+    if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst, src_il);
+    else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst, src_il);
 }
 
 // fine.x += U coarse.x   (U has <= 3 entries per row: always one lane per row)
 template <class T>
-void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst) {
+void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst, bool src_il = false) {
+    if (src_il && d > 1 && d <= 4) {
+        DISPATCH_D(d, DISPATCH_C16(fine.P.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16, (D > 1)>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
+                                         h->stream, fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src, coarse.n_pad, dst, fine.n_pad, 0, fine.P.n_slices, 1,
+                                         fine.P.col16, fine.P.win_base, fine.P.c16_arg())));
+        return;
+    }
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
         DISPATCH_D(dc, DISPATCH_C16(fine.P.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
@@ -562,6 +589,11 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         if (k > 0 && !from_zero) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);
         // level 0, fp64: the last colour launch of the pre-smoothing also writes the residual of its rows (fold_residual)
         static const bool no_fold = std::getenv("GMG_NO_NORM_FOLD") != nullptr;
+        // d = 2 .. 4: the level-0 residual is written as an INTERLEAVED multi-vector (n x d row-major) -- only the restriction reads it, and a
+        // gathered child then costs one cache line instead of d (GMG_NO_INTERLEAVE: A/B aid)
+        static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
+        const bool il = k == 0 && d > 1 && d <= 4 && !no_il && l.Aoff.lpr == 1;
+        h->il_r0 = il;
         if (k == 0 && sizeof(T) == 8 && !no_fold) h->fuse_res_out = h->lv[0].r;
         h->fuse_res_from = 0;
         h->sweep_prev_valid = false;
@@ -571,8 +603,9 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         h->fuse_res_from = 0;
         // :1066.  Straight after block sweeps on the unpadded block storage the residual comes from the sweep's explicit part alone
         if (!(k > 0 && launch_residual_delta<T>(h, l, d, Prec<T>::r(l))))
-            launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices);
-        launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]));        // :1069
+            launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices, il);
+        launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]), il);    // :1069
+        h->il_r0 = false;
     }
     prof_mark(h);
 }
@@ -582,8 +615,16 @@ void enqueue_up(gmg_handle h, int d, int k0 = 0) {
     prof_mark(h);
     for (int k = h->L - 1; k >= k0; --k) {
         Level& l = h->lv[k];
-        launch_prolong_add<T>(h, l, h->lv[k + 1], d, Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l));     // :1082
+        // d = 2 .. 4: level 1's last post-sweep left a second, interleaved copy of its x in its (idle) residual vector: the prolongation into
+        // level 0 gathers a parent's d values from one cache line
+        const bool il = k == 0 && h->il_sweep_done;
+        h->il_sweep_done = false;
+        launch_prolong_add<T>(h, l, h->lv[k + 1], d, il ? Prec<T>::r(h->lv[k + 1]) : Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l), il);     // :1082
+        static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
+        if (k == 1 && k0 == 0 && d > 1 && d <= 4 && !no_il && h->cfg.post_iters > 0 && l.ord.blocked && l.use_ep && h->cfg.smoother != GMG_SMOOTHER_JACOBI)
+            h->il_sweep_out = (void*)Prec<T>::r(l);
         launch_smooth<T>(h, l, d, h->cfg.post_iters);                                                // :1085
+        h->il_sweep_out = nullptr;
         prof_mark(h);
     }
 }

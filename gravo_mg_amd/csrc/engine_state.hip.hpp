@@ -193,6 +193,9 @@ struct gmg_solver_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof_ev;     // gmg_profile_cycle: events at the boundaries of a cycle's legs (prof_on: record them)
     bool prof_on = false; int prof_n = 0;
+    bool il_r0 = false;                   // enqueue_down, level 0, d > 1: the residual is being written as an interleaved multi-vector
+    void* il_sweep_out = nullptr;         // enqueue_up: where level 1's last post-sweep writes the interleaved copy of its x ...
+    bool il_sweep_done = false;           // ... and whether it did (the level-0 prolongation then gathers from it)
     // multi-GPU (one process per GPU): this rank's share of level 0, externally owned level-0 vectors
     hipStream_t own_stream = nullptr;
     int rank = 0, world = 1;

@@ -36,7 +36,11 @@ __device__ __forceinline__ int wave_slice(int n_slices_total, int xcd_swizzle) {
 
 // W entries of this lane's row, all loads issued before the first use: W column loads + W value loads in flight,
 // then W*D gathers in flight, then the FMAs in stored order (the accumulation order is that of a plain loop).
-template <class T, int D, int W>
+// XI = 1: x is an INTERLEAVED multi-vector (row-major n x D: the D values of a row are 8 D contiguous bytes -- one cache line per gathered
+// row instead of D; round 4, level-0 restriction / prolongation at d > 1), XI = 0: column-major with leading dimension ld.
+template <int D, int XI> __device__ __forceinline__ int64_t x_at(int c, int d, int ld) { return XI ? (int64_t)c * D + d : c + (int64_t)d * ld; }
+
+template <class T, int D, int W, int XI = 0>
 __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const T* __restrict__ vp, const T* x, int ld,
                                               T (&acc)[D]) {
     int c[W];
@@ -47,7 +51,7 @@ __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const 
 #pragma unroll
     for (int j = 0; j < W; ++j)
 #pragma unroll
-        for (int d = 0; d < D; ++d) xv[j][d] = x[c[j] + (int64_t)d * ld];
+        for (int d = 0; d < D; ++d) xv[j][d] = x[x_at<D, XI>(c[j], d, ld)];
 #pragma unroll
     for (int j = 0; j < W; ++j)
 #pragma unroll
@@ -60,7 +64,7 @@ __device__ __forceinline__ void row_dot_group(const int* __restrict__ cp, const 
 // (G entries per group: 8 with one or two right-hand sides; 6 with three -- a mesh row's six entries are one group, 90 VGPRs, 5 wavefronts
 // per SIMD: 22.9 us per colour launch against 23.5 with groups of 4 and 8 wavefronts --; 4 with four)
 template <int D> struct DotGroup { static constexpr int value = D >= 4 ? 4 : (D == 3 ? 6 : 8); };
-template <class T, int D, int G = DotGroup<D>::value>
+template <class T, int D, int G = DotGroup<D>::value, int XI = 0>
 __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                         const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                         T (&acc)[D]) {
@@ -70,15 +74,15 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
     const T* vp = val + p0 + lane;
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (; w >= G; w -= G, cp += G * 64, vp += G * 64) row_dot_group<T, D, G>(cp, vp, x, ld, acc);
+    for (; w >= G; w -= G, cp += G * 64, vp += G * 64) row_dot_group<T, D, G, XI>(cp, vp, x, ld, acc);
     switch (w) {                                                   // w < G here
-        case 1: row_dot_group<T, D, 1>(cp, vp, x, ld, acc); break;
-        case 2: row_dot_group<T, D, 2>(cp, vp, x, ld, acc); break;
-        case 3: row_dot_group<T, D, 3>(cp, vp, x, ld, acc); break;
-        case 4: if (G > 4) row_dot_group<T, D, 4>(cp, vp, x, ld, acc); break;
-        case 5: if (G > 4) row_dot_group<T, D, 5>(cp, vp, x, ld, acc); break;
-        case 6: if (G > 4) row_dot_group<T, D, 6>(cp, vp, x, ld, acc); break;
-        case 7: if (G > 4) row_dot_group<T, D, 7>(cp, vp, x, ld, acc); break;
+        case 1: row_dot_group<T, D, 1, XI>(cp, vp, x, ld, acc); break;
+        case 2: row_dot_group<T, D, 2, XI>(cp, vp, x, ld, acc); break;
+        case 3: row_dot_group<T, D, 3, XI>(cp, vp, x, ld, acc); break;
+        case 4: if (G > 4) row_dot_group<T, D, 4, XI>(cp, vp, x, ld, acc); break;
+        case 5: if (G > 4) row_dot_group<T, D, 5, XI>(cp, vp, x, ld, acc); break;
+        case 6: if (G > 4) row_dot_group<T, D, 6, XI>(cp, vp, x, ld, acc); break;
+        case 7: if (G > 4) row_dot_group<T, D, 7, XI>(cp, vp, x, ld, acc); break;
         default: break;
     }
 }
@@ -93,7 +97,7 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
 // order: the results are bit-identical to the 32-bit path.  A slice that NW windows cannot cover (rows of tiny colour classes,
 // scattered over the mesh) carries -1 as its first base and is read through the 32-bit indices: the wave learns that from the base
 // register AFTER it has issued its first group of loads, so the other slices never wait for the answer.
-template <class T, int D, int W, bool FLAGS>
+template <class T, int D, int W, bool FLAGS, int XI = 0>
 __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp, const int* __restrict__ cp32, const T* __restrict__ vp, const T* x, int ld,
                                                 int basev, int dbits, int& fallback, T (&acc)[D]) {
     unsigned pk[(W + 1) / 2];
@@ -119,7 +123,7 @@ __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp,
 #pragma unroll
     for (int j = 0; j < W; ++j)
 #pragma unroll
-        for (int d = 0; d < D; ++d) xv[j][d] = x[c[j] + (int64_t)d * ld];
+        for (int d = 0; d < D; ++d) xv[j][d] = x[x_at<D, XI>(c[j], d, ld)];
 #pragma unroll
     for (int j = 0; j < W; ++j)
 #pragma unroll
@@ -127,7 +131,7 @@ __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp,
 }
 
 // row_dot with the columns read from the codes (G is even: a group's codes are whole words)
-template <class T, int D, bool FLAGS, int G = DotGroup<D>::value>
+template <class T, int D, bool FLAGS, int G = DotGroup<D>::value, int XI = 0>
 __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
                                           const int* __restrict__ win_base, int dbits, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
     const int wshift = 16 - dbits;                                        // windows per slice = 1 << wshift
@@ -140,15 +144,15 @@ __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr,
     int fallback = -1;                                                    // not known yet
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (; w >= G; w -= G, cp += (G / 2) * 64, cp32 += G * 64, vp += G * 64) row_dot_group16<T, D, G, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc);
+    for (; w >= G; w -= G, cp += (G / 2) * 64, cp32 += G * 64, vp += G * 64) row_dot_group16<T, D, G, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc);
     switch (w) {
-        case 1: row_dot_group16<T, D, 1, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 2: row_dot_group16<T, D, 2, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 3: row_dot_group16<T, D, 3, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 4: if (G > 4) row_dot_group16<T, D, 4, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 5: if (G > 4) row_dot_group16<T, D, 5, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 6: if (G > 4) row_dot_group16<T, D, 6, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 7: if (G > 4) row_dot_group16<T, D, 7, FLAGS>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 1: row_dot_group16<T, D, 1, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 2: row_dot_group16<T, D, 2, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 3: row_dot_group16<T, D, 3, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 4: if (G > 4) row_dot_group16<T, D, 4, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 5: if (G > 4) row_dot_group16<T, D, 5, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 6: if (G > 4) row_dot_group16<T, D, 6, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 7: if (G > 4) row_dot_group16<T, D, 7, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
         default: break;
     }
 }
@@ -156,17 +160,17 @@ __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr,
 // C16 = 0: 32-bit indices.  C16 = 1: codes from slice `from` on (the uncovered slices are a short prefix of the numbering -- tiny colour
 // classes come first -- and the branch on the wave-uniform slice number has nothing to wait for).  C16 = 2: uncovered slices anywhere,
 // found through their flag.  c16_arg = from | format << 30 (format 0: 13 offset bits / 8 windows, 1: 11 offset bits / 32 windows).
-template <class T, int D, int C16, int G = DotGroup<D>::value>
+template <class T, int D, int C16, int G = DotGroup<D>::value, int XI = 0>
 __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
                                             const int* __restrict__ win_base, int c16_arg, const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                             T (&acc)[D]) {
     if constexpr (C16 == 1) {
         const int dbits = (c16_arg >> 30) & 1 ? 11 : 13;
-        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false, G>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
-        else row_dot<T, D, G>(slice_ptr, col, val, x, ld, s, lane, acc);
+        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false, G, XI>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
+        else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
     } else if constexpr (C16 == 2) {
-        row_dot16<T, D, true, G>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
-    } else row_dot<T, D, G>(slice_ptr, col, val, x, ld, s, lane, acc);
+        row_dot16<T, D, true, G, XI>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
+    } else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 
 // Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_norm(const int64_t* __restric
 // The LAST colour launch of the pre-smoothing: the same update, plus the residual r_i = b_i - (sum_{j != i} a_ij x_j + a_ii x_i^new) of
 // its own rows -- the expression of spmv_full<MODE 1> on the same operands (no later launch changes x before the residual), so the
 // residual kernel only visits the rows of the other colours.
-template <int D, int C16 = 0>
+template <int D, int C16 = 0, int YI = 0>
 __global__ __launch_bounds__(kBlock) void gs_color_residual(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                             const double* __restrict__ val, const double* __restrict__ diag,
                                                             const double* __restrict__ b, double* x, double* __restrict__ r, int ld,
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_residual(const int64_t* __res
         else { const double xi = x[row + (int64_t)c * ld]; xn = xi + omega * ((bi - acc[c]) / dg - xi); }
         x[row + (int64_t)c * ld] = xn;
         const double ax = acc[c] + dg * xn;
-        r[row + (int64_t)c * ld] = bi - ax;
+        r[YI ? (int64_t)row * D + c : row + (int64_t)c * ld] = bi - ax;           // (YI: the residual as an interleaved multi-vector, what the restriction gathers from)
     }
 }
 
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
                                                   const int* __restrict__ e_ptr, const int* __restrict__ e_col,
                                                   const T* __restrict__ e_val, const T* __restrict__ diag, const T* __restrict__ b,
                                                   const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks, int blk0,
-                                                  int vgrid) {
+                                                  int vgrid, T* __restrict__ x_out_i = nullptr) {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                            // D x 64: the block's new x
     typedef typename EpRec<T>::type Rec;
@@ -746,6 +750,10 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
+    if (x_out_i) {                                                     // a second copy as an interleaved multi-vector (what the prolongation into the finer level gathers from)
+#pragma unroll
+        for (int c = 0; c < D; ++c) x_out_i[(int64_t)row * D + c] = xs[c * 64 + lane];
+    }
     __syncthreads();                                                   // xs and the staging area are free for the next block
   }
 }
@@ -940,7 +948,7 @@ __global__ __launch_bounds__(kBlock) void jacobi_sweep(const int64_t* __restrict
 
 // MODE 0: y = A x      MODE 1: y = b - A x   (gravomg/src/multigrid_solver.cpp:1066)
 // LPR = lanes per row of the SELL layout (1, or 4 on the coarse levels): slices then hold 64 / LPR rows.
-template <class T, int D, int MODE, int LPR, int C16 = 0>
+template <class T, int D, int MODE, int LPR, int C16 = 0, int YI = 0>
 __device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                 const T* __restrict__ diag, const T* __restrict__ b, const T* __restrict__ x, T* __restrict__ y,
                                                 int ld, int s, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
@@ -953,10 +961,10 @@ __device__ __forceinline__ void spmv_full_slice(const int64_t* __restrict__ slic
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         const T ax = acc[c] + dg * x[row + (int64_t)c * ld];
-        y[row + (int64_t)c * ld] = MODE == 1 ? b[row + (int64_t)c * ld] - ax : ax;
+        y[YI ? (int64_t)row * D + c : row + (int64_t)c * ld] = MODE == 1 ? b[row + (int64_t)c * ld] - ax : ax;
     }
 }
-template <class T, int D, int MODE, int LPR, int C16 = 0>
+template <class T, int D, int MODE, int LPR, int C16 = 0, int YI = 0>
 __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                     const T* __restrict__ val, const T* __restrict__ diag,
                                                     const T* __restrict__ b, const T* __restrict__ x,
@@ -964,7 +972,7 @@ __global__ __launch_bounds__(kBlock) void spmv_full(const int64_t* __restrict__ 
                                                     int xcd_swizzle, const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    spmv_full_slice<T, D, MODE, LPR, C16>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base, c16_arg);
+    spmv_full_slice<T, D, MODE, LPR, C16, YI>(slice_ptr, col, val, diag, b, x, y, ld, s, col16, win_base, c16_arg);
 }
 // the same over a LIST of slices (a rank's rows of a level partitioned by blocks: not one contiguous range)
 template <class T, int D, int MODE, int LPR>
@@ -981,7 +989,7 @@ __global__ __launch_bounds__(kBlock) void spmv_full_list(const int64_t* __restri
 //                       ADD = 1: y[out_row] += sum val * x[col]  (prolongation x += U e, :1082)
 // row_of (may be null) maps the slice row to the output row (-1 = none); ldx/ldy are the leading
 // dimensions of the source / destination level.  LPR as in spmv_full.
-template <class T, int D, int ADD, int LPR, int C16 = 0>
+template <class T, int D, int ADD, int LPR, int C16 = 0, int XI = 0>
 __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
                                                const int* __restrict__ row_of, const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy, int s,
                                                const unsigned* __restrict__ col16 = nullptr, const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
@@ -989,7 +997,7 @@ __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice
     const int srow = s * (64 / LPR) + lane / LPR;
     T acc[D];
     // (quad layout = restrictions: a lane holds 4-5 of a row's ~18 entries -- one group of 8 in flight instead of 4 + a dependent tail)
-    row_dot_sel<T, D, C16, (LPR == 4 ? 8 : DotGroup<D>::value)>(slice_ptr, col, col16, win_base, c16_arg, val, x, ldx, s, lane, acc);
+    row_dot_sel<T, D, C16, (LPR == 4 ? 8 : DotGroup<D>::value), XI>(slice_ptr, col, col16, win_base, c16_arg, val, x, ldx, s, lane, acc);
     if (LPR == 4) { quad_reduce<T, D>(acc); if (lane & 3) return; }
     // ADD = 1 is a read-modify-write of y: only safe when every output row is produced by exactly one slice row, so that
     // instantiation never takes an output-row map (slice row == output row: unique by construction)
@@ -1001,7 +1009,7 @@ __device__ __forceinline__ void transfer_slice(const int64_t* __restrict__ slice
         else y[row + (int64_t)c * ldy] = acc[c];
     }
 }
-template <class T, int D, int ADD, int LPR, int C16 = 0>
+template <class T, int D, int ADD, int LPR, int C16 = 0, int XI = 0>
 __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const T* __restrict__ val, const int* __restrict__ row_of,
                                                    const T* __restrict__ x, int ldx, T* __restrict__ y, int ldy,
@@ -1009,7 +1017,7 @@ __global__ __launch_bounds__(kBlock) void transfer(const int64_t* __restrict__ s
                                                    const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
-    transfer_slice<T, D, ADD, LPR, C16>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base, c16_arg);
+    transfer_slice<T, D, ADD, LPR, C16, XI>(slice_ptr, col, val, row_of, x, ldx, y, ldy, s, col16, win_base, c16_arg);
 }
 template <class T, int D, int ADD, int LPR>
 __global__ __launch_bounds__(kBlock) void transfer_list(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
