@@ -578,8 +578,45 @@ public:
             const ColJob* j = (const ColJob*)p;
             j->self->solve_column(j->b + (size_t)c * j->ldb, j->x + (size_t)c * j->ldx, j->work + (size_t)c * j->self->n, j->scratch + j->nt * (size_t)c, nullptr);
         };
+        if (helper && helper->armed() && d <= kMaxCols) { solve_columns_staged(b, ldb, x, ldx, d, work, helper); return; }
         if (helper && helper->armed()) { helper->run(run, &job, d); return; }
         parallel_ranges(d, d, [&](int c0, int c1, int) { for (int c = c0; c < c1; ++c) run(&job, c); }, 2);
+    }
+
+    // d <= kMaxCols columns through the stages of the elimination tree TOGETHER (round 4): a stage's jobs are (group, column) pairs, so the team
+    // has d times as many independent jobs per stage -- above all in the top of the tree, where a stage holds one or two chains and a
+    // single column keeps one thread busy (d = 3 at n = 1 929: ~100 us per cycle with one thread per column, see the bench line).  Every
+    // (group, column) job is the single-column arithmetic on that column's own buffers: results bitwise those of solve_column.
+    static constexpr int kMaxCols = 4;
+    struct MultiJob { const SupernodalLDLT* self; double* y[kMaxCols]; double* t[kMaxCols]; bool forward; const int* groups; int ngroups; };
+    static void run_part_multi(void* p, int idx) {
+        MultiJob* j = (MultiJob*)p;
+        const int c = idx / j->ngroups, q = idx - c * j->ngroups;
+        PartJob one{j->self, j->y[c], j->t[c], j->forward, j->groups};
+        run_part(&one, q);
+    }
+    void solve_columns_staged(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work, SpinTeam* team) const {
+        const int S = (int)stage_groups_.size();
+        const size_t nt = scratch_doubles();
+        MultiJob job{this, {}, {}, true, nullptr, 0};
+        for (int c = 0; c < d; ++c) {
+            job.y[c] = work + (size_t)c * n; job.t[c] = scratch_.data() + nt * (size_t)c;
+            const double* bc = b + (size_t)c * ldb;
+            for (int i = 0; i < n; ++i) job.y[c][i] = bc[perm[i]];
+        }
+        for (int st = 0; st < S; ++st) {
+            job.groups = stage_groups_[st].data(); job.ngroups = (int)stage_groups_[st].size(); job.forward = true;
+            team->run(run_part_multi, &job, job.ngroups * d);
+        }
+        for (int c = 0; c < d; ++c) for (int j = 0; j < n; ++j) job.y[c][j] /= D_[j];
+        for (int st = S - 1; st >= 0; --st) {
+            job.groups = stage_groups_[st].data(); job.ngroups = (int)stage_groups_[st].size(); job.forward = false;
+            team->run(run_part_multi, &job, job.ngroups * d);
+        }
+        for (int c = 0; c < d; ++c) {
+            double* xc = x + (size_t)c * ldx;
+            for (int i = 0; i < n; ++i) xc[perm[i]] = job.y[c][i];
+        }
     }
 
     // share of the factor (panel entries) in the lightest / the heaviest part of the elimination tree / in the part above them
