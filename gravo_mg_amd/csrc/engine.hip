@@ -1099,7 +1099,7 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     int rc;
     if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
     const int d = h->loaded_d;
-    HelperScope helper_scope(h);
+    HelperScope helper_scope(h, d);
     for (int i = 0; i < n_cycles; ++i) {
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
         if (stop_type >= 0) {
@@ -1124,7 +1124,7 @@ int gmg_profile_cycle(gmg_handle h, int stop_type, int reps, double* ms_out, int
     int rc;
     if ((rc = check_norm_type(h, stop_type))) return rc;
     const int d = h->loaded_d;
-    HelperScope helper_scope(h);
+    HelperScope helper_scope(h, d);
     std::vector<double> acc((size_t)L + 2, 0.0);
     for (int i = 0; i < reps; ++i) {
         h->prof_on = true; h->prof_n = 0;
@@ -1166,7 +1166,7 @@ static int solve_common(gmg_handle h, const double* rhs, const double* x0, doubl
     if ((rc = check_norm_type(h, stop_type))) return rc;
     if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle (multigrid_solver.cpp:1411-1417)
     auto t_all = clk::now();
-    HelperScope helper_scope(h);
+    HelperScope helper_scope(h, d);
     if ((rc = gmg_load_problem(h, rhs, x0, d))) return rc;
     h->timing["solve_load"] = ms_since(t_all);
     h->timing["coarse_host_ms"] = 0.0;

@@ -619,7 +619,9 @@ void enqueue_up(gmg_handle h, int d, int k0 = 0) {
         // level 0 gathers a parent's d values from one cache line
         const bool il = k == 0 && h->il_sweep_done;
         h->il_sweep_done = false;
-        launch_prolong_add<T>(h, l, h->lv[k + 1], d, il ? Prec<T>::r(h->lv[k + 1]) : Prec<T>::x(h->lv[k + 1]), Prec<T>::x(l), il);     // :1082
+        const T* src = il ? Prec<T>::r(h->lv[k + 1]) : Prec<T>::x(h->lv[k + 1]);
+        if (k == h->L - 1 && h->coarse_x_host) { src = (const T*)h->coarse_x_host; h->coarse_x_host = nullptr; }      // (fp64 only: see coarse_host_begin)
+        launch_prolong_add<T>(h, l, h->lv[k + 1], d, src, Prec<T>::x(l), il);     // :1082
         static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
         if (k == 1 && k0 == 0 && d > 1 && d <= 4 && !no_il && h->cfg.post_iters > 0 && l.ord.blocked && l.use_ep && h->cfg.smoother != GMG_SMOOTHER_JACOBI)
             h->il_sweep_out = (void*)Prec<T>::r(l);
@@ -673,14 +675,15 @@ void coarse_host_solve(gmg_handle h, int d) {
 // GMG_LDLT_THREADS = threads of a solve including the caller (default: as many as the factor has parts, at most 8); 1: no team.
 struct HelperScope {
     gmg_handle h;
-    explicit HelperScope(gmg_handle hh) : h(hh) {
+    // cols: right-hand sides of the solves to come (their (part, column) jobs are independent: up to 8 threads have work with d = 3)
+    explicit HelperScope(gmg_handle hh, int cols = 1) : h(hh) {
         static const int env_threads = std::getenv("GMG_LDLT_THREADS") ? std::atoi(std::getenv("GMG_LDLT_THREADS")) : 0;
         // (every rank of a multi-GPU job keeps its team busy -- and this thread polls -- on the CPUs the job may use: a rank's team
         // is sized to its share of them (cpu_budget() divides by LOCAL_WORLD_SIZE) minus one CPU of slack, a throttled spinning
         // thread costs far more than it saves; ranks started without that variable are counted through the handle's world size)
         const int ranks = (h->dist_ready && !std::getenv("LOCAL_WORLD_SIZE")) ? std::max(1, h->world) : 1;
         const int share = cpu_budget() / ranks;
-        int threads = std::min(std::min(h->coarse.parts(), 8), share - 1);
+        int threads = std::min(std::min(h->coarse.parts() * std::max(1, std::min(cols, 4)), 8), share - 1);
         if (env_threads > 0) threads = std::min(threads, env_threads);
         if (h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT || threads < 2) { h = nullptr; return; }
         if (!h->coarse_helper || h->coarse_helper->helpers() != threads - 1) h->coarse_helper.reset(new SpinTeam(threads - 1));
@@ -705,7 +708,7 @@ int coarse_host_serve(gmg_handle h) {
 }
 
 template <class T = double>
-int coarse_host_begin(gmg_handle h, int d) {
+int coarse_host_begin(gmg_handle h, int d, bool prolong_reads_host = false) {
     Level& c = h->lv[h->L];
     const size_t cnt = (size_t)c.n_pad * d;
     double* rc = h->h_pinned;
@@ -719,9 +722,15 @@ int coarse_host_begin(gmg_handle h, int d) {
         // not see in-flight device writes a gated first contact would spin for ever.  The first coarse solve of a handle is ungated.
         if (h->gate_ok && h->gate_proven && !gate_off) {
             if (hipStreamWaitValue64(h->stream, h->h_flag + 16, ++h->flag_seq[2], hipStreamWaitValueGte, ~0ull) == hipSuccess) {
-                hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
-                                   (const double*)e, c.x, (int)cnt);
-                if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
+                // fp64: no copy of the answer into device memory -- the prolongation out of the coarsest level (the only reader) gathers it
+                // straight from the pinned host buffer, one kernel less on the critical path behind the host (GMG_COARSE_FETCH=1: the copy, A/B aid)
+                static const bool keep_fetch = std::getenv("GMG_COARSE_FETCH") != nullptr;
+                if (sizeof(T) == 8 && !keep_fetch && prolong_reads_host) h->coarse_x_host = (const double*)e;
+                else {
+                    hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
+                                       (const double*)e, c.x, (int)cnt);
+                    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
+                }
                 h->coarse_pending = true; h->coarse_pending_d = d;
                 return GMG_OK;
             }
@@ -825,7 +834,7 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
         return rc ? rc : err;
     }
     if ((rc = run_graph(h, key_salt + G_DOWN * 10000 + d * 10, [&] { head(); enqueue_down<T>(h, d); }))) return rc;
-    if ((rc = coarse_host_begin<T>(h, d))) return rc;              // (polled: the way up is enqueued behind a gate the host opens in _serve)
+    if ((rc = coarse_host_begin<T>(h, d, true))) return rc;        // (polled: the way up is enqueued behind a gate the host opens in _serve; its first kernel reads the answer from host memory)
     int err = GMG_OK;
     rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
         h->fuse_norm_type = foldable ? norm_type : -1;

@@ -584,7 +584,7 @@ int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     int rc;
     if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
     const int d = p->d, np = (int)p->peers.size(), C = h->lv[0].ord.n_colors;
-    HelperScope helper_scope(h);
+    HelperScope helper_scope(h, d);
     for (int i = 0; i < n_cycles; ++i) {
         if ((rc = p2p_vcycle(h))) return rc;
         if (stop_type < 0) continue;
