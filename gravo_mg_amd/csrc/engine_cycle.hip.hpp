@@ -620,7 +620,6 @@ void enqueue_up(gmg_handle h, int d, int k0 = 0) {
         const bool il = k == 0 && h->il_sweep_done;
         h->il_sweep_done = false;
         const T* src = il ? Prec<T>::r(h->lv[k + 1]) : Prec<T>::x(h->lv[k + 1]);
-        if (k == h->L - 1 && h->coarse_x_host) { src = (const T*)h->coarse_x_host; h->coarse_x_host = nullptr; }      // (fp64 only: see coarse_host_begin)
         launch_prolong_add<T>(h, l, h->lv[k + 1], d, src, Prec<T>::x(l), il);     // :1082
         static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
         if (k == 1 && k0 == 0 && d > 1 && d <= 4 && !no_il && h->cfg.post_iters > 0 && l.ord.blocked && l.use_ep && h->cfg.smoother != GMG_SMOOTHER_JACOBI)
@@ -708,7 +707,7 @@ int coarse_host_serve(gmg_handle h) {
 }
 
 template <class T = double>
-int coarse_host_begin(gmg_handle h, int d, bool prolong_reads_host = false) {
+int coarse_host_begin(gmg_handle h, int d) {
     Level& c = h->lv[h->L];
     const size_t cnt = (size_t)c.n_pad * d;
     double* rc = h->h_pinned;
@@ -722,15 +721,11 @@ int coarse_host_begin(gmg_handle h, int d, bool prolong_reads_host = false) {
         // not see in-flight device writes a gated first contact would spin for ever.  The first coarse solve of a handle is ungated.
         if (h->gate_ok && h->gate_proven && !gate_off) {
             if (hipStreamWaitValue64(h->stream, h->h_flag + 16, ++h->flag_seq[2], hipStreamWaitValueGte, ~0ull) == hipSuccess) {
-                // fp64: no copy of the answer into device memory -- the prolongation out of the coarsest level (the only reader) gathers it
-                // straight from the pinned host buffer, one kernel less on the critical path behind the host (GMG_COARSE_FETCH=1: the copy, A/B aid)
-                static const bool keep_fetch = std::getenv("GMG_COARSE_FETCH") != nullptr;
-                if (sizeof(T) == 8 && !keep_fetch && prolong_reads_host) h->coarse_x_host = (const double*)e;
-                else {
-                    hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
-                                       (const double*)e, c.x, (int)cnt);
-                    if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
-                }
+                // (round 4: letting the prolongation out of the coarsest level gather the answer straight from the pinned host buffer instead of this
+                // copy kernel -- one launch less behind the host -- measured 0.6608 vs 0.6582 ms per cycle: the gathers over PCIe cost what the copy costs)
+                hipLaunchKernelGGL(gmgk::fetch_from_host, dim3((unsigned)std::min<size_t>(8, (cnt + gmgk::kBlock - 1) / gmgk::kBlock)), dim3(gmgk::kBlock), 0, h->stream,
+                                   (const double*)e, c.x, (int)cnt);
+                if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
                 h->coarse_pending = true; h->coarse_pending_d = d;
                 return GMG_OK;
             }
@@ -834,7 +829,7 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
         return rc ? rc : err;
     }
     if ((rc = run_graph(h, key_salt + G_DOWN * 10000 + d * 10, [&] { head(); enqueue_down<T>(h, d); }))) return rc;
-    if ((rc = coarse_host_begin<T>(h, d, true))) return rc;        // (polled: the way up is enqueued behind a gate the host opens in _serve; its first kernel reads the answer from host memory)
+    if ((rc = coarse_host_begin<T>(h, d))) return rc;              // (polled: the way up is enqueued behind a gate the host opens in _serve)
     int err = GMG_OK;
     rc = run_graph(h, key_salt + G_UP * 10000 + d * 10 + nt, [&] {
         h->fuse_norm_type = foldable ? norm_type : -1;

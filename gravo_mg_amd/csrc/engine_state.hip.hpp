@@ -193,7 +193,6 @@ struct gmg_solver_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> prof_ev;     // gmg_profile_cycle: events at the boundaries of a cycle's legs (prof_on: record them)
     bool prof_on = false; int prof_n = 0;
-    const double* coarse_x_host = nullptr; // coarse_host_begin -> enqueue_up: the coarsest solution is read from the pinned host buffer by the prolongation
     bool il_r0 = false;                   // enqueue_down, level 0, d > 1: the residual is being written as an interleaved multi-vector
     void* il_sweep_out = nullptr;         // enqueue_up: where level 1's last post-sweep writes the interleaved copy of its x ...
     bool il_sweep_done = false;           // ... and whether it did (the level-0 prolongation then gathers from it)
