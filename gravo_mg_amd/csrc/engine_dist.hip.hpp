@@ -705,6 +705,7 @@ int gmg_p2p_set_smoother(gmg_handle h, int hybrid) try {
 
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {
     if (!h || !h->p2p || !key || !out) return GMG_ERR_INVALID;
+    if (std::string(key) == "device_bytes") { *out = (double)h->pool.live_bytes; return GMG_OK; }      // device memory this rank's handle holds (pool blocks in use)
     auto it = h->p2p->stats.find(key);
     if (it == h->p2p->stats.end()) return fail(h, GMG_ERR_INVALID, std::string("unknown key: ") + key);
     *out = it->second;

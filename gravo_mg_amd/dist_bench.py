@@ -287,6 +287,7 @@ def main(args):
             "iterations_by_smoother": {"exact_per_colour_exchange": iters, "hybrid_gs": variants.get("hybrid_gs", {}).get("iterations_to_1e-4")},
             "variants": variants,
             "host_threads_per_rank": cabi.default_host_threads(),
+            "device_bytes_per_rank": (p2p.stat("device_bytes") if p2p is not None else None),      # the set-up is replicated: every rank holds the whole operator
             "roofline": roofline,
             "cpu_baseline": {"value": None, "unit": "ms per V-cycle (incl. residual check)", "cores": 1, "kind": "port",
                              "see": "timed on rank 0 at N = 1 only (bench.py without --gpus, the driver's BENCH line of the same build): the 1-core oracle on the same workload"},

@@ -426,3 +426,20 @@ def test_diverged_solve_returns_the_last_iterate_and_says_so(cabi):
     bad.load_problem(P.rhs, P.rhs); bad.run_cycles(itb, 2)
     assert np.array_equal(np.asarray(xb).reshape(-1), bad.fetch_solution().reshape(-1))
     assert not np.array_equal(np.asarray(xb).reshape(-1), np.asarray(P.rhs).reshape(-1))
+
+
+def test_profile_cycle_splits_a_cycle_into_its_legs(cabi):
+    """gmg_profile_cycle (what bench.py reports as roofline.levels): one entry per smoothed level, the coarsest solve and the residual check; the cycles it
+    runs are ordinary cycles (the iterate moves exactly as with gmg_run_cycles) and the legs add up to about one cycle."""
+    import time
+    P = problems.torus_problem(96, 80, "poisson", 30)
+    def engine():
+        e = cabi.Engine(); e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs); e.load_problem(P.rhs, P.rhs); return e
+    a, b = engine(), engine()
+    legs = a.profile_cycle(2, 3)
+    b.run_cycles(3, 2)
+    assert legs.shape == (a.num_levels + 2,) and np.all(legs > 0) and np.all(legs < 5.0)
+    assert np.array_equal(a.fetch_solution(), b.fetch_solution())
+    t = time.perf_counter(); b.run_cycles(20, 2); per_cycle = 50 * (time.perf_counter() - t)
+    assert 0.3 * per_cycle <= legs.sum() <= 3.0 * per_cycle + 0.1
+    a.close(); b.close()
