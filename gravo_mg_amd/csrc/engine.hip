@@ -494,7 +494,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
                     parallel_ranges(c.n_pad, T, [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) if (c.new2old[r] >= 0) c.old2new[c.new2old[r]] = r; });
                     c.reordered = true;
                     lk.ord = std::move(c);
-                } else lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, reorder0 ? 1 : 0, base);   // the caller's arrays
+                } else lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, reorder0 ? 1 : 0, base, /*idx_sorted=*/true);   // the caller's arrays (canonical: checked / canonicalised at entry)
             }
             else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
             lk.n_pad = lk.ord.n_pad;
