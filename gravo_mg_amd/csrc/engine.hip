@@ -520,7 +520,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             if (lk.ord.blocked && wants_block_ep(h, lpr)) {
                 build_operator_blockcsr(lk.A, lk.ord, st.bc, 3);       // "explicit" part
                 build_operator_blockcsr(lk.A, lk.ord, st.bin, 4);      // "lower" part
-                st.use_ep = st.bc.max_block_entries <= kEpMaxBlockEntries && st.bin.max_block_entries <= kEpMaxBlockEntries;
+                st.use_ep = st.bc.max_block_entries <= kEpMaxBlockEntries && st.bin.max_block_entries <= kEpMaxBlockLower;
                 if (st.use_ep) {
                     st.ep16.resize(st.bin.col.size());
                     for (size_t i = 0; i < st.ep16.size(); ++i) st.ep16[i] = (unsigned short)st.bin.col[i];

@@ -345,7 +345,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
             hipLaunchKernelGGL(gmgs::block_entry_max, gb, dim3(256), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), l.ep_ptr, d_max.p + 1);
             HIPCHK(hipMemcpyAsync(bmax, d_max.p, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (bmax[0] <= kEpMaxBlockEntries && bmax[1] <= kEpMaxBlockEntries) {
+            if (bmax[0] <= kEpMaxBlockEntries && bmax[1] <= kEpMaxBlockLower) {
                 l.use_ep = true;
                 l.ee_nnz = nnz_e; l.ep_nnz = nnz_l;
                 l.ep_cap_e = (bmax[0] + 63) / 64 * 64; l.ep_cap_l = std::max(bmax[1], 1);

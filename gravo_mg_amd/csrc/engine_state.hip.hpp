@@ -402,6 +402,11 @@ void build_patches(gmg_handle h) {
                 Compressed G = coarse_point_graph(h->U[k - 1], Urows[k - 1]);
                 tr(("point graph l" + std::to_string(k)).c_str(), t0); t0 = clk::now();
                 h->patches[k] = grow_patch_set(G, h->cfg.block_rows);
+                // A prolongation that is not the hierarchy's (piecewise-constant aggregation: U^T U is diagonal, the point graph has no edges) leaves
+                // patches of one or two points -- a 64-row block per point.  Below a quarter of the block size on average the patches are
+                // dropped and the level's blocks are grown over its own operator at set-up time (make_block_ordering's fallback)
+                const long n_patches = (long)h->patches[k].mem_begin.size() - 1;
+                if (n_patches > 0 && (long)G.n_outer * 4 < n_patches * (long)h->cfg.block_rows) h->patches[k] = PatchSet();
                 tr(("grow patches l" + std::to_string(k)).c_str(), t0);
             }));
     if (mc && h->cfg.reorder_fine != 0 && L > 0)
@@ -466,7 +471,8 @@ void drop_system(gmg_handle h) {
 // blocked levels smaller than this use 4 lanes per row (GMG_QUAD_LEVEL_ROWS: measurement aid)
 inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 65536; return v; }
 #define kQuadLevelRows quad_level_rows()
-constexpr int kEpMaxBlockEntries = 6144;        // largest explicit / lower chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
+constexpr int kEpMaxBlockEntries = 6144;        // largest explicit chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
+constexpr int kEpMaxBlockLower = 3584;          // ... and largest lower chunk (staged as 16-byte records: 56 KB; the launch stays below the 64 KB of dynamic LDS)
 constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)
 inline bool wants_block_csr(gmg_handle h, int lpr) { return h->cfg.block_csr != 0 && lpr == 1 && h->cfg.block_rows == 64; }
 inline bool wants_block_ep(gmg_handle h, int lpr) { return h->cfg.block_ep != 0 && lpr == 1 && h->cfg.block_rows == 64; }

@@ -443,3 +443,43 @@ def test_profile_cycle_splits_a_cycle_into_its_legs(cabi):
     t = time.perf_counter(); b.run_cycles(20, 2); per_cycle = 50 * (time.perf_counter() - t)
     assert 0.3 * per_cycle <= legs.sum() <= 3.0 * per_cycle + 0.1
     a.close(); b.close()
+
+
+
+def test_block_sweeps_with_blocks_beyond_the_register_windows(cabi, oracle):
+    """gs_block_ep / residual_delta_ep keep 768 explicit and 512 lower entries of a block and 16 lower entries of a row in registers; what a
+    block has beyond that goes through their slow paths (and through an LDS region sized by the largest block).  The hierarchy's own Galerkin
+    operators stay near 22 entries per row whatever the fine graph is (explicit part of a block <= ~850, lower <= ~470), so this test
+    brings its own prolongations: piecewise-constant aggregation of a kNN(120) graph on a structured point set -- coarse rows of 60-120
+    entries, every window overflows.  Same checks as on the mesh levels: the sweep against its matrix form, the residual from the sweep's
+    explicit part against b - A x."""
+    from gravo_mg_amd import meshgen
+    n1, n2 = 128, 64
+    V, _ = meshgen.torus_mesh(n1, n2)
+    S, mass = meshgen.knn_graph_laplacian(V, 120)
+    lhs, rhs = meshgen.poisson_system(S, mass, tau=1e-3)
+    idx = np.arange(n1 * n2).reshape(n1, n2)
+    def aggregate(grid, a, b):
+        g1, g2 = grid.shape
+        agg = (np.arange(g1)[:, None] // a) * (g2 // b) + (np.arange(g2)[None, :] // b)
+        return sp.csc_matrix((np.ones(g1 * g2), (grid.ravel(), agg.ravel())), shape=(g1 * g2, (g1 // a) * (g2 // b))), np.arange((g1 // a) * (g2 // b)).reshape(g1 // a, g2 // b)
+    U0, grid1 = aggregate(idx, 2, 2)
+    U1, _ = aggregate(grid1, 4, 2)
+    P = problems.Problem(V, S, mass, [U0, U1], lhs, rhs, "dense-coarse")
+    eng = cabi.Engine(block_lanes=1)
+    eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    e_ptr = np.asarray(eng.debug_sell(1, 7)["slice_ptr"]); l_ptr = np.asarray(eng.debug_sell(1, 6)["slice_ptr"])
+    assert len(e_ptr) > 65, "level 1 does not run the entry-parallel sweep"
+    over = ((e_ptr[64::64] - e_ptr[:-64:64]).max(), (l_ptr[64::64] - l_ptr[:-64:64]).max(), np.diff(l_ptr).max())
+    assert over[0] > 768 and over[1] > 512 and over[2] > 16, over
+    _check_block_sweeps(P, eng, oracle)
+    rng = np.random.default_rng(5)
+    A = eng.level_operator(1)
+    absA = abs(A)
+    for d in (1, 3):
+        b = rng.standard_normal((A.shape[0], d)); x0 = rng.standard_normal((A.shape[0], d))
+        x, r = eng.smooth_residual(1, b, x0, 2)
+        assert eng.timing("residual_from_sweep") == 1.0
+        scale = absA @ abs(x) + abs(b)
+        assert np.abs(r - oracle.residual(A, b, x)).max() <= 1e-13 * scale.max()
+    eng.close()
