@@ -58,6 +58,25 @@ def test_bench_two_ranks_on_one_gpu(cabi, exchange, shard):
         assert ("level 1 split" in line["config"]["partition"]) == (shard == 2)
 
 
+def test_bench_two_ranks_on_one_gpu_at_the_benchmark_size(cabi):
+    """BASELINE config 4 as BASELINE words it -- the 3 M-vertex Poisson problem, row-partitioned -- through the driver's launch line with two
+    ranks on the one GPU of the test box: the same 4 cycles and residues as one GPU, level 1 partitioned, every exchange timed, and the
+    round-4 fields of the N > 1 line (hybrid Gauss-Seidel variant with its own cycle count, host threads and device bytes per rank)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GMG_DIST_BACKEND="gloo", GMG_BENCH_NO_HALO_VARIANT="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--kernel-reps", "5"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["n_vertices"] == 2999824 and line["scaling"] == "strong"
+    _check_line(line, "p2p")
+    assert line["iterations_to_1e-4"] == 4 and "level 1 split" in line["config"]["partition"]
+    hy = line["variants"]["hybrid_gs"]
+    assert hy["ms_per_step"] > 0 and 4 <= hy["iterations_to_1e-4"] <= 6 and hy["residues"][-1] <= 1e-4
+    assert line["iterations_by_smoother"] == {"exact_per_colour_exchange": 4, "hybrid_gs": hy["iterations_to_1e-4"]}
+    assert line["host_threads_per_rank"] >= 1 and line["device_bytes_per_rank"] > 5e8
+
+
 def test_a_rank_that_cannot_set_up_peer_to_peer_takes_every_rank_to_the_fallback(cabi):
     """bench.py --gpus N decides together: if one rank fails to set the peer-to-peer path up, all ranks run the collective (RCCL / here gloo)
     orchestration and the line says so."""
