@@ -540,13 +540,12 @@ __global__ __launch_bounds__(64) void gs_block_csrout(const int* __restrict__ bl
 // (kEpE * 64 explicit entries, kEpL * 64 lower entries per block, kEpW lower entries per row) read the excess from global
 // memory / LDS in the same order.  Same matrix form as the sweeps above, x_out = x_in + T^-1 (b - A x_in) with T = D +
 // strict lower triangle of the block diagonal in device order; only the summation grouping differs (tested to 1e-12).
-// What bounds it (profiles/README.md): the dependent LDS round trips of one block -- ~0.23 us of kernel time each at
-// 1.6 blocks per resident wave slot -- not LDS or HBM throughput; this formulation has ~25 of them (a first
-// entry-parallel version, which also reduced the in-block products through LDS colour by colour, had ~85 and was slower
-// than the SELL sweep).
+// What bounds it: rounds 2 and 3 read it as bound by the dependent LDS round trips of one block (a first entry-parallel
+// version, which also reduced the in-block products through LDS colour by colour, had ~85 of them instead of ~25 and was slower
+// than the SELL sweep); round 4 found the instruction count to be the bound -- see the kernel's comment below.
 constexpr int kEpE = 12, kEpL = 8, kEpW = 16;
 constexpr int kEpZeroBytes = 256;                                      // zero region in LDS: 16 staged records / 32 doubles (see ep_lds_bytes)
-// a staged lower entry: value + byte offset of its column inside the block's x, read back with ONE LDS instruction
+// a staged lower entry: value + byte offset of its column inside the block's x (one address select serves both reads)
 template <class T> struct EpRec;
 template <> struct EpRec<double> { typedef int type __attribute__((ext_vector_type(4))); };
 template <> struct EpRec<float> { typedef int type __attribute__((ext_vector_type(2))); };
