@@ -87,7 +87,9 @@ def variant_run(cabi, torch, label, H, mass, lhs, rhs, steps, warmup, kernels=Fa
     out = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps, "iterations_to_1e-4": int(it), "residues": [float(v) for v in conv[:, 1]],
            "solve_ms": solve_ms, "first_solve_ms": solve_ms, "second_solve_ms": second_ms, "first_solve_timing_ms": first, "second_solve_timing_ms": second,
            "set_system_ms": set_ms, "n_vertices": int(lhs.shape[0]),
-           "levels": [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)], "colors": [eng.level_info(k)["n_colors"] for k in range(eng.num_levels + 1)]}
+           "levels": [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)], "colors": [eng.level_info(k)["n_colors"] for k in range(eng.num_levels + 1)],
+           "level0_sweep": "multicolour (one launch per colour)" if eng.level_blocks(0) is None else
+                           "block-hybrid (one launch per sweep; chosen by gmg_config::block_fine: long rows, Stieltjes signs)"}
     d = int(rhs.shape[1])
     if reach is not None:      # systems the reference iteration itself does not bring to 1e-4 within max_iter: cycles to a looser mark
         out["reach"] = {"residue": reach, "cycles": int(next((i + 1 for i, r in enumerate(conv[:, 1]) if r <= reach), -1)), "last_residue": float(conv[-1, 1])}
@@ -407,6 +409,9 @@ def main():
         name, pos, S3, mass3, lhs3, rhs3 = meshgen.baseline_config("3")
         H3 = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S3), ratio=8.0, lower_bound=1000)
         variants["pointcloud_2M_knn8"] = variant_run(cabi, torch, name, H3, mass3, lhs3, rhs3, args.steps, args.warmup, levels=True)
+        # the same system with level 0 kept colour-major (what rounds 1-3 ran, and what the partitioned multi-GPU cycle runs): 11 launches per sweep
+        cm = variant_run(cabi, torch, name + " (block_fine = 0)", H3, mass3, lhs3, rhs3, args.steps, args.warmup, block_fine=0)
+        variants["pointcloud_2M_knn8"]["level0_colour_major"] = {k: cm[k] for k in ("ms_per_step", "iterations_to_1e-4", "solve_ms", "second_solve_ms", "set_system_ms", "colors", "cycle_frac_of_peak")}
         del H3, pos, S3, mass3, lhs3, rhs3
 
     cpu = cpu_baseline(H, mass, lhs, rhs, args.cpu_cycles) if args.cpu_cycles > 0 else None

@@ -321,6 +321,7 @@ public:
         else if (key == "row_align") c.row_align = (int)value;
         else if (key == "block_lanes") c.block_lanes = (int)value;
         else if (key == "dist_shard_levels") c.dist_shard_levels = (int)value;
+        else if (key == "block_fine") c.block_fine = (int)value;
         else throw std::invalid_argument("unknown engine option: " + key);
     }
 

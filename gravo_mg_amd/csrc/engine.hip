@@ -115,6 +115,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->verbose = 0;
     cfg->block_ep = 1;
     cfg->dist_shard_levels = 2;
+    cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
                               // problem at the same cost per cycle; centre of the 1.3 - 1.4 plateau on six workloads
@@ -134,7 +135,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.restrict_sigma < 0 || c.restrict_sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
@@ -399,7 +400,9 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         // the layouts, numeric LDL^T.  (The demos' usage: lhs = M + tau * S with a new tau per frame.)
         pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
         have_key = true;
-        if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz) {
+        // (a level 0 that gmg_config::block_fine blocked stays blocked only while the new values pass its sign test)
+        const bool keeps_fine_blocks = !(h->lv[0].ord.blocked && h->cfg.block_from_level >= 1) || stieltjes_signs(n, colptr, rowidx, val, h->cfg.host_threads);
+        if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz && keeps_fine_blocks) {
             int rc = refresh_system_values(h, n, val, t_all);
             if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
             if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything
@@ -451,7 +454,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     // Host copy of the LHS: only where a host stage needs it (host RAP, host planner, block ordering of level 0); the
     // default path works from the caller's arrays and the device copy, and gmg_get_level_operator fetches on demand.
     double ms_lhs_copied = 0;
-    const bool need_host_A0 = !device_setup || !h->cfg.device_rap || (mc && h->cfg.block_rows > 0 && h->cfg.block_from_level <= 0);
+    const bool need_host_A0 = !device_setup || !h->cfg.device_rap;
     h->lv[0].n = n; h->lv[0].nnz = colptr[n];
     std::shared_future<void> lhs_copied;
     if (need_host_A0) {
@@ -463,7 +466,15 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     std::future<int> stage_ready = std::async(std::launch::async, [h, n] { (void)hipSetDevice(h->cfg.device); return ensure_host_stage(h, (size_t)n); });
     if (!have_key) pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
     mark("pattern_key");
-    const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1];
+    // Level 0 as a blocked level (one launch per sweep instead of one per colour): asked for (block_from_level = 0), or chosen here
+    // (gmg_config::block_fine) for an operator whose multicolour sweep would be a dozen small launches -- long rows -- and for which the
+    // block-hybrid sweep is known to converge: positive diagonal, no positive off-diagonal entry (with the symmetric positive definite
+    // system the method presumes, a Stieltjes matrix: D + in-block lower part is a regular splitting).  kNN graph Laplacians qualify;
+    // meshes keep the colour-major sweep (4-7 colours, over-relaxed), Bilaplacians fail the sign test.
+    const bool blocked0 = fine_level_blocked(h, n, colptr, rowidx, val);
+    h->timing["fine_level_blocked"] = blocked0 ? 1.0 : 0.0;
+    const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1] &&
+                         h->ord_cache[0].blocked == blocked0;
     h->timing["setup_ordering_cached"] = ord_hit ? 1.0 : 0.0;
     h->timing["setup_values_only"] = 0.0;
     h->ord_cache_valid = false;       // a hit moves the cached orderings into the levels; the next call moves them back
@@ -475,13 +486,14 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         ord_done[k] = std::async(std::launch::async, [&, k] {
             auto t = clk::now();
             Level& lk = h->lv[k];
-            const bool blocked = mc && k < L && h->cfg.block_rows > 0 && k >= h->cfg.block_from_level;
+            const bool blocked = mc && k < L && h->cfg.block_rows > 0 && (k >= h->cfg.block_from_level || (k == 0 && blocked0));
             if (ord_hit) lk.ord = std::move(h->ord_cache[k]);          // same pattern + same hierarchy => same orderings
             else if (k == L) lk.ord = identity_ordering(lk.n);
             else if (blocked) {
-                if (k == 0) wait_lhs();
                 if (patches_done.valid()) patches_done.wait();
-                lk.ord = make_block_ordering(lk.A, h->cfg.block_rows, k < (int)h->patches.size() ? &h->patches[k] : nullptr);
+                // level 0: blocks = runs of block_rows points of the hierarchy's cluster order (level0_patches), coloured from the caller's arrays
+                if (k == 0) lk.ord = make_block_ordering(PatternView{n, colptr, rowidx}, h->cfg.block_rows, level0_patches(h, n));
+                else lk.ord = make_block_ordering(lk.A, h->cfg.block_rows, k < (int)h->patches.size() ? &h->patches[k] : nullptr);
             }
             else if (k == 0) {
                 if (reorder0 && patches_done.valid()) patches_done.wait();
@@ -566,7 +578,6 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     // Level 0 of a badly numbered input (random-order scans, point clouds) is renumbered for locality.  With the
     // hierarchy's cluster order at hand the LHS pattern is permuted on the device first, so that the (sequential) greedy
     // colouring runs on a locally ordered graph; that needs the LHS on the device before the ordering task starts.
-    const bool blocked0 = mc && h->cfg.block_rows > 0 && h->cfg.block_from_level <= 0 && L > 0;
     reorder0 = mc && !ord_hit && !blocked0 && wants_locality_reorder(PatternView{n, colptr, rowidx}, h->cfg.reorder_fine);
     bool A0_uploaded = false;
     // (h->cluster_order is only read once the patches are ready: build_patches may still be writing it)
@@ -1240,7 +1251,7 @@ int gmg_dist_setup(gmg_handle h, int rank, int world) try {
     if (rc) return rc;
     if (world < 1 || rank < 0 || rank >= world) return fail(h, GMG_ERR_INVALID, "bad rank / world size");
     const LevelOrdering& o = h->lv[0].ord;
-    if (o.blocked || h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the colour-major multicolour ordering on level 0");
+    if (o.blocked || h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the colour-major multicolour ordering on level 0 (gmg_config: block_from_level >= 1, block_fine = 0)");
     for (int c = 0; c < o.n_colors; ++c)
         if ((o.color_begin[c + 1] - o.color_begin[c]) % (64 * world)) return fail(h, GMG_ERR_STATE, "colour classes are not aligned to 64*world rows: create the handle with row_align = 64*world");
     h->rank = rank; h->world = world; h->dist_ready = true;

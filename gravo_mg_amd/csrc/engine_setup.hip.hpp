@@ -444,7 +444,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     const char* c16_keys[3] = {"col16_l0", "col16_R_l0", "col16_P_l0"};
     int c16_failed[6] = {0, 0, 0, 0, 0, 0};      // per operator: uncovered slices, 1 + index of the last of them
     DevTmp<int> d_c16;
-    const bool c16 = k == 0 && !l.ord.blocked && !std::getenv("GMG_NO_COL16");
+    const bool c16 = k == 0 && !std::getenv("GMG_NO_COL16");      // (a blocked level 0 too: its residual-check and transfer kernels are the colour-major level's)
     const int c16_test_fail = std::getenv("GMG_COL16_TEST_FAIL") ? std::atoi(std::getenv("GMG_COL16_TEST_FAIL")) : 0;      // tests: N > 0 every N-th slice "uncovered", N < 0 the first -N
     auto c16_launch = [&](int i, int nw) -> int {
         DevSell& op = *c16_ops[i];
@@ -522,6 +522,37 @@ int device_refill_level(gmg_handle h, int k, int* d_err) {
             (rc = device_build_sell(h, l.Aout, dA.ptr, dA.ptr + 1, dA.idx, dA.val, fout, nullptr, l.n_pad, l.Aout.lpr, nullptr, nullptr, d_err, true))) return rc;
     }
     return GMG_OK;
+}
+
+// true when every diagonal entry is positive and no stored off-diagonal entry is (threaded; stops at the first offender)
+bool stieltjes_signs(int n, const int* ptr, const int* idx, const double* val, int threads) {
+    std::atomic<int> bad{0};
+    parallel_ranges(n, threads, [&](int lo, int hi, int) {
+        for (int j = lo; j < hi; ++j) {
+            if ((j & 1023) == 0 && bad.load(std::memory_order_relaxed)) return;
+            bool diag = false;
+            for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
+                if (idx[p] == j) { diag = val[p] > 0.0; if (!diag) { bad.store(1, std::memory_order_relaxed); return; } }
+                else if (val[p] > 0.0) { bad.store(1, std::memory_order_relaxed); return; }
+            }
+            if (!diag) { bad.store(1, std::memory_order_relaxed); return; }
+        }
+    }, 1 << 14);
+    return bad.load() == 0;
+}
+
+// Shall level 0 of this system run the block-hybrid sweep?  block_from_level = 0: yes (asked for).  Otherwise gmg_config::block_fine decides:
+// the 64-row entry-parallel sweep must be the one that would run, the hierarchy must supply the blocks (cluster order), the rows must be
+// long enough for the colour-major sweep to fall apart into many small launches (>= 9 entries per row on average: kNN graphs 10-14,
+// triangle meshes 7), and the signs must make the block-hybrid sweep a regular splitting (stieltjes_signs).
+constexpr double kFineBlockMinRow = 9.0;
+bool fine_level_blocked(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) {
+    const gmg_config& c = h->cfg;
+    if (c.smoother != GMG_SMOOTHER_MULTICOLOR_GS || c.block_rows <= 0 || h->L <= 0) return false;
+    if (c.block_from_level <= 0) return true;
+    if (!c.block_fine || c.block_rows != 64 || !c.block_ep || !c.block_csr || c.reorder_fine == 0) return false;
+    if ((double)colptr[n] < kFineBlockMinRow * (double)n) return false;
+    return stieltjes_signs(n, colptr, rowidx, val, c.host_threads);
 }
 
 // One threaded pass over a compressed pattern: 0 = canonical (indices in range, strictly ascending inside each outer

@@ -420,6 +420,25 @@ void build_patches(gmg_handle h) {
     h->patches_ready = true;
 }
 
+// Patches of a blocked level 0: runs of block_rows consecutive points of the hierarchy's cluster order (points grouped by parent,
+// parents by grandparent, ...: a run of 64 is about one cell of level 2 -- a compact 2-D patch whatever the input numbering is,
+// every block full).  Depends on the hierarchy only: made on first use (after build_patches), kept while the hierarchy stands.  Null
+// without a cluster order (reorder_fine = 0): make_block_ordering then grows the blocks breadth-first over the operator's graph.
+const PatchSet* level0_patches(gmg_handle h, int n) {
+    if (h->patches.empty() || (int)h->cluster_order.size() != n || h->cfg.block_rows <= 0) return nullptr;
+    if (std::getenv("GMG_FINE_BLOCKS_GROWN")) return nullptr;      // A/B aid: blocks grown breadth-first over the operator instead
+    PatchSet& p = h->patches[0];
+    if (p.valid() && p.n == n) return &p;
+    const int br = h->cfg.block_rows, nb = (n + br - 1) / br;
+    p.n = n;
+    p.members = h->cluster_order;
+    p.block_of.assign((size_t)n, 0);
+    p.mem_begin.resize((size_t)nb + 1);
+    for (int b = 0; b <= nb; ++b) p.mem_begin[b] = std::min(n, b * br);
+    parallel_ranges(n, std::min(hw_threads(), 32), [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) p.block_of[p.members[r]] = r / br; }, 1 << 16);
+    return &p;
+}
+
 void free_level(Level& l) {
     free_csr(l.dA);
     free_sell(l.Aoff); free_sell(l.P); free_sell(l.R); free_sell(l.Ain); free_sell(l.Aout);

@@ -61,7 +61,7 @@ def main(args):
 
     def new_engine():
         kw = {} if args.block_lanes is None else {"block_lanes": args.block_lanes}
-        e = cabi.Engine(device=local, row_align=64 * world, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels, **kw)
+        e = cabi.Engine(device=local, row_align=64 * world, block_fine=0, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels, **kw)
         e.use_hierarchy(H); e.set_mass(mass); e.set_system(lhs)
         return e
 

@@ -140,6 +140,7 @@ class MultigridSolver(object):
         if world > 1:
             self.solver.set_engine_option("row_align", 64 * world)
             self.solver.set_engine_option("dist_shard_levels", int(shard_levels))
+            self.solver.set_engine_option("block_fine", 0)          # the partitioned cycle needs the colour-major level 0
             self.solver.set_engine_option("device", rank if device is None else int(device))
             self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None}
         else:

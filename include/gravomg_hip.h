@@ -96,6 +96,13 @@ typedef struct {
                               64 ENTRIES instead of one per padded column of the block's longest row; 0: the SELL / block-CSR sweeps */
     int dist_shard_levels; /* multi-GPU (gmg_p2p_*): how many levels are partitioned over the ranks.  2 (default): level 0 by rows per
                               colour AND level 1 by blocks; 1: level 0 only (levels >= 1 replicated on every rank) */
+    int block_fine;        /* 1 (default): level 0 runs the block-hybrid sweep as well (as if block_from_level were 0) when its multicolour
+                              sweep would fall apart into a dozen small launches AND the block sweep is known to converge: >= 9 stored
+                              entries per row on average, positive diagonal, no positive off-diagonal entry (a Stieltjes matrix: kNN
+                              graph Laplacians of point clouds; 2 M points: 11 colour launches per sweep -> 1).  Triangle-mesh
+                              operators (7 entries per row, 4-7 colours) keep the over-relaxed multicolour sweep, Bilaplacians fail the
+                              sign test.  The blocks are runs of 64 points of the hierarchy's cluster order.  0: level 0 is blocked only
+                              by block_from_level = 0.  The multi-GPU path (gmg_p2p_*) needs the colour-major level 0: set 0 there */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -169,7 +169,7 @@ def _check_block_sweeps(P, eng, oracle):
                 want = want + step
                 got = eng.smooth(k, b, x, iters)
                 assert rel(got, want) <= 1e-12
-    assert checked == len(P.U) - 1
+    assert checked == len(P.U) - (eng.level_blocks(0) is None)       # (level 0 too where the engine blocked it: block_from_level = 0, or gmg_config::block_fine on a kNN operator)
 
 
 def test_multicolor_gs_is_reference_gs_on_permuted_system(setup_exact, oracle):
@@ -322,7 +322,11 @@ def test_engine_variants(cabi, oracle, variant):
     ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(P.lhs)
     xr, itr, resr, _ = ref.solve(P.rhs, tol=1e-6, max_iter=200)
     assert rel(x, xr) <= 1e-5
-    if variant in ("exact_gs", "blocked_all", "small_blocks", "lane_per_row_blocks"):
+    if variant == "blocked_all":
+        # level 0 in 30 blocks (runs of 64 points of the hierarchy's cluster order) instead of 4 global colours: 12 cycles against 8 to 1e-6 on this
+        # 1 920-vertex mesh (9 with blocks grown breadth-first over the operator, GMG_FINE_BLOCKS_GROWN: profiles/r04/l_fine_blocks_probe.jsonl)
+        assert abs(it - itr) <= 5
+    elif variant in ("exact_gs", "small_blocks", "lane_per_row_blocks"):
         assert abs(it - itr) <= 2
     elif variant != "jacobi":
         assert it == itr

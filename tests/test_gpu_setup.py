@@ -336,7 +336,7 @@ def test_base_order_of_a_reordered_level_follows_the_gather_score(cabi):
     Sp, mp = meshgen.knn_graph_laplacian(P, 8)
     Hp = cabi.Hierarchy(P, meshgen.neighbors_from_stiffness(Sp), lower_bound=2000)
     assert Hp.fine_order is not None
-    ep = cabi.Engine(); ep.use_hierarchy(Hp); ep.set_mass(mp); ep.set_system(meshgen.poisson_system(Sp, mp)[0])
+    ep = cabi.Engine(block_fine=0); ep.use_hierarchy(Hp); ep.set_mass(mp); ep.set_system(meshgen.poisson_system(Sp, mp)[0])      # (colour-major level 0: a blocked one takes its blocks from the cluster order and is not renumbered)
     assert ep.timing("base_order_choice") == 0.0 and ep.timing("base_order_score_cluster") < ep.timing("base_order_score_bfs")
 
 
