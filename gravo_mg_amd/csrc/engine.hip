@@ -1824,6 +1824,12 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             best = std::min(best, 1e3 * ms_since(t0) / reps);
         }
         std::fprintf(stderr, "[gmg ldlt] factorisation: ordering %.2f ms, symbolic %.2f ms, numeric %.2f ms\n", f.phase_ms[0], f.phase_ms[1], f.phase_ms[2]);
+        {   // numeric re-factorisation (a system with the same sparsity pattern: the demos' new tau per frame), best and median of 15
+            std::vector<double> ts;
+            for (int i = 0; i < 15; ++i) { if (!f.factor(A, true)) return GMG_ERR_NUMERIC; ts.push_back(f.phase_ms[2]); }
+            std::sort(ts.begin(), ts.end());
+            std::fprintf(stderr, "[gmg ldlt] numeric re-factorisation on %d thread(s): best %.2f ms, median %.2f ms\n", SupernodalLDLT::numeric_threads(), ts.front(), ts[ts.size() / 2]);
+        }
         long part[3];
         f.split_report(part);
         std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread (best of 20 batches of %d); %d parts of the elimination "

@@ -539,6 +539,10 @@ public:
     }
 
     long factor_nnz() const { return nnz_l_; }
+    static int numeric_threads() {
+        static const int v = [] { const char* e = std::getenv("GMG_LDLT_THREADS"); return e ? std::max(1, std::atoi(e)) : 0; }();
+        return v > 0 ? v : std::max(1, std::min(hw_threads(), 8));
+    }
 
     // Read the factor once (one word per cache line): after a factorisation the panels sit in the caches of whichever core
     // computed them, and the first back-substitutions on the solving thread pay for pulling them over (~250 us instead of ~65 us
@@ -676,6 +680,11 @@ private:
     std::vector<std::vector<int>> group_cols_;   // columns of a chain
     std::vector<std::vector<int>> group_feeds_;  // groups of earlier stages (whose accumulators a chain takes in), in the order they are subtracted
     std::vector<int> own_rows_;                  // per supernode: leading rows of its structure that lie inside its own group
+    // numeric factorisation: for every supernode the descendants that update it, ascending, with the position in the descendant's row
+    // list where the rows inside this supernode's columns begin (symbolic); the supernodes of the top, ascending (plan_split)
+    std::vector<int> upd_ptr_, upd_sn_, upd_pos_;
+    std::vector<int> top_sn_;
+    std::shared_ptr<SpinTeam> fteam_;            // the numeric factorisation's team (shared by copies of the factor: only one of them factors at a time)
     std::vector<long> split_work_;               // panel entries per group
     mutable std::vector<double> scratch_;        // gathered right-hand-side rows of one supernode (a handle is not thread-safe)
     std::vector<int> inv_;                       // old -> new
@@ -892,6 +901,26 @@ private:
         for (int q = 0; q < ns_; ++q) max_rows_ = std::max(max_rows_, rows_ptr_[q + 1] - rows_ptr_[q]);
         pan_.resize_uninitialised(pan_ptr_[ns_]);
         D_.assign(n, 0.0);
+        {   // update lists: a descendant's sorted row list visits its ancestors' supernodes one after the other
+            upd_ptr_.assign((size_t)ns_ + 1, 0);
+            for (int pass = 0; pass < 2; ++pass) {
+                std::vector<int> fill(pass ? upd_ptr_ : std::vector<int>());
+                for (int dd = 0; dd < ns_; ++dd) {
+                    const int* Rd = rows_.data() + rows_ptr_[dd];
+                    const int rd = rows_ptr_[dd + 1] - rows_ptr_[dd];
+                    for (int p = 0; p < rd;) {
+                        const int t = sn_of_[Rd[p]];
+                        if (pass) { upd_sn_[fill[t]] = dd; upd_pos_[fill[t]] = p; ++fill[t]; } else upd_ptr_[t + 1]++;
+                        const int end = sn_first_[t + 1];
+                        while (p < rd && Rd[p] < end) ++p;
+                    }
+                }
+                if (!pass) {
+                    for (int t = 0; t < ns_; ++t) upd_ptr_[t + 1] += upd_ptr_[t];
+                    upd_sn_.assign((size_t)upd_ptr_[ns_], 0); upd_pos_.assign((size_t)upd_ptr_[ns_], 0);
+                }
+            }
+        }
         plan_split();
         symbolic_ready_ = true;
     }
@@ -969,8 +998,10 @@ private:
         scratch_.clear();                            // (its layout follows max_rows_ / n / groups_: the accumulators must start from zero)
         split_work_.assign((size_t)groups_, 0);
         own_rows_.assign(ns_, 0);
+        top_sn_.clear();
         for (int s = 0; s < ns_; ++s) {
             const int t = half[s];
+            if (t >= parts_) top_sn_.push_back(s);
             part_sn_[t].push_back(s);
             split_work_[t] += work[s];
             const int* R = rows_.data() + rows_ptr_[s];
@@ -1243,6 +1274,58 @@ private:
         for (int i = 0; i < n; ++i) x[perm[i]] = y[i];
     }
 
+    // Numeric factorisation, left-looking by supernodes: assemble the panel from A, subtract the updates of the descendants that reach
+    // it -- in ASCENDING order of the descendants (upd_*: fixed by the symbolic phase, so the sums do not depend on who computes them) --,
+    // factor the panel.  Threaded along the split of the elimination tree the back-substitution uses (plan_split): the parts are sets of
+    // whole subtrees, independent of each other -- one task each --; the supernodes of the top (separators: every one of them is updated by
+    // descendants from all over the tree, half of the panel entries and most of the arithmetic at n = 6 005) follow one after the other,
+    // each with its update phase cut into column ranges that run side by side (a column of the panel receives its updates in the same
+    // order whichever range it falls into, and every entry of an update is one accumulator over the descendant's columns: the factor is
+    // bitwise the same for any number of threads -- tests/test_host.py).  The demos' call (a new tau per frame, 36 k vertices, coarsest
+    // level of 6 005 unknowns) spends most of its set-up here: 7.5 ms on one thread.
+    struct NumericWork { std::vector<int> relpos; std::vector<double> U, F; };
+    // updates of supernode s restricted to its columns [c0, c1) (relative), from the descendants upd[lo, hi)
+    void apply_updates(int s, int c0, int c1, const std::vector<int>& relpos, NumericWork& wk, bool avx) {
+        const int f = sn_first_[s], w = sn_first_[s + 1] - f;
+        const int ld = w + (rows_ptr_[s + 1] - rows_ptr_[s]);
+        double* P = pan_.data() + pan_ptr_[s];
+        const int col_lo = f + c0, col_hi = f + c1;
+        for (int q = upd_ptr_[s]; q < upd_ptr_[s + 1]; ++q) {
+            const int dd = upd_sn_[q];
+            const int fd = sn_first_[dd], wd = sn_first_[dd + 1] - fd;
+            const int* Rd = rows_.data() + rows_ptr_[dd];
+            const int rd = rows_ptr_[dd + 1] - rows_ptr_[dd];
+            const int ldd = wd + rd;
+            int p0 = upd_pos_[q];
+            while (p0 < rd && Rd[p0] < col_lo) ++p0;                    // (rows inside this supernode's columns: at most w of them)
+            int k1 = 0;
+            while (p0 + k1 < rd && Rd[p0 + k1] < col_hi) ++k1;
+            if (k1 == 0) continue;
+            const int k = rd - p0;
+            const double* Lk = pan_.data() + pan_ptr_[dd] + wd + p0;
+            wk.U.resize((size_t)k * k1);
+            if (avx) { wk.F.resize((size_t)wd * k1); panel_update_blocked(Lk, ldd, k, k1, wd, D_.data() + fd, wk.U.data(), wk.F.data()); }
+            else panel_update_base(Lk, ldd, k, k1, wd, D_.data() + fd, wk.U.data());
+            for (int j = 0; j < k1; ++j) {
+                double* tc = P + (size_t)(Rd[p0 + j] - f) * ld;
+                const double* uj = wk.U.data() + (size_t)j * k;
+                for (int i = j; i < k; ++i) tc[relpos[Rd[p0 + i]]] -= uj[i];
+            }
+        }
+    }
+    void set_relpos(int s, std::vector<int>& relpos) const {
+        const int f = sn_first_[s], w = sn_first_[s + 1] - f;
+        const int* R = rows_.data() + rows_ptr_[s];
+        const int r = rows_ptr_[s + 1] - rows_ptr_[s];
+        for (int j = 0; j < w; ++j) relpos[f + j] = j;
+        for (int i = 0; i < r; ++i) relpos[R[i]] = w + i;
+    }
+    bool factor_panel(int s, bool avx) {
+        const int f = sn_first_[s], w = sn_first_[s + 1] - f;
+        const int ld = w + (rows_ptr_[s + 1] - rows_ptr_[s]);
+        double* P = pan_.data() + pan_ptr_[s];
+        return avx ? panel_factor_avx2(P, ld, ld, w, D_.data() + f) : panel_factor_base(P, ld, ld, w, D_.data() + f);
+    }
     void numeric(const Compressed& A) {
         if (pan_.fresh) pan_.fresh = false;       // first factorisation into this storage: zero already, pages not yet touched
         else {
@@ -1253,45 +1336,104 @@ private:
             }, 8);
         }
         const bool avx = has_avx2();
-        std::vector<int> relpos(n, -1);          // row -> row index inside the current panel
-        std::vector<int> head(ns_, -1), next(ns_, -1), pos(ns_, 0);      // pending descendants of each supernode, their progress
-        std::vector<double> U, Fbuf;
-        for (int s = 0; s < ns_; ++s) {
+        const int T = numeric_threads();
+        std::atomic<int> failed{0};
+        static const bool trace = std::getenv("GMG_LDLT_TRACE") != nullptr;
+        auto tr0 = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) { if (!trace) return; auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[gmg ldlt] numeric %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tr0).count()); tr0 = now; };
+        lap("zero");
+        // a team of spinning threads for the few milliseconds this takes (hand-overs of ~0.2 us: an update phase of a top supernode is
+        // ~0.2 ms of work in all, the worker pool's condition variable would eat it); created on first use, asleep when not armed
+        if (T > 1 && (!fteam_ || fteam_->helpers() != T - 1)) fteam_ = std::make_shared<SpinTeam>(T - 1);
+        SpinTeam* team = T > 1 ? fteam_.get() : nullptr;
+        struct Armed { SpinTeam* t; explicit Armed(SpinTeam* q) : t(q) { if (t) t->arm(); } ~Armed() { if (t) t->disarm(); } } armed(team);
+        auto run_jobs = [&](void (*fn)(void*, int), void* arg, int njobs) { if (team) team->run(fn, arg, njobs); else for (int j = 0; j < njobs; ++j) fn(arg, j); };
+        // ---- the parts: whole subtrees, one job per part
+        struct PartsCtx { SupernodalLDLT* self; const Compressed* A; std::atomic<int>* failed; bool avx; } pc{this, &A, &failed, avx};
+        run_jobs([](void* p, int part) {
+            PartsCtx& c = *(PartsCtx*)p;
+            SupernodalLDLT& L = *c.self;
+            NumericWork wk;
+            wk.relpos.assign((size_t)L.n, -1);
+            for (int s : L.part_sn_[(size_t)part]) {
+                if (c.failed->load(std::memory_order_relaxed)) return;
+                const int f = L.sn_first_[s], w = L.sn_first_[s + 1] - f;
+                L.set_relpos(s, wk.relpos);
+                L.s_assemble(*c.A, s, f, w, L.pan_.data() + L.pan_ptr_[s], w + (L.rows_ptr_[s + 1] - L.rows_ptr_[s]), wk.relpos);
+                L.apply_updates(s, 0, w, wk.relpos, wk, c.avx);
+                if (!L.factor_panel(s, c.avx)) { c.failed->store(1, std::memory_order_relaxed); return; }
+            }
+        }, &pc, parts_);
+        if (failed.load()) return;
+        lap("parts");
+        // ---- the top: one supernode after the other.  Its updates in two parallel steps: the dense products U = L_k D L_k1^T of all its
+        // descendants side by side (one job each, into one buffer), then their subtraction from the panel by column ranges, every range
+        // walking the descendants in ascending order
+        double t_fac = 0, t_prod = 0, t_sub = 0, w_sum = 0, r_sum = 0, u_sum = 0; int n_top = 0;
+        std::vector<int> relpos((size_t)n, -1);
+        struct Upd { int dd, p0, k, k1; size_t u, f; };
+        std::vector<Upd> ups;
+        std::vector<double> buf;
+        struct TopCtx { SupernodalLDLT* self; int s, w, slices; const std::vector<int>* relpos; std::vector<Upd>* ups; double* buf; bool avx; } tc{this, 0, 0, 1, &relpos, &ups, nullptr, avx};
+        for (int s : top_sn_) {
             const int f = sn_first_[s], w = sn_first_[s + 1] - f;
-            const int* R = rows_.data() + rows_ptr_[s];
-            const int r = rows_ptr_[s + 1] - rows_ptr_[s];
-            const int ld = w + r;
-            double* P = pan_.data() + pan_ptr_[s];
-            for (int j = 0; j < w; ++j) relpos[f + j] = j;
-            for (int i = 0; i < r; ++i) relpos[R[i]] = w + i;
-            s_assemble(A, s, f, w, P, ld, relpos);
-            // updates from the descendants that reach this supernode
-            for (int dd = head[s]; dd >= 0;) {
-                const int nxt = next[dd];
-                const int fd = sn_first_[dd], wd = sn_first_[dd + 1] - fd;
+            set_relpos(s, relpos);
+            s_assemble(A, s, f, w, pan_.data() + pan_ptr_[s], w + (rows_ptr_[s + 1] - rows_ptr_[s]), relpos);
+            const int nup = upd_ptr_[s + 1] - upd_ptr_[s];
+            ups.clear();
+            size_t need = 0;
+            for (int q = upd_ptr_[s]; q < upd_ptr_[s + 1]; ++q) {
+                const int dd = upd_sn_[q], p0 = upd_pos_[q];
                 const int* Rd = rows_.data() + rows_ptr_[dd];
-                const int rd = rows_ptr_[dd + 1] - rows_ptr_[dd];
-                const int ldd = wd + rd;
-                const int p0 = pos[dd];
+                const int rd = rows_ptr_[dd + 1] - rows_ptr_[dd], wd = sn_first_[dd + 1] - sn_first_[dd];
                 int k1 = 0;
                 while (p0 + k1 < rd && Rd[p0 + k1] < f + w) ++k1;
                 const int k = rd - p0;
-                const double* Lk = pan_.data() + pan_ptr_[dd] + wd + p0;
-                U.resize((size_t)k * k1);
-                if (avx) { Fbuf.resize((size_t)wd * k1); panel_update_blocked(Lk, ldd, k, k1, wd, D_.data() + fd, U.data(), Fbuf.data()); }
-                else panel_update_base(Lk, ldd, k, k1, wd, D_.data() + fd, U.data());
-                for (int j = 0; j < k1; ++j) {
-                    double* tc = P + (size_t)(Rd[p0 + j] - f) * ld;
-                    const double* uj = U.data() + (size_t)j * k;
-                    for (int i = j; i < k; ++i) tc[relpos[Rd[p0 + i]]] -= uj[i];
-                }
-                pos[dd] = p0 + k1;
-                if (pos[dd] < rd) { const int t = sn_of_[Rd[pos[dd]]]; next[dd] = head[t]; head[t] = dd; }
-                dd = nxt;
+                ups.push_back(Upd{dd, p0, k, k1, need, need + (size_t)k * k1});
+                need += (size_t)k * k1 + (size_t)wd * k1;
             }
-            if (!(avx ? panel_factor_avx2(P, ld, ld, w, D_.data() + f) : panel_factor_base(P, ld, ld, w, D_.data() + f))) return;
-            if (r > 0) { const int t = sn_of_[R[0]]; pos[s] = 0; next[s] = head[t]; head[t] = s; }
+            if (buf.size() < need) buf.resize(need);
+            tc.s = s; tc.w = w; tc.buf = buf.data();
+            auto tq = std::chrono::steady_clock::now();
+            run_jobs([](void* p, int q) {                       // products
+                TopCtx& c = *(TopCtx*)p;
+                SupernodalLDLT& L = *c.self;
+                const Upd& u = (*c.ups)[(size_t)q];
+                const int fd = L.sn_first_[u.dd], wd = L.sn_first_[u.dd + 1] - fd;
+                const int ldd = wd + (L.rows_ptr_[u.dd + 1] - L.rows_ptr_[u.dd]);
+                const double* Lk = L.pan_.data() + L.pan_ptr_[u.dd] + wd + u.p0;
+                if (c.avx) panel_update_blocked(Lk, ldd, u.k, u.k1, wd, L.D_.data() + fd, c.buf + u.u, c.buf + u.f);
+                else panel_update_base(Lk, ldd, u.k, u.k1, wd, L.D_.data() + fd, c.buf + u.u);
+            }, &tc, nup);
+            if (trace) { auto now = std::chrono::steady_clock::now(); t_prod += std::chrono::duration<double, std::milli>(now - tq).count(); tq = now; }
+            const int slices = std::max(1, std::min(T, w / 4));
+            tc.slices = slices;
+            run_jobs([](void* p, int sl) {                      // subtraction, columns [c0, c1) of the panel
+                TopCtx& c = *(TopCtx*)p;
+                SupernodalLDLT& L = *c.self;
+                const int f = L.sn_first_[c.s];
+                const int ld = c.w + (L.rows_ptr_[c.s + 1] - L.rows_ptr_[c.s]);
+                double* P = L.pan_.data() + L.pan_ptr_[c.s];
+                const int col_lo = f + (int)((long)c.w * sl / c.slices), col_hi = f + (int)((long)c.w * (sl + 1) / c.slices);
+                const int* relpos = c.relpos->data();
+                for (const Upd& u : *c.ups) {
+                    const int* Rd = L.rows_.data() + L.rows_ptr_[u.dd] + u.p0;
+                    for (int j = 0; j < u.k1; ++j) {
+                        if (Rd[j] < col_lo) continue;
+                        if (Rd[j] >= col_hi) break;
+                        double* tcol = P + (size_t)(Rd[j] - f) * ld;
+                        const double* uj = c.buf + u.u + (size_t)j * u.k;
+                        for (int i = j; i < u.k; ++i) tcol[relpos[Rd[i]]] -= uj[i];
+                    }
+                }
+            }, &tc, slices);
+            if (trace) t_sub += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq).count();
+            auto tf = std::chrono::steady_clock::now();
+            if (!factor_panel(s, avx)) return;      // (its rows shared between the team in ranges: slower -- short inner loops, shared cache lines)
+            if (trace) { t_fac += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf).count(); ++n_top; w_sum += w; r_sum += rows_ptr_[s + 1] - rows_ptr_[s]; u_sum += nup; }
         }
+        if (trace) std::fprintf(stderr, "[gmg ldlt] top: %d supernodes, mean width %.1f, mean rows below %.1f, mean updates %.1f, products %.2f ms, subtraction %.2f ms, panel factor %.2f ms\n", n_top, w_sum / std::max(n_top, 1), r_sum / std::max(n_top, 1), u_sum / std::max(n_top, 1), t_prod, t_sub, t_fac);
+        lap("top");
         ok = true;
     }
 

@@ -161,6 +161,34 @@ def test_same_pattern_systems_keep_or_drop_the_blocks_with_their_signs(cabi, ora
     assert res <= 1e-4 and abs(oracle.residual_check(P.lhs, P.mass, P.rhs, x, 2) - res) <= 1e-3 * res + 1e-9
 
 
+@pytest.mark.parametrize("kw", [dict(inner_precision=1), dict(use_graph=True), dict(coarse_mode=1), dict(device_setup=False)],
+                         ids=["fp32-inner-cycle", "hipgraph", "device-coarse-apply", "host-planner"])
+def test_engine_variants_on_a_blocked_fine_level(cabi, oracle, kw):
+    """The other ways of running the cycle meet a blocked level 0 too: the fp32 inner cycle of the mixed-precision iteration (fp32 twins of
+    the block storage), legs replayed from hipGraphs, the coarsest solve applied on the device, layouts from the host planner -- the same
+    answer as the plain engine (bitwise where the arithmetic is the same), confirmed by the oracle's residual check."""
+    P = _cloud()
+    ref = _engine(cabi, P)
+    e = _engine(cabi, P, **kw)
+    assert e.level_blocks(0) is not None and np.array_equal(e.level_ordering(0)[0], ref.level_ordering(0)[0])
+    x, it, res, _ = e.solve(P.rhs, tol=1e-4)
+    xr, itr, resr, _ = ref.solve(P.rhs, tol=1e-4)
+    assert res <= 1e-4 and abs(oracle.residual_check(P.lhs, P.mass, P.rhs, x, 2) - res) <= 1e-3 * res + 1e-9
+    m = P.mass[:, None]
+    if "inner_precision" in kw:
+        # the fp32 inner cycle costs this system (tau M + S, tau = 1e-6: ||x|| / ||b|| ~ 1e8, far from what mixed precision is for) cycles in either
+        # layout, more in the blocked one: 12 against 9 in fp64 here, 8 against 7 colour-major
+        _, itc, resc, _ = _engine(cabi, P, block_fine=0, **kw).solve(P.rhs, tol=1e-4)
+        print("fp32 inner cycle: blocked", it, "colour-major", itc, "fp64 blocked", itr)
+        assert resc <= 1e-4 and it <= itr + 4 and np.sqrt((m * (x - xr) ** 2).sum() / (m * xr ** 2).sum()) <= 20 * 1e-4
+    elif "coarse_mode" in kw:
+        assert abs(it - itr) <= 1 and np.sqrt((m * (x - xr) ** 2).sum() / (m * xr ** 2).sum()) <= 20 * 1e-4
+    else:
+        assert it == itr and res == resr and np.array_equal(x, xr)
+    x3, it3, res3, _ = e.solve(np.repeat(P.rhs, 3, axis=1) * np.array([[1.0, -2.0, 0.5]]), tol=1e-4)      # d = 3 through the same layout
+    assert res3 <= 1e-4 and np.allclose(x3[:, :1], x, rtol=0, atol=1e-6 * np.abs(x).max())
+
+
 def test_the_distributed_path_says_what_it_needs(cabi):
     P = _cloud()
     e = _engine(cabi, P, row_align=128)

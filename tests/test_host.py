@@ -310,3 +310,37 @@ def test_host_ldlt_team_back_substitution_gives_the_same_bits():
     diffs = re.findall(r"(\d+) threads: .* max \|difference\| to the one-thread solve ([0-9.e+-]+)", out.stderr)
     assert len(diffs) >= 2 and all(float(d) == 0.0 for _, d in diffs), out.stderr[-2000:]
     assert float(re.search(r"residual ([0-9.e+-]+)", out.stdout).group(1)) <= 1e-10
+
+
+def test_host_ldlt_threaded_factorisation_gives_the_same_bits():
+    """The numeric factorisation runs the parts of the elimination tree side by side and shares the update phase of every supernode of
+    the top between a team of threads (host_ldlt.hpp::numeric): the updates of a supernode are subtracted in ascending order of its
+    descendants whoever computes them, so the factor -- here seen through a solve -- has the same bits for 1, 3 and 8 threads, and is
+    the factor of the matrix (residual against the input, solution against scipy's LU)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla, sys\n"
+        "from gravo_mg_amd import cabi\n"
+        "from tests import problems\n"
+        "P = problems.torus_problem(96, 80, 'smoothing', 30)\n"
+        "A = sp.csc_matrix(P.lhs)\n"
+        "A = sp.csc_matrix(P.U[0].T @ A @ P.U[0])\n"          # a Galerkin operator (M + tau S: well conditioned): ~20 entries per row, 1 250 unknowns
+        "m = 70\n"
+        "T = sp.diags([-1.0, 2.2, -1.0], [-1, 0, 1], shape=(m, m))\n"
+        "G = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()\n"      # and a 4 900-unknown grid: several parts, a top of separators
+        "for M in (A, G):\n"
+        "    b = np.random.default_rng(3).standard_normal((M.shape[0], 2))\n"
+        "    x, nnz = cabi.host_ldlt_solve(M, b)\n"
+        "    assert np.linalg.norm(M @ x - b) <= 1e-10 * np.linalg.norm(b)\n"
+        "    assert np.linalg.norm(x - spla.splu(M).solve(b)) <= 1e-9 * np.linalg.norm(x)\n"
+        "    sys.stdout.write(x.tobytes().hex() + '\\n')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, GMG_LDLT_THREADS=threads)
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append(out.stdout)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000
