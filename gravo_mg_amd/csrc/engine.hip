@@ -1853,6 +1853,25 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             std::fprintf(stderr, "[gmg ldlt] %d threads: %.2f us per solve; max |difference| to the one-thread solve %.1e  (phases: parts down %.1f, top down %.1f, top up %.1f, "
                          "parts up %.1f us; %d top supernodes in %d chains)\n", threads, best2, diff, ph[0], ph[1], ph[2], ph[3], (int)ph[4], (int)ph[5]);
         }
+        {   // three right-hand sides (the demos' n x 3 call) on the team of a V-cycle solve, against three single-column solves
+            const int threads = std::min(8, std::max(2, std::min(f.parts() * 3, hw_threads() - 1)));
+            SpinTeam team(threads - 1);
+            team.arm();
+            std::vector<double> b3((size_t)n * 3), x3((size_t)n * 3), w3((size_t)n * 3), x1((size_t)n);
+            for (int c = 0; c < 3; ++c) for (int i = 0; i < n; ++i) b3[(size_t)c * n + i] = b[i] * (c + 1);
+            double best3 = 1e30, diff3 = 0.0;
+            for (int batch = 0; batch < 20; ++batch) {
+                auto t0 = clk::now();
+                for (int i = 0; i < reps; ++i) f.solve_multi(b3.data(), (size_t)n, x3.data(), (size_t)n, 3, w3.data(), &team);
+                best3 = std::min(best3, 1e3 * ms_since(t0) / reps);
+            }
+            team.disarm();
+            for (int c = 0; c < 3; ++c) {
+                f.solve_multi(b3.data() + (size_t)c * n, (size_t)n, x1.data(), (size_t)n, 1, w3.data());
+                for (int i = 0; i < n; ++i) diff3 = std::max(diff3, std::fabs(x1[i] - x3[(size_t)c * n + i]));
+            }
+            std::fprintf(stderr, "[gmg ldlt] 3 columns on %d threads: %.2f us per solve; max |difference| to single-column solves %.1e\n", threads, best3, diff3);
+        }
         { double ph[6]; f.profile(b, w.data(), nullptr, reps, ph);
           std::fprintf(stderr, "[gmg ldlt] 1 thread phases: parts down %.1f, top down %.1f, top up %.1f, parts up %.1f us\n", ph[0], ph[1], ph[2], ph[3]); }
     }

@@ -592,17 +592,59 @@ public:
     // single column keeps one thread busy (d = 3 at n = 1 929: ~100 us per cycle with one thread per column, see the bench line).  Every
     // (group, column) job is the single-column arithmetic on that column's own buffers: results bitwise those of solve_column.
     static constexpr int kMaxCols = 4;
-    struct MultiJob { const SupernodalLDLT* self; double* y[kMaxCols]; double* t[kMaxCols]; bool forward; const int* groups; int ngroups; };
+    struct MultiJob { const SupernodalLDLT* self; double* y[kMaxCols]; double* t[kMaxCols]; bool forward; const int* groups; int ngroups; int ncols; };
     static void run_part_multi(void* p, int idx) {
         MultiJob* j = (MultiJob*)p;
         const int c = idx / j->ngroups, q = idx - c * j->ngroups;
         PartJob one{j->self, j->y[c], j->t[c], j->forward, j->groups};
         run_part(&one, q);
     }
+    // the PARTS (stage 0) of a multi-column solve: one job per part taking all the columns through every supernode of the part, column by
+    // column -- the single-column arithmetic on each column's own buffers (same bits), but the panel is fetched once instead of once per
+    // column (the parts are where the team is saturated: 8 parts x 3 columns on 8 threads; the top keeps one job per (chain, column))
+    static void run_part_cols(void* p, int q) {
+        MultiJob* j = (MultiJob*)p;
+        const SupernodalLDLT* S = j->self;
+        const int g = j->groups[q], d = j->ncols;
+        const bool avx = has_avx2();
+        const std::vector<int>& list = S->part_sn_[(size_t)g];
+        if (j->forward) {
+            for (int s : list) {
+                const int f = S->sn_first_[s], w = S->sn_first_[s + 1] - f;
+                const int* R = S->rows_.data() + S->rows_ptr_[s];
+                const int r = S->rows_ptr_[s + 1] - S->rows_ptr_[s];
+                const double* P = S->pan_.data() + S->pan_ptr_[s];
+                const int k = S->own_rows_[s];
+                for (int c = 0; c < d; ++c) {
+                    double* y = j->y[c];
+                    double* t = S->group_buffer(j->t[c], g);
+                    double* acc = S->group_acc(j->t[c], g);
+                    if (avx) sn_forward1_avx2(P, w + r, w, r, y + f, t); else sn_forward1_base(P, w + r, w, r, y + f, t);
+                    for (int i = 0; i < k; ++i) y[R[i]] -= t[i];
+                    for (int i = k; i < r; ++i) acc[R[i]] += t[i];
+                }
+            }
+        } else {
+            for (size_t qq = list.size(); qq-- > 0;) {
+                const int s = list[qq];
+                const int f = S->sn_first_[s], w = S->sn_first_[s + 1] - f;
+                const int* R = S->rows_.data() + S->rows_ptr_[s];
+                const int r = S->rows_ptr_[s + 1] - S->rows_ptr_[s];
+                const double* P = S->pan_.data() + S->pan_ptr_[s];
+                for (int c = 0; c < d; ++c) {
+                    double* y = j->y[c];
+                    double* t = S->group_buffer(j->t[c], g);
+                    for (int i = 0; i < r; ++i) t[i] = y[R[i]];
+                    if (avx) sn_backward1_avx2(P, w + r, w, r, y + f, t); else sn_backward1_base(P, w + r, w, r, y + f, t);
+                }
+            }
+        }
+    }
     void solve_columns_staged(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work, SpinTeam* team) const {
         const int S = (int)stage_groups_.size();
         const size_t nt = scratch_doubles();
-        MultiJob job{this, {}, {}, true, nullptr, 0};
+        static const bool split_cols = std::getenv("GMG_LDLT_SPLIT_COLUMNS") != nullptr;      // A/B aid: the parts as (part, column) jobs too
+        MultiJob job{this, {}, {}, true, nullptr, 0, d};
         for (int c = 0; c < d; ++c) {
             job.y[c] = work + (size_t)c * n; job.t[c] = scratch_.data() + nt * (size_t)c;
             const double* bc = b + (size_t)c * ldb;
@@ -610,12 +652,14 @@ public:
         }
         for (int st = 0; st < S; ++st) {
             job.groups = stage_groups_[st].data(); job.ngroups = (int)stage_groups_[st].size(); job.forward = true;
-            team->run(run_part_multi, &job, job.ngroups * d);
+            if (st == 0 && !split_cols) team->run(run_part_cols, &job, job.ngroups);       // (stage 0 = the parts: nothing to take in from earlier stages)
+            else team->run(run_part_multi, &job, job.ngroups * d);
         }
         for (int c = 0; c < d; ++c) for (int j = 0; j < n; ++j) job.y[c][j] /= D_[j];
         for (int st = S - 1; st >= 0; --st) {
             job.groups = stage_groups_[st].data(); job.ngroups = (int)stage_groups_[st].size(); job.forward = false;
-            team->run(run_part_multi, &job, job.ngroups * d);
+            if (st == 0 && !split_cols) team->run(run_part_cols, &job, job.ngroups);
+            else team->run(run_part_multi, &job, job.ngroups * d);
         }
         for (int c = 0; c < d; ++c) {
             double* xc = x + (size_t)c * ldx;
