@@ -23,6 +23,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -81,9 +82,12 @@ struct GmgSignalAid {
 // =========================================================================================================
 // No exception leaves the C-ABI: std::bad_alloc (a 3 M-vertex set-up allocates hundreds of MB on the host), a failed
 // thread start, ... become a status code + gmg_last_error.
+// (a cycle that was unwound between the two halves of its coarsest solve leaves a gate in its stream and the process-wide shared lock that
+// goes with it: the handler opens both -- gate_unwound)
+int gate_unwound(gmg_handle h);
 #define GMG_CATCH_H                                                                                             \
-    catch (const std::exception& e_) { return h ? fail(h, GMG_ERR_STATE, std::string("exception: ") + e_.what()) : GMG_ERR_STATE; } \
-    catch (...) { return h ? fail(h, GMG_ERR_STATE, "unknown exception") : GMG_ERR_STATE; }
+    catch (const std::exception& e_) { if (h) (void)gate_unwound(h); return h ? fail(h, GMG_ERR_STATE, std::string("exception: ") + e_.what()) : GMG_ERR_STATE; } \
+    catch (...) { if (h) (void)gate_unwound(h); return h ? fail(h, GMG_ERR_STATE, "unknown exception") : GMG_ERR_STATE; }
 #define GMG_CATCH_0                                              \
     catch (...) { return GMG_ERR_STATE; }
 
@@ -165,16 +169,16 @@ void gmg_destroy(gmg_handle h) {
         drop_system(h);
         drop_device_transfers(h);
         for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)dev_free(*p);
-        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-        for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]); if (h->h_stage_ev[i]) (void)hipEventDestroy(h->h_stage_ev[i]); }
+        if (h->h_pinned) (void)sync_hipHostFree(h->h_pinned);
+        for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) (void)sync_hipHostFree(h->h_stage[i]); if (h->h_stage_ev[i]) (void)hipEventDestroy(h->h_stage_ev[i]); }
         for (hipEvent_t& e : h->h_chunk_ev) if (e) (void)hipEventDestroy(e);
-        if (h->h_norm) (void)hipHostFree(h->h_norm);
-        if (h->h_flag) (void)hipHostFree(h->h_flag);
+        if (h->h_norm) (void)sync_hipHostFree(h->h_norm);
+        if (h->h_flag) (void)sync_hipHostFree(h->h_flag);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
-        for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
+        for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)sync_hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
         for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(h->own_stream);
+        (void)sync_hipStreamDestroy(h->own_stream);
         h->pool.trim();
     }
     delete h;
@@ -1607,7 +1611,7 @@ static bool hierarchy_select_on_device(const HierarchyOptions::SelectJob& j) {
              X.down(j.col, arena + offs[12], sizeof(int) * 3 * nf, threads) && X.down(j.w, arena + offs[13], sizeof(double) * 3 * nf, threads);
     }
     (void)hipStreamSynchronize(X.st);          // nothing of this job may still be in flight when its buffers go
-    (void)hipFree(arena);
+    (void)sync_hipFree(arena);
     if (!ok) (void)hipGetLastError();
     return ok;
 }

@@ -447,11 +447,11 @@ int ensure_vectors(gmg_handle h, int d) {
     Level& c = h->lv[h->L];
     size_t need = (size_t)c.n_pad * d * 2;
     if (need > h->pinned_cap) {
-        if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+        if (h->h_pinned) (void)sync_hipHostFree(h->h_pinned);
         HIPCHK(hipHostMalloc((void**)&h->h_pinned, sizeof(double) * need, kPolledHostFlags));
         h->pinned_cap = need;
     }
-    if (h->h_norm) (void)hipHostFree(h->h_norm);
+    if (h->h_norm) (void)sync_hipHostFree(h->h_norm);
     HIPCHK(hipHostMalloc((void**)&h->h_norm, sizeof(double) * 2 * d, kPolledHostFlags));
     if (!h->h_flag) {
         HIPCHK(hipHostMalloc((void**)&h->h_flag, 256, kPolledHostFlags));
@@ -478,7 +478,7 @@ int ensure_stage(gmg_handle h, size_t n_doubles) {
 int ensure_host_stage(gmg_handle h, size_t n_doubles) {
     if (n_doubles <= h->h_stage_cap) return GMG_OK;
     for (int i = 0; i < 2; ++i) {
-        if (h->h_stage[i]) (void)hipHostFree(h->h_stage[i]);
+        if (h->h_stage[i]) (void)sync_hipHostFree(h->h_stage[i]);
         h->h_stage[i] = nullptr;
         HIPCHK(hipHostMalloc((void**)&h->h_stage[i], sizeof(double) * n_doubles, hipHostMallocDefault));
         if (!h->h_stage_ev[i]) HIPCHK(hipEventCreateWithFlags(&h->h_stage_ev[i], hipEventDisableTiming));
@@ -703,8 +703,21 @@ int coarse_host_serve(gmg_handle h) {
     const int w = wait_flag(h, 1);
     if (w == GMG_OK) coarse_host_solve(h, h->coarse_pending_d);
     __atomic_store_n(h->h_flag + 16, h->flag_seq[2], __ATOMIC_RELEASE);
+    if (h->gate_shared) { h->gate_shared = false; --tl_gates_held; gate_mutex().unlock_shared(); }
     return w;
 }
+
+}  // namespace
+// an exception crossed a cycle: open a pending gate without an answer (the stream must not stay parked, the shared lock not stay held)
+int gate_unwound(gmg_handle h) {
+    if (h->coarse_pending) {
+        h->coarse_pending = false;
+        if (h->h_flag) __atomic_store_n(h->h_flag + 16, h->flag_seq[2], __ATOMIC_RELEASE);
+    }
+    if (h->gate_shared) { h->gate_shared = false; --tl_gates_held; gate_mutex().unlock_shared(); }
+    return GMG_OK;
+}
+namespace {
 
 template <class T = double>
 int coarse_host_begin(gmg_handle h, int d) {
@@ -720,6 +733,8 @@ int coarse_host_begin(gmg_handle h, int d) {
         // safety net (an idle stream implies visible data) cannot fire behind a gate the host itself has to open, so on a host that does
         // not see in-flight device writes a gated first contact would spin for ever.  The first coarse solve of a handle is ungated.
         if (h->gate_ok && h->gate_proven && !gate_off) {
+            // (shared lock first: from here to coarse_host_serve no thread of this process starts a device-wide synchronisation, see gate_mutex)
+            if (!h->gate_shared) { gate_mutex().lock_shared(); h->gate_shared = true; ++tl_gates_held; }
             if (hipStreamWaitValue64(h->stream, h->h_flag + 16, ++h->flag_seq[2], hipStreamWaitValueGte, ~0ull) == hipSuccess) {
                 // (round 4: letting the prolongation out of the coarsest level gather the answer straight from the pinned host buffer instead of this
                 // copy kernel -- one launch less behind the host -- measured 0.6608 vs 0.6582 ms per cycle: the gathers over PCIe cost what the copy costs)
@@ -730,6 +745,7 @@ int coarse_host_begin(gmg_handle h, int d) {
                 return GMG_OK;
             }
             (void)hipGetLastError();
+            if (h->gate_shared) { h->gate_shared = false; --tl_gates_held; gate_mutex().unlock_shared(); }
             h->gate_ok = false; --h->flag_seq[2]; h->timing["gate_disabled"] = 1.0;
         }
         int w = wait_flag(h, 1);

@@ -81,14 +81,14 @@ void p2p_release(gmg_handle h) {
         if (peer.mbox_base) (void)hipIpcCloseMemHandle(peer.mbox_base);
         if (peer.flag_base) (void)hipIpcCloseMemHandle(peer.flag_base);
     }
-    if (p->mbox) (void)hipFree(p->mbox);
-    if (p->flags) (void)hipFree(p->flags);
-    if (p->d_idx) (void)hipFree(p->d_idx);
-    if (p->d_ops) (void)hipFree(p->d_ops);
-    if (p->d_err) (void)hipFree(p->d_err);
-    if (p->d_done) (void)hipFree(p->d_done);
-    if (p->d_sums) (void)hipFree(p->d_sums);
-    if (p->d_l1) (void)hipFree(p->d_l1);
+    if (p->mbox) (void)sync_hipFree(p->mbox);
+    if (p->flags) (void)sync_hipFree(p->flags);
+    if (p->d_idx) (void)sync_hipFree(p->d_idx);
+    if (p->d_ops) (void)sync_hipFree(p->d_ops);
+    if (p->d_err) (void)sync_hipFree(p->d_err);
+    if (p->d_done) (void)sync_hipFree(p->d_done);
+    if (p->d_sums) (void)sync_hipFree(p->d_sums);
+    if (p->d_l1) (void)sync_hipFree(p->d_l1);
     delete p;
     h->p2p = nullptr;
 }
@@ -368,7 +368,7 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
             for (int b : p->own_blocks[s]) for (int i = 0; i < 64; ++i) idx.push_back(64 * b + i);
             rows1_at[s + 1] = idx.size();
         }
-    if (p->d_idx) { (void)hipFree(p->d_idx); p->d_idx = nullptr; }
+    if (p->d_idx) { (void)sync_hipFree(p->d_idx); p->d_idx = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_idx, sizeof(int) * std::max<size_t>(idx.size(), 1)));
     HIPCHK(hipMemcpy(p->d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
     // ---- one op table per (kind, parity)
@@ -410,7 +410,7 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
         p->kind_blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 4095) / 4096));
     }
     if (!p->d_done) { HIPCHK(hipMalloc((void**)&p->d_done, sizeof(unsigned int) * world)); HIPCHK(hipMemset(p->d_done, 0, sizeof(unsigned int) * world)); }
-    if (p->d_ops) { (void)hipFree(p->d_ops); p->d_ops = nullptr; }
+    if (p->d_ops) { (void)sync_hipFree(p->d_ops); p->d_ops = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_ops, sizeof(gmgk::P2POp) * ops.size()));
     HIPCHK(hipMemcpy(p->d_ops, ops.data(), sizeof(gmgk::P2POp) * ops.size(), hipMemcpyHostToDevice));
     p->connected = true;

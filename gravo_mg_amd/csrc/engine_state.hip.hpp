@@ -2,6 +2,28 @@
 // engine_state, engine_setup, engine_cycle).  Device memory pool, level / handle structures, error and upload helpers.
 #pragma once
 
+// ---- device-wide synchronisation against gated streams (process-wide) ------------------------------------------
+// A V-cycle of a polled handle parks its stream behind a word only its own host thread writes (hipStreamWaitValue64, engine_cycle.hip.hpp::
+// coarse_host_begin) and goes on enqueuing the way up before it serves that word.  hipFree / hipHostFree / hipStreamDestroy wait for the
+// WHOLE device -- every stream, the parked one included -- while holding the runtime's lock: called from another thread (another handle
+// being destroyed or re-set while this one solves) they wait for the gate, and the gate's thread waits for the runtime's lock in its next
+// launch: a deadlock (found by scripts/soak_factor.py: two threads in gmg_destroy, one in gmg_solve, for ever).  Hence: a gate is held
+// under a shared lock from before it is enqueued until its word is written, and the library's device-synchronising calls take the lock
+// exclusively -- they wait until no gate of this process is pending.  (Device-wide synchronisations issued by OTHER code in the process
+// while a solve runs in another thread cannot be fenced this way: GMG_NO_STREAM_GATE=1 gives the gate up.)
+inline std::shared_mutex& gate_mutex() { static std::shared_mutex* m = new std::shared_mutex(); return *m; }      // (leaked: usable during exit)
+static thread_local int tl_gates_held = 0;          // gates pending on this thread (it must not take the exclusive lock itself)
+struct DeviceSyncGuard {
+    bool locked = false;
+    DeviceSyncGuard() { if (tl_gates_held == 0) { gate_mutex().lock(); locked = true; } }
+    ~DeviceSyncGuard() { if (locked) gate_mutex().unlock(); }
+    DeviceSyncGuard(const DeviceSyncGuard&) = delete;
+    DeviceSyncGuard& operator=(const DeviceSyncGuard&) = delete;
+};
+static inline hipError_t sync_hipFree(void* p) { DeviceSyncGuard g; return hipFree(p); }
+static inline hipError_t sync_hipHostFree(void* p) { DeviceSyncGuard g; return hipHostFree(p); }
+static inline hipError_t sync_hipStreamDestroy(hipStream_t s) { DeviceSyncGuard g; return hipStreamDestroy(s); }
+
 // ---- device memory pool (per handle) ------------------------------------------------------------------------
 // hipFree costs ~0.2 ms and synchronises the device; a setup allocates and releases ~100 arrays.  Blocks released
 // by a handle are parked in its pool and handed out again (same stream => stream order makes the reuse safe); the
@@ -25,12 +47,12 @@ struct DevPool {
     }
     void release(void* p) {
         auto it = size_of.find(p);
-        if (it == size_of.end()) { (void)hipFree(p); return; }          // not ours (allocated outside a pool scope)
+        if (it == size_of.end()) { (void)sync_hipFree(p); return; }          // not ours (allocated outside a pool scope)
         parked.emplace(it->second, p); parked_bytes += it->second; live_bytes -= std::min(live_bytes, it->second);
         if (parked_bytes > std::max<size_t>(live_bytes, (size_t)2 << 30)) trim();
     }
     void trim() {
-        for (auto& kv : parked) { (void)hipFree(kv.second); size_of.erase(kv.second); }
+        { DeviceSyncGuard g; for (auto& kv : parked) { (void)hipFree(kv.second); size_of.erase(kv.second); } }
         parked.clear(); parked_bytes = 0;
     }
 };
@@ -41,7 +63,7 @@ struct PoolScope {
     ~PoolScope() { tl_pool = prev; }
 };
 static inline hipError_t dev_malloc(void** p, size_t bytes) { return tl_pool ? tl_pool->alloc(p, bytes) : hipMalloc(p, bytes); }
-static inline hipError_t dev_free(void* p) { if (!p) return hipSuccess; if (tl_pool) { tl_pool->release(p); return hipSuccess; } return hipFree(p); }
+static inline hipError_t dev_free(void* p) { if (!p) return hipSuccess; if (tl_pool) { tl_pool->release(p); return hipSuccess; } return sync_hipFree(p); }
 
 namespace {
 
@@ -180,6 +202,7 @@ struct gmg_solver_s {
     bool gate_ok = true;                 // false once hipStreamWaitValue64 was refused: launch after the solve instead
     bool gate_proven = false;            // true once a published right-hand side was seen by the polling host while the stream was busy (ungated)
     bool coarse_pending = false;         // a gate is enqueued and the host has not answered it yet
+    bool gate_shared = false;            // ... and this thread holds gate_mutex() shared for it (released by coarse_host_serve)
     bool coarse_warm = false;            // the solving thread has read the current factor once (SupernodalLdlt::warm)
     double coarse_warm_sink = 0.0;
     int coarse_pending_d = 0;

@@ -70,3 +70,20 @@ def test_host_planner_set_system_repeated_on_a_small_mesh(cabi):
         else:
             assert it == ref[1] and np.array_equal(x, ref[0])
         del eng
+
+
+def test_handles_in_threads_do_not_deadlock_on_a_gated_stream():
+    """Regression (round 4): a polled handle parks its stream behind a word its own host thread writes (hipStreamWaitValue64) while it
+    enqueues the way up; hipFree / hipHostFree / hipStreamDestroy in ANOTHER thread (another handle destroyed or re-set) wait for the whole
+    device under the runtime's lock -- the gate's thread then never gets to its next launch: two threads in gmg_destroy, one in gmg_solve,
+    for ever (within 1-25 rounds of scripts/soak_factor.py).  Gates now hold a process-wide shared lock that those calls take exclusively
+    (engine_state.hip.hpp::gate_mutex).  Three handles in three threads, values-only and cold set-ups, solves, destruction, 60 rounds;
+    every solve repeats the single-threaded run bit for bit.  Run in a subprocess so that a relapse is a time-out, not a hung suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GMG_SOAK_WATCHDOG="60")
+    out = subprocess.run([sys.executable, "-X", "faulthandler", os.path.join(root, "scripts", "soak_factor.py"), "60"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0 and "soak ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
