@@ -43,7 +43,7 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_block_omega", C.c_double),
     ]
 
 
@@ -310,7 +310,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_block_omega=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -330,6 +330,8 @@ class Engine:
             cfg.dist_shard_levels = int(dist_shard_levels)
         if block_fine is not None:
             cfg.block_fine = int(bool(block_fine))
+        if fine_block_omega is not None:
+            cfg.fine_block_omega = float(fine_block_omega)
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -338,6 +340,7 @@ class Engine:
         self._sizes: List[int] = []
         self.pre_iters, self.post_iters = int(pre_iters), int(post_iters)
         self.gs_omega = float(cfg.gs_omega)       # relaxation factor of the level-0 sweep (engine default unless given)
+        self.fine_block_omega = float(cfg.fine_block_omega)      # ... of a blocked level 0's block sweep
 
     @classmethod
     def borrow(cls, handle: int) -> "Engine":

@@ -119,6 +119,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->verbose = 0;
     cfg->block_ep = 1;
     cfg->dist_shard_levels = 2;
+    cfg->fine_block_omega = 1.0;      // measured (profiles/r04/s_fine_omega_scan.jsonl): 1.1-1.2 saves 1-3 of 11-25 cycles on kNN clouds of 20 k .. 2 M points, 1.3 diverges at 2 M, 1.4 everywhere -- too thin a margin for a default
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
@@ -139,7 +140,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.restrict_sigma < 0 || c.restrict_sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 || !(c.fine_block_omega > 0.0 && c.fine_block_omega < 2.0) ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;

@@ -168,6 +168,14 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
         if (l.use_ep) {
             const int vgrid = (nb + 7) / 8 * 8;         // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, vgrid)
             const int grid = ep_persistent_grid(h, vgrid);
+            // (a blocked level 0 relaxes its updates: gmg_config::fine_block_omega)
+            const bool relax = &l == &h->lv[0] && h->cfg.fine_block_omega != 1.0;
+            if (relax) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D, true>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
+                                                  ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
+                                                  Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                                  out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid, out_il, (T)h->cfg.fine_block_omega));
+            } else
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
                                               ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
                                               Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),

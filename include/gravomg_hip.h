@@ -103,6 +103,10 @@ typedef struct {
                               operators (7 entries per row, 4-7 colours) keep the over-relaxed multicolour sweep, Bilaplacians fail the
                               sign test.  The blocks are runs of 64 points of the hierarchy's cluster order.  0: level 0 is blocked only
                               by block_from_level = 0.  The multi-GPU path (gmg_p2p_*) needs the colour-major level 0: set 0 there */
+    double fine_block_omega; /* relaxation factor of the block sweep of a BLOCKED level 0 (block_fine / block_from_level = 0 with the 64-row entry-parallel
+                              sweep): x_i <- x_i + omega (x_i^GS - x_i) inside the block, i.e. x_out = x_in + (D / omega + L_block)^-1 (b - A x_in); what
+                              gs_omega is to the colour-major level 0.  1.0 (default): the plain block sweep, a regular splitting of a Stieltjes matrix.  Above 1 nothing guarantees convergence any more: measured on kNN clouds, 1.1-1.2 saves
+                              1-3 of 11-25 cycles, 1.3 diverges at 2 M points, 1.4 everywhere (an opt-in knob).  Must lie in (0, 2) */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
