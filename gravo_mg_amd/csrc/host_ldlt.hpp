@@ -1321,14 +1321,15 @@ private:
     // Numeric factorisation, left-looking by supernodes: assemble the panel from A, subtract the updates of the descendants that reach
     // it -- in ASCENDING order of the descendants (upd_*: fixed by the symbolic phase, so the sums do not depend on who computes them) --,
     // factor the panel.  Threaded along the split of the elimination tree the back-substitution uses (plan_split): the parts are sets of
-    // whole subtrees, independent of each other -- one task each --; the supernodes of the top (separators: every one of them is updated by
+    // whole subtrees, independent of each other -- one job each --; the supernodes of the top (separators: every one of them is updated by
     // descendants from all over the tree, half of the panel entries and most of the arithmetic at n = 6 005) follow one after the other,
-    // each with its update phase cut into column ranges that run side by side (a column of the panel receives its updates in the same
-    // order whichever range it falls into, and every entry of an update is one accumulator over the descendant's columns: the factor is
-    // bitwise the same for any number of threads -- tests/test_host.py).  The demos' call (a new tau per frame, 36 k vertices, coarsest
-    // level of 6 005 unknowns) spends most of its set-up here: 7.5 ms on one thread.
+    // each with its update phase in two parallel steps: the dense products of its descendants side by side, then their subtraction from
+    // the panel by column ranges (a column receives its updates in the same order whichever range it falls into, and every entry of a
+    // product is one accumulator over the descendant's columns: the factor is bitwise the same for any number of threads --
+    // tests/test_host.py).  The demos' call (a new tau per frame, 36 k vertices, coarsest level of 6 005 unknowns) spent most of its
+    // set-up here: 7.5 ms on one thread, 3.0 ms on eight.
     struct NumericWork { std::vector<int> relpos; std::vector<double> U, F; };
-    // updates of supernode s restricted to its columns [c0, c1) (relative), from the descendants upd[lo, hi)
+    // updates of supernode s restricted to its columns [c0, c1) (relative), descendant after descendant (the parts: the whole supernode at once)
     void apply_updates(int s, int c0, int c1, const std::vector<int>& relpos, NumericWork& wk, bool avx) {
         const int f = sn_first_[s], w = sn_first_[s + 1] - f;
         const int ld = w + (rows_ptr_[s + 1] - rows_ptr_[s]);
@@ -1397,17 +1398,20 @@ private:
         run_jobs([](void* p, int part) {
             PartsCtx& c = *(PartsCtx*)p;
             SupernodalLDLT& L = *c.self;
-            NumericWork wk;
-            wk.relpos.assign((size_t)L.n, -1);
-            for (int s : L.part_sn_[(size_t)part]) {
-                if (c.failed->load(std::memory_order_relaxed)) return;
-                const int f = L.sn_first_[s], w = L.sn_first_[s + 1] - f;
-                L.set_relpos(s, wk.relpos);
-                L.s_assemble(*c.A, s, f, w, L.pan_.data() + L.pan_ptr_[s], w + (L.rows_ptr_[s + 1] - L.rows_ptr_[s]), wk.relpos);
-                L.apply_updates(s, 0, w, wk.relpos, wk, c.avx);
-                if (!L.factor_panel(s, c.avx)) { c.failed->store(1, std::memory_order_relaxed); return; }
-            }
+            try {                                               // (a job may run on a team thread: nothing may leave it -- the work buffers allocate)
+                NumericWork wk;
+                wk.relpos.assign((size_t)L.n, -1);
+                for (int s : L.part_sn_[(size_t)part]) {
+                    if (c.failed->load(std::memory_order_relaxed)) return;
+                    const int f = L.sn_first_[s], w = L.sn_first_[s + 1] - f;
+                    L.set_relpos(s, wk.relpos);
+                    L.s_assemble(*c.A, s, f, w, L.pan_.data() + L.pan_ptr_[s], w + (L.rows_ptr_[s + 1] - L.rows_ptr_[s]), wk.relpos);
+                    L.apply_updates(s, 0, w, wk.relpos, wk, c.avx);
+                    if (!L.factor_panel(s, c.avx)) { c.failed->store(1, std::memory_order_relaxed); return; }
+                }
+            } catch (...) { c.failed->store(2, std::memory_order_relaxed); }
         }, &pc, parts_);
+        if (failed.load() == 2) throw std::bad_alloc();      // (on the calling thread: becomes the C-ABI's error code)
         if (failed.load()) return;
         lap("parts");
         // ---- the top: one supernode after the other.  Its updates in two parallel steps: the dense products U = L_k D L_k1^T of all its
