@@ -292,15 +292,24 @@ static int h2d(gmg_handle h, void* dst, const void* src, size_t bytes) {
     if (bytes < kBounceMin) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return GMG_OK; }
     int rc = ensure_bounce(h);
     if (rc) return rc;
+    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    double t_wait = 0, t_copy = 0, t_issue = 0;
+    auto t_all = clk::now();
     for (size_t off = 0; off < bytes; off += kBounceBytes) {
         const size_t len = std::min(kBounceBytes, bytes - off);
         const int f = h->bounce_flip;
         h->bounce_flip ^= 1;
+        auto t0 = clk::now();
         HIPCHK(hipEventSynchronize(h->bounce_ev[f]));                  // the previous DMA out of this buffer is done
+        auto t1 = clk::now();
         threaded_copy_bytes(h->bounce[f], (const char*)src + off, len, h->cfg.host_threads);
+        auto t2 = clk::now();
         HIPCHK(hipMemcpyAsync((char*)dst + off, h->bounce[f], len, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipEventRecord(h->bounce_ev[f], h->stream));
+        if (trace) { t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_copy += std::chrono::duration<double, std::milli>(t2 - t1).count(); t_issue += ms_since(t2); }
     }
+    if (trace && bytes >= ((size_t)32 << 20))
+        std::fprintf(stderr, "[gmg setup] h2d %.0f MB in %.2f ms: waiting for a free bounce buffer %.2f, host copy %.2f, issuing %.2f ms\n", bytes / 1048576.0, ms_since(t_all), t_wait, t_copy, t_issue);
     return GMG_OK;
 }
 
