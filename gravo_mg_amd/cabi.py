@@ -139,6 +139,7 @@ SIGNATURES = {
     "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
     "gmg_host_plan_level": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _ip, _ip,
                                       C.POINTER(C.c_ubyte)]),
+    "gmg_host_fine_block_rule": (C.c_int, [C.c_int, _ip, _ip, _dp, _ip, _ip]),
     "gmg_host_ldlt_solve": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int64)]),
 }
 
@@ -734,6 +735,16 @@ def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024, 
     else:
         out["color_begin"] = color_begin[: n_colors + 1].copy()
     return out
+
+
+def host_fine_block_rule(A):
+    """(blocked, reason) of the rule behind gmg_config::block_fine for the system matrix A (host only): reason 0 chosen, 1 rows too short, 2 signs."""
+    a = _csc(A)
+    blocked, reason = C.c_int(0), C.c_int(0)
+    rc = lib().gmg_host_fine_block_rule(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), C.byref(blocked), C.byref(reason))
+    if rc:
+        raise GmgError(rc, "gmg_host_fine_block_rule")
+    return bool(blocked.value), int(reason.value)
 
 
 def host_ldlt_solve(A, b):

@@ -1809,6 +1809,16 @@ int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const doubl
     return GMG_OK;
 } GMG_CATCH_0
 
+int gmg_host_fine_block_rule(int n, const int* colptr, const int* rowidx, const double* val, int* blocked, int* reason) try {
+    if (n <= 0 || !colptr || !rowidx || !val || !blocked) return GMG_ERR_INVALID;
+    int why = 0;
+    if ((double)colptr[n] < kFineBlockMinRow * (double)n) why = 1;
+    else if (!stieltjes_signs(n, colptr, rowidx, val, hw_threads())) why = 2;
+    *blocked = why == 0 ? 1 : 0;
+    if (reason) *reason = why;
+    return GMG_OK;
+} GMG_CATCH_0
+
 int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x, int64_t* factor_nnz) try {
     if (n <= 0 || !colptr || !rowidx || !val || !b || !x || d <= 0) return GMG_ERR_INVALID;
     Compressed A;

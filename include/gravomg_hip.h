@@ -363,6 +363,11 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
  * n_colors + 1 and blk_begin of n_blocks + 1 entries. */
 int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma,
                         int64_t* info, int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color);
+/* Host-only view of the rule behind gmg_config::block_fine (engine_setup.hip.hpp::fine_level_blocked), for CPU tests: would level 0 of this
+ * system run the block-hybrid sweep under the DEFAULT configuration, given a hierarchy?  *blocked = 1: at least 9 stored entries per row on
+ * average, every diagonal entry positive, no positive off-diagonal entry (a Stieltjes matrix, for the symmetric positive definite systems
+ * the solver takes: the block sweep is a regular splitting).  reason (optional): 0 chosen, 1 rows too short, 2 signs. */
+int gmg_host_fine_block_rule(int n, const int* colptr, const int* rowidx, const double* val, int* blocked, int* reason);
 /* Host-only: x = A^{-1} b with the coarsest-level solver (minimum-degree + sparse LDL^T, host_ldlt.hpp),
  * b/x column-major n x d.  Returns GMG_ERR_NUMERIC on a zero pivot.  factor_nnz (optional) = nnz(L). */
 int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x,

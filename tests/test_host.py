@@ -344,3 +344,25 @@ def test_host_ldlt_threaded_factorisation_gives_the_same_bits():
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append(out.stdout)
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000
+
+
+def test_fine_block_rule_on_the_host(cabi):
+    """The rule behind gmg_config::block_fine (level 0 blocked too): kNN graph Laplacians qualify -- long rows, positive diagonal, no positive
+    off-diagonal entry --; a triangle-mesh operator has too few entries per row, a Bilaplacian has positive second-ring entries, and one
+    positive coupling or a non-positive diagonal entry disqualifies a kNN operator (the block sweep is then no regular splitting)."""
+    import scipy.sparse as sp
+    from gravo_mg_amd import meshgen
+    P = problems.pointcloud_problem(3000)
+    assert cabi.host_fine_block_rule(P.lhs) == (True, 0)
+    T = problems.torus_problem(48, 40, "poisson", 60)
+    assert cabi.host_fine_block_rule(T.lhs) == (False, 1)
+    B = problems.torus_problem(48, 40, "bilaplacian", 40)
+    assert cabi.host_fine_block_rule(B.lhs) == (False, 2)
+    A = sp.lil_matrix(P.lhs)
+    nb = sp.csc_matrix(P.lhs)[:, 5].indices; j = int(nb[nb != 5][0])
+    A[5, j] = A[j, 5] = 1e-6
+    assert cabi.host_fine_block_rule(sp.csc_matrix(A)) == (False, 2)
+    A = sp.lil_matrix(P.lhs); A[7, 7] = 0.0
+    assert cabi.host_fine_block_rule(sp.csc_matrix(A)) == (False, 2)
+    S, mass = meshgen.knn_graph_laplacian(meshgen.torus_points(2000, noise=0.002), 12)      # smoothing system of a denser graph
+    assert cabi.host_fine_block_rule(meshgen.smoothing_system(S, mass, np.zeros((2000, 3)))[0]) == (True, 0)
