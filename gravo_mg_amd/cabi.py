@@ -43,14 +43,14 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_block_omega", C.c_double),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int),
     ]
 
 
 class GmgHierarchyOptions(C.Structure):
     _fields_ = [
         ("ratio", C.c_double), ("lower_bound", C.c_int), ("check_voronoi", C.c_int), ("nested", C.c_int),
-        ("sampling", C.c_int), ("weighting", C.c_int), ("debug", C.c_int),
+        ("sampling", C.c_int), ("weighting", C.c_int), ("debug", C.c_int), ("full_clustering", C.c_int),
     ]
 
 
@@ -75,8 +75,6 @@ SIGNATURES = {
     "gmg_get_level_operator": (C.c_int, [_vp, C.c_int, _ip, _ip, _dp]),
     "gmg_get_level_ordering": (C.c_int, [_vp, C.c_int, _ip, _ip]),
     "gmg_get_level_blocks": (C.c_int, [_vp, C.c_int, _ip, _ip, C.POINTER(C.c_ubyte)]),
-    "gmg_debug_sell_info": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
-    "gmg_debug_sell_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _dp, _ip, _dp]),
     "gmg_get_timing": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_smooth": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, C.c_int]),
     "gmg_residual": (C.c_int, [_vp, C.c_int, _dp, _dp, C.c_int, _dp]),
@@ -136,11 +134,19 @@ SIGNATURES = {
     "gmg_set_fine_order": (C.c_int, [_vp, C.c_int, _ip]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
     "gmg_finalize_hierarchy": (C.c_int, [_vp]),
+    "gmg_host_ldlt_solve": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int64)]),
+}
+
+# test / measurement hooks: include/gravomg_hip_internal.h (not part of the drop-in boundary)
+INTERNAL_SIGNATURES = {
+    "gmg_debug_sell_info": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64)]),
+    "gmg_debug_sell_copy": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _dp, _ip, _dp]),
     "gmg_host_galerkin": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, _ip, _ip, _dp, _ip, _ip, _dp]),
     "gmg_host_plan_level": (C.c_int, [C.c_int, _ip, _ip, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _ip, _ip, _ip,
                                       C.POINTER(C.c_ubyte)]),
     "gmg_host_fine_block_rule": (C.c_int, [C.c_int, _ip, _ip, _dp, _ip, _ip]),
-    "gmg_host_ldlt_solve": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int64)]),
+    "gmg_debug_set": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "gmg_host_ldlt_probe": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, C.c_char_p, C.c_int]),
 }
 
 _lib = None
@@ -178,7 +184,7 @@ def lib() -> C.CDLL:
                 "gravo_mg_amd has no CPU fallback for the device path.")
         _preload_torch_hip_runtime()
         l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL_SIGNATURES.items()):
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
@@ -239,7 +245,7 @@ class Hierarchy:
     Mirrors what ``MGBS::MultigridSolver::buildHierarchy`` produces: ``U`` (list of scipy CSC matrices,
     n_k x n_{k+1}) and the reference's ``hierarchyTiming`` keys."""
 
-    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0, debug=False):
+    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0, debug=False, full_clustering=False):
         l = lib()
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         neigh = np.ascontiguousarray(neigh, dtype=np.int32)
@@ -248,7 +254,7 @@ class Hierarchy:
         opt = GmgHierarchyOptions()
         l.gmg_hierarchy_options_default(C.byref(opt))
         opt.ratio, opt.lower_bound, opt.check_voronoi, opt.nested = float(ratio), int(lower_bound), int(bool(check_voronoi)), int(bool(nested))
-        opt.sampling, opt.weighting, opt.debug = int(sampling), int(weighting), int(bool(debug))
+        opt.sampling, opt.weighting, opt.debug, opt.full_clustering = int(sampling), int(weighting), int(bool(debug)), int(bool(full_clustering))
         self._h = _vp()
         rc = l.gmg_hierarchy_build(_pd(pos), pos.shape[0], _pi(neigh), neigh.shape[1], C.byref(opt), C.byref(self._h))
         if rc:
@@ -311,7 +317,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_block_omega=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -331,8 +337,10 @@ class Engine:
             cfg.dist_shard_levels = int(dist_shard_levels)
         if block_fine is not None:
             cfg.block_fine = int(bool(block_fine))
-        if fine_block_omega is not None:
-            cfg.fine_block_omega = float(fine_block_omega)
+        if fine_col16 is not None:
+            cfg.fine_col16 = int(bool(fine_col16))
+        if stream_gate is not None:
+            cfg.stream_gate = int(bool(stream_gate))
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -341,7 +349,6 @@ class Engine:
         self._sizes: List[int] = []
         self.pre_iters, self.post_iters = int(pre_iters), int(post_iters)
         self.gs_omega = float(cfg.gs_omega)       # relaxation factor of the level-0 sweep (engine default unless given)
-        self.fine_block_omega = float(cfg.fine_block_omega)      # ... of a blocked level 0's block sweep
 
     @classmethod
     def borrow(cls, handle: int) -> "Engine":
@@ -757,3 +764,15 @@ def host_ldlt_solve(A, b):
     if rc:
         raise GmgError(rc, "gmg_host_ldlt_solve (zero pivot?)")
     return (X[:, 0].copy() if np.asarray(b).ndim == 1 else X), nnz.value
+
+
+def host_ldlt_probe(A, b, reps: int = 3) -> str:
+    """Report of the coarsest-level solver's probe (gravomg_hip_internal.h): timings on 1 .. 8 threads, bitwise agreement of the team
+    solves with the one-thread solve, supernodal against simplicial factorisation."""
+    a = _csc(A)
+    B = _f64(b)
+    buf = C.create_string_buffer(1 << 16)
+    rc = lib().gmg_host_ldlt_probe(a.shape[0], _pi(a.indptr), _pi(a.indices), _pd(a.data), _pd(B), int(reps), buf, len(buf))
+    if rc:
+        raise GmgError(rc, "gmg_host_ldlt_probe")
+    return buf.value.decode()

@@ -178,7 +178,7 @@ public:
                     int stopping_criteria, int pre_iters, int post_iters, int max_iter, bool check_voronoi, bool nested,
                     Sampling sampling_strategy, Weighting weighting, bool sig06, DenseIn normals, bool verbose, bool debug, bool ablation,
                     int ablation_num_points, bool ablation_random) {
-        const bool trace = std::getenv("GMG_CTOR_TRACE") != nullptr;      // phases of the construction on stderr
+        const bool trace = MGBS::ctorTrace();      // GMG_TRACE=ctor: phases of the construction on stderr
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!trace) return;
@@ -322,8 +322,15 @@ public:
         else if (key == "block_lanes") c.block_lanes = (int)value;
         else if (key == "dist_shard_levels") c.dist_shard_levels = (int)value;
         else if (key == "block_fine") c.block_fine = (int)value;
+        else if (key == "fine_col16") c.fine_col16 = (int)value;
+        else if (key == "stream_gate") c.stream_gate = (int)value;
+        else if (key == "inner_precision") c.inner_precision = (int)value;
         else throw std::invalid_argument("unknown engine option: " + key);
     }
+
+#ifdef GMG_TESTING
+    void test_report_diverged(int n) { solver->testReportDiverged = n; }
+#endif
 
 private:
     // The reference reports problems with printed messages only; the drop-in additionally raises, so that a missing
@@ -366,5 +373,9 @@ PYBIND11_MODULE(gravomg_bindings, m) {
         .def("hierarchy_timing", &MultigridSolver::hierarchy_timing)
         .def("convergence", &MultigridSolver::convergence)
         .def("prepare_system", &MultigridSolver::prepare_system, py::arg("lhs"))
-        .def("set_engine_option", &MultigridSolver::set_engine_option, py::arg("key"), py::arg("value"));
+        .def("set_engine_option", &MultigridSolver::set_engine_option, py::arg("key"), py::arg("value"))
+#ifdef GMG_TESTING
+        .def("_test_report_diverged", &MultigridSolver::test_report_diverged, py::arg("n"))
+#endif
+        ;
 }

@@ -34,6 +34,7 @@
 #endif
 
 #include "../../include/gravomg_hip.h"
+#include "../../include/gravomg_hip_internal.h"
 #include "host_hierarchy.hpp"
 #include "host_ldlt.hpp"
 #include "host_plan.hpp"
@@ -63,7 +64,7 @@ void gmg_fatal_signal(int sig) {
 }
 struct GmgSignalAid {
     GmgSignalAid() {
-        if (!std::getenv("GMG_SEGV_BACKTRACE")) return;
+        if (!EnvSwitches::get().segv_backtrace) return;
         void* warm[4];
         (void)backtrace(warm, 4);                  // first use loads libgcc_s (dlopen + malloc): not something to do inside a signal handler
         struct sigaction sa;
@@ -119,7 +120,8 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->verbose = 0;
     cfg->block_ep = 1;
     cfg->dist_shard_levels = 2;
-    cfg->fine_block_omega = 1.0;      // measured (profiles/r04/s_fine_omega_scan.jsonl): 1.1-1.2 saves 1-3 of 11-25 cycles on kNN clouds of 20 k .. 2 M points, 1.3 diverges at 2 M, 1.4 everywhere -- too thin a margin for a default
+    cfg->fine_col16 = 1;
+    cfg->stream_gate = 1;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
@@ -140,7 +142,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.restrict_sigma < 0 || c.restrict_sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 || !(c.fine_block_omega > 0.0 && c.fine_block_omega < 2.0) ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
@@ -153,7 +155,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
         { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0) h->n_cus = cus; else (void)hipGetLastError(); }
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
-        if (const char* e = std::getenv("GMG_POLL")) h->poll = std::atoi(e) != 0;
+        h->poll = EnvSwitches::get().poll;
         (void)ensure_bounce(h);         // 2 x 16 MB pinned, once per handle (page-locking is not free: not inside gmg_set_system)
     }
     *out = h;
@@ -593,8 +595,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         unsigned long long sc[2], sb[2];
         order_gather_score_host(PatternView{n, colptr, rowidx}, h->cluster_order, 4096, sc);
         order_gather_score_host(PatternView{n, colptr, rowidx}, h->bfs_order, 4096, sb);
-        if (const char* e = std::getenv("GMG_BASE_ORDER")) h->base_order_choice = std::atoi(e) == 1 ? 1 : 0;
-        else h->base_order_choice = (sc[1] && sb[1] && (double)sb[0] / (double)sb[1] < (double)sc[0] / (double)sc[1]) ? 1 : 0;
+        h->base_order_choice = (sc[1] && sb[1] && (double)sb[0] / (double)sb[1] < (double)sc[0] / (double)sc[1]) ? 1 : 0;
         h->timing["base_order_score_cluster"] = sc[1] ? (double)sc[0] / (double)sc[1] : 0.0;
         h->timing["base_order_score_bfs"] = sb[1] ? (double)sb[0] / (double)sb[1] : 0.0;
         h->timing["base_order_choice"] = h->base_order_choice;
@@ -1210,8 +1211,6 @@ static int solve_common(gmg_handle h, const double* rhs, const double* x0, doubl
     // Gauss-Seidel in colour order on every level, convergent for every SPD matrix (MultigridSolver::solve does).  x receives the
     // last iterate either way, as in the reference (multigrid_solver.cpp:1408-1419 never looks at the trend).
     bool diverged = !(residue <= tol) && (blown || (it > 1 && residue > first_residue));
-    // (test aid, tests/test_dropin_api.py: lets the callers' handling of GMG_DIVERGED be exercised on a system every smoother solves)
-    if (const char* f = std::getenv("GMG_TEST_FORCE_DIVERGED")) if (f[0] == '1' && (h->cfg.block_rows != 0 || h->cfg.gs_omega != 1.0)) diverged = true;
     h->timing["diverged"] = diverged ? 1.0 : 0.0;
     h->timing["blown_up"] = blown ? 1.0 : 0.0;           // stopped early: residue not finite or 1e4 x the smallest seen
     auto t_f = clk::now();
@@ -1487,8 +1486,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
     int launches = 1;
-    static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
-    const bool il = k == 0 && d > 1 && d <= 4 && !no_il && l.Aoff.lpr == 1;
+    const bool il = k == 0 && d > 1 && d <= 4 && l.Aoff.lpr == 1;
     const bool il_p = il && h->L >= 2 && h->lv[1].ord.blocked && h->lv[1].use_ep && h->cfg.post_iters > 0 && h->cfg.smoother != GMG_SMOOTHER_JACOBI;
     auto body = [&]() {
         switch (kind) {
@@ -1522,7 +1520,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
 
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o) try {
     if (!o) return GMG_ERR_INVALID;
-    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0; o->debug = 0;
+    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0; o->debug = 0; o->full_clustering = 0;
     return GMG_OK;
 } GMG_CATCH_0
 
@@ -1625,12 +1623,11 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     if (o.weighting < 0 || o.weighting > 2 || !(o.ratio > 0)) return GMG_ERR_INVALID;
     for (size_t i = 0; i < (size_t)n * K; ++i) if (neigh[i] >= n) return GMG_ERR_INVALID;
     HierarchyOptions ho;
-    ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting; ho.keep_triangles = o.debug != 0;
+    ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting; ho.keep_triangles = o.debug != 0; ho.full_clustering = o.full_clustering != 0;
     // the per-point selection stage runs on the GPU when there is one (same bits as the host loop; GMG_HIERARCHY_DEVICE=0: host only)
     {
-        const char* env = std::getenv("GMG_HIERARCHY_DEVICE");
         int ndev = 0;
-        if (!(env && std::atoi(env) == 0) && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ho.device_select = hierarchy_select_on_device;
+        if (EnvSwitches::get().hierarchy_device && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ho.device_select = hierarchy_select_on_device;
         else (void)hipGetLastError();
     }
     // first use in a process: runtime start-up, code object load and the pinned buffers (~80 ms) happen beside the sequential
@@ -1809,6 +1806,13 @@ int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const doubl
     return GMG_OK;
 } GMG_CATCH_0
 
+// set-up fault injection for the tests (gravomg_hip_internal.h)
+int gmg_debug_set(gmg_handle h, const char* key, double value) try {
+    if (!h || !key) return GMG_ERR_INVALID;
+    if (std::string(key) == "col16_uncovered") { h->dbg_col16_uncovered = (int)value; return GMG_OK; }
+    return fail(h, GMG_ERR_INVALID, std::string("unknown debug key: ") + key);
+} GMG_CATCH_H
+
 int gmg_host_fine_block_rule(int n, const int* colptr, const int* rowidx, const double* val, int* blocked, int* reason) try {
     if (n <= 0 || !colptr || !rowidx || !val || !blocked) return GMG_ERR_INVALID;
     int why = 0;
@@ -1829,8 +1833,25 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
     std::vector<double> w((size_t)n * d);
     f.solve_multi(b, (size_t)n, x, (size_t)n, d, w.data());
     if (factor_nnz) *factor_nnz = f.factor_nnz();
-    if (const char* reps_env = std::getenv("GMG_LDLT_BENCH")) {        // back-substitution time of the coarsest-level solver (host measurement aid)
-        const int reps = std::max(1, std::atoi(reps_env));
+    return GMG_OK;
+} GMG_CATCH_0
+
+// Measurement / cross-check aid of the coarsest-level solver (gravomg_hip_internal.h; tests/test_host.py, scripts/ldlt_bench.py): factorises A,
+// times the back-substitution on 1 .. 8 threads (`reps` solves per batch, best of 20 batches) and the numeric re-factorisation, compares the
+// team solves with the one-thread solve bit for bit and the supernodal factor with the simplicial one, and writes the report (text lines) into
+// `report` (cap bytes, NUL-terminated, truncated if need be).
+int gmg_host_ldlt_probe(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int reps, char* report, int cap) try {
+    if (n <= 0 || !colptr || !rowidx || !val || !b || !report || cap <= 0) return GMG_ERR_INVALID;
+    reps = std::max(1, reps);
+    Compressed A;
+    A.assign(n, n, colptr, rowidx, val);
+    SupernodalLDLT f;
+    if (!f.factor(A)) return GMG_ERR_NUMERIC;
+    std::vector<double> w((size_t)n * 3), x((size_t)n);
+    f.solve_multi(b, (size_t)n, x.data(), (size_t)n, 1, w.data());
+    std::string text;
+    auto say = [&](const char* fmt, auto... args) { char line[1024]; std::snprintf(line, sizeof(line), fmt, args...); text += line; };
+    {
         std::vector<double> xb((size_t)n);
         double best = 1e30;
         for (int batch = 0; batch < 20; ++batch) {                     // minimum over batches: the host may be shared
@@ -1838,16 +1859,16 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             for (int i = 0; i < reps; ++i) f.solve_multi(b, (size_t)n, xb.data(), (size_t)n, 1, w.data());
             best = std::min(best, 1e3 * ms_since(t0) / reps);
         }
-        std::fprintf(stderr, "[gmg ldlt] factorisation: ordering %.2f ms, symbolic %.2f ms, numeric %.2f ms\n", f.phase_ms[0], f.phase_ms[1], f.phase_ms[2]);
+        say("factorisation: ordering %.2f ms, symbolic %.2f ms, numeric %.2f ms\n", f.phase_ms[0], f.phase_ms[1], f.phase_ms[2]);
         {   // numeric re-factorisation (a system with the same sparsity pattern: the demos' new tau per frame), best and median of 15
             std::vector<double> ts;
             for (int i = 0; i < 15; ++i) { if (!f.factor(A, true)) return GMG_ERR_NUMERIC; ts.push_back(f.phase_ms[2]); }
             std::sort(ts.begin(), ts.end());
-            std::fprintf(stderr, "[gmg ldlt] numeric re-factorisation on %d thread(s): best %.2f ms, median %.2f ms\n", SupernodalLDLT::numeric_threads(), ts.front(), ts[ts.size() / 2]);
+            say("numeric re-factorisation on %d thread(s): best %.2f ms, median %.2f ms\n", SupernodalLDLT::numeric_threads(), ts.front(), ts[ts.size() / 2]);
         }
         long part[3];
         f.split_report(part);
-        std::fprintf(stderr, "[gmg ldlt] n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread (best of 20 batches of %d); %d parts of the elimination "
+        say("n=%d nnz(L)=%ld: %.2f us per single-column solve on one thread (best of 20 batches of %d); %d parts of the elimination "
                      "tree, panel entries in the lightest / heaviest part / above them: %ld / %ld / %ld\n", n, f.factor_nnz(), best, reps, f.parts(), part[0], part[1], part[2]);
         for (int threads = 2; threads <= std::min(8, f.parts()); threads += threads < 4 ? 1 : 2) {
             double best2 = 1e30, diff = 0.0;
@@ -1865,7 +1886,7 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
             team.arm();
             f.profile(b, w.data(), &team, reps, ph);
             team.disarm();
-            std::fprintf(stderr, "[gmg ldlt] %d threads: %.2f us per solve; max |difference| to the one-thread solve %.1e  (phases: parts down %.1f, top down %.1f, top up %.1f, "
+            say("%d threads: %.2f us per solve; max |difference| to the one-thread solve %.1e  (phases: parts down %.1f, top down %.1f, top up %.1f, "
                          "parts up %.1f us; %d top supernodes in %d chains)\n", threads, best2, diff, ph[0], ph[1], ph[2], ph[3], (int)ph[4], (int)ph[5]);
         }
         {   // three right-hand sides (the demos' n x 3 call) on the team of a V-cycle solve, against three single-column solves
@@ -1885,23 +1906,24 @@ int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const doubl
                 f.solve_multi(b3.data() + (size_t)c * n, (size_t)n, x1.data(), (size_t)n, 1, w3.data());
                 for (int i = 0; i < n; ++i) diff3 = std::max(diff3, std::fabs(x1[i] - x3[(size_t)c * n + i]));
             }
-            std::fprintf(stderr, "[gmg ldlt] 3 columns on %d threads: %.2f us per solve; max |difference| to single-column solves %.1e\n", threads, best3, diff3);
+            say("3 columns on %d threads: %.2f us per solve; max |difference| to single-column solves %.1e\n", threads, best3, diff3);
         }
         { double ph[6]; f.profile(b, w.data(), nullptr, reps, ph);
-          std::fprintf(stderr, "[gmg ldlt] 1 thread phases: parts down %.1f, top down %.1f, top up %.1f, parts up %.1f us\n", ph[0], ph[1], ph[2], ph[3]); }
+          say("1 thread phases: parts down %.1f, top down %.1f, top up %.1f, parts up %.1f us\n", ph[0], ph[1], ph[2], ph[3]); }
     }
-    if (std::getenv("GMG_LDLT_CROSSCHECK")) {
+    {   // the supernodal factorisation against the simplicial one it replaced
         SparseLDLT g;
         if (!g.factor(A)) return GMG_ERR_NUMERIC;
         std::vector<double> xr(n);
-        for (int c = 0; c < d; ++c) {
+        for (int c = 0; c < 1; ++c) {
             g.solve(b + (size_t)c * n, xr.data(), w.data());
             double e2 = 0, n2 = 0;
             for (int i = 0; i < n; ++i) { const double dd = xr[i] - x[(size_t)c * n + i]; e2 += dd * dd; n2 += xr[i] * xr[i]; }
-            std::fprintf(stderr, "[gmg ldlt] column %d: supernodal vs simplicial relative difference %.3e (nnz(L) %ld vs %ld)\n", c, std::sqrt(e2 / std::max(n2, 1e-300)),
+            say("column %d: supernodal vs simplicial relative difference %.3e (nnz(L) %ld vs %ld)\n", c, std::sqrt(e2 / std::max(n2, 1e-300)),
                          f.factor_nnz(), g.factor_nnz());
         }
     }
+    std::snprintf(report, (size_t)cap, "%s", text.c_str());
     return GMG_OK;
 } GMG_CATCH_0
 

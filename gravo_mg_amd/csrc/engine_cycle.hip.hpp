@@ -139,15 +139,9 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
     if (in != Prec<T>::x(l)) (void)hipMemcpyAsync(Prec<T>::x(l), in, sizeof(T) * (size_t)ld * d, hipMemcpyDeviceToDevice, h->stream);
 }
 
-// Launch geometry of the entry-parallel block sweep (kernels.hip.hpp::gs_block_ep): persistent workgroups -- `waves_per_cu` per compute
-// unit, each sweeping several blocks -- when the level has more blocks than that; one block per workgroup otherwise.
-// GMG_EP_WAVES_PER_CU: A/B aid (0 = always one block per workgroup, the launch of rounds 2 and 3).
-inline int ep_persistent_grid(gmg_handle h, int vgrid) {
-    static const int env_wpc = std::getenv("GMG_EP_WAVES_PER_CU") ? std::atoi(std::getenv("GMG_EP_WAVES_PER_CU")) : -1;
-    const int wpc = env_wpc >= 0 ? env_wpc : 0;
-    if (wpc > 0 && vgrid > wpc * h->n_cus) return std::max(8, wpc * h->n_cus / 8 * 8);
-    return vgrid;
-}
+// Launch geometry of the entry-parallel block sweep (kernels.hip.hpp::gs_block_ep): one block per workgroup.  (The kernel can also run as
+// persistent workgroups, grid < vgrid; measured in round 4 -- 8 .. 20 workgroups per compute unit -- the same or worse: profiles/r04/b_*.)
+inline int ep_persistent_grid(gmg_handle, int vgrid) { return vgrid; }
 
 // block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
 // One block-hybrid sweep in -> out over blocks [b0, b0 + nb) of a blocked level (in == nullptr: the iterate is the zero vector).
@@ -160,7 +154,7 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
     // (begin_table / ncolors_table: an explicit list of nb blocks instead of a range -- entry-parallel sweep only, which reads
     // nothing but the first row of its block from the table)
     const int* blk_begin = begin_table ? begin_table : l.d_blk_begin + b0;
-    static const bool table_always = std::getenv("GMG_EP_BLOCK_TABLE") != nullptr;      // A/B aid
+    constexpr bool table_always = false;
     const int* blk_ncolors = ncolors_table ? ncolors_table : l.d_blk_ncolors + b0;
     if (nb <= 0) return;
     for (int c0 = 0; c0 < d; c0 += 4) {
@@ -168,14 +162,6 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
         if (l.use_ep) {
             const int vgrid = (nb + 7) / 8 * 8;         // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, vgrid)
             const int grid = ep_persistent_grid(h, vgrid);
-            // (a blocked level 0 relaxes its updates: gmg_config::fine_block_omega)
-            const bool relax = &l == &h->lv[0] && h->cfg.fine_block_omega != 1.0;
-            if (relax) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D, true>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
-                                                  ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
-                                                  Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                                  out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid, out_il, (T)h->cfg.fine_block_omega));
-            } else
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
                                               ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
                                               Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
@@ -231,8 +217,7 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
 // (begin_table / nb_list: an explicit list of blocks -- a rank's blocks of a partitioned level -- instead of all of them)
 template <class T>
 bool launch_residual_delta(gmg_handle h, Level& l, int d, T* r, const int* begin_table = nullptr, int nb_list = 0) {
-    static const bool off = std::getenv("GMG_NO_DELTA_RESIDUAL") != nullptr;      // A/B aid
-    if (off || !l.use_ep || !h->sweep_prev_valid || h->cfg.smoother == GMG_SMOOTHER_JACOBI) return false;
+    if (!l.use_ep || !h->sweep_prev_valid || h->cfg.smoother == GMG_SMOOTHER_JACOBI) return false;
     h->sweep_prev_valid = false;
     const int ld = l.n_pad, nb = begin_table ? nb_list : l.ord.n_blocks();
     if (nb <= 0) return true;
@@ -596,10 +581,10 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         const bool from_zero = k > 0 && smooth_from_zero_ok(h, l, h->cfg.pre_iters);      // eps.setZero (:1072-1073) folded into the first sweep
         if (k > 0 && !from_zero) (void)hipMemsetAsync(Prec<T>::x(l), 0, sizeof(T) * (size_t)l.n_pad * d, h->stream);
         // level 0, fp64: the last colour launch of the pre-smoothing also writes the residual of its rows (fold_residual)
-        static const bool no_fold = std::getenv("GMG_NO_NORM_FOLD") != nullptr;
+        constexpr bool no_fold = false;
         // d = 2 .. 4: the level-0 residual is written as an INTERLEAVED multi-vector (n x d row-major) -- only the restriction reads it, and a
-        // gathered child then costs one cache line instead of d (GMG_NO_INTERLEAVE: A/B aid)
-        static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
+        // gathered child then costs one cache line instead of d
+        constexpr bool no_il = false;
         const bool il = k == 0 && d > 1 && d <= 4 && !no_il && l.Aoff.lpr == 1;
         h->il_r0 = il;
         if (k == 0 && sizeof(T) == 8 && !no_fold) h->fuse_res_out = h->lv[0].r;
@@ -629,7 +614,7 @@ void enqueue_up(gmg_handle h, int d, int k0 = 0) {
         h->il_sweep_done = false;
         const T* src = il ? Prec<T>::r(h->lv[k + 1]) : Prec<T>::x(h->lv[k + 1]);
         launch_prolong_add<T>(h, l, h->lv[k + 1], d, src, Prec<T>::x(l), il);     // :1082
-        static const bool no_il = std::getenv("GMG_NO_INTERLEAVE") != nullptr;
+        constexpr bool no_il = false;
         if (k == 1 && k0 == 0 && d > 1 && d <= 4 && !no_il && h->cfg.post_iters > 0 && l.ord.blocked && l.use_ep && h->cfg.smoother != GMG_SMOOTHER_JACOBI)
             h->il_sweep_out = (void*)Prec<T>::r(l);
         launch_smooth<T>(h, l, d, h->cfg.post_iters);                                                // :1085
@@ -684,11 +669,11 @@ struct HelperScope {
     gmg_handle h;
     // cols: right-hand sides of the solves to come (their (part, column) jobs are independent: up to 8 threads have work with d = 3)
     explicit HelperScope(gmg_handle hh, int cols = 1) : h(hh) {
-        static const int env_threads = std::getenv("GMG_LDLT_THREADS") ? std::atoi(std::getenv("GMG_LDLT_THREADS")) : 0;
+        const int env_threads = EnvSwitches::get().ldlt_threads;
         // (every rank of a multi-GPU job keeps its team busy -- and this thread polls -- on the CPUs the job may use: a rank's team
         // is sized to its share of them (cpu_budget() divides by LOCAL_WORLD_SIZE) minus one CPU of slack, a throttled spinning
         // thread costs far more than it saves; ranks started without that variable are counted through the handle's world size)
-        const int ranks = (h->dist_ready && !std::getenv("LOCAL_WORLD_SIZE")) ? std::max(1, h->world) : 1;
+        const int ranks = (h->dist_ready && EnvSwitches::get().local_world <= 1) ? std::max(1, h->world) : 1;
         const int share = cpu_budget() / ranks;
         int threads = std::min(std::min(h->coarse.parts() * std::max(1, std::min(cols, 4)), 8), share - 1);
         if (env_threads > 0) threads = std::min(threads, env_threads);
@@ -736,7 +721,7 @@ int coarse_host_begin(gmg_handle h, int d) {
     if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
     if (polled(h)) {
         hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1]);
-        static const bool gate_off = std::getenv("GMG_NO_STREAM_GATE") != nullptr;      // A/B aid (scripts/coarse_host_time.py)
+        const bool gate_off = h->cfg.stream_gate == 0;      // gmg_config::stream_gate
         // The gate is only used once this handle has SEEN a published right-hand side arrive while its stream was still busy: wait_flag's
         // safety net (an idle stream implies visible data) cannot fire behind a gate the host itself has to open, so on a host that does
         // not see in-flight device writes a gated first contact would spin for ever.  The first coarse solve of a handle is ungated.
@@ -826,7 +811,7 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
     const int nt = norm_type < 0 ? 9 : norm_type;
     constexpr bool mixed = sizeof(T) == 4;
     // the residual check's sums over the rows of the last colour come out of the last colour launch of the post-smoothing
-    static const bool no_fold = std::getenv("GMG_NO_NORM_FOLD") != nullptr;      // A/B aid
+    constexpr bool no_fold = false;
     const bool foldable = !mixed && !no_fold && norm_type >= 0 && h->cfg.post_iters > 0 && h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS && !h->lv[0].ord.blocked;
     // mixed precision: the fp32 cycle starts from a zero guess on the defect b32 = b - A x (already in place), its
     // result is added to the fp64 iterate, and the new defect + its norms are formed in one fp64 pass

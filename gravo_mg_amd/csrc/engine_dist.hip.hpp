@@ -261,8 +261,8 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     HIPCHK(hipMemsetAsync(p->flags, 0, sizeof(unsigned long long) * 64 * (size_t)world, h->stream));
     HIPCHK(hipMalloc((void**)&p->d_err, sizeof(int)));
     HIPCHK(hipMemsetAsync(p->d_err, 0, sizeof(int), h->stream));
-    if (const char* ts = std::getenv("GMG_P2P_TIMEOUT_S")) {
-        const double sec = std::atof(ts);
+    {
+        const double sec = EnvSwitches::get().p2p_timeout_s;      // GMG_P2P_TIMEOUT_S
         if (sec > 0.0) { const unsigned long long ticks = (unsigned long long)(sec * 1e8); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gmgk::g_p2p_timeout_ticks), &ticks, sizeof(ticks))); }
     }
     HIPCHK(hipMalloc((void**)&p->d_sums, sizeof(double) * 4 * d));

@@ -145,7 +145,6 @@ int choose_base_order(gmg_handle h, const DevCsr& dA, int n) {
     h->base_order_choice = 0;
     h->timing["base_order_score_cluster"] = h->timing["base_order_score_bfs"] = h->timing["base_order_choice"] = 0.0;
     if ((int)h->bfs_order.size() != n || (int)h->cluster_order.size() != n) { h->base_order_choice = (int)h->bfs_order.size() == n ? 1 : 0; return GMG_OK; }
-    if (const char* e = std::getenv("GMG_BASE_ORDER")) { h->base_order_choice = std::atoi(e) == 1 ? 1 : 0; return GMG_OK; }      // A/B aid
     int rc;
     if ((rc = ensure_device_order(h, h->cluster_order, &h->d_cluster_order, &h->d_cluster_inv)) || (rc = ensure_device_order(h, h->bfs_order, &h->d_bfs_order, &h->d_bfs_inv))) return rc;
     DevTmp<unsigned long long> acc;
@@ -230,7 +229,7 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
         }
         return GMG_OK;
     }
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;      // synchronising phase timers on stderr
+    const bool trace = EnvSwitches::get().trace_setup;      // synchronising phase timers on stderr
     auto tph = clk::now();
     auto phase = [&](const char* what) {
         if (!trace) return;
@@ -289,7 +288,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     const int L = h->L;
     Level& l = h->lv[k];
     int rc;
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;      // synchronising phase timers on stderr
+    const bool trace = EnvSwitches::get().trace_setup;      // synchronising phase timers on stderr
     auto tph = clk::now();
     auto phase = [&](const char* what) {
         if (!trace) return;
@@ -436,7 +435,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) return rc;
         l.P.nnz_real = h->U[k].nnz();
     }
-    // ---- 16-bit column codes of level 0's operator and transfers for the fine-level kernels (kernels.hip.hpp; GMG_NO_COL16: A/B aid): 2 of
+    // ---- 16-bit column codes of level 0's operator and transfers for the fine-level kernels (kernels.hip.hpp; gmg_config::fine_col16 = 0: 32-bit indices only): 2 of
     // the 12 bytes of an entry less to read per launch.  First with 8 windows of 8 192 columns per slice (meshes); an operator that
     // leaves more than an eighth of its slices uncovered that way (kNN graphs: the 64 rows of a slice reach into every colour class)
     // is coded again with 32 windows of 2 048, and keeps its 32-bit indices alone if that does not cover it either.
@@ -444,8 +443,8 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     const char* c16_keys[3] = {"col16_l0", "col16_R_l0", "col16_P_l0"};
     int c16_failed[6] = {0, 0, 0, 0, 0, 0};      // per operator: uncovered slices, 1 + index of the last of them
     DevTmp<int> d_c16;
-    const bool c16 = k == 0 && !std::getenv("GMG_NO_COL16");      // (a blocked level 0 too: its residual-check and transfer kernels are the colour-major level's)
-    const int c16_test_fail = std::getenv("GMG_COL16_TEST_FAIL") ? std::atoi(std::getenv("GMG_COL16_TEST_FAIL")) : 0;      // tests: N > 0 every N-th slice "uncovered", N < 0 the first -N
+    const bool c16 = k == 0 && h->cfg.fine_col16 != 0;      // (a blocked level 0 too: its residual-check and transfer kernels are the colour-major level's)
+    const int c16_test_fail = h->dbg_col16_uncovered;         // gmg_debug_set (gravomg_hip_internal.h): N > 0 every N-th slice "uncovered", N < 0 the first -N
     auto c16_launch = [&](int i, int nw) -> int {
         DevSell& op = *c16_ops[i];
         if (op.win_base) { (void)dev_free(op.win_base); op.win_base = nullptr; }

@@ -149,6 +149,7 @@ struct DistP2P;
 struct gmg_solver_s {
     DevPool pool;
     DistP2P* p2p = nullptr;              // engine-driven multi-GPU cycle (engine_dist.hip.hpp)
+    int dbg_col16_uncovered = 0;         // gmg_debug_set("col16_uncovered"): set-up fault injection of the tests (gravomg_hip_internal.h)
     gmg_config cfg;
     std::string err;
     bool has_device = false;
@@ -275,8 +276,7 @@ static int ensure_bounce(gmg_handle h) {
 }
 
 static void threaded_copy_bytes(void* dst, const void* src, size_t bytes, int threads) {
-    static const int cap = [] { const char* e = std::getenv("GMG_BOUNCE_THREADS"); return e ? std::max(1, std::atoi(e)) : 16; }();
-    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, cap)), bytes / ((size_t)1 << 20) + 1);
+    const int T = (int)std::min<size_t>(std::max(1, std::min(threads, 16)), bytes / ((size_t)1 << 20) + 1);
     // small copies stay on the calling thread: a range handed to the worker pool queues behind whatever the set-up's
     // ordering tasks have submitted (1 MB took 2 ms that way, 0.1 ms inline)
     if (T <= 1 || bytes < ((size_t)8 << 20)) { std::memcpy(dst, src, bytes); return; }
@@ -292,7 +292,7 @@ static int h2d(gmg_handle h, void* dst, const void* src, size_t bytes) {
     if (bytes < kBounceMin) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return GMG_OK; }
     int rc = ensure_bounce(h);
     if (rc) return rc;
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    const bool trace = EnvSwitches::get().trace_setup;
     double t_wait = 0, t_copy = 0, t_issue = 0;
     auto t_all = clk::now();
     for (size_t off = 0; off < bytes; off += kBounceBytes) {
@@ -412,7 +412,7 @@ void drop_device_transfers(gmg_handle h) {
 // Patches of every blocked level k >= 1 (see coarse_point_graph): depend on the hierarchy and on block_rows only.
 void build_patches(gmg_handle h) {
     const int L = h->L;
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    const bool trace = EnvSwitches::get().trace_setup;
     auto t_bp = clk::now();
     auto tr = [&](const char* what, clk::time_point t0) { if (trace) std::fprintf(stderr, "[gmg setup] build_patches %-18s %.2f ms (at %.2f)\n", what, ms_since(t0), ms_since(t_bp)); };
     h->patches.assign(L + 1, PatchSet());
@@ -458,7 +458,6 @@ void build_patches(gmg_handle h) {
 // without a cluster order (reorder_fine = 0): make_block_ordering then grows the blocks breadth-first over the operator's graph.
 const PatchSet* level0_patches(gmg_handle h, int n) {
     if (h->patches.empty() || (int)h->cluster_order.size() != n || h->cfg.block_rows <= 0) return nullptr;
-    if (std::getenv("GMG_FINE_BLOCKS_GROWN")) return nullptr;      // A/B aid: blocks grown breadth-first over the operator instead
     PatchSet& p = h->patches[0];
     if (p.valid() && p.n == n) return &p;
     const int br = h->cfg.block_rows, nb = (n + br - 1) / br;
@@ -519,9 +518,8 @@ void drop_system(gmg_handle h) {
     if (h->d_ainv) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
 }
 
-// blocked levels smaller than this use 4 lanes per row (GMG_QUAD_LEVEL_ROWS: measurement aid)
-inline int quad_level_rows() { static const int v = std::getenv("GMG_QUAD_LEVEL_ROWS") ? std::atoi(std::getenv("GMG_QUAD_LEVEL_ROWS")) : 65536; return v; }
-#define kQuadLevelRows quad_level_rows()
+// blocked levels smaller than this use 4 lanes per row (measured in round 4, profiles/r04/d_quad_threshold_ab.txt)
+constexpr int kQuadLevelRows = 65536;
 constexpr int kEpMaxBlockEntries = 6144;        // largest explicit chunk of a block the unpadded sweep keeps in LDS (48 KB of fp64 products)
 constexpr int kEpMaxBlockLower = 3584;          // ... and largest lower chunk (staged as 16-byte records: 56 KB; the launch stays below the 64 KB of dynamic LDS)
 constexpr int kBcsrMaxBlockEntries = 4096;      // largest block the block-CSR sweep stages in LDS (48 KB of fp64 entries)

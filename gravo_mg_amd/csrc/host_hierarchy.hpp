@@ -44,6 +44,7 @@ struct HierarchyOptions {
     bool nested = false;
     int weighting = 0;           // 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST (multigrid_solver.h:48-52)
     bool keep_triangles = false; // the reference's `debug`: keep every level's candidate triangles (allTriangles, multigrid_solver.cpp:281)
+    bool full_clustering = false; // run the Dijkstra clustering sweep (:1015-1056) literally instead of the shortcut that provably equals it (voronoi_dijkstra)
     // Optional accelerator for the per-point parent selection (:291-452) of a level: every fine point is independent there.  Host
     // pointers in, per-point results out; returns false when it did not run (the host loop does the level then).  A point it
     // could not handle comes back with cnt = 255 and is redone by the host routine.  Must produce the host routine's bits.
@@ -173,7 +174,7 @@ public:
             const int nc = (int)sample.size();
             auto t1 = clk::now();
             R.timing["sampling"] += ms(t0, t1);
-            voronoi_dijkstra(P, sample, NB, nbK, D, nearest, EL);                           // :170
+            voronoi_dijkstra(P, sample, NB, nbK, D, nearest, EL, opt.full_clustering);                           // :170
             auto t2 = clk::now();
             R.timing["cluster"] += ms(t1, t2);
 
@@ -485,11 +486,10 @@ private:
     // reference's output by construction (multi-threading or a GPU could only have reproduced that no-op faster).  The one
     // assumption is the sampler's early exit: it stops at a row's first -1 where the sweep skips over it, so a sample whose row
     // holds a neighbour BEHIND a -1 (the reference's tables never do: rows are padded at the end) makes the full sweep run.
-    // GMG_HIERARCHY_FULL_DIJKSTRA=1 forces it (tests/test_hierarchy_restatement.py compares the two).
+    // gmg_hierarchy_options::full_clustering forces it (tests/test_hierarchy_restatement.py compares the two).
     static void voronoi_dijkstra(detail::View<V3> P, const std::vector<int>& src, detail::View<int> NB, int K,
-                                 std::vector<double>& D, std::vector<int>& nearest, const ValueVec& EL) {
+                                 std::vector<double>& D, std::vector<int>& nearest, const ValueVec& EL, bool full) {
         std::priority_queue<detail::HeapItem, std::vector<detail::HeapItem>, std::greater<detail::HeapItem>> heap;
-        bool full = std::getenv("GMG_HIERARCHY_FULL_DIJKSTRA") != nullptr && std::atoi(std::getenv("GMG_HIERARCHY_FULL_DIJKSTRA")) != 0;
         const int ns = (int)src.size();
         std::atomic<int> gaps{0};
         // (one pass over the samples on all threads: each touches three scattered cache lines)

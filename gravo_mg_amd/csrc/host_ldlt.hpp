@@ -540,8 +540,9 @@ public:
 
     long factor_nnz() const { return nnz_l_; }
     static int numeric_threads() {
-        static const int v = [] { const char* e = std::getenv("GMG_LDLT_THREADS"); return e ? std::max(1, std::atoi(e)) : 0; }();
-        return v > 0 ? v : std::max(1, std::min(hw_threads(), 8));
+        // (a SpinTeam takes at most 15 helpers: more than 16 threads would make numeric() rebuild its team on every call)
+        const int v = EnvSwitches::get().ldlt_threads;
+        return std::min(16, v > 0 ? v : std::max(1, std::min(hw_threads(), 8)));
     }
 
     // Read the factor once (one word per cache line): after a factorisation the panels sit in the caches of whichever core
@@ -643,7 +644,6 @@ public:
     void solve_columns_staged(const double* b, size_t ldb, double* x, size_t ldx, int d, double* work, SpinTeam* team) const {
         const int S = (int)stage_groups_.size();
         const size_t nt = scratch_doubles();
-        static const bool split_cols = std::getenv("GMG_LDLT_SPLIT_COLUMNS") != nullptr;      // A/B aid: the parts as (part, column) jobs too
         MultiJob job{this, {}, {}, true, nullptr, 0, d};
         for (int c = 0; c < d; ++c) {
             job.y[c] = work + (size_t)c * n; job.t[c] = scratch_.data() + nt * (size_t)c;
@@ -652,13 +652,13 @@ public:
         }
         for (int st = 0; st < S; ++st) {
             job.groups = stage_groups_[st].data(); job.ngroups = (int)stage_groups_[st].size(); job.forward = true;
-            if (st == 0 && !split_cols) team->run(run_part_cols, &job, job.ngroups);       // (stage 0 = the parts: nothing to take in from earlier stages)
+            if (st == 0) team->run(run_part_cols, &job, job.ngroups);       // (stage 0 = the parts: nothing to take in from earlier stages; one job per part, not per (part, column): measured in round 4)
             else team->run(run_part_multi, &job, job.ngroups * d);
         }
         for (int c = 0; c < d; ++c) for (int j = 0; j < n; ++j) job.y[c][j] /= D_[j];
         for (int st = S - 1; st >= 0; --st) {
             job.groups = stage_groups_[st].data(); job.ngroups = (int)stage_groups_[st].size(); job.forward = false;
-            if (st == 0 && !split_cols) team->run(run_part_cols, &job, job.ngroups);
+            if (st == 0) team->run(run_part_cols, &job, job.ngroups);
             else team->run(run_part_multi, &job, job.ngroups * d);
         }
         for (int c = 0; c < d; ++c) {
@@ -809,7 +809,7 @@ private:
         // lowest common ancestor of consecutive leaves and -1 to parent(i): the weights inside subtree(j) then sum to 1 exactly when j
         // is in T_i.  Walking the columns in order, j is a leaf of T_i iff the previous nonzero of row i lies before first[j], and the
         // common ancestor with the previous leaf is the root of its set in a union-find in which finished columns hang below their
-        // parents.  O(nnz(A) alpha(n)) instead of the O(nnz(L)) row-subtree walk (GMG_LDLT_CHECK_COUNTS=1 runs that walk beside it).
+        // parents.  O(nnz(A) alpha(n)) instead of the O(nnz(L)) row-subtree walk (checked against that walk when it replaced it, round 3).
         std::vector<int> first(n), delta(n, 0), prevnz(n, -1), prevleaf(n, -1), uf(n);
         for (int j = 0; j < n; ++j) { first[j] = j; uf[j] = j; }
         for (int j = 0; j < n; ++j) if (parent[j] >= 0 && first[j] < first[parent[j]]) first[parent[j]] = first[j];
@@ -834,17 +834,6 @@ private:
         }
         for (int j = 0; j < n; ++j) if (parent[j] >= 0) delta[parent[j]] += delta[j];
         for (int j = 0; j < n; ++j) lnz[j] = delta[j] - 1;
-        if (std::getenv("GMG_LDLT_CHECK_COUNTS")) {
-            std::vector<int> flag(n, -1), ref(n, 0), par2(n, -1);
-            for (int k = 0; k < n; ++k) {
-                flag[k] = k;
-                for (int p = Cp_[k]; p < Cp_[k + 1]; ++p) {
-                    int i = Ci_[p];
-                    while (i < k && flag[i] != k) { if (par2[i] < 0) par2[i] = k; ref[i]++; flag[i] = k; i = par2[i]; }
-                }
-            }
-            if (ref != lnz || par2 != parent) { std::fprintf(stderr, "[gmg ldlt] column counts / tree differ from the row-subtree walk\n"); std::abort(); }
-        }
     }
 
     void symbolic(const Compressed& A) {
@@ -987,7 +976,6 @@ private:
             if (r > 0) parent[s] = sn_of_[rows_[rows_ptr_[s]]];
         }
         parts_ = (int)std::max<long>(2, std::min<long>(kMaxParts, (all + kPartWork / 2) / kPartWork));
-        if (const char* e = std::getenv("GMG_LDLT_PARTS")) parts_ = std::max(2, std::min(kMaxParts, std::atoi(e)));      // measurement aid
         std::vector<long> sub(work);
         for (int s = 0; s < ns_; ++s) if (parent[s] >= 0) { sub[parent[s]] += sub[s]; kids[parent[s]].push_back(s); }
         std::vector<int> cand;
@@ -1192,7 +1180,7 @@ private:
         return v;
     }
     static bool has_avx512() {
-        static const bool v = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && std::getenv("GMG_NO_AVX512") == nullptr; }();
+        static const bool v = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq"); }();
         return v;
     }
 #endif
@@ -1383,7 +1371,7 @@ private:
         const bool avx = has_avx2();
         const int T = numeric_threads();
         std::atomic<int> failed{0};
-        static const bool trace = std::getenv("GMG_LDLT_TRACE") != nullptr;
+        const bool trace = EnvSwitches::get().trace_ldlt;
         auto tr0 = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) { if (!trace) return; auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[gmg ldlt] numeric %-8s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tr0).count()); tr0 = now; };
         lap("zero");

@@ -268,7 +268,7 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    const bool trace = EnvSwitches::get().trace_setup;
     auto tph = std::chrono::steady_clock::now();
     auto phase = [&](const char* what) {
         if (!trace) return;
@@ -427,7 +427,7 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
     const int n = A.n_outer;
     o.n = n;
     o.blocked = true;
-    static const bool trace = std::getenv("GMG_SETUP_TRACE") != nullptr;
+    const bool trace = EnvSwitches::get().trace_setup;
     auto tph = std::chrono::steady_clock::now();
     auto phase = [&](const char* what) {
         if (!trace) return;

@@ -79,6 +79,38 @@ struct Compressed {
     }
 };
 
+// ---- the library's environment switches: ALL of them, read once per process (first use), none on a per-solve path ------------
+//   GMG_HOST_THREADS=N      host threads of this process (default: the CPUs it may use, see cpu_budget)
+//   LOCAL_WORLD_SIZE=N      set by torch.distributed.run: ranks sharing the node; a rank takes 1/N of the CPUs
+//   GMG_LDLT_THREADS=N      threads of the coarsest LDL^T (factorisation and back-substitution teams); 1 = no team
+//   GMG_TRACE=setup,ldlt,ctor   phase timers of gmg_set_system / the host factorisation / the drop-in constructor on stderr
+//   GMG_POLL=0              wait for device results with copy + hipStreamSynchronize instead of polling pinned memory
+//   GMG_HIERARCHY_DEVICE=0  hierarchy construction on the host only
+//   GMG_P2P_TIMEOUT_S=S     device-side time-out of a peer-to-peer exchange (default 4 s)
+//   GMG_SEGV_BACKTRACE=1    native stack of a fatal signal on stderr (installed at load time, engine.hip)
+// Everything else that used to be an A/B switch is either a gmg_config field or gone.
+struct EnvSwitches {
+    int host_threads = 0, local_world = 0, ldlt_threads = 0;
+    bool trace_setup = false, trace_ldlt = false, trace_ctor = false, poll = true, hierarchy_device = true, segv_backtrace = false;
+    double p2p_timeout_s = 0.0;
+    static const EnvSwitches& get() {
+        static const EnvSwitches v = [] {
+            EnvSwitches e;
+            auto num = [](const char* name) { const char* s = std::getenv(name); return s ? std::atof(s) : -1.0; };
+            if (num("GMG_HOST_THREADS") > 0) e.host_threads = (int)num("GMG_HOST_THREADS");
+            if (num("LOCAL_WORLD_SIZE") > 1) e.local_world = (int)num("LOCAL_WORLD_SIZE");
+            if (num("GMG_LDLT_THREADS") > 0) e.ldlt_threads = (int)num("GMG_LDLT_THREADS");
+            if (const char* t = std::getenv("GMG_TRACE")) { const std::string s(t); e.trace_setup = s.find("setup") != std::string::npos; e.trace_ldlt = s.find("ldlt") != std::string::npos; e.trace_ctor = s.find("ctor") != std::string::npos; }
+            e.poll = num("GMG_POLL") != 0.0;
+            e.hierarchy_device = num("GMG_HIERARCHY_DEVICE") != 0.0;
+            if (num("GMG_P2P_TIMEOUT_S") > 0) e.p2p_timeout_s = num("GMG_P2P_TIMEOUT_S");
+            e.segv_backtrace = num("GMG_SEGV_BACKTRACE") > 0;
+            return e;
+        }();
+        return v;
+    }
+};
+
 // CPUs this process may actually use: hardware threads, cut down to the scheduler affinity mask and to the cgroup CPU
 // quota.  A container on a 256-thread host with a 16-CPU quota reports 256 hardware threads; running 64-128 threads
 // there exhausts the quota within a period and the kernel then stalls the WHOLE process for tens of milliseconds
@@ -127,8 +159,9 @@ inline int cpu_budget() {
         // one process per GPU: the ranks of a node share its CPUs (torchrun exports LOCAL_WORLD_SIZE); every rank sizes its worker
         // pool, its staging threads and its back-substitution team to ITS share -- 8 ranks x 16 threads on a 16-CPU quota is the
         // throttling case above
-        if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) { const int lw = std::atoi(e); if (lw > 1) t = std::max<long>(1, t / lw); }
-        if (const char* e = std::getenv("GMG_HOST_THREADS")) { const int o = std::atoi(e); if (o > 0) t = o; }
+        const EnvSwitches& env = EnvSwitches::get();
+        if (env.local_world > 1) t = std::max<long>(1, t / env.local_world);
+        if (env.host_threads > 0) t = env.host_threads;
         return (int)std::max<long>(1, t);
     }();
     return v;

@@ -584,17 +584,14 @@ template <class T> inline size_t ep_lds_bytes(int D, int cap_e, int cap_l) {
 // results are bitwise those of the round-2 kernel.
 // `vgrid` > gridDim.x: persistent workgroups -- workgroup w sweeps the virtual blocks w, w + gridDim.x, ... (the XCD-aware map is
 // applied to the virtual index, so a workgroup's blocks stay on its XCD's part of the level).
-// RELAX (a blocked level 0, gmg_config::fine_block_omega != 1): every row's update is relaxed, x_i <- x_i + omega (x_i^GS - x_i) -- successive
-// over-relaxation inside the block, in matrix form x_out = x_in + (D / omega + L_block)^-1 (b - A x_in).  A separate instantiation: the levels
-// that do not relax keep their registers and their instruction stream.
-template <class T, int D, bool RELAX = false>
+template <class T, int D>
 __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
                                                   const unsigned char* __restrict__ row_color, const int* __restrict__ l_ptr,
                                                   const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
                                                   const int* __restrict__ e_ptr, const int* __restrict__ e_col,
                                                   const T* __restrict__ e_val, const T* __restrict__ diag, const T* __restrict__ b,
                                                   const T* __restrict__ x_in, T* __restrict__ x_out, int ld, int cap_e, int cap_l, int n_blocks, int blk0,
-                                                  int vgrid, T* __restrict__ x_out_i = nullptr, T omega = (T)1.0) {
+                                                  int vgrid, T* __restrict__ x_out_i = nullptr) {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);                            // D x 64: the block's new x
     typedef typename EpRec<T>::type Rec;
@@ -642,12 +639,6 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     T rhs[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) { rhs[c] = b[row + (int64_t)c * ld]; xs[c * 64 + lane] = (T)0.0; }      // (zero: padded register slots multiply x[0] by 0)
-    T xo[RELAX ? D : 1];                                               // RELAX: the row's own previous value
-    if constexpr (RELAX) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) xo[c] = x_in ? x_in[row + (int64_t)c * ld] : (T)0.0;
-    }
-    auto relaxed = [&](T g, int c) -> T { if constexpr (RELAX) return xo[c] + omega * (g - xo[c]); else { (void)c; return g; } };
     // ---- E: explicit part, one right-hand side at a time through the product buffer
     if (nE > 0) {
 #pragma unroll
@@ -721,7 +712,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     // point at earlier colours only)
     if (!__builtin_amdgcn_ballot_w64(mycolor == 0 && nlow > 0)) {
 #pragma unroll
-        for (int c = 0; c < D; ++c) xs[c * 64 + lane] = relaxed((rhs[c] - (T)0.0) * dg, c);
+        for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - (T)0.0) * dg;
         col0 = 1;
         __syncthreads();
     }
@@ -752,7 +743,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
                 }
             }
 #pragma unroll
-            for (int c = 0; c < D; ++c) xs[c * 64 + lane] = relaxed((rhs[c] - s_[c]) * dg, c);
+            for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - s_[c]) * dg;
         }
         __syncthreads();
     }

@@ -13,6 +13,8 @@
 
 #include <set>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <tuple>
@@ -27,6 +29,9 @@ enum Sampling { FASTDISK = 0, POISSONDISK = 1, FPS = 2, RANDOM = 3, MIS = 4 };
 enum Weighting { BARYCENTRIC = 0, UNIFORM = 1, INVDIST = 2 };
 
 namespace MGBS {
+
+// environment GMG_TRACE=ctor (the library's one trace switch, csrc/host_sparse.hpp::EnvSwitches): phases of the construction on stderr
+inline bool ctorTrace() { static const bool v = [] { const char* t = std::getenv("GMG_TRACE"); return t && std::strstr(t, "ctor"); }(); return v; }
 
 struct SparseMatrix {
     int rows_ = 0, cols_ = 0;
@@ -141,9 +146,14 @@ public:
        C-ABI handle (owned by this object) and a counter that changes whenever the device layout was rebuilt, so that a caller can
        drive the engine-driven multi-GPU cycle (gmg_p2p_*, include/gravomg_hip.h) on it.  Returns a gmg status. */
     int prepareSystem(const SparseMatrix& LHS, gmg_handle* handle, long* generation);
+#ifdef GMG_TESTING
+    int testReportDiverged = 0;      // test build of the pybind module only (tests/_native/): the next N default-engine solves report GMG_DIVERGED
+#endif
 
 private:
     int ensureEngine();
+    bool fallbackAllowed() const;
+    uint64_t configKey() const;
     int ensureSystem(const SparseMatrix& LHS);
     gmg_handle engine_ = nullptr;
     std::vector<std::pair<uint64_t, uint64_t>> uploadedU_;     // digests of what the engine holds
@@ -165,7 +175,7 @@ private:
         bool systemReady = false;
     } parked_;
     void swapParked();
-    std::set<std::pair<uint64_t, uint64_t>> needsExactGs_;     // systems (content digests) whose default iteration did not contract: straight to the fallback next time
+    std::set<std::pair<std::pair<uint64_t, uint64_t>, uint64_t>> needsExactGs_;     // (system content digest, configKey()) pairs whose default iteration did not contract: straight to the fallback next time
     std::string err_;
 };
 

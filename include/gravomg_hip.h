@@ -103,10 +103,12 @@ typedef struct {
                               operators (7 entries per row, 4-7 colours) keep the over-relaxed multicolour sweep, Bilaplacians fail the
                               sign test.  The blocks are runs of 64 points of the hierarchy's cluster order.  0: level 0 is blocked only
                               by block_from_level = 0.  The multi-GPU path (gmg_p2p_*) needs the colour-major level 0: set 0 there */
-    double fine_block_omega; /* relaxation factor of the block sweep of a BLOCKED level 0 (block_fine / block_from_level = 0 with the 64-row entry-parallel
-                              sweep): x_i <- x_i + omega (x_i^GS - x_i) inside the block, i.e. x_out = x_in + (D / omega + L_block)^-1 (b - A x_in); what
-                              gs_omega is to the colour-major level 0.  1.0 (default): the plain block sweep, a regular splitting of a Stieltjes matrix.  Above 1 nothing guarantees convergence any more: measured on kNN clouds, 1.1-1.2 saves
-                              1-3 of 11-25 cycles, 1.3 diverges at 2 M points, 1.4 everywhere (an opt-in knob).  Must lie in (0, 2) */
+    int fine_col16;        /* 1 (default): level 0 keeps, beside the int32 column indices, 16-bit column codes (window of the slice + offset, two to
+                              a word) that its kernels read instead: 2 of an entry's 12 bytes less per launch, the same columns in the same order
+                              (DESIGN.md section 3); 0: 32-bit indices only */
+    int stream_gate;       /* 1 (default): the way up of a V-cycle is enqueued BEFORE the host solves the coarsest system, parked behind a stream
+                              wait on a word the host writes after its back-substitution.  0: enqueue it afterwards -- for applications that issue
+                              device-wide synchronisations (hipDeviceSynchronize, hipFree ...) from OTHER threads while a solve is in flight */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -151,11 +153,6 @@ int gmg_get_level_ordering(gmg_handle h, int k, int* new2old, int* color_begin);
 /* Blocked levels (block-hybrid Gauss-Seidel): *n_blocks (0 if the level is colour-major), blk_begin[n_blocks+1]
  * (device rows) and row_color[n_pad] (colour of a row inside its block).  Output pointers may be NULL. */
 int gmg_get_level_blocks(gmg_handle h, int k, int* n_blocks, int* blk_begin, unsigned char* row_color);
-/* Test access to the device-resident SELL layouts of level k: which = 0 A (off-diagonal part), 1 A_in, 2 A_out,
- * 3 P (U_k), 4 R (U_k^T).  info[0..3] = n_slices, lanes per row, stored entries, has row_of.  Copy-out pointers may be
- * NULL; col receives 32-bit columns also for the 16-bit A_in; diag (which = 0 only) the level's diagonal. */
-int gmg_debug_sell_info(gmg_handle h, int k, int which, int64_t* info);
-int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int* col, double* val, int* row_of, double* diag);
 /* Named timers in ms, same keys as the reference's solverTiming (multigrid_solver.cpp:1394,1403,1445-1448):
  * "reduction", "coarsest_solve", "cycles", "solver_total", "iterations", "residue"; plus "upload",
  * "coarse_host_ms" (host back-substitutions inside the cycles). */
@@ -306,13 +303,16 @@ typedef struct {
     int sampling;          /* Sampling enum (multigrid_solver.h:40-46); only 0 = FASTDISK is supported */
     int weighting;         /* Weighting enum (multigrid_solver.h:48-52): 0 BARYCENTRIC, 1 UNIFORM, 2 INVDIST */
     int debug;             /* the reference's `debug` member: keep every level's candidate triangles (allTriangles, multigrid_solver.cpp:281) */
+    int full_clustering;   /* 0 (default): the Dijkstra clustering sweep (multigrid_solver.cpp:1015-1056) is replaced by what it provably does after the
+                              FASTDISK sampler -- resetting the samples (csrc/host_hierarchy.hpp::voronoi_dijkstra); 1: run the sweep as written
+                              (same hierarchy bit for bit; the cross-check of tests/test_hierarchy_restatement.py) */
 } gmg_hierarchy_options;
 
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o);
 /* Replaces MGBS::MultigridSolver::buildHierarchy / constructProlongation
  * (gravomg/src/multigrid_solver.cpp:43-60, 62-469).  pos: n x 3 row-major; neigh: n x K row-major,
  * padded with -1 (gravomg_bindings/src/cpp/core.cpp:15-18).  Works without a GPU; with one, the per-point parent selection
- * (:291-452) of levels with >= 200 000 points runs on it -- same prolongations, bit for bit (GMG_HIERARCHY_DEVICE=0: host only). */
+ * (:291-452) of levels with >= 200 000 points runs on it -- same prolongations, bit for bit (environment GMG_HIERARCHY_DEVICE=0: host only). */
 int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt,
                         gmg_hierarchy* out);
 void gmg_hierarchy_destroy(gmg_hierarchy hh);
@@ -348,26 +348,7 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
  * block-hybrid smoother's levels -- now instead of inside the first gmg_set_system.  Idempotent. */
 int gmg_finalize_hierarchy(gmg_handle h);
 
-/* Host-only Galerkin product Ac = U^T A U (CSC in / CSC out, caller sizes the output with the first call:
- * pass colptr_out only to get nnz in colptr_out[n_coarse]).  Exposed for the RAP parity tests. */
-int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const double* a_val,
-                      int n_coarse, const int* u_colptr, const int* u_rowidx, const double* u_val,
-                      int* c_colptr, int* c_rowidx, double* c_val);
 
-/* Host-only view of the device layout planner (colouring / block growing / SELL-64), for CPU tests of the
- * host logic.  mode 0: colour-major ordering (exact multicolour Gauss-Seidel), mode 1: block ordering
- * (block-hybrid Gauss-Seidel, `block_rows` rows per block).  In mode 0 `block_rows` is the colour-class
- * alignment (the config's row_align; 0 = 64).  info[0..5] = n_pad, n_colors, n_blocks,
- * stored SELL entries (off-diagonal), real off-diagonal entries, 0.  Output pointers may be NULL: call once
- * with NULL outputs for the sizes, then with new2old / row_color of n_pad entries, color_begin of
- * n_colors + 1 and blk_begin of n_blocks + 1 entries. */
-int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma,
-                        int64_t* info, int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color);
-/* Host-only view of the rule behind gmg_config::block_fine (engine_setup.hip.hpp::fine_level_blocked), for CPU tests: would level 0 of this
- * system run the block-hybrid sweep under the DEFAULT configuration, given a hierarchy?  *blocked = 1: at least 9 stored entries per row on
- * average, every diagonal entry positive, no positive off-diagonal entry (a Stieltjes matrix, for the symmetric positive definite systems
- * the solver takes: the block sweep is a regular splitting).  reason (optional): 0 chosen, 1 rows too short, 2 signs. */
-int gmg_host_fine_block_rule(int n, const int* colptr, const int* rowidx, const double* val, int* blocked, int* reason);
 /* Host-only: x = A^{-1} b with the coarsest-level solver (minimum-degree + sparse LDL^T, host_ldlt.hpp),
  * b/x column-major n x d.  Returns GMG_ERR_NUMERIC on a zero pivot.  factor_nnz (optional) = nnz(L). */
 int gmg_host_ldlt_solve(int n, const int* colptr, const int* rowidx, const double* val, const double* b, int d, double* x,

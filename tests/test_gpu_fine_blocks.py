@@ -81,14 +81,12 @@ def test_blocks_are_compact_patches(cabi):
     assert inside >= 0.45
 
 
-@pytest.mark.parametrize("omega", [1.0, 1.2], ids=["plain", "relaxed"])
 @pytest.mark.parametrize("d", [1, 3])
-def test_fine_level_sweep_matches_matrix_form(cabi, oracle, d, omega):
-    """One sweep of the blocked level 0 == x + T^-1 (b - A x), T = D / omega + strict lower triangle of A restricted to the block diagonal in
-    device order (residual from the oracle, T^-1 from scipy); also from the zero iterate and for two sweeps.  omega = gmg_config::fine_block_omega:
-    1 (default) is the plain block sweep; an opt-in omega relaxes every update inside the block (gs_block_ep<.., RELAX>)."""
+def test_fine_level_sweep_matches_matrix_form(cabi, oracle, d):
+    """One sweep of the blocked level 0 == x + T^-1 (b - A x), T = D + strict lower triangle of A restricted to the block diagonal in
+    device order (residual from the oracle, T^-1 from scipy); also from the zero iterate and for two sweeps."""
     P = _cloud()
-    e = _engine(cabi, P, fine_block_omega=omega)
+    e = _engine(cabi, P)
     A = sp.csr_matrix(P.lhs)
     n2o, _ = e.level_ordering(0)
     bb, _ = e.level_blocks(0)
@@ -97,7 +95,7 @@ def test_fine_level_sweep_matches_matrix_form(cabi, oracle, d, omega):
     order = n2o[real]
     Ap = A[order][:, order].tocoo()
     keep = (blk[Ap.row] == blk[Ap.col]) & (Ap.col <= Ap.row)
-    data = Ap.data[keep].copy(); data[Ap.row[keep] == Ap.col[keep]] /= omega
+    data = Ap.data[keep].copy()
     T = sp.csr_matrix((data, (Ap.row[keep], Ap.col[keep])), shape=Ap.shape)
     rng = np.random.default_rng(5)
     b = rng.standard_normal((A.shape[0], d)); x0 = rng.standard_normal((A.shape[0], d))
@@ -111,11 +109,10 @@ def test_fine_level_sweep_matches_matrix_form(cabi, oracle, d, omega):
             assert np.linalg.norm(got - x) <= 1e-12 * np.linalg.norm(x), (sweeps, np.linalg.norm(got - x) / np.linalg.norm(x))
 
 
-@pytest.mark.parametrize("omega", [1.0, 1.2], ids=["plain", "relaxed"])
-def test_cycles_match_the_model_and_the_solve_the_reference_algorithm(cabi, oracle, omega):
+def test_cycles_match_the_model_and_the_solve_the_reference_algorithm(cabi, oracle):
     from tests.vcycle_model import VcycleModel
     P = _cloud(12_000, lower_bound=150)
-    e = _engine(cabi, P, fine_block_omega=omega)
+    e = _engine(cabi, P)
     assert e.level_blocks(0) is not None and e.num_levels >= 2
     M = VcycleModel(e, P.U, P.mass, P.lhs, oracle, e.gs_omega)
     nA = spla.norm(P.lhs)

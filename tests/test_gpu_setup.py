@@ -345,7 +345,7 @@ def test_base_order_of_a_reordered_level_follows_the_gather_score(cabi):
 def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi, case, test_fail):
     """Level 0 stores its column indices a second time as 16-bit codes (window of the slice + offset inside it, gmgs::compress_cols)
     and the fine-level kernels read those: the same columns in the same order, so every iterate is bit-identical to the 32-bit path
-    (GMG_NO_COL16), also after a values-only refresh, for d = 3 and in the fp32 inner cycle."""
+    (gmg_config::fine_col16 = 0), also after a values-only refresh, for d = 3 and in the fp32 inner cycle."""
     import os
     P = {"torus": lambda: problems.torus_problem(96, 80, "poisson", 30),
          "random-order": lambda: problems.torus_problem(64, 60, "poisson", 40, order="random"),
@@ -353,15 +353,10 @@ def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi
          "smoothing-d3": lambda: problems.torus_problem(64, 60, "smoothing", 60)}[case]()
 
     def run(no16):
-        if no16:
-            os.environ["GMG_NO_COL16"] = "1"
-        elif test_fail:                          # pretend slices are not covered by their windows: every N-th (flagged one by one), or the first -N (prefix)
-            os.environ["GMG_COL16_TEST_FAIL"] = str(test_fail)
-        try:
-            e = cabi.Engine()
-            e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
-        finally:
-            os.environ.pop("GMG_NO_COL16", None); os.environ.pop("GMG_COL16_TEST_FAIL", None)
+        e = cabi.Engine(fine_col16=not no16)
+        if not no16 and test_fail:               # pretend slices are not covered by their windows: every N-th (flagged one by one), or the first -N (prefix)
+            e.debug_set("col16_uncovered", test_fail)
+        e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
         return e
     a, b = run(False), run(True)
     assert b.timing("col16_l0") == 0.0

@@ -73,7 +73,7 @@ def test_fine_order_is_the_breadth_first_order_of_the_point_graph(cabi):
 def test_clustering_sweep_after_the_disk_sampler_only_resets_the_samples(cabi, kind, ratio):
     """multigrid_solver.cpp:1015-1056 after :975-1013: the multi-source Dijkstra starts from distances the sampler seeded with
     exactly the candidates the sweep would offer, so it cannot lower anything (argument in host_hierarchy.hpp::voronoi_dijkstra) and
-    the builder skips the heap.  GMG_HIERARCHY_FULL_DIJKSTRA=1 runs the sweep as the reference writes it: same owners for every
+    the builder skips the heap.  gmg_hierarchy_options::full_clustering runs the sweep as the reference writes it: same owners for every
     point of every level, same hierarchy bit for bit -- on regular, randomly numbered, irregular, open and point-cloud inputs, with
     small and large sampling radii."""
     import os
@@ -89,11 +89,7 @@ def test_clustering_sweep_after_the_disk_sampler_only_resets_the_samples(cabi, k
     else:
         S, _ = meshgen.cotan_laplacian(V, F)
     neigh = meshgen.neighbors_from_stiffness(S)
-    try:
-        os.environ["GMG_HIERARCHY_FULL_DIJKSTRA"] = "1"
-        Hf = cabi.Hierarchy(V, neigh, ratio=ratio, lower_bound=50)
-    finally:
-        os.environ.pop("GMG_HIERARCHY_FULL_DIJKSTRA", None)
+    Hf = cabi.Hierarchy(V, neigh, ratio=ratio, lower_bound=50, full_clustering=True)
     Hs = cabi.Hierarchy(V, neigh, ratio=ratio, lower_bound=50)
     assert len(Hf.U) == len(Hs.U) >= 2
     for a, b in zip(Hf.nearest, Hs.nearest):
@@ -108,11 +104,7 @@ def test_a_neighbour_behind_a_gap_in_a_table_row_makes_the_full_sweep_run(cabi):
     import os
     V, neigh = _inputs("torus")
     neigh = np.ascontiguousarray(np.concatenate([neigh[:, :2], -np.ones((len(neigh), 1), neigh.dtype), neigh[:, 2:]], axis=1))
-    try:
-        os.environ["GMG_HIERARCHY_FULL_DIJKSTRA"] = "1"
-        Hf = cabi.Hierarchy(V, neigh, lower_bound=15)
-    finally:
-        os.environ.pop("GMG_HIERARCHY_FULL_DIJKSTRA", None)
+    Hf = cabi.Hierarchy(V, neigh, lower_bound=15, full_clustering=True)
     Hs = cabi.Hierarchy(V, neigh, lower_bound=15)
     assert len(Hf.U) == len(Hs.U) >= 1
     for a, b in zip(Hf.nearest, Hs.nearest):

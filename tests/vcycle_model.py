@@ -8,8 +8,7 @@ the oracle's arithmetic plus the orderings the device reports:
     x[rows_c] += omega * (b - A x)[rows_c] / diag[rows_c]   with (b - A x) from ``oracle.residual`` (multigrid_solver.cpp:1066).
     omega = 1 is the reference's update ``x_i <- (b_i - sum_{j != i} a_ij x_j) / a_ii`` applied colour by colour;
   * blocked levels: x += T^-1 (b - A x), T = D + strict lower triangle of A restricted to the block diagonal in device
-    order (Jacobi between blocks, Gauss-Seidel inside), residual from the oracle, triangular solve from scipy; a blocked level 0 with
-    ``fine_block_omega`` != 1 relaxes every update inside the block: T = D / omega + the same lower triangle;
+    order (Jacobi between blocks, Gauss-Seidel inside), residual from the oracle, triangular solve from scipy;
   * residual / restriction / prolongation / coarsest solve / Galerkin operators: the oracle's (gravomg_oracle.c).
 
 A per-cycle comparison against this model checks the composition of the whole cycle (level order, zero initial coarse
@@ -44,10 +43,7 @@ class VcycleModel:
                 order = n2o[real]
                 Ap = self.A[k].tocsr()[order][:, order].tocoo()
                 keep = (blk[Ap.row] == blk[Ap.col]) & (Ap.col <= Ap.row)
-                data = Ap.data[keep].copy()
-                wb = float(getattr(eng, "fine_block_omega", 1.0)) if k == 0 else 1.0      # a blocked level 0 relaxes inside the block: T = D / omega + L
-                if wb != 1.0:
-                    data[Ap.row[keep] == Ap.col[keep]] /= wb
+                data = Ap.data[keep]
                 T = sp.csr_matrix((data, (Ap.row[keep], Ap.col[keep])), shape=Ap.shape)
                 self.sm.append(("block", order, T))
 
