@@ -275,11 +275,28 @@ def main():
         kw["block_lanes"] = args.block_lanes
     eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT,
                       use_graph=args.graph, **kw)
+    # A cold set-up first, on a handle that was NOT told the system's sparsity pattern (prepare_structure = 0): what a system with an
+    # unannounced pattern pays (a Bilaplacian's two-ring, a caller's own prolongations) -- reported as set_system_cold_ms, never as the headline
+    cold = cabi.Engine(prepare_structure=False, **kw)
+    cold.use_hierarchy(H); cold.set_mass(mass)
+    t = time.perf_counter(); cold.set_system(lhs); setup_cold_ms = 1e3 * (time.perf_counter() - t)
+    cold.close(); del cold
+    # The default: gmg_use_hierarchy hands the engine the hierarchy's point graph -- the sparsity pattern of tau M + S -- and the structure of the
+    # system (orderings, colourings, layouts, symbolic Galerkin products, symbolic LDL^T) is prepared when the hierarchy is finalized
+    # (structure_prepare_ms, part of the construction like the hierarchy itself); gmg_set_system then does what depends on the VALUES: upload,
+    # numeric Galerkin chain, layout refill, numeric LDL^T (multigrid_solver.cpp:1387-1401)
+    t = time.perf_counter()
     eng.use_hierarchy(H)
+    use_hierarchy_ms = 1e3 * (time.perf_counter() - t)
+    try:
+        structure_ms = eng.timing("structure_prepare_ms")
+    except Exception:
+        structure_ms = None
     eng.set_mass(mass)
     t = time.perf_counter()
     eng.set_system(lhs)
     setup_ms = 1e3 * (time.perf_counter() - t)
+    setup_prepared = bool(eng.timing("setup_structure_prepared"))
     levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
     eng_omega = eng.gs_omega
     log(f"[bench] set_system {setup_ms:.0f} ms (reduction {eng.timing('reduction'):.0f}, coarsest {eng.timing('coarsest_solve'):.0f}, "
@@ -429,7 +446,12 @@ def main():
         "iterations_to_1e-4": iters, "residue": res, "residues_to_1e-4": [float(v) for v in conv[:, 1]],
         "iterations_reference_algorithm": cpu["iterations_to_1e-4"] if cpu else None,
         "solve_ms": solve_ms, "solver_timing_ms": timing, "second_solve_timing_ms": timing_again,
-        "set_system_ms": setup_ms, "set_system_same_pattern_ms": repeat_ms, "set_system_same_pattern_values_only": repeat_values_only,
+        "set_system_ms": setup_ms, "set_system_structure_prepared": setup_prepared, "structure_prepare_ms": structure_ms, "use_hierarchy_ms": use_hierarchy_ms,
+        "set_system_cold_ms": setup_cold_ms,
+        "set_system_note": "set_system_ms: the first gmg_set_system on a handle whose hierarchy announced the system's sparsity pattern (its point graph): "
+                           "values up, numeric Galerkin chain, layout refill, numeric LDL^T; the structural half was done once in gmg_use_hierarchy "
+                           "(structure_prepare_ms, inside use_hierarchy_ms).  set_system_cold_ms: the same call on a handle that was told nothing",
+        "set_system_same_pattern_ms": repeat_ms, "set_system_same_pattern_values_only": repeat_values_only,
         "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
         "timed_residues_tail": [float(r) for r in residues[-3:]],
         "variants": variants,

@@ -43,14 +43,14 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("prepare_structure", C.c_int),
     ]
 
 
 class GmgHierarchyOptions(C.Structure):
     _fields_ = [
         ("ratio", C.c_double), ("lower_bound", C.c_int), ("check_voronoi", C.c_int), ("nested", C.c_int),
-        ("sampling", C.c_int), ("weighting", C.c_int), ("debug", C.c_int), ("full_clustering", C.c_int),
+        ("sampling", C.c_int), ("weighting", C.c_int), ("debug", C.c_int), ("full_clustering", C.c_int), ("use_device", C.c_int),
     ]
 
 
@@ -92,32 +92,28 @@ SIGNATURES = {
     "gmg_fetch_solution": (C.c_int, [_vp, _dp]),
     "gmg_set_stream": (C.c_int, [_vp, _vp]),
     "gmg_dist_setup": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "gmg_dist_partition": (C.c_int, [_vp, C.c_int, C.c_int]),
     "gmg_dist_bind": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "gmg_dist_smooth_color": (C.c_int, [_vp, C.c_int]),
     "gmg_dist_residual_own": (C.c_int, [_vp]),
     "gmg_dist_coarse_cycle": (C.c_int, [_vp]),
     "gmg_dist_prolong_own": (C.c_int, [_vp]),
     "gmg_dist_norm_partial": (C.c_int, [_vp, C.c_int, _dp]),
-    "gmg_dist_residual_all": (C.c_int, [_vp]),
-    "gmg_dist_prolong_all": (C.c_int, [_vp]),
-    "gmg_dist_norm_all": (C.c_int, [_vp, C.c_int, _dp]),
+    "gmg_dist_all_rows": (C.c_int, [_vp, C.c_int]),
     "gmg_dist_gather": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gmg_dist_scatter": (C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "gmg_p2p_blob_bytes": (C.c_int, []),
     "gmg_p2p_prepare": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "gmg_p2p_export": (C.c_int, [_vp, C.c_void_p]),
     "gmg_p2p_connect": (C.c_int, [_vp, C.c_void_p]),
+    "gmg_p2p_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "gmg_p2p_connect_rccl": (C.c_int, [_vp, C.c_void_p]),
     "gmg_p2p_load": (C.c_int, [_vp, _dp, _dp]),
     "gmg_p2p_cycles": (C.c_int, [_vp, C.c_int, C.c_int, _dp]),
     "gmg_p2p_fetch": (C.c_int, [_vp, _dp]),
     "gmg_p2p_solve": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
-    "gmg_p2p_bench_exchange": (C.c_int, [_vp, C.c_int, _dp]),
-    "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_p2p_set_smoother": (C.c_int, [_vp, C.c_int]),
-    "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
-    "gmg_profile_cycle": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
-    "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
     "gmg_hierarchy_build": (C.c_int, [_dp, C.c_int, _ip, C.c_int, C.POINTER(GmgHierarchyOptions), C.POINTER(_vp)]),
     "gmg_hierarchy_destroy": (None, [_vp]),
@@ -132,6 +128,7 @@ SIGNATURES = {
     "gmg_hierarchy_get_triangles": (C.c_int, [_vp, C.c_int, _ip, _ip]),
     "gmg_hierarchy_get_fine_order": (C.c_int, [_vp, _ip, _ip]),
     "gmg_set_fine_order": (C.c_int, [_vp, C.c_int, _ip]),
+    "gmg_set_fine_graph": (C.c_int, [_vp, C.c_int, C.c_int, _ip]),
     "gmg_use_hierarchy": (C.c_int, [_vp, _vp]),
     "gmg_finalize_hierarchy": (C.c_int, [_vp]),
     "gmg_host_ldlt_solve": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, _dp, C.POINTER(C.c_int64)]),
@@ -146,6 +143,10 @@ INTERNAL_SIGNATURES = {
                                       C.POINTER(C.c_ubyte)]),
     "gmg_host_fine_block_rule": (C.c_int, [C.c_int, _ip, _ip, _dp, _ip, _ip]),
     "gmg_debug_set": (C.c_int, [_vp, C.c_char_p, C.c_double]),
+    "gmg_bench_kernel": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _dp, _ip]),
+    "gmg_profile_cycle": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
+    "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
+    "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
     "gmg_host_ldlt_probe": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, C.c_char_p, C.c_int]),
 }
 
@@ -245,7 +246,7 @@ class Hierarchy:
     Mirrors what ``MGBS::MultigridSolver::buildHierarchy`` produces: ``U`` (list of scipy CSC matrices,
     n_k x n_{k+1}) and the reference's ``hierarchyTiming`` keys."""
 
-    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0, debug=False, full_clustering=False):
+    def __init__(self, pos, neigh, ratio=8.0, lower_bound=1000, check_voronoi=True, nested=False, sampling=0, weighting=0, debug=False, full_clustering=False, use_device=True):
         l = lib()
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         neigh = np.ascontiguousarray(neigh, dtype=np.int32)
@@ -255,6 +256,7 @@ class Hierarchy:
         l.gmg_hierarchy_options_default(C.byref(opt))
         opt.ratio, opt.lower_bound, opt.check_voronoi, opt.nested = float(ratio), int(lower_bound), int(bool(check_voronoi)), int(bool(nested))
         opt.sampling, opt.weighting, opt.debug, opt.full_clustering = int(sampling), int(weighting), int(bool(debug)), int(bool(full_clustering))
+        opt.use_device = int(bool(use_device))
         self._h = _vp()
         rc = l.gmg_hierarchy_build(_pd(pos), pos.shape[0], _pi(neigh), neigh.shape[1], C.byref(opt), C.byref(self._h))
         if rc:
@@ -317,7 +319,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -341,6 +343,10 @@ class Engine:
             cfg.fine_col16 = int(bool(fine_col16))
         if stream_gate is not None:
             cfg.stream_gate = int(bool(stream_gate))
+        if prepare_structure is not None:
+            cfg.prepare_structure = int(bool(prepare_structure))
+        if dist_exchange is not None:
+            cfg.dist_exchange = int(dist_exchange)
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -381,8 +387,10 @@ class Engine:
             pass
 
     # -- hierarchy input
-    def set_prolongations(self, U: Sequence, finalize: bool = True, fine_order=None):
-        """fine_order: optional locality order of the level-0 points (gmg_set_fine_order), e.g. Hierarchy.fine_order."""
+    def set_prolongations(self, U: Sequence, finalize: bool = True, fine_order=None, fine_graph=None):
+        """fine_order: optional locality order of the level-0 points (gmg_set_fine_order), e.g. Hierarchy.fine_order.
+        fine_graph: optional n x K neighbour table the hierarchy was built from (gmg_set_fine_graph): the engine then prepares the structure of
+        the systems to come when the hierarchy is finalized."""
         l = lib()
         self._chk(l.gmg_set_num_levels(self._h, len(U)))
         self._sizes = []
@@ -395,6 +403,9 @@ class Engine:
         if fine_order is not None and len(U):
             fo = np.ascontiguousarray(fine_order, dtype=np.int32)
             self._chk(l.gmg_set_fine_order(self._h, fo.shape[0], _pi(fo)))
+        if fine_graph is not None and len(U):
+            fg = np.ascontiguousarray(fine_graph, dtype=np.int32)
+            self._chk(l.gmg_set_fine_graph(self._h, fg.shape[0], fg.shape[1], _pi(fg)))
         if finalize and len(U):
             self._chk(l.gmg_finalize_hierarchy(self._h))
 
@@ -580,6 +591,10 @@ class Engine:
     def set_stream(self, stream_handle: int):
         self._chk(lib().gmg_set_stream(self._h, _vp(stream_handle) if stream_handle else None))
 
+    def dist_partition(self, rank: int, world: int):
+        """Before use_hierarchy / set_system: lay out and keep only rank `rank`'s rows of levels 0-1 (gmg_dist_partition)."""
+        self._chk(lib().gmg_dist_partition(self._h, int(rank), int(world)))
+
     def dist_setup(self, rank: int, world: int):
         self._chk(lib().gmg_dist_setup(self._h, int(rank), int(world)))
 
@@ -604,16 +619,30 @@ class Engine:
         self._chk(lib().gmg_dist_norm_partial(self._h, int(type), _pd(sums)))
         return sums
 
+    def dist_all_rows(self, on: bool):
+        """dist_residual_own / dist_prolong_own / dist_norm_partial cover ALL rows of level 0 while on (gmg_dist_all_rows)."""
+        self._chk(lib().gmg_dist_all_rows(self._h, int(bool(on))))
+
     def dist_residual_all(self):
-        self._chk(lib().gmg_dist_residual_all(self._h))
+        self.dist_all_rows(True)
+        try:
+            self.dist_residual_own()
+        finally:
+            self.dist_all_rows(False)
 
     def dist_prolong_all(self):
-        self._chk(lib().gmg_dist_prolong_all(self._h))
+        self.dist_all_rows(True)
+        try:
+            self.dist_prolong_own()
+        finally:
+            self.dist_all_rows(False)
 
     def dist_norm_all(self, type: int, d: int) -> np.ndarray:
-        sums = np.zeros(2 * d)
-        self._chk(lib().gmg_dist_norm_all(self._h, int(type), _pd(sums)))
-        return sums
+        self.dist_all_rows(True)
+        try:
+            return self.dist_norm_partial(type, d)
+        finally:
+            self.dist_all_rows(False)
 
     def dist_gather(self, src_ptr: int, idx_ptr: int, n: int, dst_ptr: int):
         """dst[i] = src[idx[i]] on the engine stream (device pointers)."""
@@ -644,6 +673,11 @@ class P2PCycle:
         assert len(blob) == self.world * lib().gmg_p2p_blob_bytes()
         self.eng._chk(lib().gmg_p2p_connect(self.eng._h, blob))
 
+    def connect_rccl(self, unique_id: bytes):
+        """gmg_config::dist_exchange = 1: join the RCCL communicator made from rank 0's id (rccl_unique_id()); collective."""
+        assert len(unique_id) == 128
+        self.eng._chk(lib().gmg_p2p_connect_rccl(self.eng._h, unique_id))
+
     def load(self, b, x0):
         B, X = _f64(b), _f64(x0)
         assert B.shape == (self._n, self.d) and X.shape == B.shape
@@ -672,9 +706,7 @@ class P2PCycle:
         return X, it.value, res.value
 
     def bench_exchange(self, reps: int = 100) -> float:
-        out = C.c_double()
-        self.eng._chk(lib().gmg_p2p_bench_exchange(self.eng._h, int(reps), C.byref(out)))
-        return out.value
+        return self.bench_kind("color0", reps)
 
     def bench_kind(self, kind: str, reps: int = 100) -> float:
         """ms per exchange of the named kind ("color<k>", "halo_all", "rows0", "x1_halo", "rows1", "r0_halo"); collective;
@@ -691,6 +723,15 @@ class P2PCycle:
         out = C.c_double()
         self.eng._chk(lib().gmg_p2p_stat(self.eng._h, key.encode(), C.byref(out)))
         return out.value
+
+
+def rccl_unique_id() -> bytes:
+    """128-byte id of a new RCCL communicator (rank 0 makes it, every rank gets it: P2PCycle.connect_rccl)."""
+    buf = C.create_string_buffer(128)
+    rc = lib().gmg_p2p_rccl_unique_id(buf)
+    if rc:
+        raise GmgError(rc, "gmg_p2p_rccl_unique_id (librccl not loadable?)")
+    return buf.raw
 
 
 def host_galerkin(A, U) -> sp.csc_matrix:

@@ -322,6 +322,8 @@ public:
         else if (key == "block_lanes") c.block_lanes = (int)value;
         else if (key == "dist_shard_levels") c.dist_shard_levels = (int)value;
         else if (key == "block_fine") c.block_fine = (int)value;
+        else if (key == "dist_rank") solver->distRank = (int)value;
+        else if (key == "dist_world") solver->distWorld = (int)value;
         else if (key == "fine_col16") c.fine_col16 = (int)value;
         else if (key == "stream_gate") c.stream_gate = (int)value;
         else if (key == "inner_precision") c.inner_precision = (int)value;

@@ -6,5 +6,5 @@ out="${here}/../lib"
 mkdir -p "${out}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
-    -I"${here}/../../include" "${here}/engine.hip" -o "${out}/libgravomg_hip.so" -lpthread "$@"
+    -I"${here}/../../include" "${here}/engine.hip" -o "${out}/libgravomg_hip.so" -lpthread -ldl "$@"
 echo "built ${out}/libgravomg_hip.so"

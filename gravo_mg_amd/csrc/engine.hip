@@ -12,6 +12,7 @@
 // Reference call sites this replaces: gravomg/src/multigrid_solver.cpp:1059-1088 (V-cycle),
 // :1194-1226 (smoother), :1228-1277 (norms), :1387-1419 (solve loop).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <atomic>
 #include <chrono>
@@ -79,6 +80,7 @@ struct GmgSignalAid {
 #include "engine_state.hip.hpp"
 #include "engine_setup.hip.hpp"
 #include "engine_cycle.hip.hpp"
+#include "engine_part.hip.hpp"
 
 // =========================================================================================================
 // No exception leaves the C-ABI: std::bad_alloc (a 3 M-vertex set-up allocates hundreds of MB on the host), a failed
@@ -122,6 +124,8 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->dist_shard_levels = 2;
     cfg->fine_col16 = 1;
     cfg->stream_gate = 1;
+    cfg->prepare_structure = 1;
+    cfg->dist_exchange = 0;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
@@ -142,7 +146,7 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
     gmg_config c;
     if (cfg) c = *cfg; else gmg_config_default(&c);
     if (c.sigma < 0 || c.sigma % 64 || c.restrict_sigma < 0 || c.restrict_sigma % 64 || c.row_align <= 0 || c.row_align % 64 || c.pre_iters < 0 || c.post_iters < 0 ||
-        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 ||
+        c.reorder_fine < 0 || c.reorder_fine > 2 || c.inner_precision < 0 || c.inner_precision > 1 || c.block_rows < 0 || c.block_rows > gmgk::kBlockRows || c.block_rows % 64 || c.block_from_level < 0 || !(c.gs_omega > 0.0 && c.gs_omega < 2.0) || c.dist_shard_levels < 1 || c.dist_shard_levels > 2 || c.block_fine < 0 || c.block_fine > 1 || c.dist_exchange < 0 || c.dist_exchange > 2 ||
         (c.block_lanes != 0 && c.block_lanes != 1 && c.block_lanes != 4) || (c.block_lanes != 1 && c.block_rows > gmgk::kQuadBlockRows)) return GMG_ERR_INVALID;
     gmg_handle h = new gmg_solver_s();
     h->cfg = c;
@@ -195,6 +199,7 @@ int gmg_set_num_levels(gmg_handle h, int L) try {
     if (h->has_device) { drop_system(h); drop_device_transfers(h); }
     h->patches.clear(); h->patches_ready = false;
     h->bfs_order.clear();
+    h->fine_graph.reset();
     h->L = L;
     h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
@@ -252,6 +257,7 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) try {
     PoolScope pool_scope_(&h->pool);
     h->mass.assign(mass_diag, mass_diag + n);
     if (h->has_device && h->system_ready) return upload_mass(h);
+    h->mass_dirty = true;
     return GMG_OK;
 } GMG_CATCH_H
 
@@ -367,6 +373,11 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (h->cfg.inner_precision && (rc = refresh_fp32_twins(h, false))) return rc;
+    if (!h->mass.empty() && (h->mass_dirty || !h->d_mass)) {          // a mass set while only the placeholder structure stood (prepare_structure)
+        if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
+        if ((rc = upload_mass(h))) return rc;
+        h->mass_dirty = false;
+    }
     h->timing["coarsest_solve"] = ms_factor;
     h->timing["setup_ordering_cached"] = 1.0;
     h->timing["setup_values_only"] = 1.0;
@@ -379,7 +390,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     return GMG_OK;
 }
 
-int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) try {
+static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) {
     NEED_DEVICE();
     if (h->L <= 0) return fail(h, GMG_ERR_STATE, "hierarchy has no transfer levels (U is empty)");
     for (int k = 0; k < h->L; ++k) if (!h->U_set[k]) return fail(h, GMG_ERR_STATE, "prolongation matrix missing for level " + std::to_string(k));
@@ -401,7 +412,9 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     const int L = h->L;
     uint64_t pat_key[2] = {0, 0};
     bool have_key = false;
-    if (h->system_ready && h->live_key_valid && h->refill_ready && (int)h->lv.size() == L + 1 && h->lv[0].n == n) {
+    // (live: a system is set -- or the structure of one was prepared on placeholder values when the hierarchy was finalized, prepare_structure)
+    const bool live = h->system_ready || h->placeholder_ready;
+    if (live && h->live_key_valid && h->refill_ready && (int)h->lv.size() == L + 1 && h->lv[0].n == n) {
         // Same sparsity pattern as the live system (and the same hierarchy: refill_ready dies with it)?  Then every
         // structure on the device stands and only values move: LHS values up, numeric Galerkin passes, value refill of
         // the layouts, numeric LDL^T.  (The demos' usage: lhs = M + tau * S with a new tau per frame.)
@@ -410,12 +423,14 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         // (a level 0 that gmg_config::block_fine blocked stays blocked only while the new values pass its sign test)
         const bool keeps_fine_blocks = !(h->lv[0].ord.blocked && h->cfg.block_from_level >= 1) || stieltjes_signs(n, colptr, rowidx, val, h->cfg.host_threads);
         if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz && keeps_fine_blocks) {
+            const bool from_placeholder = h->placeholder_ready && !h->system_ready;
             int rc = refresh_system_values(h, n, val, t_all);
-            if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
+            if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
+            if (rc == GMG_OK) { h->system_ready = true; h->placeholder_ready = false; h->timing["setup_structure_prepared"] = from_placeholder ? 1.0 : 0.0; }
             if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything
         }
     }
-    if (h->system_ready && h->live_key_valid && (int)h->lv.size() == L + 1) {
+    if (live && h->live_key_valid && (int)h->lv.size() == L + 1) {
         h->ord_cache.resize(L + 1);
         for (int k = 0; k <= L; ++k) h->ord_cache[k] = std::move(h->lv[k].ord);
         h->ord_cache_key[0] = h->live_key[0]; h->ord_cache_key[1] = h->live_key[1];
@@ -434,10 +449,15 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
     h->timing["setup_wait_ordering"] = 0.0; h->timing["setup_device_layout"] = 0.0;
     const bool mc = h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS;
     bool device_setup = h->cfg.device_setup != 0;
+    const bool part = h->part_world > 1;      // gmg_dist_partition: lay out and keep this rank's rows of levels 0 / 1 only
+    if (part && !(device_setup && h->cfg.device_rap && mc)) return fail(h, GMG_ERR_UNSUPPORTED, "a partitioned set-up needs device_setup = 1, device_rap = 1 and the multicolour smoother");
+    h->partitioned = false;
+    h->pool.reset_peak();
     if (device_setup) {
         int rc = ensure_device_transfers(h);        // no-op when gmg_use_hierarchy (or an earlier system) made them
         if (rc) return rc;
         if (h->dU_flagged) device_setup = false;    // prolongation rows with more than 3 entries: host planner and host RAP
+        if (part && !device_setup) return fail(h, GMG_ERR_UNSUPPORTED, "a partitioned set-up has no host fallback (a prolongation row has more than 3 entries)");
     }
     struct LevelStage {
         SellHost sa, sin, sout, sp, sr;
@@ -684,12 +704,41 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
             };
             double ms_layout = 0;
             for (int k = L; k >= 1 && rc_all == GMG_OK; --k) ordering_of(k);
+            // A partitioned set-up (gmg_dist_partition) lays out this rank's rows of levels 0 / 1 only: it needs the partition plan -- hence
+            // both orderings -- before the first layout; everybody else's rows are masked out of the row maps the builders read
+            int *d_mask0 = nullptr, *d_mask1 = nullptr;
+            struct MaskGuard { int*& a; int*& b; ~MaskGuard() { if (a) (void)dev_free(a); if (b) (void)dev_free(b); } } mask_guard{d_mask0, d_mask1};
+            bool shard1 = false;
+            if (part && rc_all == GMG_OK) {
+                ordering_of(0);
+                auto tp = clk::now();
+                const LevelOrdering& o0 = h->lv[0].ord;
+                if (rc_all == GMG_OK && o0.blocked) { rc_all = GMG_ERR_STATE; err_all = "a partitioned set-up needs the colour-major level 0 (block_from_level >= 1)"; }
+                for (int c = 0; c < o0.n_colors && rc_all == GMG_OK; ++c)
+                    if ((o0.color_begin[c + 1] - o0.color_begin[c]) % (64 * h->part_world)) { rc_all = GMG_ERR_STATE; err_all = "colour classes are not aligned to 64*world rows: create the handle with row_align = 64*world"; }
+                if (rc_all == GMG_OK) {
+                    shard1 = plan_can_shard_level1(h, h->part_world, false);
+                    const bool reuse = h->plan && h->plan->key[0] == pat_key[0] && h->plan->key[1] == pat_key[1] && h->plan->rank == h->part_rank &&
+                                       h->plan->world == h->part_world && h->plan->shard1 == shard1 && h->plan->n_colors == o0.n_colors;
+                    if (!reuse) {
+                        if (shard1) rc_all = ensure_host_A(h, 1, false);
+                        auto plan = std::make_shared<DistPlan>();
+                        if (rc_all == GMG_OK) rc_all = build_dist_plan(h, *plan, h->part_rank, h->part_world, PatternView{n, colptr, rowidx}, shard1 ? &h->lv[1].A : nullptr, shard1);
+                        plan->key[0] = pat_key[0]; plan->key[1] = pat_key[1];
+                        if (rc_all == GMG_OK) h->plan = plan;
+                    }
+                    h->timing["dist_plan_cached"] = reuse ? 1.0 : 0.0;
+                }
+                if (rc_all == GMG_OK) rc_all = make_row_masks(h, *h->plan, &d_mask0, &d_mask1);
+                h->timing["dist_plan_ms"] = ms_since(tp);
+            }
             auto tlay = clk::now();
-            for (int k = 1; k < L && rc_all == GMG_OK; ++k) rc_all = device_layout_level(h, k, d_err.p);
+            for (int k = 1; k < L && rc_all == GMG_OK; ++k) rc_all = device_layout_level(h, k, d_err.p, (k == 1 && shard1) ? d_mask1 : nullptr, nullptr);
+            if (part && shard1 && rc_all == GMG_OK && !h->lv[1].use_ep) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "level 1 cannot run the entry-parallel block sweep (a block is too large for its LDS buffers): create the handle with dist_shard_levels = 1"; }
             ms_layout += ms_since(tlay);
-            if (rc_all == GMG_OK) ordering_of(0);
+            if (rc_all == GMG_OK && !part) ordering_of(0);
             tlay = clk::now();
-            if (rc_all == GMG_OK) rc_all = device_layout_level(h, 0, d_err.p);
+            if (rc_all == GMG_OK) rc_all = device_layout_level(h, 0, d_err.p, part ? d_mask0 : nullptr, (part && shard1) ? d_mask1 : nullptr);
             ms_layout += ms_since(tlay);
             h->timing["setup_device_layout"] = ms_layout;
             mark("device_layout");
@@ -697,6 +746,7 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
                 (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
                 (void)hipStreamSynchronize(h->stream);
                 if (herr == 2) { rc_all = GMG_ERR_NUMERIC; err_all = "system matrix has a missing or zero diagonal entry"; }
+                else if (herr != 0 && part) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "rows too long for the device layout builder: a partitioned set-up has no host fallback"; }
                 else if (herr != 0) {
                     // rows too long for the device builder: redo the layout with the host planner
                     device_setup = false;
@@ -791,20 +841,87 @@ int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, co
         if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
         int rc = upload_mass(h);
         if (rc) return rc;
+        h->mass_dirty = false;
     }
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->timing["device_bytes_peak"] = (double)h->pool.peak_live_bytes;
+    if (part) {
+        // This rank's rows of levels 0 / 1 are laid out; what the set-up needed in full -- A_0, A_1 and U_0 in natural numbering (inputs of the
+        // Galerkin chain and of the layout builders) and the column maps of the two levels -- goes back to the pool.  A later system pays for
+        // them again (no values-only refresh on a partitioned handle); the orderings and the plan stay cached under the pattern digest.
+        const bool s1 = h->plan && h->plan->shard1;
+        free_csr(h->lv[0].dA);
+        if (s1) free_csr(h->lv[1].dA);
+        if (!h->dU.empty()) { free_csr(h->dU[0]); free_ell3(h->dE3[0]); }
+        for (int k = 0; k <= (s1 ? 1 : 0); ++k) {
+            Level& lk = h->lv[k];
+            if (lk.d_old2new) { (void)dev_free(lk.d_old2new); lk.d_old2new = nullptr; }
+            if (lk.d_blk_of_row) { (void)dev_free(lk.d_blk_of_row); lk.d_blk_of_row = nullptr; }
+        }
+        h->pool.trim();                       // (parked blocks of the temporaries: the memory goes back to the device, not to this handle's pool)
+        h->partitioned = true;
+    }
+    h->timing["device_bytes"] = (double)h->pool.live_bytes;
     // only now is there a system: a failure above leaves the handle without one (no solves on a half-built state)
     h->live_key[0] = pat_key[0]; h->live_key[1] = pat_key[1];
     h->live_key_valid = true;
     h->ord_cache_valid = false;       // (moved into the levels on a hit; refilled from them by the next call)
     h->system_ready = true;
-    h->refill_ready = device_setup && device_rap_ok && h->cfg.device_setup != 0;
+    h->refill_ready = device_setup && device_rap_ok && h->cfg.device_setup != 0 && !part;
     mark("mass_done");
     h->timing["upload"] = ms_since(t_all) - h->timing["reduction"];      // everything of the setup that is not the RAP chain
     h->timing["setup_total"] = ms_since(t_all);                          // wall time of this call (the coarsest factorisation overlaps)
     h->timing["coarse_host_ms"] = 0.0;
+    h->timing["setup_structure_prepared"] = 0.0;
     return GMG_OK;
+}
+
+int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val) try {
+    return set_system_impl(h, n, colptr, rowidx, val);
 } GMG_CATCH_H
+
+// gmg_finalize_hierarchy with a fine graph (gmg_set_fine_graph / gmg_use_hierarchy): the complete set-up for a PLACEHOLDER matrix with the
+// graph's pattern -- diagonally dominant (row i: its entry count on the diagonal, -1 elsewhere: symmetric positive definite, and of the sign
+// structure of the graph Laplacians the hierarchy is built for, so that the rules that look at values -- gmg_config::block_fine -- decide as
+// they will for the real system; a system that makes them decide otherwise takes the cold path).  Everything structural then stands on the
+// device: orderings and colourings of all levels, SELL / block layouts, 16-bit column codes, the patterns of the Galerkin operators, the
+// symbolic LDL^T.  The handle holds no system afterwards (solves are refused until gmg_set_system), but a gmg_set_system whose pattern
+// digest equals the prepared one is a values-only refresh: values up, numeric Galerkin passes, layout refill, numeric LDL^T -- the part of
+// the reference's solve() preamble (multigrid_solver.cpp:1387-1401) that depends on the matrix, and nothing else.
+static int prepare_structure(gmg_handle h) {
+    const FineGraph& g = *h->fine_graph;
+    const int n = g.n;
+    auto t0 = clk::now();
+    RawVec<double> val;
+    val.resize((size_t)g.ptr[n]);
+    parallel_ranges(n, h->cfg.host_threads, [&](int lo, int hi, int) {
+        for (int i = lo; i < hi; ++i) {
+            const double diag = (double)(g.ptr[i + 1] - g.ptr[i]);
+            for (int p = g.ptr[i]; p < g.ptr[i + 1]; ++p) val[p] = g.idx[p] == i ? diag : -1.0;
+        }
+    }, 1 << 14);
+    std::vector<double> user_mass;
+    user_mass.swap(h->mass);                         // (the placeholder set-up needs no mass; whatever the caller set waits for the real system)
+    int rc = set_system_impl(h, n, g.ptr.data(), g.idx.data(), val.data());
+    h->mass.swap(user_mass);
+    if (rc != GMG_OK) { h->placeholder_ready = false; return rc; }
+    h->system_ready = false;                         // nothing to solve with: the values are placeholders
+    if (h->part_world > 1) {
+        // a partitioned handle cannot refresh values in place (it keeps no whole operator): what carries over to the real system is what
+        // depends on the pattern alone and lives on the host -- the orderings of all levels and the partition plan, both under the digest
+        h->ord_cache.resize(h->L + 1);
+        for (int k = 0; k <= h->L; ++k) h->ord_cache[k] = std::move(h->lv[k].ord);
+        h->ord_cache_key[0] = h->live_key[0]; h->ord_cache_key[1] = h->live_key[1];
+        h->ord_cache_valid = true;
+        h->live_key_valid = false;
+        drop_system(h);
+        h->pool.trim();
+    }
+    h->placeholder_ready = h->refill_ready && h->live_key_valid;
+    h->mass_dirty = !h->mass.empty();
+    h->timing["structure_prepare_ms"] = ms_since(t0);
+    return GMG_OK;
+}
 
 int gmg_num_levels(gmg_handle h) { return h ? h->L : GMG_ERR_INVALID; }
 
@@ -824,6 +941,7 @@ int gmg_get_level_operator(gmg_handle h, int k, int* colptr, int* rowidx, double
     if (!h) return GMG_ERR_INVALID;
     int rc = check_level(h, k, true);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     {
         PoolScope pool_scope_(&h->pool);
         if ((rc = ensure_host_A(h, k, true))) return rc;
@@ -890,6 +1008,7 @@ int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int*
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (which == 5) {      // slice_ptr <- row_ptr (n_pad + 1), row_of <- row_mid (n_pad)
         Level& lb = h->lv[k];
         if (!lb.use_bcsr) return GMG_OK;
@@ -939,6 +1058,7 @@ int gmg_debug_sell_copy(gmg_handle h, int k, int which, int64_t* slice_ptr, int*
 
 int gmg_get_timing(gmg_handle h, const char* key, double* out) try {
     if (!h || !key || !out) return GMG_ERR_INVALID;
+    if (std::string(key) == "device_bytes_now") { *out = (double)h->pool.live_bytes; return GMG_OK; }      // device memory the handle holds at this moment (pool blocks in use)
     auto it = h->timing.find(key);
     if (it == h->timing.end()) return fail(h, GMG_ERR_INVALID, std::string("unknown timing key: ") + key);
     *out = it->second;
@@ -951,6 +1071,7 @@ int gmg_smooth(gmg_handle h, int k, const double* b, double* x, int d, int iters
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!b || !x || d <= 0 || iters < 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -965,6 +1086,7 @@ int gmg_smooth_residual(gmg_handle h, int k, const double* b, double* x, int d, 
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!b || !x || !r || d <= 0 || iters < 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -986,6 +1108,7 @@ int gmg_residual(gmg_handle h, int k, const double* b, const double* x, int d, d
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!b || !x || !r || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -1000,6 +1123,7 @@ int gmg_spmv(gmg_handle h, int k, const double* x, int d, double* y) try {
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!x || !y || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -1013,6 +1137,7 @@ int gmg_restrict(gmg_handle h, int k, const double* r, int d, double* rc_out) tr
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!r || !rc_out || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -1026,6 +1151,7 @@ int gmg_prolong_add(gmg_handle h, int k, const double* e, int d, double* x) try 
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!e || !x || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -1054,6 +1180,7 @@ int gmg_residual_norm(gmg_handle h, const double* b, const double* x, int d, int
     NEED_DEVICE();
     int rc = check_level(h, 0, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!b || !x || !out || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = check_norm_type(h, type))) return rc;
     if ((rc = ensure_vectors(h, d))) return rc;
@@ -1114,6 +1241,7 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
     if (n_cycles < 0) return fail(h, GMG_ERR_INVALID, "bad cycle count");
     int rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
     const int d = h->loaded_d;
     HelperScope helper_scope(h, d);
@@ -1139,6 +1267,7 @@ int gmg_profile_cycle(gmg_handle h, int stop_type, int reps, double* ms_out, int
     if (!ms_out || n_out < L + 2 || reps <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments (ms_out needs levels + 2 entries)");
     if (h->cfg.use_graph) return fail(h, GMG_ERR_UNSUPPORTED, "leg profiling needs stream launches (use_graph = 0)");
     int rc;
+    if ((rc = check_whole_system(h))) return rc;
     if ((rc = check_norm_type(h, stop_type))) return rc;
     const int d = h->loaded_d;
     HelperScope helper_scope(h, d);
@@ -1180,6 +1309,7 @@ static int solve_common(gmg_handle h, const double* rhs, const double* x0, doubl
     NEED_DEVICE();
     int rc;
     if (!rhs || !x0 || !x) return fail(h, GMG_ERR_INVALID, "bad arguments");
+    if ((rc = check_whole_system(h))) return rc;
     if ((rc = check_norm_type(h, stop_type))) return rc;
     if (max_iter < 1) max_iter = 1;      // do { } while: at least one cycle (multigrid_solver.cpp:1411-1417)
     auto t_all = clk::now();
@@ -1249,11 +1379,24 @@ int gmg_set_stream(gmg_handle h, void* hip_stream) try {
     return GMG_OK;
 } GMG_CATCH_H
 
+int gmg_dist_partition(gmg_handle h, int rank, int world) try {
+    if (!h) return GMG_ERR_INVALID;
+    PoolScope pool_scope_(&h->pool);
+    if (world < 1 || rank < 0 || rank >= world) return fail(h, GMG_ERR_INVALID, "bad rank / world size");
+    if (world > 1 && h->cfg.row_align % (64 * world)) return fail(h, GMG_ERR_STATE, "create the handle with row_align = 64 * world (colour classes are cut into `world` pieces of whole slices)");
+    if (rank == h->part_rank && world == h->part_world) return GMG_OK;
+    if (h->has_device && (h->system_ready || h->placeholder_ready)) { drop_system(h); h->live_key_valid = false; }      // laid out for another partition
+    h->part_rank = rank; h->part_world = world;
+    h->plan.reset();
+    return GMG_OK;
+} GMG_CATCH_H
+
 int gmg_dist_setup(gmg_handle h, int rank, int world) try {
     NEED_DEVICE();
     int rc = check_level(h, 0, false);
     if (rc) return rc;
     if (world < 1 || rank < 0 || rank >= world) return fail(h, GMG_ERR_INVALID, "bad rank / world size");
+    if (h->partitioned && (rank != h->part_rank || world != h->part_world)) return fail(h, GMG_ERR_STATE, "the system was laid out for another rank / world size (gmg_dist_partition)");
     const LevelOrdering& o = h->lv[0].ord;
     if (o.blocked || h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the colour-major multicolour ordering on level 0 (gmg_config: block_from_level >= 1, block_fine = 0)");
     for (int c = 0; c < o.n_colors; ++c)
@@ -1285,11 +1428,6 @@ inline void own_range(gmg_handle h, int c, int& sb, int& se) {
     sb = o.color_begin[c] / 64 + h->rank * chunk;
     se = sb + chunk;
 }
-struct AllRowsScope {       // own_range() covers the whole colour while one of these is alive
-    gmg_handle h;
-    explicit AllRowsScope(gmg_handle hh) : h(hh) { h->dist_all_rows = true; }
-    ~AllRowsScope() { h->dist_all_rows = false; }
-};
 int dist_ready(gmg_handle h) {
     if (!h->dist_ready || !h->bound || h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "distributed state not set (gmg_dist_setup + gmg_dist_bind)");
     return GMG_OK;
@@ -1426,23 +1564,15 @@ int gmg_dist_norm_partial(gmg_handle h, int type, double* sums) try {
     return GMG_OK;
 } GMG_CATCH_H
 
-// The same three steps over ALL rows of level 0.  After the exchange that follows every colour sweep each rank holds the
-// complete x, so residual, prolongation-add and the norm sums can be computed redundantly instead of being exchanged:
-// 16 collectives per V-cycle (one per colour sweep) instead of 24 + an all-reduce, and the sums are identical on all ranks.
-int gmg_dist_residual_all(gmg_handle h) try {
+// The same steps over ALL rows of level 0: after the exchange that follows every colour sweep each rank holds the complete x, so residual,
+// prolongation-add and the norm sums can be computed redundantly instead of being exchanged (16 collectives per V-cycle, one per colour
+// sweep, instead of 24 + an all-reduce; the sums are then identical on all ranks).  on != 0: gmg_dist_residual_own / gmg_dist_prolong_own /
+// gmg_dist_norm_partial cover every row until it is switched off again.
+int gmg_dist_all_rows(gmg_handle h, int on) try {
     if (!h) return GMG_ERR_INVALID;
-    AllRowsScope all(h);
-    return gmg_dist_residual_own(h);
-} GMG_CATCH_H
-int gmg_dist_prolong_all(gmg_handle h) try {
-    if (!h) return GMG_ERR_INVALID;
-    AllRowsScope all(h);
-    return gmg_dist_prolong_own(h);
-} GMG_CATCH_H
-int gmg_dist_norm_all(gmg_handle h, int type, double* sums) try {
-    if (!h) return GMG_ERR_INVALID;
-    AllRowsScope all(h);
-    return gmg_dist_norm_partial(h, type, sums);
+    if (on && h->partitioned) return fail(h, GMG_ERR_STATE, "this handle holds one rank's rows only (gmg_dist_partition)");
+    h->dist_all_rows = on != 0;
+    return GMG_OK;
 } GMG_CATCH_H
 
 int gmg_dist_gather(gmg_handle h, const double* src, const int64_t* idx, int64_t n, double* dst) try {
@@ -1482,6 +1612,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     NEED_DEVICE();
     int rc = check_level(h, k, false);
     if (rc) return rc;
+    if ((rc = check_whole_system(h))) return rc;
     if (!ms_avg || reps <= 0 || d <= 0) return fail(h, GMG_ERR_INVALID, "bad arguments");
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& l = h->lv[k];
@@ -1520,7 +1651,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
 
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o) try {
     if (!o) return GMG_ERR_INVALID;
-    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0; o->debug = 0; o->full_clustering = 0;
+    o->ratio = 8.0; o->lower_bound = 1000; o->check_voronoi = 1; o->nested = 0; o->sampling = 0; o->weighting = 0; o->debug = 0; o->full_clustering = 0; o->use_device = 1;
     return GMG_OK;
 } GMG_CATCH_0
 
@@ -1624,10 +1755,10 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     for (size_t i = 0; i < (size_t)n * K; ++i) if (neigh[i] >= n) return GMG_ERR_INVALID;
     HierarchyOptions ho;
     ho.ratio = o.ratio; ho.lower_bound = o.lower_bound; ho.check_voronoi = o.check_voronoi != 0; ho.nested = o.nested != 0; ho.weighting = o.weighting; ho.keep_triangles = o.debug != 0; ho.full_clustering = o.full_clustering != 0;
-    // the per-point selection stage runs on the GPU when there is one (same bits as the host loop; GMG_HIERARCHY_DEVICE=0: host only)
+    // the per-point selection stage runs on the GPU when there is one (same bits as the host loop; gmg_hierarchy_options::use_device = 0: host only)
     {
         int ndev = 0;
-        if (EnvSwitches::get().hierarchy_device && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ho.device_select = hierarchy_select_on_device;
+        if (o.use_device != 0 && n >= ho.device_select_min_points && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) ho.device_select = hierarchy_select_on_device;
         else (void)hipGetLastError();
     }
     // first use in a process: runtime start-up, code object load and the pinned buffers (~80 ms) happen beside the sequential
@@ -1654,8 +1785,17 @@ int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const
     std::future<std::vector<int>> fine_order;
     if (n > 65536 && mean_index_distance_table(neigh, n, K) > std::max(32768.0, n / 32.0))
         fine_order = std::async(std::launch::async, [neigh, n, K] { return bfs_point_order(neigh, n, K); });
+    // ... and the point graph as a canonical sparsity pattern: what gmg_use_hierarchy gives the engine to prepare its structure for
+    std::future<std::shared_ptr<const FineGraph>> graph = std::async(std::launch::async, [neigh, n, K] {
+        auto g = std::make_shared<FineGraph>();
+        g->n = n;
+        neigh_pattern(neigh, n, K, g->ptr, g->idx);
+        return std::shared_ptr<const FineGraph>(g);
+    });
+    struct JoinGraph { std::future<std::shared_ptr<const FineGraph>>& f; ~JoinGraph() { if (f.valid()) f.wait(); } } join_graph{graph};      // (reads the caller's table: never outlives the call)
     hh->res = HierarchyBuilder::build(pos, n, neigh, K, ho);
     if (fine_order.valid()) hh->fine_order = fine_order.get();
+    hh->graph = graph.get();
     if (device_warm.valid()) device_warm.get();
     *out = hh;
     return GMG_OK;
@@ -1743,6 +1883,22 @@ int gmg_set_fine_order(gmg_handle h, int n, const int* order) try {
     return GMG_OK;
 } GMG_CATCH_H
 
+int gmg_set_fine_graph(gmg_handle h, int n, int K, const int* neigh) try {
+    if (!h || n < 0 || (n > 0 && (K <= 0 || !neigh))) return GMG_ERR_INVALID;
+    if (n == 0) { h->fine_graph.reset(); return GMG_OK; }
+    if (h->L <= 0 || !h->U_set[0] || h->U[0].n_inner != n) return fail(h, GMG_ERR_STATE, "set the prolongations first: the graph must have one row per level-0 point");
+    {
+        std::atomic<bool> bad{false};
+        parallel_ranges(n, h->cfg.host_threads, [&](int lo, int hi, int) { for (size_t i = (size_t)lo * K; i < (size_t)hi * K; ++i) if (neigh[i] >= n) { bad = true; return; } }, 1 << 14);
+        if (bad) return fail(h, GMG_ERR_INVALID, "neighbour index out of range");
+    }
+    auto g = std::make_shared<FineGraph>();
+    g->n = n;
+    neigh_pattern(neigh, n, K, g->ptr, g->idx);
+    h->fine_graph = g;
+    return GMG_OK;
+} GMG_CATCH_H
+
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) try {
     if (!h || !hh) return GMG_ERR_INVALID;
     int rc = gmg_set_num_levels(h, (int)hh->res.U.size());
@@ -1752,6 +1908,7 @@ int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh) try {
         if ((rc = gmg_set_prolongation(h, k, u.n_inner, u.n_outer, u.ptr.data(), u.idx.data(), u.val.data()))) return rc;
     }
     if (!hh->res.U.empty() && (rc = gmg_set_fine_order(h, (int)hh->fine_order.size(), hh->fine_order.data()))) return rc;
+    if (!hh->res.U.empty() && hh->graph && hh->graph->n == hh->res.U[0].n_inner) h->fine_graph = hh->graph;      // (shared, read-only: no copy)
     return gmg_finalize_hierarchy(h);
 } GMG_CATCH_H
 
@@ -1771,6 +1928,10 @@ int gmg_finalize_hierarchy(gmg_handle h) try {
         rc = hipSetDevice(h->cfg.device) == hipSuccess ? ensure_device_transfers(h) : fail(h, GMG_ERR_HIP, "hipSetDevice failed");
     }
     if (patches.valid()) patches.get();
+    // with the point graph at hand: everything structural for the systems to come, on placeholder values (prepare_structure)
+    if (rc == GMG_OK && h->cfg.prepare_structure && h->cfg.device_setup && h->cfg.device_rap && h->fine_graph && h->fine_graph->n == h->U[0].n_inner && !h->placeholder_ready &&
+        !h->system_ready)
+        rc = prepare_structure(h);
     return rc;
 } GMG_CATCH_H
 

@@ -861,6 +861,12 @@ int check_level(gmg_handle h, int k, bool allow_coarsest) {
     return GMG_OK;
 }
 
+// entry points that read whole level operators: not on a handle that holds one rank's rows of a partitioned system
+int check_whole_system(gmg_handle h) {
+    if (h->partitioned) return fail(h, GMG_ERR_STATE, "this handle holds one rank's rows of a partitioned system (gmg_dist_partition): only the gmg_p2p_* / gmg_dist_* entry points run on it");
+    return GMG_OK;
+}
+
 int check_norm_type(gmg_handle h, int type) {
     if (type < 0 || type > 3) return fail(h, GMG_ERR_INVALID, "residual norm type must be 0..3");
     if ((type == 1 || type == 2) && !h->d_mass) return fail(h, GMG_ERR_STATE, "mass matrix not set (gmg_set_mass) but an M-weighted norm was requested");

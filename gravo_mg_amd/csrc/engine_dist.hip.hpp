@@ -27,9 +27,30 @@ struct P2PPeer {
 };
 
 struct gmg_p2p_blob {                                     // what a rank publishes to the others (plain bytes, exchanged out of band)
-    hipIpcMemHandle_t mbox, flags;
+    hipIpcMemHandle_t mbox, flags, coll;                  // coll: the gathered buffer of the emulated collective (dist_exchange = 2), else zero
     int rank, world, d, n_pad, n_colors, reserved;
-    long long mbox_doubles;
+    long long mbox_doubles, coll_doubles;
+};
+
+// Collective exchange backend (gmg_config::dist_exchange = 1 / 2): every exchange of the cycle as pack -> all-gather -> unpack on the engine's
+// stream (kernels.hip.hpp::coll_pack / coll_unpack), the all-gather being ncclAllGather (librccl, loaded at run time) or, between processes
+// that share a device, its emulation through hipIpc mappings.
+struct CollBackend {
+    int mode = 0;                                         // 1: RCCL, 2: emulated over hipIpc
+    std::vector<long long> chunk;                         // [kind] doubles a rank contributes (multiple of 8, the same on every rank)
+    long long max_chunk = 0;
+    double* send = nullptr;                               // max_chunk doubles: this rank's packed chunk
+    double* recv = nullptr;                               // 2 x world x max_chunk doubles: the gathered chunks, double-buffered by the kind's parity
+    gmgk::CollSeg* d_segs = nullptr;
+    std::vector<int> pack_at, pack_n, unpack_at, unpack_n, blocks;      // ranges in d_segs: pack [kind], unpack [kind * 2 + parity]; blocks per segment [kind]
+    int* d_idx = nullptr;
+    void* lib = nullptr;                                  // librccl
+    void* comm = nullptr;                                 // ncclComm_t
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    gmgk::P2POp* d_ops = nullptr;                         // emulation: contiguous push of the chunk into every peer's gathered buffer, [(kind * 2 + parity) * n_peers + j]
+    std::vector<void*> peer_recv;                         // the peers' gathered buffers mapped here (ascending rank)
 };
 
 struct DistP2P {
@@ -63,16 +84,10 @@ struct DistP2P {
     std::vector<unsigned long long> kind_count;           // exchanges done per kind (parity = count & 1)
     unsigned long long seq = 0;                           // exchanges done in all (the arrival counters carry it)
     std::map<std::string, double> stats;
+    CollBackend coll;
 };
 
 namespace {
-
-inline int p2p_owner(const LevelOrdering& o, int world, int row, int* colour_out) {
-    int c = (int)(std::upper_bound(o.color_begin.begin(), o.color_begin.end(), row) - o.color_begin.begin()) - 1;
-    const int piece = (o.color_begin[c + 1] - o.color_begin[c]) / world;
-    if (colour_out) *colour_out = c;
-    return piece > 0 ? (row - o.color_begin[c]) / piece : 0;
-}
 
 void p2p_release(gmg_handle h) {
     DistP2P* p = h->p2p;
@@ -89,13 +104,56 @@ void p2p_release(gmg_handle h) {
     if (p->d_done) (void)sync_hipFree(p->d_done);
     if (p->d_sums) (void)sync_hipFree(p->d_sums);
     if (p->d_l1) (void)sync_hipFree(p->d_l1);
+    CollBackend& cb = p->coll;
+    for (void* q : cb.peer_recv) if (q) (void)hipIpcCloseMemHandle(q);
+    if (cb.comm && cb.comm_destroy) (void)cb.comm_destroy(cb.comm);
+    for (void* q : {(void*)cb.send, (void*)cb.recv, (void*)cb.d_segs, (void*)cb.d_idx, (void*)cb.d_ops}) if (q) (void)sync_hipFree(q);
     delete p;
     h->p2p = nullptr;
+}
+
+// The all-gather of the collective backend: every rank's chunk of `kind` (cb.send) into every rank's gathered buffer (parity half).
+int coll_all_gather(gmg_handle h, int kind, int parity) {
+    DistP2P* p = h->p2p;
+    CollBackend& cb = p->coll;
+    const int np = p->world - 1;
+    const long long chunk = cb.chunk[kind];
+    double* gathered = cb.recv + (size_t)parity * p->world * cb.max_chunk;
+    if (cb.mode == 1) {
+        const int rc = cb.all_gather(cb.send, gathered, (size_t)chunk, /*ncclFloat64*/ 8, cb.comm, h->stream);
+        if (rc != 0) return fail(h, GMG_ERR_HIP, std::string("ncclAllGather: ") + (cb.error_string ? cb.error_string(rc) : "failed"));
+        return GMG_OK;
+    }
+    // emulated: one launch -- per peer, blocks store this rank's chunk into the peer's gathered buffer and publish the sequence number; per
+    // peer, a block waits for that peer's number (gmgk::p2p_exchange on contiguous ops with nothing to copy on the pull side)
+    const int B = (int)std::min<long long>(64, std::max<long long>(1, (chunk + 4095) / 4096));
+    hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np * B), dim3(256), 0, h->stream, cb.d_ops + (size_t)(kind * 2 + parity) * np, np, cb.send, 0, 1, p->seq, p->d_err, B, p->d_done);
+    return GMG_OK;
+}
+
+// One exchange through the collective backend: pack -> all-gather -> unpack, three launches on the engine's stream.
+int coll_exchange(gmg_handle h, int kind, double* vec, int ld) {
+    DistP2P* p = h->p2p;
+    CollBackend& cb = p->coll;
+    const int parity = (int)(p->kind_count[kind]++ & 1);
+    ++p->seq;
+    const int B = cb.blocks[kind];
+    if (cb.pack_n[kind] > 0)
+        hipLaunchKernelGGL(gmgk::coll_pack, dim3(cb.pack_n[kind] * B), dim3(256), 0, h->stream, cb.d_segs + cb.pack_at[kind], cb.pack_n[kind], (const double*)vec, ld, p->d, cb.send, B);
+    int rc = coll_all_gather(h, kind, parity);
+    if (rc) return rc;
+    const int u = kind * 2 + parity;
+    if (cb.unpack_n[u] > 0) {
+        if (cb.mode == 2) hipLaunchKernelGGL(gmgk::coll_unpack<true>, dim3(cb.unpack_n[u] * B), dim3(256), 0, h->stream, cb.d_segs + cb.unpack_at[u], cb.unpack_n[u], (const double*)cb.recv, vec, ld, p->d, B);
+        else hipLaunchKernelGGL(gmgk::coll_unpack<false>, dim3(cb.unpack_n[u] * B), dim3(256), 0, h->stream, cb.d_segs + cb.unpack_at[u], cb.unpack_n[u], (const double*)cb.recv, vec, ld, p->d, B);
+    }
+    return GMG_OK;
 }
 
 // One exchange of kind `kind` on vector `vec` (leading dimension ld) -- or nothing with a single rank.
 int p2p_exchange(gmg_handle h, int kind, double* vec, int ld) {
     DistP2P* p = h->p2p;
+    if (p->world > 1 && p->coll.mode != 0) return coll_exchange(h, kind, vec, ld);
     const int np = (int)p->peers.size();
     if (np == 0) return GMG_OK;
     const int parity = (int)(p->kind_count[kind]++ & 1);
@@ -112,6 +170,142 @@ const std::vector<int>* p2p_list(const DistP2P* p, int C, int s, int t, int k) {
     if (k == C + 3 && p->shard1) return &p->halo1[(size_t)s * p->world + t];
     if (k == C + 5 && p->shard1) return &p->halo0r[(size_t)s * p->world + t];
     return nullptr;
+}
+
+// ---- collective backend: chunk sizes, segment tables and buffers (all ranks derive the same numbers from the plan)
+int coll_build(gmg_handle h) {
+    DistP2P* p = h->p2p;
+    CollBackend& cb = p->coll;
+    cb.mode = p->world > 1 ? h->cfg.dist_exchange : 0;
+    if (cb.mode == 0) return GMG_OK;
+    const int world = p->world, rank = p->rank, d = p->d, nk = p->nk, C = h->lv[0].ord.n_colors;
+    const LevelOrdering& o = h->lv[0].ord;
+    const int own_rows = h->lv[0].n_pad / world;
+    auto up8 = [](long long v) { return (v + 7) / 8 * 8; };
+    // ---- index lists: every (source, destination) list of every listed kind, the level-0 rows of every rank, the level-1 rows of every rank
+    std::vector<int> idx;
+    std::vector<size_t> list_at((size_t)world * world * nk, 0), rows0_at(world, 0), rows1_at(world, 0);
+    std::vector<int> rows1_n(world, 0);
+    for (int k = 0; k < nk; ++k)
+        for (int s = 0; s < world; ++s)
+            for (int t = 0; t < world; ++t) {
+                const std::vector<int>* l = s == t ? nullptr : p2p_list(p, C, s, t, k);
+                if (!l || (s != rank && t != rank)) continue;                      // (this rank packs its own lists and unpacks the ones addressed to it)
+                list_at[((size_t)s * world + t) * nk + k] = idx.size();
+                idx.insert(idx.end(), l->begin(), l->end());
+            }
+    for (int s = 0; s < world; ++s) {
+        rows0_at[s] = idx.size();
+        for (int c = 0; c < C; ++c) {
+            const int cnt = (o.color_begin[c + 1] - o.color_begin[c]) / world, lo = o.color_begin[c] + s * cnt;
+            for (int i = 0; i < cnt; ++i) idx.push_back(lo + i);
+        }
+    }
+    if (p->shard1)
+        for (int s = 0; s < world; ++s) {
+            rows1_at[s] = idx.size();
+            for (int b : p->own_blocks[s]) for (int i = 0; i < 64; ++i) idx.push_back(64 * b + i);
+            rows1_n[s] = 64 * (int)p->own_blocks[s].size();
+        }
+    // ---- chunk of every kind: the largest contribution of any rank
+    cb.chunk.assign(nk, 0);
+    for (int k = 0; k < nk; ++k) {
+        long long most = 0;
+        if (k == C + 1) most = (long long)own_rows * d;
+        else if (k == C + 2) most = 8;                                              // 2 d norm sums (d <= 4)
+        else if (k == C + 4) { if (p->shard1) for (int s = 0; s < world; ++s) most = std::max<long long>(most, (long long)rows1_n[s] * d); }
+        else
+            for (int s = 0; s < world; ++s) {
+                long long tot = 0;
+                for (int t = 0; t < world; ++t) if (t != s) if (const std::vector<int>* l = p2p_list(p, C, s, t, k)) tot += (long long)l->size() * d;
+                most = std::max(most, tot);
+            }
+        cb.chunk[k] = up8(most);
+        cb.max_chunk = std::max(cb.max_chunk, cb.chunk[k]);
+    }
+    cb.max_chunk = std::max<long long>(cb.max_chunk, 8);
+    // ---- segment tables
+    struct Seg { size_t at; int n; long long off; };
+    std::vector<Seg> segs;
+    cb.pack_at.assign(nk, 0); cb.pack_n.assign(nk, 0); cb.unpack_at.assign((size_t)nk * 2, 0); cb.unpack_n.assign((size_t)nk * 2, 0); cb.blocks.assign(nk, 1);
+    for (int k = 0; k < nk; ++k) {
+        long long most = 0;
+        const bool rows0 = k == C + 1, rows1 = k == C + 4 && p->shard1, listed = p2p_list(p, C, rank, (rank + 1) % world, k) != nullptr;
+        cb.pack_at[k] = (int)segs.size();
+        if (rows0) segs.push_back({rows0_at[rank], own_rows, 0});
+        else if (rows1) segs.push_back({rows1_at[rank], rows1_n[rank], 0});
+        else if (listed) {
+            long long off = 0;
+            for (int t = 0; t < world; ++t) {
+                if (t == rank) continue;
+                const std::vector<int>* l = p2p_list(p, C, rank, t, k);
+                segs.push_back({list_at[((size_t)rank * world + t) * nk + k], (int)l->size(), off});
+                off += (long long)l->size() * d;
+            }
+        }
+        cb.pack_n[k] = (int)segs.size() - cb.pack_at[k];
+        for (int par = 0; par < 2; ++par) {
+            const long long base = (long long)par * world * cb.max_chunk;
+            cb.unpack_at[(size_t)k * 2 + par] = (int)segs.size();
+            for (int s = 0; s < world && (rows0 || rows1 || listed); ++s) {
+                if (s == rank) continue;
+                if (rows0) segs.push_back({rows0_at[s], own_rows, base + (long long)s * cb.chunk[k]});
+                else if (rows1) segs.push_back({rows1_at[s], rows1_n[s], base + (long long)s * cb.chunk[k]});
+                else {
+                    long long off = 0;
+                    for (int t = 0; t < rank; ++t) if (t != s) off += (long long)p2p_list(p, C, s, t, k)->size() * d;
+                    const std::vector<int>* l = p2p_list(p, C, s, rank, k);
+                    segs.push_back({list_at[((size_t)s * world + rank) * nk + k], (int)l->size(), base + (long long)s * cb.chunk[k] + off});
+                }
+            }
+            cb.unpack_n[(size_t)k * 2 + par] = (int)segs.size() - cb.unpack_at[(size_t)k * 2 + par];
+        }
+        for (int q = cb.pack_at[k]; q < (int)segs.size(); ++q) most = std::max<long long>(most, (long long)segs[q].n * d);
+        cb.blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 4095) / 4096));
+    }
+    HIPCHK(hipMalloc((void**)&cb.d_idx, sizeof(int) * std::max<size_t>(idx.size(), 1)));
+    HIPCHK(hipMemcpy(cb.d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
+    std::vector<gmgk::CollSeg> dev(segs.size());
+    for (size_t q = 0; q < segs.size(); ++q) dev[q] = gmgk::CollSeg{cb.d_idx + segs[q].at, segs[q].n, segs[q].off};
+    HIPCHK(hipMalloc((void**)&cb.d_segs, sizeof(gmgk::CollSeg) * std::max<size_t>(dev.size(), 1)));
+    HIPCHK(hipMemcpy(cb.d_segs, dev.data(), sizeof(gmgk::CollSeg) * dev.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&cb.send, sizeof(double) * (size_t)cb.max_chunk));
+    const size_t recv_doubles = (size_t)2 * world * cb.max_chunk;
+    if (cb.mode == 2) HIPCHK(hipExtMallocWithFlags((void**)&cb.recv, sizeof(double) * recv_doubles, hipDeviceMallocFinegrained));
+    else HIPCHK(hipMalloc((void**)&cb.recv, sizeof(double) * recv_doubles));
+    HIPCHK(hipMemsetAsync(cb.send, 0, sizeof(double) * (size_t)cb.max_chunk, h->stream));
+    HIPCHK(hipMemsetAsync(cb.recv, 0, sizeof(double) * recv_doubles, h->stream));
+    p->stats["collective_chunk_doubles_max"] = (double)cb.max_chunk;
+    return GMG_OK;
+}
+
+// librccl, loaded at run time (the library does not link against it: a box without RCCL still runs the peer-to-peer path)
+struct RcclApi {
+    void* lib = nullptr;
+    struct UniqueId { char internal[128]; };
+    int (*get_unique_id)(UniqueId*) = nullptr;
+    int (*comm_init_rank)(void**, int, UniqueId, int) = nullptr;
+    int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*comm_destroy)(void*) = nullptr;
+    const char* (*error_string)(int) = nullptr;
+    bool ok() const { return lib && get_unique_id && comm_init_rank && all_gather && comm_destroy; }
+};
+RcclApi& rccl_api() {
+    static RcclApi* api = [] {
+        RcclApi* a = new RcclApi();
+        // the copy a host application (PyTorch) has loaded already, else the system's
+        for (const char* name : {"librccl.so", "librccl.so.1"}) if (!a->lib) a->lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!a->lib) a->lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (a->lib) {
+            a->get_unique_id = (int (*)(RcclApi::UniqueId*))dlsym(a->lib, "ncclGetUniqueId");
+            a->comm_init_rank = (int (*)(void**, int, RcclApi::UniqueId, int))dlsym(a->lib, "ncclCommInitRank");
+            a->all_gather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(a->lib, "ncclAllGather");
+            a->comm_destroy = (int (*)(void*))dlsym(a->lib, "ncclCommDestroy");
+            a->error_string = (const char* (*)(int))dlsym(a->lib, "ncclGetErrorString");
+        }
+        return a;
+    }();
+    return *api;
 }
 
 }  // namespace
@@ -141,100 +335,42 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     p->kind_count.assign(p->nk, 0);
     p->own_lo.resize(C); p->own_cnt.resize(C);
     for (int c = 0; c < C; ++c) { p->own_cnt[c] = (o.color_begin[c + 1] - o.color_begin[c]) / world; p->own_lo[c] = o.color_begin[c] + rank * p->own_cnt[c]; }
-    // level 1 is partitioned too when it runs the entry-parallel block sweep (big levels: 64-row blocks, block b = rows 64 b ..) with
-    // replicated levels below it, and the restriction's sorting windows do not straddle blocks
-    p->shard1 = world > 1 && h->cfg.dist_shard_levels >= 2 && h->L >= 2 && h->lv[1].ord.blocked && h->lv[1].use_ep &&
-                h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS && (h->cfg.restrict_sigma == 0 || h->cfg.restrict_sigma == 64);
-    if (p->shard1) {
-        const LevelOrdering& o1 = h->lv[1].ord;
-        for (int b = 0; b <= o1.n_blocks() && p->shard1; ++b) if (o1.blk_begin[b] != 64 * b) p->shard1 = false;
-    }
-    // ---- who reads what: for every row r (owner t) and every entry (r, c) with owner(c) = s != t, s publishes c to t
-    p->halo.assign((size_t)world * world * (C + 1), std::vector<int>());
-    p->halo1.assign((size_t)world * world, std::vector<int>());
-    p->halo0r.assign((size_t)world * world, std::vector<int>());
-    auto sort_unique = [](std::vector<int>& v) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); };
-    if (world > 1) {
-        if ((rc = ensure_host_A(h, 0, false))) return rc;
-        const Compressed& A = l.A;
-        std::vector<int> owner(l.n_pad), colour(l.n_pad);
-        parallel_ranges(l.n_pad, h->cfg.host_threads, [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) owner[r] = p2p_owner(o, world, r, &colour[r]); });
-        const int T = std::max(1, std::min(h->cfg.host_threads, 16));
-        std::vector<std::vector<std::vector<int>>> part(T, std::vector<std::vector<int>>((size_t)world * world));
-        parallel_ranges(l.n, T, [&](int lo, int hi, int t) {
-            auto& mine = part[std::min(t, T - 1)];
-            for (int i = lo; i < hi; ++i) {
-                const int r = o.old2new[i], tr = owner[r];
-                for (int q = A.ptr[i]; q < A.ptr[i + 1]; ++q) {
-                    const int c = o.old2new[A.idx[q]], s = owner[c];
-                    if (s != tr) mine[(size_t)s * world + tr].push_back(c);
-                }
-            }
-        }, 1);
-        for (int s = 0; s < world; ++s)
-            for (int t = 0; t < world; ++t) {
-                if (s == t) continue;
-                std::vector<int> all;
-                for (int w = 0; w < T; ++w) { auto& v = part[w][(size_t)s * world + t]; all.insert(all.end(), v.begin(), v.end()); }
-                sort_unique(all);
-                for (int c : all) p->halo[((size_t)s * world + t) * (C + 1) + colour[c]].push_back(c);
-                p->halo[((size_t)s * world + t) * (C + 1) + C] = all;
-            }
-        if (p->shard1) {
-            Level& l1 = h->lv[1];
-            const LevelOrdering& o1 = l1.ord;
-            const Compressed& U0 = h->U[0];                       // CSC: one column per coarse point, rows = fine points
-            const int nb = o1.n_blocks();
-            // block -> the rank that owns most of the fine rows its points prolong into (ties: the lowest rank)
-            std::vector<int> votes((size_t)nb * world, 0);
-            for (int jc = 0; jc < U0.n_outer; ++jc) {
-                const int blk = o1.old2new[jc] >> 6;
-                for (int q = U0.ptr[jc]; q < U0.ptr[jc + 1]; ++q) ++votes[(size_t)blk * world + owner[o.old2new[U0.idx[q]]]];
-            }
-            p->blk_owner.resize(nb);
-            p->own_blocks.assign(world, std::vector<int>());
-            for (int b = 0; b < nb; ++b) {
-                const int* v = &votes[(size_t)b * world];
-                p->blk_owner[b] = (int)(std::max_element(v, v + world) - v);
-                p->own_blocks[p->blk_owner[b]].push_back(b);
-            }
-            auto owner1 = [&](int row) { return p->blk_owner[row >> 6]; };
-            // x1 entries read through A1 (sweeps, residual) or through U0 (prolongation into another rank's fine rows), and r0 entries
-            // read through U0^T (restriction into another rank's coarse rows)
-            if ((rc = ensure_host_A(h, 1, false))) return rc;
-            const Compressed& A1 = l1.A;
-            for (int i = 0; i < l1.n; ++i) {
-                const int tr = owner1(o1.old2new[i]);
-                for (int q = A1.ptr[i]; q < A1.ptr[i + 1]; ++q) {
-                    const int c = o1.old2new[A1.idx[q]], s = owner1(c);
-                    if (s != tr) p->halo1[(size_t)s * world + tr].push_back(c);
-                }
-            }
-            for (int jc = 0; jc < U0.n_outer; ++jc) {
-                const int c = o1.old2new[jc], s1 = owner1(c);
-                for (int q = U0.ptr[jc]; q < U0.ptr[jc + 1]; ++q) {
-                    const int rf = o.old2new[U0.idx[q]], t0 = owner[rf];
-                    if (t0 == s1) continue;
-                    p->halo1[(size_t)s1 * world + t0].push_back(c);       // rank t0 prolongs into fine row rf: reads x1[c]
-                    p->halo0r[(size_t)t0 * world + s1].push_back(rf);     // rank s1 restricts into coarse row c: reads r0[rf]
-                }
-            }
-            for (auto& v : p->halo1) sort_unique(v);
-            for (auto& v : p->halo0r) sort_unique(v);
-            // this rank's launch tables
-            const std::vector<int>& mine = p->own_blocks[rank];
-            const int rps_r = 64 / l.R.lpr, rps_a = 64 / l1.Aoff.lpr, rps_p = 64 / l1.P.lpr;
-            std::vector<int> tab;
-            for (int b : mine) tab.push_back(o1.blk_begin[b]);
-            for (int b : mine) tab.push_back(o1.blk_ncolors[b]);
-            for (int rps : {rps_r, rps_a, rps_p}) for (int b : mine) for (int q = 0; q < 64 / rps; ++q) tab.push_back(b * (64 / rps) + q);
-            HIPCHK(hipMalloc((void**)&p->d_l1, sizeof(int) * std::max<size_t>(tab.size(), 1)));
-            if (!tab.empty()) HIPCHK(hipMemcpy(p->d_l1, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
-            const int nm = (int)mine.size();
-            p->d_own_begin = p->d_l1; p->d_own_ncolors = p->d_l1 + nm;
-            p->n_rsl = nm * (64 / rps_r); p->n_asl = nm * (64 / rps_a); p->n_psl = nm * (64 / rps_p);
-            p->d_rsl = p->d_l1 + 2 * nm; p->d_asl = p->d_rsl + p->n_rsl; p->d_psl = p->d_asl + p->n_asl;
+    // ---- who owns and who reads what (engine_part.hip.hpp::build_dist_plan).  A partitioned set-up (gmg_dist_partition) made the plan while it
+    // had the patterns at hand -- its level-0 / level-1 operators hold this rank's rows only, the natural copies are gone; otherwise it is made
+    // now from host copies of the patterns
+    std::shared_ptr<DistPlan> plan;
+    if (h->partitioned) {
+        if (!h->plan || h->plan->rank != rank || h->plan->world != world) return fail(h, GMG_ERR_STATE, "the system was partitioned for another rank / world size (gmg_dist_partition)");
+        plan = h->plan;
+    } else {
+        plan = std::make_shared<DistPlan>();
+        const bool shard1 = plan_can_shard_level1(h, world, true);
+        if (world > 1) {
+            if ((rc = ensure_host_A(h, 0, false))) return rc;
+            if (shard1 && (rc = ensure_host_A(h, 1, false))) return rc;
         }
+        const Compressed& A0 = l.A;
+        if ((rc = build_dist_plan(h, *plan, rank, world, PatternView{A0.n_outer, A0.ptr.data(), A0.idx.data()}, shard1 ? &h->lv[1].A : nullptr, shard1))) return rc;
+    }
+    p->shard1 = plan->shard1;
+    p->halo = plan->halo; p->halo1 = plan->halo1; p->halo0r = plan->halo0r;
+    p->blk_owner = plan->blk_owner; p->own_blocks = plan->own_blocks;
+    if (p->shard1) {
+        // this rank's launch tables
+        Level& l1 = h->lv[1];
+        const LevelOrdering& o1 = l1.ord;
+        const std::vector<int>& mine = p->own_blocks[rank];
+        const int rps_r = 64 / l.R.lpr, rps_a = 64 / l1.Aoff.lpr, rps_p = 64 / l1.P.lpr;
+        std::vector<int> tab;
+        for (int b : mine) tab.push_back(o1.blk_begin[b]);
+        for (int b : mine) tab.push_back(o1.blk_ncolors[b]);
+        for (int rps : {rps_r, rps_a, rps_p}) for (int b : mine) for (int q = 0; q < 64 / rps; ++q) tab.push_back(b * (64 / rps) + q);
+        HIPCHK(hipMalloc((void**)&p->d_l1, sizeof(int) * std::max<size_t>(tab.size(), 1)));
+        if (!tab.empty()) HIPCHK(hipMemcpy(p->d_l1, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+        const int nm = (int)mine.size();
+        p->d_own_begin = p->d_l1; p->d_own_ncolors = p->d_l1 + nm;
+        p->n_rsl = nm * (64 / rps_r); p->n_asl = nm * (64 / rps_a); p->n_psl = nm * (64 / rps_p);
+        p->d_rsl = p->d_l1 + 2 * nm; p->d_asl = p->d_rsl + p->n_rsl; p->d_psl = p->d_asl + p->n_asl;
     }
     // ---- mailbox layout of every rank: region (src, kind, parity) in dst's mailbox
     const long long own_rows = (long long)l.n_pad / world;
@@ -266,6 +402,8 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
         if (sec > 0.0) { const unsigned long long ticks = (unsigned long long)(sec * 1e8); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gmgk::g_p2p_timeout_ticks), &ticks, sizeof(ticks))); }
     }
     HIPCHK(hipMalloc((void**)&p->d_sums, sizeof(double) * 4 * d));
+    if (!p->d_done) { HIPCHK(hipMalloc((void**)&p->d_done, sizeof(unsigned int) * world)); HIPCHK(hipMemset(p->d_done, 0, sizeof(unsigned int) * world)); }
+    if ((rc = coll_build(h))) return rc;                  // gmg_config::dist_exchange != 0: chunk sizes, segment tables, buffers
     HIPCHK(hipStreamSynchronize(h->stream));
     p->planned = true;
     auto published = [&](int k) { double n = 0; for (int t = 0; t < world; ++t) if (t != rank) if (const std::vector<int>* v = p2p_list(p, C, rank, t, k)) n += (double)v->size(); return n; };
@@ -286,7 +424,8 @@ int gmg_p2p_export(gmg_handle h, void* blob_out) try {
     HIPCHK(hipIpcGetMemHandle(&b.mbox, p->mbox));
     HIPCHK(hipIpcGetMemHandle(&b.flags, p->flags));
     b.rank = p->rank; b.world = p->world; b.d = p->d; b.n_pad = h->lv[0].n_pad; b.n_colors = h->lv[0].ord.n_colors; b.mbox_doubles = p->box_total[p->rank];
-    b.reserved = p->shard1 ? 1 : 0;
+    b.reserved = (p->shard1 ? 1 : 0) | (p->coll.mode << 4);
+    if (p->coll.mode == 2) { HIPCHK(hipIpcGetMemHandle(&b.coll, p->coll.recv)); b.coll_doubles = 2LL * p->world * p->coll.max_chunk; }
     std::memcpy(blob_out, &b, sizeof(b));
     return GMG_OK;
 } GMG_CATCH_H
@@ -308,7 +447,10 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     };
     for (auto& peer : p->peers) close_peer(peer);
     p->peers.clear();
+    for (void*& q : p->coll.peer_recv) { if (q) (void)hipIpcCloseMemHandle(q); q = nullptr; }
+    p->coll.peer_recv.clear();
     p->connected = false;
+    if (p->coll.mode == 1) return fail(h, GMG_ERR_STATE, "this handle exchanges through RCCL (gmg_config::dist_exchange = 1): connect it with gmg_p2p_connect_rccl");
     {   // peer access to every other visible device (the IPC mapping below enables it lazily as well; "already enabled" and "not
         // supported" are both fine here -- an unreachable peer shows up in hipIpcOpenMemHandle)
         int ndev = 0;
@@ -322,7 +464,7 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
         P2PPeer peer;
         peer.rank = q;
         if (bl[q].rank != q || bl[q].world != world || bl[q].d != d || bl[q].n_pad != h->lv[0].n_pad || bl[q].n_colors != C || bl[q].mbox_doubles != p->box_total[q] ||
-            bl[q].reserved != (p->shard1 ? 1 : 0))
+            bl[q].reserved != ((p->shard1 ? 1 : 0) | (p->coll.mode << 4)) || (p->coll.mode == 2 && bl[q].coll_doubles != 2LL * world * p->coll.max_chunk))
             return fail(h, GMG_ERR_INVALID, "peer " + std::to_string(q) + " published a different partition plan (different system / ordering / configuration?)");
         // (every mapping that was opened is in p->peers -- or closed -- before an error leaves this function: p2p_release sees it)
         if (hipIpcOpenMemHandle(&peer.mbox_base, bl[q].mbox, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
@@ -335,9 +477,36 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
             return fail(h, GMG_ERR_HIP, "hipIpcOpenMemHandle failed for the arrival counters of rank " + std::to_string(q));
         }
         p->peers.push_back(peer);
+        if (p->coll.mode == 2) {
+            void* base = nullptr;
+            if (hipIpcOpenMemHandle(&base, bl[q].coll, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+                (void)hipGetLastError();
+                return fail(h, GMG_ERR_HIP, "hipIpcOpenMemHandle failed for the gathered buffer of rank " + std::to_string(q));
+            }
+            p->coll.peer_recv.push_back(base);
+        }
     }
     const int np = (int)p->peers.size();
     if (np == 0) { p->connected = true; return GMG_OK; }
+    if (p->coll.mode == 2) {
+        // the emulated all-gather: per (kind, parity, peer) one contiguous push of this rank's chunk into slot `rank` of the peer's gathered buffer
+        CollBackend& cb = p->coll;
+        std::vector<gmgk::P2POp> cops((size_t)nk * 2 * np);
+        for (int k = 0; k < nk; ++k)
+            for (int par = 0; par < 2; ++par)
+                for (int j = 0; j < np; ++j) {
+                    gmgk::P2POp& op = cops[(size_t)(k * 2 + par) * np + j];
+                    const int q = p->peers[j].rank;
+                    op.send_idx = op.recv_idx = nullptr; op.send_lo = op.recv_lo = 0; op.n_recv = 0; op.local_box = nullptr;
+                    op.n_send = (int)cb.chunk[k];
+                    op.remote_box = (double*)cb.peer_recv[j] + (size_t)par * world * cb.max_chunk + (size_t)rank * cb.chunk[k];
+                    op.remote_flag = (unsigned long long*)p->peers[j].flag_base + 64 * (size_t)rank;
+                    op.local_flag = p->flags + 64 * (size_t)q;
+                }
+        if (cb.d_ops) { (void)sync_hipFree(cb.d_ops); cb.d_ops = nullptr; }
+        HIPCHK(hipMalloc((void**)&cb.d_ops, sizeof(gmgk::P2POp) * cops.size()));
+        HIPCHK(hipMemcpy(cb.d_ops, cops.data(), sizeof(gmgk::P2POp) * cops.size(), hipMemcpyHostToDevice));
+    }
     // ---- all index lists in one device array: per (peer, listed kind) the rows sent and the rows received; then the level-0 rows
     // of every rank (piece s of every colour, in device order)
     std::vector<int> idx;
@@ -409,10 +578,41 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
             for (int j = 0; j < np; ++j) { const gmgk::P2POp& op = ops[(size_t)(k * 2 + par) * np + j]; most = std::max<long long>(most, (long long)std::max(op.n_send, op.n_recv) * d); }
         p->kind_blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 4095) / 4096));
     }
-    if (!p->d_done) { HIPCHK(hipMalloc((void**)&p->d_done, sizeof(unsigned int) * world)); HIPCHK(hipMemset(p->d_done, 0, sizeof(unsigned int) * world)); }
     if (p->d_ops) { (void)sync_hipFree(p->d_ops); p->d_ops = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_ops, sizeof(gmgk::P2POp) * ops.size()));
     HIPCHK(hipMemcpy(p->d_ops, ops.data(), sizeof(gmgk::P2POp) * ops.size(), hipMemcpyHostToDevice));
+    p->connected = true;
+    return GMG_OK;
+} GMG_CATCH_H
+
+// RCCL transport of the collective backend (gmg_config::dist_exchange = 1).  Rank 0 makes the id, the caller hands its 128 bytes to every rank
+// (torch.distributed broadcast_object_list, MPI_Bcast, a file), every rank calls gmg_p2p_connect_rccl after gmg_p2p_prepare.  No hipIpc involved.
+int gmg_p2p_rccl_unique_id(void* id_out) try {
+    if (!id_out) return GMG_ERR_INVALID;
+    RcclApi& api = rccl_api();
+    if (!api.ok()) return GMG_ERR_UNSUPPORTED;
+    RcclApi::UniqueId id;
+    if (api.get_unique_id(&id) != 0) return GMG_ERR_HIP;
+    std::memcpy(id_out, &id, sizeof(id));
+    return GMG_OK;
+} GMG_CATCH_0
+
+int gmg_p2p_connect_rccl(gmg_handle h, const void* id_in) try {
+    NEED_DEVICE();
+    DistP2P* p = h->p2p;
+    if (!p || !p->planned || !id_in) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare first");
+    if (p->world > 1 && p->coll.mode != 1) return fail(h, GMG_ERR_STATE, "create the handle with gmg_config::dist_exchange = 1 to exchange through RCCL");
+    if (p->world <= 1) { p->connected = true; return GMG_OK; }
+    RcclApi& api = rccl_api();
+    if (!api.ok()) return fail(h, GMG_ERR_UNSUPPORTED, "librccl could not be loaded (ncclGetUniqueId / ncclCommInitRank / ncclAllGather)");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    CollBackend& cb = p->coll;
+    if (cb.comm && cb.comm_destroy) { (void)cb.comm_destroy(cb.comm); cb.comm = nullptr; }
+    RcclApi::UniqueId id;
+    std::memcpy(&id, id_in, sizeof(id));
+    const int rc = api.comm_init_rank(&cb.comm, p->world, id, p->rank);
+    if (rc != 0) { cb.comm = nullptr; return fail(h, GMG_ERR_HIP, std::string("ncclCommInitRank: ") + (api.error_string ? api.error_string(rc) : "failed")); }
+    cb.all_gather = api.all_gather; cb.comm_destroy = api.comm_destroy; cb.error_string = api.error_string;
     p->connected = true;
     return GMG_OK;
 } GMG_CATCH_H
@@ -591,7 +791,18 @@ int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
         double sums[8];
         if ((rc = dist_norm_launch(h, stop_type))) return rc;                // this rank's rows -> h->d_norm
         const double* d_result = h->d_norm;
-        if (np > 0) {
+        if (p->world > 1 && p->coll.mode != 0) {
+            // collective backend: every rank's 2 d sums all-gathered, then added in rank order (the same bits everywhere)
+            CollBackend& cb = p->coll;
+            const int kind = C + 2, parity = (int)(p->kind_count[kind]++ & 1);
+            ++p->seq;
+            HIPCHK(hipMemcpyAsync(cb.send, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToDevice, h->stream));
+            if ((rc = coll_all_gather(h, kind, parity))) return rc;
+            const double* gathered = cb.recv + (size_t)parity * p->world * cb.max_chunk;
+            if (cb.mode == 2) hipLaunchKernelGGL(gmgk::coll_sum_ranks<true>, dim3(1), dim3(64), 0, h->stream, gathered, cb.chunk[kind], p->world, p->rank, (const double*)h->d_norm, 2 * d, p->d_sums);
+            else hipLaunchKernelGGL(gmgk::coll_sum_ranks<false>, dim3(1), dim3(64), 0, h->stream, gathered, cb.chunk[kind], p->world, p->rank, (const double*)h->d_norm, 2 * d, p->d_sums);
+            d_result = p->d_sums;
+        } else if (np > 0) {
             const int kind = C + 2, parity = (int)(p->kind_count[kind]++ & 1);
             ++p->seq;
             hipLaunchKernelGGL(gmgk::p2p_allreduce_small, dim3(1), dim3(64), 0, h->stream, p->d_ops + (size_t)(kind * 2 + parity) * np, np, p->rank,
@@ -692,8 +903,6 @@ int gmg_p2p_bench_kind(gmg_handle h, const char* kind_name, int reps, double* ms
     return GMG_OK;
 } GMG_CATCH_H
 
-int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg) { return gmg_p2p_bench_kind(h, "color0", reps, ms_avg); }
-
 // 0 (default): exact multicolour Gauss-Seidel on level 0, one exchange per colour (iterates independent of the rank count);
 // 1: hybrid -- Gauss-Seidel inside a rank, Jacobi across ranks, ONE exchange per sweep.  Collective in the sense that every rank must choose the same.
 int gmg_p2p_set_smoother(gmg_handle h, int hybrid) try {
@@ -706,6 +915,7 @@ int gmg_p2p_set_smoother(gmg_handle h, int hybrid) try {
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {
     if (!h || !h->p2p || !key || !out) return GMG_ERR_INVALID;
     if (std::string(key) == "device_bytes") { *out = (double)h->pool.live_bytes; return GMG_OK; }      // device memory this rank's handle holds (pool blocks in use)
+    if (std::string(key) == "device_bytes_peak") { *out = (double)h->pool.peak_live_bytes; return GMG_OK; }      // ... and its high-water mark since the last gmg_set_system began
     auto it = h->p2p->stats.find(key);
     if (it == h->p2p->stats.end()) return fail(h, GMG_ERR_INVALID, std::string("unknown key: ") + key);
     *out = it->second;

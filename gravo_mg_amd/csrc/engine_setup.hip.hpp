@@ -100,23 +100,28 @@ int build_ell3(gmg_handle h, DevEll3& e, const DevCsr& dU, int n_fine, int* d_er
 
 // Device copies of every U_k (by coarse column, and regrouped by fine row): built once per hierarchy.
 int ensure_device_transfers(gmg_handle h) {
-    if (h->dU_ready) return GMG_OK;
     const int L = h->L;
-    drop_device_transfers(h);
-    h->dU.assign(L, DevCsr());
-    h->dE3.assign(L, DevEll3());
+    bool complete = h->dU_ready && (int)h->dU.size() == L;
+    for (int k = 0; k < L && complete; ++k) complete = h->dU[k].ptr != nullptr;      // (a partitioned set-up releases U_0 when it is done)
+    if (complete) return GMG_OK;
+    if (!h->dU_ready || (int)h->dU.size() != L) {
+        drop_device_transfers(h);
+        h->dU.assign(L, DevCsr());
+        h->dE3.assign(L, DevEll3());
+    }
     DevTmp<int> d_err;
     int rc, herr = 0;
     if ((rc = d_err.alloc(h, 1))) return rc;
     HIPCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream));
     for (int k = 0; k < L; ++k) {
+        if (h->dU[k].ptr) continue;
         rc = upload_csr(h, h->dU[k], h->U[k]);
         if (rc == GMG_OK) rc = build_ell3(h, h->dE3[k], h->dU[k], h->U[k].n_inner, d_err.p);
         if (rc) return rc;
     }
     HIPCHK(hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));      // pageable host arrays have been consumed
-    h->dU_flagged = herr != 0;      // a U row with more than 3 entries: the device RAP / layout builder cannot take it
+    h->dU_flagged = h->dU_flagged || herr != 0;      // a U row with more than 3 entries: the device RAP / layout builder cannot take it
     h->dU_ready = true;
     return GMG_OK;
 }
@@ -284,9 +289,13 @@ void launch_csr_fill(gmg_handle h, Level& l, const DevCsr& dA, const gmgs::RowFi
 // Layout of level k (operator, split operator) and of the transfers k -> k+1, built on the device from Level::dA and the
 // device copies of U_k.  A row longer than gmgs::kMaxRow or a prolongation row with more than 3 entries raises *d_err:
 // the caller then falls back to the host planner.
-int device_layout_level(gmg_handle h, int k, int* d_err) {
+// own_rows / own_rows_next (partitioned set-up, engine_part.hip.hpp): masked copies of the row maps of level k / k + 1 -- new2old with -1 for the
+// rows of other ranks -- used for everything whose ROWS are that level's (operator, block-CSR parts, prolongation; restriction: level k + 1);
+// null = all rows.  The other ranks' rows come out as zero-width slices / empty chunks of the same global numbering.
+int device_layout_level(gmg_handle h, int k, int* d_err, const int* own_rows = nullptr, const int* own_rows_next = nullptr) {
     const int L = h->L;
     Level& l = h->lv[k];
+    const int* rows_k = own_rows ? own_rows : l.d_new2old;
     int rc;
     const bool trace = EnvSwitches::get().trace_setup;      // synchronising phase timers on stderr
     auto tph = clk::now();
@@ -311,7 +320,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     const DevCsr& dA = l.dA;
     if ((rc = upload(h, &d_old2new.p, l.ord.old2new))) return rc;
     phase("old2new");
-    gmgs::RowFilter f{l.d_new2old, d_old2new.p, nullptr, nullptr, 0, 1};
+    gmgs::RowFilter f{rows_k, d_old2new.p, nullptr, nullptr, 0, 1};
     const int lanes_auto = l.n < kQuadLevelRows ? 4 : 1;
     const int lpr = (l.ord.blocked && k > 0) ? (h->cfg.block_lanes ? h->cfg.block_lanes : lanes_auto) : 1;
     HIPCHK(dev_malloc((void**)&l.diag, sizeof(double) * l.n_pad));
@@ -322,13 +331,13 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         if ((rc = d_blk_of_row.alloc(h, l.n_pad)) || (rc = upload(h, &l.d_blk_begin, l.ord.blk_begin)) ||
             (rc = upload(h, &l.d_blk_ncolors, l.ord.blk_ncolors)) || (rc = upload(h, &l.d_row_color, l.ord.row_color))) return rc;
         hipLaunchKernelGGL(gmgs::block_of_rows, dim3(std::max(1, l.ord.n_blocks())), dim3(64), 0, h->stream, l.d_blk_begin, l.ord.n_blocks(), d_blk_of_row.p);
-        gmgs::RowFilter fin{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
-        gmgs::RowFilter fout{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
+        gmgs::RowFilter fin{rows_k, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 1, 1};
+        gmgs::RowFilter fout{rows_k, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 2, 1};
         if (wants_block_ep(h, lpr)) {
             // unpadded block sweep (gs_block_ep): "explicit" and "lower" parts as block-ordered CSRs.  Row pointers first:
             // the largest block's chunks size the sweep's LDS buffers
-            gmgs::RowFilter fe{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 3, 1};
-            gmgs::RowFilter fl{l.d_new2old, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 4, 1};
+            gmgs::RowFilter fe{rows_k, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 3, 1};
+            gmgs::RowFilter fl{rows_k, d_old2new.p, d_blk_of_row.p, l.d_blk_begin, 4, 1};
             DevTmp<int> len, d_max;
             int nnz_e = 0, nnz_l = 0, bmax[2] = {0, 0};
             if ((rc = len.alloc(h, l.n_pad)) || (rc = d_max.alloc(h, 2))) return rc;
@@ -393,6 +402,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
     if (k == L) return GMG_OK;
     // ---- transfers k <-> k+1
     Level& c = h->lv[k + 1];
+    const int* rows_c = own_rows_next ? own_rows_next : c.d_new2old;
     const DevCsr& dU = h->dU[k];
     const DevEll3& e3 = h->dE3[k];
     DevTmp<int> d_old2new_c, d_order, d_pbeg, d_pend;
@@ -405,7 +415,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
             int pow2 = 1;
             while (pow2 < sigma) pow2 <<= 1;
             if ((rc = d_order.alloc(h, np))) return rc;
-            hipLaunchKernelGGL(gmgs::window_order_by_length, dim3((np + sigma - 1) / sigma), dim3(256), 0, h->stream, dU.ptr, c.d_new2old, np, sigma, pow2, d_order.p);
+            hipLaunchKernelGGL(gmgs::window_order_by_length, dim3((np + sigma - 1) / sigma), dim3(256), 0, h->stream, dU.ptr, rows_c, np, sigma, pow2, d_order.p);
         } else if (sigma > 0) {
             std::vector<int> order(np);
             auto len_of = [&](int r) { int old = c.ord.new2old[r]; return old >= 0 ? U.ptr[old + 1] - U.ptr[old] : 0; };
@@ -419,7 +429,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
             HIPCHK(hipStreamSynchronize(h->stream));      // `order` (pageable) dies at scope end
         }
         phase("R order");
-        gmgs::RowFilter fr{c.d_new2old, d_old2new.p, nullptr, nullptr, 0, 0};
+        gmgs::RowFilter fr{rows_c, d_old2new.p, nullptr, nullptr, 0, 0};
         const int lpr_r = h->cfg.block_lanes == 1 ? 1 : 4;
         if ((rc = device_build_sell(h, l.R, dU.ptr, dU.ptr + 1, dU.idx, dU.val, fr, sigma > 0 ? d_order.p : nullptr, np, lpr_r, nullptr, nullptr, d_err))) return rc;
         l.R.nnz_real = U.nnz();
@@ -431,7 +441,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         const int nf = l.n;
         if ((rc = d_pbeg.alloc(h, nf)) || (rc = d_pend.alloc(h, nf))) return rc;
         hipLaunchKernelGGL(gmgs::ell3_ptr, dim3((nf + 255) / 256), dim3(256), 0, h->stream, e3.cnt, nf, d_pbeg.p, d_pend.p);
-        gmgs::RowFilter fp{l.d_new2old, d_old2new_c.p, nullptr, nullptr, 0, 0};
+        gmgs::RowFilter fp{rows_k, d_old2new_c.p, nullptr, nullptr, 0, 0};
         if ((rc = device_build_sell(h, l.P, d_pbeg.p, d_pend.p, e3.col, e3.val, fp, nullptr, l.n_pad, 1, nullptr, nullptr, d_err))) return rc;
         l.P.nnz_real = h->U[k].nnz();
     }
@@ -452,7 +462,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err) {
         HIPCHK(dev_malloc((void**)&op.win_base, sizeof(int) * (size_t)op.n_slices * nw));
         HIPCHK(hipMemsetAsync(d_c16.p + 2 * i, 0, 2 * sizeof(int), h->stream));
         const int* a_ptr = i == 0 ? dA.ptr : (const int*)nullptr;
-        const int* n2o = i == 0 ? l.d_new2old : (const int*)nullptr;
+        const int* n2o = i == 0 ? rows_k : (const int*)nullptr;
         if (nw == 8) hipLaunchKernelGGL(gmgs::compress_cols<8>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i);
         else hipLaunchKernelGGL(gmgs::compress_cols<32>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i);
         op.c16_dbits = nw == 8 ? 13 : 11;
@@ -549,6 +559,7 @@ bool fine_level_blocked(gmg_handle h, int n, const int* colptr, const int* rowid
     const gmg_config& c = h->cfg;
     if (c.smoother != GMG_SMOOTHER_MULTICOLOR_GS || c.block_rows <= 0 || h->L <= 0) return false;
     if (c.block_from_level <= 0) return true;
+    if (h->part_world > 1) return false;      // the partitioned multi-GPU cycle exchanges per colour: level 0 stays colour-major (gmg_dist_partition)
     if (!c.block_fine || c.block_rows != 64 || !c.block_ep || !c.block_csr || c.reorder_fine == 0) return false;
     if ((double)colptr[n] < kFineBlockMinRow * (double)n) return false;
     return stieltjes_signs(n, colptr, rowidx, val, c.host_threads);

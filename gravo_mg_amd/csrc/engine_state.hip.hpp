@@ -32,17 +32,20 @@ struct DevPool {
     std::multimap<size_t, void*> parked;
     std::map<void*, size_t> size_of;      // every block this pool handed out (live or parked)
     size_t parked_bytes = 0, live_bytes = 0;
+    size_t peak_live_bytes = 0;           // high-water mark of live_bytes since reset_peak() (a partitioned set-up holds whole operators for a while)
+    void reset_peak() { peak_live_bytes = live_bytes; }
     static size_t round_up(size_t b) { return (std::max<size_t>(b, 1) + 511) & ~(size_t)511; }
     hipError_t alloc(void** p, size_t bytes) {
         const size_t need = round_up(bytes);
         auto it = parked.lower_bound(need);
         if (it != parked.end() && it->first <= need + need / 8 + 65536) {
             *p = it->second; parked_bytes -= it->first; live_bytes += it->first; parked.erase(it);
+            peak_live_bytes = std::max(peak_live_bytes, live_bytes);
             return hipSuccess;
         }
         hipError_t e = hipMalloc(p, need);
         if (e != hipSuccess) { trim(); (void)hipGetLastError(); e = hipMalloc(p, need); }
-        if (e == hipSuccess) { size_of[*p] = need; live_bytes += need; }
+        if (e == hipSuccess) { size_of[*p] = need; live_bytes += need; peak_live_bytes = std::max(peak_live_bytes, live_bytes); }
         return e;
     }
     void release(void* p) {
@@ -139,12 +142,34 @@ struct Level {
 
 }  // namespace
 
+// The level-0 point graph a hierarchy was built from (`neigh` + the diagonal) as a canonical sparsity pattern (host_plan.hpp::neigh_pattern):
+// the pattern of every system the hierarchy is built for (tau M + S, M + tau S of that mesh / point cloud).  Shared, read-only.
+struct FineGraph {
+    int n = 0;
+    RawVec<int> ptr, idx;
+};
+
 struct gmg_hierarchy_s {
     HierarchyResult res;
+    std::shared_ptr<const FineGraph> graph;      // made beside the construction; gmg_use_hierarchy hands it to the engine (gmg_set_fine_graph does the same from a table)
     std::vector<int> fine_order;         // breadth-first order of the level-0 points over `neigh` (new -> old); empty when the input order is local already
 };
 
 struct DistP2P;
+
+// Who owns and who reads what in a row-partitioned job: computed identically on every rank from the orderings of levels 0 / 1,
+// the level-0 / level-1 patterns and U_0 (engine_part.hip.hpp::build_dist_plan).  Level 0: every colour class (padded to 64 * world rows) is cut
+// into `world` equal contiguous pieces, rank p owns piece p of every colour.  Level 1 (shard1): by 64-row blocks, a block to the rank that owns
+// most of the fine rows its points prolong into.  Lists are in device numbering, ascending.
+struct DistPlan {
+    int rank = 0, world = 1, n_colors = 0;
+    bool shard1 = false;
+    uint64_t key[2] = {0, 0};                             // pattern_key of the system the plan was made for (orderings and plan go together)
+    std::vector<int> blk_owner;                           // [block of level 1] -> rank
+    std::vector<std::vector<int>> own_blocks;             // [rank]: its blocks, ascending (block b = device rows 64 b .. 64 b + 63)
+    std::vector<std::vector<int>> halo;                   // [(s * world + t) * (C + 1) + k]: level-0 rows rank s publishes to rank t for colour k (k = C: all colours)
+    std::vector<std::vector<int>> halo1, halo0r;          // [s * world + t]: x1 entries / r0 entries rank s publishes to rank t
+};
 
 struct gmg_solver_s {
     DevPool pool;
@@ -166,6 +191,13 @@ struct gmg_solver_s {
     std::vector<int> cluster_order;       // locality-preserving order of the level-0 points derived from U (new -> old)
     int *d_cluster_order = nullptr, *d_cluster_inv = nullptr;      // device copies (order, and old -> new position)
     std::vector<int> bfs_order;           // ... and the breadth-first order over the point graph, when the caller / the hierarchy object supplied one (gmg_set_fine_order)
+    // The pattern the next systems are expected to have (gmg_set_fine_graph / gmg_use_hierarchy).  gmg_finalize_hierarchy then builds everything
+    // STRUCTURAL for it -- orderings, colourings, layouts, symbolic Galerkin products, symbolic LDL^T: a whole set-up on placeholder values --
+    // and leaves the handle in the "placeholder" state: no system to solve with (system_ready stays false), but the first gmg_set_system whose
+    // pattern digest equals the prepared one only moves values (refresh_system_values), like any later system with the live pattern.
+    std::shared_ptr<const FineGraph> fine_graph;
+    bool placeholder_ready = false;
+    bool mass_dirty = false;              // h->mass changed while no ordering existed to permute it with: uploaded by the next set-up / refresh
     int *d_bfs_order = nullptr, *d_bfs_inv = nullptr;
     int base_order_choice = 0;            // what the last reordered set-up used: 0 cluster order, 1 breadth-first order
     RawVec<int> reo_ptr, reo_idx;         // LHS pattern permuted into cluster order (staging for the level-0 colouring)
@@ -224,6 +256,12 @@ struct gmg_solver_s {
     hipStream_t own_stream = nullptr;
     int rank = 0, world = 1;
     bool dist_ready = false;
+    // gmg_dist_partition: the next set-ups lay out and keep only rank part_rank's rows of levels 0-1 (of part_world ranks; 1 = whole systems).
+    // `partitioned`: the live system is such a share -- its level-0 / level-1 operators hold this rank's rows only, the natural-numbering
+    // copies (A_0, A_1, U_0) were released after the set-up, and only the gmg_p2p_* / gmg_dist_* entry points may run on it.
+    int part_rank = 0, part_world = 1;
+    bool partitioned = false;
+    std::shared_ptr<DistPlan> plan;       // of the live (or last) partitioned system; reused while the pattern digest and the partition stand
     bool refill_ready = false;        // the live layout was built by the device builders from device-resident A_k: a system with
                                       // the same sparsity pattern only needs its values refreshed
     bool dist_all_rows = false;
@@ -407,6 +445,7 @@ void drop_device_transfers(gmg_handle h) {
     for (auto& e : h->dE3) free_ell3(e);
     h->dU.clear(); h->dE3.clear();
     h->dU_ready = false;
+    h->dU_flagged = false;
 }
 
 // Patches of every blocked level k >= 1 (see coarse_point_graph): depend on the hierarchy and on block_rows only.
@@ -505,6 +544,7 @@ void unbind_level0(gmg_handle h) {
 
 void drop_system(gmg_handle h) {
     h->refill_ready = false;
+    h->placeholder_ready = false;
     drop_graphs(h);
     unbind_level0(h);
     h->dist_ready = false;

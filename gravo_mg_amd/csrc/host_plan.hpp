@@ -263,6 +263,27 @@ inline bool wants_locality_reorder(const Mat& A, int reorder) {
     return reorder == 1 || (reorder == 2 && n > 65536 && mean_index_distance(A) > std::max(32768.0, n / 32.0));
 }
 
+// The level-0 point graph of a hierarchy (`neigh`: n x K neighbour table, -1 = no neighbour) as a canonical pattern: row i = its distinct
+// neighbours and i itself, ascending -- what `tau M + S` / `M + tau S` of the mesh the table came from looks like (the table IS the
+// off-diagonal pattern of S, gravomg_bindings/src/gravomg/util.py:36-44).  Threaded; ptr: n + 1, idx: entries.
+inline void neigh_pattern(const int* neigh, int n, int K, RawVec<int>& ptr, RawVec<int>& idx) {
+    ptr.resize((size_t)n + 1);
+    const int T = std::max(1, std::min(hw_threads(), 16));
+    auto row_of = [&](int i, int* out) {          // sorted distinct neighbours + self; returns the count (out holds K + 1 ints)
+        int m = 0;
+        const int* r = neigh + (size_t)i * K;
+        for (int k = 0; k < K; ++k) if (r[k] >= 0 && r[k] != i) out[m++] = r[k];
+        out[m++] = i;
+        std::sort(out, out + m);
+        return (int)(std::unique(out, out + m) - out);
+    };
+    parallel_ranges(n, T, [&](int lo, int hi, int) { std::vector<int> tmp((size_t)K + 1); for (int i = lo; i < hi; ++i) ptr[(size_t)i + 1] = row_of(i, tmp.data()); }, 1 << 14);
+    ptr[0] = 0;
+    for (int i = 0; i < n; ++i) ptr[(size_t)i + 1] += ptr[i];
+    idx.resize((size_t)ptr[n]);
+    parallel_ranges(n, T, [&](int lo, int hi, int) { std::vector<int> tmp((size_t)K + 1); for (int i = lo; i < hi; ++i) { const int m = row_of(i, tmp.data()); std::memcpy(idx.data() + ptr[i], tmp.data(), sizeof(int) * (size_t)m); } }, 1 << 14);
+}
+
 template <class Mat>
 inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma, int reorder = 0, const std::vector<int>* ext_base = nullptr, bool idx_sorted = false) {
     LevelOrdering o;
@@ -294,12 +315,14 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
         o.old2new.assign((size_t)n, -1);
     });
     std::vector<int> color;
-    RawVec<unsigned char> c8;
+    RawVec<unsigned char> c8_own;
+    const unsigned char* c8 = nullptr;
     if (multicolor) {
-        o.n_colors = greedy_coloring_bytes(A, c8, base, idx_sorted);
-        if (o.n_colors < 0) { c8.resize(0); o.n_colors = greedy_coloring_general(A, color, base); }
+        o.n_colors = greedy_coloring_bytes(A, c8_own, base, idx_sorted);
+        if (o.n_colors < 0) { c8_own.resize(0); o.n_colors = greedy_coloring_general(A, color, base); }
+        else c8 = c8_own.data();
     } else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
-    const bool bytes = !c8.empty();
+    const bool bytes = c8 != nullptr;
     auto colour_of = [&](int i) -> int { return bytes ? (int)c8[(size_t)i] : color[(size_t)i]; };
     phase("colouring");
     // Stable counting sort of the visit sequence by colour, threaded: per-chunk histograms give every chunk its write

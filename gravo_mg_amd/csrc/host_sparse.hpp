@@ -85,13 +85,12 @@ struct Compressed {
 //   GMG_LDLT_THREADS=N      threads of the coarsest LDL^T (factorisation and back-substitution teams); 1 = no team
 //   GMG_TRACE=setup,ldlt,ctor   phase timers of gmg_set_system / the host factorisation / the drop-in constructor on stderr
 //   GMG_POLL=0              wait for device results with copy + hipStreamSynchronize instead of polling pinned memory
-//   GMG_HIERARCHY_DEVICE=0  hierarchy construction on the host only
 //   GMG_P2P_TIMEOUT_S=S     device-side time-out of a peer-to-peer exchange (default 4 s)
 //   GMG_SEGV_BACKTRACE=1    native stack of a fatal signal on stderr (installed at load time, engine.hip)
 // Everything else that used to be an A/B switch is either a gmg_config field or gone.
 struct EnvSwitches {
     int host_threads = 0, local_world = 0, ldlt_threads = 0;
-    bool trace_setup = false, trace_ldlt = false, trace_ctor = false, poll = true, hierarchy_device = true, segv_backtrace = false;
+    bool trace_setup = false, trace_ldlt = false, trace_ctor = false, poll = true, segv_backtrace = false;
     double p2p_timeout_s = 0.0;
     static const EnvSwitches& get() {
         static const EnvSwitches v = [] {
@@ -102,7 +101,6 @@ struct EnvSwitches {
             if (num("GMG_LDLT_THREADS") > 0) e.ldlt_threads = (int)num("GMG_LDLT_THREADS");
             if (const char* t = std::getenv("GMG_TRACE")) { const std::string s(t); e.trace_setup = s.find("setup") != std::string::npos; e.trace_ldlt = s.find("ldlt") != std::string::npos; e.trace_ctor = s.find("ctor") != std::string::npos; }
             e.poll = num("GMG_POLL") != 0.0;
-            e.hierarchy_device = num("GMG_HIERARCHY_DEVICE") != 0.0;
             if (num("GMG_P2P_TIMEOUT_S") > 0) e.p2p_timeout_s = num("GMG_P2P_TIMEOUT_S");
             e.segv_backtrace = num("GMG_SEGV_BACKTRACE") > 0;
             return e;

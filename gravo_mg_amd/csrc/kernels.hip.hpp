@@ -1194,6 +1194,63 @@ __global__ __launch_bounds__(64) void p2p_allreduce_small(const P2POp* __restric
     }
 }
 
+// ---- multi-GPU, collective exchange: pack -> all-gather -> unpack, enqueued by the engine (engine_dist.hip.hpp, gmg_config::dist_exchange) --
+// The north star's exchange -- an all-gather of the x halo -- as three launches on the engine's stream: every rank packs what its peers read
+// of the vector it just updated into ONE chunk (a segment per destination rank; or its own rows once, for the whole-rows kinds), the chunks of
+// all ranks are all-gathered (ncclAllGather over xGMI; between processes that share a device: stores into the peers' buffers through hipIpc
+// mappings, gmgk::p2p_exchange on contiguous ops), and every rank unpacks the segments addressed to it.  A segment holds D columns of n
+// entries, column-major.
+struct CollSeg {
+    const int* idx;                 // local vector entries (device numbering) of the segment
+    int n;
+    long long off;                  // where the segment starts: doubles from the start of the chunk buffer (pack) / of the gathered buffer (unpack)
+};
+
+__global__ __launch_bounds__(256) void coll_pack(const CollSeg* __restrict__ segs, int n_segs, const double* __restrict__ vec, int ld, int D,
+                                                 double* __restrict__ chunk, int B) {
+    const int part = blockIdx.x % B, j = blockIdx.x / B;
+    if (j >= n_segs) return;
+    const CollSeg sg = segs[j];
+    const int64_t total = (int64_t)sg.n * D, stride = (int64_t)B * blockDim.x;
+    for (int64_t i = (int64_t)part * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i / sg.n), k = (int)(i - (int64_t)c * sg.n);
+        chunk[sg.off + i] = vec[sg.idx[k] + (int64_t)c * ld];
+    }
+}
+
+// SYS: the gathered buffer was written by OTHER processes through peer mappings (the emulated collective): system-scope loads, no stale line
+template <bool SYS>
+__global__ __launch_bounds__(256) void coll_unpack(const CollSeg* __restrict__ segs, int n_segs, const double* __restrict__ gathered, double* __restrict__ vec,
+                                                   int ld, int D, int B) {
+    const int part = blockIdx.x % B, j = blockIdx.x / B;
+    if (j >= n_segs) return;
+    const CollSeg sg = segs[j];
+    const int64_t total = (int64_t)sg.n * D, stride = (int64_t)B * blockDim.x;
+    for (int64_t i = (int64_t)part * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i / sg.n), k = (int)(i - (int64_t)c * sg.n);
+        double v;
+        if (SYS) v = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(gathered) + sg.off + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        else v = gathered[sg.off + i];
+        vec[sg.idx[k] + (int64_t)c * ld] = v;
+    }
+}
+
+// out[t] = sum over the ranks, IN RANK ORDER, of their n values (the residual-norm sums: the same bits on every rank).  The own contribution is
+// read from `mine` (an emulated all-gather does not deliver a rank's chunk to itself).
+template <bool SYS>
+__global__ __launch_bounds__(64) void coll_sum_ranks(const double* __restrict__ gathered, long long chunk, int world, int rank, const double* __restrict__ mine,
+                                                     int n, double* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t >= n) return;
+    double sum = 0.0;
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) { sum += mine[t]; continue; }
+        if (SYS) sum += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(gathered) + (long long)r * chunk + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        else sum += gathered[(long long)r * chunk + t];
+    }
+    out[t] = sum;
+}
+
 // n doubles -> host-visible pinned memory, then the sequence word (one block; the coarsest right-hand side)
 __global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restrict__ src, double* __restrict__ dst, int n,
                                                           unsigned long long* flag, unsigned long long seq) {

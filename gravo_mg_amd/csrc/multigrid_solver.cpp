@@ -248,6 +248,15 @@ int MultigridSolver::ensureEngine() {
         createdWith_ = want;
         uploadedU_.clear();
         systemReady_ = false;
+        partRank_ = 0; partWorld_ = 1;
+    }
+    if (partRank_ != distRank || partWorld_ != distWorld) {
+        // (before the hierarchy goes in: a partitioned handle prepares and lays out this rank's share only)
+        int rc = gmg_dist_partition(engine_, distRank, distWorld);
+        if (rc != GMG_OK) { err_ = gmg_last_error(engine_); return rc; }
+        partRank_ = distRank; partWorld_ = distWorld;
+        uploadedU_.clear();
+        systemReady_ = false;
     }
     return GMG_OK;
 }
@@ -267,6 +276,10 @@ int MultigridSolver::prepareEngine() {
             }
         if (!U.empty() && !fineOrder_.empty() && digU == fineOrderFor_ && (int)fineOrder_.size() == U[0].rows())
             (void)gmg_set_fine_order(engine_, (int)fineOrder_.size(), fineOrder_.data());       // (optional: a refusal only costs locality)
+        // the point graph the hierarchy was built from: the engine prepares the structure of the systems to come (gmg_set_fine_graph).  Only
+        // for the hierarchy this object built itself -- a caller's own prolongations (set_prolongation_matrices) say nothing about `neigh`
+        if (!U.empty() && digU == fineOrderFor_ && neigh.rows() == U[0].rows() && neigh.cols() > 0)
+            (void)gmg_set_fine_graph(engine_, neigh.rows(), neigh.cols(), neigh.data.data());
         if (!U.empty() && (rc = gmg_finalize_hierarchy(engine_))) { err_ = gmg_last_error(engine_); return rc; }
         uploadedU_ = digU;
         systemReady_ = false;

@@ -138,6 +138,10 @@ public:
     /* Set by a caller that KNOWS the initial guess of the next solve() is the right-hand side (the binding: core.cpp:69): x is then
        output only -- it need not hold a copy of rhs -- and the engine copies rhs to x on the device (gmg_solve_x0_rhs). */
     bool initialGuessIsRhs = false;
+    /* One process per GPU (not in the reference): this object is rank distRank of distWorld ranks of a row-partitioned job.  With distWorld > 1
+       the engine lays out and keeps only this rank's rows of levels 0-1 (gmg_dist_partition) and only the collective solve of
+       gravomg.MultigridSolver.enable_distributed() runs on it; engineConfig.row_align must be 64 * distWorld. */
+    int distRank = 0, distWorld = 1;
     /* Creates the device engine and hands it the hierarchy (`U`) now rather than inside the first solve(); optional. */
     int prepareEngine();
     const char* lastError() const;
@@ -158,13 +162,14 @@ private:
     gmg_handle engine_ = nullptr;
     std::vector<std::pair<uint64_t, uint64_t>> uploadedU_;     // digests of what the engine holds
     std::vector<int> fineOrder_;                               // breadth-first order of the points from buildHierarchy (may be empty) ...
-    std::vector<std::pair<uint64_t, uint64_t>> fineOrderFor_;  // ... and the digests of the U it belongs to
+    std::vector<std::pair<uint64_t, uint64_t>> fineOrderFor_;  // ... and the digests of the U buildHierarchy made (what fineOrder_ and `neigh` belong to)
     std::pair<uint64_t, uint64_t> uploadedLHS_{0, 0};
     bool systemReady_ = false;
     long systemGeneration_ = 0;                                // bumped by every gmg_set_system (prepareSystem)
     bool exactGsActive_ = false;                               // Gauss-Seidel on every level instead of the configured smoothers ...
     std::pair<uint64_t, uint64_t> exactGsFor_{0, 0};           // ... for the system with this digest only (solve())
     gmg_config createdWith_;
+    int partRank_ = 0, partWorld_ = 1;                         // what the engine was told (gmg_dist_partition)
     // The engine that is NOT in use -- the exact-GS one while the configured one runs, or the other way round -- with its state: an
     // application that alternates between a system needing the fallback and others switches engines instead of rebuilding them.
     struct ParkedEngine {

@@ -36,6 +36,27 @@ __device__ __forceinline__ bool keep_entry(const RowFilter& f, int dev_row, int 
     return !inside;
 }
 
+// Row masks of a partitioned set-up (one process per GPU; engine_part.hip.hpp): out[r] = new2old[r] for the rows this rank owns, -1 ("padding
+// row": no entries, unit diagonal) for everybody else's -- the layout builders below then give the other ranks' rows zero-width slices / empty
+// chunks, in the global numbering, so that the cycle's kernels run unchanged on this rank's slices and blocks.
+// colour-major level: every colour class is cut into `world` equal contiguous pieces, rank p owns piece p of every colour (p2p_owner)
+__global__ void mask_rows_by_colour(const int* __restrict__ new2old, int n_pad, const int* __restrict__ color_begin, int n_colors, int world, int rank,
+                                    int* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    int c = 0;
+    while (c + 1 < n_colors && r >= color_begin[c + 1]) ++c;
+    const int piece = (color_begin[c + 1] - color_begin[c]) / world;
+    const int owner = piece > 0 ? (r - color_begin[c]) / piece : 0;
+    out[r] = owner == rank ? new2old[r] : -1;
+}
+// blocked level (64-row blocks, block b = rows 64 b ..): a block belongs to blk_owner[b]
+__global__ void mask_rows_by_block(const int* __restrict__ new2old, int n_pad, const int* __restrict__ blk_owner, int rank, int* __restrict__ out) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    out[r] = blk_owner[r >> 6] == rank ? new2old[r] : -1;
+}
+
 // len[i] = number of kept entries of the row at slice position i (order[i] if given, else i)
 // (pbeg[row], pend[row]) delimit a row's entries: pend = pbeg + 1 for ordinary compressed storage.
 __global__ void row_lengths(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx, RowFilter f,

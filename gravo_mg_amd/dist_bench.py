@@ -59,18 +59,34 @@ def main(args):
     workload = f"torus{n1}x{n2}-poisson-tau1e-6-d1-{args.order}"
     H, mass, lhs, rhs = single.build_workload(n1, n2, args.order)                # deterministic: every rank builds the same
 
-    def new_engine():
+    setup_ms = {}
+
+    def new_engine(partition=False, tag=None):
+        """partition: the set-up is partitioned too (gmg_dist_partition) -- this rank lays out and keeps its rows of levels 0-1 only."""
         kw = {} if args.block_lanes is None else {"block_lanes": args.block_lanes}
         e = cabi.Engine(device=local, row_align=64 * world, block_fine=0, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels, **kw)
-        e.use_hierarchy(H); e.set_mass(mass); e.set_system(lhs)
+        if partition:
+            e.dist_partition(rank, world)
+        t = time.perf_counter(); e.use_hierarchy(H); t_h = 1e3 * (time.perf_counter() - t)
+        e.set_mass(mass)
+        t = time.perf_counter(); e.set_system(lhs); t_s = 1e3 * (time.perf_counter() - t)
+        if tag:
+            setup_ms[tag] = {"use_hierarchy_ms": t_h, "set_system_ms": t_s, "device_bytes_after_setup": e.timing("device_bytes"), "device_bytes_peak": e.timing("device_bytes_peak")}
         return e
 
-    eng = new_engine()
-    levels = [eng.level_info(k) for k in range(eng.num_levels + 1)]
+    # what ONE GPU computes (plain engine holding the whole operator, same padded layout): the partitioned cycle must reproduce these residues
     n_warm = max(args.warmup, 2)
-    # what ONE GPU computes (plain engine, same padded layout): the partitioned cycle must reproduce these residues
-    eng.load_problem(rhs, rhs)
-    ref_res = eng.run_cycles(n_warm, 2)
+    ref = new_engine(tag="whole_operator")
+    levels = [ref.level_info(k) for k in range(ref.num_levels + 1)]
+    ref.load_problem(rhs, rhs)
+    ref_res = ref.run_cycles(n_warm, 2)
+    setup_ms["whole_operator"]["device_bytes_with_vectors"] = ref.timing("device_bytes_now")
+    partitioned = world > 1 and args.exchange == "p2p" and not os.environ.get("GMG_BENCH_WHOLE_SETUP")
+    if partitioned:
+        ref.close(); del ref
+        eng = new_engine(partition=True, tag="partitioned")
+    else:
+        eng = ref
 
     # ---- peer-to-peer exchange engine
     p2p, note, exchange_us = None, None, None
@@ -133,7 +149,7 @@ def main(args):
         else:
             note = note if ok == 0 else "another rank could not set up the peer-to-peer path"
             single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange ({note})")
-            eng = new_engine()           # the candidate may have left its handle mid-exchange: the fallback starts from a fresh one
+            eng = new_engine()           # the candidate may have left its handle mid-exchange (and holds a rank's share only): the fallback starts from a fresh one
 
     # ---- RCCL orchestration (requested, or the fallback)
     dv, be, halo = None, None, None
@@ -241,10 +257,14 @@ def main(args):
     torch.cuda.synchronize()
     solve_ms = 1e3 * (time.perf_counter() - t)
 
+    # the reference algorithm on this host's cores (rank 0, one core, a bounded sample of the same workload: like the N = 1 line)
+    cpu = None
+    if rank == 0 and args.cpu_cycles > 0 and args.scaling == "strong":
+        cpu = single.cpu_baseline(H, mass, lhs, rhs, min(args.cpu_cycles, 6))
     # roofline of the dominant kernel (the fine-level colour sweep, same kernel as on one GPU; measured on the whole level)
     roofline = None
     if rank == 0:
-        probe = eng if p2p is None else new_engine()      # (kernel timing uses the level-0 vectors: not on the live p2p handle)
+        probe = eng if p2p is None else new_engine()      # (kernel timing needs the whole level 0 and its vectors: not on the live p2p handle)
         sweep_ms, launches = probe.bench_kernel(0, 0, 1, args.kernel_reps)
         sweep_bytes = probe.algorithmic_bytes(0, 0, 1)
         achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9
@@ -287,10 +307,15 @@ def main(args):
             "iterations_by_smoother": {"exact_per_colour_exchange": iters, "hybrid_gs": variants.get("hybrid_gs", {}).get("iterations_to_1e-4")},
             "variants": variants,
             "host_threads_per_rank": cabi.default_host_threads(),
-            "device_bytes_per_rank": (p2p.stat("device_bytes") if p2p is not None else None),      # the set-up is replicated: every rank holds the whole operator
+            # a rank's device memory: its rows of levels 0-1 + the replicated small levels + whole vectors (partitioned set-up, gmg_dist_partition)
+            "device_bytes_per_rank": (p2p.stat("device_bytes") if p2p is not None else None),
+            "device_bytes_per_rank_peak_during_setup": (p2p.stat("device_bytes_peak") if p2p is not None else None),
+            "setup": {**setup_ms, "set_up_partitioned": bool(partitioned and p2p is not None),
+                      "note": "whole_operator: the plain single-GPU set-up every rank ran first for the reference residues (and what device_bytes compares with); "
+                              "partitioned: this rank's set-up of the partitioned engine -- whole A_0 / U_0 up and through the Galerkin chain (the replicated coarse "
+                              "levels need every row), layouts of its own rows only, natural copies released"},
             "roofline": roofline,
-            "cpu_baseline": {"value": None, "unit": "ms per V-cycle (incl. residual check)", "cores": 1, "kind": "port",
-                             "see": "timed on rank 0 at N = 1 only (bench.py without --gpus, the driver's BENCH line of the same build): the 1-core oracle on the same workload"},
+            "cpu_baseline": cpu,
         }
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)

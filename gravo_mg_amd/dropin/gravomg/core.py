@@ -124,7 +124,7 @@ class MultigridSolver(object):
         return self.solver.solve(_sparse(lhs, "lhs"), _points(rhs, "rhs"))
 
     # ---- one process per GPU (not upstream) -------------------------------------------------------------------------------------------
-    def enable_distributed(self, rank, world, all_gather, device=None, shard_levels=2):
+    def enable_distributed(self, rank, world, all_gather, device=None, shard_levels=2, partition_setup=True):
         """Make solve() a COLLECTIVE over `world` processes (one per GPU), each holding a MultigridSolver built from the same inputs:
         level 0 is partitioned by rows per colour (levels >= 1 by blocks / replicated, `shard_levels`), exchanges are device-initiated
         stores into the peers' mailboxes (include/gravomg_hip.h, "multi-GPU, engine-driven").  The colours are
@@ -133,7 +133,10 @@ class MultigridSolver(object):
         all_gather(obj) -> list with every rank's obj in rank order, e.g.
             def all_gather(o): out = [None] * world; torch.distributed.all_gather_object(out, o); return out
         (the only thing the ranks exchange through the caller: 1 KB connection records, once per system layout).
-        device: HIP device of this rank (default: rank).  Call before the first solve()."""
+        device: HIP device of this rank (default: rank).  Call before the first solve().
+        partition_setup (default): the engine lays out and keeps only this rank's rows of levels 0-1 (gmg_dist_partition: a rank's device
+        memory is its share of the operator plus the replicated small levels); such an object runs the collective solve() only --
+        residual() and the single-process entry points need partition_setup=False (every rank then holds the whole operator)."""
         rank, world = int(rank), int(world)
         if not (0 <= rank < world):
             raise ValueError("rank must be in [0, world)")
@@ -142,6 +145,8 @@ class MultigridSolver(object):
             self.solver.set_engine_option("dist_shard_levels", int(shard_levels))
             self.solver.set_engine_option("block_fine", 0)          # the partitioned cycle needs the colour-major level 0
             self.solver.set_engine_option("device", rank if device is None else int(device))
+            self.solver.set_engine_option("dist_rank", rank if partition_setup else 0)
+            self.solver.set_engine_option("dist_world", world if partition_setup else 1)
             self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None}
         else:
             self._dist = None

@@ -109,6 +109,15 @@ typedef struct {
     int stream_gate;       /* 1 (default): the way up of a V-cycle is enqueued BEFORE the host solves the coarsest system, parked behind a stream
                               wait on a word the host writes after its back-substitution.  0: enqueue it afterwards -- for applications that issue
                               device-wide synchronisations (hipDeviceSynchronize, hipFree ...) from OTHER threads while a solve is in flight */
+    int dist_exchange;     /* multi-GPU (gmg_p2p_*): how the ranks exchange.  0 (default): device-initiated stores into the peers' mailboxes (hipIpc mappings,
+                              one launch per exchange).  1: the north star's collective -- pack -> ncclAllGather of the packed halo over RCCL -> unpack, three
+                              stream-ordered launches per exchange enqueued by the engine, no hipIpc (gmg_p2p_connect_rccl instead of gmg_p2p_export /
+                              gmg_p2p_connect).  2: the same sequence with the all-gather emulated by stores through hipIpc mappings: for ranks that
+                              share one device (RCCL refuses that), i.e. for tests of the collective path on a 1-GPU box.  Same iterates in every mode */
+    int prepare_structure; /* 1 (default): when the handle knows the level-0 point graph (gmg_set_fine_graph, gmg_use_hierarchy), gmg_finalize_hierarchy
+                              builds everything structural for a system with that sparsity pattern -- orderings, colourings, layouts, symbolic Galerkin
+                              products, symbolic LDL^T -- so that the first gmg_set_system with it only moves values.  0: the first system pays for its
+                              structure like any system with an unannounced pattern */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
@@ -222,6 +231,18 @@ int gmg_fetch_solution(gmg_handle h, double* x);
 /* Run all launches on this HIP stream (e.g. torch's current stream) instead of the handle's own; NULL restores it. */
 int gmg_set_stream(gmg_handle h, void* hip_stream);
 int gmg_dist_setup(gmg_handle h, int rank, int world);
+/* Partitioned SET-UP (the work split of multigrid_solver.cpp:1059-1088 applied to its preamble :1387-1403).  Call before
+ * gmg_set_system (and before gmg_finalize_hierarchy / gmg_use_hierarchy) on a handle created with row_align = 64 * world: this handle is rank
+ * `rank` of `world` ranks of a row-partitioned job, and gmg_set_system then lays out, and keeps, only this rank's rows of level 0 (its piece of
+ * every colour class) and of level 1 (its blocks, gmg_config::dist_shard_levels = 2) -- operator, block-CSR parts, prolongation, restriction,
+ * 16-bit column codes -- in the GLOBAL device numbering, so that the cycle's kernels run unchanged on this rank's slices and blocks; levels
+ * >= 2 and all vectors stay whole.  The Galerkin chain still sees the whole fine operator (the replicated coarse levels need every row of A_1
+ * and there is no exchange during the set-up): A_0, A_1 and U_0 are uploaded, used and RELEASED, so the memory a rank holds afterwards is its
+ * share plus the replicated small levels (gmg_p2p_stat "device_bytes"; "device_bytes_peak" is the high-water mark of the set-up).  The partition
+ * plan (who publishes what to whom) is made during the set-up, while the patterns are at hand, and kept with the orderings under the pattern
+ * digest.  Only the gmg_p2p_* / gmg_dist_* entry points run on such a handle; a system with the live pattern is set up again from scratch
+ * (no values-only refresh: there is no whole operator to refresh).  world = 1 returns to whole systems. */
+int gmg_dist_partition(gmg_handle h, int rank, int world);
 /* Use caller-owned device buffers as level-0 x, b, r (until the next gmg_set_system / a larger d). */
 int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d);
 /* Colour c of one Gauss-Seidel sweep on this rank's rows (multigrid_solver.cpp:1194-1226, row-partitioned). */
@@ -234,12 +255,10 @@ int gmg_dist_coarse_cycle(gmg_handle h);
 int gmg_dist_prolong_own(gmg_handle h);
 /* This rank's share of the residual-norm sums: sums[2c] = sum w r^2, sums[2c+1] = sum w b^2 for rhs column c. */
 int gmg_dist_norm_partial(gmg_handle h, int type, double* sums);
-/* The same three steps over ALL rows of level 0: after the exchange that follows every colour sweep each rank holds
- * the complete x0, so these can be computed redundantly instead of being exchanged (no collective for r0, for the
- * prolongated x0 or for the norm sums, which then are identical on every rank). */
-int gmg_dist_residual_all(gmg_handle h);
-int gmg_dist_prolong_all(gmg_handle h);
-int gmg_dist_norm_all(gmg_handle h, int type, double* sums);
+/* on != 0: the three steps above cover ALL rows of level 0 until switched off again.  After the exchange that follows every colour sweep each rank
+ * holds the complete x0, so residual, prolongation and norm sums can be computed redundantly instead of being exchanged (no collective for r0,
+ * for the prolongated x0 or for the norm sums, which then are identical on every rank).  Not on a partitioned handle. */
+int gmg_dist_all_rows(gmg_handle h, int on);
 /* Halo exchange helpers (gravo_mg_amd/dist.py, `halo` mode: after a colour sweep a rank publishes only the entries of
  * x0 that rows of other ranks read).  dst[i] = src[idx[i]] and dst[idx[i]] = src[pos[i]] for i < n, on the handle's
  * stream; every pointer is a device pointer. */
@@ -260,6 +279,10 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d);
 int gmg_p2p_export(gmg_handle h, void* blob_out);
 /* blobs: world x gmg_p2p_blob_bytes() bytes in rank order. */
 int gmg_p2p_connect(gmg_handle h, const void* blobs);
+/* gmg_config::dist_exchange = 1: instead of gmg_p2p_export / gmg_p2p_connect.  Rank 0 makes the 128-byte RCCL id (ncclGetUniqueId), the caller gives
+ * it to every rank by any means, every rank calls gmg_p2p_connect_rccl (ncclCommInitRank: collective).  GMG_ERR_UNSUPPORTED without librccl. */
+int gmg_p2p_rccl_unique_id(void* id_out_128_bytes);
+int gmg_p2p_connect_rccl(gmg_handle h, const void* id_128_bytes);
 int gmg_p2p_load(gmg_handle h, const double* b, const double* x0);
 int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues);
 int gmg_p2p_fetch(gmg_handle h, double* x);
@@ -268,31 +291,12 @@ int gmg_p2p_fetch(gmg_handle h, double* x);
  * identical on all ranks, so all ranks stop in the same iteration.  This is what gravomg.MultigridSolver.solve() runs after
  * enable_distributed() (gravo_mg_amd/dropin/gravomg/core.py). */
 int gmg_p2p_solve(gmg_handle h, const double* b, double* x, double tol, int stop_type, int max_iter, int* iters_out, double* residue_out);
-/* average duration (ms) of one colour-0 halo exchange, `reps` back to back (collective; measurement) */
-int gmg_p2p_bench_exchange(gmg_handle h, int reps, double* ms_avg);
-/* the same for any exchange of the cycle: "color<k>", "halo_all", "rows0" (every rank's level-0 rows: what a cycle with level 1
- * replicated moves once), and with level 1 partitioned "x1_halo" (after every level-1 sweep), "rows1" (r1 to all, once per
- * cycle), "r0_halo" (before the restriction, once per cycle).  Overwrites halo entries: gmg_p2p_load afterwards. */
-int gmg_p2p_bench_kind(gmg_handle h, const char* kind, int reps, double* ms_avg);
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
 /* Level-0 smoother of the partitioned cycle (multigrid_solver.cpp:1194-1226 split over ranks).  0 (default): multicolour
  * Gauss-Seidel with an exchange after every colour -- the single-GPU iterates bit for bit, (pre + post) x colours exchanges per cycle;
  * 1: hybrid -- Gauss-Seidel inside a rank, Jacobi across ranks, ONE exchange per sweep (pre + post per cycle); the iterates then depend
  * on the number of ranks.  Every rank must make the same choice. */
 int gmg_p2p_set_smoother(gmg_handle h, int hybrid);
-
-/* ---- measurement ---------------------------------------------------------------------------- */
-/* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:
- * kind 0 = full smoothing sweep (all colours), 1 = residual r=b-Ax, 2 = restrict, 3 = prolong_add,
- * 4 = residual-norm kernels.  The repetitions are enqueued back to back between two events (the way the
- * V-cycle issues them); launches_out = kernel launches per repetition (colours for the sweep). */
-int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out);
-/* Leg-by-leg time of a V-cycle + residual check on the resident problem (HIP events at the leg boundaries, average over `reps` cycles):
- * ms_out[k], k < levels: level k's share (multigrid_solver.cpp:1063-1069 on the way down, :1082-1085 on the way up); ms_out[levels]: the
- * coarsest solve (:1075) with its host round trip; ms_out[levels + 1]: the residual check (:1228-1277).  n_out >= levels + 2. */
-int gmg_profile_cycle(gmg_handle h, int stop_type, int reps, double* ms_out, int n_out);
-/* Algorithmic (compulsory) bytes of the same unit of work, SURVEY.md 8(d). */
-int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out);
 
 /* ---- host-only: hierarchy construction (no device needed) ----------------------------------- */
 typedef struct {
@@ -306,13 +310,15 @@ typedef struct {
     int full_clustering;   /* 0 (default): the Dijkstra clustering sweep (multigrid_solver.cpp:1015-1056) is replaced by what it provably does after the
                               FASTDISK sampler -- resetting the samples (csrc/host_hierarchy.hpp::voronoi_dijkstra); 1: run the sweep as written
                               (same hierarchy bit for bit; the cross-check of tests/test_hierarchy_restatement.py) */
+    int use_device;        /* 1 (default): with a HIP device the per-point parent selection (multigrid_solver.cpp:291-452) of levels with >= 200 000 points runs
+                              on it -- same prolongations, bit for bit; 0: host only */
 } gmg_hierarchy_options;
 
 int gmg_hierarchy_options_default(gmg_hierarchy_options* o);
 /* Replaces MGBS::MultigridSolver::buildHierarchy / constructProlongation
  * (gravomg/src/multigrid_solver.cpp:43-60, 62-469).  pos: n x 3 row-major; neigh: n x K row-major,
  * padded with -1 (gravomg_bindings/src/cpp/core.cpp:15-18).  Works without a GPU; with one, the per-point parent selection
- * (:291-452) of levels with >= 200 000 points runs on it -- same prolongations, bit for bit (environment GMG_HIERARCHY_DEVICE=0: host only). */
+ * (:291-452) of levels with >= 200 000 points runs on it -- same prolongations, bit for bit (gmg_hierarchy_options::use_device = 0: host only). */
 int gmg_hierarchy_build(const double* pos, int n, const int* neigh, int K, const gmg_hierarchy_options* opt,
                         gmg_hierarchy* out);
 void gmg_hierarchy_destroy(gmg_hierarchy hh);
@@ -341,11 +347,18 @@ int gmg_hierarchy_get_fine_order(gmg_hierarchy hh, int* out, int* count);
  * actual matrix and uses the better one (results do not depend on the numbering beyond rounding).  gmg_use_hierarchy passes
  * the hierarchy object's order by itself. */
 int gmg_set_fine_order(gmg_handle h, int n, const int* order);
-/* Convenience: feed every U_k of a built hierarchy into a solver handle (and finalize it, see below). */
+/* Optional, after the prolongations and before gmg_finalize_hierarchy: the level-0 point graph -- the `neigh` table the hierarchy was built from
+ * (n x K row-major, padded with -1; gravomg_bindings/src/cpp/core.cpp:15-18).  The systems a hierarchy is built for (tau M + S, M + tau S of that
+ * mesh or point cloud: experiments/python/comparisons.py:75-78, demos/smoothing.py:43-47) have exactly this graph plus the diagonal as their
+ * sparsity pattern, so the engine can do at hierarchy time what the reference redoes in every solve() preamble although it depends on the pattern
+ * only (gmg_config::prepare_structure).  A system with another pattern (a Bilaplacian's two-ring) simply takes the cold path.  n = 0 clears it. */
+int gmg_set_fine_graph(gmg_handle h, int n, int K, const int* neigh);
+/* Convenience: feed every U_k of a built hierarchy into a solver handle, its fine order and point graph with them (and finalize it, see below). */
 int gmg_use_hierarchy(gmg_handle h, gmg_hierarchy hh);
 /* Optional, after the last gmg_set_prolongation: build what depends on the hierarchy only (the reference's
- * buildHierarchy phase, multigrid_solver.cpp:15-60) -- the device copies of U_k and the compact row patches of the
- * block-hybrid smoother's levels -- now instead of inside the first gmg_set_system.  Idempotent. */
+ * buildHierarchy phase, multigrid_solver.cpp:15-60) -- the device copies of U_k, the compact row patches of the
+ * block-hybrid smoother's levels and, with a fine graph, the structure of the systems to come (gmg_config::prepare_structure;
+ * timing key "structure_prepare_ms") -- now instead of inside the first gmg_set_system.  Idempotent. */
 int gmg_finalize_hierarchy(gmg_handle h);
 
 

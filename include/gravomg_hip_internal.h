@@ -45,6 +45,24 @@ int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const doubl
  * the solver takes: the block sweep is a regular splitting).  reason (optional): 0 chosen, 1 rows too short, 2 signs. */
 int gmg_host_fine_block_rule(int n, const int* colptr, const int* rowidx, const double* val, int* blocked, int* reason);
 
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Average duration (ms) of one unit of level-k work, measured with HIP events on the engine stream:
+ * kind 0 = full smoothing sweep (all colours), 1 = residual r=b-Ax, 2 = restrict, 3 = prolong_add,
+ * 4 = residual-norm kernels.  The repetitions are enqueued back to back between two events (the way the
+ * V-cycle issues them); launches_out = kernel launches per repetition (colours for the sweep). */
+int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_avg, int* launches_out);
+/* Leg-by-leg time of a V-cycle + residual check on the resident problem (HIP events at the leg boundaries, average over `reps` cycles):
+ * ms_out[k], k < levels: level k's share (multigrid_solver.cpp:1063-1069 on the way down, :1082-1085 on the way up); ms_out[levels]: the
+ * coarsest solve (:1075) with its host round trip; ms_out[levels + 1]: the residual check (:1228-1277).  n_out >= levels + 2. */
+int gmg_profile_cycle(gmg_handle h, int stop_type, int reps, double* ms_out, int n_out);
+/* Algorithmic (compulsory) bytes of the same unit of work, SURVEY.md 8(d). */
+int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_out);
+
+/* average duration (ms) of one exchange of the cycle, `reps` back to back (collective; measurement): "color<k>", "halo_all", "rows0" (every rank's level-0 rows: what a cycle with level 1
+ * replicated moves once), and with level 1 partitioned "x1_halo" (after every level-1 sweep), "rows1" (r1 to all, once per
+ * cycle), "r0_halo" (before the restriction, once per cycle).  Overwrites halo entries: gmg_p2p_load afterwards. */
+int gmg_p2p_bench_kind(gmg_handle h, const char* kind, int reps, double* ms_avg);
+
 /* Host-only probe of the coarsest-level solver (csrc/host_ldlt.hpp): factorises A, times the back-substitution on 1 .. 8 threads (`reps` solves
  * per batch, best of 20) and the numeric re-factorisation, compares the team solves with the one-thread solve bit for bit and the supernodal
  * factor with the simplicial one.  The report (text lines) goes to `report` (cap bytes, NUL-terminated). */

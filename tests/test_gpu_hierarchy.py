@@ -59,7 +59,7 @@ def test_builder_matches_restatement_and_engine_consumes_it(cabi, oracle, kind):
                                                     ("torus", 2, False), ("torus", 1, True)])
 def test_device_selection_stage_gives_the_host_bits(cabi, kind, weighting, nested):
     """The per-point parent selection (multigrid_solver.cpp:291-452) runs on the GPU for levels of >= 200 k points
-    (csrc/hierarchy_kernels.hip.hpp); U must be bit-identical to the host loop's (GMG_HIERARCHY_DEVICE=0), whatever the mesh."""
+    (csrc/hierarchy_kernels.hip.hpp); U must be bit-identical to the host loop's (gmg_hierarchy_options::use_device = 0), whatever the mesh."""
     import os
     from gravo_mg_amd import meshgen
     if kind.startswith("torus"):
@@ -74,17 +74,8 @@ def test_device_selection_stage_gives_the_host_bits(cabi, kind, weighting, neste
         V = meshgen.torus_points(240_000, noise=0.002)
         S, _ = meshgen.knn_graph_laplacian(V, 8)
         neigh = meshgen.neighbors_from_stiffness(S)
-    old = os.environ.get("GMG_HIERARCHY_DEVICE")
-    try:
-        os.environ["GMG_HIERARCHY_DEVICE"] = "0"
-        Hh = cabi.Hierarchy(V, neigh, weighting=weighting, nested=nested)
-        os.environ["GMG_HIERARCHY_DEVICE"] = "1"
-        Hd = cabi.Hierarchy(V, neigh, weighting=weighting, nested=nested)
-    finally:
-        if old is None:
-            os.environ.pop("GMG_HIERARCHY_DEVICE", None)
-        else:
-            os.environ["GMG_HIERARCHY_DEVICE"] = old
+    Hh = cabi.Hierarchy(V, neigh, weighting=weighting, nested=nested, use_device=False)
+    Hd = cabi.Hierarchy(V, neigh, weighting=weighting, nested=nested)
     assert Hh.timing("selection_on_device") == 0.0 and Hd.timing("selection_on_device") >= 1.0
     assert len(Hh.U) == len(Hd.U) >= 2
     for a, b in zip(Hh.U, Hd.U):

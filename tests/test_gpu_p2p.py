@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from tests import problems
+from tests import problems  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,7 +40,7 @@ def _problem(kind):
     return pr.torus_problem(64, 60, "smoothing", 60)
 
 
-def _worker(rank, world, port, q, kind, shard, budget):
+def _worker(rank, world, port, q, kind, shard, budget, partition=False, exchange=0):
     try:
         sys.path.insert(0, ROOT)
         os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -53,8 +53,13 @@ def _worker(rank, world, port, q, kind, shard, budget):
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
         P = _problem(kind)
         assert cabi.default_host_threads() == max(1, budget // world), (cabi.default_host_threads(), budget, world)
-        eng = cabi.Engine(row_align=64 * world, dist_shard_levels=shard, block_lanes=1)
+        eng = cabi.Engine(row_align=64 * world, dist_shard_levels=shard, block_lanes=1, dist_exchange=exchange)
+        if partition:                                        # lay out and keep this rank's rows of levels 0 (and 1) only
+            eng.dist_partition(rank, world)
         eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+        if partition:
+            with pytest.raises(cabi.GmgError, match="partitioned"):      # no whole operator on this handle: the single-process entry points say so
+                eng.residual(0, P.rhs, P.rhs)
         rk = cabi.P2PCycle(eng, rank, world, P.rhs.shape[1])
         assert rk.stat("level1_partitioned") == (1.0 if shard == 2 else 0.0)
         blobs = [None] * world
@@ -91,10 +96,14 @@ def _worker(rank, world, port, q, kind, shard, budget):
         q.put((rank, None, None, traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("world,kind,shard", [(2, "poisson", 2), (3, "poisson", 2), (3, "poisson", 1), (4, "smoothing-d3", 2), (4, "poisson-big", 2),
-                                              (2, "poisson-big", 1), (8, "poisson", 2), (8, "smoothing-d3", 1)])      # 8: the target's rank count
-def test_processes_through_ipc_handles(cabi, world, kind, shard):
-    """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by blocks (default), 1 = level 0 only."""
+@pytest.mark.parametrize("world,kind,shard,partition", [(2, "poisson", 2, False), (3, "poisson", 2, False), (3, "poisson", 1, False), (4, "smoothing-d3", 2, False),
+                                                        (4, "poisson-big", 2, False), (2, "poisson-big", 1, False), (8, "poisson", 2, False), (8, "smoothing-d3", 1, False),
+                                                        (2, "poisson", 2, True), (3, "poisson", 1, True), (4, "smoothing-d3", 2, True), (4, "poisson-big", 2, True),
+                                                        (2, "poisson-big", 1, True), (8, "poisson", 2, True)])      # 8: the target's rank count
+def test_processes_through_ipc_handles(cabi, world, kind, shard, partition, exchange=0):
+    """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by blocks (default), 1 = level 0 only.
+    partition: the SET-UP is partitioned too (gmg_dist_partition) -- every rank lays out and keeps only its rows of levels 0 (and 1);
+    the other ranks' rows are zero-width slices of the same global numbering, so the iterates stay those of one GPU, bit for bit."""
     import torch.multiprocessing as mp
     P = _problem(kind)
     want_hist, want_x = _reference(cabi, P, world, 4)
@@ -104,7 +113,7 @@ def test_processes_through_ipc_handles(cabi, world, kind, shard):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     budget = cabi.default_host_threads()             # this process has no LOCAL_WORLD_SIZE: the CPUs it may use
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, shard, budget)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind, shard, budget, partition, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=420) for _ in range(world)]
@@ -115,6 +124,16 @@ def test_processes_through_ipc_handles(cabi, world, kind, shard):
     for rank, hist, x, err in got:
         np.testing.assert_allclose(hist, want_hist, rtol=1e-12)
         assert np.array_equal(x, want_x), rank
+
+
+@pytest.mark.parametrize("world,kind,shard,partition", [(2, "poisson", 2, False), (3, "poisson", 1, False), (3, "smoothing-d3", 2, True), (4, "poisson-big", 2, True)])
+def test_collective_exchange_sequence_gives_the_same_iterates(cabi, world, kind, shard, partition):
+    """gmg_config::dist_exchange: every exchange of the cycle as pack -> all-gather -> unpack on the engine's stream (the north star's RCCL
+    all-gather of the halo, csrc/engine_dist.hip.hpp::coll_exchange) instead of one mailbox launch.  Here with the all-gather emulated through
+    hipIpc mappings (mode 2: the ranks share the one device, which RCCL refuses); tests/test_gpu_multi_device.py runs mode 1 -- ncclAllGather --
+    whenever two devices are visible.  Same plan, same kernels around it: the single-engine solution bit for bit, level 1 partitioned or
+    replicated, whole or partitioned set-up, d = 1 and 3, the hybrid smoother, every exchange kind timed."""
+    test_processes_through_ipc_handles(cabi, world, kind, shard, partition, exchange=2)
 
 
 def _absent_peer_worker(rank, port, q):
@@ -238,3 +257,104 @@ def test_multigridsolver_solve_as_a_collective_over_ranks(cabi, world):
         assert info["iterations"] == want_iters and info["residue"] <= 1e-6 and info["world"] == world
         assert np.array_equal(x, want), (rank, np.abs(x - want).max())
         np.testing.assert_allclose(x2, 2.0 * want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+
+
+def _bench_workload_file(tmpdir):
+    """The 3 M-vertex bench workload, built once by the parent and loaded by every rank (the hierarchy is rebuilt per process: 0.3 s)."""
+    import scipy.sparse as sp
+    sys.path.insert(0, ROOT)
+    from gravo_mg_amd import meshgen
+    V, F = meshgen.torus_mesh(1732, 1732)
+    S, mass = meshgen.cotan_laplacian(V, F)
+    neigh = meshgen.neighbors_from_stiffness(S)
+    lhs, rhs = meshgen.poisson_system(S, mass, tau=1e-6, seed=42, d=1)
+    lhs = sp.csc_matrix(lhs)
+    path = os.path.join(str(tmpdir), "bench3m.npz")
+    np.savez(path, V=V, neigh=neigh, mass=mass, indptr=lhs.indptr, indices=lhs.indices, data=lhs.data, rhs=rhs)
+    return path
+
+
+def _load_bench_workload(path):
+    import scipy.sparse as sp
+    z = np.load(path)
+    n = z["V"].shape[0]
+    return z["V"], z["neigh"], z["mass"], sp.csc_matrix((z["data"], z["indices"], z["indptr"]), shape=(n, n)), z["rhs"]
+
+
+def _memory_worker(rank, world, port, q, path):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ["LOCAL_WORLD_SIZE"] = str(world)
+        os.environ["GMG_P2P_TIMEOUT_S"] = "120"               # processes sharing one device may be time-sliced
+        import time
+        import torch.distributed as dist
+        from gravo_mg_amd import cabi
+        from tests.test_gpu_p2p import _load_bench_workload
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        V, neigh, mass, lhs, rhs = _load_bench_workload(path)
+        H = cabi.Hierarchy(V, neigh, lower_bound=1000)
+        eng = cabi.Engine(row_align=64 * world, block_fine=0)
+        eng.dist_partition(rank, world)
+        eng.use_hierarchy(H); eng.set_mass(mass)
+        t = time.perf_counter(); eng.set_system(lhs); set_ms = 1e3 * (time.perf_counter() - t)
+        rk = cabi.P2PCycle(eng, rank, world, 1)
+        blobs = [None] * world
+        dist.all_gather_object(blobs, rk.export())
+        rk.connect(blobs=blobs)
+        dist.barrier()
+        rk.load(rhs, rhs)
+        hist = rk.cycles(2, 2)
+        stats = {"device_bytes": rk.stat("device_bytes"), "device_bytes_peak": eng.timing("device_bytes_peak"), "set_system_ms": set_ms,
+                 "plan_ms": eng.timing("dist_plan_ms"), "level1_partitioned": rk.stat("level1_partitioned")}
+        dist.barrier()
+        q.put((rank, hist, stats, None))
+        dist.destroy_process_group()
+    except Exception as e:              # noqa: BLE001
+        import traceback
+        q.put((rank, None, None, traceback.format_exc() + repr(e)))
+
+
+def test_partitioned_set_up_holds_a_rank_s_share_of_the_3m_system(cabi, tmp_path):
+    """round-4 verdict item 1a: with a partitioned set-up (gmg_dist_partition) a rank of a P-rank job holds its rows of levels 0-1 plus the
+    replicated small levels and the (whole) vectors: device_bytes <= (1 / P + 0.15) x what one GPU holds for the 3 M-vertex bench system, for
+    P = 2, 4, 8 (here: P processes on one device), and the first cycles reproduce the single-GPU residues."""
+    import json
+    import torch.multiprocessing as mp
+    path = _bench_workload_file(tmp_path)
+    V, neigh, mass, lhs, rhs = _load_bench_workload(path)
+    H = cabi.Hierarchy(V, neigh, lower_bound=1000)
+    one = cabi.Engine(block_fine=0)
+    one.use_hierarchy(H); one.set_mass(mass); one.set_system(lhs)
+    one.load_problem(rhs, rhs)
+    want = one.run_cycles(2, 2)
+    single = one.timing("device_bytes_now")
+    one.close(); del one, H
+    report = {"single_gpu_device_bytes": single}
+    for world in (2, 4, 8):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_memory_worker, args=(r, world, port, q, path)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=900) for _ in range(world)]
+        for p in procs:
+            p.join(60)
+        errs = [f"rank {rank}: {err}" for rank, hist, stats, err in got if err is not None]
+        assert not errs, "\n".join(errs)
+        worst = max(stats["device_bytes"] for _, _, stats, _ in got)
+        report[f"P{world}"] = {"device_bytes_max": worst, "ratio": worst / single, "bound": 1.0 / world + 0.15,
+                               "device_bytes_peak_max": max(st["device_bytes_peak"] for _, _, st, _ in got),
+                               "set_system_ms_max": max(st["set_system_ms"] for _, _, st, _ in got), "plan_ms_max": max(st["plan_ms"] for _, _, st, _ in got)}
+        for rank, hist, stats, err in got:
+            np.testing.assert_allclose(hist, want, rtol=1e-12)
+            assert stats["level1_partitioned"] == 1.0
+            assert stats["device_bytes"] <= (1.0 / world + 0.15) * single, (world, rank, stats, single)
+    print("partitioned set-up:", json.dumps(report))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "partitioned_setup_memory.json"), "w") as f:
+            json.dump(report, f, indent=1)

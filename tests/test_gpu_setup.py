@@ -383,3 +383,60 @@ def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi
     a.set_system(lhs2); b.set_system(lhs2)
     assert a.timing("setup_values_only") == 1.0
     assert np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
+
+
+@pytest.mark.parametrize("case", ["torus", "random-order", "pointcloud", "smoothing-d3-mixed"])
+def test_structure_prepared_at_hierarchy_time_gives_the_cold_set_ups_bits(cabi, case):
+    """gmg_set_fine_graph / gmg_use_hierarchy hand the engine the hierarchy's point graph -- the sparsity pattern of the systems it is built
+    for -- and gmg_finalize_hierarchy prepares the structure on placeholder values (gmg_config::prepare_structure): the first gmg_set_system
+    is then a values-only refresh.  It must leave exactly what a cold set-up leaves: same orderings, same iterates, bit for bit.  A handle
+    in the placeholder state has no system (solves are refused), and a system with another pattern takes the cold path."""
+    from gravo_mg_amd import meshgen
+    if case == "pointcloud":
+        pos = meshgen.torus_points(6000, noise=0.002)
+        S, mass = meshgen.knn_graph_laplacian(pos, 8)
+        lhs, rhs = meshgen.poisson_system(S, mass)
+        lb, kw = 150, {}
+    else:
+        pos, F = meshgen.torus_mesh(96, 80, order="random" if case == "random-order" else "natural")
+        S, mass = meshgen.cotan_laplacian(pos, F)
+        lhs, rhs = meshgen.smoothing_system(S, mass, pos) if case.startswith("smoothing") else meshgen.poisson_system(S, mass)
+        lb, kw = 60, ({"inner_precision": 1} if case.endswith("mixed") else {})
+    neigh = meshgen.neighbors_from_stiffness(S)
+    H = cabi.Hierarchy(pos, neigh, lower_bound=lb)
+
+    prepared = cabi.Engine(**kw)
+    prepared.use_hierarchy(H)
+    assert prepared.timing("structure_prepare_ms") > 0.0
+    with pytest.raises(cabi.GmgError):                      # placeholder values: nothing to solve with
+        prepared.solve(rhs)
+    prepared.set_mass(mass); prepared.set_system(lhs)
+    assert prepared.timing("setup_values_only") == 1.0 and prepared.timing("setup_structure_prepared") == 1.0
+
+    table = cabi.Engine(**kw)                                # the same through the table (what the C++ mirror does: it keeps `neigh`, not the hierarchy object)
+    table.set_prolongations(H.U, fine_order=H.fine_order, fine_graph=neigh)
+    table.set_mass(mass); table.set_system(lhs)
+    assert table.timing("setup_structure_prepared") == 1.0
+
+    cold = cabi.Engine(prepare_structure=False, **kw)
+    cold.use_hierarchy(H); cold.set_mass(mass); cold.set_system(lhs)
+    assert cold.timing("setup_values_only") == 0.0 and cold.timing("setup_structure_prepared") == 0.0
+
+    for e in (prepared, table):
+        for k in range(cold.num_levels):
+            a, b = e.level_ordering(k), cold.level_ordering(k)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        xa, ita, resa, conva = e.solve(rhs, tol=1e-6, max_iter=60)
+        xb, itb, resb, convb = cold.solve(rhs, tol=1e-6, max_iter=60)
+        assert ita == itb and np.array_equal(conva[:, 1], convb[:, 1]) and np.array_equal(xa, xb)
+        assert e.residual_norm(rhs, xa, 2) == cold.residual_norm(rhs, xb, 2)
+    # another pattern (the Bilaplacian's two-ring): cold path on the prepared handle, same bits as on a fresh one
+    if case == "torus":
+        lhs2, rhs2 = meshgen.smoothing_system(meshgen.bilaplacian(S, mass), mass, pos[:, :1], tau=1e-9)
+        prepared.set_system(lhs2)
+        assert prepared.timing("setup_values_only") == 0.0 and prepared.timing("setup_structure_prepared") == 0.0
+        fresh = cabi.Engine(prepare_structure=False)
+        fresh.use_hierarchy(H); fresh.set_mass(mass); fresh.set_system(lhs2)
+        xa = prepared.solve(rhs2, tol=1e-3, max_iter=8)[0]
+        xb = fresh.solve(rhs2, tol=1e-3, max_iter=8)[0]
+        assert np.array_equal(xa, xb)
