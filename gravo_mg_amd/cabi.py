@@ -43,7 +43,7 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("prepare_structure", C.c_int),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("merge_tiny_colors", C.c_int), ("prepare_structure", C.c_int),
     ]
 
 
@@ -319,7 +319,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None, merge_tiny_colors=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -347,6 +347,8 @@ class Engine:
             cfg.prepare_structure = int(bool(prepare_structure))
         if dist_exchange is not None:
             cfg.dist_exchange = int(dist_exchange)
+        if merge_tiny_colors is not None:
+            cfg.merge_tiny_colors = int(bool(merge_tiny_colors))
         self._h = _vp()
         rc = l.gmg_create(C.byref(cfg), C.byref(self._h))
         if rc:
@@ -469,6 +471,10 @@ class Engine:
                                             _pi(row_of) if has_row_of else None, _pd(diag) if diag is not None else None))
         return {"n_slices": ns, "lpr": lpr, "slice_ptr": sp_, "col": col, "val": val, "row_of": row_of, "diag": diag}
 
+    def debug_set(self, key: str, value: float):
+        """Set-up fault injection for the tests (gravomg_hip_internal.h), effective from the next set_system."""
+        self._chk(lib().gmg_debug_set(self._h, key.encode(), float(value)))
+
     def timing(self, key: str) -> float:
         out = C.c_double()
         self._chk(lib().gmg_get_timing(self._h, key.encode(), C.byref(out)))
@@ -536,14 +542,22 @@ class Engine:
         self._chk(lib().gmg_vcycle(self._h, _pd(B), _pd(X), B.shape[1]))
         return self._shape_like(X, x)
 
-    def solve(self, rhs, x0=None, tol=1e-4, stop_type=2, max_iter=100):
+    def solve(self, rhs, x0=None, tol=1e-4, stop_type=2, max_iter=100, out=None):
         """Returns (x, iterations, residue, convergence[(ms, residue), ...]).  x0 defaults to rhs
-        (gravomg_bindings/src/cpp/core.cpp:69)."""
+        (gravomg_bindings/src/cpp/core.cpp:69).  The C-ABI takes column-major n x d blocks (Eigen::MatrixXd): a C-ordered (n, d) rhs with
+        d > 1 is converted first -- pass np.asfortranarray(rhs) to keep that copy out of a timed call.  out: an (n, d) column-major float64
+        array that receives x (with x0 = None; a caller that solves repeatedly spares the allocation and first touch of a fresh result:
+        ~4 ms for 72 MB)."""
         B = _f64(rhs)
         iters, res = C.c_int(), C.c_double()
         conv = np.zeros(2 * max(int(max_iter), 1))
         if x0 is None:                       # gmg_solve_x0_rhs: x is output only (no copy of rhs made here, none uploaded)
-            X = np.empty(B.shape, order="F")
+            if out is not None:
+                if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.shape == B.shape and out.flags.f_contiguous):
+                    raise ValueError("out must be a column-major float64 array of the shape of rhs")
+                X = out
+            else:
+                X = np.empty(B.shape, order="F")
             rc = lib().gmg_solve_x0_rhs(self._h, _pd(B), _pd(X), B.shape[1], float(tol), int(stop_type), int(max_iter),
                                         C.byref(iters), C.byref(res), _pd(conv))
         else:

@@ -126,6 +126,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->stream_gate = 1;
     cfg->prepare_structure = 1;
     cfg->dist_exchange = 0;
+    cfg->merge_tiny_colors = 1;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
@@ -256,7 +257,8 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) try {
     if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
     PoolScope pool_scope_(&h->pool);
     h->mass.assign(mass_diag, mass_diag + n);
-    if (h->has_device && h->system_ready) return upload_mass(h);
+    // (with a system -- or the prepared structure of one: the ordering that permutes the mass exists -- it goes to the device now)
+    if (h->has_device && (h->system_ready || h->placeholder_ready) && !h->lv.empty() && h->lv[0].n == n && h->lv[0].d_new2old) { h->mass_dirty = false; return upload_mass(h); }
     h->mass_dirty = true;
     return GMG_OK;
 } GMG_CATCH_H
@@ -319,7 +321,8 @@ static void coarse_inverse(gmg_handle h, std::vector<double>& inv) {
 
 // gmg_set_system for a matrix with the sparsity pattern of the live system: values only.  Returns 1 when it cannot be
 // done in place (nothing has been changed then, except values that the full path overwrites anyway).
-static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all) {
+// values_uploaded: the caller has already put `val` into the resident A_0 (the speculative upload of set_system_impl)
+static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all, bool values_uploaded = false) {
     const int L = h->L;
     auto mark = [&](const std::string& what) { h->timing["t_" + what] = ms_since(t_all); };
     for (int k = 0; k <= L; ++k) if (!h->lv[k].dA.ptr || !h->lv[k].dA.idx || !h->lv[k].dA.val) return 1;
@@ -333,7 +336,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     HIPCHK(hipMemsetAsync(d_err.p, 0, sizeof(int), h->stream));
     h->loaded_d = 0;
     for (int k = 0; k <= L; ++k) h->lv[k].hostA_values = false;          // host copies (if any) keep their pattern only
-    if ((rc = h2d(h, h->lv[0].dA.val, val, sizeof(double) * (size_t)h->lv[0].nnz))) return rc;
+    if (!values_uploaded && (rc = h2d(h, h->lv[0].dA.val, val, sizeof(double) * (size_t)h->lv[0].nnz))) return rc;
     mark("upload_A0");
     auto t0 = clk::now();
     for (int k = 1; k <= L; ++k) {
@@ -399,37 +402,60 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     for (int k = 0; k + 1 < h->L; ++k)
         if (h->U[k].n_outer != h->U[k + 1].n_inner) return fail(h, GMG_ERR_INVALID, "U[k] / U[k+1] shapes do not chain");
     auto t_all = clk::now();
+    HIPCHK(hipSetDevice(h->cfg.device));
+    const int L = h->L;
     Compressed canon;       // only filled when the caller's storage is unsorted or has duplicates
+    // A system of the live system's size is most likely the live pattern with new values (the demos' new tau per frame; the first system after
+    // the structure was prepared): its values go up to the resident A_0 AHEAD of the verdict, while the worker threads inspect and digest the
+    // pattern (3-4 ms at 3 M vertices, as long as the upload itself).  Should the pattern be another one after all, nothing is lost but the
+    // live system, which the full set-up replaces anyway.
+    bool speculative_upload = false;
+    uint64_t pat_key[2] = {0, 0};
+    bool have_key = false;
     {
-        const int what = inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads);
-        if (what == 2) return fail(h, GMG_ERR_INVALID, "index out of range in LHS");
+        std::future<int> inspected = std::async(std::launch::async, [&] { return inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads); });
+        std::future<void> keyed;
+        if ((h->system_ready || h->placeholder_ready) && h->live_key_valid && h->refill_ready && (int)h->lv.size() == L + 1 && h->lv[0].n == n && colptr[0] == 0 &&
+            (int64_t)colptr[n] == h->lv[0].nnz && h->lv[0].dA.val) {
+            keyed = std::async(std::launch::async, [&] { pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key); });
+            h->loaded_d = 0;
+            const int rc_up = h2d(h, h->lv[0].dA.val, val, sizeof(double) * (size_t)h->lv[0].nnz);
+            speculative_upload = true;
+            keyed.get();
+            have_key = true;
+            if (rc_up != GMG_OK) { (void)inspected.get(); h->system_ready = false; h->placeholder_ready = false; return rc_up; }
+        }
+        const int what = inspected.get();
+        if (what == 2) { if (speculative_upload) { h->system_ready = false; h->placeholder_ready = false; } return fail(h, GMG_ERR_INVALID, "index out of range in LHS"); }
         if (what == 1) {
             canon = canonical_copy(n, n, colptr, rowidx, val, h->cfg.host_threads);
             colptr = canon.ptr.data(); rowidx = canon.idx.data(); val = canon.val.data();
+            have_key = false;
+            // (the values went up in the caller's storage order, the resident pattern is canonical: the live system is void, and this
+            // matrix takes the full set-up from its canonical copy)
+            if (speculative_upload) { speculative_upload = false; h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }
         }
     }
-    HIPCHK(hipSetDevice(h->cfg.device));
-    const int L = h->L;
-    uint64_t pat_key[2] = {0, 0};
-    bool have_key = false;
     // (live: a system is set -- or the structure of one was prepared on placeholder values when the hierarchy was finalized, prepare_structure)
     const bool live = h->system_ready || h->placeholder_ready;
     if (live && h->live_key_valid && h->refill_ready && (int)h->lv.size() == L + 1 && h->lv[0].n == n) {
         // Same sparsity pattern as the live system (and the same hierarchy: refill_ready dies with it)?  Then every
         // structure on the device stands and only values move: LHS values up, numeric Galerkin passes, value refill of
         // the layouts, numeric LDL^T.  (The demos' usage: lhs = M + tau * S with a new tau per frame.)
-        pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key);
-        have_key = true;
+        if (!have_key) { pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key); have_key = true; }
         // (a level 0 that gmg_config::block_fine blocked stays blocked only while the new values pass its sign test)
         const bool keeps_fine_blocks = !(h->lv[0].ord.blocked && h->cfg.block_from_level >= 1) || stieltjes_signs(n, colptr, rowidx, val, h->cfg.host_threads);
         if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz && keeps_fine_blocks) {
             const bool from_placeholder = h->placeholder_ready && !h->system_ready;
-            int rc = refresh_system_values(h, n, val, t_all);
+            int rc = refresh_system_values(h, n, val, t_all, speculative_upload);
             if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
             if (rc == GMG_OK) { h->system_ready = true; h->placeholder_ready = false; h->timing["setup_structure_prepared"] = from_placeholder ? 1.0 : 0.0; }
             if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything
         }
     }
+    // (the resident values were overwritten ahead of the verdict and the pattern turned out to be another one: the live system is gone -- the
+    // full path below drops it anyway; a failure on the way must not leave a system that solves with foreign values)
+    if (speculative_upload) { h->system_ready = false; h->placeholder_ready = false; }
     if (live && h->live_key_valid && (int)h->lv.size() == L + 1) {
         h->ord_cache.resize(L + 1);
         for (int k = 0; k <= L; ++k) h->ord_cache[k] = std::move(h->lv[k].ord);
@@ -701,6 +727,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
                 mark("ordering_ready_l" + std::to_string(k));
                 if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); return; }
                 rc_all = upload(h, &h->lv[k].d_new2old, h->lv[k].ord.new2old);
+                if (rc_all == GMG_OK) rc_all = upload_tiny_tasks(h, h->lv[k]);
             };
             double ms_layout = 0;
             for (int k = L; k >= 1 && rc_all == GMG_OK; --k) ordering_of(k);
@@ -765,7 +792,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         int rc;
         try { ord_done[k].get(); } catch (const std::exception& e) { rc_all = GMG_ERR_STATE; err_all = std::string("ordering of level ") + std::to_string(k) + ": " + e.what(); break; }
         auto tu = clk::now();
-        if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) { rc_all = rc; break; }
+        if ((rc = upload(h, &l.d_new2old, l.ord.new2old)) || (rc = upload_tiny_tasks(h, l))) { rc_all = rc; break; }
         ms_h2d += ms_since(tu);
         if (k == L) break;
         op_done[k].get();
@@ -858,7 +885,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             if (lk.d_old2new) { (void)dev_free(lk.d_old2new); lk.d_old2new = nullptr; }
             if (lk.d_blk_of_row) { (void)dev_free(lk.d_blk_of_row); lk.d_blk_of_row = nullptr; }
         }
-        h->pool.trim();                       // (parked blocks of the temporaries: the memory goes back to the device, not to this handle's pool)
+        h->pool.trim_large((size_t)4 << 20);   // (the big temporaries go back to the device, not to this handle's pool)
         h->partitioned = true;
     }
     h->timing["device_bytes"] = (double)h->pool.live_bytes;
@@ -915,9 +942,11 @@ static int prepare_structure(gmg_handle h) {
         h->ord_cache_valid = true;
         h->live_key_valid = false;
         drop_system(h);
-        h->pool.trim();
+        h->pool.trim_large((size_t)4 << 20);
     }
     h->placeholder_ready = h->refill_ready && h->live_key_valid;
+    // (the level vectors of a one-column problem, so that the first solve does not pay their allocation either; a wider block re-allocates)
+    if (h->placeholder_ready) (void)ensure_vectors(h, 1);
     h->mass_dirty = !h->mass.empty();
     h->timing["structure_prepare_ms"] = ms_since(t0);
     return GMG_OK;
@@ -1621,7 +1650,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     const bool il_p = il && h->L >= 2 && h->lv[1].ord.blocked && h->lv[1].use_ep && h->cfg.post_iters > 0 && h->cfg.smoother != GMG_SMOOTHER_JACOBI;
     auto body = [&]() {
         switch (kind) {
-            case 0: launch_smooth<double>(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors; break;
+            case 0: launch_smooth<double>(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors - ((l.d_tiny_seg && l.ord.tiny_colors > 0) ? l.ord.tiny_colors - 1 : 0); break;
             // (level 0 with 2 .. 4 right-hand sides: the variants the cycle runs -- residual written / gathered as an interleaved multi-vector,
             // prolongation from the interleaved copy of level 1's x: engine_cycle.hip.hpp::enqueue_down / enqueue_up)
             case 1: launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r, -1, il); break;
@@ -1917,6 +1946,7 @@ int gmg_finalize_hierarchy(gmg_handle h) try {
     if (h->L <= 0) return fail(h, GMG_ERR_STATE, "no hierarchy set");
     for (int k = 0; k < h->L; ++k) if (!h->U_set[k]) return fail(h, GMG_ERR_STATE, "prolongation matrix missing for level " + std::to_string(k));
     if (!h->has_device) return GMG_OK;
+    PoolScope pool_scope_(&h->pool);      // (everything below allocates and releases through the handle's pool: its byte counts are what gmg_p2p_stat reports)
     // data that belongs to the hierarchy, not to a system (gmg_set_system would make it on its first call otherwise):
     // the compact patches of the blocked levels, the device copies of U_k
     // (the patches are host work on helper threads, the transfers device work driven from this thread: side by side)
@@ -1924,7 +1954,6 @@ int gmg_finalize_hierarchy(gmg_handle h) try {
     if (!h->patches_ready) patches = std::async(std::launch::async, [h] { build_patches(h); });
     int rc = GMG_OK;
     if (h->cfg.device_setup) {
-        PoolScope pool_scope_(&h->pool);
         rc = hipSetDevice(h->cfg.device) == hipSuccess ? ensure_device_transfers(h) : fail(h, GMG_ERR_HIP, "hipSetDevice failed");
     }
     if (patches.valid()) patches.get();

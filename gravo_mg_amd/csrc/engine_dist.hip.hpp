@@ -49,6 +49,7 @@ struct CollBackend {
     int (*all_gather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*comm_destroy)(void*) = nullptr;
     const char* (*error_string)(int) = nullptr;
+    unsigned long long count = 0;                         // collective exchanges done: its parity picks the half of `recv` (see coll_exchange)
     gmgk::P2POp* d_ops = nullptr;                         // emulation: contiguous push of the chunk into every peer's gathered buffer, [(kind * 2 + parity) * n_peers + j]
     std::vector<void*> peer_recv;                         // the peers' gathered buffers mapped here (ascending rank)
 };
@@ -135,7 +136,11 @@ int coll_all_gather(gmg_handle h, int kind, int parity) {
 int coll_exchange(gmg_handle h, int kind, double* vec, int ld) {
     DistP2P* p = h->p2p;
     CollBackend& cb = p->coll;
-    const int parity = (int)(p->kind_count[kind]++ & 1);
+    // The gathered buffer has two halves that ALL kinds share, used alternately by consecutive collective exchanges whatever their kind: a peer
+    // writes exchange m + 2 into the half of exchange m only after it has seen this rank's contribution to m + 1, which this rank enqueued behind
+    // its unpack of m.  (A parity per kind, as the mailbox regions have, would let two consecutive exchanges of different kinds share a half.)
+    ++p->kind_count[kind];
+    const int parity = (int)(cb.count++ & 1);
     ++p->seq;
     const int B = cb.blocks[kind];
     if (cb.pack_n[kind] > 0)
@@ -794,7 +799,8 @@ int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
         if (p->world > 1 && p->coll.mode != 0) {
             // collective backend: every rank's 2 d sums all-gathered, then added in rank order (the same bits everywhere)
             CollBackend& cb = p->coll;
-            const int kind = C + 2, parity = (int)(p->kind_count[kind]++ & 1);
+            const int kind = C + 2, parity = (int)(cb.count++ & 1);
+            ++p->kind_count[kind];
             ++p->seq;
             HIPCHK(hipMemcpyAsync(cb.send, h->d_norm, sizeof(double) * 2 * d, hipMemcpyDeviceToDevice, h->stream));
             if ((rc = coll_all_gather(h, kind, parity))) return rc;

@@ -19,11 +19,19 @@ whole = cabi.Engine(row_align=64 * P, block_fine=0)
 whole.use_hierarchy(H); whole.set_mass(mass); whole.set_system(lhs)
 info(whole, "whole ")
 whole.close(); del whole
-for prep in (True, False):
+for prep in (True,):
     part = cabi.Engine(row_align=64 * P, block_fine=0, prepare_structure=prep)
     part.dist_partition(0, P)
     part.use_hierarchy(H); part.set_mass(mass); part.set_system(lhs)
     info(part, f"rank0/{P} prep={prep}")
+    marks = {}
+    for m in ["pattern_key", "upload_A0"] + [f"rap_l{k}" for k in range(1, 6)] + [f"ordering_ready_l{k}" for k in range(6)] + ["device_layout", "tasks_joined", "factor_joined", "mass_done"]:
+        try:
+            marks[m] = round(part.timing("t_" + m), 2)
+        except Exception:
+            pass
+    print("    marks", sorted(marks.items(), key=lambda kv: kv[1]))
+    print("    parked after set-up MB: see device_bytes_now vs hipMemGetInfo")
     for key in ("dist_plan_ms", "dist_plan_cached", "setup_ordering_cached", "reduction", "setup_device_layout"):
         try:
             print("   ", key, part.timing(key))

@@ -79,12 +79,14 @@ def _worker(rank, world, port, q, kind, shard, budget, partition=False, exchange
             rk.load(P.rhs, P.rhs)
             hh = rk.cycles(2, 2)
             ok_h = bool(hh[1] < hh[0] < 1.0)
+            why_h = tuple(hh)
         else:
             xh, ith, resh = rk.solve(P.rhs, P.rhs, tol=1e-4, stop_type=2, max_iter=100)
             ok_h = bool(resh <= 1e-4 and its <= ith <= 3 * its + 3 and np.abs(xh - xs).max() <= 1e-2 * np.abs(xs).max())
+            why_h = (resh, ith, its, float(np.abs(xh - xs).max() / np.abs(xs).max()))
         rk.set_smoother(False)
         dist.barrier()
-        assert ok_h
+        assert ok_h, why_h
         kinds = [] if world >= 8 else (["color0", "halo_all", "rows0"] + (["x1_halo", "rows1", "r0_halo"] if shard == 2 else []))
         us = {k: 1e3 * rk.bench_kind(k, 20) for k in kinds}
         assert all(v > 0 for v in us.values()), us
