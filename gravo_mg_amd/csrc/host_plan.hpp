@@ -261,13 +261,14 @@ inline double mean_index_distance(const Mat& A) {
 }
 
 // Tasks of the merged launch for the tiny leading colour classes of a colour-major ordering (LevelOrdering::tiny_*).  A class is tiny when it
-// holds at most max(n / 64, 4096) rows; at least two of them are needed for the merge to save a launch, and a component of more than 2 048
-// rows (a class that is small but connected through the others) calls it off: one workgroup would walk it alone.
+// holds at most n / 64 rows (a launch that moves a few MB sits at the launch floor); at least two of them are needed for the merge to save a
+// launch, and a component of more than 256 rows (classes that are small but connected through each other) calls it off: a workgroup takes a
+// row per thread and colour, more would make it walk the component in rounds.
 template <class Mat>
 inline void plan_tiny_colors(const Mat& A, LevelOrdering& o) {
     o.tiny_colors = 0; o.tiny_rows.clear(); o.tiny_seg.clear();
     if (o.blocked || o.n_colors < 3) return;
-    const int limit = std::max(o.n / 64, 4096);
+    const int limit = o.n / 64;
     int T = 0;
     while (T < o.n_colors - 1 && o.color_begin[T + 1] - o.color_begin[T] <= limit) ++T;      // (classes are in ascending size; the last one is never merged)
     if (T < 2) return;
@@ -293,7 +294,7 @@ inline void plan_tiny_colors(const Mat& A, LevelOrdering& o) {
         comp_size[comp_of[r]]++;
     }
     if (comp_size.empty()) return;
-    if (*std::max_element(comp_size.begin(), comp_size.end()) > 2048) return;
+    if (*std::max_element(comp_size.begin(), comp_size.end()) > 256) return;
     std::vector<int> task_of_comp(comp_size.size());
     int n_tasks = 0, fill = 0;
     for (size_t c = 0; c < comp_size.size(); ++c) {

@@ -192,11 +192,27 @@ __global__ __launch_bounds__(256) void gs_tiny_colors(const int* __restrict__ ta
             T acc[D];
 #pragma unroll
             for (int k = 0; k < D; ++k) acc[k] = 0.0;
-            for (int j = 0; j < w; ++j) {
-                const int cj = col[p0 + (int64_t)j * 64 + lane];
-                const T v = val[p0 + (int64_t)j * 64 + lane];
+            // groups of kTinyGroup entries: all their index / value loads in flight, then all the gathers, then the multiply-adds in stored
+            // order -- a row costs two memory round trips per group instead of two per entry (a task walks its colours one after the other:
+            // the dependent round trips ARE its run time)
+            constexpr int kTinyGroup = 12;
+            const int* cp = col + p0 + lane;
+            const T* vp = val + p0 + lane;
+            for (int j0 = 0; j0 < w; j0 += kTinyGroup) {
+                int cj[kTinyGroup];
+                T vj[kTinyGroup], xj[kTinyGroup][D];
 #pragma unroll
-                for (int k = 0; k < D; ++k) acc[k] += v * __hip_atomic_load(x + cj + (int64_t)k * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < kTinyGroup; ++j) { const bool in = j0 + j < w; cj[j] = in ? cp[(int64_t)(j0 + j) * 64] : 0; vj[j] = in ? vp[(int64_t)(j0 + j) * 64] : (T)0.0; }
+#pragma unroll
+                for (int j = 0; j < kTinyGroup; ++j)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) xj[j][k] = __hip_atomic_load(x + cj[j] + (int64_t)k * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int j = 0; j < kTinyGroup; ++j)
+                    if (j0 + j < w) {
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc[k] += vj[j] * xj[j][k];
+                    }
             }
             const T dg = diag[row];
 #pragma unroll

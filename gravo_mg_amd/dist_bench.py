@@ -61,10 +61,12 @@ def main(args):
 
     setup_ms = {}
 
-    def new_engine(partition=False, tag=None):
-        """partition: the set-up is partitioned too (gmg_dist_partition) -- this rank lays out and keeps its rows of levels 0-1 only."""
+    def new_engine(partition=False, tag=None, dist_exchange=0):
+        """partition: the set-up is partitioned too (gmg_dist_partition) -- this rank lays out and keeps its rows of levels 0-1 only.
+        dist_exchange: 0 mailboxes, 1 pack -> ncclAllGather -> unpack enqueued by the engine, 2 the same with the all-gather emulated over hipIpc."""
         kw = {} if args.block_lanes is None else {"block_lanes": args.block_lanes}
-        e = cabi.Engine(device=local, row_align=64 * world, block_fine=0, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels, **kw)
+        e = cabi.Engine(device=local, row_align=64 * world, block_fine=0, use_graph=False, coarse_mode=coarse_mode, dist_shard_levels=args.shard_levels,
+                        dist_exchange=dist_exchange, **kw)
         if partition:
             e.dist_partition(rank, world)
         t = time.perf_counter(); e.use_hierarchy(H); t_h = 1e3 * (time.perf_counter() - t)
@@ -192,39 +194,54 @@ def main(args):
     ms_per_step = 1e3 * float(tmax.item()) / args.steps
     colls_per_cycle = (dv.n_collectives / max(n_warm + args.warmup + args.steps, 1)) if dv is not None else 0
 
-    # ---- variant (never `value`): the north star's collective -- RCCL all-gather of the packed x halo per colour sweep -- timed for a
-    # few cycles beside the peer-to-peer default, so that the named exchange has a number on every node the driver measures.
-    # Every step that could fail on one rank is followed by a collective agreement before the ranks enter a collective together.
     variants = {}
+    # ---- variant (never `value`): the north star's collective -- an all-gather of the packed x halo after every colour sweep -- as the ENGINE runs
+    # it (gmg_config::dist_exchange): pack -> all-gather -> unpack enqueued on the engine's stream, the same partition plan and kernels around it,
+    # no Python between the colours.  With one device per rank the all-gather is ncclAllGather (librccl, loaded by the library); ranks that share
+    # a device (GMG_DIST_BACKEND=gloo: RCCL refuses that) run the same sequence with the all-gather emulated through hipIpc mappings -- what
+    # this measures there is the cost of three launches per exchange instead of one, not a link.
     if p2p is not None and world > 1 and not os.environ.get("GMG_BENCH_NO_HALO_VARIANT"):
-        okv, dv2, be2, why = 1, None, None, None
+        mode = 1 if backend == "nccl" else 2
+        okv, cyc2, why = 1, None, None
         try:
-            eng_h = new_engine()
-            be2 = EngineBackend(eng_h, 1, rank, world, torch.device("cuda", local))
-            new2old, cb = eng_h.level_ordering(0)
-            A = lhs.tocsr()
-            halo2 = HaloPlan(A.indptr, A.indices, new2old, cb, be2.n_pad, world, rank, 1, device=be2.device)
-            dv2 = DistVCycle(be2, halo=halo2)
-            be2.load(rhs, rhs)
+            eng_c = new_engine(partition=True, dist_exchange=mode)
+            cyc2 = cabi.P2PCycle(eng_c, rank, world, 1)
         except Exception as e:          # noqa: BLE001
             okv, why = 0, repr(e)
         if agreed(okv):
+            try:
+                if mode == 1:
+                    ids = [None] * world
+                    dist.all_gather_object(ids, cabi.rccl_unique_id() if rank == 0 else None, group=cpu_group)
+                    cyc2.connect_rccl(ids[0])
+                else:
+                    blobs2 = [None] * world
+                    dist.all_gather_object(blobs2, cyc2.export(), group=cpu_group)
+                    cyc2.connect(blobs2)
+            except Exception as e:      # noqa: BLE001
+                okv, why = 0, repr(e)
+        else:
+            okv = 0
+        if agreed(okv):
             k = max(1, min(args.steps, 10))
-            warm = []
-            for _ in range(n_warm):
-                dv2.vcycle(); warm.append(dv2.residual_norm(2))
+            cyc2.load(rhs, rhs)
+            warm = cyc2.cycles(n_warm, 2)
             torch.cuda.synchronize(); dist.barrier()
             th0 = time.perf_counter()
-            for _ in range(k):
-                dv2.vcycle(); dv2.residual_norm(2)
+            cyc2.cycles(k, 2)
             torch.cuda.synchronize(); dist.barrier()
             th = torch.tensor([time.perf_counter() - th0], dtype=torch.float64, device="cuda")
             dist.all_reduce(th, op=dist.ReduceOp.MAX)
-            variants["rccl_halo_allgather"] = {"ms_per_step": 1e3 * float(th.item()) / k, "steps": k, "collectives_per_cycle": dv2.n_collectives / (n_warm + k),
+            variants["rccl_halo_allgather"] = {"ms_per_step": 1e3 * float(th.item()) / k, "steps": k,
+                                               "transport": "ncclAllGather (librccl)" if mode == 1 else "all-gather emulated through hipIpc mappings (the ranks share a device)",
+                                               "launches_per_exchange": 3, "exchanges_per_cycle": 25 if cyc2.stat("level1_partitioned") == 1.0 else 19,
                                                "residues_match_single_gpu": bool(np.allclose(warm, ref_res, rtol=1e-9)),
-                                               "what": "level 0 row-partitioned, levels >= 1 replicated; pack -> all_gather_into_tensor -> unpack per colour sweep (gravo_mg_amd/dist.py)"}
+                                               "ratio_to_mailbox_path": 1e3 * float(th.item()) / k / ms_per_step,
+                                               "what": "every exchange of the engine-driven cycle as pack -> all-gather -> unpack on the engine's stream (gmg_config::dist_exchange); "
+                                                       "same partition (levels 0-1), same iterates"}
+            del cyc2
         else:
-            variants["rccl_halo_allgather"] = {"ms_per_step": None, "reason": why or "another rank could not set the RCCL orchestration up"}
+            variants["rccl_halo_allgather"] = {"ms_per_step": None, "reason": why or "another rank could not set the collective exchange up"}
 
     # ---- variant (never `value`): hybrid Gauss-Seidel on level 0 -- GS inside a rank, Jacobi across ranks, ONE exchange per
     # sweep instead of one per colour: fewer, equally small messages; the iterates depend on the rank count, so the cycle count is recorded

@@ -1,7 +1,6 @@
 """Back-substitution time of the coarsest-level solver on the 3 M-vertex bench hierarchy (host only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("GMG_LDLT_BENCH", "200")
 import numpy as np
 from gravo_mg_amd import cabi, meshgen
 V, F = meshgen.torus_mesh(1732, 1732); S, mass = meshgen.cotan_laplacian(V, F)
@@ -11,3 +10,4 @@ for U in H.U:
 b = np.random.default_rng(0).standard_normal(A.shape[0])
 x, nnz = cabi.host_ldlt_solve(A, b)
 print("n", A.shape[0], "nnz(L)", nnz, "residual", np.linalg.norm(A @ x - b) / np.linalg.norm(b))
+print(cabi.host_ldlt_probe(A, b, reps=200))      # gravomg_hip_internal.h: timings on 1 .. 8 threads, bitwise agreement, supernodal vs simplicial

@@ -466,8 +466,8 @@ def test_tiny_colour_classes_in_one_launch_change_nothing(cabi, case):
         e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
     print(case, "colours", a.level_info(0)["n_colors"], "merged classes", a.timing("tiny_colors_l0"), "tasks", a.timing("tiny_tasks_l0"), "rows", a.timing("tiny_rows_l0"))
     assert b.timing("tiny_colors_l0") == 0.0
-    if case in ("bilaplacian", "pointcloud-colour-major"):
-        assert a.timing("tiny_colors_l0") >= 2.0          # these graphs do leave tiny classes behind
+    if case in ("sphere", "random-order-d3"):
+        assert a.timing("tiny_colors_l0") >= 2.0          # these graphs do leave tiny classes behind (a class of at most n / 64 rows)
     rng = np.random.default_rng(7)
     x0 = rng.standard_normal(P.rhs.shape)
     assert np.array_equal(a.smooth(0, P.rhs, x0, 1), b.smooth(0, P.rhs, x0, 1))
