@@ -325,7 +325,6 @@ public:
         else if (key == "dist_rank") solver->distRank = (int)value;
         else if (key == "dist_world") solver->distWorld = (int)value;
         else if (key == "fine_col16") c.fine_col16 = (int)value;
-        else if (key == "merge_tiny_colors") c.merge_tiny_colors = (int)value;
         else if (key == "stream_gate") c.stream_gate = (int)value;
         else if (key == "inner_precision") c.inner_precision = (int)value;
         else throw std::invalid_argument("unknown engine option: " + key);

@@ -126,7 +126,6 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->stream_gate = 1;
     cfg->prepare_structure = 1;
     cfg->dist_exchange = 0;
-    cfg->merge_tiny_colors = 1;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
     cfg->gs_omega = 1.35;     // measured (profiles/r02/a_iteration_ab.json, f_iteration_ab_omega_scan.json): 7 -> 4 V-cycles to 1e-4 on the 3 M Poisson
@@ -727,7 +726,6 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
                 mark("ordering_ready_l" + std::to_string(k));
                 if (h->lv[k].ord.n_colors > 255) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "more than 255 colours on level " + std::to_string(k); return; }
                 rc_all = upload(h, &h->lv[k].d_new2old, h->lv[k].ord.new2old);
-                if (rc_all == GMG_OK) rc_all = upload_tiny_tasks(h, h->lv[k]);
             };
             double ms_layout = 0;
             for (int k = L; k >= 1 && rc_all == GMG_OK; --k) ordering_of(k);
@@ -792,7 +790,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         int rc;
         try { ord_done[k].get(); } catch (const std::exception& e) { rc_all = GMG_ERR_STATE; err_all = std::string("ordering of level ") + std::to_string(k) + ": " + e.what(); break; }
         auto tu = clk::now();
-        if ((rc = upload(h, &l.d_new2old, l.ord.new2old)) || (rc = upload_tiny_tasks(h, l))) { rc_all = rc; break; }
+        if ((rc = upload(h, &l.d_new2old, l.ord.new2old))) { rc_all = rc; break; }
         ms_h2d += ms_since(tu);
         if (k == L) break;
         op_done[k].get();
@@ -1650,7 +1648,7 @@ int gmg_bench_kernel(gmg_handle h, int kind, int k, int d, int reps, double* ms_
     const bool il_p = il && h->L >= 2 && h->lv[1].ord.blocked && h->lv[1].use_ep && h->cfg.post_iters > 0 && h->cfg.smoother != GMG_SMOOTHER_JACOBI;
     auto body = [&]() {
         switch (kind) {
-            case 0: launch_smooth<double>(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors - ((l.d_tiny_seg && l.ord.tiny_colors > 0) ? l.ord.tiny_colors - 1 : 0); break;
+            case 0: launch_smooth<double>(h, l, d, 2); launches = (h->cfg.smoother == GMG_SMOOTHER_JACOBI || l.ord.blocked) ? 1 : l.ord.n_colors; break;
             // (level 0 with 2 .. 4 right-hand sides: the variants the cycle runs -- residual written / gathered as an interleaved multi-vector,
             // prolongation from the interleaved copy of level 1's x: engine_cycle.hip.hpp::enqueue_down / enqueue_up)
             case 1: launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r, -1, il); break;

@@ -93,16 +93,10 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
     const T omega = fine ? (T)h->cfg.gs_omega : (T)1.0;       // over-relaxation on the finest level only (gmg_config::gs_omega)
     T* x = Prec<T>::x(l);
     const T* b = Prec<T>::b(l);
-    // tiny leading colour classes: ONE launch for all of them (gs_tiny_colors), then a launch per remaining class
-    const int tiny = (l.d_tiny_seg && l.d_tiny_rows) ? l.ord.tiny_colors : 0;
     for (int it = 0; it < iters; ++it)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            if (tiny > 0) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_tiny_colors<T, D>), dim3(l.ord.tiny_tasks()), dim3(256), 0, h->stream, l.d_tiny_seg, l.d_tiny_rows, tiny,
-                                                  l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld, ld, omega));
-            }
-            for (int c = tiny; c < l.ord.n_colors; ++c) {
+            for (int c = 0; c < l.ord.n_colors; ++c) {
                 int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
                 if (se <= sb) continue;
                 if (fold_norm<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;

@@ -266,7 +266,7 @@ int coll_build(gmg_handle h) {
             cb.unpack_n[(size_t)k * 2 + par] = (int)segs.size() - cb.unpack_at[(size_t)k * 2 + par];
         }
         for (int q = cb.pack_at[k]; q < (int)segs.size(); ++q) most = std::max<long long>(most, (long long)segs[q].n * d);
-        cb.blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 4095) / 4096));
+        cb.blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 1023) / 1024));
     }
     HIPCHK(hipMalloc((void**)&cb.d_idx, sizeof(int) * std::max<size_t>(idx.size(), 1)));
     HIPCHK(hipMemcpy(cb.d_idx, idx.data(), sizeof(int) * idx.size(), hipMemcpyHostToDevice));
@@ -575,13 +575,13 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
                     op.recv_idx = p->d_idx + rows1_at[q];
                 }
             }
-    // blocks per peer and direction: one per 4096 values of the largest transfer of the kind (all ranks derive the same number)
+    // blocks per peer and direction: one per 1024 values of the largest transfer of the kind (all ranks derive the same number)
     p->kind_blocks.assign(nk, 1);
     for (int k = 0; k < nk; ++k) {
         long long most = 0;
         for (int par = 0; par < 1; ++par)
             for (int j = 0; j < np; ++j) { const gmgk::P2POp& op = ops[(size_t)(k * 2 + par) * np + j]; most = std::max<long long>(most, (long long)std::max(op.n_send, op.n_recv) * d); }
-        p->kind_blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 4095) / 4096));
+        p->kind_blocks[k] = (int)std::min<long long>(64, std::max<long long>(1, (most + 1023) / 1024));       // (a block per 1 024 values: four dependent index -> value -> store chains per thread)
     }
     if (p->d_ops) { (void)sync_hipFree(p->d_ops); p->d_ops = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_ops, sizeof(gmgk::P2POp) * ops.size()));

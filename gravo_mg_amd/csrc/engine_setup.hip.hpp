@@ -25,19 +25,6 @@ int upload_csr_raw(gmg_handle h, DevCsr& d, int n_outer, const int* ptr, const i
     return GMG_OK;
 }
 
-// the tasks of the merged launch for a colour-major level's tiny leading classes (LevelOrdering::tiny_*; gmg_config::merge_tiny_colors)
-int upload_tiny_tasks(gmg_handle h, Level& l) {
-    if (l.d_tiny_seg) { (void)dev_free(l.d_tiny_seg); l.d_tiny_seg = nullptr; }
-    if (l.d_tiny_rows) { (void)dev_free(l.d_tiny_rows); l.d_tiny_rows = nullptr; }
-    const bool fine = !h->lv.empty() && &l == &h->lv[0];
-    if (fine) { h->timing["tiny_colors_l0"] = 0.0; h->timing["tiny_tasks_l0"] = 0.0; h->timing["tiny_rows_l0"] = 0.0; }
-    if (!h->cfg.merge_tiny_colors || l.ord.tiny_colors < 2 || l.ord.tiny_rows.empty()) return GMG_OK;
-    int rc;
-    if ((rc = upload(h, &l.d_tiny_seg, l.ord.tiny_seg)) || (rc = upload(h, &l.d_tiny_rows, l.ord.tiny_rows))) return rc;
-    if (fine) { h->timing["tiny_colors_l0"] = l.ord.tiny_colors; h->timing["tiny_tasks_l0"] = l.ord.tiny_tasks(); h->timing["tiny_rows_l0"] = (double)l.ord.tiny_rows.size(); }
-    return GMG_OK;
-}
-
 template <class T>
 struct DevTmp {                       // scratch device array released at scope exit (stream-ordered reuse through the pool)
     T* p = nullptr;

@@ -139,7 +139,6 @@ struct Level {
     int ep_cap_e = 0, ep_cap_l = 0;      // most explicit / lower entries of one block (explicit: rounded up to 64): LDS capacity of the sweep
     int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
     unsigned char* d_row_color = nullptr;
-    int *d_tiny_seg = nullptr, *d_tiny_rows = nullptr;      // colour-major level with tiny leading classes: the tasks of their merged launch (LevelOrdering::tiny_*)
     int* d_new2old = nullptr;
     int* d_old2new = nullptr;         // kept after the layout (with d_blk_of_row) so that a system with the same pattern can
     int* d_blk_of_row = nullptr;      // refill the value arrays in place (refresh_system_values)
@@ -534,8 +533,6 @@ void free_level(Level& l) {
     if (l.d_row_color) { (void)dev_free(l.d_row_color); l.d_row_color = nullptr; }
     for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)dev_free(*p); *p = nullptr; }
     for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)dev_free(*p); *p = nullptr; }
-    if (l.d_tiny_seg) { (void)dev_free(l.d_tiny_seg); l.d_tiny_seg = nullptr; }
-    if (l.d_tiny_rows) { (void)dev_free(l.d_tiny_rows); l.d_tiny_rows = nullptr; }
     if (l.d_new2old) { (void)dev_free(l.d_new2old); l.d_new2old = nullptr; }
     if (l.d_old2new) { (void)dev_free(l.d_old2new); l.d_old2new = nullptr; }
     if (l.d_blk_of_row) { (void)dev_free(l.d_blk_of_row); l.d_blk_of_row = nullptr; }

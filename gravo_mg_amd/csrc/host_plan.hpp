@@ -89,15 +89,6 @@ struct LevelOrdering {
     std::vector<int> blk_ncolors;     // n_blocks
     std::vector<unsigned char> row_color;   // n_pad, colour of a row inside its block (padding rows: 0)
     int n_blocks() const { return blk_begin.empty() ? 0 : (int)blk_begin.size() - 1; }
-    // Colour-major levels whose greedy colouring leaves a few TINY classes behind (irregular graphs: a Bilaplacian's 14 classes, five of a
-    // few thousand rows; they come first in the device order): one launch per such class sits at the ~5 us launch floor.  The rows of
-    // the first `tiny_colors` classes are instead grouped into tasks -- unions of connected components of the graph restricted to those
-    // rows, so that no coupling between two of these rows crosses a task -- and ONE launch (kernels.hip.hpp::gs_tiny_colors) gives every
-    // task to a workgroup that walks its rows colour by colour with a barrier in between: the same updates in the same order.
-    int tiny_colors = 0;                    // 0: every class has its own launch
-    std::vector<int> tiny_rows;             // device rows of the tiny classes, grouped by task, inside a task by colour (ascending row)
-    std::vector<int> tiny_seg;              // [task * (tiny_colors + 1) + c]: where colour c of the task starts in tiny_rows
-    int tiny_tasks() const { return tiny_colors > 0 ? (int)tiny_seg.size() / (tiny_colors + 1) : 0; }
 };
 
 struct SellHost {
@@ -260,63 +251,6 @@ inline double mean_index_distance(const Mat& A) {
     return cnt ? sum / cnt : 0.0;
 }
 
-// Tasks of the merged launch for the tiny leading colour classes of a colour-major ordering (LevelOrdering::tiny_*).  A class is tiny when it
-// holds at most n / 64 rows (a launch that moves a few MB sits at the launch floor); at least two of them are needed for the merge to save a
-// launch, and a component of more than 256 rows (classes that are small but connected through each other) calls it off: a workgroup takes a
-// row per thread and colour, more would make it walk the component in rounds.
-template <class Mat>
-inline void plan_tiny_colors(const Mat& A, LevelOrdering& o) {
-    o.tiny_colors = 0; o.tiny_rows.clear(); o.tiny_seg.clear();
-    if (o.blocked || o.n_colors < 3) return;
-    const int limit = o.n / 64;
-    int T = 0;
-    while (T < o.n_colors - 1 && o.color_begin[T + 1] - o.color_begin[T] <= limit) ++T;      // (classes are in ascending size; the last one is never merged)
-    if (T < 2) return;
-    const int R = o.color_begin[T];
-    std::vector<int> uf(R);
-    std::iota(uf.begin(), uf.end(), 0);
-    auto find = [&](int v) { int r = v; while (uf[r] != r) r = uf[r]; while (uf[v] != r) { const int nx = uf[v]; uf[v] = r; v = nx; } return r; };
-    for (int r = 0; r < R; ++r) {
-        const int i = o.new2old[r];
-        if (i < 0) continue;
-        for (int p = A.ptr[i]; p < A.ptr[i + 1]; ++p) {
-            const int q = o.old2new[A.idx[p]];
-            if (q < R && q != r) { const int a = find(r), b = find(q); if (a != b) uf[std::max(a, b)] = std::min(a, b); }
-        }
-    }
-    // components in order of their smallest row; packed greedily into tasks of up to 256 rows
-    std::vector<int> comp_of(R, -1), comp_size;
-    for (int r = 0; r < R; ++r) {
-        if (o.new2old[r] < 0) continue;
-        const int root = find(r);
-        if (comp_of[root] < 0) { comp_of[root] = (int)comp_size.size(); comp_size.push_back(0); }
-        comp_of[r] = comp_of[root];
-        comp_size[comp_of[r]]++;
-    }
-    if (comp_size.empty()) return;
-    if (*std::max_element(comp_size.begin(), comp_size.end()) > 256) return;
-    std::vector<int> task_of_comp(comp_size.size());
-    int n_tasks = 0, fill = 0;
-    for (size_t c = 0; c < comp_size.size(); ++c) {
-        if (n_tasks == 0 || fill + comp_size[c] > 256) { ++n_tasks; fill = 0; }
-        task_of_comp[c] = n_tasks - 1;
-        fill += comp_size[c];
-    }
-    // counting sort of the rows by (task, colour); rows ascend inside a bucket
-    auto colour_of_row = [&](int r) { return (int)(std::upper_bound(o.color_begin.begin(), o.color_begin.begin() + T + 1, r) - o.color_begin.begin()) - 1; };
-    std::vector<int> seg((size_t)n_tasks * (T + 1) + 1, 0);
-    for (int r = 0; r < R; ++r) if (comp_of[r] >= 0) seg[(size_t)task_of_comp[comp_of[r]] * (T + 1) + colour_of_row(r) + 1]++;
-    // (slot t * (T + 1) + c + 1 counts bucket (t, c); the slot in front of every task's first bucket stays 0: the prefix sums below give, in
-    // slot t * (T + 1) + c, the start of bucket (t, c), and in slot t * (T + 1) + T the end of the task == the start of the next one)
-    for (size_t q = 1; q < seg.size(); ++q) seg[q] += seg[q - 1];
-    std::vector<int> at(seg.begin(), seg.end() - 1);
-    o.tiny_rows.resize((size_t)seg.back());
-    for (int r = 0; r < R; ++r) if (comp_of[r] >= 0) o.tiny_rows[(size_t)at[(size_t)task_of_comp[comp_of[r]] * (T + 1) + colour_of_row(r)]++] = r;
-    seg.pop_back();
-    o.tiny_seg.swap(seg);
-    o.tiny_colors = T;
-}
-
 // multicolor = false -> a single "colour" holding every row (Jacobi-type smoothers, coarsest level).
 // reorder: 0 never, 1 always, 2 automatic -- when the input vertex order has poor locality (a randomly ordered scan
 // or point cloud: every gather of x misses the caches, measured 3x per V-cycle at 3 M vertices) the rows inside a
@@ -455,8 +389,6 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
             if (o.new2old[r] >= 0) o.old2new[o.new2old[r]] = r;
     });
     phase("inverse");
-    if (multicolor) plan_tiny_colors(A, o);
-    phase("tiny classes");
     return o;
 }
 

@@ -173,61 +173,6 @@ __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_pt
     } else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 
-// The tiny leading colour classes of a colour-major level in ONE launch (host_plan.hpp::plan_tiny_colors): workgroup t walks the rows of task t
-// colour by colour, a barrier between the colours.  No coupling between two rows of these classes crosses a task, rows of one colour do not
-// couple, so every row sees exactly what it sees when each class has its own launch; the row sum runs over the row's SELL slots in stored
-// order with the same multiply-add as row_dot, the update is gs_color's: the same bits.  One thread per row (the slots of a row are 64 entries
-// apart: uncoalesced, but these classes are a few thousand rows); x is read past the vector L1 (values written by other waves of the
-// workgroup one barrier ago).  Always through the 32-bit column indices.
-template <class T, int D>
-__global__ __launch_bounds__(256) void gs_tiny_colors(const int* __restrict__ task_seg, const int* __restrict__ task_rows, int n_colors,
-                                                      const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const T* __restrict__ val,
-                                                      const T* __restrict__ diag, const T* __restrict__ b, T* x, int ld, T omega) {
-    const int* seg = task_seg + (size_t)blockIdx.x * (n_colors + 1);
-    for (int c = 0; c < n_colors; ++c) {
-        for (int i = seg[c] + (int)threadIdx.x; i < seg[c + 1]; i += 256) {
-            const int row = task_rows[i], s = row >> 6, lane = row & 63;
-            const int64_t p0 = slice_ptr[s];
-            const int w = (int)((slice_ptr[s + 1] - p0) >> 6);
-            T acc[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) acc[k] = 0.0;
-            // groups of kTinyGroup entries: all their index / value loads in flight, then all the gathers, then the multiply-adds in stored
-            // order -- a row costs two memory round trips per group instead of two per entry (a task walks its colours one after the other:
-            // the dependent round trips ARE its run time)
-            constexpr int kTinyGroup = 12;
-            const int* cp = col + p0 + lane;
-            const T* vp = val + p0 + lane;
-            for (int j0 = 0; j0 < w; j0 += kTinyGroup) {
-                int cj[kTinyGroup];
-                T vj[kTinyGroup], xj[kTinyGroup][D];
-#pragma unroll
-                for (int j = 0; j < kTinyGroup; ++j) { const bool in = j0 + j < w; cj[j] = in ? cp[(int64_t)(j0 + j) * 64] : 0; vj[j] = in ? vp[(int64_t)(j0 + j) * 64] : (T)0.0; }
-#pragma unroll
-                for (int j = 0; j < kTinyGroup; ++j)
-#pragma unroll
-                    for (int k = 0; k < D; ++k) xj[j][k] = __hip_atomic_load(x + cj[j] + (int64_t)k * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int j = 0; j < kTinyGroup; ++j)
-                    if (j0 + j < w) {
-#pragma unroll
-                        for (int k = 0; k < D; ++k) acc[k] += vj[j] * xj[j][k];
-                    }
-            }
-            const T dg = diag[row];
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-                T* xp = x + row + (int64_t)k * ld;
-                const T gs = (b[row + (int64_t)k * ld] - acc[k]) / dg;
-                if (omega == (T)1.0) __hip_atomic_store(xp, gs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else { const T xi = __hip_atomic_load(xp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(xp, xi + omega * (gs - xi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-        }
-        __threadfence();
-        __syncthreads();
-    }
-}
-
 // Quad layout (LPR = 4 lanes per row): add the four sub-lane partial sums; every lane of the quad gets the total.
 template <class T, int D>
 __device__ __forceinline__ void quad_reduce(T (&acc)[D]) {

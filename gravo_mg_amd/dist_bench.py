@@ -240,6 +240,7 @@ def main(args):
                                                "what": "every exchange of the engine-driven cycle as pack -> all-gather -> unpack on the engine's stream (gmg_config::dist_exchange); "
                                                        "same partition (levels 0-1), same iterates"}
             del cyc2
+            eng_c.close(); del eng_c
         else:
             variants["rccl_halo_allgather"] = {"ms_per_step": None, "reason": why or "another rank could not set the collective exchange up"}
 

@@ -114,9 +114,6 @@ typedef struct {
                               stream-ordered launches per exchange enqueued by the engine, no hipIpc (gmg_p2p_connect_rccl instead of gmg_p2p_export /
                               gmg_p2p_connect).  2: the same sequence with the all-gather emulated by stores through hipIpc mappings: for ranks that
                               share one device (RCCL refuses that), i.e. for tests of the collective path on a 1-GPU box.  Same iterates in every mode */
-    int merge_tiny_colors; /* 1 (default): the tiny leading colour classes an irregular graph leaves a colour-major level with (a Bilaplacian: 14 classes, five
-                              of a few thousand rows, each a launch at the ~5 us floor) are swept by ONE launch, a workgroup per group of connected rows,
-                              colour by colour with a barrier in between -- the same updates in the same order, bit for bit; 0: a launch per class */
     int prepare_structure; /* 1 (default): when the handle knows the level-0 point graph (gmg_set_fine_graph, gmg_use_hierarchy), gmg_finalize_hierarchy
                               builds everything structural for a system with that sparsity pattern -- orderings, colourings, layouts, symbolic Galerkin
                               products, symbolic LDL^T -- so that the first gmg_set_system with it only moves values.  0: the first system pays for its

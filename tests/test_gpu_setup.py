@@ -440,38 +440,3 @@ def test_structure_prepared_at_hierarchy_time_gives_the_cold_set_ups_bits(cabi, 
         xa = prepared.solve(rhs2, tol=1e-3, max_iter=8)[0]
         xb = fresh.solve(rhs2, tol=1e-3, max_iter=8)[0]
         assert np.array_equal(xa, xb)
-
-
-@pytest.mark.parametrize("case", ["bilaplacian", "sphere", "pointcloud-colour-major", "random-order-d3"])
-def test_tiny_colour_classes_in_one_launch_change_nothing(cabi, case):
-    """Irregular graphs leave a colour-major level 0 with a few tiny colour classes (they come first in the device order); each used to be a
-    launch at the ~5 us floor.  gmg_config::merge_tiny_colors sweeps them in ONE launch -- a workgroup per group of connected rows, colour by
-    colour behind a barrier (kernels.hip.hpp::gs_tiny_colors): the same updates in the same order, so sweeps, cycles and solutions are bit for
-    bit those of the launch-per-class engine (which the matrix-form tests of tests/test_gpu_parity.py pin to the oracle)."""
-    from gravo_mg_amd import meshgen
-    if case == "bilaplacian":
-        P = problems.torus_problem(150, 140, "bilaplacian", 100)
-        kw = {}
-    elif case == "sphere":
-        P = problems.sphere_problem(40_000, lower_bound=200, order="spatial")
-        kw = {}
-    elif case == "pointcloud-colour-major":
-        P = problems.pointcloud_problem(30_000, lower_bound=200)
-        kw = {"block_fine": 0}
-    else:
-        P = problems.torus_problem(150, 140, "smoothing", 100, order="random")
-        kw = {}
-    a = cabi.Engine(**kw); b = cabi.Engine(merge_tiny_colors=False, **kw)
-    for e in (a, b):
-        e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
-    print(case, "colours", a.level_info(0)["n_colors"], "merged classes", a.timing("tiny_colors_l0"), "tasks", a.timing("tiny_tasks_l0"), "rows", a.timing("tiny_rows_l0"))
-    assert b.timing("tiny_colors_l0") == 0.0
-    if case in ("sphere", "random-order-d3"):
-        assert a.timing("tiny_colors_l0") >= 2.0          # these graphs do leave tiny classes behind (a class of at most n / 64 rows)
-    rng = np.random.default_rng(7)
-    x0 = rng.standard_normal(P.rhs.shape)
-    assert np.array_equal(a.smooth(0, P.rhs, x0, 1), b.smooth(0, P.rhs, x0, 1))
-    assert np.array_equal(a.smooth(0, P.rhs, x0, 3), b.smooth(0, P.rhs, x0, 3))
-    for e in (a, b):
-        e.load_problem(P.rhs, P.rhs)
-    assert np.array_equal(a.run_cycles(3, 2), b.run_cycles(3, 2)) and np.array_equal(a.fetch_solution(), b.fetch_solution())
