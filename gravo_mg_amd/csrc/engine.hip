@@ -159,6 +159,9 @@ int gmg_create(const gmg_config* cfg, gmg_handle* out) try {
         { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c.device) == hipSuccess && cus > 0) h->n_cus = cus; else (void)hipGetLastError(); }
         (void)hipEventCreate(&h->ev0);
         (void)hipEventCreate(&h->ev1);
+        if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) { h->aux_stream = nullptr; (void)hipGetLastError(); }
+        if (hipEventCreateWithFlags(&h->aux_ev, hipEventDisableTiming) != hipSuccess) { h->aux_ev = nullptr; (void)hipGetLastError(); }
+        if (hipMalloc((void**)&h->d_aux_err, sizeof(int)) != hipSuccess) { h->d_aux_err = nullptr; (void)hipGetLastError(); }
         h->poll = EnvSwitches::get().poll;
         (void)ensure_bounce(h);         // 2 x 16 MB pinned, once per handle (page-locking is not free: not inside gmg_set_system)
     }
@@ -183,6 +186,9 @@ void gmg_destroy(gmg_handle h) {
         if (h->h_flag) (void)sync_hipHostFree(h->h_flag);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
+        if (h->aux_ev) (void)hipEventDestroy(h->aux_ev);
+        if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)sync_hipStreamDestroy(h->aux_stream); }
+        if (h->d_aux_err) (void)sync_hipFree(h->d_aux_err);
         for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)sync_hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
         for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
         (void)sync_hipStreamDestroy(h->own_stream);
@@ -200,6 +206,7 @@ int gmg_set_num_levels(gmg_handle h, int L) try {
     h->patches.clear(); h->patches_ready = false;
     h->bfs_order.clear();
     h->fine_graph.reset();
+    h->rap_need.clear();
     h->L = L;
     h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
@@ -232,6 +239,7 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
     }
     h->U_set[k] = 1;
     h->ord_cache_valid = false;
+    if (k == 0) h->rap_need.clear();
     return GMG_OK;
 } GMG_CATCH_H
 
@@ -321,7 +329,8 @@ static void coarse_inverse(gmg_handle h, std::vector<double>& inv) {
 // gmg_set_system for a matrix with the sparsity pattern of the live system: values only.  Returns 1 when it cannot be
 // done in place (nothing has been changed then, except values that the full path overwrites anyway).
 // values_uploaded: the caller has already put `val` into the resident A_0 (the speculative upload of set_system_impl)
-static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all, bool values_uploaded = false) {
+// l1_rows_done: ... and has queued the numeric Galerkin pass of the first l1_rows_done rows of level 1 behind it (flag: h->d_aux_err)
+static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all, bool values_uploaded = false, int l1_rows_done = 0) {
     const int L = h->L;
     auto mark = [&](const std::string& what) { h->timing["t_" + what] = ms_since(t_all); };
     for (int k = 0; k <= L; ++k) if (!h->lv[k].dA.ptr || !h->lv[k].dA.idx || !h->lv[k].dA.val) return 1;
@@ -340,7 +349,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     auto t0 = clk::now();
     for (int k = 1; k <= L; ++k) {
         Level& lk = h->lv[k];
-        if ((rc = device_rap(h, h->lv[k - 1].dA, h->dU[k - 1], h->dE3[k - 1], lk.dA, lk.A, false, k == L, &lk.nnz, d_err.p, true))) return rc < 0 ? rc : GMG_ERR_STATE;
+        if ((rc = device_rap(h, h->lv[k - 1].dA, h->dU[k - 1], h->dE3[k - 1], lk.dA, lk.A, false, k == L, &lk.nnz, d_err.p, true, k == 1 ? l1_rows_done : 0))) return rc < 0 ? rc : GMG_ERR_STATE;
         if (k == L) lk.hostA_values = true;
         mark("rap_l" + std::to_string(k));
     }
@@ -357,11 +366,14 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     });
     auto tl = clk::now();
     for (int k = 0; k < L && rc == GMG_OK; ++k) rc = device_refill_level(h, k, d_err.p);
-    int herr = 0;
+    int herr = 0, herr_aux = 0;
     if (rc == GMG_OK) {
         (void)hipMemcpyAsync(&herr, d_err.p, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        if (l1_rows_done > 0) (void)hipMemcpyAsync(&herr_aux, h->d_aux_err, sizeof(int), hipMemcpyDeviceToHost, h->stream);
         (void)hipStreamSynchronize(h->stream);
+        if (herr == 0) herr = herr_aux;
     }
+    h->timing["setup_rap_rows_pipelined"] = l1_rows_done;
     h->timing["setup_device_layout"] = ms_since(tl);
     mark("device_layout");
     const bool factor_ok = factor_done.get();
@@ -409,6 +421,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     // pattern (3-4 ms at 3 M vertices, as long as the upload itself).  Should the pattern be another one after all, nothing is lost but the
     // live system, which the full set-up replaces anyway.
     bool speculative_upload = false;
+    int l1_rows_done = 0;             // coarse rows of level 1 whose numeric Galerkin pass was queued behind the chunks of that upload
     uint64_t pat_key[2] = {0, 0};
     bool have_key = false;
     {
@@ -418,7 +431,36 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             (int64_t)colptr[n] == h->lv[0].nnz && h->lv[0].dA.val) {
             keyed = std::async(std::launch::async, [&] { pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key); });
             h->loaded_d = 0;
-            const int rc_up = h2d(h, h->lv[0].dA.val, val, sizeof(double) * (size_t)h->lv[0].nnz);
+            // ... and the numeric Galerkin pass of level 1 -- the longest kernel of the refresh -- follows the values chunk by chunk on a second
+            // stream: coarse row p needs the rows of A_0 its children are (U_0's column p), and in a locally numbered mesh those arrive in
+            // order (rap_need: the largest child row of the coarse rows 0 .. p).  A randomly numbered input needs the last chunk for the first
+            // row: everything then runs after the upload, as before.
+            const bool pipeline = L >= 2 && h->aux_stream && h->aux_ev && h->d_aux_err && h->dU_ready && (int)h->dU.size() == L && h->dU[0].ptr && h->dE3[0].cnt &&
+                                  h->lv[1].dA.ptr && h->lv[1].dA.idx && h->lv[1].dA.val && h->lv[1].dA.n_outer == h->U[0].n_outer && !h->dU_flagged;
+            if (pipeline && h->rap_need.empty()) {
+                const Compressed& U0 = h->U[0];
+                h->rap_need.resize((size_t)U0.n_outer);
+                int run = -1;
+                for (int p = 0; p < U0.n_outer; ++p) { if (U0.ptr[p + 1] > U0.ptr[p]) run = std::max(run, U0.idx[U0.ptr[p + 1] - 1]); h->rap_need[p] = run; }
+            }
+            const size_t val_bytes = sizeof(double) * (size_t)h->lv[0].nnz;
+            std::function<void(size_t, hipEvent_t)> after_chunk = [&](size_t bytes_done, hipEvent_t arrived) {
+                const int nc = h->U[0].n_outer;
+                const int64_t entries = (int64_t)(bytes_done / sizeof(double));
+                const int rows = (int)(std::upper_bound(colptr, colptr + n + 1, (int)std::min<int64_t>(entries, colptr[n])) - colptr) - 1;      // complete rows of A_0
+                int p_hi = bytes_done >= val_bytes ? nc : (int)(std::upper_bound(h->rap_need.begin(), h->rap_need.end(), rows - 1) - h->rap_need.begin());
+                if (p_hi - l1_rows_done < 32768 && bytes_done < val_bytes) return;
+                if (p_hi <= l1_rows_done) return;
+                (void)hipStreamWaitEvent(h->aux_stream, arrived, 0);
+                const DevCsr &dA0 = h->lv[0].dA, &dU0 = h->dU[0], &dC = h->lv[1].dA;
+                const DevEll3& e3 = h->dE3[0];
+                hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(p_hi - l1_rows_done), dim3(64), 0, h->aux_stream, dA0.ptr, dA0.idx, dA0.val, dU0.ptr, dU0.idx, dU0.val, e3.cnt, e3.col, e3.val, nc,
+                                   (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, h->d_aux_err, l1_rows_done);
+                l1_rows_done = p_hi;
+            };
+            if (pipeline) (void)hipMemsetAsync(h->d_aux_err, 0, sizeof(int), h->aux_stream);
+            const int rc_up = h2d(h, h->lv[0].dA.val, val, val_bytes, pipeline ? &after_chunk : nullptr);
+            if (pipeline) { (void)hipEventRecord(h->aux_ev, h->aux_stream); (void)hipStreamWaitEvent(h->stream, h->aux_ev, 0); }
             speculative_upload = true;
             keyed.get();
             have_key = true;
@@ -446,7 +488,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         const bool keeps_fine_blocks = !(h->lv[0].ord.blocked && h->cfg.block_from_level >= 1) || stieltjes_signs(n, colptr, rowidx, val, h->cfg.host_threads);
         if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz && keeps_fine_blocks) {
             const bool from_placeholder = h->placeholder_ready && !h->system_ready;
-            int rc = refresh_system_values(h, n, val, t_all, speculative_upload);
+            int rc = refresh_system_values(h, n, val, t_all, speculative_upload, speculative_upload ? l1_rows_done : 0);
             if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
             if (rc == GMG_OK) { h->system_ready = true; h->placeholder_ready = false; h->timing["setup_structure_prepared"] = from_placeholder ? 1.0 : 0.0; }
             if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything

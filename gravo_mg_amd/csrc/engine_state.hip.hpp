@@ -139,6 +139,9 @@ struct Level {
     int ep_cap_e = 0, ep_cap_l = 0;      // most explicit / lower entries of one block (explicit: rounded up to 64): LDS capacity of the sweep
     int *d_blk_begin = nullptr, *d_blk_ncolors = nullptr;
     unsigned char* d_row_color = nullptr;
+    // where every stored slot of the operator layouts came from in dA.val (-1: padding), made with the layouts: a system with the live
+    // sparsity pattern refreshes the values by plain gathers (engine_setup.hip.hpp::device_refill_level); not made for a partitioned set-up
+    int *src_A = nullptr, *src_diag = nullptr, *src_ee = nullptr, *src_ep = nullptr;
     int* d_new2old = nullptr;
     int* d_old2new = nullptr;         // kept after the layout (with d_blk_of_row) so that a system with the same pattern can
     int* d_blk_of_row = nullptr;      // refill the value arrays in place (refresh_system_values)
@@ -253,6 +256,11 @@ struct gmg_solver_s {
     std::map<int, hipGraphExec_t> graphs;
     int loaded_d = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second stream + event: the numeric Galerkin pass of level 1 runs there, range by range, behind the chunks of a values upload (set_system_impl)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_ev = nullptr;
+    int* d_aux_err = nullptr;             // error flag of the kernels queued on aux_stream
+    std::vector<int> rap_need;            // [coarse row p of level 1]: the largest fine row any of the rows 0 .. p prolongs from (cumulative): rows 0 .. p are computable once it has arrived
     std::vector<hipEvent_t> prof_ev;     // gmg_profile_cycle: events at the boundaries of a cycle's legs (prof_on: record them)
     bool prof_on = false; int prof_n = 0;
     bool il_r0 = false;                   // enqueue_down, level 0, d > 1: the residual is being written as an interleaved multi-vector
@@ -332,7 +340,8 @@ static void threaded_copy_bytes(void* dst, const void* src, size_t bytes, int th
     }, 1);
 }
 
-static int h2d(gmg_handle h, void* dst, const void* src, size_t bytes) {
+// after_chunk (optional): called after every chunk has been put on the wire, with the bytes issued so far and the event that completes with that chunk
+static int h2d(gmg_handle h, void* dst, const void* src, size_t bytes, const std::function<void(size_t, hipEvent_t)>* after_chunk = nullptr) {
     if (bytes < kBounceMin) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream)); return GMG_OK; }
     int rc = ensure_bounce(h);
     if (rc) return rc;
@@ -350,6 +359,7 @@ static int h2d(gmg_handle h, void* dst, const void* src, size_t bytes) {
         auto t2 = clk::now();
         HIPCHK(hipMemcpyAsync((char*)dst + off, h->bounce[f], len, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipEventRecord(h->bounce_ev[f], h->stream));
+        if (after_chunk) (*after_chunk)(off + len, h->bounce_ev[f]);
         if (trace) { t_wait += std::chrono::duration<double, std::milli>(t1 - t0).count(); t_copy += std::chrono::duration<double, std::milli>(t2 - t1).count(); t_issue += ms_since(t2); }
     }
     if (trace && bytes >= ((size_t)32 << 20))
@@ -533,6 +543,7 @@ void free_level(Level& l) {
     if (l.d_row_color) { (void)dev_free(l.d_row_color); l.d_row_color = nullptr; }
     for (double** p : {&l.diag, &l.x, &l.b, &l.r, &l.tmp}) { if (*p) (void)dev_free(*p); *p = nullptr; }
     for (float** p : {&l.diag32, &l.x32, &l.b32, &l.r32, &l.tmp32}) { if (*p) (void)dev_free(*p); *p = nullptr; }
+    for (int** q : {&l.src_A, &l.src_diag, &l.src_ee, &l.src_ep}) { if (*q) (void)dev_free(*q); *q = nullptr; }
     if (l.d_new2old) { (void)dev_free(l.d_new2old); l.d_new2old = nullptr; }
     if (l.d_old2new) { (void)dev_free(l.d_old2new); l.d_old2new = nullptr; }
     if (l.d_blk_of_row) { (void)dev_free(l.d_blk_of_row); l.d_blk_of_row = nullptr; }

@@ -148,7 +148,7 @@ template <class ColT, int CAP>
 __device__ __forceinline__ void sell_fill_row(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
                                               const double* __restrict__ val, const RowFilter& f, int lpr, int r, int old, int s, int l,
                                               const int64_t* __restrict__ slice_ptr, ColT* __restrict__ col, double* __restrict__ out_val,
-                                              double* __restrict__ diag, int* __restrict__ err_flag) {
+                                              double* __restrict__ diag, int* __restrict__ err_flag, int* __restrict__ src, int* __restrict__ diag_src) {
     RowCols<CAP> R;
     double dg = 1.0;
     bool has_diag = old < 0;
@@ -157,26 +157,31 @@ __device__ __forceinline__ void sell_fill_row(const int* __restrict__ pbeg, cons
         if (ok && f.drop_diag && (!has_diag || dg == 0.0)) atomicExch(err_flag, 2);      // missing / zero diagonal
         diag[r] = dg;
     }
+    if (diag_src) diag_src[r] = -1;
     const int64_t base = slice_ptr[s];
     const int w = (int)((slice_ptr[s + 1] - base) >> 6);
     auto at = [&](int e) { return base + (int64_t)(e / lpr) * 64 + l * lpr + (e % lpr); };
     if (old >= 0 && ok)
         for (int p = pbeg[old]; p < pend[old]; ++p) {
             const int oc = idx[p];
-            if (f.drop_diag && oc == old) continue;
+            if (f.drop_diag && oc == old) { if (diag_src) diag_src[r] = p; continue; }
             int c;
             if (!keep_entry(f, r, old, oc, c)) continue;
             const int64_t q = at(cols_rank<CAP>(R, c));
             col[q] = (ColT)c; out_val[q] = val[p];
+            if (src) src[q] = p;
         }
-    for (int e = ok ? R.n : 0; e < w * lpr; ++e) { const int64_t q = at(e); col[q] = (ColT)0; out_val[q] = 0.0; }
+    for (int e = ok ? R.n : 0; e < w * lpr; ++e) { const int64_t q = at(e); col[q] = (ColT)0; out_val[q] = 0.0; if (src) src[q] = -1; }
 }
 
 template <class ColT>
 __global__ void sell_fill(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
                           const double* __restrict__ val, RowFilter f,
                           const int* __restrict__ order, int lpr, int n_rows_pad, const int64_t* __restrict__ slice_ptr,
-                          ColT* __restrict__ col, double* __restrict__ out_val, double* __restrict__ diag, int* __restrict__ err_flag) {
+                          ColT* __restrict__ col, double* __restrict__ out_val, double* __restrict__ diag, int* __restrict__ err_flag,
+                          int* __restrict__ src = nullptr, int* __restrict__ diag_src = nullptr) {
+    // src / diag_src (optional): where every slot / diagonal entry came from in `val` (-1: padding) -- what a system with the same sparsity pattern
+    // needs to refresh the values by a plain gather (refill_values) instead of ranking the columns of every row again
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n_rows_pad;
     const int rps = 64 / lpr;
@@ -185,9 +190,9 @@ __global__ void sell_fill(const int* __restrict__ pbeg, const int* __restrict__ 
     const int old = live ? f.new2old_row[r] : -1;
     const int wmax = wave_max_raw_len(pbeg, pend, old);          // (all lanes take part in the shuffles)
     if (!live) return;
-    if (wmax <= 8) sell_fill_row<ColT, 8>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag);
-    else if (wmax <= 32) sell_fill_row<ColT, 32>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag);
-    else sell_fill_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag);
+    if (wmax <= 8) sell_fill_row<ColT, 8>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag, src, diag_src);
+    else if (wmax <= 32) sell_fill_row<ColT, 32>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag, src, diag_src);
+    else sell_fill_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, lpr, r, old, s, l, slice_ptr, col, out_val, diag, err_flag, src, diag_src);
 }
 
 // Block-CSR of a big blocked level (kernels.hip.hpp::gs_blockcsr): off-diagonal entries of device row r at
@@ -240,7 +245,7 @@ __global__ void csr_fill(const int* __restrict__ pbeg, const int* __restrict__ p
 template <class ColT, int CAP>
 __device__ __forceinline__ void csr_fill_plain_row(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx,
                                                    const double* __restrict__ val, const RowFilter& f, int r, int old, const int* __restrict__ row_ptr,
-                                                   ColT* __restrict__ col, double* __restrict__ out_val, int* __restrict__ err_flag) {
+                                                   ColT* __restrict__ col, double* __restrict__ out_val, int* __restrict__ err_flag, int* __restrict__ src) {
     RowCols<CAP> R;
     double dg = 1.0; bool hd = false;
     if (!cols_gather<CAP>(pbeg, pend, idx, val, f, r, old, R, dg, hd, err_flag)) return;
@@ -250,21 +255,41 @@ __device__ __forceinline__ void csr_fill_plain_row(const int* __restrict__ pbeg,
         if (!keep_entry(f, r, old, idx[p], c)) continue;
         const int q = q0 + cols_rank<CAP>(R, c);
         col[q] = (ColT)c; out_val[q] = val[p];
+        if (src) src[q] = p;
     }
 }
 
 template <class ColT>
 __global__ void csr_fill_plain(const int* __restrict__ pbeg, const int* __restrict__ pend, const int* __restrict__ idx, const double* __restrict__ val,
                                RowFilter f, int n_rows_pad, const int* __restrict__ row_ptr, ColT* __restrict__ col, double* __restrict__ out_val,
-                               int* __restrict__ err_flag) {
+                               int* __restrict__ err_flag, int* __restrict__ src = nullptr) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = r < n_rows_pad;
     const int old = live ? f.new2old_row[r] : -1;
     const int wmax = wave_max_raw_len(pbeg, pend, old);
     if (!live || old < 0) return;
-    if (wmax <= 8) csr_fill_plain_row<ColT, 8>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
-    else if (wmax <= 32) csr_fill_plain_row<ColT, 32>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
-    else csr_fill_plain_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag);
+    if (wmax <= 8) csr_fill_plain_row<ColT, 8>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag, src);
+    else if (wmax <= 32) csr_fill_plain_row<ColT, 32>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag, src);
+    else csr_fill_plain_row<ColT, kMaxRow>(pbeg, pend, idx, val, f, r, old, row_ptr, col, out_val, err_flag, src);
+}
+
+// Values-only refresh of a layout through its source map (sell_fill / csr_fill_plain with `src`): out[q] = val[src[q]], 0 for padding slots.
+__global__ void refill_values(const int* __restrict__ src, const double* __restrict__ val, int64_t n, double* __restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const int p = __builtin_nontemporal_load(src + q);
+    out[q] = p >= 0 ? val[p] : 0.0;
+}
+// ... and of the diagonal: diag[r] = val[diag_src[r]] (1 for padding rows); a zero diagonal entry raises the error flag (2) like sell_fill
+__global__ void refill_diag(const int* __restrict__ diag_src, const int* __restrict__ new2old, const double* __restrict__ val, int n_pad, double* __restrict__ diag,
+                            int* __restrict__ err_flag) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_pad) return;
+    const int p = diag_src[r];
+    double dg = 1.0;
+    if (p >= 0) { dg = val[p]; if (dg == 0.0) atomicExch(err_flag, 2); }
+    else if (new2old[r] >= 0) atomicExch(err_flag, 2);
+    diag[r] = dg;
 }
 
 // 16-bit column codes of a SELL operator (kernels.hip.hpp, "16-bit column codes"): one wavefront per slice, NW windows of 65536 / NW
@@ -560,10 +585,10 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
                                                const int* __restrict__ u_cptr, const int* __restrict__ u_ridx, const double* __restrict__ u_cval,
                                                const int* __restrict__ ur_cnt, const int* __restrict__ ur_col, const double* __restrict__ ur_val,
                                                int n_coarse, const int* __restrict__ c_ptr, int* __restrict__ c_cnt, int* __restrict__ c_idx,
-                                               double* __restrict__ c_val, int* __restrict__ err_flag) {
+                                               double* __restrict__ c_val, int* __restrict__ err_flag, int p_begin = 0) {
 #pragma clang fp contract(off)      // multiply and add rounded separately, like the host implementation (no FMA)
     __shared__ int keys[kRapSet];
-    const int p = blockIdx.x;
+    const int p = p_begin + (int)blockIdx.x;      // (p_begin: a range of coarse rows -- the numeric pass pipelined behind the upload of the values, engine.hip)
     const int lane = threadIdx.x;
     if (p >= n_coarse) return;
     for (int s = lane; s < kRapSet; s += 64) keys[s] = 0x7fffffff;

@@ -195,6 +195,26 @@ def main(args):
     colls_per_cycle = (dv.n_collectives / max(n_warm + args.warmup + args.steps, 1)) if dv is not None else 0
 
     variants = {}
+    # ---- variant (never `value`): hybrid Gauss-Seidel on level 0 (SURVEY.md 8e) -- GS inside a rank, Jacobi across ranks, ONE exchange per
+    # sweep instead of one per colour: fewer, equally small messages; the iterates depend on the rank count, so the cycle count is recorded
+    if p2p is not None and world > 1:
+        p2p.set_smoother(True)
+        load()
+        hh = []
+        while True:
+            hh += run(1)
+            if not (hh[-1] > 1e-4 and len(hh) < 100):
+                break
+        load(); run(args.warmup)
+        torch.cuda.synchronize(); dist.barrier()
+        th0 = time.perf_counter(); run(args.steps); torch.cuda.synchronize(); dist.barrier()
+        th = torch.tensor([time.perf_counter() - th0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        p2p.set_smoother(False)
+        variants["hybrid_gs"] = {"ms_per_step": 1e3 * float(th.item()) / args.steps, "iterations_to_1e-4": len(hh), "residues": [float(v) for v in hh],
+                                 "exchanges_per_cycle_level0": 2 + 2 + 1,
+                                 "what": "level 0: Gauss-Seidel inside a rank, Jacobi across ranks, one halo exchange per sweep (gmg_p2p_set_smoother); the default exchanges after every colour"}
+
     # ---- variant (never `value`): the north star's collective -- an all-gather of the packed x halo after every colour sweep -- as the ENGINE runs
     # it (gmg_config::dist_exchange): pack -> all-gather -> unpack enqueued on the engine's stream, the same partition plan and kernels around it,
     # no Python between the colours.  With one device per rank the all-gather is ncclAllGather (librccl, loaded by the library); ranks that share
@@ -243,26 +263,6 @@ def main(args):
             eng_c.close(); del eng_c
         else:
             variants["rccl_halo_allgather"] = {"ms_per_step": None, "reason": why or "another rank could not set the collective exchange up"}
-
-    # ---- variant (never `value`): hybrid Gauss-Seidel on level 0 (SURVEY.md 8e) -- GS inside a rank, Jacobi across ranks, ONE exchange per
-    # sweep instead of one per colour: fewer, equally small messages; the iterates depend on the rank count, so the cycle count is recorded
-    if p2p is not None and world > 1:
-        p2p.set_smoother(True)
-        load()
-        hh = []
-        while True:
-            hh += run(1)
-            if not (hh[-1] > 1e-4 and len(hh) < 100):
-                break
-        load(); run(args.warmup)
-        torch.cuda.synchronize(); dist.barrier()
-        th0 = time.perf_counter(); run(args.steps); torch.cuda.synchronize(); dist.barrier()
-        th = torch.tensor([time.perf_counter() - th0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(th, op=dist.ReduceOp.MAX)
-        p2p.set_smoother(False)
-        variants["hybrid_gs"] = {"ms_per_step": 1e3 * float(th.item()) / args.steps, "iterations_to_1e-4": len(hh), "residues": [float(v) for v in hh],
-                                 "exchanges_per_cycle_level0": 2 + 2 + 1,
-                                 "what": "level 0: Gauss-Seidel inside a rank, Jacobi across ranks, one halo exchange per sweep (gmg_p2p_set_smoother); the default exchanges after every colour"}
 
     load()
     t = time.perf_counter()
