@@ -96,6 +96,30 @@ int gate_unwound(gmg_handle h);
 
 void p2p_release_handle(gmg_handle h);      // engine_dist.hip.hpp
 
+// The order in which the numeric Galerkin pass of level 1 can follow the upload of A_0's values (set_system_impl): coarse row p needs the rows of
+// A_0 its children are (U_0's column p, ascending), so the coarse rows are bucketed by their largest child (64 fine rows per bucket, counting
+// sort) -- in a locally numbered mesh a tenth of them becomes computable with every tenth of the upload.
+static void drop_rap_order(gmg_handle h) {
+    h->rap_need.clear();
+    if (h->d_rap_order) { (void)sync_hipFree(h->d_rap_order); h->d_rap_order = nullptr; }
+}
+static bool ensure_rap_order(gmg_handle h) {
+    if (!h->rap_need.empty() && h->d_rap_order) return true;
+    drop_rap_order(h);
+    const Compressed& U0 = h->U[0];
+    const int nc = U0.n_outer, nf = U0.n_inner;
+    if (nc <= 0 || nf <= 0) return false;
+    const int nb = (nf + 63) / 64 + 1;                    // (bucket 0: coarse rows without children)
+    std::vector<int> start((size_t)nb + 1, 0), order((size_t)nc), bucket((size_t)nc);
+    for (int p = 0; p < nc; ++p) { bucket[p] = U0.ptr[p + 1] > U0.ptr[p] ? (U0.idx[U0.ptr[p + 1] - 1] >> 6) + 1 : 0; ++start[(size_t)bucket[p] + 1]; }
+    for (int b = 0; b < nb; ++b) start[b + 1] += start[b];
+    h->rap_need.resize((size_t)nc);
+    for (int p = 0; p < nc; ++p) { const int at = start[bucket[p]]++; order[at] = p; h->rap_need[at] = bucket[p] > 0 ? (bucket[p] - 1) * 64 + 63 : -1; }
+    if (hipMalloc((void**)&h->d_rap_order, sizeof(int) * (size_t)nc) != hipSuccess) { (void)hipGetLastError(); h->d_rap_order = nullptr; h->rap_need.clear(); return false; }
+    if (hipMemcpy(h->d_rap_order, order.data(), sizeof(int) * (size_t)nc, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); drop_rap_order(h); return false; }
+    return true;
+}
+
 extern "C" {
 
 int gmg_config_default(gmg_config* cfg) try {
@@ -189,6 +213,7 @@ void gmg_destroy(gmg_handle h) {
         if (h->aux_ev) (void)hipEventDestroy(h->aux_ev);
         if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)sync_hipStreamDestroy(h->aux_stream); }
         if (h->d_aux_err) (void)sync_hipFree(h->d_aux_err);
+        drop_rap_order(h);
         for (int i = 0; i < 2; ++i) { if (h->bounce[i]) (void)sync_hipHostFree(h->bounce[i]); if (h->bounce_ev[i]) (void)hipEventDestroy(h->bounce_ev[i]); }
         for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
         (void)sync_hipStreamDestroy(h->own_stream);
@@ -206,7 +231,7 @@ int gmg_set_num_levels(gmg_handle h, int L) try {
     h->patches.clear(); h->patches_ready = false;
     h->bfs_order.clear();
     h->fine_graph.reset();
-    h->rap_need.clear();
+    drop_rap_order(h);
     h->L = L;
     h->ord_cache_valid = false;
     h->U.assign(L, Compressed());
@@ -239,7 +264,7 @@ int gmg_set_prolongation(gmg_handle h, int k, int n_fine, int n_coarse, const in
     }
     h->U_set[k] = 1;
     h->ord_cache_valid = false;
-    if (k == 0) h->rap_need.clear();
+    if (k == 0) drop_rap_order(h);
     return GMG_OK;
 } GMG_CATCH_H
 
@@ -424,6 +449,8 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     int l1_rows_done = 0;             // coarse rows of level 1 whose numeric Galerkin pass was queued behind the chunks of that upload
     uint64_t pat_key[2] = {0, 0};
     bool have_key = false;
+    int rc_spec = 1;                  // result of the refresh that ran ahead of the verdict (spec_done)
+    bool spec_done = false;
     {
         std::future<int> inspected = std::async(std::launch::async, [&] { return inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads); });
         std::future<void> keyed;
@@ -432,36 +459,34 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             keyed = std::async(std::launch::async, [&] { pattern_key(n, colptr, rowidx, h->cfg.host_threads, pat_key); });
             h->loaded_d = 0;
             // ... and the numeric Galerkin pass of level 1 -- the longest kernel of the refresh -- follows the values chunk by chunk on a second
-            // stream: coarse row p needs the rows of A_0 its children are (U_0's column p), and in a locally numbered mesh those arrive in
-            // order (rap_need: the largest child row of the coarse rows 0 .. p).  A randomly numbered input needs the last chunk for the first
-            // row: everything then runs after the upload, as before.
+            // stream, over the coarse rows in the order in which their inputs arrive (ensure_rap_order).  A randomly numbered input needs the
+            // last chunk for nearly every row: everything then runs after the upload, as before.
             const bool pipeline = L >= 2 && h->aux_stream && h->aux_ev && h->d_aux_err && h->dU_ready && (int)h->dU.size() == L && h->dU[0].ptr && h->dE3[0].cnt &&
-                                  h->lv[1].dA.ptr && h->lv[1].dA.idx && h->lv[1].dA.val && h->lv[1].dA.n_outer == h->U[0].n_outer && !h->dU_flagged;
-            if (pipeline && h->rap_need.empty()) {
-                const Compressed& U0 = h->U[0];
-                h->rap_need.resize((size_t)U0.n_outer);
-                int run = -1;
-                for (int p = 0; p < U0.n_outer; ++p) { if (U0.ptr[p + 1] > U0.ptr[p]) run = std::max(run, U0.idx[U0.ptr[p + 1] - 1]); h->rap_need[p] = run; }
-            }
+                                  h->lv[1].dA.ptr && h->lv[1].dA.idx && h->lv[1].dA.val && h->lv[1].dA.n_outer == h->U[0].n_outer && !h->dU_flagged && ensure_rap_order(h);
             const size_t val_bytes = sizeof(double) * (size_t)h->lv[0].nnz;
             std::function<void(size_t, hipEvent_t)> after_chunk = [&](size_t bytes_done, hipEvent_t arrived) {
                 const int nc = h->U[0].n_outer;
                 const int64_t entries = (int64_t)(bytes_done / sizeof(double));
-                const int rows = (int)(std::upper_bound(colptr, colptr + n + 1, (int)std::min<int64_t>(entries, colptr[n])) - colptr) - 1;      // complete rows of A_0
+                // complete rows of A_0 (a colptr that is not ascending -- the inspection is still running -- gives some row count: the rows computed from
+                // it are recomputed by the full set-up that follows a failed inspection)
+                const int rows = (int)(std::upper_bound(colptr, colptr + n + 1, (int)std::min<int64_t>(entries, colptr[n])) - colptr) - 1;
                 int p_hi = bytes_done >= val_bytes ? nc : (int)(std::upper_bound(h->rap_need.begin(), h->rap_need.end(), rows - 1) - h->rap_need.begin());
                 if (p_hi - l1_rows_done < 32768 && bytes_done < val_bytes) return;
                 if (p_hi <= l1_rows_done) return;
                 (void)hipStreamWaitEvent(h->aux_stream, arrived, 0);
                 const DevCsr &dA0 = h->lv[0].dA, &dU0 = h->dU[0], &dC = h->lv[1].dA;
                 const DevEll3& e3 = h->dE3[0];
-                hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(p_hi - l1_rows_done), dim3(64), 0, h->aux_stream, dA0.ptr, dA0.idx, dA0.val, dU0.ptr, dU0.idx, dU0.val, e3.cnt, e3.col, e3.val, nc,
-                                   (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, h->d_aux_err, l1_rows_done);
+                hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(p_hi - l1_rows_done), dim3(64), 0, h->aux_stream, dA0.ptr, dA0.idx, dA0.val, dU0.ptr, dU0.idx, dU0.val, e3.cnt, e3.col, e3.val, p_hi,
+                                   (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, h->d_aux_err, l1_rows_done, (const int*)h->d_rap_order);
                 l1_rows_done = p_hi;
             };
             if (pipeline) (void)hipMemsetAsync(h->d_aux_err, 0, sizeof(int), h->aux_stream);
             const int rc_up = h2d(h, h->lv[0].dA.val, val, val_bytes, pipeline ? &after_chunk : nullptr);
             if (pipeline) { (void)hipEventRecord(h->aux_ev, h->aux_stream); (void)hipStreamWaitEvent(h->stream, h->aux_ev, 0); }
             speculative_upload = true;
+            // ... and so does the rest of the refresh (Galerkin chain, layout refills, numeric LDL^T): none of it reads the pattern the threads are
+            // still inspecting, all of it is overwritten by the full set-up should the verdict be "another pattern"
+            if (rc_up == GMG_OK) { rc_spec = refresh_system_values(h, n, val, t_all, true, l1_rows_done); spec_done = true; }
             keyed.get();
             have_key = true;
             if (rc_up != GMG_OK) { (void)inspected.get(); h->system_ready = false; h->placeholder_ready = false; return rc_up; }
@@ -474,7 +499,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             have_key = false;
             // (the values went up in the caller's storage order, the resident pattern is canonical: the live system is void, and this
             // matrix takes the full set-up from its canonical copy)
-            if (speculative_upload) { speculative_upload = false; h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }
+            if (speculative_upload) { speculative_upload = false; spec_done = false; h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }
         }
     }
     // (live: a system is set -- or the structure of one was prepared on placeholder values when the hierarchy was finalized, prepare_structure)
@@ -488,9 +513,13 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         const bool keeps_fine_blocks = !(h->lv[0].ord.blocked && h->cfg.block_from_level >= 1) || stieltjes_signs(n, colptr, rowidx, val, h->cfg.host_threads);
         if (pat_key[0] == h->live_key[0] && pat_key[1] == h->live_key[1] && colptr[n] == h->lv[0].nnz && keeps_fine_blocks) {
             const bool from_placeholder = h->placeholder_ready && !h->system_ready;
-            int rc = refresh_system_values(h, n, val, t_all, speculative_upload, speculative_upload ? l1_rows_done : 0);
+            int rc = spec_done ? rc_spec : refresh_system_values(h, n, val, t_all);
             if (rc != GMG_OK && rc != 1) { h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }      // half-refreshed values: no solves on them
-            if (rc == GMG_OK) { h->system_ready = true; h->placeholder_ready = false; h->timing["setup_structure_prepared"] = from_placeholder ? 1.0 : 0.0; }
+            if (rc == GMG_OK) {
+                h->system_ready = true; h->placeholder_ready = false; h->timing["setup_structure_prepared"] = from_placeholder ? 1.0 : 0.0;
+                h->timing["t_verdict"] = h->timing["setup_total"] = ms_since(t_all);
+                h->timing["upload"] = h->timing["setup_total"] - h->timing["reduction"];
+            }
             if (rc != 1) return rc;                 // 1: could not be done in place -> the full path below rebuilds everything
         }
     }
@@ -986,7 +1015,7 @@ static int prepare_structure(gmg_handle h) {
     }
     h->placeholder_ready = h->refill_ready && h->live_key_valid;
     // (the level vectors of a one-column problem, so that the first solve does not pay their allocation either; a wider block re-allocates)
-    if (h->placeholder_ready) (void)ensure_vectors(h, 1);
+    if (h->placeholder_ready) { (void)ensure_vectors(h, 1); (void)ensure_rap_order(h); }
     h->mass_dirty = !h->mass.empty();
     h->timing["structure_prepare_ms"] = ms_since(t0);
     return GMG_OK;
@@ -1999,8 +2028,14 @@ int gmg_finalize_hierarchy(gmg_handle h) try {
     if (patches.valid()) patches.get();
     // with the point graph at hand: everything structural for the systems to come, on placeholder values (prepare_structure)
     if (rc == GMG_OK && h->cfg.prepare_structure && h->cfg.device_setup && h->cfg.device_rap && h->fine_graph && h->fine_graph->n == h->U[0].n_inner && !h->placeholder_ready &&
-        !h->system_ready)
-        rc = prepare_structure(h);
+        !h->system_ready) {
+        // (an optional preparation: should it fail -- device memory, a graph the device builders cannot take -- the handle is left as a handle
+        // without a system and the first gmg_set_system pays for its structure; the reason stays readable through "structure_prepare_failed")
+        const int prc = prepare_structure(h);
+        h->timing["structure_prepare_failed"] = prc == GMG_OK ? 0.0 : 1.0;
+        if (prc != GMG_OK) { drop_system(h); h->live_key_valid = false; h->system_ready = false; }
+        h->fine_graph.reset();      // the digest of the prepared pattern is all that is needed from here on
+    }
     return rc;
 } GMG_CATCH_H
 

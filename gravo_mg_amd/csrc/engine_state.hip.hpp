@@ -260,7 +260,10 @@ struct gmg_solver_s {
     hipStream_t aux_stream = nullptr;
     hipEvent_t aux_ev = nullptr;
     int* d_aux_err = nullptr;             // error flag of the kernels queued on aux_stream
-    std::vector<int> rap_need;            // [coarse row p of level 1]: the largest fine row any of the rows 0 .. p prolongs from (cumulative): rows 0 .. p are computable once it has arrived
+    // the coarse rows of level 1 in the order in which the rows of A_0 they need arrive: d_rap_order[i] = coarse row, rap_need[i] = an upper bound of the
+    // largest fine row the rows d_rap_order[0 .. i] prolong from (ascending): those are computable once that row has arrived (ensure_rap_order)
+    std::vector<int> rap_need;
+    int* d_rap_order = nullptr;
     std::vector<hipEvent_t> prof_ev;     // gmg_profile_cycle: events at the boundaries of a cycle's legs (prof_on: record them)
     bool prof_on = false; int prof_n = 0;
     bool il_r0 = false;                   // enqueue_down, level 0, d > 1: the residual is being written as an interleaved multi-vector

@@ -585,12 +585,14 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
                                                const int* __restrict__ u_cptr, const int* __restrict__ u_ridx, const double* __restrict__ u_cval,
                                                const int* __restrict__ ur_cnt, const int* __restrict__ ur_col, const double* __restrict__ ur_val,
                                                int n_coarse, const int* __restrict__ c_ptr, int* __restrict__ c_cnt, int* __restrict__ c_idx,
-                                               double* __restrict__ c_val, int* __restrict__ err_flag, int p_begin = 0) {
+                                               double* __restrict__ c_val, int* __restrict__ err_flag, int p_begin = 0,
+                                               const int* __restrict__ row_list = nullptr) {
 #pragma clang fp contract(off)      // multiply and add rounded separately, like the host implementation (no FMA)
     __shared__ int keys[kRapSet];
-    const int p = p_begin + (int)blockIdx.x;      // (p_begin: a range of coarse rows -- the numeric pass pipelined behind the upload of the values, engine.hip)
+    // (p_begin / row_list: a range of coarse rows, or of a list of them -- the numeric pass pipelined behind the upload of the values, engine.hip)
+    if (p_begin + (int)blockIdx.x >= n_coarse) return;
+    const int p = row_list ? row_list[p_begin + (int)blockIdx.x] : p_begin + (int)blockIdx.x;
     const int lane = threadIdx.x;
-    if (p >= n_coarse) return;
     for (int s = lane; s < kRapSet; s += 64) keys[s] = 0x7fffffff;
     __syncthreads();
     const int ub = u_cptr[p], ue = u_cptr[p + 1];

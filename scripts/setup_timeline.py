@@ -11,7 +11,7 @@ if len(sys.argv) > 2:
 ev.sort()
 # the last set_system: from the last 'row_lengths' burst back to the preceding big H2D copy chain; take the window that starts at the last
 # gap > 100 ms before the final rap_rows<0> launch
-raps = [i for i, e in enumerate(ev) if "rap_rows<0>" in e[2]]
+raps = [i for i, e in enumerate(ev) if "rap_rows<" in e[2]]
 cold = [i for i in raps]
 # first rap_rows<0> of the last cold set-up = the one preceded (within 30 ms) by large H2D copies and whose chain has >= 3 count passes
 starts = []

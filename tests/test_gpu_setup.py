@@ -185,6 +185,51 @@ def test_same_pattern_refreshes_values_in_place(cabi, variant):
     assert eng.timing("setup_values_only") == 0.0
 
 
+def test_another_pattern_of_the_same_size_and_entry_count_takes_the_full_set_up(cabi):
+    """gmg_set_system refreshes the live system's values AHEAD of the pattern verdict whenever size and entry count match (upload, Galerkin
+    chain, refills and numeric LDL^T run beside the threads that inspect and digest the pattern).  When the verdict is "another pattern" --
+    here: a few vertices renumbered, and then the live pattern in unsorted storage -- the full set-up must follow and give a fresh engine's bits."""
+    import scipy.sparse as sp
+    P = problems.torus_problem(96, 80, "smoothing", 60)
+    n = P.lhs.shape[0]
+    perm = np.arange(n); perm[100:400] = perm[100:400][::-1].copy()
+    B = sp.csc_matrix(sp.csr_matrix(P.lhs)[perm][:, perm]); B.sort_indices()
+    assert B.nnz == P.lhs.nnz and not (np.array_equal(B.indices, sp.csc_matrix(P.lhs).indices) and np.array_equal(B.indptr, sp.csc_matrix(P.lhs).indptr))
+    eng = cabi.Engine(); eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    eng.set_system(B)
+    assert eng.timing("setup_values_only") == 0.0
+    fresh = cabi.Engine(); fresh.set_prolongations(P.U); fresh.set_mass(P.mass); fresh.set_system(B)
+    for k in range(eng.num_levels + 1):
+        A1, A2 = eng.level_operator(k), fresh.level_operator(k)
+        assert np.array_equal(A1.indptr, A2.indptr) and np.array_equal(A1.indices, A2.indices) and np.array_equal(A1.data, A2.data)
+    eng.load_problem(P.rhs, P.rhs); fresh.load_problem(P.rhs, P.rhs)
+    assert np.array_equal(eng.run_cycles(4, 2), fresh.run_cycles(4, 2))
+    assert np.array_equal(eng.fetch_solution(), fresh.fetch_solution())
+    # back to the first pattern, then the same matrix with every column stored backwards: same size, same entry count, values in other places
+    eng.set_system(P.lhs)
+    A = sp.csc_matrix(P.lhs); A.sort_indices()
+    idx, val = A.indices.copy(), A.data.copy()
+    for j in range(n):
+        idx[A.indptr[j]:A.indptr[j + 1]] = idx[A.indptr[j]:A.indptr[j + 1]][::-1]; val[A.indptr[j]:A.indptr[j + 1]] = val[A.indptr[j]:A.indptr[j + 1]][::-1]
+    eng._chk(cabi.lib().gmg_set_system(eng._h, n, cabi._pi(A.indptr), cabi._pi(idx), cabi._pd(val)))
+    assert eng.timing("setup_values_only") == 0.0
+    fresh = cabi.Engine(); fresh.set_prolongations(P.U); fresh.set_mass(P.mass); fresh.set_system(A)
+    for k in range(eng.num_levels + 1):
+        A1, A2 = eng.level_operator(k), fresh.level_operator(k)
+        assert np.array_equal(A1.indptr, A2.indptr) and np.array_equal(A1.indices, A2.indices) and np.array_equal(A1.data, A2.data)
+    eng.load_problem(P.rhs, P.rhs); fresh.load_problem(P.rhs, P.rhs)
+    assert np.array_equal(eng.run_cycles(4, 2), fresh.run_cycles(4, 2))
+    # ... and a matrix of the live pattern whose values make the refresh fail (a zero on the diagonal) reports that, and the next good one works
+    bad = sp.csc_matrix(P.lhs).copy(); bad.sort_indices()
+    j = 1234; col = slice(bad.indptr[j], bad.indptr[j + 1]); bad.data[col] = np.where(bad.indices[col] == j, 0.0, bad.data[col])
+    with pytest.raises(Exception):
+        eng._chk(cabi.lib().gmg_set_system(eng._h, n, cabi._pi(bad.indptr), cabi._pi(bad.indices), cabi._pd(bad.data)))
+    eng.set_system(P.lhs)
+    ref = cabi.Engine(); ref.set_prolongations(P.U); ref.set_mass(P.mass); ref.set_system(P.lhs)
+    eng.load_problem(P.rhs, P.rhs); ref.load_problem(P.rhs, P.rhs)
+    assert np.array_equal(eng.run_cycles(4, 2), ref.run_cycles(4, 2))
+
+
 def test_non_canonical_lhs_storage_is_accepted(cabi):
     """Unsorted row indices and duplicate entries (summed, like Eigen's setFromTriplets) give the same system."""
     import scipy.sparse as sp
