@@ -727,9 +727,10 @@ class P2PCycle:
         self.eng._chk(lib().gmg_p2p_bench_kind(self.eng._h, kind.encode(), int(reps), C.byref(out)))
         return out.value
 
-    def set_smoother(self, hybrid: bool):
-        """False: exact multicolour GS, an exchange per colour (default); True: hybrid GS (GS inside a rank, Jacobi across ranks), one per sweep."""
-        self.eng._chk(lib().gmg_p2p_set_smoother(self.eng._h, int(bool(hybrid))))
+    def set_smoother(self, hybrid):
+        """0 / False: exact multicolour GS, an exchange launch per colour (default); 1 / True: hybrid GS (GS inside a rank, Jacobi across ranks), one
+        exchange per sweep; 2: exact, the exchange of a colour folded into that colour's sweep launch (mailbox backend: no exchange launch)."""
+        self.eng._chk(lib().gmg_p2p_set_smoother(self.eng._h, int(hybrid)))
 
     def stat(self, key: str) -> float:
         out = C.c_double()

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>

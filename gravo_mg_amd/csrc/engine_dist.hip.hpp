@@ -60,6 +60,11 @@ struct DistP2P {
                                                           // C+3 = x1 halo, C+4 = level-1 rows, C+5 = r0 halo of the restriction (the last three: level 1 partitioned)
     bool shard1 = false;
     bool hybrid = false;                                  // gmg_p2p_set_smoother: Gauss-Seidel inside a rank, Jacobi across ranks (one exchange per sweep)
+    bool fold = false;                                    // gmg_p2p_set_smoother(2): the exchange of a colour folded into its sweep launch (gmgk::gs_color_push)
+    int* d_pub = nullptr;                                 // per colour: pub_ptr (own slices + 1), then pub_ent (int2), gmgk::PushTail
+    std::vector<size_t> pub_ptr_at, pub_ent_at;           // [colour]: offsets (ints) in d_pub
+    std::vector<int> pub_waves;                           // [colour]: own slices with a published row
+    unsigned long long exchange_launches = 0;             // launches spent on exchanges so far (gmg_p2p_stat "exchange_launches")
     std::vector<int> blk_owner;                           // [block of level 1] -> rank
     std::vector<std::vector<int>> own_blocks;             // [rank]: its blocks, ascending (block b = device rows 64 b .. 64 b + 63)
     int* d_l1 = nullptr;                                  // this rank's launch tables, one allocation:
@@ -105,6 +110,7 @@ void p2p_release(gmg_handle h) {
     if (p->d_done) (void)sync_hipFree(p->d_done);
     if (p->d_sums) (void)sync_hipFree(p->d_sums);
     if (p->d_l1) (void)sync_hipFree(p->d_l1);
+    if (p->d_pub) (void)sync_hipFree(p->d_pub);
     CollBackend& cb = p->coll;
     for (void* q : cb.peer_recv) if (q) (void)hipIpcCloseMemHandle(q);
     if (cb.comm && cb.comm_destroy) (void)cb.comm_destroy(cb.comm);
@@ -143,6 +149,7 @@ int coll_exchange(gmg_handle h, int kind, double* vec, int ld) {
     const int parity = (int)(cb.count++ & 1);
     ++p->seq;
     const int B = cb.blocks[kind];
+    p->exchange_launches += (cb.pack_n[kind] > 0) + 1 + (cb.unpack_n[kind * 2 + parity] > 0);
     if (cb.pack_n[kind] > 0)
         hipLaunchKernelGGL(gmgk::coll_pack, dim3(cb.pack_n[kind] * B), dim3(256), 0, h->stream, cb.d_segs + cb.pack_at[kind], cb.pack_n[kind], (const double*)vec, ld, p->d, cb.send, B);
     int rc = coll_all_gather(h, kind, parity);
@@ -164,9 +171,44 @@ int p2p_exchange(gmg_handle h, int kind, double* vec, int ld) {
     const int parity = (int)(p->kind_count[kind]++ & 1);
     ++p->seq;
     const int B = p->kind_blocks[kind];
+    ++p->exchange_launches;
     hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np * B), dim3(256), 0, h->stream, p->d_ops + (size_t)(kind * 2 + parity) * np, np, vec, ld, p->d,
                        p->seq, p->d_err, B, p->d_done);
     return GMG_OK;
+}
+
+// One colour of a level-0 sweep on this rank's rows WITH its exchange (gmgk::gs_color_push): false when the colour has to take the two-launch
+// form (no rows of this colour here, collective backend, tables missing).
+bool p2p_smooth_color_folded(gmg_handle h, int c) {
+    DistP2P* p = h->p2p;
+    const int np = (int)p->peers.size();
+    if (!p->fold || p->hybrid || p->coll.mode != 0 || np == 0 || !p->d_pub || h->dist_all_rows || h->loaded_d != p->d) return false;
+    Level& l = h->lv[0];
+    int sb, se;
+    own_range(h, c, sb, se);
+    if (se <= sb) return false;
+    const int parity = (int)(p->kind_count[c]++ & 1);
+    ++p->seq;
+    gmgk::PushTail pt;
+    pt.pub_ptr = p->d_pub + p->pub_ptr_at[c];
+    pt.pub_ent = reinterpret_cast<const int2*>(p->d_pub + p->pub_ent_at[c]);
+    pt.ops = p->d_ops + (size_t)(c * 2 + parity) * np;
+    pt.n_peers = np; pt.n_pub_waves = p->pub_waves[c];
+    pt.done = p->d_done + p->world;
+    pt.seq = p->seq; pt.err = p->d_err;
+    const int ld = l.n_pad;
+    const dim3 grid(grid_for(se - sb)), block(gmgk::kBlock);
+    if (l.Aoff.c16_mode == 1) {
+        DISPATCH_D(p->d, hipLaunchKernelGGL((gmgk::gs_color_push<D, 2>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
+                                            h->cfg.gs_omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), pt));
+    } else if (l.Aoff.c16_mode == 2) {
+        DISPATCH_D(p->d, hipLaunchKernelGGL((gmgk::gs_color_push<D, 3>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
+                                            h->cfg.gs_omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), pt));
+    } else {
+        DISPATCH_D(p->d, hipLaunchKernelGGL((gmgk::gs_color_push<D, 1>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
+                                            h->cfg.gs_omega, (const unsigned*)nullptr, (const int*)nullptr, 0, pt));
+    }
+    return true;
 }
 
 // the index list rank s publishes to rank t for exchange kind k (null: the kind has no list)
@@ -407,7 +449,7 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
         if (sec > 0.0) { const unsigned long long ticks = (unsigned long long)(sec * 1e8); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gmgk::g_p2p_timeout_ticks), &ticks, sizeof(ticks))); }
     }
     HIPCHK(hipMalloc((void**)&p->d_sums, sizeof(double) * 4 * d));
-    if (!p->d_done) { HIPCHK(hipMalloc((void**)&p->d_done, sizeof(unsigned int) * world)); HIPCHK(hipMemset(p->d_done, 0, sizeof(unsigned int) * world)); }
+    if (!p->d_done) { HIPCHK(hipMalloc((void**)&p->d_done, sizeof(unsigned int) * (world + 1))); HIPCHK(hipMemset(p->d_done, 0, sizeof(unsigned int) * (world + 1))); }      // (+ 1: gs_color_push)
     if ((rc = coll_build(h))) return rc;                  // gmg_config::dist_exchange != 0: chunk sizes, segment tables, buffers
     HIPCHK(hipStreamSynchronize(h->stream));
     p->planned = true;
@@ -586,6 +628,41 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     if (p->d_ops) { (void)sync_hipFree(p->d_ops); p->d_ops = nullptr; }
     HIPCHK(hipMalloc((void**)&p->d_ops, sizeof(gmgk::P2POp) * ops.size()));
     HIPCHK(hipMemcpy(p->d_ops, ops.data(), sizeof(gmgk::P2POp) * ops.size(), hipMemcpyHostToDevice));
+    // ---- tables of the folded exchange (gmgk::gs_color_push): per colour, the entries of this rank's send lists by slice of its piece
+    {
+        std::vector<int> tab;
+        p->pub_ptr_at.assign(C, 0); p->pub_ent_at.assign(C, 0); p->pub_waves.assign(C, 0);
+        bool fits = true;
+        for (int c = 0; c < C; ++c) {
+            int sb, se;
+            own_range(h, c, sb, se);
+            const int ns = std::max(se - sb, 0);
+            std::vector<std::array<int, 2>> ent;
+            for (int j = 0; j < np; ++j) {
+                const std::vector<int>& sl = *p2p_list(p, C, rank, p->peers[j].rank, c);
+                if (sl.size() >= ((size_t)1 << 24)) fits = false;
+                for (size_t k = 0; k < sl.size(); ++k) {
+                    if (sl[k] < sb * 64 || sl[k] >= se * 64) { fits = false; continue; }
+                    ent.push_back({sl[k], (int)((unsigned)j << 24 | (unsigned)k)});
+                }
+            }
+            std::stable_sort(ent.begin(), ent.end(), [](const std::array<int, 2>& a, const std::array<int, 2>& b) { return a[0] < b[0]; });
+            if (tab.size() & 1) tab.push_back(0);
+            p->pub_ptr_at[c] = tab.size();
+            std::vector<int> ptr((size_t)ns + 1, 0);
+            for (const auto& e : ent) ++ptr[(size_t)(e[0] / 64 - sb) + 1];
+            for (int q = 0; q < ns; ++q) { p->pub_waves[c] += ptr[q + 1] > 0; ptr[q + 1] += ptr[q]; }
+            tab.insert(tab.end(), ptr.begin(), ptr.end());
+            if (tab.size() & 1) tab.push_back(0);                          // (int2 entries: 8-byte aligned)
+            p->pub_ent_at[c] = tab.size();
+            for (const auto& e : ent) { tab.push_back(e[0]); tab.push_back(e[1]); }
+        }
+        if (p->d_pub) { (void)sync_hipFree(p->d_pub); p->d_pub = nullptr; }
+        if (fits && np < 64) {
+            HIPCHK(hipMalloc((void**)&p->d_pub, sizeof(int) * std::max<size_t>(tab.size(), 2)));
+            HIPCHK(hipMemcpy(p->d_pub, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
+        }
+    }
     p->connected = true;
     return GMG_OK;
 } GMG_CATCH_H
@@ -652,6 +729,7 @@ int p2p_smooth(gmg_handle h, int iters) {
     int rc;
     for (int it = 0; it < iters; ++it) {
         for (int c = 0; c < l.ord.n_colors; ++c) {
+            if (p2p_smooth_color_folded(h, c)) continue;
             if ((rc = gmg_dist_smooth_color(h, c))) return rc;
             if (!hybrid && (rc = p2p_exchange(h, c, l.x, l.n_pad))) return rc;
         }
@@ -913,14 +991,16 @@ int gmg_p2p_bench_kind(gmg_handle h, const char* kind_name, int reps, double* ms
 // 1: hybrid -- Gauss-Seidel inside a rank, Jacobi across ranks, ONE exchange per sweep.  Collective in the sense that every rank must choose the same.
 int gmg_p2p_set_smoother(gmg_handle h, int hybrid) try {
     if (!h || !h->p2p) return h ? fail(h, GMG_ERR_STATE, "no distributed plan (gmg_p2p_prepare)") : GMG_ERR_INVALID;
-    if (hybrid != 0 && hybrid != 1) return fail(h, GMG_ERR_INVALID, "smoother must be 0 (exact) or 1 (hybrid)");
-    h->p2p->hybrid = hybrid != 0;
+    if (hybrid < 0 || hybrid > 2) return fail(h, GMG_ERR_INVALID, "smoother must be 0 (exact), 1 (hybrid) or 2 (exact, exchange folded into the colour launches)");
+    h->p2p->hybrid = hybrid == 1;
+    h->p2p->fold = hybrid == 2;
     return GMG_OK;
 } GMG_CATCH_H
 
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {
     if (!h || !h->p2p || !key || !out) return GMG_ERR_INVALID;
     if (std::string(key) == "device_bytes") { *out = (double)h->pool.live_bytes; return GMG_OK; }      // device memory this rank's handle holds (pool blocks in use)
+    if (std::string(key) == "exchange_launches") { *out = (double)h->p2p->exchange_launches; return GMG_OK; }      // launches spent on exchanges so far (the folded colour exchanges: none)
     if (std::string(key) == "device_bytes_peak") { *out = (double)h->pool.peak_live_bytes; return GMG_OK; }      // ... and its high-water mark since the last gmg_set_system began
     auto it = h->p2p->stats.find(key);
     if (it == h->p2p->stats.end()) return fail(h, GMG_ERR_INVALID, std::string("unknown key: ") + key);

@@ -1123,17 +1123,20 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
         for (int64_t i = (int64_t)part * blockDim.x + threadIdx.x; i < total; i += stride) {
             const int c = (int)(i / op.n_send), k = (int)(i - (int64_t)c * op.n_send);
             const int src = op.send_idx ? op.send_idx[k] : op.send_lo + k;
-            op.remote_box[i] = vec[src + (int64_t)c * ld];
+            // write-through stores, drained below: nothing of this exchange sits in an L2 that a release fence would have to write back
+            // (buffer_wbl2 + buffer_inv at system scope: ~3.5 us of every exchange launch)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(op.remote_box + i), (unsigned long long)__double_as_longlong(vec[src + (int64_t)c * ld]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        __threadfence_system();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             bool last = true;
             if (B > 1) {
-                last = __hip_atomic_fetch_add(done + j, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)B - 1;
+                last = __hip_atomic_fetch_add(done + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)B - 1;
                 if (last) __hip_atomic_store(done + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (last) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (last) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     } else {                                                          // ---- pull
         __shared__ int timed_out;
@@ -1142,8 +1145,9 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
             const unsigned long long t0 = wall_clock64();            // 100 MHz constant clock
             // (an exchange that already timed out means the peer is gone: the launches still queued behind it give up at once)
             if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = 1;
-            while (!timed_out && __hip_atomic_load(op.local_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-                __builtin_amdgcn_s_sleep(8);
+            // (relaxed polls; the values are read with system-scope loads, which no cache serves)
+            while (!timed_out && __hip_atomic_load(op.local_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+                __builtin_amdgcn_s_sleep(4);
                 if (wall_clock64() - t0 > g_p2p_timeout_ticks) { timed_out = 1; atomicExch(err, 1); break; }
             }
         }
@@ -1157,6 +1161,110 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
             // system-scope loads: the region is rewritten by the peer every exchange, no stale cached copy may be served
             const unsigned long long bits = __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             vec[dst + (int64_t)c * ld] = __longlong_as_double((long long)bits);
+        }
+    }
+}
+
+// ---- the exchange of a colour FOLDED into that colour's sweep (gmg_p2p_set_smoother mode 2) ----------------------------------
+// No exchange launch: a wave of gs_color_push that has updated its 64 rows stores the ones peers read straight from its registers into the
+// peers' mailboxes (pub_ent: the entries of all send lists that fall into the slice), fences at system scope and counts itself done; the LAST
+// publishing wave of the launch publishes the sequence number to every peer and then PULLS: waits for every peer's number and copies the
+// peers' values into x.  The pull may overlap the rest of the launch: it writes x entries of the peers' rows of THIS colour, which no row
+// of this colour reads (that is what a colouring is), and the launch boundary orders it before the next colour's gathers.  A launch without
+// any published row (pt.n_pub_waves == 0) hands both jobs to its first wave.  Region reuse is as in p2p_exchange: a rank's pull of exchange
+// m is inside its launch m, which precedes its launch (= push) m + 1 in the stream.
+struct PushTail {
+    const int* pub_ptr;             // [slices of the launch + 1]: entries of pub_ent per slice
+    const int2* pub_ent;            // (row, peer << 24 | position in that peer's send list), rows ascending
+    const P2POp* ops;               // one per peer: the colour's exchange (kind, parity)
+    int n_peers, n_pub_waves;       // n_pub_waves: slices with at least one entry
+    unsigned int* done;             // publishing waves that have finished (device memory, zero between launches)
+    unsigned long long seq;
+    int* err;
+};
+
+template <int D, int FINE>
+__global__ __launch_bounds__(kBlock) void gs_color_push(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const double* __restrict__ val,
+                                                        const double* __restrict__ diag, const double* __restrict__ b, double* x, int ld, int slice_begin,
+                                                        int slice_end, double omega, const unsigned* __restrict__ col16, const int* __restrict__ win_base,
+                                                        int c16_arg, PushTail pt) {
+    const int s = slice_begin + wave_slice(slice_end - slice_begin, 1);
+    const int lane = threadIdx.x & 63;
+    int finish = pt.n_pub_waves == 0 && blockIdx.x == 0 && threadIdx.x < 64;
+    if (s < slice_end) {
+        const int row = s * 64 + lane;
+        double acc[D], xn[D];
+        row_dot_sel<double, D, (FINE >= 2 ? FINE - 1 : 0)>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);
+        const double dg = diag[row];
+        if (omega == 1.0) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) { xn[c] = (b[row + (int64_t)c * ld] - acc[c]) / dg; x[row + (int64_t)c * ld] = xn[c]; }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const double xi = x[row + (int64_t)c * ld];
+                xn[c] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
+                x[row + (int64_t)c * ld] = xn[c];
+            }
+        }
+        const int q0 = pt.pub_ptr[s - slice_begin], q1 = pt.pub_ptr[s - slice_begin + 1];       // wave-uniform
+        if (q1 > q0) {
+            for (int q = q0; q < q1; q += 64) {
+                const bool valid = q + lane < q1;
+                const int2 e = valid ? pt.pub_ent[q + lane] : make_int2(row, 0);
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    const double v = __shfl(xn[c], e.x & 63, 64);
+                    // write-through stores (no L2 line to write back later: a release FENCE here would write back and invalidate the XCD's L2 in the
+                    // middle of the sweep -- measured: +8 us per colour launch)
+                    if (valid) {
+                        const P2POp& op = pt.ops[e.y >> 24];
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(op.remote_box + (e.y & 0xffffff) + (int64_t)c * op.n_send),
+                                           (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have arrived before this wave counts itself done
+            int last = 0;
+            if (lane == 0) last = __hip_atomic_fetch_add(pt.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pt.n_pub_waves - 1u;
+            finish = __builtin_amdgcn_readfirstlane(last);
+        }
+    }
+    if (!finish) return;
+    // ---- exactly one wave of the launch: publish the sequence number, then pull
+    if (lane == 0) __hip_atomic_store(pt.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (every publishing wave drained its write-through stores before it took its ticket, and this wave drew the last one: the number may follow)
+    if (lane < pt.n_peers) __hip_atomic_store(pt.ops[lane].remote_flag, pt.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int j = 0; j < pt.n_peers; ++j) {
+        const P2POp op = pt.ops[j];
+        int timed_out = 0;
+        if (lane == 0) {
+            const unsigned long long t0 = wall_clock64();
+            if (__hip_atomic_load(pt.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) timed_out = 1;
+            // relaxed polls (an acquire per poll would invalidate caches under the waves still sweeping); the values are read with system-scope
+            // loads below, which no cache serves
+            while (!timed_out && __hip_atomic_load(op.local_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < pt.seq) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > g_p2p_timeout_ticks) { timed_out = 1; atomicExch(pt.err, 1); break; }
+            }
+        }
+        if (__builtin_amdgcn_readfirstlane(timed_out)) return;
+        const int64_t total = (int64_t)op.n_recv * D;
+        const unsigned long long* box = reinterpret_cast<const unsigned long long*>(op.local_box);
+        // (one wave copies a few hundred values: eight independent system-scope loads per lane in flight, then the stores)
+        for (int64_t i0 = lane; i0 < total; i0 += 64 * 8) {
+            unsigned long long bits[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = i0 + 64 * u;
+                const bool in = i < total;
+                const int c = in ? (int)(i / op.n_recv) : 0, k = in ? (int)(i - (int64_t)c * op.n_recv) : 0;
+                dst[u] = in ? op.recv_idx[k] + c * ld : -1;
+                bits[u] = in ? __hip_atomic_load(box + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (dst[u] >= 0) x[dst[u]] = __longlong_as_double((long long)bits[u]);
         }
     }
 }
