@@ -188,7 +188,7 @@ __device__ __forceinline__ void quad_reduce(T (&acc)[D]) {
 // Rows of one colour do not couple, so the parallel update equals the reference's sequential sweep in
 // the colour-permuted ordering.  omega != 1 relaxes the update (SOR, gmg_config::gs_omega).  FINE tags the level-0 instantiation so that profilers report the dominant
 // (fine-level) launches under their own kernel name.
-template <class T, int D, int FINE>
+template <class T, int D, int FINE, int XI = 0>
 __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const T* __restrict__ val, const T* __restrict__ diag,
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
@@ -199,16 +199,16 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     T acc[D];
-    row_dot_sel<T, D, (FINE >= 2 ? FINE - 1 : 0)>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);      // FINE 2 / 3: level 0 with 16-bit column codes (row_dot_sel mode 1 / 2)
+    row_dot_sel<T, D, (FINE >= 2 ? FINE - 1 : 0), DotGroup<D>::value, XI>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);      // FINE 2 / 3: level 0 with 16-bit column codes (row_dot_sel mode 1 / 2)
     const T dg = diag[row];
     if (omega == (T)1.0) {                 // kernel argument: a scalar branch.  The reference's update, no read of x_i
 #pragma unroll
-        for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
+        for (int c = 0; c < D; ++c) x[x_at<D, XI>(row, c, ld)] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
     } else {                               // successive over-relaxation: x_i <- x_i + omega (x_i^GS - x_i)
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const T xi = x[row + (int64_t)c * ld];
-            x[row + (int64_t)c * ld] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
+            const T xi = x[x_at<D, XI>(row, c, ld)];
+            x[x_at<D, XI>(row, c, ld)] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
         }
     }
 }
@@ -1055,7 +1055,8 @@ __device__ __forceinline__ void block_reduce_partials(const double* __restrict__
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < kReduceBlock / 64; ++w) t += red[w][threadIdx.x];
-        out[threadIdx.x] = t;
+        // (system scope: a write-through store -- `out` may be host memory that the host polls for, reduce_partials)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(out + threadIdx.x), (unsigned long long)__double_as_longlong(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1067,8 +1068,10 @@ __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __
     __shared__ double red[kReduceBlock / 64][kReduceMaxComp];
     block_reduce_partials(partials, n_blocks, ncomp, out, red);
     if (flag && threadIdx.x < 64) {
-        __threadfence_system();
-        if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the sums went out as write-through stores: drained, they are ahead of the sequence word (no system fence: that writes the L2 back and
+        // invalidates it, microseconds per residual check)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1362,10 +1365,11 @@ __global__ __launch_bounds__(64) void coll_sum_ranks(const double* __restrict__ 
 // n doubles -> host-visible pinned memory, then the sequence word (one block; the coarsest right-hand side)
 __global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restrict__ src, double* __restrict__ dst, int n,
                                                           unsigned long long* flag, unsigned long long seq) {
-    for (int i = threadIdx.x; i < n; i += kBlock) dst[i] = src[i];
-    __threadfence_system();
+    for (int i = threadIdx.x; i < n; i += kBlock)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + i), (unsigned long long)__double_as_longlong(src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores, drained: ahead of the sequence word without a system fence
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // n doubles from host-visible pinned memory (the host's coarsest solution; the stream was held until the host had written it)

@@ -1,6 +1,6 @@
 """3 M-vertex smoothing system with d = 1, 2, 3, 4 right-hand sides: cycle time and fine-level kernel rates."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gravo_mg_amd import cabi, meshgen
 V, F = meshgen.torus_mesh(1732, 1732)
