@@ -90,55 +90,99 @@ def main(args):
     else:
         eng = ref
 
-    # ---- peer-to-peer exchange engine
-    p2p, note, exchange_us = None, None, None
-    if args.exchange == "p2p" and world > 1:
-        ok, note = 1, "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
+    # ---- engine-driven cycle: mailboxes (hipIpc) first; should a rank be unable to set them up, the same cycle with every exchange as
+    # pack -> ncclAllGather -> unpack on the engine's stream (gmg_config::dist_exchange = 1; no hipIpc) -- the Python orchestration below is the last resort
+    p2p, note, exchange_us, engine_exchange = None, None, None, None
+    cpu_group = dist.new_group(backend="gloo") if world > 1 else None
+
+    def agreed(local_ok):
+        """MIN over the ranks: every step below is collective, so a rank that failed locally still takes part in the next
+        agreement (contributing 0) instead of leaving the others waiting in a collective it never enters."""
+        flags = [None] * world
+        dist.all_gather_object(flags, int(local_ok), group=cpu_group)
+        return min(flags) == 1
+
+    def engine_cycle(mode, engine):
+        """One candidate: plan + buffers (local), connect (collective), first cycles = the single-GPU residues (collective on the devices).
+        Returns (P2PCycle or None, why not)."""
+        ok, why = 1, None
         cand, blob = None, None
-        cpu_group = dist.new_group(backend="gloo")
-
-        def agreed(local_ok):
-            """MIN over the ranks: every step below is collective, so a rank that failed locally still takes part in the next
-            agreement (contributing 0) instead of leaving the others waiting in a collective it never enters."""
-            flags = [None] * world
-            dist.all_gather_object(flags, int(local_ok), group=cpu_group)
-            return min(flags) == 1
-
-        # step 1 (local): plan + mailbox; step 2 (collective): everybody's IPC blobs, None from a rank that failed
         try:
-            if os.environ.get("GMG_P2P_SELFTEST_FAIL") and rank == world - 1:      # test hook: one rank cannot set the path up
+            if mode == 0 and os.environ.get("GMG_P2P_SELFTEST_FAIL") and rank == world - 1:      # test hook: one rank cannot set the mailboxes up
                 raise RuntimeError("forced by GMG_P2P_SELFTEST_FAIL")
-            cand = cabi.P2PCycle(eng, rank, world, 1)
-            blob = cand.export()
+            cand = cabi.P2PCycle(engine, rank, world, 1)
+            blob = cand.export() if mode != 1 else b""
         except Exception as e:          # noqa: BLE001
-            ok, note = 0, f"peer-to-peer set-up failed on rank {rank}: {e!r}"
+            ok, why = 0, f"set-up failed on rank {rank}: {e!r}"
         blobs = [None] * world
         dist.all_gather_object(blobs, blob, group=cpu_group)
         if ok and any(b is None for b in blobs):
-            ok, note = 0, f"rank {[i for i, b in enumerate(blobs) if b is None]} could not set up the peer-to-peer path"
-        # step 3 (local): map the peers' mailboxes
+            ok, why = 0, f"rank {[i for i, b in enumerate(blobs) if b is None]} could not set it up"
+        ids = [None] * world
+        if mode == 1:
+            my_id = None
+            if rank == 0 and ok:
+                try:
+                    my_id = cabi.rccl_unique_id()
+                except Exception as e:      # noqa: BLE001
+                    ok, why = 0, f"ncclGetUniqueId failed: {e!r}"
+            dist.all_gather_object(ids, my_id, group=cpu_group)
+            if ok and ids[0] is None:
+                ok, why = 0, "rank 0 could not make the RCCL id"
         if ok:
             try:
-                cand.connect(blobs)
+                if mode == 1:
+                    cand.connect_rccl(ids[0])
+                else:
+                    cand.connect(blobs)
             except Exception as e:      # noqa: BLE001
-                ok, note = 0, f"peer-to-peer connect failed on rank {rank}: {e!r}"
+                ok, why = 0, f"connect failed on rank {rank}: {e!r}"
         if not agreed(ok):
-            if ok:
-                ok, note = 0, "another rank could not map the mailboxes"
-        else:
-            # step 4 (collective on the devices): the first cycles must reproduce the single-GPU residues; a rank that fails here
-            # shows up on the others as a device-side time-out (an error, not a hang)
-            try:
-                cand.load(rhs, rhs)
-                got = cand.cycles(n_warm, 2)
-                if not np.allclose(got, ref_res, rtol=1e-9):
-                    ok, note = 0, f"peer-to-peer residues {list(got)} differ from the single-GPU engine's {list(ref_res)}"
-            except Exception as e:      # noqa: BLE001
-                ok, note = 0, f"peer-to-peer cycles failed on rank {rank}: {e!r}"
+            return None, why or "another rank could not set it up"
+        # (collective on the devices: a rank that fails here shows up on the others as a device-side time-out -- an error, not a hang)
+        try:
+            cand.load(rhs, rhs)
+            got = cand.cycles(n_warm, 2)
+            if not np.allclose(got, ref_res, rtol=1e-9):
+                ok, why = 0, f"residues {list(got)} differ from the single-GPU engine's {list(ref_res)}"
+        except Exception as e:          # noqa: BLE001
+            ok, why = 0, f"cycles failed on rank {rank}: {e!r}"
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            p2p = cand
+        if int(flag.item()) != 1:
+            return None, why or "another rank's first cycles failed"
+        return cand, None
+
+    if args.exchange == "p2p" and world > 1:
+        p2p, why0 = engine_cycle(0, eng)
+        if p2p is not None:
+            engine_exchange, note = "p2p", "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
+        else:
+            single.log(f"[bench] rank {rank}: no peer-to-peer mailboxes ({why0}); trying the engine's collective exchange")
+            mode = 1 if backend == "nccl" else 2
+            okc, eng_c = 1, None
+            try:
+                if os.environ.get("GMG_BENCH_NO_ENGINE_COLLECTIVE"):          # test hook: straight to the last resort
+                    raise RuntimeError("skipped by GMG_BENCH_NO_ENGINE_COLLECTIVE")
+                eng_c = new_engine(partition=partitioned, dist_exchange=mode)
+            except Exception as e:      # noqa: BLE001
+                okc, why0 = 0, f"{why0}; collective engine: {e!r}"
+            if agreed(okc):
+                p2p, why1 = engine_cycle(mode, eng_c)
+            else:
+                p2p, why1 = None, "a rank could not build the collective engine"
+            if p2p is not None:
+                eng.close(); eng = eng_c
+                engine_exchange = "engine-collective"
+                note = (f"mailboxes unavailable ({why0}); every exchange as pack -> " + ("ncclAllGather" if mode == 1 else "all-gather emulated over hipIpc")
+                        + " -> unpack on the engine's stream (gmg_config::dist_exchange)")
+            else:
+                note = f"peer-to-peer set-up failed ({why0}); engine collective failed ({why1})"
+                single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange orchestrated from Python ({note})")
+                if eng_c is not None:
+                    eng_c.close()
+                eng = new_engine()           # the candidates may have left their handles mid-exchange (and hold a rank's share only): the fallback starts from a fresh one
+        if p2p is not None:
             sharded1 = p2p.stat("level1_partitioned") == 1.0
             C, pre, post = levels[0]["n_colors"], 2, 2
             # every exchange of a cycle, timed alone (push + wait + pull in one launch, 200 back to back), and how often a cycle runs it
@@ -148,10 +192,6 @@ def main(args):
             exchange_us["per_cycle"] = {**{k: v for k, v in per_cycle.items() if v}, "color<k> (each of %d colours)" % C: (pre + post)}
             exchange_us["sum_per_cycle"] = (sum(exchange_us[k] * n for k, n in per_cycle.items() if n)
                                             + (pre + post) * sum(1e3 * p2p.bench_kind(f"color{c}", 100) for c in range(C)))
-        else:
-            note = note if ok == 0 else "another rank could not set up the peer-to-peer path"
-            single.log(f"[bench] rank {rank}: falling back to the RCCL halo exchange ({note})")
-            eng = new_engine()           # the candidate may have left its handle mid-exchange (and holds a rank's share only): the fallback starts from a fresh one
 
     # ---- RCCL orchestration (requested, or the fallback)
     dv, be, halo = None, None, None
@@ -199,7 +239,7 @@ def main(args):
     # publishing waves store their rows straight into the peers' mailboxes, the last one publishes the sequence number and pulls -- no exchange
     # launch for the (pre + post) x C colour exchanges of a cycle; the same iterates.  The default is timed again right after it (same state of
     # the box), so that the two numbers compare.
-    if p2p is not None and world > 1:
+    if p2p is not None and world > 1 and engine_exchange == "p2p":
         def timed(k):
             load(); run(args.warmup)
             n_before = p2p.stat("exchange_launches")
@@ -250,7 +290,7 @@ def main(args):
     # no Python between the colours.  With one device per rank the all-gather is ncclAllGather (librccl, loaded by the library); ranks that share
     # a device (GMG_DIST_BACKEND=gloo: RCCL refuses that) run the same sequence with the all-gather emulated through hipIpc mappings -- what
     # this measures there is the cost of three launches per exchange instead of one, not a link.
-    if p2p is not None and world > 1 and not os.environ.get("GMG_BENCH_NO_HALO_VARIANT"):
+    if p2p is not None and world > 1 and engine_exchange == "p2p" and not os.environ.get("GMG_BENCH_NO_HALO_VARIANT"):
         mode = 1 if backend == "nccl" else 2
         okv, cyc2, why = 1, None, None
         try:
@@ -328,9 +368,14 @@ def main(args):
                          f"({int(p2p.stat('r0_halo_rows_published'))} rows), r1 completed on every rank once per cycle; levels >= 2 replicated")
             else:
                 lower = "levels >= 1 replicated, r0 pushed to all peers once per cycle"
-            partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm); per colour sweep ONE exchange "
-                         f"kernel: each rank stores the halo entries its peers read into their mailboxes over xGMI ({int(p2p.stat('halo_rows_published'))} rows "
-                         f"published by rank 0) and waits for theirs; {lower}; no collective call in the cycle")
+            if engine_exchange == "p2p":
+                how = (f"per colour sweep ONE exchange kernel: each rank stores the halo entries its peers read into their mailboxes over xGMI "
+                       f"({int(p2p.stat('halo_rows_published'))} rows published by rank 0) and waits for theirs")
+                tail = "no collective call in the cycle"
+            else:
+                how = (f"per colour sweep one pack -> all-gather -> unpack sequence on the engine's stream ({int(p2p.stat('halo_rows_published'))} rows published by rank 0)")
+                tail = "every exchange of the cycle is such a sequence, none is issued from Python"
+            partition = f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm); {how}; {lower}; {tail}"
         elif halo is not None:
             partition = (f"level 0 split {world}-way by rows (sweeps, residual, prolongation, norm), coarse levels replicated; per colour sweep one RCCL "
                          f"all-gather of the packed halo entries of x ({halo.published_rows} rows in all), r all-gathered once per cycle")
@@ -347,7 +392,7 @@ def main(args):
                                    "block-hybrid Gauss-Seidel (replicated)",
                        "coarse_solve": args.coarse, "hipgraph": False, "partition": partition, "tolerance": 1e-4, "stopping_criteria": 2},
             "iterations_to_1e-4": iters, "residue": res, "residues_to_1e-4": [float(v) for v in hist], "solve_ms": solve_ms,
-            "exchange": "p2p" if p2p is not None else ("none (one rank)" if world == 1 else args.exchange if args.exchange != "p2p" else "halo (fallback)"),
+            "exchange": engine_exchange if p2p is not None else ("none (one rank)" if world == 1 else args.exchange if args.exchange != "p2p" else "halo (fallback)"),
             "exchange_note": note, "exchange_us": exchange_us, "single_gpu_residues_reproduced": reproduced,
             "collectives_per_cycle": colls_per_cycle, "collective_backend": backend,
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,

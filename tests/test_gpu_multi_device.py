@@ -77,16 +77,23 @@ def test_bench_two_ranks_on_one_gpu_at_the_benchmark_size(cabi):
     assert line["host_threads_per_rank"] >= 1 and line["device_bytes_per_rank"] > 5e8
 
 
-def test_a_rank_that_cannot_set_up_peer_to_peer_takes_every_rank_to_the_fallback(cabi):
-    """bench.py --gpus N decides together: if one rank fails to set the peer-to-peer path up, all ranks run the collective (RCCL / here gloo)
-    orchestration and the line says so."""
+@pytest.mark.parametrize("last_resort", [False, True])
+def test_a_rank_that_cannot_set_up_peer_to_peer_takes_every_rank_to_the_fallback(cabi, last_resort):
+    """bench.py --gpus N decides together: if one rank fails to set the mailboxes up, all ranks run the engine-driven cycle with every exchange as
+    pack -> all-gather -> unpack on the engine's stream (ncclAllGather; emulated over hipIpc for ranks that share a device, as here); if that
+    cannot be set up either, the orchestration from Python (RCCL / here gloo).  The line says which."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GMG_DIST_BACKEND="gloo", GMG_P2P_SELFTEST_FAIL="1")
+    if last_resort:
+        env["GMG_BENCH_NO_ENGINE_COLLECTIVE"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29545",
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--n1", "400", "--n2", "400", "--kernel-reps", "5"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["exchange"] == "halo (fallback)" and "could not set up" in line["exchange_note"] or "forced" in line["exchange_note"]
-    assert line["collectives_per_cycle"] > 0 and line["single_gpu_residues_reproduced"] is True
+    assert "forced" in line["exchange_note"] or "could not set" in line["exchange_note"]
+    if last_resort:
+        assert line["exchange"] == "halo (fallback)" and line["collectives_per_cycle"] > 0
+    else:
+        assert line["exchange"] == "engine-collective" and line["collectives_per_cycle"] == 0 and "pack" in line["config"]["partition"]
+    assert line["single_gpu_residues_reproduced"] is True
     assert line["residue"] <= 1e-4 and 3 <= line["iterations_to_1e-4"] <= 8
-
