@@ -124,7 +124,7 @@ class MultigridSolver(object):
         return self.solver.solve(_sparse(lhs, "lhs"), _points(rhs, "rhs"))
 
     # ---- one process per GPU (not upstream) -------------------------------------------------------------------------------------------
-    def enable_distributed(self, rank, world, all_gather, device=None, shard_levels=2, partition_setup=True):
+    def enable_distributed(self, rank, world, all_gather, device=None, shard_levels=2, partition_setup=True, exchange="mailbox"):
         """Make solve() a COLLECTIVE over `world` processes (one per GPU), each holding a MultigridSolver built from the same inputs:
         level 0 is partitioned by rows per colour (levels >= 1 by blocks / replicated, `shard_levels`), exchanges are device-initiated
         stores into the peers' mailboxes (include/gravomg_hip.h, "multi-GPU, engine-driven").  The colours are
@@ -136,7 +136,12 @@ class MultigridSolver(object):
         device: HIP device of this rank (default: rank).  Call before the first solve().
         partition_setup (default): the engine lays out and keeps only this rank's rows of levels 0-1 (gmg_dist_partition: a rank's device
         memory is its share of the operator plus the replicated small levels); such an object runs the collective solve() only --
-        residual() and the single-process entry points need partition_setup=False (every rank then holds the whole operator)."""
+        residual() and the single-process entry points need partition_setup=False (every rank then holds the whole operator).
+        exchange: "mailbox" (default: device-initiated stores through hipIpc mappings, one launch per exchange) or "rccl" (every exchange as
+        pack -> ncclAllGather -> unpack on the engine's stream, gmg_config::dist_exchange = 1: for boxes where processes cannot map each
+        other's device memory); the same partition, the same iterates."""
+        if exchange not in ("mailbox", "rccl"):
+            raise ValueError("exchange must be 'mailbox' or 'rccl'")
         rank, world = int(rank), int(world)
         if not (0 <= rank < world):
             raise ValueError("rank must be in [0, world)")
@@ -147,7 +152,8 @@ class MultigridSolver(object):
             self.solver.set_engine_option("device", rank if device is None else int(device))
             self.solver.set_engine_option("dist_rank", rank if partition_setup else 0)
             self.solver.set_engine_option("dist_world", world if partition_setup else 1)
-            self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None}
+            self.solver.set_engine_option("dist_exchange", 1 if exchange == "rccl" else 0)
+            self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None, "exchange": exchange}
         else:
             self._dist = None
 
@@ -165,7 +171,11 @@ class MultigridSolver(object):
         if D["key"] != key:                               # new layout (or another d): partition, export, connect
             eng = cabi.Engine.borrow(handle)
             cyc = cabi.P2PCycle(eng, D["rank"], D["world"], rhs.shape[1])
-            cyc.connect(D["all_gather"](cyc.export()))
+            if D["exchange"] == "rccl":
+                ids = D["all_gather"](cabi.rccl_unique_id() if D["rank"] == 0 else None)      # rank 0 makes the communicator id
+                cyc.connect_rccl(ids[0])
+            else:
+                cyc.connect(D["all_gather"](cyc.export()))
             D["cycle"], D["key"] = cyc, key
         # x0 = rhs, as the binding does; then gmg_p2p_solve: do { V-cycle; residualCheck } while (residue > tol && it < maxIter)
         x, it, residue = D["cycle"].solve(rhs, rhs, tol=tol, stop_type=stop_type, max_iter=max_iter)

@@ -13,19 +13,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("exchange", ["p2p", "halo"])
+@pytest.mark.parametrize("exchange", ["p2p", "halo", "engine-collective"])
 def test_bench_two_gpus_with_rccl(cabi, exchange):
+    """engine-collective: a rank is made to fail the mailbox set-up, all ranks move to the engine-driven cycle whose exchanges are
+    pack -> ncclAllGather -> unpack on the engine's stream (librccl loaded by the library, gmg_p2p_connect_rccl)."""
     if cabi.device_count() < 2:
         pytest.skip("needs two HIP devices")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("GMG_DIST_BACKEND", None)
+    if exchange == "engine-collective":
+        env["GMG_P2P_SELFTEST_FAIL"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--n1", "600", "--n2", "600", "--exchange", exchange]
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--n1", "600", "--n2", "600", "--exchange",
+           "p2p" if exchange == "engine-collective" else exchange]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["collective_backend"] == "nccl"
-    _check_line(line, exchange)
+    if exchange == "engine-collective":
+        assert line["exchange"] == "engine-collective" and "ncclAllGather" in line["exchange_note"] and line["collectives_per_cycle"] == 0
+        assert line["residue"] <= 1e-4 and line["single_gpu_residues_reproduced"] is True
+    else:
+        _check_line(line, exchange)
 
 
 def _check_line(line, exchange):
