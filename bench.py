@@ -348,7 +348,7 @@ def main():
     info0 = eng.level_info(0)
     stored_bytes = sweep_bytes - (2.0 * (info0["nnz"] - info0["n"]) - 32.0 * info0["n_pad"] / 64 if col16 else 0.0)
     roofline = {
-        "bound": "hbm", "kernel": "gmgk::gs_color<1,%d> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour%s)" % (2 if col16 else 1, "; 16-bit column codes" if col16 else ""),
+        "bound": "hbm", "kernel": "gmgk::gs_color<double,1,%d,0> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour%s)" % (2 if col16 else 1, "; 16-bit column codes" if col16 else ""),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_source,
         "launch_ms": sweep_ms / launches, "launches_per_sweep": launches,
@@ -429,6 +429,16 @@ def main():
         H2 = cabi.Hierarchy(pos2, meshgen.neighbors_from_stiffness(S2), ratio=8.0, lower_bound=1000)
         variants["poisson_722k"] = variant_run(cabi, torch, name2, H2, mass2, lhs2, rhs2, args.steps, args.warmup, levels=True)
         del H2, pos2, S2, mass2, lhs2, rhs2
+        # the demos' own size (demos/smoothing.py on a ~36 k-vertex mesh): M + 1e-3 S, n x 3 -- a cycle here is launch latency and the host's
+        # coarsest solve (6 k unknowns), not bytes; the dense coarsest inverse on the device beside it (what it costs to MAKE is in its set_system_ms)
+        Vm, Fm = meshgen.torus_mesh(190, 190)
+        Sm, mass_m = meshgen.cotan_laplacian(Vm, Fm)
+        lhs_m, rhs_m = meshgen.smoothing_system(Sm, mass_m, Vm)
+        Hm = cabi.Hierarchy(Vm, meshgen.neighbors_from_stiffness(Sm), ratio=8.0, lower_bound=1000)
+        variants["smoothing_36k_d3"] = variant_run(cabi, torch, "smoothing M + 1e-3 S, d = 3, 36 100 vertices", Hm, mass_m, lhs_m, rhs_m, args.steps, args.warmup)
+        dc = variant_run(cabi, torch, "smoothing 36 k, d = 3, dense coarsest inverse on the device", Hm, mass_m, lhs_m, rhs_m, args.steps, args.warmup, coarse_mode=cabi.COARSE_DEVICE_INVERSE)
+        variants["smoothing_36k_d3"]["device_coarse_inverse"] = {k: dc[k] for k in ("ms_per_step", "iterations_to_1e-4", "solve_ms", "second_solve_ms", "set_system_ms")}
+        del Vm, Fm, Sm, mass_m, lhs_m, rhs_m, Hm
         name, pos, S3, mass3, lhs3, rhs3 = meshgen.baseline_config("3")
         H3 = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S3), ratio=8.0, lower_bound=1000)
         variants["pointcloud_2M_knn8"] = variant_run(cabi, torch, name, H3, mass3, lhs3, rhs3, args.steps, args.warmup, levels=True)
