@@ -184,54 +184,6 @@ inline int greedy_coloring_bytes(const Mat& A, RawVec<unsigned char>& c8, const 
     return ncol;
 }
 
-// Tiny colour classes cost a launch each in every sweep (a launch has a floor of ~5 us whatever it holds): the stragglers the first-fit
-// colouring leaves behind on an irregular graph -- a few hundred or thousand vertices that found all big colours taken -- are moved into
-// the big classes where a local change allows it.  For a vertex v of a class below n / 64: (1) a big colour none of its neighbours has;
-// else (2) a big colour c exactly ONE neighbour u has, where u itself can take another big colour: u moves, v takes c.  Sequential over
-// the few tiny-class vertices in index order (deterministic); the colouring stays proper by construction; classes that end up empty are
-// removed.  The pattern must be symmetric (as for the colouring itself).  Returns the new number of colours.
-template <class Mat>
-inline int absorb_tiny_colour_classes(const Mat& A, unsigned char* cc, int ncol) {
-    const int n = A.n_outer;
-    if (ncol <= 2 || ncol > 64 || n < 4096) return ncol;
-    std::vector<int64_t> count((size_t)ncol, 0);
-    for (int i = 0; i < n; ++i) ++count[cc[i]];
-    uint64_t big = 0;
-    for (int c = 0; c < ncol; ++c) if (count[c] * 64 >= (int64_t)n) big |= (uint64_t)1 << c;
-    if (big == 0 || big == ((ncol == 64) ? ~(uint64_t)0 : (((uint64_t)1 << ncol) - 1))) return ncol;
-    auto neighbour_mask = [&](int v, int skip) {
-        uint64_t m = 0;
-        for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { const int j = A.idx[p]; if (j != v && j != skip) m |= (uint64_t)1 << cc[j]; }
-        return m;
-    };
-    for (int v = 0; v < n; ++v) {
-        const int t = cc[v];
-        if ((big >> t) & 1) continue;
-        const uint64_t taken = neighbour_mask(v, -1);
-        uint64_t free_big = big & ~taken;
-        if (free_big) { const int c = __builtin_ctzll(free_big); cc[v] = (unsigned char)c; --count[t]; ++count[c]; continue; }
-        // every big colour is taken: one that a single neighbour holds, and that neighbour has somewhere else to go
-        int once[64], who[64];
-        for (int c = 0; c < ncol; ++c) { once[c] = 0; who[c] = -1; }
-        for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { const int j = A.idx[p]; if (j != v) { ++once[cc[j]]; who[cc[j]] = j; } }
-        for (int c = 0; c < ncol; ++c) {
-            if (!((big >> c) & 1) || once[c] != 1) continue;
-            const int u = who[c];
-            const uint64_t u_free = big & ~neighbour_mask(u, v) & ~((uint64_t)1 << c);
-            if (!u_free) continue;
-            const int cu = __builtin_ctzll(u_free);
-            cc[u] = (unsigned char)cu; --count[c]; ++count[cu];
-            cc[v] = (unsigned char)c; --count[t]; ++count[c];
-            break;
-        }
-    }
-    // remove the classes that ended up empty (the others keep their relative order)
-    int remap[64], kept = 0;
-    for (int c = 0; c < ncol; ++c) remap[c] = count[c] > 0 ? kept++ : -1;
-    if (kept != ncol) for (int i = 0; i < n; ++i) cc[i] = (unsigned char)remap[cc[i]];
-    return kept;
-}
-
 template <class Mat>
 inline int greedy_coloring(const Mat& A, std::vector<int>& color, const std::vector<int>& order = std::vector<int>()) {
     RawVec<unsigned char> c8;
@@ -368,7 +320,7 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     if (multicolor) {
         o.n_colors = greedy_coloring_bytes(A, c8_own, base, idx_sorted);
         if (o.n_colors < 0) { c8_own.resize(0); o.n_colors = greedy_coloring_general(A, color, base); }
-        else { o.n_colors = absorb_tiny_colour_classes(A, c8_own.data(), o.n_colors); c8 = c8_own.data(); }
+        else c8 = c8_own.data();
     } else { color.assign(n, 0); o.n_colors = n > 0 ? 1 : 0; }
     const bool bytes = c8 != nullptr;
     auto colour_of = [&](int i) -> int { return bytes ? (int)c8[(size_t)i] : color[(size_t)i]; };
