@@ -295,8 +295,10 @@ int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
 /* Level-0 smoother of the partitioned cycle (multigrid_solver.cpp:1194-1226 split over ranks).  0 (default): multicolour
  * Gauss-Seidel with an exchange after every colour -- the single-GPU iterates bit for bit, (pre + post) x colours exchanges per cycle;
  * 1: hybrid -- Gauss-Seidel inside a rank, Jacobi across ranks, ONE exchange per sweep (pre + post per cycle); the iterates then depend
- * on the number of ranks.  Every rank must make the same choice. */
-int gmg_p2p_set_smoother(gmg_handle h, int hybrid);
+ * on the number of ranks;  2: as 0 -- the same iterates -- with the exchange of a colour folded into that colour's sweep launch (mailbox
+ * backend: publishing waves store their rows into the peers' mailboxes, the last one pulls; no exchange launch for the colour halos).
+ * Every rank must make the same choice. */
+int gmg_p2p_set_smoother(gmg_handle h, int mode);
 
 /* ---- host-only: hierarchy construction (no device needed) ----------------------------------- */
 typedef struct {
