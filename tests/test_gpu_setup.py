@@ -230,6 +230,65 @@ def test_another_pattern_of_the_same_size_and_entry_count_takes_the_full_set_up(
     assert np.array_equal(eng.run_cycles(4, 2), ref.run_cycles(4, 2))
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_sequences_of_systems_match_fresh_engines(cabi, seed):
+    """A handle that lives through a random sequence of systems -- new values on the live pattern (the refresh that runs ahead of the pattern
+    verdict), other patterns of the same size and entry count, other entry counts, unsorted storage, a matrix whose refresh fails, shorter and
+    longer hierarchies, with and without the structure prepared from the point graph -- computes after every step what a fresh engine computes."""
+    import scipy.sparse as sp
+    from gravo_mg_amd import meshgen
+    rng = np.random.default_rng(seed)
+    P = problems.torus_problem(96, 80, "smoothing", 60)
+    n = P.lhs.shape[0]
+    base = sp.csc_matrix(P.lhs); base.sort_indices()
+    S = P.S
+    eng = cabi.Engine()
+    state = {"U": P.U}
+    graph = meshgen.neighbors_from_stiffness(S) if seed != 1 else None       # seeds 2, 3: the hierarchy announces the pattern (structure prepared)
+    eng.set_prolongations(P.U, fine_graph=graph); eng.set_mass(P.mass)
+
+    def fresh_check(lhs_canonical):
+        fresh = cabi.Engine(); fresh.set_prolongations(state["U"]); fresh.set_mass(P.mass); fresh.set_system(lhs_canonical)
+        eng.load_problem(P.rhs, P.rhs); fresh.load_problem(P.rhs, P.rhs)
+        assert np.array_equal(eng.run_cycles(2, 2), fresh.run_cycles(2, 2))
+        assert np.array_equal(eng.fetch_solution(), fresh.fetch_solution())
+        fresh.close()
+
+    eng.set_system(base); fresh_check(base)
+    for step in range(14):
+        op = int(rng.integers(0, 6))
+        tau = float(10.0 ** rng.uniform(-4, -2))
+        A = sp.csc_matrix(sp.diags(P.mass) + tau * S); A.sort_indices()
+        if op == 0:                                        # the live pattern, new values
+            eng.set_system(A); fresh_check(A)
+        elif op == 1:                                      # a few vertices renumbered: same size, same entry count, another pattern
+            lo = int(rng.integers(0, n - 400)); perm = np.arange(n); perm[lo:lo + 300] = perm[lo:lo + 300][::-1].copy()
+            B = sp.csc_matrix(sp.csr_matrix(A)[perm][:, perm]); B.sort_indices()
+            eng.set_system(B); fresh_check(B)
+        elif op == 2:                                      # one more symmetric coupling
+            i, j = int(rng.integers(0, n)), int(rng.integers(0, n))
+            if i == j:
+                continue
+            B = sp.csc_matrix(A + sp.coo_matrix(([-1e-9, -1e-9], ([i, j], [j, i])), shape=A.shape)); B.sort_indices()
+            eng.set_system(B); fresh_check(B)
+        elif op == 3:                                      # every column stored backwards
+            idx, val = A.indices.copy(), A.data.copy()
+            for c in range(0, n, 3):
+                idx[A.indptr[c]:A.indptr[c + 1]] = idx[A.indptr[c]:A.indptr[c + 1]][::-1]; val[A.indptr[c]:A.indptr[c + 1]] = val[A.indptr[c]:A.indptr[c + 1]][::-1]
+            eng._chk(cabi.lib().gmg_set_system(eng._h, n, cabi._pi(A.indptr), cabi._pi(idx), cabi._pd(val)))
+            fresh_check(A)
+        elif op == 4:                                      # a zero on the diagonal: an error, and no system afterwards
+            bad = A.copy(); c = int(rng.integers(0, n)); col = slice(bad.indptr[c], bad.indptr[c + 1])
+            bad.data[col] = np.where(bad.indices[col] == c, 0.0, bad.data[col])
+            with pytest.raises(Exception):
+                eng._chk(cabi.lib().gmg_set_system(eng._h, n, cabi._pi(bad.indptr), cabi._pi(bad.indices), cabi._pd(bad.data)))
+            eng.set_system(A); fresh_check(A)
+        else:                                              # another hierarchy depth on the same handle
+            state["U"] = P.U[:1] if len(state["U"]) == len(P.U) else P.U
+            eng.set_prolongations(state["U"], fine_graph=graph)
+            eng.set_system(A); fresh_check(A)
+
+
 def test_non_canonical_lhs_storage_is_accepted(cabi):
     """Unsorted row indices and duplicate entries (summed, like Eigen's setFromTriplets) give the same system."""
     import scipy.sparse as sp
