@@ -452,6 +452,11 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     bool have_key = false;
     int rc_spec = 1;                  // result of the refresh that ran ahead of the verdict (spec_done)
     bool spec_done = false;
+    // A handle WITHOUT a live system has nothing to refresh: the cold set-up's first device step -- A_0 in natural numbering, 250 MB at 3 M
+    // vertices -- goes up beside the inspection instead of after it (into a matrix of its own: the levels are rebuilt further down)
+    DevCsr early_A0;
+    bool early_upload = false;
+    struct EarlyGuard { DevCsr& d; ~EarlyGuard() { free_csr(d); } } early_guard{early_A0};
     {
         std::future<int> inspected = std::async(std::launch::async, [&] { return inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads); });
         std::future<void> keyed;
@@ -492,12 +497,19 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             have_key = true;
             if (rc_up != GMG_OK) { (void)inspected.get(); h->system_ready = false; h->placeholder_ready = false; return rc_up; }
         }
+        if (!speculative_upload && !(h->system_ready || h->placeholder_ready) && h->cfg.device_setup && h->cfg.device_rap && h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS &&
+            colptr[0] == 0 && colptr[n] >= n) {
+            const int rc_up = upload_csr_raw(h, early_A0, n, colptr, rowidx, val);
+            if (rc_up != GMG_OK) { (void)inspected.get(); return rc_up; }
+            early_upload = true;
+        }
         const int what = inspected.get();
         if (what == 2) { if (speculative_upload) { h->system_ready = false; h->placeholder_ready = false; } return fail(h, GMG_ERR_INVALID, "index out of range in LHS"); }
         if (what == 1) {
             canon = canonical_copy(n, n, colptr, rowidx, val, h->cfg.host_threads);
             colptr = canon.ptr.data(); rowidx = canon.idx.data(); val = canon.val.data();
             have_key = false;
+            if (early_upload) { free_csr(early_A0); early_upload = false; }      // (it went up in the caller's storage order)
             // (the values went up in the caller's storage order, the resident pattern is canonical: the live system is void, and this
             // matrix takes the full set-up from its canonical copy)
             if (speculative_upload) { speculative_upload = false; spec_done = false; h->system_ready = false; h->placeholder_ready = false; h->refill_ready = false; }
@@ -704,6 +716,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     // colouring runs on a locally ordered graph; that needs the LHS on the device before the ordering task starts.
     reorder0 = mc && !ord_hit && !blocked0 && wants_locality_reorder(PatternView{n, colptr, rowidx}, h->cfg.reorder_fine);
     bool A0_uploaded = false;
+    if (early_upload && device_setup && h->cfg.device_rap) { free_csr(h->lv[0].dA); h->lv[0].dA = early_A0; early_A0 = DevCsr(); A0_uploaded = true; }
     // (h->cluster_order is only read once the patches are ready: build_patches may still be writing it)
     const bool have_bfs = (int)h->bfs_order.size() == n, have_cluster = h->patches_ready && (int)h->cluster_order.size() == n;
     h->base_order_choice = (reorder0 && h->patches_ready && have_bfs && !have_cluster) ? 1 : 0;
@@ -718,7 +731,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         h->timing["base_order_choice"] = h->base_order_choice;
     }
     if (reorder0 && device_setup && h->cfg.device_rap && (have_cluster || (h->patches_ready && have_bfs))) {
-        int rc = upload_csr_raw(h, h->lv[0].dA, n, colptr, rowidx, val);
+        int rc = A0_uploaded ? GMG_OK : upload_csr_raw(h, h->lv[0].dA, n, colptr, rowidx, val);
         if (rc == GMG_OK) { A0_uploaded = true; rc = choose_base_order(h, h->lv[0].dA, n); }
         if (rc == GMG_OK) rc = device_permute_pattern(h, h->lv[0].dA, n, colptr[n]);
         if (rc != GMG_OK) { join_tasks(); return rc; }
