@@ -23,7 +23,7 @@ def worker(rank, world, port, q, kind, shard, reps):
         t0 = time.time()
         for rep in range(reps):
             hybrid = rep % 4 == 3
-            rk.set_smoother(hybrid)
+            rk.set_smoother(1 if hybrid else (2 if rep % 4 == 2 else 0))      # (2: the colour exchanges folded into the colour launches -- the exact smoother's bits)
             if rep % 2 == 0:
                 rk.load(P.rhs, P.rhs); hist = rk.cycles(5, 2); x = rk.fetch()
                 sig = (hist.tobytes(), x.tobytes())
