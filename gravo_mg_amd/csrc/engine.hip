@@ -101,8 +101,9 @@ void p2p_release_handle(gmg_handle h);      // engine_dist.hip.hpp
 // A_0 its children are (U_0's column p, ascending), so the coarse rows are bucketed by their largest child (64 fine rows per bucket, counting
 // sort) -- in a locally numbered mesh a tenth of them becomes computable with every tenth of the upload.
 static void drop_rap_order(gmg_handle h) {
-    h->rap_need.clear();
+    h->rap_need.clear(); h->rap_need2.clear();
     if (h->d_rap_order) { (void)sync_hipFree(h->d_rap_order); h->d_rap_order = nullptr; }
+    if (h->d_rap_order2) { (void)sync_hipFree(h->d_rap_order2); h->d_rap_order2 = nullptr; }
 }
 static bool ensure_rap_order(gmg_handle h) {
     if (!h->rap_need.empty() && h->d_rap_order) return true;
@@ -118,6 +119,28 @@ static bool ensure_rap_order(gmg_handle h) {
     for (int p = 0; p < nc; ++p) { const int at = start[bucket[p]]++; order[at] = p; h->rap_need[at] = bucket[p] > 0 ? (bucket[p] - 1) * 64 + 63 : -1; }
     if (hipMalloc((void**)&h->d_rap_order, sizeof(int) * (size_t)nc) != hipSuccess) { (void)hipGetLastError(); h->d_rap_order = nullptr; h->rap_need.clear(); return false; }
     if (hipMemcpy(h->d_rap_order, order.data(), sizeof(int) * (size_t)nc, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); drop_rap_order(h); return false; }
+    // level 2 (optional: without it the level's pass simply runs after level 1's): need of row q = the largest need among its children on level 1
+    if (h->L >= 3 && h->U[1].n_inner == nc && h->U[1].n_outer > 0) {
+        const Compressed& U1 = h->U[1];
+        const int nc2 = U1.n_outer;
+        std::vector<int> need1((size_t)nc);                     // by level-1 row (natural numbering)
+        for (int at = 0; at < nc; ++at) need1[order[at]] = h->rap_need[at];
+        std::vector<std::pair<int, int>> rows((size_t)nc2);
+        for (int q = 0; q < nc2; ++q) {
+            int m = -1;
+            for (int e = U1.ptr[q]; e < U1.ptr[q + 1]; ++e) m = std::max(m, need1[U1.idx[e]]);
+            rows[q] = {m, q};
+        }
+        std::sort(rows.begin(), rows.end());
+        std::vector<int> order2((size_t)nc2);
+        h->rap_need2.resize((size_t)nc2);
+        for (int i = 0; i < nc2; ++i) { h->rap_need2[i] = rows[i].first; order2[i] = rows[i].second; }
+        if (hipMalloc((void**)&h->d_rap_order2, sizeof(int) * (size_t)nc2) != hipSuccess || hipMemcpy(h->d_rap_order2, order2.data(), sizeof(int) * (size_t)nc2, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->d_rap_order2) { (void)sync_hipFree(h->d_rap_order2); h->d_rap_order2 = nullptr; }
+            h->rap_need2.clear();
+        }
+    }
     return true;
 }
 
@@ -356,7 +379,7 @@ static void coarse_inverse(gmg_handle h, std::vector<double>& inv) {
 // done in place (nothing has been changed then, except values that the full path overwrites anyway).
 // values_uploaded: the caller has already put `val` into the resident A_0 (the speculative upload of set_system_impl)
 // l1_rows_done: ... and has queued the numeric Galerkin pass of the first l1_rows_done rows of level 1 behind it (flag: h->d_aux_err)
-static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all, bool values_uploaded = false, int l1_rows_done = 0) {
+static int refresh_system_values(gmg_handle h, int n, const double* val, clk::time_point t_all, bool values_uploaded = false, int l1_rows_done = 0, int l2_rows_done = 0) {
     const int L = h->L;
     auto mark = [&](const std::string& what) { h->timing["t_" + what] = ms_since(t_all); };
     for (int k = 0; k <= L; ++k) if (!h->lv[k].dA.ptr || !h->lv[k].dA.idx || !h->lv[k].dA.val) return 1;
@@ -375,7 +398,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     auto t0 = clk::now();
     for (int k = 1; k <= L; ++k) {
         Level& lk = h->lv[k];
-        if ((rc = device_rap(h, h->lv[k - 1].dA, h->dU[k - 1], h->dE3[k - 1], lk.dA, lk.A, false, k == L, &lk.nnz, d_err.p, true, k == 1 ? l1_rows_done : 0))) return rc < 0 ? rc : GMG_ERR_STATE;
+        if ((rc = device_rap(h, h->lv[k - 1].dA, h->dU[k - 1], h->dE3[k - 1], lk.dA, lk.A, false, k == L, &lk.nnz, d_err.p, true, k == 1 ? l1_rows_done : (k == 2 ? l2_rows_done : 0)))) return rc < 0 ? rc : GMG_ERR_STATE;
         if (k == L) lk.hostA_values = true;
         mark("rap_l" + std::to_string(k));
     }
@@ -400,6 +423,7 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
         if (herr == 0) herr = herr_aux;
     }
     h->timing["setup_rap_rows_pipelined"] = l1_rows_done;
+    h->timing["setup_rap_rows_pipelined_l2"] = l2_rows_done;
     h->timing["setup_device_layout"] = ms_since(tl);
     mark("device_layout");
     const bool factor_ok = factor_done.get();
@@ -448,6 +472,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     // live system, which the full set-up replaces anyway.
     bool speculative_upload = false;
     int l1_rows_done = 0;             // coarse rows of level 1 whose numeric Galerkin pass was queued behind the chunks of that upload
+    int l2_rows_done = 0;             // ... and of level 2 behind those
     uint64_t pat_key[2] = {0, 0};
     bool have_key = false;
     int rc_spec = 1;                  // result of the refresh that ran ahead of the verdict (spec_done)
@@ -469,6 +494,8 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             // last chunk for nearly every row: everything then runs after the upload, as before.
             const bool pipeline = L >= 2 && h->aux_stream && h->aux_ev && h->d_aux_err && h->dU_ready && (int)h->dU.size() == L && h->dU[0].ptr && h->dE3[0].cnt &&
                                   h->lv[1].dA.ptr && h->lv[1].dA.idx && h->lv[1].dA.val && h->lv[1].dA.n_outer == h->U[0].n_outer && !h->dU_flagged && ensure_rap_order(h);
+            const bool pipeline2 = pipeline && L >= 3 && !h->rap_need2.empty() && h->d_rap_order2 && h->dU[1].ptr && h->dE3[1].cnt && h->lv[2].dA.ptr && h->lv[2].dA.idx && h->lv[2].dA.val &&
+                                   h->lv[2].dA.n_outer == h->U[1].n_outer && (int)h->rap_need2.size() == h->U[1].n_outer;
             const size_t val_bytes = sizeof(double) * (size_t)h->lv[0].nnz;
             std::function<void(size_t, hipEvent_t)> after_chunk = [&](size_t bytes_done, hipEvent_t arrived) {
                 const int nc = h->U[0].n_outer;
@@ -476,15 +503,30 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
                 // complete rows of A_0 (a colptr that is not ascending -- the inspection is still running -- gives some row count: the rows computed from
                 // it are recomputed by the full set-up that follows a failed inspection)
                 const int rows = (int)(std::upper_bound(colptr, colptr + n + 1, (int)std::min<int64_t>(entries, colptr[n])) - colptr) - 1;
-                int p_hi = bytes_done >= val_bytes ? nc : (int)(std::upper_bound(h->rap_need.begin(), h->rap_need.end(), rows - 1) - h->rap_need.begin());
-                if (p_hi - l1_rows_done < 32768 && bytes_done < val_bytes) return;
-                if (p_hi <= l1_rows_done) return;
-                (void)hipStreamWaitEvent(h->aux_stream, arrived, 0);
-                const DevCsr &dA0 = h->lv[0].dA, &dU0 = h->dU[0], &dC = h->lv[1].dA;
-                const DevEll3& e3 = h->dE3[0];
-                hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(p_hi - l1_rows_done), dim3(64), 0, h->aux_stream, dA0.ptr, dA0.idx, dA0.val, dU0.ptr, dU0.idx, dU0.val, e3.cnt, e3.col, e3.val, p_hi,
-                                   (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, h->d_aux_err, l1_rows_done, (const int*)h->d_rap_order);
-                l1_rows_done = p_hi;
+                const bool last = bytes_done >= val_bytes;
+                int p_hi = last ? nc : (int)(std::upper_bound(h->rap_need.begin(), h->rap_need.end(), rows - 1) - h->rap_need.begin());
+                if (p_hi - l1_rows_done < 32768 && !last) return;
+                if (p_hi > l1_rows_done) {
+                    (void)hipStreamWaitEvent(h->aux_stream, arrived, 0);
+                    const DevCsr &dA0 = h->lv[0].dA, &dU0 = h->dU[0], &dC = h->lv[1].dA;
+                    const DevEll3& e3 = h->dE3[0];
+                    hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(p_hi - l1_rows_done), dim3(64), 0, h->aux_stream, dA0.ptr, dA0.idx, dA0.val, dU0.ptr, dU0.idx, dU0.val, e3.cnt, e3.col, e3.val, p_hi,
+                                       (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, h->d_aux_err, l1_rows_done, (const int*)h->d_rap_order);
+                    l1_rows_done = p_hi;
+                }
+                // level 2 behind it, on the same stream: the rows whose children on level 1 are all among the rows launched so far (the pieces
+                // of level 1 end at a boundary of `need`: every row that needs no more than fine row rows - 1 has been launched)
+                if (pipeline2) {
+                    const int nc2 = h->U[1].n_outer;
+                    const int q_hi = last ? nc2 : (int)(std::upper_bound(h->rap_need2.begin(), h->rap_need2.end(), rows - 1) - h->rap_need2.begin());
+                    if (q_hi > l2_rows_done && (last || q_hi - l2_rows_done >= 4096)) {
+                        const DevCsr &dA1 = h->lv[1].dA, &dU1 = h->dU[1], &dC2 = h->lv[2].dA;
+                        const DevEll3& e31 = h->dE3[1];
+                        hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(q_hi - l2_rows_done), dim3(64), 0, h->aux_stream, dA1.ptr, dA1.idx, dA1.val, dU1.ptr, dU1.idx, dU1.val, e31.cnt, e31.col, e31.val, q_hi,
+                                           (const int*)dC2.ptr, (int*)nullptr, dC2.idx, dC2.val, h->d_aux_err, l2_rows_done, (const int*)h->d_rap_order2);
+                        l2_rows_done = q_hi;
+                    }
+                }
             };
             if (pipeline) (void)hipMemsetAsync(h->d_aux_err, 0, sizeof(int), h->aux_stream);
             const int rc_up = h2d(h, h->lv[0].dA.val, val, val_bytes, pipeline ? &after_chunk : nullptr);
@@ -492,7 +534,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             speculative_upload = true;
             // ... and so does the rest of the refresh (Galerkin chain, layout refills, numeric LDL^T): none of it reads the pattern the threads are
             // still inspecting, all of it is overwritten by the full set-up should the verdict be "another pattern"
-            if (rc_up == GMG_OK) { rc_spec = refresh_system_values(h, n, val, t_all, true, l1_rows_done); spec_done = true; }
+            if (rc_up == GMG_OK) { rc_spec = refresh_system_values(h, n, val, t_all, true, l1_rows_done, l2_rows_done); spec_done = true; }
             keyed.get();
             have_key = true;
             if (rc_up != GMG_OK) { (void)inspected.get(); h->system_ready = false; h->placeholder_ready = false; return rc_up; }

@@ -229,6 +229,7 @@ int device_rap(gmg_handle h, const DevCsr& dA, const DevCsr& dU, const DevEll3& 
     if (reuse_pattern && dC.ptr && dC.idx && dC.val && dC.n_outer == nc && *nnz_out > 0 && !pattern) {
         const int64_t nnz = *nnz_out;
         // (rows_done: the first rows were computed already -- queued behind the chunks of the values upload, engine.hip::set_system_impl)
+        if (rows_done > 0 && rows_done < nc) rows_done = 0;      // (the pipelined pieces follow a row LIST: a partial set is not a prefix of the natural order -- all rows again)
         if (rows_done < nc)
             hipLaunchKernelGGL(gmgs::rap_rows<2>, dim3(nc - rows_done), dim3(64), 0, h->stream, dA.ptr, dA.idx, dA.val, dU.ptr, dU.idx, dU.val, e3.cnt, e3.col, e3.val, nc,
                                (const int*)dC.ptr, (int*)nullptr, dC.idx, dC.val, d_err, rows_done);

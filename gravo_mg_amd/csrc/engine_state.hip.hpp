@@ -264,6 +264,10 @@ struct gmg_solver_s {
     // largest fine row the rows d_rap_order[0 .. i] prolong from (ascending): those are computable once that row has arrived (ensure_rap_order)
     std::vector<int> rap_need;
     int* d_rap_order = nullptr;
+    // ... and the same for level 2: its row q is computable once the level-1 rows it prolongs from (U_1's column q) are, i.e. once the fine row
+    // rap_need2[i] = max over those of their rap_need has arrived
+    std::vector<int> rap_need2;
+    int* d_rap_order2 = nullptr;
     std::vector<hipEvent_t> prof_ev;     // gmg_profile_cycle: events at the boundaries of a cycle's legs (prof_on: record them)
     bool prof_on = false; int prof_n = 0;
     bool il_r0 = false;                   // enqueue_down, level 0, d > 1: the residual is being written as an interleaved multi-vector
