@@ -143,6 +143,13 @@ void launch_jacobi_sweeps(gmg_handle h, Level& l, int d, int iters) {
 // persistent workgroups, grid < vgrid; measured in round 4 -- 8 .. 20 workgroups per compute unit -- the same or worse: profiles/r04/b_*.)
 inline int ep_persistent_grid(gmg_handle, int vgrid) { return vgrid; }
 
+// Does the entry-parallel block sweep of level l STREAM its operator (non-temporal loads)?  Yes when the operator's chunks (12 B per explicit,
+// 10 B per lower entry in fp64) are more than the memory-side cache (256 MB on MI355X) holds beside the cycle's vectors between two of the
+// launches that read them: level 0 of a point cloud (300 MB) -- measured 0.634 ms per cycle streamed, 0.699 with ordinary loads; the 506 k-row
+// level 1 of the 3 M mesh (76 MB, five readers per cycle): 140 us per cycle streamed, 125 not.
+constexpr int64_t kEpResidentBytes = (int64_t)128 << 20;
+inline bool ep_streams(const Level& l) { return l.ee_nnz * 12 + l.ep_nnz * 10 > kEpResidentBytes; }
+
 // block-hybrid Gauss-Seidel: one launch per sweep, ping-pong between x and tmp
 // One block-hybrid sweep in -> out over blocks [b0, b0 + nb) of a blocked level (in == nullptr: the iterate is the zero vector).
 // The kernels find their rows through blk_begin[block]: a sub-range is the same launch on offset block tables.
@@ -162,10 +169,17 @@ void launch_block_sweep_range(gmg_handle h, Level& l, int d, const T* in, T* out
         if (l.use_ep) {
             const int vgrid = (nb + 7) / 8 * 8;         // multiple of 8: the kernel's XCD-aware block map is a bijection onto [0, vgrid)
             const int grid = ep_persistent_grid(h, vgrid);
-            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
-                                              ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
-                                              Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
-                                              out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid, out_il));
+            if (ep_streams(l)) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D, true>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
+                                                  ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
+                                                  Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                                  out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid, out_il));
+            } else {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_ep<T, D, false>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(D, l.ep_cap_e, l.ep_cap_l), h->stream,
+                                                  ((begin_table || table_always) ? blk_begin : (const int*)nullptr), blk_ncolors, l.d_row_color, l.ep_ptr, l.ep_col, Prec<T>::epval(l), l.ee_ptr, l.ee_col,
+                                                  Prec<T>::eeval(l), Prec<T>::diag(l), b + (size_t)c0 * ld, (in ? in + (size_t)c0 * ld : nullptr),
+                                                  out + (size_t)c0 * ld, ld, l.ep_cap_e, l.ep_cap_l, nb, b0, vgrid, out_il));
+            }
         } else if (l.use_bcsr && d > 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_block_csrout<T, D, (D == 1 ? 32 : 24)>), dim3(nb), dim3(64),
                                               (size_t)l.bc_cap * (sizeof(T) + sizeof(int)) + (size_t)D * 64 * sizeof(T), h->stream, blk_begin,
@@ -226,9 +240,15 @@ bool launch_residual_delta(gmg_handle h, Level& l, int d, T* r, const int* begin
     const T* x_new = Prec<T>::x(l);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_delta_ep<T, D>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(0, l.ep_cap_e, 0), h->stream, begin_table,
-                                          l.ee_ptr, l.ee_col, Prec<T>::eeval(l), (x_old ? x_old + (size_t)c0 * ld : nullptr), x_new + (size_t)c0 * ld,
-                                          r + (size_t)c0 * ld, ld, nb));
+        if (ep_streams(l)) {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_delta_ep<T, D, true>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(0, l.ep_cap_e, 0), h->stream, begin_table,
+                                              l.ee_ptr, l.ee_col, Prec<T>::eeval(l), (x_old ? x_old + (size_t)c0 * ld : nullptr), x_new + (size_t)c0 * ld,
+                                              r + (size_t)c0 * ld, ld, nb));
+        } else {
+            DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::residual_delta_ep<T, D, false>), dim3(grid), dim3(64), gmgk::ep_lds_bytes<T>(0, l.ep_cap_e, 0), h->stream, begin_table,
+                                              l.ee_ptr, l.ee_col, Prec<T>::eeval(l), (x_old ? x_old + (size_t)c0 * ld : nullptr), x_new + (size_t)c0 * ld,
+                                              r + (size_t)c0 * ld, ld, nb));
+        }
     }
     return true;
 }

@@ -584,7 +584,11 @@ template <class T> inline size_t ep_lds_bytes(int D, int cap_e, int cap_l) {
 // results are bitwise those of the round-2 kernel.
 // `vgrid` > gridDim.x: persistent workgroups -- workgroup w sweeps the virtual blocks w, w + gridDim.x, ... (the XCD-aware map is
 // applied to the virtual index, so a workgroup's blocks stay on its XCD's part of the level).
-template <class T, int D>
+// STREAM: the operator's chunks are read with non-temporal loads (a level whose operator is too big to stay in the 256 MB memory-side cache
+// between the launches that read it -- level 0 of a point cloud); otherwise with ordinary loads: the ~76 MB of the 506 k-row level of the
+// 3 M mesh are read by five consecutive launches per cycle, and the second to fifth then find them on the chip (level 1: 140 -> 125 us per
+// cycle, profiles/r05/t_*).
+template <class T, int D, bool STREAM>
 __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
                                                   const unsigned char* __restrict__ row_color, const int* __restrict__ l_ptr,
                                                   const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     T ev[kEpE];
     if (nE > 0) {
 #pragma unroll
-        for (int k = 0; k < kEpE; ++k) { ec[k] = ep_load<int, true>(rc, lane_b * 4 + 256 * k); ev[k] = ep_load<T, true>(rv, lane_b * (int)sizeof(T) + 64 * k * (int)sizeof(T)); }
+        for (int k = 0; k < kEpE; ++k) { ec[k] = ep_load<int, STREAM>(rc, lane_b * 4 + 256 * k); ev[k] = ep_load<T, STREAM>(rv, lane_b * (int)sizeof(T) + 64 * k * (int)sizeof(T)); }
     } else {
 #pragma unroll
         for (int k = 0; k < kEpE; ++k) { ec[k] = 0; ev[k] = (T)0.0; }
@@ -631,7 +635,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
     T lv[kEpL];
     unsigned short lc[kEpL];
 #pragma unroll
-    for (int m = 0; m < kEpL; ++m) { lv[m] = ep_load<T, true>(rlv, lane_b * (int)sizeof(T) + 64 * m * (int)sizeof(T)); lc[m] = ep_load<unsigned short, true>(rlc, lane_b * 2 + 128 * m); }
+    for (int m = 0; m < kEpL; ++m) { lv[m] = ep_load<T, STREAM>(rlv, lane_b * (int)sizeof(T) + 64 * m * (int)sizeof(T)); lc[m] = ep_load<unsigned short, STREAM>(rlc, lane_b * 2 + 128 * m); }
     const int eb = e_ptr[row] - e0, ee = x_in ? e_ptr[row + 1] - e0 : eb;
     const int lb = l_ptr[row] - q0, nlow = l_ptr[row + 1] - q0 - lb;
     const int mycolor = row_color[row];
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
 // (the residual SpMV reads the merged SELL operator, 25-29 % padding: 31 us; this: see profiles/).  The value differs from
 // b - A x_new by the rounding of the sweep's last division, |a_ii x_i| eps -- the size of the rounding error of evaluating b - A x
 // itself.  x_old == nullptr: the sweep started from the zero vector.  Launch geometry and entry-parallel reduction as in gs_block_ep.
-template <class T, int D>
+template <class T, int D, bool STREAM>
 __global__ __launch_bounds__(64) void residual_delta_ep(const int* __restrict__ blk_begin, const int* __restrict__ e_ptr, const int* __restrict__ e_col,
                                                         const T* __restrict__ e_val, const T* __restrict__ x_old, const T* __restrict__ x_new,
                                                         T* __restrict__ r, int ld, int n_blocks) {
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(64) void residual_delta_ep(const int* __restrict__ 
     int ec[kEpE];
     T ev[kEpE];
 #pragma unroll
-    for (int k = 0; k < kEpE; ++k) { ec[k] = ep_load<int, true>(rc, lane * 4 + 256 * k); ev[k] = ep_load<T, true>(rv, lane * (int)sizeof(T) + 64 * k * (int)sizeof(T)); }
+    for (int k = 0; k < kEpE; ++k) { ec[k] = ep_load<int, STREAM>(rc, lane * 4 + 256 * k); ev[k] = ep_load<T, STREAM>(rv, lane * (int)sizeof(T) + 64 * k * (int)sizeof(T)); }
     const int eb = e_ptr[row] - e0, ee = e_ptr[row + 1] - e0;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -872,8 +876,9 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
 #pragma unroll
         for (int j = 0; j < WQ; ++j)
             if (j < w) {
-                v[j] = __builtin_nontemporal_load(in_val + p0 + (int64_t)j * 64 + lane);
-                cpk[j >> 1] |= (unsigned)__builtin_nontemporal_load(in_col + p0 + (int64_t)j * 64 + lane) << ((j & 1) * 16);
+                // (ordinary loads: the quad layout is for levels of < 65 536 rows, whose operator stays on the chip from one launch to the next)
+                v[j] = in_val[p0 + (int64_t)j * 64 + lane];
+                cpk[j >> 1] |= (unsigned)in_col[p0 + (int64_t)j * 64 + lane] << ((j & 1) * 16);
             }
         T acc[D];
         if (x_in) { row_dot<T, D>(out_ptr, out_col, out_val, x_in, ld, s, lane, acc); quad_reduce<T, D>(acc); }
