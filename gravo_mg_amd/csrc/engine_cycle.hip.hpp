@@ -19,6 +19,8 @@ namespace {
     switch (mode) {                      \
         case 1: { constexpr int C16 = 1; __VA_ARGS__; } break; \
         case 2: { constexpr int C16 = 2; __VA_ARGS__; } break; \
+        case 3: { constexpr int C16 = 3; __VA_ARGS__; } break; \
+        case 4: { constexpr int C16 = 4; __VA_ARGS__; } break; \
         default: { constexpr int C16 = 0; __VA_ARGS__; } break; \
     }
 
@@ -59,7 +61,7 @@ bool fold_norm<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, 
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
     const int nblk = grid_for(se - sb), first = norm_grid(sb);
     if ((size_t)(first + nblk) > (size_t)h->partial_blocks) return false;
-    DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::gs_color_norm<D, C16>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+    DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color_norm<D, C16>), dim3(nblk), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                      l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, l.n_pad, sb, se, h->cfg.gs_omega, w, h->d_partials + (size_t)first * 2 * d,
                                      l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
     h->fuse_norm_blocks = nblk;
@@ -74,11 +76,11 @@ template <>
 bool fold_residual<double>(gmg_handle h, Level& l, int d, bool last_launch, int sb, int se) {
     if (!last_launch || !h->fuse_res_out || &l != &h->lv[0] || d > 4 || l.ord.n_colors < 2 || se != l.Aoff.n_slices || sb <= 0) return false;
     if (h->il_r0 && d > 1) {
-        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16, (D > 1)>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16, (D > 1)>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                          l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega,
                                          l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
     } else {
-        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color_residual<D, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                          l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, h->fuse_res_out, l.n_pad, sb, se, h->cfg.gs_omega,
                                          l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
     }
@@ -101,14 +103,10 @@ void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
                 if (se <= sb) continue;
                 if (fold_norm<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
                 if (fold_residual<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
-                if (fine && l.Aoff.c16_mode == 1) {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 2>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                if (fine && l.Aoff.c16_mode != 0) {           // FINE = 1 + C16 (c16_sel: 1 / 2 streamed, 3 / 4 a fine level that stays on the chip)
+                    DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color<T, D, C16 + 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
-                } else if (fine && l.Aoff.c16_mode == 2) {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 3>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
+                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
                 } else if (fine) {
                     DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
                                                       l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
@@ -272,31 +270,21 @@ void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const 
     const int ld = l.n_pad;
     if (n_slices < 0) n_slices = l.Aoff.n_slices;
     if (y_il && mode == 1 && LPR == 1 && d > 1 && d <= 4) {        // residual as an interleaved multi-vector (level 0, d > 1: what the restriction gathers from)
-        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, C16, (D > 1)>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+        DISPATCH_D(d, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, C16, (D > 1)>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                          l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b, x, y, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
         return;
     }
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        if (LPR == 1 && l.Aoff.c16_mode == 1) {           // level 0 with 16-bit column codes
+        if (LPR == 1 && l.Aoff.c16_mode != 0) {           // level 0 with 16-bit column codes
             if (mode == 1) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, 1>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, C16>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                                   l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
-                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
+                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
             } else {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, 1, 1>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, 1, C16>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                                   l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
-                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
-            }
-        } else if (LPR == 1 && l.Aoff.c16_mode == 2) {
-            if (mode == 1) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, 1, 2>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                                  l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
-                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
-            } else {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, 1, 2>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
-                                                  l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
-                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
+                                                  y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
             }
         } else if (mode == 1) {
             DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 1, LPR>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
@@ -319,14 +307,14 @@ void launch_spmv(gmg_handle h, Level& l, int d, int mode, const T* b, const T* x
 template <class T, int LPR>
 void launch_restrict_lpr(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst, bool src_il = false) {
     if (src_il && d > 1 && d <= 4) {
-        DISPATCH_D(d, DISPATCH_C16(fine.R.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16, (D > 1)>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
+        DISPATCH_D(d, DISPATCH_C16(fine.R.c16_sel(), hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16, (D > 1)>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
                                          h->stream, fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src, fine.n_pad, dst, coarse.n_pad, 0, fine.R.n_slices, 1,
                                          fine.R.col16, fine.R.win_base, fine.R.c16_arg())));
         return;
     }
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, DISPATCH_C16(fine.R.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
+        DISPATCH_D(dc, DISPATCH_C16(fine.R.c16_sel(), hipLaunchKernelGGL((gmgk::transfer<T, D, 0, LPR, C16>), dim3(grid_for(fine.R.n_slices)), dim3(gmgk::kBlock), 0,
                                           h->stream, fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src + (size_t)c0 * fine.n_pad, fine.n_pad,
                                           dst + (size_t)c0 * coarse.n_pad, coarse.n_pad, 0, fine.R.n_slices, 1, fine.R.col16, fine.R.win_base, fine.R.c16_arg())));
     }
@@ -341,14 +329,14 @@ void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* s
 template <class T>
 void launch_prolong_add(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst, bool src_il = false) {
     if (src_il && d > 1 && d <= 4) {
-        DISPATCH_D(d, DISPATCH_C16(fine.P.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16, (D > 1)>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
+        DISPATCH_D(d, DISPATCH_C16(fine.P.c16_sel(), hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16, (D > 1)>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
                                          h->stream, fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src, coarse.n_pad, dst, fine.n_pad, 0, fine.P.n_slices, 1,
                                          fine.P.col16, fine.P.win_base, fine.P.c16_arg())));
         return;
     }
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, DISPATCH_C16(fine.P.c16_mode, hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
+        DISPATCH_D(dc, DISPATCH_C16(fine.P.c16_sel(), hipLaunchKernelGGL((gmgk::transfer<T, D, 1, 1, C16>), dim3(grid_for(fine.P.n_slices)), dim3(gmgk::kBlock), 0,
                                           h->stream, fine.P.slice_ptr, fine.P.col, Prec<T>::val(fine.P), (const int*)nullptr, src + (size_t)c0 * coarse.n_pad,
                                           coarse.n_pad, dst + (size_t)c0 * fine.n_pad, fine.n_pad, 0, fine.P.n_slices, 1, fine.P.col16, fine.P.win_base, fine.P.c16_arg())));
     }
@@ -413,7 +401,7 @@ int launch_norm(gmg_handle h, int d, int type) {
     const bool poll = polled(h);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0, C16>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream,
+        DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 0, C16>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream,
                                           l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w,
                                           l.n_pad, n_slices, (float*)nullptr, h->d_partials, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
         launch_reduce(h, nblk + folded, dc, c0, c0 + 4 >= d);
@@ -790,7 +778,7 @@ int launch_residual_to_f32(gmg_handle h, int d, int type) {
     const int nblk = norm_grid(l.Aoff.n_slices);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 1, C16>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream,
+        DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::residual_norm_slices<D, 1, C16>), dim3(nblk), dim3(gmgk::kNormWaves * 64), 0, h->stream,
                                           l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * l.n_pad, l.x + (size_t)c0 * l.n_pad, w, l.n_pad,
                                           l.Aoff.n_slices, l.b32 + (size_t)c0 * l.n_pad, h->d_partials, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
         launch_reduce(h, nblk, dc, c0, c0 + 4 >= d);

@@ -90,7 +90,9 @@ struct DevSell {
     int c16_dbits = 13;                //          offset bits of a code: 13 = 8 windows of 8 192 columns per slice, 11 = 32 windows of 2 048
     int c16_mode = 0;                  //          0 none, 1 codes from slice c16_from on (uncovered slices are a short prefix), 2 uncovered slices flagged one by one
     int c16_from = 0;
+    bool resident = false;             //          the layout is small enough to stay in the memory-side cache between the launches that read it: ordinary loads (c16_sel)
     int c16_arg() const { return (c16_mode == 1 ? c16_from : 0) | (c16_dbits == 11 ? 1 << 30 : 0); }      // the kernels' c16_arg (kernels.hip.hpp::row_dot_sel)
+    int c16_sel() const { return c16_mode ? c16_mode + (resident ? 2 : 0) : 0; }      // the kernels' C16 template argument: 3 / 4 = modes 1 / 2 read with ordinary loads
 };
 
 // natural-numbering compressed matrix on the device (A_k, U_k by coarse column)

@@ -97,15 +97,17 @@ __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, c
 // order: the results are bit-identical to the 32-bit path.  A slice that NW windows cannot cover (rows of tiny colour classes,
 // scattered over the mesh) carries -1 as its first base and is read through the 32-bit indices: the wave learns that from the base
 // register AFTER it has issued its first group of loads, so the other slices never wait for the answer.
-template <class T, int D, int W, bool FLAGS, int XI = 0>
+template <class T, int D, int W, bool FLAGS, int XI = 0, bool KEEP = false>
 __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp, const int* __restrict__ cp32, const T* __restrict__ vp, const T* x, int ld,
                                                 int basev, int dbits, int& fallback, T (&acc)[D]) {
     unsigned pk[(W + 1) / 2];
     T v[W];
+    // KEEP: the level's operators are small enough to stay on the chip between the launches that read them (DevSell::resident) -- ordinary
+    // loads; otherwise the matrix is streamed past the caches, which then belong to the vectors
 #pragma unroll
-    for (int q = 0; q < (W + 1) / 2; ++q) pk[q] = __builtin_nontemporal_load(cp + q * 64);
+    for (int q = 0; q < (W + 1) / 2; ++q) pk[q] = KEEP ? cp[q * 64] : __builtin_nontemporal_load(cp + q * 64);
 #pragma unroll
-    for (int j = 0; j < W; ++j) v[j] = __builtin_nontemporal_load(vp + j * 64);
+    for (int j = 0; j < W; ++j) v[j] = KEEP ? vp[j * 64] : __builtin_nontemporal_load(vp + j * 64);
     if constexpr (FLAGS) { if (fallback < 0) fallback = __builtin_amdgcn_readfirstlane(basev) < 0 ? 1 : 0; }
     int c[W];
     if (FLAGS && fallback) {
@@ -131,7 +133,7 @@ __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp,
 }
 
 // row_dot with the columns read from the codes (G is even: a group's codes are whole words)
-template <class T, int D, bool FLAGS, int G = DotGroup<D>::value, int XI = 0>
+template <class T, int D, bool FLAGS, int G = DotGroup<D>::value, int XI = 0, bool KEEP = false>
 __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
                                           const int* __restrict__ win_base, int dbits, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
     const int wshift = 16 - dbits;                                        // windows per slice = 1 << wshift
@@ -144,19 +146,20 @@ __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr,
     int fallback = -1;                                                    // not known yet
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    for (; w >= G; w -= G, cp += (G / 2) * 64, cp32 += G * 64, vp += G * 64) row_dot_group16<T, D, G, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc);
+    for (; w >= G; w -= G, cp += (G / 2) * 64, cp32 += G * 64, vp += G * 64) row_dot_group16<T, D, G, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc);
     switch (w) {
-        case 1: row_dot_group16<T, D, 1, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 2: row_dot_group16<T, D, 2, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 3: row_dot_group16<T, D, 3, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 4: if (G > 4) row_dot_group16<T, D, 4, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 5: if (G > 4) row_dot_group16<T, D, 5, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 6: if (G > 4) row_dot_group16<T, D, 6, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
-        case 7: if (G > 4) row_dot_group16<T, D, 7, FLAGS, XI>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 1: row_dot_group16<T, D, 1, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 2: row_dot_group16<T, D, 2, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 3: row_dot_group16<T, D, 3, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 4: if (G > 4) row_dot_group16<T, D, 4, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 5: if (G > 4) row_dot_group16<T, D, 5, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 6: if (G > 4) row_dot_group16<T, D, 6, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
+        case 7: if (G > 4) row_dot_group16<T, D, 7, FLAGS, XI, KEEP>(cp, cp32, vp, x, ld, basev, dbits, fallback, acc); break;
         default: break;
     }
 }
 
+// C16 = 3 / 4: as 1 / 2 with ordinary instead of non-temporal loads of the operator (a fine level that fits the memory-side cache).
 // C16 = 0: 32-bit indices.  C16 = 1: codes from slice `from` on (the uncovered slices are a short prefix of the numbering -- tiny colour
 // classes come first -- and the branch on the wave-uniform slice number has nothing to wait for).  C16 = 2: uncovered slices anywhere,
 // found through their flag.  c16_arg = from | format << 30 (format 0: 13 offset bits / 8 windows, 1: 11 offset bits / 32 windows).
@@ -164,12 +167,12 @@ template <class T, int D, int C16, int G = DotGroup<D>::value, int XI = 0>
 __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
                                             const int* __restrict__ win_base, int c16_arg, const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                             T (&acc)[D]) {
-    if constexpr (C16 == 1) {
+    if constexpr (C16 == 1 || C16 == 3) {
         const int dbits = (c16_arg >> 30) & 1 ? 11 : 13;
-        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false, G, XI>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
+        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false, G, XI, C16 == 3>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
         else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
-    } else if constexpr (C16 == 2) {
-        row_dot16<T, D, true, G, XI>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
+    } else if constexpr (C16 == 2 || C16 == 4) {
+        row_dot16<T, D, true, G, XI, C16 == 4>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
     } else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 
