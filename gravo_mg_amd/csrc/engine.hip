@@ -1601,14 +1601,10 @@ int gmg_dist_smooth_color(gmg_handle h, int c) try {
     if (se > sb)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            if (l.Aoff.c16_mode == 1) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 2>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+            if (l.Aoff.c16_mode != 0) {       // (c16_sel: a rank whose share of the fine operators fits its memory-side cache reads them with ordinary loads)
+                DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color<double, D, C16 + 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                                   l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega,
-                                                  l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
-            } else if (l.Aoff.c16_mode == 2) {
-                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 3>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
-                                                  l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega,
-                                                  l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg()));
+                                                  l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
             } else {
                 DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                                   l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega));
@@ -1630,7 +1626,7 @@ int gmg_dist_residual_own(gmg_handle h) try {
         if (se <= sb) continue;
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::spmv_full<double, D, 1, 1, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0,
+            DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::spmv_full<double, D, 1, 1, C16>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0,
                                               h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld,
                                               l.r + (size_t)c0 * ld, ld, sb, se, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
         }

@@ -198,12 +198,9 @@ bool p2p_smooth_color_folded(gmg_handle h, int c) {
     pt.seq = p->seq; pt.err = p->d_err;
     const int ld = l.n_pad;
     const dim3 grid(grid_for(se - sb)), block(gmgk::kBlock);
-    if (l.Aoff.c16_mode == 1) {
-        DISPATCH_D(p->d, hipLaunchKernelGGL((gmgk::gs_color_push<D, 2>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
-                                            h->cfg.gs_omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), pt));
-    } else if (l.Aoff.c16_mode == 2) {
-        DISPATCH_D(p->d, hipLaunchKernelGGL((gmgk::gs_color_push<D, 3>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
-                                            h->cfg.gs_omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), pt));
+    if (l.Aoff.c16_mode != 0) {
+        DISPATCH_D(p->d, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color_push<D, C16 + 1>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
+                                            h->cfg.gs_omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), pt)));
     } else {
         DISPATCH_D(p->d, hipLaunchKernelGGL((gmgk::gs_color_push<D, 1>), grid, block, 0, h->stream, l.Aoff.slice_ptr, l.Aoff.col, l.Aoff.val, l.diag, l.b, l.x, ld, sb, se,
                                             h->cfg.gs_omega, (const unsigned*)nullptr, (const int*)nullptr, 0, pt));
