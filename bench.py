@@ -91,6 +91,7 @@ def variant_run(cabi, torch, label, H, mass, lhs, rhs, steps, warmup, kernels=Fa
     eng.load_problem(rhs, rhs); eng.run_cycles(warmup, 2)
     torch.cuda.synchronize(); t0 = time.perf_counter(); eng.run_cycles(steps, 2); torch.cuda.synchronize()
     out = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / steps, "iterations_to_1e-4": int(it), "residues": [float(v) for v in conv[:, 1]],
+           "coarse_on_device": bool(eng.timing("coarse_on_device")), "coarse_inverse_ms": (eng.timing("coarse_inverse_ms") if eng.timing("coarse_on_device") else None),
            "solve_ms": solve_ms, "first_solve_ms": solve_ms, "second_solve_ms": second_ms, "first_solve_timing_ms": first, "second_solve_timing_ms": second,
            "set_system_ms": set_ms, "n_vertices": int(lhs.shape[0]),
            "levels": [eng.level_info(k)["n"] for k in range(eng.num_levels + 1)], "colors": [eng.level_info(k)["n_colors"] for k in range(eng.num_levels + 1)],
@@ -162,7 +163,13 @@ def level_roofline(eng, rhs, reps=10):
         out.append({"level": k, "rows": eng.level_info(k)["n"], "ms": float(legs[k]), "algorithmic_bytes": by, "GBps": by / (legs[k] * 1e-3) / 1e9,
                     "frac": by / (legs[k] * 1e-3) / 1e9 / HBM_PEAK_GBS})
     by = eng.algorithmic_bytes(4, 0, d)
-    out.append({"level": "coarsest solve (host LDL^T round trip, %d unknowns)" % eng.level_info(L)["n"], "ms": float(legs[L])})
+    nl = eng.level_info(L)["n"]
+    if eng.timing("coarse_on_device"):
+        by_c = 8.0 * nl * nl + 4.0 * nl + 2 * 8.0 * nl * d
+        out.append({"level": "coarsest solve (dense inverse applied on the device, %d unknowns)" % nl, "ms": float(legs[L]), "algorithmic_bytes": by_c,
+                    "GBps": by_c / (legs[L] * 1e-3) / 1e9, "frac": by_c / (legs[L] * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    else:
+        out.append({"level": "coarsest solve (host LDL^T round trip, %d unknowns)" % nl, "ms": float(legs[L])})
     out.append({"level": "residual check (level 0)", "ms": float(legs[L + 1]), "algorithmic_bytes": by, "GBps": by / (legs[L + 1] * 1e-3) / 1e9,
                 "frac": by / (legs[L + 1] * 1e-3) / 1e9 / HBM_PEAK_GBS})
     return {"legs": out, "sum_ms": float(legs.sum()), "note": "events at the leg boundaries cost a few us per cycle: sum_ms is above ms_per_step by that much"}
@@ -234,7 +241,9 @@ def main():
     ap.add_argument("--config", default=None, choices=["1", "2", "3", "4", "4r", "4s", "5", "5b", "6"],
                     help="profiling aid: another BASELINE config (meshgen.baseline_config) as the main workload instead of the torus --n1 x --n2")
     ap.add_argument("--cpu-cycles", type=int, default=25, help="V-cycles timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--coarse", default="host", choices=["host", "device"])
+    ap.add_argument("--coarse", default="auto", choices=["auto", "host", "device"],
+                    help="gmg_config::coarse_mode: auto (the library default: dense inverse applied on the device while n_L <= 8192), host (LDL^T "
+                         "back-substitution, one round trip per cycle), device")
     ap.add_argument("--graph", action="store_true", help="replay the cycle legs from hipGraphs (same cycle time, ~5 ms instantiation per system)")
     ap.add_argument("--kernel-reps", type=int, default=50)
     ap.add_argument("--block-rows", type=int, default=None, help="block-hybrid GS rows per block (engine default if unset)")
@@ -279,8 +288,8 @@ def main():
         kw["block_from_level"] = args.block_from_level
     if args.block_lanes is not None:
         kw["block_lanes"] = args.block_lanes
-    eng = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT,
-                      use_graph=args.graph, **kw)
+    coarse_mode = {"auto": cabi.COARSE_AUTO, "host": cabi.COARSE_HOST_LDLT, "device": cabi.COARSE_DEVICE_INVERSE}[args.coarse]
+    eng = cabi.Engine(coarse_mode=coarse_mode, use_graph=args.graph, **kw)
     # A cold set-up first, on a handle that was NOT told the system's sparsity pattern (prepare_structure = 0): what a system with an
     # unannounced pattern pays (a Bilaplacian's two-ring, a caller's own prolongations) -- reported as set_system_cold_ms, never as the headline
     cold = cabi.Engine(prepare_structure=False, **kw)
@@ -362,7 +371,7 @@ def main():
     cyc_bytes = cycle_algorithmic_bytes(eng, d0)
     roofline["cycle"] = {"algorithmic_bytes": cyc_bytes, "achieved": cyc_bytes / (ms_per_step * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": cyc_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "whole V-cycle + residual check (every level, launch boundaries and the host coarsest solve included) over ms_per_step"}
+                         "note": "whole V-cycle + residual check (every level, launch boundaries and the coarsest solve included) over ms_per_step"}
 
     if not args.graph:              # (the leg-by-leg profile needs stream launches: gmg_profile_cycle refuses a handle that replays hipGraphs)
         lv_roof = level_roofline(eng, rhs)
@@ -378,22 +387,26 @@ def main():
     repeat_ms = 1e3 * (time.perf_counter() - t)
     repeat_values_only = bool(eng.timing("setup_values_only"))
 
-    # ---- informational variant (never `value`): the coarsest solve applied on the device ----
+    # ---- informational variant (never `value`): the coarsest solve as the reference places it -- on the host (multigrid_solver.cpp:1075), one
+    # device -> host -> device round trip per cycle -- against the default, which applies the dense inverse on the device
     variants = {}
-    if args.coarse == "host" and not args.no_variants:
+    coarse_on_device = bool(eng.timing("coarse_on_device"))
+    coarse_inverse_ms = eng.timing("coarse_inverse_ms") if coarse_on_device else None
+    if args.coarse == "auto" and not args.no_variants:
         del eng
-        eng2 = cabi.Engine(coarse_mode=cabi.COARSE_DEVICE_INVERSE, use_graph=args.graph, **kw)
+        eng2 = cabi.Engine(coarse_mode=cabi.COARSE_HOST_LDLT, use_graph=args.graph, **kw)
         eng2.use_hierarchy(H)
         eng2.set_mass(mass)
-        eng2.set_system(lhs)
+        t = time.perf_counter(); eng2.set_system(lhs); set2 = 1e3 * (time.perf_counter() - t)
         eng2.load_problem(rhs, rhs)
         eng2.run_cycles(args.warmup, 2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         res2 = eng2.run_cycles(args.steps, 2)
         torch.cuda.synchronize()
-        variants["device_coarse_apply"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / args.steps,
-                                           "residues_match_host_mode": bool(np.allclose(res2, residues, rtol=1e-6))}
+        variants["host_coarse_solve"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / args.steps, "set_system_ms": set2,
+                                         "residues_match_default": bool(np.allclose(res2, residues, rtol=1e-6)),
+                                         "what": "gmg_config::coarse_mode = GMG_COARSE_HOST_LDLT: supernodal LDL^T back-substitution on the host per cycle"}
         del eng2
 
     # ---- informational variants (never `value`): the same problem in random vertex order (SURVEY.md 8d asks for both orderings),
@@ -437,8 +450,8 @@ def main():
         lhs_m, rhs_m = meshgen.smoothing_system(Sm, mass_m, Vm)
         Hm = cabi.Hierarchy(Vm, meshgen.neighbors_from_stiffness(Sm), ratio=8.0, lower_bound=1000)
         variants["smoothing_36k_d3"] = variant_run(cabi, torch, "smoothing M + 1e-3 S, d = 3, 36 100 vertices", Hm, mass_m, lhs_m, rhs_m, args.steps, args.warmup)
-        dc = variant_run(cabi, torch, "smoothing 36 k, d = 3, dense coarsest inverse on the device", Hm, mass_m, lhs_m, rhs_m, args.steps, args.warmup, coarse_mode=cabi.COARSE_DEVICE_INVERSE)
-        variants["smoothing_36k_d3"]["device_coarse_inverse"] = {k: dc[k] for k in ("ms_per_step", "iterations_to_1e-4", "solve_ms", "second_solve_ms", "set_system_ms")}
+        dc = variant_run(cabi, torch, "smoothing 36 k, d = 3, coarsest solve on the host", Hm, mass_m, lhs_m, rhs_m, args.steps, args.warmup, coarse_mode=cabi.COARSE_HOST_LDLT)
+        variants["smoothing_36k_d3"]["host_coarse_solve"] = {k: dc[k] for k in ("ms_per_step", "iterations_to_1e-4", "solve_ms", "second_solve_ms", "set_system_ms")}
         del Vm, Fm, Sm, mass_m, lhs_m, rhs_m, Hm
         name, pos, S3, mass3, lhs3, rhs3 = meshgen.baseline_config("3")
         H3 = cabi.Hierarchy(pos, meshgen.neighbors_from_stiffness(S3), ratio=8.0, lower_bound=1000)
@@ -458,13 +471,15 @@ def main():
         "config": {"workload": workload, "n_vertices": n0, "levels": [l["n"] for l in levels], "colors": [l["n_colors"] for l in levels],
                    "smoother": f"2+2 sweeps; level 0: multicolour Gauss-Seidel over-relaxed by {eng_omega:g} (SOR, one launch per colour); levels >= 1: "
                                "block-hybrid Gauss-Seidel (64-row blocks: Gauss-Seidel inside a block, Jacobi between blocks, one launch per sweep)",
-                   "coarse_solve": args.coarse, "hipgraph": args.graph,
+                   "coarse_solve": args.coarse + (" (dense inverse applied on the device, built on the device at set_system)" if coarse_on_device else " (host LDL^T per cycle)"),
+                   "hipgraph": args.graph,
                    "tolerance": 1e-4, "stopping_criteria": 2},
         "iterations_to_1e-4": iters, "residue": res, "residues_to_1e-4": [float(v) for v in conv[:, 1]],
         "iterations_reference_algorithm": cpu["iterations_to_1e-4"] if cpu else None,
         "solve_ms": solve_ms, "solver_timing_ms": timing, "second_solve_timing_ms": timing_again,
         "set_system_ms": setup_ms, "set_system_structure_prepared": setup_prepared, "structure_prepare_ms": structure_ms, "use_hierarchy_ms": use_hierarchy_ms,
-        "set_system_cold_ms": setup_cold_ms,
+        "set_system_cold_ms": setup_cold_ms, "coarse_inverse_ms": coarse_inverse_ms,
+        "construct_plus_first_solve_ms": use_hierarchy_ms + setup_ms + solve_ms,
         "set_system_note": "set_system_ms: the first gmg_set_system on a handle whose hierarchy announced the system's sparsity pattern (its point graph): "
                            "values up, numeric Galerkin chain, layout refill, numeric LDL^T; the structural half was done once in gmg_use_hierarchy "
                            "(structure_prepare_ms, inside use_hierarchy_ms).  set_system_cold_ms: the same call on a handle that was told nothing",

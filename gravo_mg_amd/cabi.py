@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("GMG_LIB_PATH") or os.path.join(_HERE, "lib", "libgrav
 GMG_OK, GMG_ERR_INVALID, GMG_ERR_NO_DEVICE, GMG_ERR_HIP, GMG_ERR_STATE, GMG_ERR_NUMERIC, GMG_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6
 DIVERGED = 1          # gmg_solve only, not an error: the iteration did not contract
 SMOOTHER_MULTICOLOR_GS, SMOOTHER_JACOBI = 0, 1
-COARSE_HOST_LDLT, COARSE_DEVICE_INVERSE = 0, 1
+COARSE_HOST_LDLT, COARSE_DEVICE_INVERSE, COARSE_AUTO = 0, 1, 2
 
 _STATUS_NAMES = {
     -1: "GMG_ERR_INVALID", -2: "GMG_ERR_NO_DEVICE", -3: "GMG_ERR_HIP", -4: "GMG_ERR_STATE",
@@ -114,6 +114,7 @@ SIGNATURES = {
     "gmg_p2p_solve": (C.c_int, [_vp, _dp, _dp, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "gmg_p2p_stat": (C.c_int, [_vp, C.c_char_p, _dp]),
     "gmg_p2p_set_smoother": (C.c_int, [_vp, C.c_int]),
+    "gmg_p2p_set_fences": (C.c_int, [_vp, C.c_int]),
     "gmg_hierarchy_options_default": (C.c_int, [C.POINTER(GmgHierarchyOptions)]),
     "gmg_hierarchy_build": (C.c_int, [_dp, C.c_int, _ip, C.c_int, C.POINTER(GmgHierarchyOptions), C.POINTER(_vp)]),
     "gmg_hierarchy_destroy": (None, [_vp]),
@@ -147,6 +148,7 @@ INTERNAL_SIGNATURES = {
     "gmg_profile_cycle": (C.c_int, [_vp, C.c_int, C.c_int, _dp, C.c_int]),
     "gmg_algorithmic_bytes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _dp]),
     "gmg_p2p_bench_kind": (C.c_int, [_vp, C.c_char_p, C.c_int, _dp]),
+    "gmg_p2p_debug_collective_roundtrip": (C.c_int, [_vp, _dp, C.POINTER(C.c_longlong)]),
     "gmg_host_ldlt_probe": (C.c_int, [C.c_int, _ip, _ip, _dp, _dp, C.c_int, C.c_char_p, C.c_int]),
 }
 
@@ -318,7 +320,7 @@ class Engine:
     """One gmg_handle: device-resident hierarchy + V-cycle on one HIP stream."""
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
-                 coarse_mode=COARSE_HOST_LDLT, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
+                 coarse_mode=COARSE_AUTO, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
                  device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None):
         l = lib()
         cfg = GmgConfig()
@@ -732,10 +734,21 @@ class P2PCycle:
         exchange per sweep; 2: exact, the exchange of a colour folded into that colour's sweep launch (mailbox backend: no exchange launch)."""
         self.eng._chk(lib().gmg_p2p_set_smoother(self.eng._h, int(hybrid)))
 
+    def set_fences(self, fenced: bool):
+        """True (default): system-scope release / acquire fences around the sequence words of the mailbox exchanges; False: the gfx942 / gfx950
+        form without the cache write-back (gmg_p2p_set_fences) -- check the first cycles against a trusted run when you take it."""
+        self.eng._chk(lib().gmg_p2p_set_fences(self.eng._h, int(bool(fenced))))
+
     def stat(self, key: str) -> float:
         out = C.c_double()
         self.eng._chk(lib().gmg_p2p_stat(self.eng._h, key.encode(), C.byref(out)))
         return out.value
+
+    def collective_roundtrip(self):
+        """(max |sent - gathered|, values compared) of one rows-of-x exchange through the collective backend (internal test hook)."""
+        diff, cnt = C.c_double(), C.c_longlong()
+        self.eng._chk(lib().gmg_p2p_debug_collective_roundtrip(self.eng._h, C.byref(diff), C.byref(cnt)))
+        return diff.value, cnt.value
 
 
 def rccl_unique_id() -> bytes:

@@ -113,7 +113,13 @@ static bool ensure_rap_order(gmg_handle h) {
     if (nc <= 0 || nf <= 0) return false;
     const int nb = (nf + 63) / 64 + 1;                    // (bucket 0: coarse rows without children)
     std::vector<int> start((size_t)nb + 1, 0), order((size_t)nc), bucket((size_t)nc);
-    for (int p = 0; p < nc; ++p) { bucket[p] = U0.ptr[p + 1] > U0.ptr[p] ? (U0.idx[U0.ptr[p + 1] - 1] >> 6) + 1 : 0; ++start[(size_t)bucket[p] + 1]; }
+    // (the largest child: the maximum over the column -- a caller of the raw C-ABI may hand over columns whose row indices are not ascending)
+    for (int p = 0; p < nc; ++p) {
+        int big = -1;
+        for (int e = U0.ptr[p]; e < U0.ptr[p + 1]; ++e) big = std::max(big, U0.idx[e]);
+        bucket[p] = big >= 0 ? (big >> 6) + 1 : 0;
+        ++start[(size_t)bucket[p] + 1];
+    }
     for (int b = 0; b < nb; ++b) start[b + 1] += start[b];
     h->rap_need.resize((size_t)nc);
     for (int p = 0; p < nc; ++p) { const int at = start[bucket[p]]++; order[at] = p; h->rap_need[at] = bucket[p] > 0 ? (bucket[p] - 1) * 64 + 63 : -1; }
@@ -154,7 +160,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->jacobi_omega = 0.67;
     cfg->pre_iters = 2;       // gravomg_bindings/src/gravomg/core.py:10
     cfg->post_iters = 2;
-    cfg->coarse_mode = GMG_COARSE_HOST_LDLT;
+    cfg->coarse_mode = GMG_COARSE_AUTO;
     cfg->use_graph = 0;      // measured: the cycle is not launch-bound (eager == graph per cycle) and instantiating costs ~5 ms per system
     cfg->sigma = 0;          // measured: no length sorting inside colour classes beats every window size (irregular meshes; profiles/README.md)
     cfg->row_align = 64;
@@ -312,6 +318,9 @@ static int upload_mass(gmg_handle h) {
 int gmg_set_mass(gmg_handle h, int n, const double* mass_diag) try {
     if (!h || n <= 0 || !mass_diag) return h ? fail(h, GMG_ERR_INVALID, "bad mass arguments") : GMG_ERR_INVALID;
     PoolScope pool_scope_(&h->pool);
+    // a live system (or the prepared structure of one) fixes n: a mass of another size could only leave the M-weighted norms on stale weights
+    if ((h->system_ready || h->placeholder_ready) && !h->lv.empty() && h->lv[0].n != n)
+        return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
     h->mass.assign(mass_diag, mass_diag + n);
     // (with a system -- or the prepared structure of one: the ordering that permutes the mass exists -- it goes to the device now)
     if (h->has_device && (h->system_ready || h->placeholder_ready) && !h->lv.empty() && h->lv[0].n == n && h->lv[0].d_new2old) { h->mass_dirty = false; return upload_mass(h); }
@@ -361,18 +370,74 @@ static int refresh_fp32_twins(gmg_handle h, bool alloc) {
     return GMG_OK;
 }
 
-// dense inverse of the coarsest operator from the host factor (GMG_COARSE_DEVICE_INVERSE)
-static void coarse_inverse(gmg_handle h, std::vector<double>& inv) {
-    const int nl = h->lv[h->L].A.n_outer;
-    inv.resize((size_t)nl * nl);
-    parallel_ranges(nl, h->cfg.host_threads, [&](int lo, int hi, int) {
-        std::vector<double> e(nl, 0.0), w(nl);
-        for (int j = lo; j < hi; ++j) {
-            e[j] = 1.0;
-            h->coarse.solve(e.data(), inv.data() + (size_t)j * nl, w.data());
-            e[j] = 0.0;
-        }
-    });
+// Where the coarsest solve of this system runs (gmg_config::coarse_mode): GMG_COARSE_AUTO puts it on the device while the dense inverse is small
+// enough to be read once per cycle for less than the host round trip costs (n_L <= kCoarseDeviceMax: 512 MB, ~0.1 ms; the reference's
+// lower_bound = 1000 / ratio = 8 keep n_L below 8 000).
+constexpr int kCoarseDeviceMax = 8192;
+static bool want_coarse_device(gmg_handle h, int n_coarse) {
+    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) return true;
+    return h->cfg.coarse_mode == GMG_COARSE_AUTO && n_coarse <= kCoarseDeviceMax;
+}
+
+// Dense inverse of the coarsest operator, built ON THE DEVICE from the host's sparse factor (setup_kernels.hip.hpp::coarse_inverse_tiles): the factor
+// goes up in the device's chunk layout (a few MB), one launch carries every 64-column tile of the identity through it, a second one mirrors the
+// lower triangle, a third one moves it from the factor's numbering into the level's.  (Until round 6 the host solved n_L right-hand sides one by
+// one: 188 - 226 ms of set-up at n_L = 6 005.)
+static int build_coarse_inverse_device(gmg_handle h) {
+    auto t0 = clk::now();
+    const int nl = h->coarse.n;
+    SupernodalLDLT::DeviceFactor E;
+    h->coarse.export_device_factor(E);
+    h->timing["coarse_inverse_export_ms"] = ms_since(t0);
+    // tile width: enough workgroups for the chip's compute units on a small level (121 tiles of 16 columns at n_L = 1 929, 188 of 32 at 6 005)
+    const int width = nl <= 4096 ? 16 : (nl <= 8192 ? 32 : 64);
+    std::vector<int> tile_ptr_h, tile_q_h;
+    E.tile_paths(width, tile_ptr_h, tile_q_h);
+    DevTmp<int> q_col0, q_w, q_rptr, rows, lev_ptr, lev_q, tile_ptr, tile_q;
+    DevTmp<double> vals, tri, dinv;
+    int rc;
+    auto up_i = [&](DevTmp<int>& d, const std::vector<int>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(int) * v.size()); };
+    auto up_d = [&](DevTmp<double>& d, const std::vector<double>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(double) * v.size()); };
+    if ((rc = up_i(q_col0, E.q_col0)) || (rc = up_i(q_w, E.q_w)) || (rc = up_i(q_rptr, E.q_rptr)) || (rc = up_i(rows, E.rows)) ||
+        (rc = up_i(lev_ptr, E.lev_ptr)) || (rc = up_i(lev_q, E.lev_q)) || (rc = up_i(tile_ptr, tile_ptr_h)) || (rc = up_i(tile_q, tile_q_h)) || (rc = up_d(vals, E.vals)) || (rc = up_d(tri, E.tri)) || (rc = up_d(dinv, E.dinv)))
+        return rc;
+    std::vector<int> inv_h((size_t)nl);
+    for (int i = 0; i < nl; ++i) inv_h[(size_t)E.perm[(size_t)i]] = i;
+    DevTmp<int> perm_d, inv_d;
+    if ((rc = up_i(perm_d, E.perm)) || (rc = up_i(inv_d, inv_h))) return rc;
+    const size_t bytes = sizeof(double) * (size_t)nl * nl;
+    DevTmp<double> X;                                       // the inverse in the factor's numbering
+    if ((rc = X.alloc(h, std::max<size_t>((size_t)nl * nl, 1)))) return rc;
+    if (h->d_ainv && h->ainv_n != nl) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
+    if (!h->d_ainv) HIPCHK(dev_malloc((void**)&h->d_ainv, std::max<size_t>(bytes, 8)));
+    h->ainv_n = nl;
+    HIPCHK(hipMemsetAsync(X.p, 0, bytes, h->stream));
+    gmgs::InvFactor F;
+    F.n = nl; F.nq = E.nq; F.nlev = E.nlev;
+    F.q_col0 = q_col0.p; F.q_w = q_w.p; F.q_rptr = q_rptr.p; F.rows = rows.p; F.lev_ptr = lev_ptr.p; F.lev_q = lev_q.p; F.tile_ptr = tile_ptr.p; F.tile_q = tile_q.p;
+    F.vals = vals.p; F.tri = tri.p; F.dinv = dinv.p;
+    static_assert(gmgs::kInvChunk == SupernodalLDLT::kChunk, "chunk width of the exported factor");
+    const int nt = (nl + width - 1) / width, nm = (nl + 63) / 64;
+    h->timing["coarse_inverse_upload_ms"] = ms_since(t0) - h->timing["coarse_inverse_export_ms"];
+    if (nl > 0) {
+        (void)hipEventRecord(h->ev0, h->stream);
+        const dim3 block(64 * gmgs::kInvWaves);
+        if (width == 16) hipLaunchKernelGGL(gmgs::coarse_inverse_tiles<16>, dim3(nt), block, 0, h->stream, F, X.p);
+        else if (width == 32) hipLaunchKernelGGL(gmgs::coarse_inverse_tiles<32>, dim3(nt), block, 0, h->stream, F, X.p);
+        else hipLaunchKernelGGL(gmgs::coarse_inverse_tiles<64>, dim3(nt), block, 0, h->stream, F, X.p);
+        (void)hipEventRecord(h->ev1, h->stream);
+        hipLaunchKernelGGL(gmgs::mirror_lower_to_upper, dim3(nm, nm), dim3(256), 0, h->stream, X.p, nl);
+        // ... and into the level's numbering: the product kernel then reads its vectors contiguously
+        if (nl <= 8192) hipLaunchKernelGGL(gmgs::permute_symmetric, dim3(nl), dim3(256), sizeof(double) * (size_t)nl, h->stream, (const double*)X.p, (const int*)perm_d.p, (const int*)inv_d.p, nl, h->d_ainv);
+        else hipLaunchKernelGGL(gmgs::permute_symmetric_scatter, dim3(nl), dim3(256), 0, h->stream, (const double*)X.p, (const int*)perm_d.p, nl, h->d_ainv);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));        // (the temporaries above go back to the pool; the host copy E dies here)
+    if (nl > 0) { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->timing["coarse_inverse_tiles_ms"] = ms; }
+    h->timing["coarse_inverse_ms"] = ms_since(t0);
+    h->timing["coarse_inverse_levels"] = E.nlev;
+    h->timing["coarse_inverse_chunks"] = E.nq;
+    return GMG_OK;
 }
 
 // gmg_set_system for a matrix with the sparsity pattern of the live system: values only.  Returns 1 when it cannot be
@@ -404,12 +469,10 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     }
     h->timing["reduction"] = ms_since(t0);
     double ms_factor = 0;
-    std::vector<double> inv;
     std::future<bool> factor_done = std::async(std::launch::async, [&] {
         auto t = clk::now();
         bool ok = h->coarse.factor(h->lv[L].A, true);
         h->coarse_warm = false;
-        if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) coarse_inverse(h, inv);
         ms_factor = ms_since(t);
         return ok;
     });
@@ -432,10 +495,9 @@ static int refresh_system_values(gmg_handle h, int n, const double* val, clk::ti
     if (herr == 2) return fail(h, GMG_ERR_NUMERIC, "system matrix has a missing or zero diagonal entry");
     if (herr != 0) { h->refill_ready = false; return fail(h, GMG_ERR_STATE, "value refresh failed on the device"); }
     if (!factor_ok) return fail(h, GMG_ERR_NUMERIC, "coarsest operator is singular (LDL^T hit a zero pivot)");
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
-        if ((rc = upload(h, &h->d_ainv, inv))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
+    h->coarse_device = want_coarse_device(h, h->lv[L].A.n_outer);
+    h->timing["coarse_on_device"] = h->coarse_device ? 1.0 : 0.0;
+    if (h->coarse_device && (rc = build_coarse_inverse_device(h))) return rc;
     if (h->cfg.inner_precision && (rc = refresh_fp32_twins(h, false))) return rc;
     if (!h->mass.empty() && (h->mass_dirty || !h->d_mass)) {          // a mass set while only the placeholder structure stood (prepare_structure)
         if ((int)h->mass.size() != n) return fail(h, GMG_ERR_INVALID, "mass size does not match the system");
@@ -580,7 +642,10 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     }
     // (the resident values were overwritten ahead of the verdict and the pattern turned out to be another one: the live system is gone -- the
     // full path below drops it anyway; a failure on the way must not leave a system that solves with foreign values)
-    if (speculative_upload) { h->system_ready = false; h->placeholder_ready = false; }
+    if (speculative_upload) {
+        h->system_ready = false; h->placeholder_ready = false;
+        if (spec_done && rc_spec != GMG_OK) h->err.clear();      // (the refresh ran on a matrix of another pattern: its complaint is about that combination, not about this call)
+    }
     if (live && h->live_key_valid && (int)h->lv.size() == L + 1) {
         h->ord_cache.resize(L + 1);
         for (int k = 0; k <= L; ++k) h->ord_cache[k] = std::move(h->lv[k].ord);
@@ -625,7 +690,6 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     std::vector<std::shared_future<void>> ord_done(L + 1);
     std::vector<std::future<void>> op_done(L), tr_done(L);
     std::future<bool> factor_done;
-    std::vector<double> inv;        // dense A_L^{-1} (device coarse mode)
     double ms_factor = 0;
     // Host copy of the LHS (kept for gmg_get_level_operator, the level-0 ordering and the host fallbacks): 250 MB at
     // 3 M vertices, made in the background while the device works from the caller's arrays.
@@ -828,7 +892,6 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         auto t = clk::now();
         bool ok = h->coarse.factor(h->lv[L].A, ord_hit);
         h->coarse_warm = false;
-        if (ok && h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) coarse_inverse(h, inv);
         ms_factor = ms_since(t);
         return ok;
     });
@@ -979,10 +1042,11 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             h->partial_blocks = nblk;
         }
     }
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
-        int rc;
-        if ((rc = upload(h, &h->d_ainv, inv))) return rc;
-        HIPCHK(hipStreamSynchronize(h->stream));
+    h->coarse_device = want_coarse_device(h, h->lv[L].A.n_outer);
+    h->timing["coarse_on_device"] = h->coarse_device ? 1.0 : 0.0;
+    if (h->coarse_device) {
+        int rc = build_coarse_inverse_device(h);
+        if (rc) return rc;
     }
     if (h->cfg.inner_precision) {
         // fp32 twins of every value array (same layout): the inner V-cycle of the mixed-precision iteration
@@ -1324,7 +1388,7 @@ int gmg_coarse_solve(gmg_handle h, const double* rc_in, int d, double* e) try {
     if ((rc = ensure_vectors(h, d))) return rc;
     Level& c = h->lv[h->L];
     if ((rc = to_device(h, h->L, rc_in, d, c.b))) return rc;
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
+    if (h->coarse_device) enqueue_coarse_device<double>(h, d);
     else if ((rc = coarse_host_roundtrip<double>(h, d))) return rc;
     h->loaded_d = 0;
     return to_host(h, h->L, c.x, d, e);
@@ -1588,8 +1652,9 @@ int dist_ready(gmg_handle h) {
 }
 }  // namespace
 
-// One colour of one Gauss-Seidel sweep on this rank's rows of level 0.
-int gmg_dist_smooth_color(gmg_handle h, int c) try {
+// One colour of one Gauss-Seidel sweep on this rank's rows of level 0.  plain_rows (hybrid smoother, engine_dist.hip.hpp::p2p_smooth): one 64-bit word per
+// slice, bit set = the row takes omega = 1.
+static int dist_smooth_color_impl(gmg_handle h, int c, const unsigned long long* plain_rows) {
     NEED_DEVICE();
     int rc = dist_ready(h);
     if (rc) return rc;
@@ -1601,7 +1666,15 @@ int gmg_dist_smooth_color(gmg_handle h, int c) try {
     if (se > sb)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
-            if (l.Aoff.c16_mode != 0) {       // (c16_sel: a rank whose share of the fine operators fits its memory-side cache reads them with ordinary loads)
+            if (l.Aoff.c16_mode != 0 && plain_rows) {
+                DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color<double, D, C16 + 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+                                                  l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega,
+                                                  l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), plain_rows)));
+            } else if (plain_rows) {
+                DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<double, D, 1, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
+                                                  l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega,
+                                                  (const unsigned*)nullptr, (const int*)nullptr, 0, plain_rows));
+            } else if (l.Aoff.c16_mode != 0) {       // (c16_sel: a rank whose share of the fine operators fits its memory-side cache reads them with ordinary loads)
                 DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color<double, D, C16 + 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream, l.Aoff.slice_ptr,
                                                   l.Aoff.col, l.Aoff.val, l.diag, l.b + (size_t)c0 * ld, l.x + (size_t)c0 * ld, ld, sb, se, 1, h->cfg.gs_omega,
                                                   l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
@@ -1611,7 +1684,8 @@ int gmg_dist_smooth_color(gmg_handle h, int c) try {
             }
         }
     return GMG_OK;
-} GMG_CATCH_H
+}
+int gmg_dist_smooth_color(gmg_handle h, int c) try { return dist_smooth_color_impl(h, c, nullptr); } GMG_CATCH_H
 
 // r0[own rows] = b0 - A x0
 int gmg_dist_residual_own(gmg_handle h) try {
@@ -1642,7 +1716,7 @@ static int dist_coarse_cycle_enqueue(gmg_handle h) {
     const int d = h->loaded_d;
     launch_restrict<double>(h, h->lv[0], h->lv[1], d, h->lv[0].r, h->lv[1].b);
     enqueue_down<double>(h, d, 1);
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
+    if (h->coarse_device) enqueue_coarse_device<double>(h, d);
     else if ((rc = coarse_host_begin<double>(h, d))) return rc;
     enqueue_up<double>(h, d, 1);
     return GMG_OK;
@@ -1696,7 +1770,7 @@ static int dist_norm_launch(gmg_handle h, int type) {
                                               h->d_partials + (size_t)c * nblk * 2 * dc));
         }
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk * nc, 2 * dc, h->d_norm + 2 * c0,
-                           (unsigned long long*)nullptr, 0ull);
+                           (unsigned long long*)nullptr, 0ull, 0);
     }
     return GMG_OK;
 }

@@ -282,7 +282,7 @@ void launch_spmv_lpr(gmg_handle h, Level& l, int d, int mode, const T* b, const 
                                                   l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld, x + (size_t)c0 * ld,
                                                   y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
             } else {
-                DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_mode, hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, 1, C16>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
+                DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::spmv_full<T, D, 0, 1, C16>), dim3(grid_for(n_slices)), dim3(gmgk::kBlock), 0, h->stream,
                                                   l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), (const T*)nullptr, x + (size_t)c0 * ld,
                                                   y + (size_t)c0 * ld, ld, 0, n_slices, 1, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
             }
@@ -383,10 +383,10 @@ int wait_norm(gmg_handle h) {
 void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
     if (polled(h))
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->h_norm + 2 * c0,
-                           last ? h->h_flag : nullptr, last ? ++h->flag_seq[0] : 0ull);
+                           last ? h->h_flag : nullptr, last ? ++h->flag_seq[0] : 0ull, (int)EnvSwitches::get().publish_fenced);
     else
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0,
-                           (unsigned long long*)nullptr, 0ull);
+                           (unsigned long long*)nullptr, 0ull, 0);
 }
 
 // sums of w r^2 / w b^2 per column -> h_norm[2*d] (after wait_norm)
@@ -685,7 +685,7 @@ struct HelperScope {
         const int share = cpu_budget() / ranks;
         int threads = std::min(std::min(h->coarse.parts() * std::max(1, std::min(cols, 4)), 8), share - 1);
         if (env_threads > 0) threads = std::min(threads, env_threads);
-        if (h->cfg.coarse_mode != GMG_COARSE_HOST_LDLT || threads < 2) { h = nullptr; return; }
+        if (h->coarse_device || threads < 2) { h = nullptr; return; }
         if (!h->coarse_helper || h->coarse_helper->helpers() != threads - 1) h->coarse_helper.reset(new SpinTeam(threads - 1));
         h->coarse_helper->stay_near_caller();
         h->coarse_helper->arm();
@@ -728,7 +728,7 @@ int coarse_host_begin(gmg_handle h, int d) {
     double* e = h->h_pinned + cnt;
     if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);          // tiny (n_L doubles): convert on the device, ship fp64
     if (polled(h)) {
-        hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1]);
+        hipLaunchKernelGGL(gmgk::publish_to_host, dim3(1), dim3(gmgk::kBlock), 0, h->stream, c.b, rc, (int)cnt, h->h_flag + 8, ++h->flag_seq[1], (int)EnvSwitches::get().publish_fenced);
         const bool gate_off = h->cfg.stream_gate == 0;      // gmg_config::stream_gate
         // The gate is only used once this handle has SEEN a published right-hand side arrive while its stream was still busy: wait_flag's
         // safety net (an idle stream implies visible data) cannot fire behind a gate the host itself has to open, so on a host that does
@@ -832,7 +832,7 @@ int vcycle_legs(gmg_handle h, int d, int norm_type, int key_salt) {
         } else if (norm_type >= 0) err = launch_norm(h, d, norm_type);
         prof_mark(h);
     };
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) {
+    if (h->coarse_device) {
         int err = GMG_OK;
         rc = run_graph(h, key_salt + G_FULL * 10000 + d * 10 + nt, [&] {
             head();

@@ -30,6 +30,7 @@ struct gmg_p2p_blob {                                     // what a rank publish
     hipIpcMemHandle_t mbox, flags, coll;                  // coll: the gathered buffer of the emulated collective (dist_exchange = 2), else zero
     int rank, world, d, n_pad, n_colors, reserved;
     long long mbox_doubles, coll_doubles;
+    char device_uuid[16];                                 // hipDeviceGetUuid of the rank's device: two ranks on one device are refused at connect time
 };
 
 // Collective exchange backend (gmg_config::dist_exchange = 1 / 2): every exchange of the cycle as pack -> all-gather -> unpack on the engine's
@@ -61,6 +62,8 @@ struct DistP2P {
     bool shard1 = false;
     bool hybrid = false;                                  // gmg_p2p_set_smoother: Gauss-Seidel inside a rank, Jacobi across ranks (one exchange per sweep)
     bool fold = false;                                    // gmg_p2p_set_smoother(2): the exchange of a colour folded into its sweep launch (gmgk::gs_color_push)
+    bool fenced = true;                                   // gmg_p2p_set_fences: release / acquire fences around the sequence words (kernels.hip.hpp::publish_order)
+    unsigned long long* d_plain_rows = nullptr;           // hybrid smoother: one word per level-0 slice, bit = the row couples to another rank's rows (takes omega = 1)
     int* d_pub = nullptr;                                 // per colour: pub_ptr (own slices + 1), then pub_ent (int2), gmgk::PushTail
     std::vector<size_t> pub_ptr_at, pub_ent_at;           // [colour]: offsets (ints) in d_pub
     std::vector<int> pub_waves;                           // [colour]: own slices with a published row
@@ -111,6 +114,7 @@ void p2p_release(gmg_handle h) {
     if (p->d_sums) (void)sync_hipFree(p->d_sums);
     if (p->d_l1) (void)sync_hipFree(p->d_l1);
     if (p->d_pub) (void)sync_hipFree(p->d_pub);
+    if (p->d_plain_rows) (void)sync_hipFree(p->d_plain_rows);
     CollBackend& cb = p->coll;
     for (void* q : cb.peer_recv) if (q) (void)hipIpcCloseMemHandle(q);
     if (cb.comm && cb.comm_destroy) (void)cb.comm_destroy(cb.comm);
@@ -134,7 +138,7 @@ int coll_all_gather(gmg_handle h, int kind, int parity) {
     // emulated: one launch -- per peer, blocks store this rank's chunk into the peer's gathered buffer and publish the sequence number; per
     // peer, a block waits for that peer's number (gmgk::p2p_exchange on contiguous ops with nothing to copy on the pull side)
     const int B = (int)std::min<long long>(64, std::max<long long>(1, (chunk + 4095) / 4096));
-    hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np * B), dim3(256), 0, h->stream, cb.d_ops + (size_t)(kind * 2 + parity) * np, np, cb.send, 0, 1, p->seq, p->d_err, B, p->d_done);
+    hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np * B), dim3(256), 0, h->stream, cb.d_ops + (size_t)(kind * 2 + parity) * np, np, cb.send, 0, 1, p->seq, p->d_err, B, p->d_done, p->fenced ? 1 : 0);
     return GMG_OK;
 }
 
@@ -165,7 +169,7 @@ int coll_exchange(gmg_handle h, int kind, double* vec, int ld) {
 // One exchange of kind `kind` on vector `vec` (leading dimension ld) -- or nothing with a single rank.
 int p2p_exchange(gmg_handle h, int kind, double* vec, int ld) {
     DistP2P* p = h->p2p;
-    if (p->world > 1 && p->coll.mode != 0) return coll_exchange(h, kind, vec, ld);
+    if (p->coll.mode != 0) return coll_exchange(h, kind, vec, ld);
     const int np = (int)p->peers.size();
     if (np == 0) return GMG_OK;
     const int parity = (int)(p->kind_count[kind]++ & 1);
@@ -173,7 +177,7 @@ int p2p_exchange(gmg_handle h, int kind, double* vec, int ld) {
     const int B = p->kind_blocks[kind];
     ++p->exchange_launches;
     hipLaunchKernelGGL(gmgk::p2p_exchange, dim3(2 * np * B), dim3(256), 0, h->stream, p->d_ops + (size_t)(kind * 2 + parity) * np, np, vec, ld, p->d,
-                       p->seq, p->d_err, B, p->d_done);
+                       p->seq, p->d_err, B, p->d_done, p->fenced ? 1 : 0);
     return GMG_OK;
 }
 
@@ -195,7 +199,7 @@ bool p2p_smooth_color_folded(gmg_handle h, int c) {
     pt.ops = p->d_ops + (size_t)(c * 2 + parity) * np;
     pt.n_peers = np; pt.n_pub_waves = p->pub_waves[c];
     pt.done = p->d_done + p->world;
-    pt.seq = p->seq; pt.err = p->d_err;
+    pt.seq = p->seq; pt.err = p->d_err; pt.fenced = p->fenced ? 1 : 0;
     const int ld = l.n_pad;
     const dim3 grid(grid_for(se - sb)), block(gmgk::kBlock);
     if (l.Aoff.c16_mode != 0) {
@@ -220,7 +224,9 @@ const std::vector<int>* p2p_list(const DistP2P* p, int C, int s, int t, int k) {
 int coll_build(gmg_handle h) {
     DistP2P* p = h->p2p;
     CollBackend& cb = p->coll;
-    cb.mode = p->world > 1 ? h->cfg.dist_exchange : 0;
+    // (RCCL takes a communicator of one rank: dist_exchange = 1 on a single rank runs every exchange of the cycle through the real library --
+    // dlopen, ncclCommInitRank, ncclAllGather on the engine's stream; the emulation needs a peer to store into)
+    cb.mode = (p->world > 1 || h->cfg.dist_exchange == 1) ? h->cfg.dist_exchange : 0;
     if (cb.mode == 0) return GMG_OK;
     const int world = p->world, rank = p->rank, d = p->d, nk = p->nk, C = h->lv[0].ord.n_colors;
     const LevelOrdering& o = h->lv[0].ord;
@@ -265,6 +271,7 @@ int coll_build(gmg_handle h) {
                 most = std::max(most, tot);
             }
         cb.chunk[k] = up8(most);
+        if (cb.mode == 1) cb.chunk[k] = std::max<long long>(cb.chunk[k], 8);      // (no zero-count ncclAllGather: a kind without payload still is one collective on every rank)
         cb.max_chunk = std::max(cb.max_chunk, cb.chunk[k]);
     }
     cb.max_chunk = std::max<long long>(cb.max_chunk, 8);
@@ -372,6 +379,7 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     unbind_level0(h);
     DistP2P* p = h->p2p = new DistP2P();
     p->rank = rank; p->world = world; p->d = d;
+    p->fenced = !EnvSwitches::get().p2p_fence_free;
     Level& l = h->lv[0];
     const LevelOrdering& o = l.ord;
     const int C = o.n_colors;
@@ -399,6 +407,17 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     p->shard1 = plan->shard1;
     p->halo = plan->halo; p->halo1 = plan->halo1; p->halo0r = plan->halo0r;
     p->blk_owner = plan->blk_owner; p->own_blocks = plan->own_blocks;
+    {   // rows of this rank that read another rank's rows = (the pattern is symmetric) the rows it publishes: they take the plain Gauss-Seidel
+        // update in the hybrid smoother, whose coupling across ranks is a Jacobi one (gmgk::gs_color<..., OM = 1>)
+        std::vector<unsigned long long> words((size_t)l.n_pad / 64, 0ull);
+        double cnt = 0;
+        for (int t = 0; t < world; ++t)
+            if (t != rank)
+                for (int row : p->halo[((size_t)rank * world + t) * (C + 1) + C]) { unsigned long long& w = words[(size_t)row >> 6]; const unsigned long long bit = 1ull << (row & 63); cnt += !(w & bit); w |= bit; }
+        HIPCHK(hipMalloc((void**)&p->d_plain_rows, sizeof(unsigned long long) * std::max<size_t>(words.size(), 1)));
+        if (!words.empty()) HIPCHK(hipMemcpy(p->d_plain_rows, words.data(), sizeof(unsigned long long) * words.size(), hipMemcpyHostToDevice));
+        p->stats["boundary_rows"] = cnt;
+    }
     if (p->shard1) {
         // this rank's launch tables
         Level& l1 = h->lv[1];
@@ -470,6 +489,13 @@ int gmg_p2p_export(gmg_handle h, void* blob_out) try {
     b.rank = p->rank; b.world = p->world; b.d = p->d; b.n_pad = h->lv[0].n_pad; b.n_colors = h->lv[0].ord.n_colors; b.mbox_doubles = p->box_total[p->rank];
     b.reserved = (p->shard1 ? 1 : 0) | (p->coll.mode << 4);
     if (p->coll.mode == 2) { HIPCHK(hipIpcGetMemHandle(&b.coll, p->coll.recv)); b.coll_doubles = 2LL * p->world * p->coll.max_chunk; }
+    {
+        hipUUID id;
+        std::memset(&id, 0, sizeof(id));
+        if (hipDeviceGetUuid(&id, h->cfg.device) != hipSuccess) { (void)hipGetLastError(); std::memset(&id, 0, sizeof(id)); }
+        static_assert(sizeof(id.bytes) == sizeof(b.device_uuid), "hipUUID is 16 bytes");
+        std::memcpy(b.device_uuid, id.bytes, sizeof(b.device_uuid));
+    }
     std::memcpy(blob_out, &b, sizeof(b));
     return GMG_OK;
 } GMG_CATCH_H
@@ -495,6 +521,16 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     p->coll.peer_recv.clear();
     p->connected = false;
     if (p->coll.mode == 1) return fail(h, GMG_ERR_STATE, "this handle exchanges through RCCL (gmg_config::dist_exchange = 1): connect it with gmg_p2p_connect_rccl");
+    // one device per rank: the exchange kernels of ranks that share a device wait for each other ON that device (2.5 ms per cycle with four
+    // ranks on one GPU, half a second with eight) -- refused unless the caller says it is meant (GMG_P2P_SHARED_DEVICE=1: functional tests)
+    if (!EnvSwitches::get().p2p_shared_device) {
+        const char zero[16] = {0};
+        for (int a = 0; a < world; ++a)
+            for (int b = a + 1; b < world; ++b)
+                if (std::memcmp(bl[a].device_uuid, zero, 16) != 0 && std::memcmp(bl[a].device_uuid, bl[b].device_uuid, 16) == 0)
+                    return fail(h, GMG_ERR_STATE, "ranks " + std::to_string(a) + " and " + std::to_string(b) + " are on the same device (same UUID): one device per rank "
+                                "(check HIP_VISIBLE_DEVICES / LOCAL_RANK); GMG_P2P_SHARED_DEVICE=1 allows it for functional tests");
+    }
     {   // peer access to every other visible device (the IPC mapping below enables it lazily as well; "already enabled" and "not
         // supported" are both fine here -- an unreachable peer shows up in hipIpcOpenMemHandle)
         int ndev = 0;
@@ -680,8 +716,11 @@ int gmg_p2p_connect_rccl(gmg_handle h, const void* id_in) try {
     NEED_DEVICE();
     DistP2P* p = h->p2p;
     if (!p || !p->planned || !id_in) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare first");
-    if (p->world > 1 && p->coll.mode != 1) return fail(h, GMG_ERR_STATE, "create the handle with gmg_config::dist_exchange = 1 to exchange through RCCL");
-    if (p->world <= 1) { p->connected = true; return GMG_OK; }
+    if (p->coll.mode != 1) {
+        if (p->world > 1) return fail(h, GMG_ERR_STATE, "create the handle with gmg_config::dist_exchange = 1 to exchange through RCCL");
+        p->connected = true;                                                // one rank without the collective backend: nothing to connect
+        return GMG_OK;
+    }
     RcclApi& api = rccl_api();
     if (!api.ok()) return fail(h, GMG_ERR_UNSUPPORTED, "librccl could not be loaded (ncclGetUniqueId / ncclCommInitRank / ncclAllGather)");
     HIPCHK(hipSetDevice(h->cfg.device));
@@ -727,7 +766,7 @@ int p2p_smooth(gmg_handle h, int iters) {
     for (int it = 0; it < iters; ++it) {
         for (int c = 0; c < l.ord.n_colors; ++c) {
             if (p2p_smooth_color_folded(h, c)) continue;
-            if ((rc = gmg_dist_smooth_color(h, c))) return rc;
+            if ((rc = dist_smooth_color_impl(h, c, hybrid ? h->p2p->d_plain_rows : nullptr))) return rc;
             if (!hybrid && (rc = p2p_exchange(h, c, l.x, l.n_pad))) return rc;
         }
         if (hybrid && (rc = p2p_exchange(h, l.ord.n_colors, l.x, l.n_pad))) return rc;
@@ -801,7 +840,7 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
     if ((rc = p2p_exchange(h, C + 4, l1.r, l1.n_pad))) return rc;                      // everybody's rows -> complete r1 on every rank
     launch_restrict<double>(h, l1, h->lv[2], d, l1.r, h->lv[2].b);                      // :1069, replicated from here down
     enqueue_down<double>(h, d, 2);
-    if (h->cfg.coarse_mode == GMG_COARSE_DEVICE_INVERSE) enqueue_coarse_device<double>(h, d);
+    if (h->coarse_device) enqueue_coarse_device<double>(h, d);
     else if ((rc = coarse_host_begin<double>(h, d))) return rc;       // the host half is served at the end of the cycle's enqueue (p2p_vcycle)
     enqueue_up<double>(h, d, 2);
     for (int c0 = 0; c0 < d && p->n_psl > 0; c0 += 4) {                               // :1082 into my rows of level 1
@@ -871,7 +910,7 @@ int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
         double sums[8];
         if ((rc = dist_norm_launch(h, stop_type))) return rc;                // this rank's rows -> h->d_norm
         const double* d_result = h->d_norm;
-        if (p->world > 1 && p->coll.mode != 0) {
+        if (p->coll.mode != 0) {
             // collective backend: every rank's 2 d sums all-gathered, then added in rank order (the same bits everywhere)
             CollBackend& cb = p->coll;
             const int kind = C + 2, parity = (int)(cb.count++ & 1);
@@ -994,8 +1033,41 @@ int gmg_p2p_set_smoother(gmg_handle h, int hybrid) try {
     return GMG_OK;
 } GMG_CATCH_H
 
+// Test hook (include/gravomg_hip_internal.h): one exchange of every rank's level-0 rows of x through the collective backend, then the gathered
+// buffer's slot of THIS rank against what it packed -- what ncclAllGather delivered, seen from the host.
+int gmg_p2p_debug_collective_roundtrip(gmg_handle h, double* max_abs_diff, long long* doubles) try {
+    NEED_DEVICE();
+    DistP2P* p = h->p2p;
+    if (!p || !p->connected || !h->bound || !max_abs_diff || !doubles) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
+    CollBackend& cb = p->coll;
+    if (cb.mode == 0) return fail(h, GMG_ERR_STATE, "this handle has no collective backend (gmg_config::dist_exchange)");
+    Level& l = h->lv[0];
+    const int kind = l.ord.n_colors + 1;
+    const int parity = (int)(cb.count & 1);                               // the half coll_exchange is about to use
+    int rc = coll_exchange(h, kind, l.x, l.n_pad);
+    if (rc) return rc;
+    const long long n = (long long)(l.n_pad / p->world) * p->d;
+    std::vector<double> sent((size_t)n), got((size_t)n);
+    HIPCHK(hipMemcpyAsync(sent.data(), cb.send, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(got.data(), cb.recv + ((size_t)parity * p->world + p->rank) * cb.max_chunk, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double worst = 0.0;
+    for (long long i = 0; i < n; ++i) worst = std::max(worst, std::fabs(sent[(size_t)i] - got[(size_t)i]));
+    *max_abs_diff = worst; *doubles = n;
+    return GMG_OK;
+} GMG_CATCH_H
+
+int gmg_p2p_set_fences(gmg_handle h, int fenced) try {
+    if (!h || !h->p2p) return h ? fail(h, GMG_ERR_STATE, "no distributed plan (gmg_p2p_prepare)") : GMG_ERR_INVALID;
+    h->p2p->fenced = fenced != 0;
+    return GMG_OK;
+} GMG_CATCH_H
+
 int gmg_p2p_stat(gmg_handle h, const char* key, double* out) try {
     if (!h || !h->p2p || !key || !out) return GMG_ERR_INVALID;
+    if (std::string(key) == "fenced") { *out = h->p2p->fenced ? 1.0 : 0.0; return GMG_OK; }
+    if (std::string(key) == "collective_mode") { *out = (double)h->p2p->coll.mode; return GMG_OK; }
+    if (std::string(key) == "collective_exchanges") { *out = (double)h->p2p->coll.count; return GMG_OK; }
     if (std::string(key) == "device_bytes") { *out = (double)h->pool.live_bytes; return GMG_OK; }      // device memory this rank's handle holds (pool blocks in use)
     if (std::string(key) == "exchange_launches") { *out = (double)h->p2p->exchange_launches; return GMG_OK; }      // launches spent on exchanges so far (the folded colour exchanges: none)
     if (std::string(key) == "device_bytes_peak") { *out = (double)h->pool.peak_live_bytes; return GMG_OK; }      // ... and its high-water mark since the last gmg_set_system began

@@ -251,7 +251,9 @@ struct gmg_solver_s {
     double coarse_warm_sink = 0.0;
     int coarse_pending_d = 0;
     bool poll = true;             // GMG_POLL=0: copy + hipStreamSynchronize instead (the waiting thread then sleeps instead of spinning)
-    double* d_ainv = nullptr;                              // GMG_COARSE_DEVICE_INVERSE
+    double* d_ainv = nullptr;                              // coarse_device: dense A_L^-1, level numbering (engine.hip::build_coarse_inverse_device)
+    int ainv_n = 0;
+    bool coarse_device = false;                            // the coarsest solve of the live system runs on the device (gmg_config::coarse_mode, decided per system)
     std::vector<double> coarse_work;
     std::unique_ptr<SpinTeam> coarse_helper;        // the other threads of the coarsest back-substitution, armed for the duration of a solve (HelperScope)
     std::map<std::string, double> timing;
@@ -582,6 +584,7 @@ void drop_system(gmg_handle h) {
     if (h->d_mass) { (void)dev_free(h->d_mass); h->d_mass = nullptr; }
     if (h->d_minv) { (void)dev_free(h->d_minv); h->d_minv = nullptr; }
     if (h->d_ainv) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
+    h->ainv_n = 0;
 }
 
 // blocked levels smaller than this use 4 lanes per row (measured in round 4, profiles/r04/d_quad_threshold_ab.txt)

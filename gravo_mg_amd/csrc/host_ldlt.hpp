@@ -704,6 +704,116 @@ public:
         out[5] = (double)(groups_ - parts_);
     }
 
+    // ---- the factor as the DEVICE reads it (engine.hip: the dense inverse of the coarsest operator is built on the GPU, setup_kernels.hip.hpp::
+    // coarse_inverse_tiles).  Supernodes are cut into CHUNKS of <= kChunk columns; a chunk's rows below its own columns are the later columns of
+    // its supernode followed by the supernode's row list, its values row-major, kChunk per row (zero padded), its diagonal block a padded
+    // kChunk x kChunk strictly lower triangle.  fdesc: first column of the subtree below the chunk's last column (the numbering is a postorder, a
+    // subtree is a run of columns): L^-1 e_c is nonzero only in chunks whose subtree holds c.  Levels of the way up: a chunk comes after every
+    // chunk that owns one of its rows (its ancestors); level 0 = the roots.  pattern: lists that depend on the structure only.
+    static constexpr int kChunk = 8;
+    struct DeviceFactor {
+        int n = 0, nq = 0, nlev = 0;
+        std::vector<int> q_col0, q_w, q_rptr, q_fdesc, rows, lev_ptr, lev_q, perm, first_q;      // first_q[c]: the chunk that holds column c
+        // the chunks a tile of `width` columns visits on the way down: the union of its columns' paths to the root, ascending
+        void tile_paths(int width, std::vector<int>& tile_ptr, std::vector<int>& tile_q) const {
+            const int nt = (n + width - 1) / width;
+            tile_ptr.assign((size_t)nt + 1, 0); tile_q.clear();
+            std::vector<int> mark((size_t)nq, -1);
+            for (int t = 0; t < nt; ++t) {
+                const size_t at = tile_q.size();
+                for (int c = t * width; c < std::min(n, (t + 1) * width); ++c)
+                    for (int q = first_q[(size_t)c]; q >= 0 && mark[(size_t)q] != t;) {
+                        mark[(size_t)q] = t; tile_q.push_back(q);
+                        q = q_rptr[q + 1] > q_rptr[q] ? first_q[(size_t)rows[(size_t)q_rptr[q]]] : -1;
+                    }
+                std::sort(tile_q.begin() + (long)at, tile_q.end());
+                tile_ptr[(size_t)t + 1] = (int)tile_q.size();
+            }
+        }
+        std::vector<double> vals, tri, dinv;
+    };
+    void export_device_factor(DeviceFactor& E) const {
+        E.n = n;
+        E.perm = perm;
+        E.q_col0.clear(); E.q_w.clear(); E.q_rptr.assign(1, 0); E.rows.clear();
+        E.first_q.assign((size_t)n, 0);
+        size_t n_rows = 0;
+        for (int s = 0; s < ns_; ++s) {
+            const int f = sn_first_[s], w = sn_first_[s + 1] - f, r = rows_ptr_[s + 1] - rows_ptr_[s];
+            for (int c0 = 0; c0 < w; c0 += kChunk) { const int wc = std::min(kChunk, w - c0); n_rows += (size_t)(w - c0 - wc) + r; }
+        }
+        E.rows.reserve(n_rows);
+        for (int s = 0; s < ns_; ++s) {
+            const int f = sn_first_[s], w = sn_first_[s + 1] - f, r = rows_ptr_[s + 1] - rows_ptr_[s];
+            const int* R = rows_.data() + rows_ptr_[s];
+            for (int c0 = 0; c0 < w; c0 += kChunk) {
+                const int wc = std::min(kChunk, w - c0), q = (int)E.q_col0.size();
+                E.q_col0.push_back(f + c0); E.q_w.push_back(wc);
+                for (int j = 0; j < wc; ++j) E.first_q[(size_t)f + c0 + j] = q;
+                for (int i = c0 + wc; i < w; ++i) E.rows.push_back(f + i);
+                for (int i = 0; i < r; ++i) E.rows.push_back(R[i]);
+                E.q_rptr.push_back((int)E.rows.size());
+            }
+        }
+        E.nq = (int)E.q_col0.size();
+        // values
+        E.vals.assign(E.rows.size() * kChunk, 0.0);
+        E.tri.assign((size_t)E.nq * kChunk * kChunk, 0.0);
+        E.dinv.resize((size_t)n);
+        for (int j = 0; j < n; ++j) E.dinv[j] = 1.0 / D_[j];
+        {
+            int q = 0;
+            for (int s = 0; s < ns_; ++s) {
+                const int f = sn_first_[s], w = sn_first_[s + 1] - f, r = rows_ptr_[s + 1] - rows_ptr_[s], ld = w + r;
+                const double* P = pan_.data() + pan_ptr_[s];
+                for (int c0 = 0; c0 < w; c0 += kChunk, ++q) {
+                    const int wc = std::min(kChunk, w - c0);
+                    double* T = E.tri.data() + (size_t)q * kChunk * kChunk;
+                    for (int jj = 0; jj < wc; ++jj)
+                        for (int ii = jj + 1; ii < wc; ++ii) T[ii * kChunk + jj] = P[(size_t)(c0 + jj) * ld + c0 + ii];
+                    double* V = E.vals.data() + (size_t)E.q_rptr[q] * kChunk;
+                    const int below = ld - (c0 + wc);                      // rows c0 + wc .. ld - 1 of the panel, in order
+                    for (int jj = 0; jj < wc; ++jj) {
+                        const double* col = P + (size_t)(c0 + jj) * ld + c0 + wc;
+                        for (int i = 0; i < below; ++i) V[(size_t)i * kChunk + jj] = col[i];
+                    }
+                }
+            }
+        }
+        // subtrees and levels (structure only)
+        std::vector<int> fd((size_t)n);
+        for (int j = 0; j < n; ++j) fd[j] = j;
+        E.q_fdesc.assign((size_t)E.nq, 0);
+        {   // parent of a column = its first row below the diagonal: the next column of its supernode, or the supernode's first row
+            for (int s = 0; s < ns_; ++s) {
+                const int f = sn_first_[s], l = sn_first_[s + 1] - 1;
+                for (int j = f; j < l; ++j) fd[j + 1] = std::min(fd[j + 1], fd[j]);
+                if (rows_ptr_[s + 1] > rows_ptr_[s]) { const int p = rows_[rows_ptr_[s]]; fd[p] = std::min(fd[p], fd[l]); }
+            }
+        }
+        std::vector<int> lvl((size_t)E.nq, 0);
+        int deepest = 0;
+        for (int q = E.nq - 1; q >= 0; --q) {
+            E.q_fdesc[q] = fd[(size_t)E.q_col0[q] + E.q_w[q] - 1];
+            int m = -1;
+            for (int i = E.q_rptr[q]; i < E.q_rptr[q + 1]; ++i) m = std::max(m, lvl[E.first_q[(size_t)E.rows[i]]]);
+            lvl[q] = m + 1;
+            deepest = std::max(deepest, lvl[q]);
+        }
+        E.nlev = E.nq ? deepest + 1 : 0;
+        E.lev_ptr.assign((size_t)E.nlev + 1, 0);
+        for (int q = 0; q < E.nq; ++q) E.lev_ptr[(size_t)lvl[q] + 1]++;
+        for (int v = 0; v < E.nlev; ++v) E.lev_ptr[v + 1] += E.lev_ptr[v];
+        E.lev_q.resize((size_t)E.nq);
+        {   // within a level: the chunks with the most rows first (the waves of a tile take them round robin)
+            std::vector<int> fill(E.lev_ptr.begin(), E.lev_ptr.end() - (E.nlev ? 1 : 0));
+            for (int q = 0; q < E.nq; ++q) E.lev_q[(size_t)fill[lvl[q]]++] = q;
+            for (int v = 0; v < E.nlev; ++v)
+                std::stable_sort(E.lev_q.begin() + E.lev_ptr[v], E.lev_q.begin() + E.lev_ptr[v + 1],
+                                 [&](int a, int b2) { return E.q_rptr[a + 1] - E.q_rptr[a] > E.q_rptr[b2 + 1] - E.q_rptr[b2]; });
+        }
+    }
+
 private:
     static constexpr int kMaxWidth = 48;        // columns per supernode (panel stays in L1/L2)
     bool symbolic_ready_ = false;

@@ -87,11 +87,16 @@ struct Compressed {
 //   GMG_POLL=0              wait for device results with copy + hipStreamSynchronize instead of polling pinned memory
 //   GMG_P2P_TIMEOUT_S=S     device-side time-out of a peer-to-peer exchange (default 4 s)
 //   GMG_SEGV_BACKTRACE=1    native stack of a fatal signal on stderr (installed at load time, engine.hip)
+//   GMG_P2P_FENCE_FREE=1    default of gmg_p2p_set_fences for new plans: 0 = the fence-free gfx942 / gfx950 publication (kernels.hip.hpp::publish_order)
+//   GMG_PUBLISH_FENCED=1    device -> pinned host publications (residual sums, coarsest right-hand side) behind a system-scope release fence
+//   GMG_P2P_SHARED_DEVICE=1 gmg_p2p_connect accepts ranks that sit on the SAME device (functional tests on a one-GPU box; exchange kernels of
+//                           such ranks wait for each other on one device: milliseconds per exchange, never a measurement)
 // Everything else that used to be an A/B switch is either a gmg_config field or gone.
 struct EnvSwitches {
     int host_threads = 0, local_world = 0, ldlt_threads = 0;
     bool trace_setup = false, trace_ldlt = false, trace_ctor = false, poll = true, segv_backtrace = false;
     double p2p_timeout_s = 0.0;
+    bool p2p_fence_free = false, publish_fenced = false, p2p_shared_device = false;
     static const EnvSwitches& get() {
         static const EnvSwitches v = [] {
             EnvSwitches e;
@@ -103,6 +108,9 @@ struct EnvSwitches {
             e.poll = num("GMG_POLL") != 0.0;
             if (num("GMG_P2P_TIMEOUT_S") > 0) e.p2p_timeout_s = num("GMG_P2P_TIMEOUT_S");
             e.segv_backtrace = num("GMG_SEGV_BACKTRACE") > 0;
+            e.p2p_fence_free = num("GMG_P2P_FENCE_FREE") > 0;
+            e.publish_fenced = num("GMG_PUBLISH_FENCED") > 0;
+            e.p2p_shared_device = num("GMG_P2P_SHARED_DEVICE") > 0;
             return e;
         }();
         return v;

@@ -191,27 +191,39 @@ __device__ __forceinline__ void quad_reduce(T (&acc)[D]) {
 // Rows of one colour do not couple, so the parallel update equals the reference's sequential sweep in
 // the colour-permuted ordering.  omega != 1 relaxes the update (SOR, gmg_config::gs_omega).  FINE tags the level-0 instantiation so that profilers report the dominant
 // (fine-level) launches under their own kernel name.
-template <class T, int D, int FINE, int XI = 0>
+template <class T, int D, int FINE, int OM = 0>
 __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                                    const T* __restrict__ val, const T* __restrict__ diag,
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
                                                    int slice_end, int xcd_swizzle, T omega, const unsigned* __restrict__ col16 = nullptr,
-                                                   const int* __restrict__ win_base = nullptr, int c16_arg = 0) {
+                                                   const int* __restrict__ win_base = nullptr, int c16_arg = 0,
+                                                   const unsigned long long* __restrict__ plain_rows = nullptr) {
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
     const int row = s * 64 + lane;
     T acc[D];
-    row_dot_sel<T, D, (FINE >= 2 ? FINE - 1 : 0), DotGroup<D>::value, XI>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);      // FINE 2 / 3: level 0 with 16-bit column codes (row_dot_sel mode 1 / 2)
+    row_dot_sel<T, D, (FINE >= 2 ? FINE - 1 : 0)>(slice_ptr, col, col16, win_base, c16_arg, val, x, ld, s, lane, acc);      // FINE 2 / 3: level 0 with 16-bit column codes (row_dot_sel mode 1 / 2)
     const T dg = diag[row];
+    if constexpr (OM != 0) {
+        // hybrid Gauss-Seidel of a partitioned level 0 (engine_dist.hip.hpp::p2p_smooth): rows whose bit is set in plain_rows[slice] couple to rows of
+        // another rank, whose values are a sweep old -- a Jacobi coupling, which over-relaxation amplifies: those rows take the plain update
+        const T om = (plain_rows[s] >> lane) & 1ull ? (T)1.0 : omega;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const T xi = x[row + (int64_t)c * ld];
+            x[row + (int64_t)c * ld] = xi + om * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
+        }
+        return;
+    }
     if (omega == (T)1.0) {                 // kernel argument: a scalar branch.  The reference's update, no read of x_i
 #pragma unroll
-        for (int c = 0; c < D; ++c) x[x_at<D, XI>(row, c, ld)] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
+        for (int c = 0; c < D; ++c) x[row + (int64_t)c * ld] = (b[row + (int64_t)c * ld] - acc[c]) / dg;
     } else {                               // successive over-relaxation: x_i <- x_i + omega (x_i^GS - x_i)
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            const T xi = x[x_at<D, XI>(row, c, ld)];
-            x[x_at<D, XI>(row, c, ld)] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
+            const T xi = x[row + (int64_t)c * ld];
+            x[row + (int64_t)c * ld] = xi + omega * ((b[row + (int64_t)c * ld] - acc[c]) / dg - xi);
         }
     }
 }
@@ -1036,6 +1048,26 @@ __global__ __launch_bounds__(kBlock) void transfer_list(const int64_t* __restric
     transfer_slice<T, D, ADD, LPR>(slice_ptr, col, val, row_of, x, ldx, y, ldy, __builtin_amdgcn_readfirstlane(slices[i]));
 }
 
+// ---- publishing data to another agent (a peer GPU's mailbox, pinned host memory) behind a sequence word ------------------------------
+// Portable form (fenced != 0; the default of the multi-GPU entry points): a system-scope RELEASE fence between the data stores and the
+// store of the sequence word, a system-scope ACQUIRE fence after the poll that saw it -- the HIP memory model's publication idiom.
+// gfx942 / gfx950 form (fenced == 0; opt-in: gmg_p2p_set_fences / GMG_P2P_FENCE_FREE, GMG_PUBLISH_FENCE_FREE): every datum is a
+// system-scope (sc0 sc1, write-through) atomic store, so nothing of it sits dirty in an L2 that a release would have to write back
+// (buffer_wbl2 -- which also writes back the sweep's own dirty lines: ~3.5 us per exchange launch); `s_waitcnt vmcnt(0)` is the part of
+// the release sequence that orders the stores ahead of the word (the LLVM AMDGPU memory model for gfx940+: stores are counted in vmcnt
+// and complete at the memory side before it reaches zero; on gfx10+ they count in vscnt -- hence the architecture check); readers take
+// the data with system-scope atomic loads, which no cache serves.  Anything else than these two targets does not compile this form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "kernels.hip.hpp: the fence-free publication sequence (publish_order) relies on gfx942 / gfx950 store completion semantics"
+#endif
+__device__ __forceinline__ void publish_order(int fenced) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+}
+__device__ __forceinline__ void consume_order(int fenced) {
+    if (fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
 // out[c] = sum over blocks of partials[block][c], c < ncomp <= kReduceMaxComp.  One block of kReduceBlock threads, fixed order
 // (thread-strided sums, wave shuffles, then the 16 wave sums in index order): one pass over the partials and one barrier.
 constexpr int kReduceBlock = 1024;
@@ -1072,13 +1104,13 @@ __device__ __forceinline__ void block_reduce_partials(const double* __restrict__
 // that word instead of paying a copy kernel and a stream synchronisation per residual check.  (The sums are written by the
 // threads of wave 0; lane 0 of that wave releases them: one system-scope fence, not one per thread.)
 __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
-                                                                double* __restrict__ out, unsigned long long* flag, unsigned long long seq) {
+                                                                double* __restrict__ out, unsigned long long* flag, unsigned long long seq, int fenced) {
     __shared__ double red[kReduceBlock / 64][kReduceMaxComp];
     block_reduce_partials(partials, n_blocks, ncomp, out, red);
     if (flag && threadIdx.x < 64) {
         // the sums went out as write-through stores: drained, they are ahead of the sequence word (no system fence: that writes the L2 back and
-        // invalidates it, microseconds per residual check)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // invalidates it, microseconds per residual check; publish_order)
+        publish_order(fenced);
         if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -1124,7 +1156,7 @@ __device__ unsigned long long g_p2p_timeout_ticks = 400000000ull;
 // push block to finish (done[peer], device memory, zero between launches) publishes the sequence number; no block of this
 // launch waits for another block of it, only for the PEER's push.
 __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ ops, int n_peers, double* vec, int ld, int D,
-                                                    unsigned long long seq, int* err, int B, unsigned int* done) {
+                                                    unsigned long long seq, int* err, int B, unsigned int* done, int fenced) {
     const int part = blockIdx.x % B, j = (blockIdx.x / B) % n_peers;
     const bool push = (int)blockIdx.x < n_peers * B;
     const P2POp op = ops[j];
@@ -1139,15 +1171,20 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(op.remote_box + i), (unsigned long long)__double_as_longlong(vec[src + (int64_t)c * ld]),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish_order(fenced);
         __syncthreads();
         if (threadIdx.x == 0) {
             bool last = true;
             if (B > 1) {
-                last = __hip_atomic_fetch_add(done + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)B - 1;
+                // (fenced: the tickets carry the happens-before of the blocks that finished earlier to the one that publishes)
+                last = (fenced ? __hip_atomic_fetch_add(done + j, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                               : __hip_atomic_fetch_add(done + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == (unsigned)B - 1;
                 if (last) __hip_atomic_store(done + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (last) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (last) {
+                if (fenced) __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store(op.remote_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     } else {                                                          // ---- pull
         __shared__ int timed_out;
@@ -1161,6 +1198,7 @@ __global__ __launch_bounds__(256) void p2p_exchange(const P2POp* __restrict__ op
                 __builtin_amdgcn_s_sleep(4);
                 if (wall_clock64() - t0 > g_p2p_timeout_ticks) { timed_out = 1; atomicExch(err, 1); break; }
             }
+            consume_order(fenced);          // (relaxed while spinning, one acquire after the poll that saw the number)
         }
         __syncthreads();
         if (timed_out) return;
@@ -1192,6 +1230,7 @@ struct PushTail {
     unsigned int* done;             // publishing waves that have finished (device memory, zero between launches)
     unsigned long long seq;
     int* err;
+    int fenced;                     // publish_order / consume_order
 };
 
 template <int D, int FINE>
@@ -1235,9 +1274,10 @@ __global__ __launch_bounds__(kBlock) void gs_color_push(const int64_t* __restric
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the stores have arrived before this wave counts itself done
+            publish_order(pt.fenced);      // the stores have arrived before this wave counts itself done
             int last = 0;
-            if (lane == 0) last = __hip_atomic_fetch_add(pt.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)pt.n_pub_waves - 1u;
+            if (lane == 0) last = (pt.fenced ? __hip_atomic_fetch_add(pt.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+                                             : __hip_atomic_fetch_add(pt.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == (unsigned)pt.n_pub_waves - 1u;
             finish = __builtin_amdgcn_readfirstlane(last);
         }
     }
@@ -1245,7 +1285,10 @@ __global__ __launch_bounds__(kBlock) void gs_color_push(const int64_t* __restric
     // ---- exactly one wave of the launch: publish the sequence number, then pull
     if (lane == 0) __hip_atomic_store(pt.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // (every publishing wave drained its write-through stores before it took its ticket, and this wave drew the last one: the number may follow)
-    if (lane < pt.n_peers) __hip_atomic_store(pt.ops[lane].remote_flag, pt.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane < pt.n_peers) {
+        if (pt.fenced) __hip_atomic_store(pt.ops[lane].remote_flag, pt.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        else __hip_atomic_store(pt.ops[lane].remote_flag, pt.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     for (int j = 0; j < pt.n_peers; ++j) {
         const P2POp op = pt.ops[j];
         int timed_out = 0;
@@ -1260,6 +1303,7 @@ __global__ __launch_bounds__(kBlock) void gs_color_push(const int64_t* __restric
             }
         }
         if (__builtin_amdgcn_readfirstlane(timed_out)) return;
+        consume_order(pt.fenced);
         const int64_t total = (int64_t)op.n_recv * D;
         const unsigned long long* box = reinterpret_cast<const unsigned long long*>(op.local_box);
         // (one wave copies a few hundred values: eight independent system-scope loads per lane in flight, then the stores)
@@ -1372,10 +1416,10 @@ __global__ __launch_bounds__(64) void coll_sum_ranks(const double* __restrict__ 
 
 // n doubles -> host-visible pinned memory, then the sequence word (one block; the coarsest right-hand side)
 __global__ __launch_bounds__(kBlock) void publish_to_host(const double* __restrict__ src, double* __restrict__ dst, int n,
-                                                          unsigned long long* flag, unsigned long long seq) {
+                                                          unsigned long long* flag, unsigned long long seq, int fenced) {
     for (int i = threadIdx.x; i < n; i += kBlock)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + i), (unsigned long long)__double_as_longlong(src[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // write-through stores, drained: ahead of the sequence word without a system fence
+    publish_order(fenced);      // write-through stores, drained: ahead of the sequence word (fence-free form: without a system fence)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1535,8 +1579,9 @@ __global__ void permute_mass(const double* __restrict__ mass, const int* __restr
     minv[r] = 1.0 / v;
 }
 
-// Coarsest level, GMG_COARSE_DEVICE_INVERSE: e = Ainv * rc, Ainv dense symmetric n x n (ld = n), one wave
-// per row, lanes stride the row (coalesced), wave reduction.  x/y leading dimension ldv.
+// Coarsest level on the device (gmg_config::coarse_mode): e = A_L^-1 rc with the dense symmetric inverse, n x n (ld = n), level numbering (built by
+// setup_kernels.hip.hpp::coarse_inverse_tiles).  One wave per row, lanes stride the row (coalesced; the matrix is the traffic: 8 n^2 bytes per
+// application, streamed -- the vectors are a few KB and stay in the caches), wave reduction in a fixed order.  x/y leading dimension ldv.
 template <int D>
 __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ Ainv, int n, const double* __restrict__ x,
                                                      double* __restrict__ y, int ldv) {
@@ -1547,7 +1592,17 @@ __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ 
 #pragma unroll
     for (int c = 0; c < D; ++c) acc[c] = 0.0;
     const double* a = Ainv + (int64_t)row * n;
-    for (int j = lane; j < n; j += 64) {
+    int j = lane;
+    for (; j + 192 < n; j += 256) {                 // four independent matrix loads in flight per lane
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(a + j + 64 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] += v[u] * x[j + 64 * u + (int64_t)c * ldv];
+    }
+    for (; j < n; j += 64) {
         const double v = a[j];
 #pragma unroll
         for (int c = 0; c < D; ++c) acc[c] += v * x[j + (int64_t)c * ldv];

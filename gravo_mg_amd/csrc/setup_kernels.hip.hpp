@@ -757,4 +757,208 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
         if (mine[g] >= 0) { c_idx[out0 + g * 64 + lane] = mine[g]; c_val[out0 + g * 64 + lane] = acc[g]; }
 }
 
+// ---- dense inverse of the coarsest operator, built on the device from the host's sparse LDL^T factor --------------------------------
+// (multigrid_solver.cpp:1401 + :1075: the reference factors A_L once per solve() and back-substitutes once per cycle; GMG_COARSE_DEVICE_INVERSE
+// turns the per-cycle part into ONE dense symmetric matrix-vector product on the device -- no host round trip inside the cycle.)
+// X = A_L^-1 = P^T (L^-T D^-1 L^-1) P, stored in the FACTOR's numbering (the product kernel permutes the vectors): n right-hand sides e_c,
+// every one an independent pair of sparse triangular solves.  One workgroup owns a TILE of 64 columns c (one lane per column: a row of X
+// restricted to the tile is 512 contiguous bytes) and carries it through the whole factor:
+//   * down (L y = e_c): y is nonzero only at ancestors of c in the elimination tree, so only chunks whose subtree meets the tile are visited
+//     (q_fdesc); one wave walks them in ascending order -- push form: the chunk's own columns are finished in registers, then every row below
+//     receives its update (a lane only ever re-reads what it wrote itself: program order);
+//   * up (L^T x = D^-1 y), needed for rows j >= c only (the inverse is symmetric; the other triangle is mirrored afterwards): pull form by
+//     LEVELS of the elimination tree from the roots down, the chunks of a level dealt to the workgroup's waves, a barrier per level.
+// Every entry of X is produced by one lane with a fixed order of operations: the result is deterministic (ranks of a multi-GPU job that
+// replicate the coarsest level get the same bits).  Traffic: a tile reads sum(rows of the chunks) x 512 B per pass from its own 64-column slab,
+// which the L2 / memory-side cache serve; arithmetic nnz(L) x n fused multiply-adds in all -- microseconds of the chip's fp64 rate, which is why
+// the build is latency-bound (one dependent global round trip per level) and not a candidate for MFMA.
+struct InvFactor {
+    int n, nq, nlev;
+    const int *q_col0, *q_w, *q_rptr, *rows, *lev_ptr, *lev_q, *tile_ptr, *tile_q;
+    const double *vals, *tri, *dinv;
+};
+constexpr int kInvChunk = 8;            // = gmg::SupernodalLDLT::kChunk
+constexpr int kInvWaves = 16;
+constexpr int kInvThin = 16;            // a level with fewer chunks than this is shared chunk by chunk among all the waves of the workgroup
+
+// W = columns of a tile (16 / 32 / 64).  A wave covers W columns x S = 64 / W ROW SLOTS: lane = slot * W + column, so that one load instruction
+// fetches S different rows of the tile's slab (a small coarsest level has few tiles: the width is chosen so that there are enough workgroups,
+// and the slots keep all 64 lanes busy).  Way down: the chunks on the tile's paths to the root (tile_q, ascending), one after the other, every
+// wave pushing its share of the rows below.  Way up: level by level; a level with many chunks gives every wave its own chunks, a thin level (the
+// separator chains at the top of the tree: one or two chunks with hundreds of rows) is worked off chunk by chunk by ALL waves, their partial
+// sums added in wave order through LDS.  Every value has one fixed summation order: same bits on every device.
+template <int W>
+__global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor F, double* X) {
+    constexpr int S = 64 / W;
+    __shared__ double red[kInvWaves][kInvChunk][W];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cl = lane % W, slot = lane / W;
+    const int c0 = blockIdx.x * W, c = c0 + cl;
+    const bool valid = c < F.n;
+    const int64_t ld = F.n;
+    double* Xc = X + (valid ? c : 0);
+    // partial sums of the S slots -> every slot holds the total (fixed order: slot pairs (0,1)(2,3), then the two pairs)
+    auto slots_sum = [&](double v) {
+        if constexpr (S >= 2) v += __shfl_xor(v, W, 64);
+        if constexpr (S >= 4) v += __shfl_xor(v, 2 * W, 64);
+        return v;
+    };
+    if (wave == 0 && slot == 0 && valid) Xc[(int64_t)c * ld] = 1.0;
+    __syncthreads();
+    // ---- way down (L y = e_c, push form).  y of the previous chunk is stored by wave 0 only after the barrier that follows the other waves' loads of it
+    {
+        double y[kInvChunk];
+        int pcol0 = -1, pw = 0;
+        const int t0 = F.tile_ptr[blockIdx.x], t1 = F.tile_ptr[blockIdx.x + 1];
+        for (int t = t0; t <= t1; ++t) {
+            if (wave == 0 && slot == 0 && valid && pcol0 >= 0) {
+#pragma unroll
+                for (int jj = 1; jj < kInvChunk; ++jj) if (jj < pw) Xc[(int64_t)(pcol0 + jj) * ld] = y[jj];
+            }
+            if (t == t1) break;
+            const int q = F.tile_q[t];
+            const int col0 = F.q_col0[q], w = F.q_w[q];
+#pragma unroll
+            for (int jj = 0; jj < kInvChunk; ++jj) y[jj] = (jj < w && valid) ? Xc[(int64_t)(col0 + jj) * ld] : 0.0;
+            const double* T = F.tri + (int64_t)q * kInvChunk * kInvChunk;
+#pragma unroll
+            for (int jj = 0; jj < kInvChunk; ++jj)
+#pragma unroll
+                for (int ii = jj + 1; ii < kInvChunk; ++ii) y[ii] -= T[ii * kInvChunk + jj] * y[jj];
+            pcol0 = col0; pw = w;
+            const int r0 = F.q_rptr[q], r1 = F.q_rptr[q + 1];
+            // rows r0 + (wave * S + slot) + k * (kInvWaves * S): every (row, column) has exactly one lane; four rows in flight per lane
+            for (int i = r0 + wave * S + slot; i < r1; i += 4 * kInvWaves * S) {
+                double xv[4], acc[4];
+                int row[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int iu = i + u * kInvWaves * S;
+                    const bool in = iu < r1 && valid;
+                    row[u] = in ? F.rows[iu] : -1;
+                    xv[u] = in ? Xc[(int64_t)row[u] * ld] : 0.0;
+                    const double* V = F.vals + (int64_t)(iu < r1 ? iu : r0) * kInvChunk;
+                    acc[u] = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < kInvChunk; ++jj) acc[u] += V[jj] * y[jj];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (row[u] >= 0) Xc[(int64_t)row[u] * ld] = xv[u] - acc[u];
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- way up (L^T x = D^-1 y, pull form), rows >= c0 only
+    auto gather_rows = [&](int q, int first, int stride, double (&acc)[kInvChunk]) {
+        const int r0 = F.q_rptr[q], r1 = F.q_rptr[q + 1];
+        for (int i = r0 + first; i < r1; i += 4 * stride) {
+            double xi[4];
+            int iu[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { iu[u] = i + u * stride; xi[u] = (iu[u] < r1 && valid) ? Xc[(int64_t)F.rows[iu[u]] * ld] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double* V = F.vals + (int64_t)(iu[u] < r1 ? iu[u] : r0) * kInvChunk;
+#pragma unroll
+                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] -= V[jj] * xi[u];
+            }
+        }
+    };
+    auto finish_chunk = [&](int q, int col0, int w, double (&acc)[kInvChunk]) {        // acc: sums over the rows below; every slot holds them
+#pragma unroll
+        for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] += (jj < w && valid) ? Xc[(int64_t)(col0 + jj) * ld] * F.dinv[col0 + jj] : 0.0;
+        const double* T = F.tri + (int64_t)q * kInvChunk * kInvChunk;
+#pragma unroll
+        for (int jj = kInvChunk - 2; jj >= 0; --jj)
+#pragma unroll
+            for (int ii = jj + 1; ii < kInvChunk; ++ii) acc[jj] -= T[ii * kInvChunk + jj] * acc[ii];
+        if (slot == 0 && valid) {
+#pragma unroll
+            for (int jj = 0; jj < kInvChunk; ++jj) if (jj < w) Xc[(int64_t)(col0 + jj) * ld] = acc[jj];
+        }
+    };
+    for (int lev = 0; lev < F.nlev; ++lev) {
+        const int k0 = F.lev_ptr[lev], k1 = F.lev_ptr[lev + 1];
+        if (k1 - k0 >= kInvThin) {
+            for (int k = k0 + wave; k < k1; k += kInvWaves) {
+                const int q = F.lev_q[k];
+                const int col0 = F.q_col0[q], w = F.q_w[q];
+                if (col0 + w - 1 < c0) continue;
+                double acc[kInvChunk];
+#pragma unroll
+                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
+                gather_rows(q, slot, S, acc);
+#pragma unroll
+                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = slots_sum(acc[jj]);
+                finish_chunk(q, col0, w, acc);
+            }
+            __syncthreads();
+        } else {
+            for (int k = k0; k < k1; ++k) {
+                const int q = F.lev_q[k];
+                const int col0 = F.q_col0[q], w = F.q_w[q];
+                if (col0 + w - 1 < c0) continue;                                // (workgroup-uniform)
+                double acc[kInvChunk];
+#pragma unroll
+                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
+                gather_rows(q, wave * S + slot, kInvWaves * S, acc);
+#pragma unroll
+                for (int jj = 0; jj < kInvChunk; ++jj) { const double v = slots_sum(acc[jj]); if (slot == 0) red[wave][jj][cl] = v; }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < kInvChunk; ++jj) {
+                        double v = 0.0;
+#pragma unroll
+                        for (int wv = 0; wv < kInvWaves; ++wv) v += red[wv][jj][cl];
+                        acc[jj] = v;
+                    }
+                    finish_chunk(q, col0, w, acc);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// X[j][c] for j < c from X[c][j] (the tiles computed rows j >= c0 of their columns): 64 x 64 blocks through LDS, both sides coalesced.  A block on
+// the diagonal mirrors its own lower triangle.  grid: (nb, nb), nb = ceil(n / 64); blocks below the diagonal return.
+__global__ __launch_bounds__(256) void mirror_lower_to_upper(double* __restrict__ X, int n) {
+    const int bj = blockIdx.y, bc = blockIdx.x;           // writes block (row block bj, column block bc), bj <= bc, from block (bc, bj)
+    if (bj > bc) return;
+    __shared__ double t[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int row = bc * 64 + r, col = bj * 64 + tx;
+        t[r][tx] = (row < n && col < n) ? X[(int64_t)row * n + col] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int row = bj * 64 + r, col = bc * 64 + tx;   // X[row][col] = X[col][row] = t[tx][r]
+        if (row < n && col < n && row < col) X[(int64_t)row * n + col] = t[tx][r];
+    }
+}
+
+// out[perm[j]][perm[c]] = X[j][c]: the inverse from the factor's numbering into the level's (perm: factor -> level, inv its inverse), one
+// workgroup per row: the row goes through LDS, so that both the read of X and the write of `out` are contiguous.  Dynamic LDS: n doubles.
+__global__ __launch_bounds__(256) void permute_symmetric(const double* __restrict__ X, const int* __restrict__ perm, const int* __restrict__ inv, int n,
+                                                         double* __restrict__ out) {
+    extern __shared__ double row[];
+    const int j = blockIdx.x;
+    const double* src = X + (int64_t)j * n;
+    for (int c = threadIdx.x; c < n; c += 256) row[c] = src[c];
+    __syncthreads();
+    double* dst = out + (int64_t)perm[j] * n;
+    for (int c = threadIdx.x; c < n; c += 256) dst[c] = row[inv[c]];
+}
+
+// the same for rows that do not fit LDS (n > 8 192: only with GMG_COARSE_DEVICE_INVERSE forced on a large coarsest level): scattered writes
+__global__ __launch_bounds__(256) void permute_symmetric_scatter(const double* __restrict__ X, const int* __restrict__ perm, int n, double* __restrict__ out) {
+    const int j = blockIdx.x;
+    const double* src = X + (int64_t)j * n;
+    double* dst = out + (int64_t)perm[j] * n;
+    for (int c = threadIdx.x; c < n; c += 256) dst[perm[c]] = src[c];
+}
+
 }  // namespace gmgs

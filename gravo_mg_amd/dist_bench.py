@@ -45,6 +45,8 @@ def main(args):
     # GMG_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that): a functional end-to-end check of the
     # N > 1 path on a 1-GPU box, not a measurement
     backend = os.environ.get("GMG_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        os.environ.setdefault("GMG_P2P_SHARED_DEVICE", "1")      # (read by the library at its first use, below: gmg_p2p_connect refuses ranks on one device otherwise)
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if backend == "nccl":
@@ -52,7 +54,7 @@ def main(args):
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus or args.gpus <= 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    coarse_mode = cabi.COARSE_DEVICE_INVERSE if args.coarse == "device" else cabi.COARSE_HOST_LDLT
+    coarse_mode = {"auto": cabi.COARSE_AUTO, "host": cabi.COARSE_HOST_LDLT, "device": cabi.COARSE_DEVICE_INVERSE}[args.coarse]
 
     grow = world ** 0.5 if args.scaling == "weak" else 1.0                         # weak: n1 x n2 vertices per rank, same aspect ratio
     n1, n2 = int(round(args.n1 * grow)), int(round(args.n2 * grow))
@@ -82,6 +84,12 @@ def main(args):
     levels = [ref.level_info(k) for k in range(ref.num_levels + 1)]
     ref.load_problem(rhs, rhs)
     ref_res = ref.run_cycles(n_warm, 2)
+    ref.load_problem(rhs, rhs)
+    ref_hist = []
+    while True:                               # the single-GPU solve to 1e-4: what the partitioned solve below must reproduce
+        ref_hist += [float(v) for v in ref.run_cycles(1, 2)]
+        if not (ref_hist[-1] > 1e-4 and len(ref_hist) < 100):
+            break
     setup_ms["whole_operator"]["device_bytes_with_vectors"] = ref.timing("device_bytes_now")
     partitioned = world > 1 and args.exchange == "p2p" and not os.environ.get("GMG_BENCH_WHOLE_SETUP")
     if partitioned:
@@ -102,15 +110,18 @@ def main(args):
         dist.all_gather_object(flags, int(local_ok), group=cpu_group)
         return min(flags) == 1
 
-    def engine_cycle(mode, engine):
+    def engine_cycle(mode, engine, fenced=True):
         """One candidate: plan + buffers (local), connect (collective), first cycles = the single-GPU residues (collective on the devices).
-        Returns (P2PCycle or None, why not)."""
+        fenced (mailboxes only): gmg_p2p_set_fences -- False is the gfx950 publication without the cache write-back, taken only if those first
+        cycles reproduce the single-GPU residues.  Returns (P2PCycle or None, why not)."""
         ok, why = 1, None
         cand, blob = None, None
         try:
             if mode == 0 and os.environ.get("GMG_P2P_SELFTEST_FAIL") and rank == world - 1:      # test hook: one rank cannot set the mailboxes up
                 raise RuntimeError("forced by GMG_P2P_SELFTEST_FAIL")
             cand = cabi.P2PCycle(engine, rank, world, 1)
+            if mode == 0:
+                cand.set_fences(fenced)
             blob = cand.export() if mode != 1 else b""
         except Exception as e:          # noqa: BLE001
             ok, why = 0, f"set-up failed on rank {rank}: {e!r}"
@@ -153,8 +164,19 @@ def main(args):
             return None, why or "another rank's first cycles failed"
         return cand, None
 
+    exchange_fences = None
     if args.exchange == "p2p" and world > 1:
-        p2p, why0 = engine_cycle(0, eng)
+        # mailboxes, first WITHOUT the release / acquire fences around the sequence words (csrc/kernels.hip.hpp::publish_order: the gfx942 / gfx950
+        # form, ~3.5 us less per exchange launch) -- an opt-in of this caller, which checks the first cycles against the single-GPU residues;
+        # should they differ (or the set-up fail), the library's default: the fenced form
+        want_fence_free = not os.environ.get("GMG_BENCH_P2P_FENCED")
+        p2p, why0 = engine_cycle(0, eng, fenced=not want_fence_free)
+        exchange_fences = "none (write-through stores drained ahead of the sequence word; first cycles checked against the single-GPU residues)" if want_fence_free else "release/acquire (system scope)"
+        if p2p is None and want_fence_free:
+            single.log(f"[bench] rank {rank}: mailboxes without fences not taken ({why0}); trying the fenced form")
+            p2p, why0b = engine_cycle(0, eng, fenced=True)
+            exchange_fences = f"release/acquire (system scope); the fence-free form was not taken: {why0}"
+            why0 = why0b or why0
         if p2p is not None:
             engine_exchange, note = "p2p", "peer-to-peer mailboxes (hipIpc), one exchange kernel per colour"
         else:
@@ -394,6 +416,8 @@ def main(args):
             "iterations_to_1e-4": iters, "residue": res, "residues_to_1e-4": [float(v) for v in hist], "solve_ms": solve_ms,
             "exchange": engine_exchange if p2p is not None else ("none (one rank)" if world == 1 else args.exchange if args.exchange != "p2p" else "halo (fallback)"),
             "exchange_note": note, "exchange_us": exchange_us, "single_gpu_residues_reproduced": reproduced,
+            "exchange_fences": exchange_fences if engine_exchange == "p2p" else None,
+            "single_gpu_solve_reproduced": bool(len(hist) == len(ref_hist) and np.allclose(hist, ref_hist, rtol=1e-9)),
             "collectives_per_cycle": colls_per_cycle, "collective_backend": backend,
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
             "timed_residues_tail": [float(r) for r in residues[-3:]],

@@ -45,7 +45,11 @@ typedef enum {
 } gmg_status;
 
 enum { GMG_SMOOTHER_MULTICOLOR_GS = 0, GMG_SMOOTHER_JACOBI = 1 };
-enum { GMG_COARSE_HOST_LDLT = 0, GMG_COARSE_DEVICE_INVERSE = 1 };
+/* where the coarsest direct solve (multigrid_solver.cpp:1075) is applied.  HOST_LDLT: back-substitution with the host's supernodal factor, one
+ * device -> host -> device round trip per cycle.  DEVICE_INVERSE: one dense symmetric matrix-vector product with A_L^-1 on the device; the inverse
+ * is built on the device from the host's factor at gmg_set_system (timing keys "coarse_inverse_ms").  AUTO (default): DEVICE_INVERSE while the
+ * coarsest level has at most 8 192 unknowns (the reference's lower_bound = 1000, ratio = 8 keep it below 8 000), else HOST_LDLT. */
+enum { GMG_COARSE_HOST_LDLT = 0, GMG_COARSE_DEVICE_INVERSE = 1, GMG_COARSE_AUTO = 2 };
 
 typedef struct {
     int device;            /* HIP device ordinal */
@@ -53,7 +57,7 @@ typedef struct {
     double jacobi_omega;   /* damping for GMG_SMOOTHER_JACOBI (default 0.67) */
     int pre_iters;         /* MultigridSolver::preIters  (gravomg_bindings/src/cpp/core.cpp:55) */
     int post_iters;        /* MultigridSolver::postIters (core.cpp:56) */
-    int coarse_mode;       /* GMG_COARSE_*: where the coarsest direct solve is applied (default host) */
+    int coarse_mode;       /* GMG_COARSE_*: where the coarsest direct solve is applied (default GMG_COARSE_AUTO) */
     int use_graph;         /* 1: replay the V-cycle legs from captured hipGraphs; 0 (default): plain stream launches */
     int sigma;             /* length-sorting window (rows) inside the colour classes of a colour-major level (multiple of 64; 0 = no sorting,
                               the default: sorting rows by length trades SELL padding for locality of the gathers, and on the irregular
@@ -148,7 +152,11 @@ int gmg_set_mass(gmg_handle h, int n, const double* mass_diag);
  * The reference recomputes all of this on every solve(); here a matrix with the sparsity pattern of the live system
  * (recognised by a 128-bit digest of colptr/rowidx) only refreshes values in place -- numeric Galerkin passes, layout
  * refill, numeric LDL^T; timing key "setup_values_only" = 1 -- and a matrix with a pattern seen before on this handle
- * reuses the orderings ("setup_ordering_cached" = 1).  Results are those of a fresh handle in every case. */
+ * reuses the orderings ("setup_ordering_cached" = 1).  Results are those of a fresh handle in every case.
+ * A call that FAILS (GMG_ERR_INVALID for an index out of range, GMG_ERR_NUMERIC for a zero diagonal / pivot, ...) leaves the handle WITHOUT a
+ * system: a matrix of the live system's size has its values uploaded over the resident A_0 -- and the refresh started -- while the pattern is
+ * still being inspected, so the previous system does not survive a rejected call; the next solve returns GMG_ERR_STATE until a gmg_set_system
+ * succeeds (the reference has no persistent system either: solve() receives the LHS every time, multigrid_solver.cpp:1367). */
 int gmg_set_system(gmg_handle h, int n, const int* colptr, const int* rowidx, const double* val);
 
 /* ---- introspection -------------------------------------------------------------------------- */
@@ -277,7 +285,9 @@ int gmg_dist_scatter(gmg_handle h, const double* src, const int64_t* pos, const 
 int gmg_p2p_blob_bytes(void);
 int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d);
 int gmg_p2p_export(gmg_handle h, void* blob_out);
-/* blobs: world x gmg_p2p_blob_bytes() bytes in rank order. */
+/* blobs: world x gmg_p2p_blob_bytes() bytes in rank order.  GMG_ERR_STATE when two ranks of the job sit on the same device (the blobs carry
+ * the device's UUID): their exchange kernels would wait for each other on one GPU -- a mis-mapped HIP_VISIBLE_DEVICES then is an error at
+ * connect time instead of seconds per exchange.  GMG_P2P_SHARED_DEVICE=1 in the environment allows it (functional tests on a one-GPU box). */
 int gmg_p2p_connect(gmg_handle h, const void* blobs);
 /* gmg_config::dist_exchange = 1: instead of gmg_p2p_export / gmg_p2p_connect.  Rank 0 makes the 128-byte RCCL id (ncclGetUniqueId), the caller gives
  * it to every rank by any means, every rank calls gmg_p2p_connect_rccl (ncclCommInitRank: collective).  GMG_ERR_UNSUPPORTED without librccl. */
@@ -299,6 +309,14 @@ int gmg_p2p_stat(gmg_handle h, const char* key, double* out);
  * backend: publishing waves store their rows into the peers' mailboxes, the last one pulls; no exchange launch for the colour halos).
  * Every rank must make the same choice. */
 int gmg_p2p_set_smoother(gmg_handle h, int mode);
+/* Memory ordering of the mailbox exchanges (replaces nothing in the reference: the cost of splitting multigrid_solver.cpp:1194-1226 over devices).
+ * 1 (default): the HIP memory model's publication idiom -- a system-scope release fence between the halo stores and the store of the sequence
+ * number, an acquire fence after the poll that saw it; portable, and ~3.5 us per exchange launch for writing the L2 back.  0: the gfx942 /
+ * gfx950 form without the cache write-back (write-through system-scope stores, drained with s_waitcnt vmcnt(0) ahead of the number, system-scope
+ * loads on the other side; csrc/kernels.hip.hpp::publish_order) -- opt-in: a caller that takes it should check the first cycles against a run it
+ * trusts (bench.py --gpus N does: the single-GPU residues, and falls back to the fenced form).  Default of new plans: GMG_P2P_FENCE_FREE=1 makes
+ * it 0.  Every rank must make the same choice (a mixed job is still ordered correctly -- each side fences or not for itself). */
+int gmg_p2p_set_fences(gmg_handle h, int fenced);
 
 /* ---- host-only: hierarchy construction (no device needed) ----------------------------------- */
 typedef struct {

@@ -63,6 +63,11 @@ int gmg_algorithmic_bytes(gmg_handle h, int kind, int k, int d, double* bytes_ou
  * cycle), "r0_halo" (before the restriction, once per cycle).  Overwrites halo entries: gmg_p2p_load afterwards. */
 int gmg_p2p_bench_kind(gmg_handle h, const char* kind, int reps, double* ms_avg);
 
+/* Collective backend (gmg_config::dist_exchange != 0), after gmg_p2p_load: one exchange of every rank's level-0 rows of x (pack -> all-gather ->
+ * unpack), then this rank's slot of the gathered buffer against what it packed.  max_abs_diff must be 0; doubles = values compared.  With
+ * dist_exchange = 1 this is ncclAllGather's delivery seen from the host -- also on ONE rank (RCCL takes a one-rank communicator). */
+int gmg_p2p_debug_collective_roundtrip(gmg_handle h, double* max_abs_diff, long long* doubles);
+
 /* Host-only probe of the coarsest-level solver (csrc/host_ldlt.hpp): factorises A, times the back-substitution on 1 .. 8 threads (`reps` solves
  * per batch, best of 20) and the numeric re-factorisation, compares the team solves with the one-thread solve bit for bit and the supernodal
  * factor with the simplicial one.  The report (text lines) goes to `report` (cap bytes, NUL-terminated). */

@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 
 
 def worker(rank, world, port, kind, shard):
-    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"; os.environ["LOCAL_WORLD_SIZE"] = str(world); os.environ["GMG_P2P_TIMEOUT_S"] = "20"
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"; os.environ["LOCAL_WORLD_SIZE"] = str(world); os.environ["GMG_P2P_TIMEOUT_S"] = "20"; os.environ["GMG_P2P_SHARED_DEVICE"] = "1"
     import numpy as np
     import torch.distributed as dist
     from gravo_mg_amd import cabi

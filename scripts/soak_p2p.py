@@ -8,7 +8,7 @@ import numpy as np
 
 def worker(rank, world, port, q, kind, shard, reps):
     try:
-        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"; os.environ["LOCAL_WORLD_SIZE"] = str(world); os.environ["GMG_P2P_TIMEOUT_S"] = "30"
+        os.environ["GMG_P2P_SHARED_DEVICE"] = "1"; os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"; os.environ["LOCAL_WORLD_SIZE"] = str(world); os.environ["GMG_P2P_TIMEOUT_S"] = "30"
         import torch.distributed as dist
         from gravo_mg_amd import cabi
         from tests.test_gpu_p2p import _problem

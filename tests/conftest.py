@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The multi-rank tests put several ranks on the ONE device of the test box (functional checks of the N > 1 path); gmg_p2p_connect refuses that
+# unless told it is meant (include/gravomg_hip.h).  Spawned workers inherit the variable; test_gpu_p2p.py removes it in one test.
+os.environ.setdefault("GMG_P2P_SHARED_DEVICE", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -71,6 +71,16 @@ def _worker(rank, world, port, q, kind, shard, budget, partition=False, exchange
         x = rk.fetch()
         xs, its, ress = rk.solve(P.rhs, P.rhs, tol=1e-4, stop_type=2, max_iter=50)      # the collective solve loop completes on this budget
         assert ress <= 1e-4 and its >= 1 and eng.timing("diverged") == 0.0
+        if exchange == 0:
+            # the opt-in publication without the cache write-back (gmg_p2p_set_fences(0); default: release / acquire fences): the same bits
+            assert rk.stat("fenced") == 1.0
+            rk.set_fences(False)
+            rk.load(P.rhs, P.rhs)
+            hist_nf = rk.cycles(4, 2)
+            x_nf = rk.fetch()
+            rk.set_fences(True)
+            dist.barrier()
+            assert np.array_equal(hist_nf, hist) and np.array_equal(x_nf, x)
         # hybrid Gauss-Seidel (one exchange per sweep): another convergent iteration -- same solution to the tolerance; more cycles the smaller a
         # rank's piece is (this 7 680-vertex problem: 4 exact, 7 at four ranks, 11 at eight).  No assertion between collectives: a rank that
         # leaves early shows up on the others as a time-out.  Eight ranks run two hybrid cycles only (see the time-out note above)
@@ -152,6 +162,102 @@ def test_collective_exchange_sequence_gives_the_same_iterates(cabi, world, kind,
     whenever two devices are visible.  Same plan, same kernels around it: the single-engine solution bit for bit, level 1 partitioned or
     replicated, whole or partitioned set-up, d = 1 and 3, the hybrid smoother, every exchange kind timed."""
     test_processes_through_ipc_handles(cabi, world, kind, shard, partition, exchange=2)
+
+
+def _same_device_worker(rank, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        os.environ.pop("GMG_P2P_SHARED_DEVICE", None)       # what a real job runs with
+        import torch.distributed as dist
+        from gravo_mg_amd import cabi
+        from tests.test_gpu_p2p import _problem
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+        P = _problem("poisson")
+        eng = cabi.Engine(row_align=128, block_lanes=1)
+        eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+        rk = cabi.P2PCycle(eng, rank, 2, 1)
+        blobs = [None, None]
+        dist.all_gather_object(blobs, rk.export())
+        try:
+            rk.connect(blobs=blobs)
+            q.put((rank, "connected"))
+        except cabi.GmgError as e:
+            q.put((rank, str(e)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:              # noqa: BLE001
+        import traceback
+        q.put((rank, "worker failed: " + traceback.format_exc() + repr(e)))
+
+
+def test_two_ranks_on_one_device_are_refused_at_connect_time(cabi):
+    """A mis-mapped HIP_VISIBLE_DEVICES (every rank on device 0) must be an error when the ranks connect, not seconds of device-side spinning per
+    exchange: the connection records carry the device's UUID (gmg_p2p_connect; GMG_P2P_SHARED_DEVICE=1 -- what this suite sets -- allows it)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_same_device_worker, args=(r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for r in range(2):
+        assert "same device" in got[r] and "GMG_P2P_SHARED_DEVICE" in got[r], got
+
+
+_RCCL_ONE_RANK = r"""
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+from gravo_mg_amd import cabi
+from tests.test_gpu_p2p import _problem, _reference
+out = {}
+for kind in ("poisson", "smoothing-d3"):
+    P = _problem(kind)
+    want_hist, want_x = _reference(cabi, P, 1, 4)
+    eng = cabi.Engine(row_align=64, block_lanes=1, dist_exchange=1)
+    eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+    rk = cabi.P2PCycle(eng, 0, 1, P.rhs.shape[1])
+    mode = rk.stat("collective_mode")
+    rk.connect_rccl(cabi.rccl_unique_id())            # dlopen(librccl) -> ncclGetUniqueId -> ncclCommInitRank(nranks = 1)
+    rk.load(P.rhs, P.rhs)
+    hist = rk.cycles(4, 2)                            # every exchange of the cycle: pack -> ncclAllGather -> unpack on the engine's stream
+    n_coll = rk.stat("collective_exchanges")
+    x = rk.fetch()
+    diff, cnt = rk.collective_roundtrip()
+    xs, its, ress = rk.solve(P.rhs, P.rhs, tol=1e-4, stop_type=2, max_iter=50)
+    out[kind] = {"mode": mode, "hist_equal": bool(np.allclose(hist, want_hist, rtol=1e-12, atol=0)), "x_equal": bool(np.array_equal(x, want_x)), "collectives": n_coll,
+                 "roundtrip_diff": diff, "roundtrip_doubles": cnt, "solve_residue": ress, "solve_iters": its,
+                 "colors": eng.level_info(0)["n_colors"]}
+    del rk; eng.close()
+out["librccl_mapped"] = any("librccl" in l for l in open("/proc/self/maps"))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_rccl_all_gather_backend_on_one_rank(cabi):
+    """First contact with the real library on the one-GPU box: gmg_config::dist_exchange = 1 with world = 1 -- RCCL takes a one-rank communicator --
+    runs dlopen(librccl) -> ncclGetUniqueId -> ncclCommInitRank -> every exchange kind of the cycle as pack -> ncclAllGather -> unpack on the
+    engine's stream, the residual sums through the gathered buffer, and gives the plain engine's iterates bit for bit (d = 1 and 3).  In a
+    child process with a time-out: a communicator that cannot initialise on some box must fail this test, not hang the suite."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    run = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, ROOT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=420)
+    assert run.returncode == 0, (run.stdout[-1500:], run.stderr[-3000:])
+    res = json.loads([l for l in run.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res.pop("librccl_mapped") is True
+    for kind, r in res.items():
+        assert r["mode"] == 1.0 and r["hist_equal"] and r["x_equal"], (kind, r)
+        # per cycle: (pre + post) x colours + the rows of r0 + the halo of all colours + the norm sums
+        assert r["collectives"] >= 4 * (4 * r["colors"] + 3), (kind, r)
+        assert r["roundtrip_diff"] == 0.0 and r["roundtrip_doubles"] > 1000, (kind, r)
+        assert r["solve_residue"] <= 1e-4 and r["solve_iters"] >= 1, (kind, r)
 
 
 def _absent_peer_worker(rank, port, q):

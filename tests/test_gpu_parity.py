@@ -487,3 +487,45 @@ def test_block_sweeps_with_blocks_beyond_the_register_windows(cabi, oracle):
         scale = absA @ abs(x) + abs(b)
         assert np.abs(r - oracle.residual(A, b, x)).max() <= 1e-13 * scale.max()
     eng.close()
+
+
+@pytest.mark.parametrize("n1,n2,kind,lower_bound", [(190, 190, "smoothing", 1000), (300, 280, "poisson", 1000), (130, 120, "poisson", 300), (64, 60, "poisson", 20)])
+def test_device_built_coarse_inverse_against_the_host_factor(cabi, oracle, n1, n2, kind, lower_bound):
+    """The dense inverse of the coarsest operator is built ON THE DEVICE from the host's sparse LDL^T factor (setup_kernels.hip.hpp::coarse_inverse_tiles:
+    every 64-column tile of the identity through the factor, lower triangle mirrored) and applied with the vectors permuted into the factor's
+    numbering (gmgk::dense_symv).  Against the host back-substitution with the same factor (GMG_COARSE_HOST_LDLT) and the oracle's coarse solve
+    (multigrid_solver.cpp:1075, 1401), at coarsest sizes from one tile to ~6 000 unknowns (94 tiles, the demos' size), three right-hand sides; two
+    handles build the same bits (ranks of a multi-GPU job replicate this level)."""
+    import scipy.sparse.linalg as spla
+    from tests import problems
+    P = problems.torus_problem(n1, n2, kind, lower_bound)
+    dev = cabi.Engine()                                   # default: GMG_COARSE_AUTO -> device (n_L <= 8192)
+    dev.set_prolongations(P.U); dev.set_mass(P.mass); dev.set_system(P.lhs)
+    assert dev.timing("coarse_on_device") == 1.0 and dev.timing("coarse_inverse_ms") > 0
+    host = cabi.Engine(coarse_mode=cabi.COARSE_HOST_LDLT)
+    host.set_prolongations(P.U); host.set_mass(P.mass); host.set_system(P.lhs)
+    assert host.timing("coarse_on_device") == 0.0
+    AL = dev.level_operator(len(P.U))
+    nl = AL.shape[0]
+    rc = np.random.default_rng(11).standard_normal((nl, 3))
+    e_dev, e_host = dev.coarse_solve(rc), host.coarse_solve(rc)
+    nA = spla.norm(AL)
+    # the explicit inverse is as accurate as cond(A_L) eps allows (a backward-stable solve is better than that in the residual): both bounds
+    # carry the condition of this coarsest operator
+    cond = np.linalg.cond(AL.toarray()) if nl <= 2500 else 1e9
+    assert np.linalg.norm(AL @ (e_dev - e_host)) <= 1e-14 * cond * nA * np.linalg.norm(e_host) + 1e-10 * nA * np.linalg.norm(e_host)
+    assert rel(e_dev, e_host) <= 1e-13 * cond + 1e-9
+    O = oracle.Hierarchy(P.U, P.mass)
+    O.set_system(P.lhs)
+    assert rel(e_dev, O.coarse_solve(rc)) <= 1e-13 * cond + 1e-9
+    # one column alone = that column of the block (the product kernel's instantiations for d = 1 and d = 3)
+    assert np.array_equal(dev.coarse_solve(rc[:, 1]).ravel(), e_dev[:, 1])
+    # symmetric: e = X rc with X = X^T  =>  rc_a . (X rc_b) = rc_b . (X rc_a)
+    assert abs(rc[:, 0] @ e_dev[:, 1] - rc[:, 1] @ e_dev[:, 0]) <= 1e-12 * np.abs(rc[:, 0] @ e_dev[:, 1]) + 1e-12 * np.linalg.norm(e_dev)
+    other = cabi.Engine()
+    other.set_prolongations(P.U); other.set_mass(P.mass); other.set_system(P.lhs)
+    assert np.array_equal(other.coarse_solve(rc), e_dev)
+    # the solves agree in cycle count and residue
+    xd, itd, resd, _ = dev.solve(P.rhs, tol=1e-4)
+    xh, ith, resh, _ = host.solve(P.rhs, tol=1e-4)
+    assert itd == ith and abs(resd - resh) <= 1e-3 * resh      # (tau = 1e-6: cond(A_L) ~ 1e8 -- the two coarse solves differ by cond x eps)

@@ -35,7 +35,7 @@ def test_config_defaults_follow_reference_python_defaults(cabi):
     assert cabi.lib().gmg_config_default(C.byref(cfg)) == 0
     # gravomg_bindings/src/gravomg/core.py:10  pre_iters=2, post_iters=2
     assert (cfg.pre_iters, cfg.post_iters) == (2, 2)
-    assert cfg.smoother == cabi.SMOOTHER_MULTICOLOR_GS and cfg.coarse_mode == cabi.COARSE_HOST_LDLT
+    assert cfg.smoother == cabi.SMOOTHER_MULTICOLOR_GS and cfg.coarse_mode == cabi.COARSE_AUTO
     opt = cabi.GmgHierarchyOptions()
     assert cabi.lib().gmg_hierarchy_options_default(C.byref(opt)) == 0
     assert (opt.ratio, opt.lower_bound, opt.check_voronoi, opt.nested, opt.sampling, opt.weighting) == (8.0, 1000, 1, 0, 0, 0)
