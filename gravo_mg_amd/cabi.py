@@ -787,7 +787,7 @@ def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024, 
     1 = block ordering (block-hybrid GS, `block_rows` rows per block)."""
     a = _csc(A)
     n = a.shape[0]
-    if mode == 0:
+    if mode != 1:
         block_rows = row_align
     info = (C.c_int64 * 6)()
     # sizes first (null outputs), then the arrays: the padded length and the block count depend on the graph

@@ -2180,12 +2180,14 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
 
 int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma, int64_t* info,
                         int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color) try {
-    if (n <= 0 || !colptr || !rowidx || !val || mode < 0 || mode > 1) return GMG_ERR_INVALID;
+    if (n <= 0 || !colptr || !rowidx || !val || mode < 0 || mode > 3) return GMG_ERR_INVALID;
     if (mode == 1 && (block_rows <= 0 || block_rows > gmgk::kBlockRows || block_rows % 64)) return GMG_ERR_INVALID;
     if (sigma < 0 || sigma % 64) return GMG_ERR_INVALID;
     Compressed A;
     A.assign(n, n, colptr, rowidx, val);
-    LevelOrdering o = mode == 1 ? make_block_ordering(A, block_rows) : make_ordering(A, true, (block_rows > 0 && block_rows % 64 == 0) ? block_rows : 64, sigma);
+    // (mode 2: colour-major with the locality reordering forced -- the colouring then walks a visit ORDER; mode 3: colour-major, row indices declared ascending)
+    LevelOrdering o = mode == 1 ? make_block_ordering(A, block_rows)
+                                : make_ordering(A, true, (block_rows > 0 && block_rows % 64 == 0) ? block_rows : 64, sigma, mode == 2 ? 1 : 0, nullptr, mode == 3);
     if (o.n_colors > 256) return GMG_ERR_UNSUPPORTED;
     SellHost sa; std::vector<double> dg; std::string e;
     if (!build_operator_sell(A, o, 0, sa, dg, e)) return GMG_ERR_NUMERIC;

@@ -184,6 +184,10 @@ inline int greedy_coloring_bytes(const Mat& A, RawVec<unsigned char>& c8, const 
     return ncol;
 }
 
+// (Round 6 built the same colouring as a dataflow over strips of the visit sequence on several threads -- a vertex waits for the bytes of the
+// neighbours visited before it -- and removed it again: on a mesh in a local order the colouring is a chain along every mesh row, each row two
+// columns behind the one above, so threads either hold consecutive strips of ONE chain (cyclic deal: no parallelism) or read colour bytes a peer
+// wrote nanoseconds ago (a coherence miss per vertex: 40 -> 280 ms on eight threads at 3 M vertices).  docs/rounds/round6.md.)
 template <class Mat>
 inline int greedy_coloring(const Mat& A, std::vector<int>& color, const std::vector<int>& order = std::vector<int>()) {
     RawVec<unsigned char> c8;

@@ -369,8 +369,8 @@ def main(args):
 
     # the reference algorithm on this host's cores (rank 0, one core, a bounded sample of the same workload: like the N = 1 line)
     cpu = None
-    if rank == 0 and args.cpu_cycles > 0 and args.scaling == "strong":
-        cpu = single.cpu_baseline(H, mass, lhs, rhs, min(args.cpu_cycles, 6))
+    if rank == 0 and args.cpu_cycles > 0:          # (every N > 1 line carries it; a weak-scaling workload is N times larger: fewer cycles)
+        cpu = single.cpu_baseline(H, mass, lhs, rhs, min(args.cpu_cycles, 6 if args.scaling == "strong" else 3))
     # roofline of the dominant kernel (the fine-level colour sweep, same kernel as on one GPU; measured on the whole level)
     roofline = None
     if rank == 0:

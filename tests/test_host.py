@@ -363,3 +363,4 @@ def test_fine_block_rule_on_the_host(cabi):
     assert cabi.host_fine_block_rule(sp.csc_matrix(A)) == (False, 2)
     S, mass = meshgen.knn_graph_laplacian(meshgen.torus_points(2000, noise=0.002), 12)      # smoothing system of a denser graph
     assert cabi.host_fine_block_rule(meshgen.smoothing_system(S, mass, np.zeros((2000, 3)))[0]) == (True, 0)
+
