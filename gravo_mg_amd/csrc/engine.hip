@@ -389,17 +389,19 @@ static int build_coarse_inverse_device(gmg_handle h) {
     SupernodalLDLT::DeviceFactor E;
     h->coarse.export_device_factor(E);
     h->timing["coarse_inverse_export_ms"] = ms_since(t0);
-    // tile width: enough workgroups for the chip's compute units on a small level (121 tiles of 16 columns at n_L = 1 929, 188 of 32 at 6 005)
-    const int width = nl <= 4096 ? 16 : (nl <= 8192 ? 32 : 64);
+    // tile width: enough workgroups for the chip's compute units (121 tiles of 16 columns at n_L = 1 929, 376 at 6 005: two 1024-thread
+    // workgroups per compute unit are resident), wider tiles only where there would be more tiles than that
+    const int width = nl <= 8192 ? 16 : (nl <= 16384 ? 32 : 64);
     std::vector<int> tile_ptr_h, tile_q_h;
     E.tile_paths(width, tile_ptr_h, tile_q_h);
-    DevTmp<int> q_col0, q_w, q_rptr, rows, lev_ptr, lev_q, tile_ptr, tile_q;
+    const std::vector<int> lev_big_h = E.big_per_level(gmgs::kInvBigRows);
+    DevTmp<int> q_col0, q_w, q_rptr, rows, lev_ptr, lev_q, lev_big, tile_ptr, tile_q;
     DevTmp<double> vals, tri, dinv;
     int rc;
     auto up_i = [&](DevTmp<int>& d, const std::vector<int>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(int) * v.size()); };
     auto up_d = [&](DevTmp<double>& d, const std::vector<double>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(double) * v.size()); };
     if ((rc = up_i(q_col0, E.q_col0)) || (rc = up_i(q_w, E.q_w)) || (rc = up_i(q_rptr, E.q_rptr)) || (rc = up_i(rows, E.rows)) ||
-        (rc = up_i(lev_ptr, E.lev_ptr)) || (rc = up_i(lev_q, E.lev_q)) || (rc = up_i(tile_ptr, tile_ptr_h)) || (rc = up_i(tile_q, tile_q_h)) || (rc = up_d(vals, E.vals)) || (rc = up_d(tri, E.tri)) || (rc = up_d(dinv, E.dinv)))
+        (rc = up_i(lev_ptr, E.lev_ptr)) || (rc = up_i(lev_q, E.lev_q)) || (rc = up_i(lev_big, lev_big_h)) || (rc = up_i(tile_ptr, tile_ptr_h)) || (rc = up_i(tile_q, tile_q_h)) || (rc = up_d(vals, E.vals)) || (rc = up_d(tri, E.tri)) || (rc = up_d(dinv, E.dinv)))
         return rc;
     std::vector<int> inv_h((size_t)nl);
     for (int i = 0; i < nl; ++i) inv_h[(size_t)E.perm[(size_t)i]] = i;
@@ -414,7 +416,7 @@ static int build_coarse_inverse_device(gmg_handle h) {
     HIPCHK(hipMemsetAsync(X.p, 0, bytes, h->stream));
     gmgs::InvFactor F;
     F.n = nl; F.nq = E.nq; F.nlev = E.nlev;
-    F.q_col0 = q_col0.p; F.q_w = q_w.p; F.q_rptr = q_rptr.p; F.rows = rows.p; F.lev_ptr = lev_ptr.p; F.lev_q = lev_q.p; F.tile_ptr = tile_ptr.p; F.tile_q = tile_q.p;
+    F.q_col0 = q_col0.p; F.q_w = q_w.p; F.q_rptr = q_rptr.p; F.rows = rows.p; F.lev_ptr = lev_ptr.p; F.lev_q = lev_q.p; F.lev_big = lev_big.p; F.tile_ptr = tile_ptr.p; F.tile_q = tile_q.p;
     F.vals = vals.p; F.tri = tri.p; F.dinv = dinv.p;
     static_assert(gmgs::kInvChunk == SupernodalLDLT::kChunk, "chunk width of the exported factor");
     const int nt = (nl + width - 1) / width, nm = (nl + 63) / 64;
@@ -734,7 +736,8 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             else if (blocked) {
                 if (patches_done.valid()) patches_done.wait();
                 // level 0: blocks = runs of block_rows points of the hierarchy's cluster order (level0_patches), coloured from the caller's arrays
-                if (k == 0) lk.ord = make_block_ordering(PatternView{n, colptr, rowidx}, h->cfg.block_rows, level0_patches(h, n));
+                // (row_align = 64 P: the block count is padded to a multiple of P, so that P ranks own whole blocks -- engine_dist.hip.hpp::p2p_smooth)
+                if (k == 0) lk.ord = make_block_ordering(PatternView{n, colptr, rowidx}, h->cfg.block_rows, level0_patches(h, n), std::max(1, h->cfg.row_align / 64));
                 else lk.ord = make_block_ordering(lk.A, h->cfg.block_rows, k < (int)h->patches.size() ? &h->patches[k] : nullptr);
             }
             else if (k == 0) {
@@ -1616,8 +1619,10 @@ int gmg_dist_setup(gmg_handle h, int rank, int world) try {
     if (world < 1 || rank < 0 || rank >= world) return fail(h, GMG_ERR_INVALID, "bad rank / world size");
     if (h->partitioned && (rank != h->part_rank || world != h->part_world)) return fail(h, GMG_ERR_STATE, "the system was laid out for another rank / world size (gmg_dist_partition)");
     const LevelOrdering& o = h->lv[0].ord;
-    if (o.blocked || h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the colour-major multicolour ordering on level 0 (gmg_config: block_from_level >= 1, block_fine = 0)");
-    for (int c = 0; c < o.n_colors; ++c)
+    if (h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the multicolour / block-hybrid smoothers (gmg_config::smoother)");
+    // a blocked level 0 (gmg_config::block_fine: kNN operators) is ONE class of rows cut into `world` runs of whole 64-row blocks
+    if (o.blocked && (h->cfg.block_rows != 64 || !h->lv[0].use_ep)) return fail(h, GMG_ERR_STATE, "a blocked level 0 is partitioned only with 64-row blocks on the unpadded block storage (block_rows = 64, block_ep = 1)");
+    for (int c = 0; c < dist_classes(o); ++c)
         if ((o.color_begin[c + 1] - o.color_begin[c]) % (64 * world)) return fail(h, GMG_ERR_STATE, "colour classes are not aligned to 64*world rows: create the handle with row_align = 64*world");
     h->rank = rank; h->world = world; h->dist_ready = true;
     return GMG_OK;
@@ -1659,7 +1664,8 @@ static int dist_smooth_color_impl(gmg_handle h, int c, const unsigned long long*
     int rc = dist_ready(h);
     if (rc) return rc;
     Level& l = h->lv[0];
-    if (c < 0 || c >= l.ord.n_colors) return fail(h, GMG_ERR_INVALID, "colour out of range");
+    if (c < 0 || c >= dist_classes(l.ord)) return fail(h, GMG_ERR_INVALID, "colour out of range");
+    if (l.ord.blocked) return fail(h, GMG_ERR_STATE, "level 0 is blocked: its sweep is a block sweep (gmg_p2p_cycles), not a colour sweep");
     int sb, se;
     own_range(h, c, sb, se);
     const int d = h->loaded_d, ld = l.n_pad;
@@ -1694,7 +1700,7 @@ int gmg_dist_residual_own(gmg_handle h) try {
     if (rc) return rc;
     Level& l = h->lv[0];
     const int d = h->loaded_d, ld = l.n_pad;
-    for (int c = 0; c < l.ord.n_colors; ++c) {
+    for (int c = 0; c < dist_classes(l.ord); ++c) {
         int sb, se;
         own_range(h, c, sb, se);
         if (se <= sb) continue;
@@ -1736,7 +1742,7 @@ int gmg_dist_prolong_own(gmg_handle h) try {
     Level& l = h->lv[0];
     Level& cl = h->lv[1];
     const int d = h->loaded_d;
-    for (int c = 0; c < l.ord.n_colors; ++c) {
+    for (int c = 0; c < dist_classes(l.ord); ++c) {
         int sb, se;
         own_range(h, c, sb, se);
         if (se <= sb) continue;
@@ -1758,7 +1764,7 @@ static int dist_norm_launch(gmg_handle h, int type) {
     Level& l = h->lv[0];
     const int d = h->loaded_d;
     const double* w = type == 1 ? h->d_minv : (type == 2 ? h->d_mass : nullptr);
-    const int nc = l.ord.n_colors;
+    const int nc = dist_classes(l.ord);
     const int nblk = std::max(1, kNormBlocks / std::max(nc, 1));
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);

@@ -228,7 +228,7 @@ int coll_build(gmg_handle h) {
     // dlopen, ncclCommInitRank, ncclAllGather on the engine's stream; the emulation needs a peer to store into)
     cb.mode = (p->world > 1 || h->cfg.dist_exchange == 1) ? h->cfg.dist_exchange : 0;
     if (cb.mode == 0) return GMG_OK;
-    const int world = p->world, rank = p->rank, d = p->d, nk = p->nk, C = h->lv[0].ord.n_colors;
+    const int world = p->world, rank = p->rank, d = p->d, nk = p->nk, C = dist_classes(h->lv[0].ord);
     const LevelOrdering& o = h->lv[0].ord;
     const int own_rows = h->lv[0].n_pad / world;
     auto up8 = [](long long v) { return (v + 7) / 8 * 8; };
@@ -382,7 +382,7 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
     p->fenced = !EnvSwitches::get().p2p_fence_free;
     Level& l = h->lv[0];
     const LevelOrdering& o = l.ord;
-    const int C = o.n_colors;
+    const int C = dist_classes(o);
     p->nk = C + 6;
     p->kind_count.assign(p->nk, 0);
     p->own_lo.resize(C); p->own_cnt.resize(C);
@@ -486,7 +486,7 @@ int gmg_p2p_export(gmg_handle h, void* blob_out) try {
     std::memset(&b, 0, sizeof(b));
     HIPCHK(hipIpcGetMemHandle(&b.mbox, p->mbox));
     HIPCHK(hipIpcGetMemHandle(&b.flags, p->flags));
-    b.rank = p->rank; b.world = p->world; b.d = p->d; b.n_pad = h->lv[0].n_pad; b.n_colors = h->lv[0].ord.n_colors; b.mbox_doubles = p->box_total[p->rank];
+    b.rank = p->rank; b.world = p->world; b.d = p->d; b.n_pad = h->lv[0].n_pad; b.n_colors = dist_classes(h->lv[0].ord); b.mbox_doubles = p->box_total[p->rank];
     b.reserved = (p->shard1 ? 1 : 0) | (p->coll.mode << 4);
     if (p->coll.mode == 2) { HIPCHK(hipIpcGetMemHandle(&b.coll, p->coll.recv)); b.coll_doubles = 2LL * p->world * p->coll.max_chunk; }
     {
@@ -507,7 +507,7 @@ int gmg_p2p_connect(gmg_handle h, const void* blobs) try {
     NEED_DEVICE();
     DistP2P* p = h->p2p;
     if (!p || !p->planned || !blobs) return fail(h, GMG_ERR_STATE, "call gmg_p2p_prepare first");
-    const int world = p->world, rank = p->rank, C = h->lv[0].ord.n_colors, nk = p->nk, d = p->d;
+    const int world = p->world, rank = p->rank, C = dist_classes(h->lv[0].ord), nk = p->nk, d = p->d;
     const gmg_p2p_blob* bl = (const gmg_p2p_blob*)blobs;
     // (a second connect: the mappings of the first one are closed, not dropped -- re-opening a handle that is still mapped can fail)
     auto close_peer = [](P2PPeer& peer) {
@@ -763,6 +763,23 @@ int p2p_smooth(gmg_handle h, int iters) {
     Level& l = h->lv[0];
     const bool hybrid = h->p2p->hybrid;
     int rc;
+    if (l.ord.blocked) {
+        // a blocked level 0 (gmg_config::block_fine: kNN operators -- one launch per sweep on one GPU too): this rank's run of whole 64-row blocks,
+        // one halo exchange per sweep.  The block-hybrid sweep takes the couplings to other blocks from the previous iterate, so the iterates are
+        // those of the single-GPU engine whatever the number of ranks is, exactly like the partitioned level 1 below.
+        int sb, se;
+        own_range(h, 0, sb, se);                           // slices of 64 rows = blocks
+        const int d = h->p2p->d;
+        double* in = l.x;
+        double* out = l.tmp;
+        for (int it = 0; it < iters; ++it) {
+            launch_block_sweep_range<double>(h, l, d, in, out, sb, se - sb);
+            if ((rc = p2p_exchange(h, 1, out, l.n_pad))) return rc;      // kind 1 of a one-class level: the halo of all rows
+            std::swap(in, out);
+        }
+        if (in != l.x) HIPCHK(hipMemcpyAsync(l.x, in, sizeof(double) * (size_t)l.n_pad * d, hipMemcpyDeviceToDevice, h->stream));
+        return GMG_OK;
+    }
     for (int it = 0; it < iters; ++it) {
         for (int c = 0; c < l.ord.n_colors; ++c) {
             if (p2p_smooth_color_folded(h, c)) continue;
@@ -779,7 +796,7 @@ int p2p_smooth(gmg_handle h, int iters) {
 int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero) {
     DistP2P* p = h->p2p;
     Level& l1 = h->lv[1];
-    const int C = h->lv[0].ord.n_colors, d = p->d, nb = (int)p->own_blocks[p->rank].size();
+    const int C = dist_classes(h->lv[0].ord), d = p->d, nb = (int)p->own_blocks[p->rank].size();
     double* in = from_zero ? nullptr : l1.x;
     double* out = l1.tmp;
     int rc;
@@ -804,7 +821,7 @@ int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero) {
 int p2p_coarse_cycle_sharded(gmg_handle h) {
     DistP2P* p = h->p2p;
     Level &l0 = h->lv[0], &l1 = h->lv[1];
-    const int C = l0.ord.n_colors, d = p->d;
+    const int C = dist_classes(l0.ord), d = p->d;
     int rc;
     if ((rc = p2p_exchange(h, C + 5, l0.r, l0.n_pad))) return rc;                      // r0 entries my restriction rows read
     if (p->n_rsl > 0)                                                                 // :1069 on my rows of level 1
@@ -855,7 +872,7 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
 
 int p2p_vcycle_enqueue(gmg_handle h) {
     Level& l = h->lv[0];
-    const int C = l.ord.n_colors;
+    const int C = dist_classes(l.ord);
     int rc;
     if ((rc = p2p_smooth(h, h->cfg.pre_iters))) return rc;                // :1063
     if ((rc = gmg_dist_residual_own(h))) return rc;                       // :1066, own rows
@@ -881,7 +898,7 @@ int p2p_vcycle(gmg_handle h) {
 int p2p_kind_by_name(gmg_handle h, const std::string& name, int* kind, double** vec, int* ld) {
     DistP2P* p = h->p2p;
     Level& l0 = h->lv[0];
-    const int C = l0.ord.n_colors;
+    const int C = dist_classes(l0.ord);
     *vec = l0.x; *ld = l0.n_pad;
     if (name.rfind("color", 0) == 0) { *kind = std::atoi(name.c_str() + 5); return *kind >= 0 && *kind < C ? GMG_OK : GMG_ERR_INVALID; }
     if (name == "halo_all") { *kind = C; return GMG_OK; }
@@ -902,7 +919,7 @@ int gmg_p2p_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     if (!p || !p->connected || !h->bound) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
     int rc;
     if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
-    const int d = p->d, np = (int)p->peers.size(), C = h->lv[0].ord.n_colors;
+    const int d = p->d, np = (int)p->peers.size(), C = dist_classes(h->lv[0].ord);
     HelperScope helper_scope(h, d);
     for (int i = 0; i < n_cycles; ++i) {
         if ((rc = p2p_vcycle(h))) return rc;
@@ -948,7 +965,7 @@ int gmg_p2p_fetch(gmg_handle h, double* x) try {
     if (!p || !p->connected || !h->bound || !x) return fail(h, GMG_ERR_STATE, "no distributed problem loaded (gmg_p2p_load)");
     Level& l = h->lv[0];
     // the level-0 rows exchange moves every rank's own rows of a level-0 vector
-    int rc = p2p_exchange(h, l.ord.n_colors + 1, l.x, l.n_pad);
+    int rc = p2p_exchange(h, dist_classes(l.ord) + 1, l.x, l.n_pad);
     if (rc) return rc;
     int herr = 0;
     HIPCHK(hipMemcpyAsync(&herr, p->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1042,7 +1059,7 @@ int gmg_p2p_debug_collective_roundtrip(gmg_handle h, double* max_abs_diff, long 
     CollBackend& cb = p->coll;
     if (cb.mode == 0) return fail(h, GMG_ERR_STATE, "this handle has no collective backend (gmg_config::dist_exchange)");
     Level& l = h->lv[0];
-    const int kind = l.ord.n_colors + 1;
+    const int kind = dist_classes(l.ord) + 1;
     const int parity = (int)(cb.count & 1);                               // the half coll_exchange is about to use
     int rc = coll_exchange(h, kind, l.x, l.n_pad);
     if (rc) return rc;

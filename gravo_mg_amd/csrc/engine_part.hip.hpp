@@ -38,7 +38,7 @@ inline bool plan_can_shard_level1(gmg_handle h, int world, bool use_ep_known) {
 int build_dist_plan(gmg_handle h, DistPlan& P, int rank, int world, const PatternView& A0, const Compressed* A1, bool shard1) {
     Level& l = h->lv[0];
     const LevelOrdering& o = l.ord;
-    const int C = o.n_colors;
+    const int C = dist_classes(o);
     P = DistPlan();
     P.rank = rank; P.world = world; P.n_colors = C; P.shard1 = shard1 && world > 1;
     P.halo.assign((size_t)world * world * (C + 1), std::vector<int>());
@@ -145,10 +145,10 @@ int make_row_masks(gmg_handle h, const DistPlan& P, int** d_mask0, int** d_mask1
     const LevelOrdering& o = l0.ord;
     DevTmp<int> d_cb;
     int rc;
-    if ((rc = d_cb.alloc(h, (size_t)o.n_colors + 1))) return rc;
-    HIPCHK(hipMemcpyAsync(d_cb.p, o.color_begin.data(), sizeof(int) * ((size_t)o.n_colors + 1), hipMemcpyHostToDevice, h->stream));
+    if ((rc = d_cb.alloc(h, (size_t)dist_classes(o) + 1))) return rc;
+    HIPCHK(hipMemcpyAsync(d_cb.p, o.color_begin.data(), sizeof(int) * ((size_t)dist_classes(o) + 1), hipMemcpyHostToDevice, h->stream));
     HIPCHK(dev_malloc((void**)d_mask0, sizeof(int) * (size_t)l0.n_pad));
-    hipLaunchKernelGGL(gmgs::mask_rows_by_colour, dim3((l0.n_pad + 255) / 256), dim3(256), 0, h->stream, l0.d_new2old, l0.n_pad, d_cb.p, o.n_colors, P.world, P.rank, *d_mask0);
+    hipLaunchKernelGGL(gmgs::mask_rows_by_colour, dim3((l0.n_pad + 255) / 256), dim3(256), 0, h->stream, l0.d_new2old, l0.n_pad, d_cb.p, dist_classes(o), P.world, P.rank, *d_mask0);
     if (P.shard1) {
         Level& l1 = h->lv[1];
         DevTmp<int> d_own;

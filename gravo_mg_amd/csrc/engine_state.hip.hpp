@@ -303,6 +303,10 @@ struct gmg_solver_s {
 
 namespace {
 
+// Classes of rows a partitioned level 0 is cut by (engine_dist.hip.hpp): its colour classes, or -- blocked (gmg_config::block_fine) -- the one range
+// of all rows (LevelOrdering::color_begin = {0, n_pad}; n_colors then counts the colours INSIDE a block).
+inline int dist_classes(const LevelOrdering& o) { return o.blocked ? 1 : o.n_colors; }
+
 int fail(gmg_handle h, int code, const std::string& msg) {
     if (h) h->err = msg;
     return code;

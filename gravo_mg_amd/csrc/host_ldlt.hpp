@@ -714,6 +714,13 @@ public:
     struct DeviceFactor {
         int n = 0, nq = 0, nlev = 0;
         std::vector<int> q_col0, q_w, q_rptr, q_fdesc, rows, lev_ptr, lev_q, perm, first_q;      // first_q[c]: the chunk that holds column c
+        // chunks of every level with at least `big_rows` rows below them (they come first in lev_q: sorted by rows, descending)
+        std::vector<int> big_per_level(int big_rows) const {
+            std::vector<int> out((size_t)nlev, 0);
+            for (int v = 0; v < nlev; ++v)
+                for (int k = lev_ptr[(size_t)v]; k < lev_ptr[(size_t)v + 1] && q_rptr[(size_t)lev_q[(size_t)k] + 1] - q_rptr[(size_t)lev_q[(size_t)k]] >= big_rows; ++k) ++out[(size_t)v];
+            return out;
+        }
         // the chunks a tile of `width` columns visits on the way down: the union of its columns' paths to the root, ascending
         void tile_paths(int width, std::vector<int>& tile_ptr, std::vector<int>& tile_q) const {
             const int nt = (n + width - 1) / width;

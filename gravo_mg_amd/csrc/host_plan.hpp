@@ -449,7 +449,7 @@ inline Compressed coarse_point_graph(const Compressed& U, const Compressed& Urow
 // colour.  Every block is padded to a multiple of 64 rows so SELL slices never straddle blocks.
 // `patches`: grown beforehand (over the coarse point graph of the hierarchy) or, if null, grown here over A's graph.
 template <class Mat>
-inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const PatchSet* patches = nullptr) {
+inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const PatchSet* patches = nullptr, int block_align = 1) {
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
@@ -470,12 +470,15 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
     const int nb = (int)mem_begin.size() - 1;
     const int T = std::max(1, std::min(hw_threads(), 32));
     // ---- phase 2 (threaded over blocks): greedy colouring of the in-block subgraph in BFS order, colour sort, padding
-    o.blk_begin.assign((size_t)nb + 1, 0);
-    for (int b = 0; b < nb; ++b) o.blk_begin[b + 1] = o.blk_begin[b] + round_up(mem_begin[b + 1] - mem_begin[b], kSlice);
-    o.n_pad = nb ? o.blk_begin[nb] : kSlice;
+    // block_align > 1 (a level 0 that P ranks cut into P runs of whole blocks, gmg_config::row_align = 64 P): empty 64-row blocks are appended
+    // until the block count is a multiple of it (padding rows: no entries, unit diagonal, zero right-hand side)
+    const int nb_all = block_align > 1 ? round_up(std::max(nb, 1), block_align) : nb;
+    o.blk_begin.assign((size_t)nb_all + 1, 0);
+    for (int b = 0; b < nb_all; ++b) o.blk_begin[b + 1] = o.blk_begin[b] + (b < nb ? round_up(mem_begin[b + 1] - mem_begin[b], kSlice) : kSlice);
+    o.n_pad = nb_all ? o.blk_begin[nb_all] : kSlice;
     o.new2old.assign(o.n_pad, -1);
     o.row_color.assign(o.n_pad, 0);
-    o.blk_ncolors.assign(nb, 0);
+    o.blk_ncolors.assign(nb_all, 0);
     std::vector<int> color(n, -1);
     parallel_ranges(nb, T, [&](int lo, int hi, int) {
         std::vector<char> forbid;

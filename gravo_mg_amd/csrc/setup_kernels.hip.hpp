@@ -774,19 +774,19 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
 // the build is latency-bound (one dependent global round trip per level) and not a candidate for MFMA.
 struct InvFactor {
     int n, nq, nlev;
-    const int *q_col0, *q_w, *q_rptr, *rows, *lev_ptr, *lev_q, *tile_ptr, *tile_q;
+    const int *q_col0, *q_w, *q_rptr, *rows, *lev_ptr, *lev_q, *lev_big, *tile_ptr, *tile_q;      // lev_big[level]: its first chunks with >= kInvBigRows rows
     const double *vals, *tri, *dinv;
 };
 constexpr int kInvChunk = 8;            // = gmg::SupernodalLDLT::kChunk
 constexpr int kInvWaves = 16;
-constexpr int kInvThin = 16;            // a level with fewer chunks than this is shared chunk by chunk among all the waves of the workgroup
+constexpr int kInvBigRows = 192;        // a chunk with at least this many rows below it is worked off by ALL waves of the workgroup together
 
 // W = columns of a tile (16 / 32 / 64).  A wave covers W columns x S = 64 / W ROW SLOTS: lane = slot * W + column, so that one load instruction
 // fetches S different rows of the tile's slab (a small coarsest level has few tiles: the width is chosen so that there are enough workgroups,
 // and the slots keep all 64 lanes busy).  Way down: the chunks on the tile's paths to the root (tile_q, ascending), one after the other, every
-// wave pushing its share of the rows below.  Way up: level by level; a level with many chunks gives every wave its own chunks, a thin level (the
-// separator chains at the top of the tree: one or two chunks with hundreds of rows) is worked off chunk by chunk by ALL waves, their partial
-// sums added in wave order through LDS.  Every value has one fixed summation order: same bits on every device.
+// wave pushing its share of the rows below.  Way up: level by level; the big chunks of a level (separators: hundreds of rows below them; the host
+// lists them first) are worked off one by one by ALL waves, their partial sums added in wave order through LDS; the others go to the waves
+// one chunk each, side by side.  Every value has one fixed summation order: same bits on every device.
 template <int W>
 __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor F, double* X) {
     constexpr int S = 64 / W;
@@ -852,13 +852,14 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
     // ---- way up (L^T x = D^-1 y, pull form), rows >= c0 only
     auto gather_rows = [&](int q, int first, int stride, double (&acc)[kInvChunk]) {
         const int r0 = F.q_rptr[q], r1 = F.q_rptr[q + 1];
-        for (int i = r0 + first; i < r1; i += 4 * stride) {
-            double xi[4];
-            int iu[4];
+        constexpr int U = 8;                                                 // gathers in flight per lane (a big level's slabs live in HBM: latency, not bytes)
+        for (int i = r0 + first; i < r1; i += U * stride) {
+            double xi[U];
+            int iu[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { iu[u] = i + u * stride; xi[u] = (iu[u] < r1 && valid) ? Xc[(int64_t)F.rows[iu[u]] * ld] : 0.0; }
+            for (int u = 0; u < U; ++u) { iu[u] = i + u * stride; xi[u] = (iu[u] < r1 && valid) ? Xc[(int64_t)F.rows[iu[u]] * ld] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 const double* V = F.vals + (int64_t)(iu[u] < r1 ? iu[u] : r0) * kInvChunk;
 #pragma unroll
                 for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] -= V[jj] * xi[u];
@@ -879,46 +880,43 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
         }
     };
     for (int lev = 0; lev < F.nlev; ++lev) {
-        const int k0 = F.lev_ptr[lev], k1 = F.lev_ptr[lev + 1];
-        if (k1 - k0 >= kInvThin) {
-            for (int k = k0 + wave; k < k1; k += kInvWaves) {
-                const int q = F.lev_q[k];
-                const int col0 = F.q_col0[q], w = F.q_w[q];
-                if (col0 + w - 1 < c0) continue;
-                double acc[kInvChunk];
+        const int k0 = F.lev_ptr[lev], k1 = F.lev_ptr[lev + 1], kb = k0 + F.lev_big[lev];
+        for (int k = k0; k < kb; ++k) {                                      // the big ones, together
+            const int q = F.lev_q[k];
+            const int col0 = F.q_col0[q], w = F.q_w[q];
+            if (col0 + w - 1 < c0) continue;                                // (workgroup-uniform)
+            double acc[kInvChunk];
 #pragma unroll
-                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
-                gather_rows(q, slot, S, acc);
+            for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
+            gather_rows(q, wave * S + slot, kInvWaves * S, acc);
 #pragma unroll
-                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = slots_sum(acc[jj]);
+            for (int jj = 0; jj < kInvChunk; ++jj) { const double v = slots_sum(acc[jj]); if (slot == 0) red[wave][jj][cl] = v; }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int jj = 0; jj < kInvChunk; ++jj) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int wv = 0; wv < kInvWaves; ++wv) v += red[wv][jj][cl];
+                    acc[jj] = v;
+                }
                 finish_chunk(q, col0, w, acc);
             }
             __syncthreads();
-        } else {
-            for (int k = k0; k < k1; ++k) {
-                const int q = F.lev_q[k];
-                const int col0 = F.q_col0[q], w = F.q_w[q];
-                if (col0 + w - 1 < c0) continue;                                // (workgroup-uniform)
-                double acc[kInvChunk];
-#pragma unroll
-                for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
-                gather_rows(q, wave * S + slot, kInvWaves * S, acc);
-#pragma unroll
-                for (int jj = 0; jj < kInvChunk; ++jj) { const double v = slots_sum(acc[jj]); if (slot == 0) red[wave][jj][cl] = v; }
-                __syncthreads();
-                if (wave == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < kInvChunk; ++jj) {
-                        double v = 0.0;
-#pragma unroll
-                        for (int wv = 0; wv < kInvWaves; ++wv) v += red[wv][jj][cl];
-                        acc[jj] = v;
-                    }
-                    finish_chunk(q, col0, w, acc);
-                }
-                __syncthreads();
-            }
         }
+        for (int k = kb + wave; k < k1; k += kInvWaves) {                    // the others: one per wave
+            const int q = F.lev_q[k];
+            const int col0 = F.q_col0[q], w = F.q_w[q];
+            if (col0 + w - 1 < c0) continue;
+            double acc[kInvChunk];
+#pragma unroll
+            for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
+            gather_rows(q, slot, S, acc);
+#pragma unroll
+            for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = slots_sum(acc[jj]);
+            finish_chunk(q, col0, w, acc);
+        }
+        __syncthreads();
     }
 }
 

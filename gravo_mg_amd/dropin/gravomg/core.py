@@ -135,7 +135,8 @@ class MultigridSolver(object):
         (the only thing the ranks exchange through the caller: 1 KB connection records, once per system layout).
         device: HIP device of this rank (default: rank).  Call before the first solve().
         partition_setup (default): the engine lays out and keeps only this rank's rows of levels 0-1 (gmg_dist_partition: a rank's device
-        memory is its share of the operator plus the replicated small levels); such an object runs the collective solve() only --
+        memory is its share of the operator plus the replicated small levels; not for systems whose level 0 runs the block sweep -- kNN graph
+        Laplacians --, which keep the single-GPU smoother and take whole operators on every rank); such an object runs the collective solve() only --
         residual() and the single-process entry points need partition_setup=False (every rank then holds the whole operator).
         exchange: "mailbox" (default: device-initiated stores through hipIpc mappings, one launch per exchange) or "rccl" (every exchange as
         pack -> ncclAllGather -> unpack on the engine's stream, gmg_config::dist_exchange = 1: for boxes where processes cannot map each
@@ -148,12 +149,11 @@ class MultigridSolver(object):
         if world > 1:
             self.solver.set_engine_option("row_align", 64 * world)
             self.solver.set_engine_option("dist_shard_levels", int(shard_levels))
-            self.solver.set_engine_option("block_fine", 0)          # the partitioned cycle needs the colour-major level 0
             self.solver.set_engine_option("device", rank if device is None else int(device))
             self.solver.set_engine_option("dist_rank", rank if partition_setup else 0)
             self.solver.set_engine_option("dist_world", world if partition_setup else 1)
             self.solver.set_engine_option("dist_exchange", 1 if exchange == "rccl" else 0)
-            self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None, "exchange": exchange}
+            self._dist = {"rank": rank, "world": world, "all_gather": all_gather, "cycle": None, "key": None, "exchange": exchange, "partition_setup": bool(partition_setup), "rule_checked": False}
         else:
             self._dist = None
 
@@ -166,6 +166,15 @@ class MultigridSolver(object):
         from gravo_mg_amd import cabi                     # ctypes view of the same libgravomg_hip.so
         D = self._dist
         tol, stop_type, max_iter = self._solve_args
+        if D["partition_setup"] and not D["rule_checked"]:
+            # One smoother per system at every N: an operator whose level 0 runs the block sweep on one GPU (long rows, Stieltjes signs: kNN graph
+            # Laplacians, gmg_config::block_fine) runs it on N too, partitioned by runs of whole blocks -- but a partitioned SET-UP keeps level 0
+            # colour-major, so such a system takes the whole-operator set-up on every rank.  The rule looks at the matrix only: every rank decides alike.
+            D["rule_checked"] = True
+            if cabi.host_fine_block_rule(lhs)[0]:
+                D["partition_setup"] = False
+                self.solver.set_engine_option("dist_rank", 0)
+                self.solver.set_engine_option("dist_world", 1)
         handle, generation = self.solver.prepare_system(lhs)
         key = (handle, generation, rhs.shape[1])
         if D["key"] != key:                               # new layout (or another d): partition, export, connect

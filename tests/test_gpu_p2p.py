@@ -37,6 +37,8 @@ def _problem(kind):
         return pr.torus_problem(96, 80, "poisson", 30)
     if kind == "poisson-big":
         return pr.torus_problem(300, 280, "poisson", 100)       # level 1: ~10 k rows, ~165 blocks
+    if kind == "cloud":
+        return pr.pointcloud_problem(9000, 8, 120)              # kNN operator: level 0 itself runs the block sweep (gmg_config::block_fine)
     return pr.torus_problem(64, 60, "smoothing", 60)
 
 
@@ -60,6 +62,8 @@ def _worker(rank, world, port, q, kind, shard, budget, partition=False, exchange
         if partition:
             with pytest.raises(cabi.GmgError, match="partitioned"):      # no whole operator on this handle: the single-process entry points say so
                 eng.residual(0, P.rhs, P.rhs)
+        blocked0 = eng.level_blocks(0) is not None           # level 0 on the block sweep: partitioned by runs of whole blocks, one exchange per sweep
+        assert blocked0 == (kind == "cloud")
         rk = cabi.P2PCycle(eng, rank, world, P.rhs.shape[1])
         assert rk.stat("level1_partitioned") == (1.0 if shard == 2 else 0.0)
         blobs = [None] * world
@@ -98,7 +102,7 @@ def _worker(rank, world, port, q, kind, shard, budget, partition=False, exchange
         dist.barrier()
         assert ok_h, why_h
         # the colour exchanges folded into the colour launches (gmgk::gs_color_push): the same iterates bit for bit, 4 C fewer launches per cycle
-        if exchange == 0:
+        if exchange == 0 and not blocked0:
             n0 = rk.stat("exchange_launches")
             rk.load(P.rhs, P.rhs)
             hist_u = rk.cycles(2, 2)
@@ -127,7 +131,8 @@ def _worker(rank, world, port, q, kind, shard, budget, partition=False, exchange
 @pytest.mark.parametrize("world,kind,shard,partition", [(2, "poisson", 2, False), (3, "poisson", 2, False), (3, "poisson", 1, False), (4, "smoothing-d3", 2, False),
                                                         (4, "poisson-big", 2, False), (2, "poisson-big", 1, False), (8, "poisson", 2, False), (8, "smoothing-d3", 1, False),
                                                         (2, "poisson", 2, True), (3, "poisson", 1, True), (4, "smoothing-d3", 2, True), (4, "poisson-big", 2, True),
-                                                        (2, "poisson-big", 1, True), (8, "poisson", 2, True)])      # 8: the target's rank count
+                                                        (2, "poisson-big", 1, True), (8, "poisson", 2, True),
+                                                        (2, "cloud", 2, False), (3, "cloud", 1, False), (4, "cloud", 2, False)])      # 8: the target's rank count; cloud: blocked level 0
 def test_processes_through_ipc_handles(cabi, world, kind, shard, partition, exchange=0):
     """shard = levels partitioned over the ranks: 2 = level 0 by rows per colour and level 1 by blocks (default), 1 = level 0 only.
     partition: the SET-UP is partitioned too (gmg_dist_partition) -- every rank lays out and keeps only its rows of levels 0 (and 1);
@@ -154,7 +159,7 @@ def test_processes_through_ipc_handles(cabi, world, kind, shard, partition, exch
         assert np.array_equal(x, want_x), rank
 
 
-@pytest.mark.parametrize("world,kind,shard,partition", [(2, "poisson", 2, False), (3, "poisson", 1, False), (3, "smoothing-d3", 2, True), (4, "poisson-big", 2, True)])
+@pytest.mark.parametrize("world,kind,shard,partition", [(2, "poisson", 2, False), (3, "poisson", 1, False), (3, "smoothing-d3", 2, True), (4, "poisson-big", 2, True), (2, "cloud", 2, False)])
 def test_collective_exchange_sequence_gives_the_same_iterates(cabi, world, kind, shard, partition):
     """gmg_config::dist_exchange: every exchange of the cycle as pack -> all-gather -> unpack on the engine's stream (the north star's RCCL
     all-gather of the halo, csrc/engine_dist.hip.hpp::coll_exchange) instead of one mailbox launch.  Here with the all-gather emulated through
@@ -316,15 +321,20 @@ def test_a_missing_peer_is_an_error_not_a_hang(cabi):
     assert 3.0 <= dt <= 8.5, dt          # one 4 s wait, not one per queued exchange
 
 
-def _dropin_inputs():
+def _dropin_inputs(kind="mesh"):
     from gravo_mg_amd import meshgen
+    if kind == "cloud":                                       # kNN graph Laplacian: level 0 on the block sweep (gmg_config::block_fine), d = 1
+        P = meshgen.torus_points(20000, noise=0.002)
+        S, mass = meshgen.knn_graph_laplacian(P, 8)
+        lhs, rhs = meshgen.poisson_system(S, mass)
+        return P, meshgen.neighbors_from_stiffness(S), mass, lhs, rhs
     V, F = meshgen.torus_mesh(150, 140)
     S, mass = meshgen.cotan_laplacian(V, F)
     lhs, rhs = meshgen.smoothing_system(S, mass, V)           # the demos' call: n x 3 right-hand side
     return V, meshgen.neighbors_from_stiffness(S), mass, lhs, rhs
 
 
-def _dropin_worker(rank, world, port, q):
+def _dropin_worker(rank, world, port, q, kind="mesh"):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, os.path.join(ROOT, "gravo_mg_amd", "dropin"))
@@ -334,7 +344,7 @@ def _dropin_worker(rank, world, port, q):
         import gravomg
         from tests.test_gpu_p2p import _dropin_inputs
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-        V, neigh, mass, lhs, rhs = _dropin_inputs()
+        V, neigh, mass, lhs, rhs = _dropin_inputs(kind)
         solver = gravomg.MultigridSolver(V, neigh, sp.diags(mass).tocsc(), lower_bound=100, tolerance=1e-6)
 
         def all_gather(obj):
@@ -352,16 +362,17 @@ def _dropin_worker(rank, world, port, q):
         q.put((rank, None, None, None, traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multigridsolver_solve_as_a_collective_over_ranks(cabi, world):
+@pytest.mark.parametrize("world,kind", [(2, "mesh"), (3, "mesh"), (2, "cloud")])
+def test_multigridsolver_solve_as_a_collective_over_ranks(cabi, world, kind):
     """gravomg.MultigridSolver.enable_distributed(): solve() of the drop-in class runs the engine-driven multi-GPU cycle on the engine
     it already owns (`prepare_system` hands out its C-ABI handle) -- here `world` processes on one GPU.  Same number of V-cycles and,
-    bit for bit, the single-process solution on every rank (global colours: the partition does not change the iterates)."""
+    bit for bit, the single-process solution on every rank (global colours: the partition does not change the iterates).  cloud: a kNN operator,
+    whose level 0 runs the block sweep on one GPU and on N (partitioned by runs of whole blocks; its set-up falls back to whole operators)."""
     import scipy.sparse as sp
     import torch.multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, "gravo_mg_amd", "dropin"))
     import gravomg
-    V, neigh, mass, lhs, rhs = _dropin_inputs()
+    V, neigh, mass, lhs, rhs = _dropin_inputs(kind)
     single = gravomg.MultigridSolver(V, neigh, sp.diags(mass).tocsc(), lower_bound=100, tolerance=1e-6)
     want = single.solve(lhs, rhs)
     want_iters = int(single.solver_timing["iterations"])
@@ -370,7 +381,7 @@ def test_multigridsolver_solve_as_a_collective_over_ranks(cabi, world):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dropin_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_dropin_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
