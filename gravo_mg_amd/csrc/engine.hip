@@ -179,6 +179,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->fine_col16 = 1;
     cfg->stream_gate = 1;
     cfg->prepare_structure = 1;
+    cfg->fuse_restrict_sweep = 1;
     cfg->dist_exchange = 0;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
@@ -1621,7 +1622,7 @@ int gmg_dist_setup(gmg_handle h, int rank, int world) try {
     const LevelOrdering& o = h->lv[0].ord;
     if (h->cfg.smoother != GMG_SMOOTHER_MULTICOLOR_GS) return fail(h, GMG_ERR_STATE, "the distributed path needs the multicolour / block-hybrid smoothers (gmg_config::smoother)");
     // a blocked level 0 (gmg_config::block_fine: kNN operators) is ONE class of rows cut into `world` runs of whole 64-row blocks
-    if (o.blocked && (h->cfg.block_rows != 64 || !h->lv[0].use_ep)) return fail(h, GMG_ERR_STATE, "a blocked level 0 is partitioned only with 64-row blocks on the unpadded block storage (block_rows = 64, block_ep = 1)");
+    if (o.blocked && (h->cfg.block_rows != 64 || !h->lv[0].use_ep)) return fail(h, GMG_ERR_STATE, "a blocked level 0 is partitioned only as 64-row blocks of the entry-parallel sweep (block_rows = 64, block_ep = 1, one lane per row): set block_fine = 0 or block_lanes = 1");
     for (int c = 0; c < dist_classes(o); ++c)
         if ((o.color_begin[c + 1] - o.color_begin[c]) % (64 * world)) return fail(h, GMG_ERR_STATE, "colour classes are not aligned to 64*world rows: create the handle with row_align = 64*world");
     h->rank = rank; h->world = world; h->dist_ready = true;

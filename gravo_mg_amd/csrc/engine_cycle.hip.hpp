@@ -210,7 +210,14 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
     bool last_known = false;
     T* il = (T*)h->il_sweep_out;          // (enqueue_up: the last sweep also writes the level's x as an interleaved multi-vector)
     h->il_sweep_out = nullptr; h->il_sweep_done = false;
-    for (int it = 0; it < iters; ++it) {
+    int it0 = 0;
+    if (from_zero && h->first_sweep_fused) {      // the restriction into this level already ran the first sweep (launch_restrict_sweep0): its result is in tmp
+        h->first_sweep_fused = false;
+        before_last = nullptr; last_known = true;
+        in = out; out = Prec<T>::x(l);
+        it0 = 1;
+    }
+    for (int it = it0; it < iters; ++it) {
         const bool with_il = il && it == iters - 1 && l.use_ep && d > 1 && d <= 4;
         launch_block_sweep_range<T>(h, l, d, in, out, 0, nb, nullptr, nullptr, with_il ? il : nullptr);
         if (with_il) h->il_sweep_done = true;
@@ -323,6 +330,42 @@ template <class T>
 void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, T* dst, bool src_il = false) {
     if (fine.R.lpr == 4) launch_restrict_lpr<T, 4>(h, fine, coarse, d, src, dst, src_il);
     else launch_restrict_lpr<T, 1>(h, fine, coarse, d, src, dst, src_il);
+}
+
+// coarse.b = U^T fine.r AND the first pre-sweep of the coarse level from the zero iterate, in one launch (kernels.hip.hpp::restrict_sweep0), where the
+// layouts allow it: the coarse level runs the entry-parallel block sweep on blocks b = rows 64 b .., its restriction has the quad layout with
+// 64-row sorting windows (a workgroup's four slices = one block), and the level's pre-smoothing starts from zero.  The coarse level's
+// launch_block_sweeps then starts with its second sweep (h->first_sweep_fused).
+template <class T>
+bool restrict_sweep0_ok(gmg_handle h, const Level& fine, const Level& coarse, int d) {
+    if (!h->cfg.fuse_restrict_sweep || h->cfg.smoother == GMG_SMOOTHER_JACOBI || h->cfg.pre_iters <= 0 || d > 4) return false;
+    if (!coarse.ord.blocked || !coarse.use_ep || fine.R.lpr != 4 || !(h->cfg.restrict_sigma == 0 || h->cfg.restrict_sigma == 64)) return false;
+    return coarse.n_pad == 64 * coarse.ord.n_blocks() && fine.R.n_slices == 4 * coarse.ord.n_blocks();      // (use_ep: block b = rows 64 b .. 64 b + 63)
+}
+template <class T>
+void launch_restrict_sweep0(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, bool src_il) {
+    const int nb = coarse.ord.n_blocks();
+    const int vgrid = (nb + 7) / 8 * 8;
+    const size_t lds_sweep = gmgk::ep_lds_bytes<T>(d, 0, coarse.ep_cap_l);
+    const size_t lds = lds_sweep + (size_t)d * 64 * sizeof(T);
+    T* bdst = Prec<T>::b(coarse);
+    T* xdst = Prec<T>::tmp(coarse);               // (the result of a from-zero first sweep lives in tmp: launch_block_sweeps)
+#define GMG_RS0(XI_)                                                                                                                                        \
+    DISPATCH_D(d, DISPATCH_C16(fine.R.c16_sel(), {                                                                                                           \
+        if (ep_streams(coarse))                                                                                                                              \
+            hipLaunchKernelGGL((gmgk::restrict_sweep0<T, D, true, C16, (XI_ && D > 1)>), dim3(vgrid), dim3(256), lds, h->stream, fine.R.slice_ptr, fine.R.col,   \
+                               Prec<T>::val(fine.R), fine.R.row_of, src, fine.n_pad, fine.R.col16, fine.R.win_base, fine.R.c16_arg(), bdst, coarse.d_blk_ncolors,      \
+                               coarse.d_row_color, coarse.ep_ptr, coarse.ep_col, Prec<T>::epval(coarse), Prec<T>::diag(coarse), xdst, coarse.n_pad, nb, vgrid,       \
+                               (int)lds_sweep);                                                                                                              \
+        else                                                                                                                                                 \
+            hipLaunchKernelGGL((gmgk::restrict_sweep0<T, D, false, C16, (XI_ && D > 1)>), dim3(vgrid), dim3(256), lds, h->stream, fine.R.slice_ptr, fine.R.col,  \
+                               Prec<T>::val(fine.R), fine.R.row_of, src, fine.n_pad, fine.R.col16, fine.R.win_base, fine.R.c16_arg(), bdst, coarse.d_blk_ncolors,      \
+                               coarse.d_row_color, coarse.ep_ptr, coarse.ep_col, Prec<T>::epval(coarse), Prec<T>::diag(coarse), xdst, coarse.n_pad, nb, vgrid,       \
+                               (int)lds_sweep);                                                                                                              \
+    }))
+    if (src_il && d > 1) { GMG_RS0(1); } else { GMG_RS0(0); }
+#undef GMG_RS0
+    h->first_sweep_fused = true;
 }
 
 // fine.x += U coarse.x   (U has <= 3 entries per row: always one lane per row)
@@ -583,6 +626,7 @@ inline void prof_mark(gmg_handle h) {
 template <class T = double>
 void enqueue_down(gmg_handle h, int d, int k0 = 0) {
     const int L = h->L;
+    h->first_sweep_fused = false;                  // (set by launch_restrict_sweep0 for the level that follows)
     for (int k = k0; k < L; ++k) {
         Level& l = h->lv[k];
         prof_mark(h);
@@ -605,7 +649,11 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         // :1066.  Straight after block sweeps on the unpadded block storage the residual comes from the sweep's explicit part alone
         if (!(k > 0 && launch_residual_delta<T>(h, l, d, Prec<T>::r(l))))
             launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices, il);
-        launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]), il);    // :1069
+        // :1069 (+ the first pre-sweep of level k + 1 where the layouts allow the two in one launch)
+        if (k + 1 < L && restrict_sweep0_ok<T>(h, l, h->lv[k + 1], d) && smooth_from_zero_ok(h, h->lv[k + 1], h->cfg.pre_iters))
+            launch_restrict_sweep0<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), il);
+        else
+            launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]), il);
         h->il_r0 = false;
     }
     prof_mark(h);

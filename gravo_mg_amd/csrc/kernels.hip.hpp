@@ -589,6 +589,100 @@ template <class T> inline size_t ep_lds_bytes(int D, int cap_e, int cap_l) {
     return (size_t)D * 64 * sizeof(T) + kEpZeroBytes + stage;
 }
 
+// The sequential half of the entry-parallel block sweep (gs_block_ep below; also the tail of gmgk::restrict_sweep0): the lower in-block entries go
+// through LDS into the row's lane, then the colours of the block one after the other on the block's x in LDS, then the store.  `rhs` = b minus
+// the explicit part.  One wave = one block; every __syncthreads() here is reached by exactly the waves of the workgroup that are still alive.
+template <class T, int D>
+__device__ __forceinline__ void ep_block_lower(T* xs, T* zeroT, typename EpRec<T>::type* srec, int lane, int row, int blk, int q0, int nL, int lb, int nlow, int mycolor, T dg,
+                                               T (&rhs)[D], T (&lv)[kEpL], unsigned short (&lc)[kEpL], const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
+                                               const int* __restrict__ blk_ncolors, T* __restrict__ x_out, int ld, T* __restrict__ x_out_i) {
+    typedef typename EpRec<T>::type Rec;
+    const Rec* zeroR = reinterpret_cast<const Rec*>(zeroT);
+    // ---- L: slots -> LDS (records: value, byte offset of the column in xs) -> the row's lane
+    auto make_rec = [](T val, unsigned short col) {
+        Rec rr;
+        if constexpr (sizeof(T) == 8) { long long bits; __builtin_memcpy(&bits, &val, 8); rr.x = (int)bits; rr.y = (int)(bits >> 32); rr.z = (int)col * 8; rr.w = 0; }
+        else { int bits; __builtin_memcpy(&bits, &val, 4); rr.x = bits; rr.y = (int)col * 4; }
+        return rr;
+    };
+#pragma unroll
+    for (int m = 0; m < kEpL; ++m) srec[64 * m + lane] = make_rec(lv[m], lc[m]);
+    if (nL > 64 * kEpL)
+        for (int e = 64 * kEpL + lane; e < nL; e += 64) srec[e] = make_rec(l_val[q0 + e], l_col[q0 + e]);
+    __syncthreads();
+    T v[kEpW];
+    int xa[kEpW];                                                      // byte offsets of the columns inside xs (column 0 of a multi-vector)
+    {
+        const Rec* ra = srec + lb;
+#pragma unroll
+        for (int j = 0; j < kEpW; ++j) {                               // (one select of the ADDRESS: slots beyond the row's run read a zero record)
+            const Rec rr = (j < nlow ? ra : zeroR)[j];
+            if constexpr (sizeof(T) == 8) { const long long bits = ((long long)(unsigned)rr.x) | ((long long)rr.y << 32); __builtin_memcpy(&v[j], &bits, 8); xa[j] = rr.z; }
+            else { const int bits = rr.x; __builtin_memcpy(&v[j], &bits, 4); xa[j] = rr.y; }
+        }
+    }
+    const int nc = blk_ncolors[blk];
+    // four lower entries of this lane's row: all gathers in flight, then the FMAs in stored order
+    auto chunk4 = [&](int j0, T (&s_)[D]) {
+        T xv[4][D];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < D; ++c) xv[j][c] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(xs + c * 64) + xa[j0 + j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
+    };
+    int col0 = 0;
+    // rows of the first colour have no lower entries (rows of one colour do not couple): their update is rhs / diag, written by every lane
+    // at once -- the other lanes' values are overwritten when their colour comes (nothing reads them before: a row's lower entries
+    // point at earlier colours only)
+    if (!__builtin_amdgcn_ballot_w64(mycolor == 0 && nlow > 0)) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - (T)0.0) * dg;
+        col0 = 1;
+        __syncthreads();
+    }
+    for (int col = col0; col < nc; ++col) {
+        if (mycolor == col) {
+            T s_[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) s_[c] = (T)0.0;
+            // (wave-uniform tests: most rows of the early colours have few lower entries)
+            if (__builtin_amdgcn_ballot_w64(nlow > 0)) {
+                chunk4(0, s_);
+                if (__builtin_amdgcn_ballot_w64(nlow > 4)) {
+                    chunk4(4, s_);
+                    if (__builtin_amdgcn_ballot_w64(nlow > 8)) {
+                        chunk4(8, s_);
+                        if (__builtin_amdgcn_ballot_w64(nlow > 12)) {
+                            chunk4(12, s_);
+                            for (int j = kEpW; j < nlow; ++j) {       // rows with more lower entries than the register window (rare)
+                                const Rec rr = srec[lb + j];
+                                T vj; int cb;
+                                if constexpr (sizeof(T) == 8) { const long long bits = ((long long)(unsigned)rr.x) | ((long long)rr.y << 32); __builtin_memcpy(&vj, &bits, 8); cb = rr.z; }
+                                else { const int bits = rr.x; __builtin_memcpy(&vj, &bits, 4); cb = rr.y; }
+#pragma unroll
+                                for (int c = 0; c < D; ++c) s_[c] += vj * *reinterpret_cast<const T*>(reinterpret_cast<const char*>(xs + c * 64) + cb);
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - s_[c]) * dg;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
+    if (x_out_i) {                                                     // a second copy as an interleaved multi-vector (what the prolongation into the finer level gathers from)
+#pragma unroll
+        for (int c = 0; c < D; ++c) x_out_i[(int64_t)row * D + c] = xs[c * 64 + lane];
+    }
+}
+
 // Round 4: the sweep is bound by the INSTRUCTIONS a wave issues -- a SIMD retires one block every ~3.2 us whether four or five
 // waves share it (persistent launches with 8 ... 20 workgroups per compute unit: 12 us per block and wave up to 4 waves per SIMD,
 // 16.5 us with 5; profiles/README.md round 4), 1 375 instructions per block at ~5.5 cycles each, of which the guarded loads (a
@@ -689,91 +783,83 @@ __global__ __launch_bounds__(64) void gs_block_ep(const int* __restrict__ blk_be
             __syncthreads();                                           // the buffer is free again
         }
     }
-    // ---- L: slots -> LDS (records: value, byte offset of the column in xs) -> the row's lane
-    auto make_rec = [](T val, unsigned short col) {
-        Rec rr;
-        if constexpr (sizeof(T) == 8) { long long bits; __builtin_memcpy(&bits, &val, 8); rr.x = (int)bits; rr.y = (int)(bits >> 32); rr.z = (int)col * 8; rr.w = 0; }
-        else { int bits; __builtin_memcpy(&bits, &val, 4); rr.x = bits; rr.y = (int)col * 4; }
-        return rr;
-    };
-#pragma unroll
-    for (int m = 0; m < kEpL; ++m) srec[64 * m + lane] = make_rec(lv[m], lc[m]);
-    if (nL > 64 * kEpL)
-        for (int e = 64 * kEpL + lane; e < nL; e += 64) srec[e] = make_rec(l_val[q0 + e], l_col[q0 + e]);
-    __syncthreads();
-    T v[kEpW];
-    int xa[kEpW];                                                      // byte offsets of the columns inside xs (column 0 of a multi-vector)
-    {
-        const Rec* ra = srec + lb;
-#pragma unroll
-        for (int j = 0; j < kEpW; ++j) {                               // (one select of the ADDRESS: slots beyond the row's run read a zero record)
-            const Rec rr = (j < nlow ? ra : zeroR)[j];
-            if constexpr (sizeof(T) == 8) { const long long bits = ((long long)(unsigned)rr.x) | ((long long)rr.y << 32); __builtin_memcpy(&v[j], &bits, 8); xa[j] = rr.z; }
-            else { const int bits = rr.x; __builtin_memcpy(&v[j], &bits, 4); xa[j] = rr.y; }
-        }
-    }
-    const int nc = blk_ncolors[blk];
-    // four lower entries of this lane's row: all gathers in flight, then the FMAs in stored order
-    auto chunk4 = [&](int j0, T (&s_)[D]) {
-        T xv[4][D];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < D; ++c) xv[j][c] = *reinterpret_cast<const T*>(reinterpret_cast<const char*>(xs + c * 64) + xa[j0 + j]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int c = 0; c < D; ++c) s_[c] += v[j0 + j] * xv[j][c];
-    };
-    int col0 = 0;
-    // rows of the first colour have no lower entries (rows of one colour do not couple): their update is rhs / diag, written by every lane
-    // at once -- the other lanes' values are overwritten when their colour comes (nothing reads them before: a row's lower entries
-    // point at earlier colours only)
-    if (!__builtin_amdgcn_ballot_w64(mycolor == 0 && nlow > 0)) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - (T)0.0) * dg;
-        col0 = 1;
-        __syncthreads();
-    }
-    for (int col = col0; col < nc; ++col) {
-        if (mycolor == col) {
-            T s_[D];
-#pragma unroll
-            for (int c = 0; c < D; ++c) s_[c] = (T)0.0;
-            // (wave-uniform tests: most rows of the early colours have few lower entries)
-            if (__builtin_amdgcn_ballot_w64(nlow > 0)) {
-                chunk4(0, s_);
-                if (__builtin_amdgcn_ballot_w64(nlow > 4)) {
-                    chunk4(4, s_);
-                    if (__builtin_amdgcn_ballot_w64(nlow > 8)) {
-                        chunk4(8, s_);
-                        if (__builtin_amdgcn_ballot_w64(nlow > 12)) {
-                            chunk4(12, s_);
-                            for (int j = kEpW; j < nlow; ++j) {       // rows with more lower entries than the register window (rare)
-                                const Rec rr = srec[lb + j];
-                                T vj; int cb;
-                                if constexpr (sizeof(T) == 8) { const long long bits = ((long long)(unsigned)rr.x) | ((long long)rr.y << 32); __builtin_memcpy(&vj, &bits, 8); cb = rr.z; }
-                                else { const int bits = rr.x; __builtin_memcpy(&vj, &bits, 4); cb = rr.y; }
-#pragma unroll
-                                for (int c = 0; c < D; ++c) s_[c] += vj * *reinterpret_cast<const T*>(reinterpret_cast<const char*>(xs + c * 64) + cb);
-                            }
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < D; ++c) xs[c * 64 + lane] = (rhs[c] - s_[c]) * dg;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int c = 0; c < D; ++c) x_out[row + (int64_t)c * ld] = xs[c * 64 + lane];
-    if (x_out_i) {                                                     // a second copy as an interleaved multi-vector (what the prolongation into the finer level gathers from)
-#pragma unroll
-        for (int c = 0; c < D; ++c) x_out_i[(int64_t)row * D + c] = xs[c * 64 + lane];
-    }
+    ep_block_lower<T, D>(xs, zeroT, srec, lane, row, blk, q0, nL, lb, nlow, mycolor, dg, rhs, lv, lc, l_col, l_val, blk_ncolors, x_out, ld, x_out_i);
     __syncthreads();                                                   // xs and the staging area are free for the next block
   }
+}
+
+// Restriction INTO a blocked level fused with that level's first pre-sweep (multigrid_solver.cpp:1069 + :1072-1073 + the first trip of :1063).
+// The coarse correction starts from the zero iterate, so its first block sweep needs nothing but the right-hand side of its own block: no
+// explicit part, no halo.  The restriction (quad layout: 16 coarse rows per slice, rows length-sorted inside 64-row windows) produces exactly
+// the 64 right-hand sides of block b in the four slices 4 b .. 4 b + 3 -- one workgroup of four waves -- so the same workgroup goes on: the
+// values are written to b (the later sweeps and the residual read them) AND kept in LDS, wave 0 runs the sequential half of the block sweep
+// on them (ep_block_lower) and writes the level's first iterate.  One launch less per level and cycle, and b is not read back; the arithmetic
+// of both halves is that of transfer<.., 0, 4, ..> and gs_block_ep<..>(x_in = nullptr): the same bits.
+// Grid: vgrid = n_blocks rounded up to 8 workgroups of 256 threads (the XCD-aware block map of gs_block_ep).  Dynamic LDS: ep_lds_bytes(D, 0, cap_l)
+// + D * 64 values (bs_off: where those begin).
+template <class T, int D, bool STREAM, int C16, int XI>
+__global__ __launch_bounds__(256) void restrict_sweep0(const int64_t* __restrict__ r_slice_ptr, const int* __restrict__ r_col, const T* __restrict__ r_val,
+                                                       const int* __restrict__ r_row_of, const T* __restrict__ r_fine, int ldx,
+                                                       const unsigned* __restrict__ r_col16, const int* __restrict__ r_win_base, int r_c16_arg,
+                                                       T* __restrict__ b_out, const int* __restrict__ blk_ncolors, const unsigned char* __restrict__ row_color,
+                                                       const int* __restrict__ l_ptr, const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
+                                                       const T* __restrict__ diag, T* __restrict__ x_out, int ld, int n_blocks, int vgrid, int bs_off) {
+    extern __shared__ unsigned char smem_raw[];
+    T* xs = reinterpret_cast<T*>(smem_raw);
+    typedef typename EpRec<T>::type Rec;
+    T* zeroT = xs + D * 64;
+    Rec* srec = reinterpret_cast<Rec*>(zeroT + kEpZeroBytes / sizeof(T));
+    T* bs = reinterpret_cast<T*>(smem_raw + bs_off);
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int chunk = vgrid >> 3;
+    const int blk = __builtin_amdgcn_readfirstlane(((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3));
+    if (blk >= n_blocks) return;
+    const int r0 = blk << 6;
+    // wave 0: everything the sweep will need is requested before the restriction's own loads
+    int q0 = 0, nL = 0, lb = 0, nlow = 0, mycolor = 0;
+    T dg = (T)1.0;
+    T lv[kEpL];
+    unsigned short lc[kEpL];
+    if (wave == 0) {
+        reinterpret_cast<int*>(zeroT)[lane] = 0;
+        const int row = r0 + lane;
+        q0 = l_ptr[r0];
+        nL = l_ptr[r0 + 64] - q0;
+        const __amdgpu_buffer_rsrc_t rlv = ep_chunk(l_val + q0, nL * (int)sizeof(T)), rlc = ep_chunk(l_col + q0, nL * 2);
+#pragma unroll
+        for (int m = 0; m < kEpL; ++m) { lv[m] = ep_load<T, STREAM>(rlv, lane * (int)sizeof(T) + 64 * m * (int)sizeof(T)); lc[m] = ep_load<unsigned short, STREAM>(rlc, lane * 2 + 128 * m); }
+        lb = l_ptr[row] - q0;
+        nlow = l_ptr[row + 1] - q0 - lb;
+        mycolor = row_color[row];
+        dg = (T)1.0 / diag[row];
+#pragma unroll
+        for (int c = 0; c < D; ++c) { bs[c * 64 + lane] = (T)0.0; xs[c * 64 + lane] = (T)0.0; }      // (padding rows of the block: right-hand side zero)
+    } else {
+#pragma unroll
+        for (int m = 0; m < kEpL; ++m) { lv[m] = (T)0.0; lc[m] = 0; }
+    }
+    __syncthreads();
+    {   // ---- the restriction of slice 4 blk + wave (transfer_slice<T, D, 0, 4, C16, XI>)
+        const int s = 4 * blk + wave;
+        const int srow = s * 16 + lane / 4;
+        T acc[D];
+        row_dot_sel<T, D, C16, 8, XI>(r_slice_ptr, r_col, r_col16, r_win_base, r_c16_arg, r_val, r_fine, ldx, s, lane, acc);
+        quad_reduce<T, D>(acc);
+        if ((lane & 3) == 0) {
+            const int row = r_row_of ? r_row_of[srow] : srow;
+            if (row >= 0) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) { b_out[row + (int64_t)c * ld] = acc[c]; bs[c * 64 + (row - r0)] = acc[c]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    // ---- wave 0: the block sweep from the zero iterate (gs_block_ep with x_in == nullptr)
+    T rhs[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) rhs[c] = bs[c * 64 + lane];
+    ep_block_lower<T, D>(xs, zeroT, srec, lane, r0 + lane, blk, q0, nL, lb, nlow, mycolor, dg, rhs, lv, lc, l_col, l_val, blk_ncolors, x_out, ld, (T*)nullptr);
 }
 
 // Residual of a blocked level RIGHT AFTER a block-hybrid sweep x_old -> x_new, from the sweep's own explicit part: the sweep solved
@@ -1078,10 +1164,21 @@ __device__ __forceinline__ void block_reduce_partials(const double* __restrict__
     double v[kReduceMaxComp];
 #pragma unroll
     for (int c = 0; c < kReduceMaxComp; ++c) v[c] = 0.0;
-    for (int i = threadIdx.x; i < n_blocks; i += kReduceBlock)
+    // (four strides of partials in flight per thread -- the loads of a stride are independent, the additions keep the order i, i + 1024, ...: at
+    // d = 3 the check's 5 000 x 6 sums took five dependent round trips, 12.5 us of a 1 ms cycle)
+    for (int i0 = threadIdx.x; i0 < n_blocks; i0 += 4 * kReduceBlock) {
+        double t[4][kReduceMaxComp];
 #pragma unroll
-        for (int c = 0; c < kReduceMaxComp; ++c)
-            if (c < ncomp) v[c] += partials[(int64_t)i * ncomp + c];
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kReduceBlock;
+#pragma unroll
+            for (int c = 0; c < kReduceMaxComp; ++c) t[u][c] = (c < ncomp && i < n_blocks) ? partials[(int64_t)i * ncomp + c] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < kReduceMaxComp; ++c) v[c] += t[u][c];
+    }
 #pragma unroll
     for (int c = 0; c < kReduceMaxComp; ++c) {
         if (c >= ncomp) break;

@@ -106,7 +106,8 @@ typedef struct {
                               graph Laplacians of point clouds; 2 M points: 11 colour launches per sweep -> 1).  Triangle-mesh
                               operators (7 entries per row, 4-7 colours) keep the over-relaxed multicolour sweep, Bilaplacians fail the
                               sign test.  The blocks are runs of 64 points of the hierarchy's cluster order.  0: level 0 is blocked only
-                              by block_from_level = 0.  The multi-GPU path (gmg_p2p_*) needs the colour-major level 0: set 0 there */
+                              by block_from_level = 0.  The multi-GPU path (gmg_p2p_*) cuts such a level 0 into runs of whole blocks, one halo
+                              exchange per sweep (a PARTITIONED set-up, gmg_dist_partition, keeps level 0 colour-major) */
     int fine_col16;        /* 1 (default): level 0 keeps, beside the int32 column indices, 16-bit column codes (window of the slice + offset, two to
                               a word) that its kernels read instead: 2 of an entry's 12 bytes less per launch, the same columns in the same order
                               (DESIGN.md section 3); 0: 32-bit indices only */
@@ -122,6 +123,9 @@ typedef struct {
                               builds everything structural for a system with that sparsity pattern -- orderings, colourings, layouts, symbolic Galerkin
                               products, symbolic LDL^T -- so that the first gmg_set_system with it only moves values.  0: the first system pays for its
                               structure like any system with an unannounced pattern */
+    int fuse_restrict_sweep; /* 1 (default): the restriction into a level that runs the entry-parallel block sweep also runs that level's first pre-sweep
+                              (the coarse correction starts from zero, multigrid_solver.cpp:1072-1073: its first sweep needs only the block's own right-hand
+                              sides) -- one launch less per such level and cycle, the same bits; 0: two launches */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -190,9 +190,15 @@ def test_engine_variants_on_a_blocked_fine_level(cabi, oracle, kw):
     assert res3 <= 1e-4 and np.allclose(x3[:, :1], x, rtol=0, atol=1e-6 * np.abs(x).max())
 
 
-def test_the_distributed_path_says_what_it_needs(cabi):
+def test_the_distributed_path_takes_a_blocked_level_0(cabi):
+    """A blocked level 0 is partitioned by runs of whole 64-row blocks of the entry-parallel sweep (round 6: the same smoother at every rank count,
+    tests/test_gpu_p2p.py runs it): the block count is padded to a multiple of the rank count (gmg_config::row_align = 64 P); a colour sweep
+    is refused on such a level (its sweep is a block sweep)."""
     P = _cloud()
     e = _engine(cabi, P, row_align=128)
-    with pytest.raises(cabi.GmgError, match="block_fine"):
-        e.dist_setup(0, 2)
+    e.dist_setup(0, 2)
+    assert e.level_blocks(0) is not None and (e.level_info(0)["n_pad"] // 64) % 2 == 0
+    three = _engine(cabi, P, row_align=192)
+    three.dist_setup(1, 3)
+    assert (three.level_info(0)["n_pad"] // 64) % 3 == 0
     _engine(cabi, P, row_align=128, block_fine=0).dist_setup(0, 2)
