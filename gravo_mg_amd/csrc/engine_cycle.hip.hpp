@@ -336,15 +336,27 @@ void launch_restrict(gmg_handle h, Level& fine, Level& coarse, int d, const T* s
 // layouts allow it: the coarse level runs the entry-parallel block sweep on blocks b = rows 64 b .., its restriction has the quad layout with
 // 64-row sorting windows (a workgroup's four slices = one block), and the level's pre-smoothing starts from zero.  The coarse level's
 // launch_block_sweeps then starts with its second sweep (h->first_sweep_fused).
+// which fused form the restriction into `coarse` takes: 0 none, 1 restrict_sweep0 (entry-parallel sweep), 2 gs_block4<.., FR = true> (quad layout)
 template <class T>
-bool restrict_sweep0_ok(gmg_handle h, const Level& fine, const Level& coarse, int d) {
-    if (!h->cfg.fuse_restrict_sweep || h->cfg.smoother == GMG_SMOOTHER_JACOBI || h->cfg.pre_iters <= 0 || d > 4) return false;
-    if (!coarse.ord.blocked || !coarse.use_ep || fine.R.lpr != 4 || !(h->cfg.restrict_sigma == 0 || h->cfg.restrict_sigma == 64)) return false;
-    return coarse.n_pad == 64 * coarse.ord.n_blocks() && fine.R.n_slices == 4 * coarse.ord.n_blocks();      // (use_ep: block b = rows 64 b .. 64 b + 63)
+int restrict_sweep0_kind(gmg_handle h, const Level& fine, const Level& coarse, int d, bool src_il) {
+    if (!h->cfg.fuse_restrict_sweep || h->cfg.smoother == GMG_SMOOTHER_JACOBI || h->cfg.pre_iters <= 0 || d > 4) return 0;
+    if (!coarse.ord.blocked || fine.R.lpr != 4 || !(h->cfg.restrict_sigma == 0 || h->cfg.restrict_sigma == 64)) return 0;
+    if (coarse.use_ep) return (coarse.n_pad == 64 * coarse.ord.n_blocks() && fine.R.n_slices == 4 * coarse.ord.n_blocks()) ? 1 : 0;      // (block b = rows 64 b .. 64 b + 63)
+    // quad layout: a wave of the block sweep covers the 16 rows of one restriction slice; plain 32-bit restriction, column-major source
+    if (!(coarse.use_bcsr && d > 1) && coarse.Ain.lpr == 4 && fine.R.c16_mode == 0 && !src_il && fine.R.n_slices * 16 == coarse.n_pad) return 2;
+    return 0;
 }
 template <class T>
-void launch_restrict_sweep0(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, bool src_il) {
+void launch_restrict_sweep0(gmg_handle h, Level& fine, Level& coarse, int d, const T* src, bool src_il, int kind) {
     const int nb = coarse.ord.n_blocks();
+    if (kind == 2) {
+        DISPATCH_D(d, hipLaunchKernelGGL((gmgk::gs_block4<T, D, 8, true>), dim3(nb), dim3(4 * h->cfg.block_rows), 0, h->stream, coarse.d_blk_begin, coarse.d_blk_ncolors,
+                                         coarse.d_row_color, coarse.Ain.slice_ptr, coarse.ain_col16, Prec<T>::val(coarse.Ain), coarse.Aout.slice_ptr, coarse.Aout.col,
+                                         Prec<T>::val(coarse.Aout), Prec<T>::diag(coarse), (const T*)nullptr, (const T*)nullptr, Prec<T>::tmp(coarse), coarse.n_pad,
+                                         fine.R.slice_ptr, fine.R.col, Prec<T>::val(fine.R), fine.R.row_of, src, fine.n_pad, Prec<T>::b(coarse)));
+        h->first_sweep_fused = true;
+        return;
+    }
     const int vgrid = (nb + 7) / 8 * 8;
     const size_t lds_sweep = gmgk::ep_lds_bytes<T>(d, 0, coarse.ep_cap_l);
     const size_t lds = lds_sweep + (size_t)d * 64 * sizeof(T);
@@ -650,8 +662,8 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         if (!(k > 0 && launch_residual_delta<T>(h, l, d, Prec<T>::r(l))))
             launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices, il);
         // :1069 (+ the first pre-sweep of level k + 1 where the layouts allow the two in one launch)
-        if (k + 1 < L && restrict_sweep0_ok<T>(h, l, h->lv[k + 1], d) && smooth_from_zero_ok(h, h->lv[k + 1], h->cfg.pre_iters))
-            launch_restrict_sweep0<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), il);
+        const int fused = (k + 1 < L && smooth_from_zero_ok(h, h->lv[k + 1], h->cfg.pre_iters)) ? restrict_sweep0_kind<T>(h, l, h->lv[k + 1], d, il) : 0;
+        if (fused) launch_restrict_sweep0<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), il, fused);
         else
             launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]), il);
         h->il_r0 = false;

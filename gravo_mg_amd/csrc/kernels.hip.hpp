@@ -937,15 +937,22 @@ __global__ __launch_bounds__(64) void residual_delta_ep(const int* __restrict__ 
 // row is spread over four lanes: each lane keeps <= WQ in-block entries in registers, gathers them from LDS in one
 // batch, and the quad adds its four partial sums with two cross-lane steps.  Same mathematics as gs_block.
 constexpr int kQuadBlockRows = 256;
-template <class T, int D, int WQ>
+// FR (restriction fused, like restrict_sweep0 for the entry-parallel levels): the level's first pre-sweep starts from zero (x_in == nullptr), and a wave's
+// 16 rows are exactly one slice of the restriction INTO this level (quad layout, rows sorted inside 64-row windows, blocks are multiples of 64
+// rows): the wave first forms those right-hand sides (transfer<.., 0, 4>'s arithmetic), writes them to b_out and leaves them in LDS for the sweep.
+template <class T, int D, int WQ, bool FR = false>
 __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ blk_begin, const int* __restrict__ blk_ncolors,
                                                         const unsigned char* __restrict__ row_color,
                                                         const int64_t* __restrict__ in_ptr, const unsigned short* __restrict__ in_col,
                                                         const T* __restrict__ in_val, const int64_t* __restrict__ out_ptr,
                                                         const int* __restrict__ out_col, const T* __restrict__ out_val,
                                                         const T* __restrict__ diag, const T* __restrict__ b,
-                                                        const T* __restrict__ x_in, T* __restrict__ x_out, int ld) {
+                                                        const T* __restrict__ x_in, T* __restrict__ x_out, int ld,
+                                                        const int64_t* __restrict__ r_slice_ptr = nullptr, const int* __restrict__ r_col = nullptr,
+                                                        const T* __restrict__ r_val = nullptr, const int* __restrict__ r_row_of = nullptr,
+                                                        const T* __restrict__ r_fine = nullptr, int ldx = 0, T* __restrict__ b_out = nullptr) {
     __shared__ T xs[D][kQuadBlockRows];
+    __shared__ T bs[FR ? D : 1][FR ? kQuadBlockRows : 1];
     const int blk = blockIdx.x;
     const int r0 = blk_begin[blk];
     const int nrows = blk_begin[blk + 1] - r0;            // multiple of 64, <= 256
@@ -987,10 +994,38 @@ __global__ __launch_bounds__(kBlockRows) void gs_block4(const int* __restrict__ 
 #pragma unroll
             for (int c = 0; c < D; ++c) acc[c] = 0.0;
         }
+        if constexpr (!FR) {
 #pragma unroll
-        for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
+            for (int c = 0; c < D; ++c) rhs[c] = b[row + (int64_t)c * ld] - acc[c];
+        }
         dg = 1.0 / diag[row];
         mycolor = row_color[row];
+    }
+    if constexpr (FR) {
+        if (active && writer) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) bs[c][lrow] = (T)0.0;          // (padding rows of the block: right-hand side zero)
+        }
+        __syncthreads();
+        if (active) {
+            const int s = (r0 >> 4) + wave;
+            T racc[D];
+            row_dot_sel<T, D, 0, 8, 0>(r_slice_ptr, r_col, (const unsigned*)nullptr, (const int*)nullptr, 0, r_val, r_fine, ldx, s, lane, racc);
+            quad_reduce<T, D>(racc);
+            if (writer) {
+                const int srow = s * 16 + (lane >> 2);
+                const int orow = r_row_of ? r_row_of[srow] : srow;
+                if (orow >= 0) {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) { b_out[orow + (int64_t)c * ld] = racc[c]; bs[c][orow - r0] = racc[c]; }
+                }
+            }
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) rhs[c] = bs[c][lrow];
+        }
     }
     __syncthreads();
     const int nc = blk_ncolors[blk];

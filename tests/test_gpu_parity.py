@@ -531,19 +531,19 @@ def test_device_built_coarse_inverse_against_the_host_factor(cabi, oracle, n1, n
     assert itd == ith and abs(resd - resh) <= 1e-3 * resh      # (tau = 1e-6: cond(A_L) ~ 1e8 -- the two coarse solves differ by cond x eps)
 
 
-@pytest.mark.parametrize("kind,d", [("poisson", 1), ("smoothing", 3), ("cloud", 1), ("poisson-mixed", 1)])
+@pytest.mark.parametrize("kind,d", [("poisson", 1), ("smoothing", 3), ("cloud", 1), ("poisson-mixed", 1), ("poisson-quad", 1), ("smoothing-quad", 3), ("poisson-quad-mixed", 1)])
 def test_restriction_fused_with_the_first_pre_sweep_gives_the_same_bits(cabi, kind, d):
     """gmg_config::fuse_restrict_sweep: the restriction into a level on the entry-parallel block sweep also runs that level's first pre-sweep
     (gmgk::restrict_sweep0: the coarse correction starts from zero, multigrid_solver.cpp:1069 + 1072-1073 + the first trip of :1063).  Same operations
     as transfer + gs_block_ep in two launches: cycles and solution bit for bit, for d = 1 and 3 (level-0 residual interleaved), a point cloud
-    (blocked level 0) and the fp32 inner cycle."""
+    (blocked level 0) and the fp32 inner cycle; -quad: the small levels keep their quad layout, where the fused form is gs_block4<.., FR = true>."""
     from tests import problems
     if kind == "cloud":
         P = problems.pointcloud_problem(9000, 8, 120)
     else:
-        P = problems.torus_problem(300, 280, "smoothing" if kind == "smoothing" else "poisson", 100)
-    kw = dict(block_lanes=1)            # (one lane per row: the small levels of these problems take the big levels' layout -- the entry-parallel sweep)
-    if kind == "poisson-mixed":
+        P = problems.torus_problem(300, 280, "smoothing" if kind.startswith("smoothing") else "poisson", 100)
+    kw = {} if "quad" in kind else dict(block_lanes=1)            # (one lane per row: the small levels of these problems take the big levels' layout -- the entry-parallel sweep)
+    if "mixed" in kind:
         kw["inner_precision"] = 1
     out = []
     for fuse in (1, 0):
