@@ -2,8 +2,9 @@
 //
 // One handle = one HIP device, one stream.  The hierarchy (all A_k as SELL-64 + diagonal, all U_k / U_k^T) is built on
 // the device once per system (gmg_set_system); a V-cycle is a fixed launch sequence on that stream (smooth -> residual
-// -> restrict ... coarse solve ... prolong-add -> smooth), optionally captured into hipGraphs.  The coarsest direct
-// solve stays on the host (supernodal LDL^T, host_ldlt.hpp) unless GMG_COARSE_DEVICE_INVERSE is selected.
+// -> restrict ... coarse solve ... prolong-add -> smooth), optionally captured into hipGraphs.  The coarsest operator is
+// factored on the host (supernodal LDL^T, host_ldlt.hpp); per cycle it is applied as a dense inverse on the device (built on
+// the device from that factor; gmg_config::coarse_mode = GMG_COARSE_AUTO, the default) or back-substituted on the host.
 //
 // One translation unit, in four files: engine_state.hip.hpp (memory pool, level / handle structures, helpers),
 // engine_setup.hip.hpp (device-side layout construction, Galerkin products), engine_cycle.hip.hpp (launch helpers,

@@ -213,7 +213,7 @@ class MultigridSolver(object):
 
     def set_engine_option(self, key, value):
         """MI355X engine knobs (not upstream): smoother (0 multicolour Gauss-Seidel, 1 weighted Jacobi), gs_omega, jacobi_omega,
-        coarse_mode (0 host LDL^T, 1 dense inverse applied on the device), use_graph, block_rows, block_from_level, device."""
+        coarse_mode (0 host LDL^T back-substitution per cycle, 1 dense inverse built and applied on the device, 2 = default: 1 while the coarsest level has <= 8 192 unknowns -- a system solved ONCE is faster with 0), use_graph, block_rows, block_from_level, device."""
         self.solver.set_engine_option(str(key), float(value))
 
 
