@@ -397,13 +397,20 @@ static int build_coarse_inverse_device(gmg_handle h) {
     std::vector<int> tile_ptr_h, tile_q_h;
     E.tile_paths(width, tile_ptr_h, tile_q_h);
     const std::vector<int> lev_big_h = E.big_per_level(gmgs::kInvBigRows);
-    DevTmp<int> q_col0, q_w, q_rptr, rows, lev_ptr, lev_q, lev_big, tile_ptr, tile_q;
+    // chunk records in the kernel's two orders (setup_kernels.hip.hpp::InvFactor)
+    auto record = [&](int q) { return make_int4(E.q_col0[(size_t)q] | (E.q_w[(size_t)q] << 24), E.q_rptr[(size_t)q], E.q_rptr[(size_t)q + 1], q); };
+    std::vector<int4> lev_meta_h(E.lev_q.size()), tile_meta_h(tile_q_h.size());
+    for (size_t k = 0; k < E.lev_q.size(); ++k) lev_meta_h[k] = record(E.lev_q[k]);
+    for (size_t t = 0; t < tile_q_h.size(); ++t) tile_meta_h[t] = record(tile_q_h[t]);
+    DevTmp<int4> lev_meta, tile_meta;
+    DevTmp<int> rows, lev_ptr, lev_big, tile_ptr;
     DevTmp<double> vals, tri, dinv;
     int rc;
     auto up_i = [&](DevTmp<int>& d, const std::vector<int>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(int) * v.size()); };
+    auto up_4 = [&](DevTmp<int4>& d, const std::vector<int4>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(int4) * v.size()); };
     auto up_d = [&](DevTmp<double>& d, const std::vector<double>& v) -> int { int r = d.alloc(h, std::max<size_t>(v.size(), 1)); if (r) return r; return v.empty() ? GMG_OK : h2d(h, d.p, v.data(), sizeof(double) * v.size()); };
-    if ((rc = up_i(q_col0, E.q_col0)) || (rc = up_i(q_w, E.q_w)) || (rc = up_i(q_rptr, E.q_rptr)) || (rc = up_i(rows, E.rows)) ||
-        (rc = up_i(lev_ptr, E.lev_ptr)) || (rc = up_i(lev_q, E.lev_q)) || (rc = up_i(lev_big, lev_big_h)) || (rc = up_i(tile_ptr, tile_ptr_h)) || (rc = up_i(tile_q, tile_q_h)) || (rc = up_d(vals, E.vals)) || (rc = up_d(tri, E.tri)) || (rc = up_d(dinv, E.dinv)))
+    if ((rc = up_4(lev_meta, lev_meta_h)) || (rc = up_4(tile_meta, tile_meta_h)) || (rc = up_i(rows, E.rows)) || (rc = up_i(lev_ptr, E.lev_ptr)) || (rc = up_i(lev_big, lev_big_h)) ||
+        (rc = up_i(tile_ptr, tile_ptr_h)) || (rc = up_d(vals, E.vals)) || (rc = up_d(tri, E.tri)) || (rc = up_d(dinv, E.dinv)))
         return rc;
     std::vector<int> inv_h((size_t)nl);
     for (int i = 0; i < nl; ++i) inv_h[(size_t)E.perm[(size_t)i]] = i;
@@ -418,7 +425,7 @@ static int build_coarse_inverse_device(gmg_handle h) {
     HIPCHK(hipMemsetAsync(X.p, 0, bytes, h->stream));
     gmgs::InvFactor F;
     F.n = nl; F.nq = E.nq; F.nlev = E.nlev;
-    F.q_col0 = q_col0.p; F.q_w = q_w.p; F.q_rptr = q_rptr.p; F.rows = rows.p; F.lev_ptr = lev_ptr.p; F.lev_q = lev_q.p; F.lev_big = lev_big.p; F.tile_ptr = tile_ptr.p; F.tile_q = tile_q.p;
+    F.lev_meta = lev_meta.p; F.tile_meta = tile_meta.p; F.rows = rows.p; F.lev_ptr = lev_ptr.p; F.lev_big = lev_big.p; F.tile_ptr = tile_ptr.p;
     F.vals = vals.p; F.tri = tri.p; F.dinv = dinv.p;
     static_assert(gmgs::kInvChunk == SupernodalLDLT::kChunk, "chunk width of the exported factor");
     const int nt = (nl + width - 1) / width, nm = (nl + 63) / 64;
@@ -2266,6 +2273,24 @@ int gmg_host_ldlt_probe(int n, const int* colptr, const int* rowidx, const doubl
             for (int i = 0; i < 15; ++i) { if (!f.factor(A, true)) return GMG_ERR_NUMERIC; ts.push_back(f.phase_ms[2]); }
             std::sort(ts.begin(), ts.end());
             say("numeric re-factorisation on %d thread(s): best %.2f ms, median %.2f ms\n", SupernodalLDLT::numeric_threads(), ts.front(), ts[ts.size() / 2]);
+        }
+        {   // the factor as the device reads it (export_device_factor) and the device kernel's schedule, on the host: some columns of the inverse by the
+            // chunk algorithm against the back-substitution of the same unit vectors
+            SupernodalLDLT::DeviceFactor E;
+            f.export_device_factor(E);
+            std::vector<double> col((size_t)n), e((size_t)n, 0.0), ref((size_t)n), wk((size_t)n);
+            double worst = 0.0, scale = 0.0;
+            const int picks = std::min(n, 24);
+            for (int t = 0; t < picks; ++t) {
+                const int c = (int)((long)t * (n - 1) / std::max(picks - 1, 1));          // factor numbering, spread from the first leaf to the root
+                SupernodalLDLT::emulate_device_column(E, c, col.data());
+                e[(size_t)f.perm[(size_t)c]] = 1.0;
+                f.solve(e.data(), ref.data(), wk.data());
+                e[(size_t)f.perm[(size_t)c]] = 0.0;
+                for (int j = c; j < n; ++j) { worst = std::max(worst, std::fabs(col[(size_t)j] - ref[(size_t)f.perm[(size_t)j]])); scale = std::max(scale, std::fabs(ref[(size_t)f.perm[(size_t)j]])); }
+            }
+            say("device factor layout: %d chunks of <= %d columns in %d levels; %d columns of the inverse by the chunk algorithm vs back-substitution: max |difference| %.3e of max |entry| %.3e\n",
+                E.nq, SupernodalLDLT::kChunk, E.nlev, picks, worst, scale);
         }
         long part[3];
         f.split_report(part);

@@ -739,6 +739,43 @@ public:
         }
         std::vector<double> vals, tri, dinv;
     };
+    // Column c (factor numbering) of A^-1 in rows >= c, by the algorithm of the device kernel on the exported layout -- way down in push form along the
+    // column's path to the root, way up in pull form level by level -- on ONE column: the host's check of the layout and of the schedule
+    // (gmg_host_ldlt_probe; tests/test_host.py).  x: n doubles, rows < c are left zero.
+    static void emulate_device_column(const DeviceFactor& E, int c, double* x) {
+        const int n = E.n;
+        std::fill(x, x + n, 0.0);
+        x[c] = 1.0;
+        for (int q = E.first_q[(size_t)c]; q >= 0;) {                                       // way down: the chunks on the path, ascending
+            const int col0 = E.q_col0[(size_t)q], w = E.q_w[(size_t)q];
+            double y[kChunk];
+            for (int jj = 0; jj < kChunk; ++jj) y[jj] = jj < w ? x[col0 + jj] : 0.0;
+            const double* T = E.tri.data() + (size_t)q * kChunk * kChunk;
+            for (int jj = 0; jj < kChunk; ++jj) for (int ii = jj + 1; ii < kChunk; ++ii) y[ii] -= T[ii * kChunk + jj] * y[jj];
+            for (int jj = 1; jj < w; ++jj) x[col0 + jj] = y[jj];
+            for (int i = E.q_rptr[(size_t)q]; i < E.q_rptr[(size_t)q + 1]; ++i) {
+                double acc = 0.0;
+                for (int jj = 0; jj < kChunk; ++jj) acc += E.vals[(size_t)i * kChunk + jj] * y[jj];
+                x[E.rows[(size_t)i]] -= acc;
+            }
+            q = E.q_rptr[(size_t)q + 1] > E.q_rptr[(size_t)q] ? E.first_q[(size_t)E.rows[(size_t)E.q_rptr[(size_t)q]]] : -1;
+        }
+        for (int v = 0; v < E.nlev; ++v)                                                    // way up: level by level, every chunk that reaches row c or beyond
+            for (int k = E.lev_ptr[(size_t)v]; k < E.lev_ptr[(size_t)v + 1]; ++k) {
+                const int q = E.lev_q[(size_t)k], col0 = E.q_col0[(size_t)q], w = E.q_w[(size_t)q];
+                if (col0 + w - 1 < c) continue;
+                double acc[kChunk];
+                for (int jj = 0; jj < kChunk; ++jj) acc[jj] = 0.0;
+                for (int i = E.q_rptr[(size_t)q]; i < E.q_rptr[(size_t)q + 1]; ++i) {
+                    const double xi = x[E.rows[(size_t)i]];
+                    for (int jj = 0; jj < kChunk; ++jj) acc[jj] -= E.vals[(size_t)i * kChunk + jj] * xi;
+                }
+                for (int jj = 0; jj < kChunk; ++jj) acc[jj] += jj < w ? x[col0 + jj] * E.dinv[(size_t)col0 + jj] : 0.0;
+                const double* T = E.tri.data() + (size_t)q * kChunk * kChunk;
+                for (int jj = kChunk - 2; jj >= 0; --jj) for (int ii = jj + 1; ii < kChunk; ++ii) acc[jj] -= T[ii * kChunk + jj] * acc[ii];
+                for (int jj = 0; jj < w; ++jj) x[col0 + jj] = acc[jj];
+            }
+    }
     void export_device_factor(DeviceFactor& E) const {
         E.n = n;
         E.perm = perm;

@@ -774,7 +774,10 @@ __global__ __launch_bounds__(64) void rap_rows(const int* __restrict__ a_ptr, co
 // the build is latency-bound (one dependent global round trip per level) and not a candidate for MFMA.
 struct InvFactor {
     int n, nq, nlev;
-    const int *q_col0, *q_w, *q_rptr, *rows, *lev_ptr, *lev_q, *lev_big, *tile_ptr, *tile_q;      // lev_big[level]: its first chunks with >= kInvBigRows rows
+    // chunk records {first column | width << 24, first row entry, end of its row entries, chunk number}: lev_meta in the order of the way up (level by
+    // level, the chunks with >= kInvBigRows rows first: lev_big[level] of them), tile_meta in the order of a tile's way down (tile_ptr)
+    const int4 *lev_meta, *tile_meta;
+    const int *rows, *lev_ptr, *lev_big, *tile_ptr;
     const double *vals, *tri, *dinv;
 };
 constexpr int kInvChunk = 8;            // = gmg::SupernodalLDLT::kChunk
@@ -783,10 +786,12 @@ constexpr int kInvBigRows = 192;        // a chunk with at least this many rows 
 
 // W = columns of a tile (16 / 32 / 64).  A wave covers W columns x S = 64 / W ROW SLOTS: lane = slot * W + column, so that one load instruction
 // fetches S different rows of the tile's slab (a small coarsest level has few tiles: the width is chosen so that there are enough workgroups,
-// and the slots keep all 64 lanes busy).  Way down: the chunks on the tile's paths to the root (tile_q, ascending), one after the other, every
+// and the slots keep all 64 lanes busy).  Way down: the chunks on the tile's paths to the root (tile_meta, ascending), one after the other, every
 // wave pushing its share of the rows below.  Way up: level by level; the big chunks of a level (separators: hundreds of rows below them; the host
 // lists them first) are worked off one by one by ALL waves, their partial sums added in wave order through LDS; the others go to the waves
 // one chunk each, side by side.  Every value has one fixed summation order: same bits on every device.
+// The kernel is a chain of dependent memory round trips (record -> row numbers -> rows of X -> store), so the record of the NEXT chunk is
+// requested before the current one is worked on, and a chunk's own rows of X are requested before its gathers.
 template <int W>
 __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor F, double* X) {
     constexpr int S = 64 / W;
@@ -810,23 +815,24 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
         double y[kInvChunk];
         int pcol0 = -1, pw = 0;
         const int t0 = F.tile_ptr[blockIdx.x], t1 = F.tile_ptr[blockIdx.x + 1];
+        int4 next = t0 < t1 ? F.tile_meta[t0] : make_int4(0, 0, 0, 0);
         for (int t = t0; t <= t1; ++t) {
             if (wave == 0 && slot == 0 && valid && pcol0 >= 0) {
 #pragma unroll
                 for (int jj = 1; jj < kInvChunk; ++jj) if (jj < pw) Xc[(int64_t)(pcol0 + jj) * ld] = y[jj];
             }
             if (t == t1) break;
-            const int q = F.tile_q[t];
-            const int col0 = F.q_col0[q], w = F.q_w[q];
+            const int4 m = next;
+            if (t + 1 < t1) next = F.tile_meta[t + 1];
+            const int col0 = m.x & 0xffffff, w = m.x >> 24, r0 = m.y, r1 = m.z;
 #pragma unroll
             for (int jj = 0; jj < kInvChunk; ++jj) y[jj] = (jj < w && valid) ? Xc[(int64_t)(col0 + jj) * ld] : 0.0;
-            const double* T = F.tri + (int64_t)q * kInvChunk * kInvChunk;
+            const double* T = F.tri + (int64_t)m.w * kInvChunk * kInvChunk;
 #pragma unroll
             for (int jj = 0; jj < kInvChunk; ++jj)
 #pragma unroll
                 for (int ii = jj + 1; ii < kInvChunk; ++ii) y[ii] -= T[ii * kInvChunk + jj] * y[jj];
             pcol0 = col0; pw = w;
-            const int r0 = F.q_rptr[q], r1 = F.q_rptr[q + 1];
             // rows r0 + (wave * S + slot) + k * (kInvWaves * S): every (row, column) has exactly one lane; four rows in flight per lane
             for (int i = r0 + wave * S + slot; i < r1; i += 4 * kInvWaves * S) {
                 double xv[4], acc[4];
@@ -850,8 +856,11 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
     }
     __syncthreads();
     // ---- way up (L^T x = D^-1 y, pull form), rows >= c0 only
-    auto gather_rows = [&](int q, int first, int stride, double (&acc)[kInvChunk]) {
-        const int r0 = F.q_rptr[q], r1 = F.q_rptr[q + 1];
+    auto own_rows = [&](int col0, int w, double (&yv)[kInvChunk]) {                 // D^-1 y of the chunk's own columns (requested before the gathers)
+#pragma unroll
+        for (int jj = 0; jj < kInvChunk; ++jj) yv[jj] = (jj < w && valid) ? Xc[(int64_t)(col0 + jj) * ld] * F.dinv[col0 + jj] : 0.0;
+    };
+    auto gather_rows = [&](int r0, int r1, int first, int stride, double (&acc)[kInvChunk]) {
         constexpr int U = 8;                                                 // gathers in flight per lane (a big level's slabs live in HBM: latency, not bytes)
         for (int i = r0 + first; i < r1; i += U * stride) {
             double xi[U];
@@ -866,9 +875,9 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
             }
         }
     };
-    auto finish_chunk = [&](int q, int col0, int w, double (&acc)[kInvChunk]) {        // acc: sums over the rows below; every slot holds them
+    auto finish_chunk = [&](int q, int col0, int w, double (&acc)[kInvChunk], const double (&yv)[kInvChunk]) {        // acc: sums over the rows below; every slot holds them
 #pragma unroll
-        for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] += (jj < w && valid) ? Xc[(int64_t)(col0 + jj) * ld] * F.dinv[col0 + jj] : 0.0;
+        for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] += yv[jj];
         const double* T = F.tri + (int64_t)q * kInvChunk * kInvChunk;
 #pragma unroll
         for (int jj = kInvChunk - 2; jj >= 0; --jj)
@@ -882,13 +891,14 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
     for (int lev = 0; lev < F.nlev; ++lev) {
         const int k0 = F.lev_ptr[lev], k1 = F.lev_ptr[lev + 1], kb = k0 + F.lev_big[lev];
         for (int k = k0; k < kb; ++k) {                                      // the big ones, together
-            const int q = F.lev_q[k];
-            const int col0 = F.q_col0[q], w = F.q_w[q];
+            const int4 m = F.lev_meta[k];
+            const int col0 = m.x & 0xffffff, w = m.x >> 24;
             if (col0 + w - 1 < c0) continue;                                // (workgroup-uniform)
-            double acc[kInvChunk];
+            double acc[kInvChunk], yv[kInvChunk];
 #pragma unroll
-            for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
-            gather_rows(q, wave * S + slot, kInvWaves * S, acc);
+            for (int jj = 0; jj < kInvChunk; ++jj) { acc[jj] = 0.0; yv[jj] = 0.0; }
+            if (wave == 0) own_rows(col0, w, yv);
+            gather_rows(m.y, m.z, wave * S + slot, kInvWaves * S, acc);
 #pragma unroll
             for (int jj = 0; jj < kInvChunk; ++jj) { const double v = slots_sum(acc[jj]); if (slot == 0) red[wave][jj][cl] = v; }
             __syncthreads();
@@ -900,21 +910,25 @@ __global__ __launch_bounds__(64 * kInvWaves) void coarse_inverse_tiles(InvFactor
                     for (int wv = 0; wv < kInvWaves; ++wv) v += red[wv][jj][cl];
                     acc[jj] = v;
                 }
-                finish_chunk(q, col0, w, acc);
+                finish_chunk(m.w, col0, w, acc, yv);
             }
             __syncthreads();
         }
-        for (int k = kb + wave; k < k1; k += kInvWaves) {                    // the others: one per wave
-            const int q = F.lev_q[k];
-            const int col0 = F.q_col0[q], w = F.q_w[q];
+        int k = kb + wave;                                                   // the others: one per wave, the next record in flight
+        int4 next = k < k1 ? F.lev_meta[k] : make_int4(0, 0, 0, 0);
+        for (; k < k1; k += kInvWaves) {
+            const int4 m = next;
+            if (k + kInvWaves < k1) next = F.lev_meta[k + kInvWaves];
+            const int col0 = m.x & 0xffffff, w = m.x >> 24;
             if (col0 + w - 1 < c0) continue;
-            double acc[kInvChunk];
+            double acc[kInvChunk], yv[kInvChunk];
 #pragma unroll
             for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = 0.0;
-            gather_rows(q, slot, S, acc);
+            own_rows(col0, w, yv);
+            gather_rows(m.y, m.z, slot, S, acc);
 #pragma unroll
             for (int jj = 0; jj < kInvChunk; ++jj) acc[jj] = slots_sum(acc[jj]);
-            finish_chunk(q, col0, w, acc);
+            finish_chunk(m.w, col0, w, acc, yv);
         }
         __syncthreads();
     }

@@ -1,6 +1,6 @@
 # evidence of the round's last build, one job: suite, bench line, kernel stats + timelines, PMC passes, ranks on one GPU.  bash scripts/r06_evidence.sh <tag>
 T=${1:-z}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06$T; mkdir -p $O; cd $R
-git rev-parse HEAD > $O/commit.txt 2>/dev/null || true
+cp profiles/r06/commit.txt $O/commit.txt
 timeout -s KILL 2700 python -m pytest tests -m gpu -q --tb=short --durations=8 2>&1 | grep -v "Gloo\|socket.cpp\|amdgpu.ids" | tail -40 > $O/pytest_gpu_summary.txt
 grep -n "passed\|failed\|^FAILED" $O/pytest_gpu_summary.txt | head
 timeout -s KILL 1200 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 200 $O/bench.json; echo

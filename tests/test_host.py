@@ -364,3 +364,31 @@ def test_fine_block_rule_on_the_host(cabi):
     S, mass = meshgen.knn_graph_laplacian(meshgen.torus_points(2000, noise=0.002), 12)      # smoothing system of a denser graph
     assert cabi.host_fine_block_rule(meshgen.smoothing_system(S, mass, np.zeros((2000, 3)))[0]) == (True, 0)
 
+
+
+@pytest.mark.parametrize("kind", ["grid", "coarsest"])
+def test_device_factor_layout_and_schedule_on_the_host(kind):
+    """The dense inverse of the coarsest operator is built on the GPU from the host's sparse factor in a layout of its own (chunks of <= 8
+    columns, row-major values, levels of the elimination tree: SupernodalLDLT::export_device_factor) by a kernel that carries the identity
+    through it (setup_kernels.hip.hpp::coarse_inverse_tiles).  The same algorithm on the same arrays, on the host, one column at a time
+    (emulate_device_column), against the back-substitution of the unit vectors -- the layout and the schedule without a GPU; the GPU suite has
+    the kernel itself (tests/test_gpu_parity.py::test_device_built_coarse_inverse_against_the_host_factor)."""
+    import re
+    from gravo_mg_amd import cabi
+    if kind == "grid":
+        m = 70
+        T = sp.diags([-1.0, 2.3, -1.0], [-1, 0, 1], shape=(m, m))
+        A = (sp.kron(sp.identity(m), T) + sp.kron(T, sp.identity(m))).tocsc()
+    else:                               # a real coarsest Galerkin operator (~21 entries per row, nnz(L) / n ~ 100)
+        P = problems.torus_problem(130, 120, "smoothing", 300)
+        A = P.lhs
+        for U in P.U:
+            A = cabi.host_galerkin(A, U)
+        A = sp.csc_matrix(A)
+    b = np.random.default_rng(5).standard_normal(A.shape[0])
+    report = cabi.host_ldlt_probe(A, b, reps=1)
+    m1 = re.search(r"device factor layout: (\d+) chunks of <= 8 columns in (\d+) levels; (\d+) columns .* max \|difference\| ([0-9.e+-]+) of max \|entry\| ([0-9.e+-]+)", report)
+    assert m1, report[-1500:]
+    chunks, levels, cols, diff, scale = int(m1.group(1)), int(m1.group(2)), int(m1.group(3)), float(m1.group(4)), float(m1.group(5))
+    assert chunks >= A.shape[0] // 8 and 2 <= levels <= chunks and cols == 24
+    assert diff <= 1e-11 * scale, (diff, scale)
