@@ -1056,7 +1056,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     }
     h->coarse_device = want_coarse_device(h, h->lv[L].A.n_outer);
     h->timing["coarse_on_device"] = h->coarse_device ? 1.0 : 0.0;
-    if (h->coarse_device) {
+    if (h->coarse_device && !h->preparing_structure) {
         int rc = build_coarse_inverse_device(h);
         if (rc) return rc;
     }
@@ -1120,6 +1120,21 @@ static int prepare_structure(gmg_handle h) {
     const FineGraph& g = *h->fine_graph;
     const int n = g.n;
     auto t0 = clk::now();
+    {   // The systems to come are symmetric (tau M + S): a point graph that is not (the kNN table of a point cloud: j among i's neighbours, i not among
+        // j's) is not their pattern -- its placeholder set-up would be paid here and the first real system would take the cold path all the same
+        // (round-5 advice).  One threaded pass, a binary search per entry (the rows are sorted).
+        std::atomic<bool> symmetric{true};
+        parallel_ranges(n, h->cfg.host_threads, [&](int lo, int hi, int) {
+            for (int i = lo; i < hi && symmetric.load(std::memory_order_relaxed); ++i)
+                for (int p = g.ptr[i]; p < g.ptr[i + 1]; ++p) {
+                    const int j = g.idx[p];
+                    if (j == i) continue;
+                    if (!std::binary_search(g.idx.data() + g.ptr[j], g.idx.data() + g.ptr[j + 1], i)) { symmetric.store(false, std::memory_order_relaxed); break; }
+                }
+        }, 1 << 14);
+        h->timing["structure_prepare_symmetric_graph"] = symmetric.load() ? 1.0 : 0.0;
+        if (!symmetric.load()) { h->timing["structure_prepare_ms"] = ms_since(t0); return GMG_OK; }
+    }
     RawVec<double> val;
     val.resize((size_t)g.ptr[n]);
     parallel_ranges(n, h->cfg.host_threads, [&](int lo, int hi, int) {
@@ -1130,7 +1145,12 @@ static int prepare_structure(gmg_handle h) {
     }, 1 << 14);
     std::vector<double> user_mass;
     user_mass.swap(h->mass);                         // (the placeholder set-up needs no mass; whatever the caller set waits for the real system)
-    int rc = set_system_impl(h, n, g.ptr.data(), g.idx.data(), val.data());
+    struct Flag { bool& f; explicit Flag(bool& x) : f(x) { f = true; } ~Flag() { f = false; } };
+    int rc;
+    {
+        Flag preparing(h->preparing_structure);     // (no dense coarse inverse of placeholder values: the refresh with the real ones builds it)
+        rc = set_system_impl(h, n, g.ptr.data(), g.idx.data(), val.data());
+    }
     h->mass.swap(user_mass);
     if (rc != GMG_OK) { h->placeholder_ready = false; return rc; }
     h->system_ready = false;                         // nothing to solve with: the values are placeholders

@@ -544,3 +544,30 @@ def test_structure_prepared_at_hierarchy_time_gives_the_cold_set_ups_bits(cabi, 
         xa = prepared.solve(rhs2, tol=1e-3, max_iter=8)[0]
         xb = fresh.solve(rhs2, tol=1e-3, max_iter=8)[0]
         assert np.array_equal(xa, xb)
+
+
+def test_an_asymmetric_point_graph_is_not_prepared_for(cabi):
+    """The structure is prepared for systems with the point graph's pattern (tau M + S of a symmetric graph).  A kNN table that is not symmetric --
+    j among i's neighbours, i not among j's -- cannot be the pattern of a symmetric system: gmg_finalize_hierarchy notices (one threaded pass) and
+    skips the placeholder set-up instead of paying for it and taking the cold path anyway (round-5 advice); results are those of a cold handle."""
+    from gravo_mg_amd import meshgen
+    pos = meshgen.torus_points(6000, noise=0.002)
+    S, mass = meshgen.knn_graph_laplacian(pos, 8)
+    lhs, rhs = meshgen.poisson_system(S, mass)
+    neigh = meshgen.neighbors_from_stiffness(S).copy()
+    i = 123
+    j = int([v for v in neigh[i] if v >= 0 and v != i][0])
+    row = neigh[j]
+    assert i in row and j in neigh[i]
+    row[row == i] = [v for v in row if v >= 0 and v != i and v != j][0]      # j forgets i (the slot repeats another neighbour): i -> j stays
+    H = cabi.Hierarchy(pos, neigh, lower_bound=150)
+    e = cabi.Engine()
+    e.set_prolongations(H.U, fine_order=H.fine_order, fine_graph=neigh)       # the table as the caller holds it (gmg_set_fine_graph: what the C++ mirror passes)
+    assert e.timing("structure_prepare_symmetric_graph") == 0.0
+    e.set_mass(mass); e.set_system(lhs)
+    assert e.timing("setup_structure_prepared") == 0.0 and e.timing("setup_values_only") == 0.0
+    cold = cabi.Engine(prepare_structure=False)
+    cold.use_hierarchy(H); cold.set_mass(mass); cold.set_system(lhs)
+    xa, ita, resa, _ = e.solve(rhs, tol=1e-6, max_iter=60)
+    xb, itb, resb, _ = cold.solve(rhs, tol=1e-6, max_iter=60)
+    assert ita == itb and np.array_equal(xa, xb)
