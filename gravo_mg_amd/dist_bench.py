@@ -42,6 +42,9 @@ def main(args):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the device-side time-out of an exchange (default 4 s): the first exchanges of a job meet ranks that are still loading code objects or paging the
+    # image in -- a rank that is merely late must not send all ranks to the fallback
+    os.environ.setdefault("GMG_P2P_TIMEOUT_S", "20")
     # GMG_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that): a functional end-to-end check of the
     # N > 1 path on a 1-GPU box, not a measurement
     backend = os.environ.get("GMG_DIST_BACKEND", "nccl")
