@@ -9,4 +9,6 @@ bash scripts/r06_pmc.sh $T 3m; bash scripts/r06_pmc.sh $T 3m_smoothing_d3 --conf
 cd $R
 python scripts/coarse_inverse_timing.py 2>&1 | grep -v amdgpu > $O/coarse_inverse_timing.txt
 for W in 2 4 8; do timeout -s KILL 300 python scripts/p2p_hybrid_probe.py $W poisson-big 2 2>&1 | grep "exact\|hybrid"; done > $O/hybrid_smoother_ranks_on_one_gpu.txt
+timeout -s KILL 900 python bench.py --n1 2828 --n2 2828 --no-variants --cpu-cycles 0 > $O/bench_8m.json 2> $O/bench_8m.err; tail -c 150 $O/bench_8m.json; echo
+timeout -s KILL 1500 python bench.py --n1 4472 --n2 4472 --no-variants --cpu-cycles 0 > $O/bench_20m.json 2> $O/bench_20m.err; tail -c 150 $O/bench_20m.json; echo
 for W in 2 4; do GMG_DIST_BACKEND=gloo timeout -s KILL 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $W --master-addr 127.0.0.1 --master-port 2953$W bench.py --gpus $W --steps 10 --warmup 2 2>$O/dist_$W.err | tail -1 > $O/bench_${W}ranks_1gpu.json; tail -c 300 $O/bench_${W}ranks_1gpu.json; echo; done
