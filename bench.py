@@ -356,8 +356,15 @@ def main():
     col16 = bool(eng.timing("col16_l0"))
     info0 = eng.level_info(0)
     stored_bytes = sweep_bytes - (2.0 * (info0["nnz"] - info0["n"]) - 32.0 * info0["n_pad"] / 64 if col16 else 0.0)
+    # the launch the figure is about, under the name rocprofv3 lists it by: template values <value type, right-hand sides, 1 + column-code mode (+ 2: an
+    # operator that stays in the memory-side cache and is read with ordinary loads), 0>; a level 0 on the block sweep (kNN operators) is one gs_block_ep launch per sweep
+    if eng.level_blocks(0) is not None:
+        kernel_name = "gmgk::gs_block_ep<double,%d,...> (level 0 on the block-hybrid sweep, one launch per sweep: gmg_config::block_fine)" % d0
+    else:
+        fine_t = (int(eng.timing("col16_l0_mode")) + (2 if eng.timing("fine_operators_resident") else 0) + 1) if col16 else 1
+        kernel_name = "gmgk::gs_color<double,%d,%d,0> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour%s)" % (d0, fine_t, "; 16-bit column codes" if col16 else "")
     roofline = {
-        "bound": "hbm", "kernel": "gmgk::gs_color<double,1,%d,0> (fine-level multicolour Gauss-Seidel / SOR, one launch per colour%s)" % (2 if col16 else 1, "; 16-bit column codes" if col16 else ""),
+        "bound": "hbm", "kernel": kernel_name,
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_source,
         "launch_ms": sweep_ms / launches, "launches_per_sweep": launches,

@@ -257,7 +257,9 @@ int gmg_dist_setup(gmg_handle h, int rank, int world);
 int gmg_dist_partition(gmg_handle h, int rank, int world);
 /* Use caller-owned device buffers as level-0 x, b, r (until the next gmg_set_system / a larger d). */
 int gmg_dist_bind(gmg_handle h, double* x0, double* b0, double* r0, int d);
-/* Colour c of one Gauss-Seidel sweep on this rank's rows (multigrid_solver.cpp:1194-1226, row-partitioned). */
+/* Colour c of one Gauss-Seidel sweep on this rank's rows (multigrid_solver.cpp:1194-1226, row-partitioned).  GMG_ERR_STATE on a level 0 that runs the
+ * block sweep (gmg_config::block_fine): such a level is ONE class of rows cut into `world` runs of whole 64-row blocks, swept block-wise with one halo
+ * exchange per sweep by the engine-driven cycle (gmg_p2p_cycles); the step-by-step entry points below serve colour-major levels. */
 int gmg_dist_smooth_color(gmg_handle h, int c);
 /* r0[own rows] = b0 - A x0 (:1066). */
 int gmg_dist_residual_own(gmg_handle h);
