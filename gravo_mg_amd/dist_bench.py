@@ -242,6 +242,28 @@ def main(args):
     def load():
         (p2p.load if p2p is not None else be.load)(rhs, rhs)
 
+    # ---- mailboxes: which form of the level-0 colour exchanges is faster HERE -- one exchange launch behind every colour launch, or the exchange
+    # folded into the colour launch (gmgk::gs_color_push, gmg_p2p_set_smoother(2): the same iterates bit for bit, (pre + post) x colours launches
+    # fewer per cycle)?  A short probe of both, decided on the MAX over ranks (the same number on every rank); the headline runs the faster one.
+    exchange_form = None
+    if p2p is not None and world > 1 and engine_exchange == "p2p" and not os.environ.get("GMG_BENCH_NO_FOLD_PROBE"):
+        def probe(mode, k=6):
+            p2p.set_smoother(mode)
+            load(); run(2)
+            torch.cuda.synchronize(); dist.barrier()
+            tq = time.perf_counter(); r = run(k); torch.cuda.synchronize(); dist.barrier()
+            tt = torch.tensor([time.perf_counter() - tq], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1e3 * float(tt.item()) / k, r
+        t_plain, r_plain = probe(0)
+        t_fold, r_fold = probe(2)
+        same = bool(np.array_equal(np.asarray(r_plain), np.asarray(r_fold)))
+        flag = torch.tensor([int(same)], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_fold = bool(int(flag.item()) == 1 and t_fold < 0.97 * t_plain)
+        p2p.set_smoother(2 if use_fold else 0)
+        exchange_form = {"chosen": "folded into the colour launches" if use_fold else "one exchange launch per colour", "probe_ms_per_cycle": {"separate": t_plain, "folded": t_fold},
+                         "same_residues": same}
     load()
     first = run(n_warm)
     reproduced = bool(np.allclose(first, ref_res, rtol=1e-9))
@@ -284,6 +306,7 @@ def main(args):
             ms, launches_f, _ = timed(args.steps); samples_f.append(ms)
             p2p.set_smoother(0)
             ms, launches_u, _ = timed(args.steps); samples_u.append(ms)
+        p2p.set_smoother(2 if (exchange_form and exchange_form["chosen"].startswith("folded")) else 0)
         variants["halo_push_fold"] = {"ms_per_step": min(samples_f), "exchange_launches_per_cycle": launches_f, "samples_ms": samples_f,
                                       "default_again": {"ms_per_step": min(samples_u), "exchange_launches_per_cycle": launches_u, "samples_ms": samples_u},
                                       "residues_match_single_gpu": bool(np.allclose(folded_first, ref_res, rtol=1e-9)),
@@ -305,7 +328,7 @@ def main(args):
         th0 = time.perf_counter(); run(args.steps); torch.cuda.synchronize(); dist.barrier()
         th = torch.tensor([time.perf_counter() - th0], dtype=torch.float64, device="cuda")
         dist.all_reduce(th, op=dist.ReduceOp.MAX)
-        p2p.set_smoother(False)
+        p2p.set_smoother(2 if (exchange_form and exchange_form["chosen"].startswith("folded")) else 0)
         variants["hybrid_gs"] = {"ms_per_step": 1e3 * float(th.item()) / args.steps, "iterations_to_1e-4": len(hh), "residues": [float(v) for v in hh],
                                  "exchanges_per_cycle_level0": 2 + 2 + 1,
                                  "what": "level 0: Gauss-Seidel inside a rank, Jacobi across ranks, one halo exchange per sweep (gmg_p2p_set_smoother); the default exchanges after every colour"}
@@ -396,6 +419,8 @@ def main(args):
             if engine_exchange == "p2p":
                 how = (f"per colour sweep ONE exchange kernel: each rank stores the halo entries its peers read into their mailboxes over xGMI "
                        f"({int(p2p.stat('halo_rows_published'))} rows published by rank 0) and waits for theirs")
+                if exchange_form and exchange_form["chosen"].startswith("folded"):
+                    how += " -- the colour halos leave INSIDE the colour launches here (gs_color_push: boundary waves store from registers, the last one publishes and pulls; chosen by a probe of both forms)"
                 tail = "no collective call in the cycle"
             else:
                 how = (f"per colour sweep one pack -> all-gather -> unpack sequence on the engine's stream ({int(p2p.stat('halo_rows_published'))} rows published by rank 0)")
@@ -420,6 +445,7 @@ def main(args):
             "exchange": engine_exchange if p2p is not None else ("none (one rank)" if world == 1 else args.exchange if args.exchange != "p2p" else "halo (fallback)"),
             "exchange_note": note, "exchange_us": exchange_us, "single_gpu_residues_reproduced": reproduced,
             "exchange_fences": exchange_fences if engine_exchange == "p2p" else None,
+            "level0_exchange_form": exchange_form,
             "single_gpu_solve_reproduced": bool(len(hist) == len(ref_hist) and np.allclose(hist, ref_hist, rtol=1e-9)),
             "collectives_per_cycle": colls_per_cycle, "collective_backend": backend,
             "mvertex_cycles_per_s": n0 / ms_per_step / 1e3,
