@@ -698,6 +698,15 @@ inline void launch_cvt(gmg_handle h, const float* src, double* dst, size_t n) {
     hipLaunchKernelGGL(gmgk::cvt_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, src, dst, (int64_t)n);
 }
 
+#ifndef GMG_SYMV_ROWS
+#define GMG_SYMV_ROWS 0
+#endif
+inline int symv_rows(int n, int d) {
+    if (GMG_SYMV_ROWS > 0) return GMG_SYMV_ROWS;       // (A/B builds)
+    if (n >= 4096) return 4;
+    return (n >= 2500 || d > 1) ? 2 : 1;
+}
+
 // e = A_L^{-1} rc with the dense inverse (always applied in fp64; the fp32 cycle converts around it)
 template <class T = double>
 void enqueue_coarse_device(gmg_handle h, int d) {
@@ -706,8 +715,14 @@ void enqueue_coarse_device(gmg_handle h, int d) {
     if (sizeof(T) == 4) launch_cvt(h, c.b32, c.b, cnt);
     for (int c0 = 0; c0 < d; c0 += 4) {
         int dc = std::min(4, d - c0);
-        DISPATCH_D(dc, hipLaunchKernelGGL(gmgk::dense_symv<D>, dim3((c.n + gmgk::kWavesPerBlock - 1) / gmgk::kWavesPerBlock), dim3(gmgk::kBlock), 0,
-                                          h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad));
+        // rows per wave: the rows of a wave share the loads of the vectors (what bounds the product at d = 3 and at n_L beyond the L1's reach); a small
+        // level keeps one row per wave -- it needs every wave it can get to cover the memory latency
+        const int rows_per_wave = symv_rows(c.n, dc);
+        const int per_block = gmgk::kWavesPerBlock * rows_per_wave;
+        const dim3 grid((c.n + per_block - 1) / per_block);
+        if (rows_per_wave == 4) { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, 4>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
+        else if (rows_per_wave == 2) { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, 2>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
+        else { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, 1>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
     }
     if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
 }

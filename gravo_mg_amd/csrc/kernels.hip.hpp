@@ -1714,38 +1714,60 @@ __global__ void permute_mass(const double* __restrict__ mass, const int* __restr
 // Coarsest level on the device (gmg_config::coarse_mode): e = A_L^-1 rc with the dense symmetric inverse, n x n (ld = n), level numbering (built by
 // setup_kernels.hip.hpp::coarse_inverse_tiles).  One wave per row, lanes stride the row (coalesced; the matrix is the traffic: 8 n^2 bytes per
 // application, streamed -- the vectors are a few KB and stay in the caches), wave reduction in a fixed order.  x/y leading dimension ldv.
-template <int D>
+// R rows per wave: the R rows share every load of x (with d = 3 and one row per wave the vectors were read three times as often as the matrix -- from the
+// L2, whose bandwidth then bounded the product: 288 MB in 95 us at n = 6 005); a row's sum keeps its order (lane-strided, then the shuffle tree).
+template <int D, int R>
 __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ Ainv, int n, const double* __restrict__ x,
                                                      double* __restrict__ y, int ldv) {
-    const int row = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * R;
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    double acc[D];
+    if (row0 >= n) return;
+    double acc[R][D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) acc[c] = 0.0;
-    const double* a = Ainv + (int64_t)row * n;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[r][c] = 0.0;
+    const double* a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = Ainv + (int64_t)(row0 + r < n ? row0 + r : row0) * n;      // (rows beyond the last: recomputed, not stored)
+    constexpr int U = R >= 4 ? 2 : 4;               // matrix loads in flight per lane: R * U
     int j = lane;
-    for (; j + 192 < n; j += 256) {                 // four independent matrix loads in flight per lane
-        double v[4];
+    for (; j + 64 * (U - 1) < n; j += 64 * U) {
+        double v[R][U], xv[U][D];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(a + j + 64 * u);
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+            for (int r = 0; r < R; ++r) v[r][u] = __builtin_nontemporal_load(a[r] + j + 64 * u);
 #pragma unroll
-            for (int c = 0; c < D; ++c) acc[c] += v[u] * x[j + 64 * u + (int64_t)c * ldv];
+            for (int c = 0; c < D; ++c) xv[u][c] = x[j + 64 * u + (int64_t)c * ldv];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[r][c] += v[r][u] * xv[u][c];
     }
     for (; j < n; j += 64) {
-        const double v = a[j];
+        double xv[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] += v * x[j + (int64_t)c * ldv];
+        for (int c = 0; c < D; ++c) xv[c] = x[j + (int64_t)c * ldv];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double v = a[r][j];
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[r][c] += v * xv[c];
+        }
     }
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-        double v = acc[c];
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) y[row + (int64_t)c * ldv] = v;
-    }
+        for (int c = 0; c < D; ++c) {
+            double v = acc[r][c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && row0 + r < n) y[row0 + r + (int64_t)c * ldv] = v;
+        }
 }
 
 }  // namespace gmgk
