@@ -591,7 +591,9 @@ template <class T> inline size_t ep_lds_bytes(int D, int cap_e, int cap_l) {
 
 // The sequential half of the entry-parallel block sweep (gs_block_ep below; also the tail of gmgk::restrict_sweep0): the lower in-block entries go
 // through LDS into the row's lane, then the colours of the block one after the other on the block's x in LDS, then the store.  `rhs` = b minus
-// the explicit part.  One wave = one block; every __syncthreads() here is reached by exactly the waves of the workgroup that are still alive.
+// the explicit part.  One wave = one block; every __syncthreads() here is reached by exactly the waves of the workgroup that are still alive
+// (restrict_sweep0 retires three of its four waves before it calls this: S_BARRIER "waits on only the surviving waves" of a workgroup whose
+// other waves have terminated -- CDNA ISA guide, S_BARRIER).
 template <class T, int D>
 __device__ __forceinline__ void ep_block_lower(T* xs, T* zeroT, typename EpRec<T>::type* srec, int lane, int row, int blk, int q0, int nL, int lb, int nlow, int mycolor, T dg,
                                                T (&rhs)[D], T (&lv)[kEpL], unsigned short (&lc)[kEpL], const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
