@@ -1345,6 +1345,7 @@ int gmg_smooth_residual(gmg_handle h, int k, const double* b, double* x, int d, 
     if (from_zero) HIPCHK(hipMemsetAsync(l.x, 0, sizeof(double) * (size_t)l.n_pad * d, h->stream));
     else if ((rc = to_device(h, k, x, d, l.x))) return rc;
     h->sweep_prev_valid = false;
+    h->first_sweep_fused = false;                  // (a single level's sweeps: nothing ran ahead of them)
     launch_smooth<double>(h, l, d, iters, zero);
     const bool delta = k > 0 && launch_residual_delta<double>(h, l, d, l.r);        // exactly what enqueue_down does
     if (!delta) launch_spmv<double>(h, l, d, 1, l.b, l.x, l.r);
@@ -1749,7 +1750,8 @@ static int dist_coarse_cycle_enqueue(gmg_handle h) {
     int rc = dist_ready(h);
     if (rc) return rc;
     const int d = h->loaded_d;
-    launch_restrict<double>(h, h->lv[0], h->lv[1], d, h->lv[0].r, h->lv[1].b);
+    h->first_sweep_fused = false;
+    restrict_into<double>(h, 0, d, false);          // (+ level 1's first sweep where the layouts allow it)
     enqueue_down<double>(h, d, 1);
     if (h->coarse_device) enqueue_coarse_device<double>(h, d);
     else if ((rc = coarse_host_begin<double>(h, d))) return rc;

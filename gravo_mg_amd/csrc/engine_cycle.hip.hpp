@@ -211,8 +211,9 @@ void launch_block_sweeps(gmg_handle h, Level& l, int d, int iters, bool from_zer
     T* il = (T*)h->il_sweep_out;          // (enqueue_up: the last sweep also writes the level's x as an interleaved multi-vector)
     h->il_sweep_out = nullptr; h->il_sweep_done = false;
     int it0 = 0;
-    if (from_zero && h->first_sweep_fused) {      // the restriction into this level already ran the first sweep (launch_restrict_sweep0): its result is in tmp
-        h->first_sweep_fused = false;
+    const bool first_fused = from_zero && h->first_sweep_fused;
+    h->first_sweep_fused = false;                  // (consumed by the level it was set for -- or void)
+    if (first_fused) {                             // the restriction into this level already ran the first sweep (launch_restrict_sweep0): its result is in tmp
         before_last = nullptr; last_known = true;
         in = out; out = Prec<T>::x(l);
         it0 = 1;
@@ -635,10 +636,21 @@ inline void prof_mark(gmg_handle h) {
     (void)hipEventRecord(h->prof_ev[h->prof_n++], h->stream);
 }
 
+// coarse.b = U_k^T r_k (:1069) into level k + 1 -- together with that level's first pre-sweep where the layouts allow the two in one launch
+// (restrict_sweep0_kind; the level's launch_block_sweeps then starts with its second sweep: h->first_sweep_fused)
+template <class T>
+void restrict_into(gmg_handle h, int k, int d, bool il) {
+    Level& l = h->lv[k];
+    Level& c = h->lv[k + 1];
+    const int fused = (k + 1 < h->L && smooth_from_zero_ok(h, c, h->cfg.pre_iters)) ? restrict_sweep0_kind<T>(h, l, c, d, il) : 0;
+    if (fused) launch_restrict_sweep0<T>(h, l, c, d, Prec<T>::r(l), il, fused);
+    else launch_restrict<T>(h, l, c, d, Prec<T>::r(l), Prec<T>::b(c), il);
+}
+
 template <class T = double>
 void enqueue_down(gmg_handle h, int d, int k0 = 0) {
     const int L = h->L;
-    h->first_sweep_fused = false;                  // (set by launch_restrict_sweep0 for the level that follows)
+    if (k0 == 0) h->first_sweep_fused = false;     // (set by restrict_into for the level that follows; a caller that starts lower restricted into level k0 itself)
     for (int k = k0; k < L; ++k) {
         Level& l = h->lv[k];
         prof_mark(h);
@@ -662,10 +674,7 @@ void enqueue_down(gmg_handle h, int d, int k0 = 0) {
         if (!(k > 0 && launch_residual_delta<T>(h, l, d, Prec<T>::r(l))))
             launch_spmv<T>(h, l, d, 1, Prec<T>::b(l), Prec<T>::x(l), Prec<T>::r(l), res_slices, il);
         // :1069 (+ the first pre-sweep of level k + 1 where the layouts allow the two in one launch)
-        const int fused = (k + 1 < L && smooth_from_zero_ok(h, h->lv[k + 1], h->cfg.pre_iters)) ? restrict_sweep0_kind<T>(h, l, h->lv[k + 1], d, il) : 0;
-        if (fused) launch_restrict_sweep0<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), il, fused);
-        else
-            launch_restrict<T>(h, l, h->lv[k + 1], d, Prec<T>::r(l), Prec<T>::b(h->lv[k + 1]), il);
+        restrict_into<T>(h, k, d, il);
         h->il_r0 = false;
     }
     prof_mark(h);

@@ -72,6 +72,7 @@ struct DistP2P {
     std::vector<std::vector<int>> own_blocks;             // [rank]: its blocks, ascending (block b = device rows 64 b .. 64 b + 63)
     int* d_l1 = nullptr;                                  // this rank's launch tables, one allocation:
     int *d_own_begin = nullptr, *d_own_ncolors = nullptr; //   first row / colour count of its blocks (the block sweep's tables)
+    int* d_own_blocks = nullptr;                          //   their numbers (restrict_sweep0's block list)
     int *d_rsl = nullptr, *d_asl = nullptr, *d_psl = nullptr;   //   slices of U0^T, of A1 and of U1 that hold its rows
     int n_rsl = 0, n_asl = 0, n_psl = 0;
     std::vector<std::vector<int>> halo1, halo0r;          // [s * world + t]: x1 entries / r0 entries rank s publishes to rank t, ascending
@@ -427,13 +428,14 @@ int gmg_p2p_prepare(gmg_handle h, int rank, int world, int d) try {
         std::vector<int> tab;
         for (int b : mine) tab.push_back(o1.blk_begin[b]);
         for (int b : mine) tab.push_back(o1.blk_ncolors[b]);
+        for (int b : mine) tab.push_back(b);
         for (int rps : {rps_r, rps_a, rps_p}) for (int b : mine) for (int q = 0; q < 64 / rps; ++q) tab.push_back(b * (64 / rps) + q);
         HIPCHK(hipMalloc((void**)&p->d_l1, sizeof(int) * std::max<size_t>(tab.size(), 1)));
         if (!tab.empty()) HIPCHK(hipMemcpy(p->d_l1, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
         const int nm = (int)mine.size();
-        p->d_own_begin = p->d_l1; p->d_own_ncolors = p->d_l1 + nm;
+        p->d_own_begin = p->d_l1; p->d_own_ncolors = p->d_l1 + nm; p->d_own_blocks = p->d_l1 + 2 * nm;
         p->n_rsl = nm * (64 / rps_r); p->n_asl = nm * (64 / rps_a); p->n_psl = nm * (64 / rps_p);
-        p->d_rsl = p->d_l1 + 2 * nm; p->d_asl = p->d_rsl + p->n_rsl; p->d_psl = p->d_asl + p->n_asl;
+        p->d_rsl = p->d_l1 + 3 * nm; p->d_asl = p->d_rsl + p->n_rsl; p->d_psl = p->d_asl + p->n_asl;
     }
     // ---- mailbox layout of every rank: region (src, kind, parity) in dst's mailbox
     const long long own_rows = (long long)l.n_pad / world;
@@ -793,7 +795,8 @@ int p2p_smooth(gmg_handle h, int iters) {
 
 // `iters` block sweeps on this rank's blocks of level 1, each followed by the x1 halo exchange; the result ends in l1.x
 // (from_zero: the iterate is the zero vector and the first sweep takes no input, like launch_block_sweeps).
-int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero) {
+// first_fused: the first (from-zero) sweep already ran inside the restriction's launch (restrict_sweep0 on this rank's blocks): its result is in tmp
+int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero, bool first_fused = false) {
     DistP2P* p = h->p2p;
     Level& l1 = h->lv[1];
     const int C = dist_classes(h->lv[0].ord), d = p->d, nb = (int)p->own_blocks[p->rank].size();
@@ -802,7 +805,7 @@ int p2p_smooth_level1(gmg_handle h, int iters, bool from_zero) {
     int rc;
     const double* before_last = nullptr;
     for (int it = 0; it < iters; ++it) {
-        launch_block_sweep_range<double>(h, l1, d, in, out, 0, nb, p->d_own_begin, p->d_own_ncolors);
+        if (!(it == 0 && first_fused)) launch_block_sweep_range<double>(h, l1, d, in, out, 0, nb, p->d_own_begin, p->d_own_ncolors);
         if ((rc = p2p_exchange(h, C + 3, out, l1.n_pad))) return rc;
         before_last = in;
         if (it == 0 && from_zero) { in = out; out = l1.x; }
@@ -824,7 +827,26 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
     const int C = dist_classes(l0.ord), d = p->d;
     int rc;
     if ((rc = p2p_exchange(h, C + 5, l0.r, l0.n_pad))) return rc;                      // r0 entries my restriction rows read
-    if (p->n_rsl > 0)                                                                 // :1069 on my rows of level 1
+    const bool from_zero = smooth_from_zero_ok(h, l1, h->cfg.pre_iters);
+    // :1069 on my rows of level 1 -- together with the first pre-sweep of my blocks where the layouts allow it (restrict_sweep0 over this rank's
+    // block list: a workgroup's four restriction slices are one block; same bits as the two launches)
+    const bool fuse = from_zero && p->n_rsl > 0 && d <= 4 && restrict_sweep0_kind<double>(h, l0, l1, d, false) == 1 && l0.R.lpr == 4 && p->n_rsl == 4 * (int)p->own_blocks[p->rank].size();
+    if (fuse) {
+        const int nbk = (int)p->own_blocks[p->rank].size();
+        const int vgrid = (nbk + 7) / 8 * 8;
+        const size_t lds_sweep = gmgk::ep_lds_bytes<double>(d, 0, l1.ep_cap_l);
+        const size_t lds = lds_sweep + (size_t)d * 64 * sizeof(double);
+        DISPATCH_D(d, DISPATCH_C16(l0.R.c16_sel(), {
+            if (ep_streams(l1))
+                hipLaunchKernelGGL((gmgk::restrict_sweep0<double, D, true, C16, 0>), dim3(vgrid), dim3(256), lds, h->stream, l0.R.slice_ptr, l0.R.col, l0.R.val, l0.R.row_of, l0.r, l0.n_pad,
+                                   l0.R.col16, l0.R.win_base, l0.R.c16_arg(), l1.b, l1.d_blk_ncolors, l1.d_row_color, l1.ep_ptr, l1.ep_col, l1.ep_val, l1.diag, l1.tmp, l1.n_pad, nbk, vgrid,
+                                   (int)lds_sweep, (const int*)p->d_own_blocks);
+            else
+                hipLaunchKernelGGL((gmgk::restrict_sweep0<double, D, false, C16, 0>), dim3(vgrid), dim3(256), lds, h->stream, l0.R.slice_ptr, l0.R.col, l0.R.val, l0.R.row_of, l0.r, l0.n_pad,
+                                   l0.R.col16, l0.R.win_base, l0.R.c16_arg(), l1.b, l1.d_blk_ncolors, l1.d_row_color, l1.ep_ptr, l1.ep_col, l1.ep_val, l1.diag, l1.tmp, l1.n_pad, nbk, vgrid,
+                                   (int)lds_sweep, (const int*)p->d_own_blocks);
+        }));
+    } else if (p->n_rsl > 0)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             if (l0.R.lpr == 4) {
@@ -837,9 +859,8 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
                                                   p->d_rsl, p->n_rsl));
             }
         }
-    const bool from_zero = smooth_from_zero_ok(h, l1, h->cfg.pre_iters);
     if (!from_zero) HIPCHK(hipMemsetAsync(l1.x, 0, sizeof(double) * (size_t)l1.n_pad * d, h->stream));       // :1072-1073
-    if ((rc = p2p_smooth_level1(h, h->cfg.pre_iters, from_zero))) return rc;              // :1063
+    if ((rc = p2p_smooth_level1(h, h->cfg.pre_iters, from_zero, fuse))) return rc;        // :1063
     const bool from_sweep = launch_residual_delta<double>(h, l1, d, l1.r, p->d_own_begin, (int)p->own_blocks[p->rank].size());      // :1066 on my rows ...
     if (!from_sweep && p->n_asl > 0)                                                  // ... or with the residual SpMV
         for (int c0 = 0; c0 < d; c0 += 4) {
@@ -855,7 +876,8 @@ int p2p_coarse_cycle_sharded(gmg_handle h) {
             }
         }
     if ((rc = p2p_exchange(h, C + 4, l1.r, l1.n_pad))) return rc;                      // everybody's rows -> complete r1 on every rank
-    launch_restrict<double>(h, l1, h->lv[2], d, l1.r, h->lv[2].b);                      // :1069, replicated from here down
+    h->first_sweep_fused = false;
+    restrict_into<double>(h, 1, d, false);                                            // :1069, replicated from here down (+ level 2's first sweep where fused)
     enqueue_down<double>(h, d, 2);
     if (h->coarse_device) enqueue_coarse_device<double>(h, d);
     else if ((rc = coarse_host_begin<double>(h, d))) return rc;       // the host half is served at the end of the cycle's enqueue (p2p_vcycle)

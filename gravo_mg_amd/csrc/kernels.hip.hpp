@@ -805,7 +805,8 @@ __global__ __launch_bounds__(256) void restrict_sweep0(const int64_t* __restrict
                                                        const unsigned* __restrict__ r_col16, const int* __restrict__ r_win_base, int r_c16_arg,
                                                        T* __restrict__ b_out, const int* __restrict__ blk_ncolors, const unsigned char* __restrict__ row_color,
                                                        const int* __restrict__ l_ptr, const unsigned short* __restrict__ l_col, const T* __restrict__ l_val,
-                                                       const T* __restrict__ diag, T* __restrict__ x_out, int ld, int n_blocks, int vgrid, int bs_off) {
+                                                       const T* __restrict__ diag, T* __restrict__ x_out, int ld, int n_blocks, int vgrid, int bs_off,
+                                                       const int* __restrict__ blk_list = nullptr) {
     extern __shared__ unsigned char smem_raw[];
     T* xs = reinterpret_cast<T*>(smem_raw);
     typedef typename EpRec<T>::type Rec;
@@ -814,8 +815,10 @@ __global__ __launch_bounds__(256) void restrict_sweep0(const int64_t* __restrict
     T* bs = reinterpret_cast<T*>(smem_raw + bs_off);
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int chunk = vgrid >> 3;
-    const int blk = __builtin_amdgcn_readfirstlane(((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3));
-    if (blk >= n_blocks) return;
+    const int vb = __builtin_amdgcn_readfirstlane(((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3));
+    if (vb >= n_blocks) return;
+    // blk_list: the blocks of ONE rank of a level partitioned by blocks (engine_dist.hip.hpp), n_blocks of them; else the level's blocks in order
+    const int blk = blk_list ? __builtin_amdgcn_readfirstlane(blk_list[vb]) : vb;
     const int r0 = blk << 6;
     // wave 0: everything the sweep will need is requested before the restriction's own loads
     int q0 = 0, nL = 0, lb = 0, nlow = 0, mycolor = 0;
