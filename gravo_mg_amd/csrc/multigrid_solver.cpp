@@ -81,15 +81,24 @@ std::pair<uint64_t, uint64_t> SparseMatrix::digest() const {
     return {a, b};
 }
 
+// Where this class departs from the engine's defaults.  The reference's callers hand solve() a NEW system matrix per call (a new tau per frame,
+// demos/smoothing.py:43-52), and solve() sets everything up again every time (multigrid_solver.cpp:1387-1401): a caller like that solves each
+// system ONCE, with 4-6 V-cycles, and the engine's default -- a dense inverse of the coarsest operator built per gmg_set_system, which pays off
+// from ~50 cycles per system on -- would cost it 2-7 ms per solve for 0.2-0.7 ms saved.  The coarsest solve therefore stays where
+// the reference has it, on the host; set_engine_option("coarse_mode", 2) selects the engine's default for callers that keep a system.
+static void dropInDefaults(gmg_config& c) { c.coarse_mode = GMG_COARSE_HOST_LDLT; }
+
 MultigridSolver::MultigridSolver(MatrixXd& V_, MatrixXi& neigh_, SparseMatrix& M_) : V(V_), neigh(neigh_), M(M_) {
     hierarchyTiming["n_vertices"] = V.rows();               // multigrid_solver.cpp:21
     gmg_config_default(&engineConfig);
+    dropInDefaults(engineConfig);
     std::memset(&createdWith_, 0, sizeof(createdWith_));
 }
 
 MultigridSolver::MultigridSolver(MatrixXd&& V_, MatrixXi&& neigh_, SparseMatrix&& M_) : V(std::move(V_)), neigh(std::move(neigh_)), M(std::move(M_)) {
     hierarchyTiming["n_vertices"] = V.rows();
     gmg_config_default(&engineConfig);
+    dropInDefaults(engineConfig);
     std::memset(&createdWith_, 0, sizeof(createdWith_));
 }
 

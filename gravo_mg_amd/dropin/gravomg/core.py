@@ -140,7 +140,9 @@ class MultigridSolver(object):
         residual() and the single-process entry points need partition_setup=False (every rank then holds the whole operator).
         exchange: "mailbox" (default: device-initiated stores through hipIpc mappings, one launch per exchange) or "rccl" (every exchange as
         pack -> ncclAllGather -> unpack on the engine's stream, gmg_config::dist_exchange = 1: for boxes where processes cannot map each
-        other's device memory); the same partition, the same iterates."""
+        other's device memory); the same partition, the same iterates.  (The coarsest solve stays where the single-process object has it -- on the host by
+        default -- so that the ranks reproduce its iterates bit for bit; set_engine_option("coarse_mode", 2) before the first solve moves it onto
+        the devices: no host work per rank inside a cycle.)"""
         if exchange not in ("mailbox", "rccl"):
             raise ValueError("exchange must be 'mailbox' or 'rccl'")
         rank, world = int(rank), int(world)
