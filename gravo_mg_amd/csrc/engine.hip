@@ -181,6 +181,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->stream_gate = 1;
     cfg->prepare_structure = 1;
     cfg->fuse_restrict_sweep = 1;
+    cfg->speculate_head = 1;
     cfg->dist_exchange = 0;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
@@ -234,7 +235,7 @@ void gmg_destroy(gmg_handle h) {
         p2p_release_handle(h);
         drop_system(h);
         drop_device_transfers(h);
-        for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm}) if (*p) (void)dev_free(*p);
+        for (double** p : {&h->d_stage, &h->d_partials, &h->d_norm, &h->d_watch}) if (*p) (void)dev_free(*p);
         if (h->h_pinned) (void)sync_hipHostFree(h->h_pinned);
         for (int i = 0; i < 2; ++i) { if (h->h_stage[i]) (void)sync_hipHostFree(h->h_stage[i]); if (h->h_stage_ev[i]) (void)hipEventDestroy(h->h_stage_ev[i]); }
         for (hipEvent_t& e : h->h_chunk_ev) if (e) (void)hipEventDestroy(e);
@@ -1487,6 +1488,21 @@ int gmg_load_problem(gmg_handle h, const double* b, const double* x0, int d) try
     return GMG_OK;
 } GMG_CATCH_H
 
+namespace {
+// arms the device-side decision of the residual checks enqueued inside its scope (launch_reduce) and clears it, with a head that was not
+// taken up, on every way out
+struct WatchScope {
+    gmg_handle h; bool on;
+    WatchScope(gmg_handle h_, bool on_, int mode, double tol, int type) : h(h_), on(on_) {
+        h->head_enqueued = false;
+        if (!on) return;
+        h->timing["heads_enqueued"] += 0.0; h->timing["head_decision_differs"] += 0.0;
+        h->watch_active = true; h->watch_mode = mode; h->watch_tol = tol; h->watch_type = type; h->watch_cycles_done = 0;
+    }
+    ~WatchScope() { h->watch_active = false; h->head_enqueued = false; }
+};
+}  // namespace
+
 int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) try {
     NEED_DEVICE();
     if (h->loaded_d <= 0) return fail(h, GMG_ERR_STATE, "no problem loaded (gmg_load_problem)");
@@ -1496,9 +1512,14 @@ int gmg_run_cycles(gmg_handle h, int n_cycles, int stop_type, double* residues) 
     if (stop_type >= 0 && (rc = check_norm_type(h, stop_type))) return rc;
     const int d = h->loaded_d;
     HelperScope helper_scope(h, d);
+    // (a fixed number of cycles: the first colour launch of the next one goes into the stream before the host has seen this one's norm,
+    // as in the solve loop -- there the check's reduction decides on the device whether that launch does anything, solve_common)
+    WatchScope watch(h, stop_type >= 0 && head_eligible(h, d), 0, 0.0, stop_type);
     for (int i = 0; i < n_cycles; ++i) {
+        h->watch_cycles_done = i + 1;
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
         if (stop_type >= 0) {
+            if (watch.on && i + 1 < n_cycles) enqueue_head(h, d);
             if ((rc = wait_norm(h))) return rc;
             if (residues) residues[i] = norm_from_sums(h->h_norm, d, stop_type);
         }
@@ -1571,9 +1592,17 @@ static int solve_common(gmg_handle h, const double* rhs, const double* x0, doubl
     auto t0 = clk::now();
     double residue = 0.0, first_residue = 0.0, least_residue = 0.0;
     int it = 0;
-    bool blown = false;
+    bool blown = false, go_on = false;
+    // Head of the next cycle (gmg_config::speculate_head): the check's reduction takes the decision below on the device too (same sums, same
+    // correctly rounded arithmetic: gmgk::reduce_partials / SolveWatch) and the first colour launch of the next cycle is enqueued behind it at
+    // once -- it returns without touching x when the iteration has stopped.  The ~6 us the host needs to see the norm and to get a launch to
+    // the device are hidden behind that launch.  The host follows the device's word (one decision, not two).
+    WatchScope watch(h, head_eligible(h, d), 1, tol, stop_type);
     do {
+        h->watch_cycles_done = it + 1;
         if ((rc = vcycle_resident(h, d, stop_type))) return rc;
+        const bool head = watch.on && it + 2 <= max_iter;          // (a cycle after this one is allowed)
+        if (head) enqueue_head(h, d);
         if ((rc = wait_norm(h))) return rc;
         residue = norm_from_sums(h->h_norm, d, stop_type);
         if (it == 0) first_residue = least_residue = residue;
@@ -1583,7 +1612,14 @@ static int solve_common(gmg_handle h, const double* rhs, const double* x0, doubl
         if (h->cfg.verbose) std::printf("%d,%f,%.14f \n", it, ms_since(t0), residue);
         // no way back from here (the reference would spin to max_iter on NaNs): stop, the caller is told below
         blown = !std::isfinite(residue) || (it >= 3 && residue > 1e4 * least_residue);
-    } while (residue > tol && it < max_iter && !blown);
+        go_on = residue > tol && it < max_iter && !blown;
+        if (head) {
+            const bool device_go = __atomic_load_n(h->h_flag + 1, __ATOMIC_ACQUIRE) != 0;
+            if (device_go != go_on) h->timing["head_decision_differs"] += 1.0;      // (never seen: the two sides compute the same bits)
+            go_on = device_go;
+            if (!go_on) h->head_enqueued = false;                  // that launch found the word cleared and returned
+        }
+    } while (go_on);
     h->timing["cycles"] = ms_since(t0);
     // Not contracting: the iteration ended above the tolerance with a residue that is not finite or larger than after the first cycle.
     // The parallel smoothers are not the reference's lexicographic Gauss-Seidel (block sweeps on the Galerkin levels take the

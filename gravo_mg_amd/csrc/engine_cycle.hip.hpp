@@ -88,34 +88,70 @@ bool fold_residual<double>(gmg_handle h, Level& l, int d, bool last_launch, int 
     return true;
 }
 
+inline bool polled(gmg_handle h);
+
+// one colour launch of a sweep over level l (columns c0 .. c0 + dc); go: see gmgk::gs_color
 template <class T>
-void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
+void launch_gs_color(gmg_handle h, Level& l, int c0, int dc, int sb, int se, const int* go = nullptr) {
     const int ld = l.n_pad;
     const bool fine = &l == &h->lv[0];
     const T omega = fine ? (T)h->cfg.gs_omega : (T)1.0;       // over-relaxation on the finest level only (gmg_config::gs_omega)
     T* x = Prec<T>::x(l);
     const T* b = Prec<T>::b(l);
+    if (fine && l.Aoff.c16_mode != 0) {           // FINE = 1 + C16 (c16_sel: 1 / 2 streamed, 3 / 4 a fine level that stays on the chip)
+        DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color<T, D, C16 + 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                          l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                          x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg(), (const unsigned long long*)nullptr, go)));
+    } else if (fine) {
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                          l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                          x + (size_t)c0 * ld, ld, sb, se, 1, omega, (const unsigned*)nullptr, (const int*)nullptr, 0, (const unsigned long long*)nullptr, go));
+    } else {
+        DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
+                                          l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
+                                          x + (size_t)c0 * ld, ld, sb, se, 1, omega));
+    }
+}
+
+inline int first_color(const Level& l) {
+    for (int c = 0; c < l.ord.n_colors; ++c)
+        if (l.ord.color_begin[c + 1] / 64 > l.ord.color_begin[c] / 64) return c;
+    return -1;
+}
+
+// Head of the next cycle: may the first colour launch of the level-0 pre-smoothing be enqueued ahead of the solve loop's decision?  Stream
+// launches with the polled check (the reduction publishes the decision), fp64, colour-major level 0 with a colour class in front of the one the
+// residual rides on, one group of columns, the whole system on this device.
+inline bool head_eligible(gmg_handle h, int d) {
+    return h->cfg.speculate_head && polled(h) && !h->cfg.inner_precision && h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS && h->cfg.pre_iters > 0 && h->L >= 1 &&
+           !h->lv[0].ord.blocked && h->lv[0].ord.n_colors >= 2 && first_color(h->lv[0]) >= 0 && first_color(h->lv[0]) < h->lv[0].ord.n_colors - 1 && d >= 1 && d <= 4 &&
+           !h->partitioned && h->part_world <= 1 && h->d_watch && !h->prof_on;
+}
+inline void enqueue_head(gmg_handle h, int d) {
+    Level& l = h->lv[0];
+    const int c = first_color(l);
+    launch_gs_color<double>(h, l, 0, d, l.ord.color_begin[c] / 64, l.ord.color_begin[c + 1] / 64, reinterpret_cast<const int*>(h->d_watch + 1));
+    h->head_enqueued = true;
+    h->timing["heads_enqueued"] += 1.0;
+}
+
+template <class T>
+void launch_gs_sweeps(gmg_handle h, Level& l, int d, int iters) {
+    const bool fine = &l == &h->lv[0];
+    // (the first launch of this cycle is already in the stream: enqueue_head)
+    const bool skip_head = fine && h->head_enqueued;
+    if (fine) h->head_enqueued = false;
+    const int c_head = skip_head ? first_color(l) : -1;
     for (int it = 0; it < iters; ++it)
         for (int c0 = 0; c0 < d; c0 += 4) {
             int dc = std::min(4, d - c0);
             for (int c = 0; c < l.ord.n_colors; ++c) {
                 int sb = l.ord.color_begin[c] / 64, se = l.ord.color_begin[c + 1] / 64;
                 if (se <= sb) continue;
+                if (it == 0 && c0 == 0 && c == c_head) continue;
                 if (fold_norm<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
                 if (fold_residual<T>(h, l, d, it == iters - 1 && c == l.ord.n_colors - 1, sb, se)) continue;
-                if (fine && l.Aoff.c16_mode != 0) {           // FINE = 1 + C16 (c16_sel: 1 / 2 streamed, 3 / 4 a fine level that stays on the chip)
-                    DISPATCH_D(dc, DISPATCH_C16(l.Aoff.c16_sel(), hipLaunchKernelGGL((gmgk::gs_color<T, D, C16 + 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega, l.Aoff.col16, l.Aoff.win_base, l.Aoff.c16_arg())));
-                } else if (fine) {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 1>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega));
-                } else {
-                    DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::gs_color<T, D, 0>), dim3(grid_for(se - sb)), dim3(gmgk::kBlock), 0, h->stream,
-                                                      l.Aoff.slice_ptr, l.Aoff.col, Prec<T>::val(l.Aoff), Prec<T>::diag(l), b + (size_t)c0 * ld,
-                                                      x + (size_t)c0 * ld, ld, sb, se, 1, omega));
-                }
+                launch_gs_color<T>(h, l, c0, dc, sb, se);
             }
         }
 }
@@ -437,9 +473,13 @@ int wait_norm(gmg_handle h) {
 
 // the reduction of one group of <= 4 columns: into h_norm + flag when polled, into d_norm (+ a copy later) otherwise
 void launch_reduce(gmg_handle h, int nblk, int dc, int c0, bool last) {
-    if (polled(h))
+    if (polled(h)) {
+        gmgk::SolveWatch watch{nullptr, nullptr, nullptr, 0.0, 0, 0, 0, 0};
+        if (h->watch_active && last && c0 == 0 && h->d_watch)         // (one group of columns: the kernel sees every sum the decision needs)
+            watch = gmgk::SolveWatch{reinterpret_cast<int*>(h->d_watch + 1), h->h_flag + 1, h->d_watch, h->watch_tol, h->watch_mode, h->watch_type, dc, h->watch_cycles_done};
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->h_norm + 2 * c0,
-                           last ? h->h_flag : nullptr, last ? ++h->flag_seq[0] : 0ull, (int)EnvSwitches::get().publish_fenced);
+                           last ? h->h_flag : nullptr, last ? ++h->flag_seq[0] : 0ull, (int)EnvSwitches::get().publish_fenced, watch);
+    }
     else
         hipLaunchKernelGGL(gmgk::reduce_partials, dim3(1), dim3(gmgk::kReduceBlock), 0, h->stream, h->d_partials, nblk, 2 * dc, h->d_norm + 2 * c0,
                            (unsigned long long*)nullptr, 0ull, 0);
@@ -517,6 +557,10 @@ int ensure_vectors(gmg_handle h, int d) {
 
     if (h->d_norm) (void)dev_free(h->d_norm);
     HIPCHK(dev_malloc((void**)&h->d_norm, sizeof(double) * 2 * d));
+    if (!h->d_watch) {
+        HIPCHK(dev_malloc((void**)&h->d_watch, 16));
+        HIPCHK(hipMemsetAsync(h->d_watch, 0, 16, h->stream));
+    }
     h->dcap = d;
     h->loaded_d = 0;
     return GMG_OK;

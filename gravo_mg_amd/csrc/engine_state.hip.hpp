@@ -228,6 +228,13 @@ struct gmg_solver_s {
     hipEvent_t h_chunk_ev[16] = {};      // per-chunk arrival of a download (to_host): 8 per staging buffer
     double* d_partials = nullptr; int partial_blocks = 0;
     double* d_norm = nullptr;
+    // Head of the next cycle (gmg_config::speculate_head; engine.hip::solve_common): the solve loop's decision is taken by the check's
+    // reduction on the device (d_watch: {double least; int go}), the first colour launch of the next cycle is enqueued behind it before the
+    // host has seen the norm, and returns at once when the iteration stopped.  watch_*: what the reduction needs to decide; head_enqueued:
+    // the next level-0 pre-smoothing starts with its second launch.
+    double* d_watch = nullptr;
+    bool watch_active = false; int watch_mode = 0, watch_type = 0, watch_cycles_done = 0; double watch_tol = 0.0;
+    bool head_enqueued = false;
     double* h_pinned = nullptr; size_t pinned_cap = 0;     // coarse rhs / solution staging
     double* h_norm = nullptr;
     // polled completion (stream launches only): a kernel writes its small result into pinned memory and then a sequence

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(kBlock) void gs_color(const int64_t* __restrict__ s
                                                    const T* __restrict__ b, T* x, int ld, int slice_begin,
                                                    int slice_end, int xcd_swizzle, T omega, const unsigned* __restrict__ col16 = nullptr,
                                                    const int* __restrict__ win_base = nullptr, int c16_arg = 0,
-                                                   const unsigned long long* __restrict__ plain_rows = nullptr) {
+                                                   const unsigned long long* __restrict__ plain_rows = nullptr, const int* __restrict__ go = nullptr) {
+    // `go`: this launch was enqueued AHEAD of the solve loop's decision (the first colour launch of the next cycle, behind the residual check of
+    // this one: engine.hip, "head of the next cycle"); the check's reduction wrote the decision -- a stopped iteration's x stays as it is
+    if (go != nullptr && *go == 0) return;
     const int s = slice_begin + wave_slice(slice_end - slice_begin, xcd_swizzle);
     if (s >= slice_end) return;
     const int lane = threadIdx.x & 63;
@@ -1240,10 +1243,52 @@ __device__ __forceinline__ void block_reduce_partials(const double* __restrict__
 // flag != nullptr: `out` is host-visible pinned memory and `seq` is published in *flag after the sums -- the host polls
 // that word instead of paying a copy kernel and a stream synchronisation per residual check.  (The sums are written by the
 // threads of wave 0; lane 0 of that wave releases them: one system-scope fence, not one per thread.)
+// The solve loop's decision, taken where the sums are (`watch.go` != nullptr): the host's arithmetic (engine_cycle.hip.hpp::norm_from_sums and the
+// loop of engine.hip::solve_common: sqrt and division are correctly rounded on both sides), so that a launch enqueued behind this one can be
+// told whether the iteration goes on.  The host does not decide a second time: it reads the word this kernel publishes beside the sums.
+struct SolveWatch {
+    int* go;                    // device word the speculative launch reads (nullptr: no decision wanted)
+    unsigned long long* host_go;  // the same decision for the host (pinned, beside the sequence word)
+    double* least;              // device: smallest residue of this solve so far
+    double tol;
+    int mode;                   // 0: always go on (a fixed number of cycles, gmg_run_cycles); 1: the solve loop's test
+    int norm_type, d, cycles_done;
+};
 __global__ __launch_bounds__(kReduceBlock) void reduce_partials(const double* __restrict__ partials, int n_blocks, int ncomp,
-                                                                double* __restrict__ out, unsigned long long* flag, unsigned long long seq, int fenced) {
+                                                                double* __restrict__ out, unsigned long long* flag, unsigned long long seq, int fenced,
+                                                                SolveWatch watch = SolveWatch{nullptr, nullptr, nullptr, 0.0, 0, 0, 0, 0}) {
     __shared__ double red[kReduceBlock / 64][kReduceMaxComp];
     block_reduce_partials(partials, n_blocks, ncomp, out, red);
+    if (watch.go != nullptr && threadIdx.x == 0) {
+        int go = 1;
+        if (watch.mode == 1) {
+            double s[kReduceMaxComp];
+            for (int c = 0; c < ncomp; ++c) {                              // (the sums as block_reduce_partials formed them: same order)
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < kReduceBlock / 64; ++w) t += red[w][c];
+                s[c] = t;
+            }
+            double res = 0.0;
+            if (watch.norm_type == 3) {
+                double t = 0.0;
+                for (int c = 0; c < watch.d; ++c) t += s[2 * c];
+                res = __builtin_sqrt(t);
+            } else {
+                for (int c = 0; c < watch.d; ++c) {
+                    const double v = watch.norm_type == 0 ? __builtin_sqrt(s[2 * c]) / __builtin_sqrt(s[2 * c + 1]) : __builtin_sqrt(s[2 * c] / s[2 * c + 1]);
+                    if (c == 0 || v > res) res = v;
+                }
+            }
+            double least = watch.cycles_done <= 1 ? res : *watch.least;
+            if (res < least) least = res;
+            *watch.least = least;
+            const bool blown = !__builtin_isfinite(res) || (watch.cycles_done >= 3 && res > 1e4 * least);
+            go = (res > watch.tol && !blown) ? 1 : 0;
+        }
+        *watch.go = go;
+        __hip_atomic_store(watch.host_go, (unsigned long long)go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (flag && threadIdx.x < 64) {
         // the sums went out as write-through stores: drained, they are ahead of the sequence word (no system fence: that writes the L2 back and
         // invalidates it, microseconds per residual check; publish_order)

@@ -126,6 +126,11 @@ typedef struct {
     int fuse_restrict_sweep; /* 1 (default): the restriction into a level that runs the entry-parallel block sweep also runs that level's first pre-sweep
                               (the coarse correction starts from zero, multigrid_solver.cpp:1072-1073: its first sweep needs only the block's own right-hand
                               sides) -- one launch less per such level and cycle, the same bits; 0: two launches */
+    int speculate_head;    /* 1 (default): the solve loop (multigrid_solver.cpp:1408-1419: cycle, residual check, decision) enqueues the FIRST colour launch
+                              of the next cycle behind the check before the host has seen the norm; the check's reduction takes the loop's decision on the
+                              device (same sums, same arithmetic) and that launch returns at once when the iteration has stopped -- the ~6 us of host latency
+                              between two cycles disappear, iterates and iteration counts are unchanged.  Stream launches, fp64, colour-major level 0, d <= 4,
+                              one device; otherwise, and with 0, the host decides before anything of the next cycle is enqueued */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -556,3 +556,61 @@ def test_restriction_fused_with_the_first_pre_sweep_gives_the_same_bits(cabi, ki
         eng.close()
     assert P.rhs.shape[1] == d
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("kind,d", [("poisson", 1), ("smoothing", 3), ("poisson-host-coarse", 1), ("poisson-omega1", 1)])
+def test_head_of_the_next_cycle_is_enqueued_ahead_of_the_decision_and_changes_nothing(cabi, kind, d):
+    """gmg_config::speculate_head: the solve loop (multigrid_solver.cpp:1408-1419) puts the first colour launch of the next cycle into the stream behind
+    the residual check before the host has seen the norm; the check's reduction decides on the device whether the iteration goes on, and a stopped
+    iteration's launch returns without touching x.  Iterates, iteration counts and residue histories are those of the loop that waits -- when the
+    tolerance stops it, when max_iter stops it (no head behind the last allowed cycle), when the first cycle already meets the tolerance (the head
+    is in the stream and must do nothing), and for a fixed number of cycles (gmg_run_cycles)."""
+    from tests import problems
+    P = problems.torus_problem(300, 280, "smoothing" if kind.startswith("smoothing") else "poisson", 100)
+    kw = {}
+    if "host-coarse" in kind:
+        kw["coarse_mode"] = cabi.COARSE_HOST_LDLT
+    if "omega1" in kind:
+        kw["gs_omega"] = 1.0
+    out = []
+    for spec in (1, 0):
+        eng = cabi.Engine(speculate_head=spec, **kw)
+        eng.set_prolongations(P.U); eng.set_mass(P.mass); eng.set_system(P.lhs)
+        res = {}
+        for name, tol, max_iter in (("to the tolerance", 1e-6, 100), ("max_iter", 1e-30, 3), ("one cycle allowed", 1e-30, 1), ("first cycle is enough", 1e3, 100),
+                                     ("second solve", 1e-5, 100)):
+            x, it, r, conv = eng.solve(P.rhs, tol=tol, max_iter=max_iter)
+            res[name] = (x.copy(), it, r, conv[:, 1].copy())
+        if spec:
+            assert eng.timing("heads_enqueued") >= res["to the tolerance"][1] + 2 and eng.timing("head_decision_differs") == 0.0
+        else:
+            assert not _has_timing(eng, "heads_enqueued")
+        eng.load_problem(P.rhs, P.rhs)
+        res["run_cycles"] = (eng.run_cycles(4, 2).copy(), eng.fetch_solution().copy())
+        if spec:
+            assert eng.timing("heads_enqueued") >= res["to the tolerance"][1] + 2 + 3
+        # a cycle through the plain entry points afterwards starts with its own first launch
+        eng.load_problem(P.rhs, P.rhs)
+        res["then one cycle"] = (eng.run_cycles(1, -1), eng.fetch_solution().copy())
+        out.append(res)
+        eng.close()
+    assert P.rhs.shape[1] == d
+    a, b = out
+    assert a["to the tolerance"][1] > 2 and a["max_iter"][1] == 3 and a["one cycle allowed"][1] == 1 and a["first cycle is enough"][1] == 1
+    for name in ("to the tolerance", "max_iter", "one cycle allowed", "first cycle is enough", "second solve"):
+        assert a[name][1] == b[name][1], name
+        assert a[name][2] == b[name][2], name
+        assert np.array_equal(a[name][3], b[name][3]), name
+        assert np.array_equal(a[name][0], b[name][0]), name
+    assert np.array_equal(a["run_cycles"][0], b["run_cycles"][0]) and np.array_equal(a["run_cycles"][1], b["run_cycles"][1])
+    assert np.array_equal(a["then one cycle"][1], b["then one cycle"][1])
+    # the stopped iteration's x is the one after its last cycle: one cycle from x0 = rhs, whatever was in the stream behind the check
+    assert np.array_equal(a["first cycle is enough"][0], a["one cycle allowed"][0])
+
+
+def _has_timing(eng, key):
+    try:
+        eng.timing(key)
+        return True
+    except Exception:
+        return False
