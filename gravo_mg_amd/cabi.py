@@ -43,7 +43,7 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("prepare_structure", C.c_int), ("fuse_restrict_sweep", C.c_int), ("speculate_head", C.c_int),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("prepare_structure", C.c_int), ("fuse_restrict_sweep", C.c_int), ("speculate_head", C.c_int), ("uniform_slices", C.c_int),
     ]
 
 
@@ -321,7 +321,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_AUTO, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None, fuse_restrict_sweep=None, speculate_head=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None, fuse_restrict_sweep=None, speculate_head=None, uniform_slices=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -351,6 +351,8 @@ class Engine:
             cfg.fuse_restrict_sweep = int(bool(fuse_restrict_sweep))
         if speculate_head is not None:
             cfg.speculate_head = int(bool(speculate_head))
+        if uniform_slices is not None:
+            cfg.uniform_slices = int(bool(uniform_slices))
         if dist_exchange is not None:
             cfg.dist_exchange = int(dist_exchange)
         self._h = _vp()

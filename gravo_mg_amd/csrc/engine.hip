@@ -182,6 +182,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->prepare_structure = 1;
     cfg->fuse_restrict_sweep = 1;
     cfg->speculate_head = 1;
+    cfg->uniform_slices = 1;
     cfg->dist_exchange = 0;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;

@@ -467,20 +467,25 @@ int device_layout_level(gmg_handle h, int k, int* d_err, const int* own_rows = n
     // is coded again with 32 windows of 2 048, and keeps its 32-bit indices alone if that does not cover it either.
     DevSell* c16_ops[3] = {&l.Aoff, &l.R, &l.P};
     const char* c16_keys[3] = {"col16_l0", "col16_R_l0", "col16_P_l0"};
-    int c16_failed[6] = {0, 0, 0, 0, 0, 0};      // per operator: uncovered slices, 1 + index of the last of them
+    int c16_failed[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // per operator: uncovered slices, 1 + index of the last of them; [6 + i]: slices of another width than the mean
     DevTmp<int> d_c16;
     const bool c16 = k == 0 && h->cfg.fine_col16 != 0;      // (a blocked level 0 too: its residual-check and transfer kernels are the colour-major level's)
     const int c16_test_fail = h->dbg_col16_uncovered;         // gmg_debug_set (gravomg_hip_internal.h): N > 0 every N-th slice "uncovered", N < 0 the first -N
+    int c16_wexp[3] = {-1, -1, -1};
     auto c16_launch = [&](int i, int nw) -> int {
         DevSell& op = *c16_ops[i];
         if (op.win_base) { (void)dev_free(op.win_base); op.win_base = nullptr; }
         if (!op.col16) HIPCHK(dev_malloc((void**)&op.col16, sizeof(unsigned) * (size_t)op.stored));
         HIPCHK(dev_malloc((void**)&op.win_base, sizeof(int) * (size_t)op.n_slices * nw));
         HIPCHK(hipMemsetAsync(d_c16.p + 2 * i, 0, 2 * sizeof(int), h->stream));
+        HIPCHK(hipMemsetAsync(d_c16.p + 6 + i, 0, sizeof(int), h->stream));
+        const int64_t per_slice = op.stored / ((int64_t)op.n_slices * 64);
+        const int w_exp = (per_slice >= 1 && per_slice <= 63 && per_slice * op.n_slices * 64 == op.stored && h->cfg.uniform_slices) ? (int)per_slice : -1;
+        c16_wexp[i] = w_exp;
         const int* a_ptr = i == 0 ? dA.ptr : (const int*)nullptr;
         const int* n2o = i == 0 ? rows_k : (const int*)nullptr;
-        if (nw == 8) hipLaunchKernelGGL(gmgs::compress_cols<8>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i);
-        else hipLaunchKernelGGL(gmgs::compress_cols<32>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i);
+        if (nw == 8) hipLaunchKernelGGL(gmgs::compress_cols<8>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i, w_exp, d_c16.p + 6 + i);
+        else hipLaunchKernelGGL(gmgs::compress_cols<32>, dim3((op.n_slices + 3) / 4), dim3(256), 0, h->stream, op.slice_ptr, op.col, a_ptr, n2o, op.val, op.n_slices, c16_test_fail, op.col16, op.win_base, d_c16.p + 2 * i, w_exp, d_c16.p + 6 + i);
         op.c16_dbits = nw == 8 ? 13 : 11;
         return GMG_OK;
     };
@@ -489,13 +494,13 @@ int device_layout_level(gmg_handle h, int k, int* d_err, const int* own_rows = n
     auto c16_mode_of = [&](int i) { const DevSell& op = *c16_ops[i]; return c16_failed[2 * i + 1] <= op.n_slices / 16 ? 1 : (c16_failed[2 * i] <= op.n_slices / 8 ? 2 : 0); };
     if (k == 0) for (const char* key : c16_keys) h->timing[key] = 0.0;
     if (c16) {
-        if ((rc = d_c16.alloc(h, 6))) return rc;
+        if ((rc = d_c16.alloc(h, 9))) return rc;
         for (int i = 0; i < 3; ++i) {
             DevSell& op = *c16_ops[i];
-            if (op.stored <= 0 || op.n_slices <= 0 || (i == 0 && op.lpr != 1)) continue;
+            if (op.stored <= 0 || op.n_slices <= 0 || op.n_slices >= (1 << 24) || (i == 0 && op.lpr != 1)) continue;
             if ((rc = c16_launch(i, 8))) return rc;
         }
-        HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 9 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     }
     HIPCHK(hipStreamSynchronize(h->stream));      // uploads from the orderings' (pageable) arrays are done
     if (c16) {
@@ -503,7 +508,7 @@ int device_layout_level(gmg_handle h, int k, int* d_err, const int* own_rows = n
         for (int i = 0; i < 3; ++i)
             if (c16_ops[i]->col16 && c16_mode_of(i) == 0) { if ((rc = c16_launch(i, 32))) return rc; again = true; }
         if (again) {
-            HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 6 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(c16_failed, d_c16.p, 9 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
         for (int i = 0; i < 3; ++i) {
@@ -512,7 +517,9 @@ int device_layout_level(gmg_handle h, int k, int* d_err, const int* own_rows = n
             if (!op.col16) { h->timing[std::string(c16_keys[i]) + "_windows"] = 0; continue; }
             op.c16_mode = c16_mode_of(i);
             op.c16_from = c16_failed[2 * i + 1];
-            if (op.c16_mode == 0) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; op.c16_dbits = 13; op.c16_from = 0; }
+            op.uniform_w = (c16_wexp[i] > 0 && c16_failed[6 + i] == 0) ? c16_wexp[i] : 0;
+            h->timing[std::string(c16_keys[i]) + "_uniform_width"] = op.uniform_w;
+            if (op.c16_mode == 0) { (void)dev_free(op.col16); (void)dev_free(op.win_base); op.col16 = nullptr; op.win_base = nullptr; op.c16_dbits = 13; op.c16_from = 0; op.uniform_w = 0; }
             else h->timing[c16_keys[i]] = 1.0;
             h->timing[std::string(c16_keys[i]) + "_windows"] = op.col16 ? (op.c16_dbits == 13 ? 8 : 32) : 0;
             h->timing[std::string(c16_keys[i]) + "_mode"] = op.c16_mode;

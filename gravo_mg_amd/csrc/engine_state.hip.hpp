@@ -91,7 +91,8 @@ struct DevSell {
     int c16_mode = 0;                  //          0 none, 1 codes from slice c16_from on (uncovered slices are a short prefix), 2 uncovered slices flagged one by one
     int c16_from = 0;
     bool resident = false;             //          the layout is small enough to stay in the memory-side cache between the launches that read it: ordinary loads (c16_sel)
-    int c16_arg() const { return (c16_mode == 1 ? c16_from : 0) | (c16_dbits == 11 ? 1 << 30 : 0); }      // the kernels' c16_arg (kernels.hip.hpp::row_dot_sel)
+    int uniform_w = 0;                 //          > 0: every slice is this many entries wide, slice s starts at 64 uniform_w s (the kernels then do not read slice_ptr: row_dot)
+    int c16_arg() const { return (c16_mode == 1 ? c16_from : 0) | uniform_w << 24 | (c16_dbits == 11 ? 1 << 30 : 0); }      // the kernels' c16_arg (kernels.hip.hpp::row_dot_sel)
     int c16_sel() const { return c16_mode ? c16_mode + (resident ? 2 : 0) : 0; }      // the kernels' C16 template argument: 3 / 4 = modes 1 / 2 read with ordinary loads
 };
 

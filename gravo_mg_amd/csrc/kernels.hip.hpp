@@ -67,9 +67,11 @@ template <int D> struct DotGroup { static constexpr int value = D >= 4 ? 4 : (D 
 template <class T, int D, int G = DotGroup<D>::value, int XI = 0>
 __device__ __forceinline__ void row_dot(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col,
                                         const T* __restrict__ val, const T* x, int ld, int s, int lane,
-                                        T (&acc)[D]) {
-    const int64_t p0 = slice_ptr[s];
-    int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+                                        T (&acc)[D], int uw = 0) {
+    // uw > 0: every slice of this operator is uw entries wide (DevSell::uniform_w) -- the slice's place follows from its number and the wave's
+    // first loads are the entries themselves, not the two pointers they would otherwise wait for (one dependent memory round trip less per wave)
+    const int64_t p0 = uw ? (int64_t)s * (uw << 6) : slice_ptr[s];
+    int w = uw ? uw : (int)((slice_ptr[s + 1] - p0) >> 6);
     const int* cp = col + p0 + lane;
     const T* vp = val + p0 + lane;
 #pragma unroll
@@ -135,11 +137,11 @@ __device__ __forceinline__ void row_dot_group16(const unsigned* __restrict__ cp,
 // row_dot with the columns read from the codes (G is even: a group's codes are whole words)
 template <class T, int D, bool FLAGS, int G = DotGroup<D>::value, int XI = 0, bool KEEP = false>
 __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
-                                          const int* __restrict__ win_base, int dbits, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D]) {
+                                          const int* __restrict__ win_base, int dbits, const T* __restrict__ val, const T* x, int ld, int s, int lane, T (&acc)[D], int uw = 0) {
     const int wshift = 16 - dbits;                                        // windows per slice = 1 << wshift
     const int basev = win_base[((int64_t)s << wshift) + (lane & ((1 << wshift) - 1))];
-    const int64_t p0 = slice_ptr[s];
-    int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+    const int64_t p0 = uw ? (int64_t)s * (uw << 6) : slice_ptr[s];        // (uw: see row_dot)
+    int w = uw ? uw : (int)((slice_ptr[s + 1] - p0) >> 6);
     const unsigned* cp = col16 + p0 + lane;
     const int* cp32 = col + p0 + lane;
     const T* vp = val + p0 + lane;
@@ -162,17 +164,19 @@ __device__ __forceinline__ void row_dot16(const int64_t* __restrict__ slice_ptr,
 // C16 = 3 / 4: as 1 / 2 with ordinary instead of non-temporal loads of the operator (a fine level that fits the memory-side cache).
 // C16 = 0: 32-bit indices.  C16 = 1: codes from slice `from` on (the uncovered slices are a short prefix of the numbering -- tiny colour
 // classes come first -- and the branch on the wave-uniform slice number has nothing to wait for).  C16 = 2: uncovered slices anywhere,
-// found through their flag.  c16_arg = from | format << 30 (format 0: 13 offset bits / 8 windows, 1: 11 offset bits / 32 windows).
+// found through their flag.  c16_arg = from (24 bits) | uniform slice width << 24 (6 bits, 0: widths differ -- read the slice pointers) | format << 30
+// (format 0: 13 offset bits / 8 windows, 1: 11 offset bits / 32 windows).
 template <class T, int D, int C16, int G = DotGroup<D>::value, int XI = 0>
 __device__ __forceinline__ void row_dot_sel(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const unsigned* __restrict__ col16,
                                             const int* __restrict__ win_base, int c16_arg, const T* __restrict__ val, const T* x, int ld, int s, int lane,
                                             T (&acc)[D]) {
     if constexpr (C16 == 1 || C16 == 3) {
         const int dbits = (c16_arg >> 30) & 1 ? 11 : 13;
-        if (s >= (c16_arg & 0x3fffffff)) row_dot16<T, D, false, G, XI, C16 == 3>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc);
-        else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
+        const int uw = (c16_arg >> 24) & 63;
+        if (s >= (c16_arg & 0xffffff)) row_dot16<T, D, false, G, XI, C16 == 3>(slice_ptr, col, col16, win_base, dbits, val, x, ld, s, lane, acc, uw);
+        else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc, uw);
     } else if constexpr (C16 == 2 || C16 == 4) {
-        row_dot16<T, D, true, G, XI, C16 == 4>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc);
+        row_dot16<T, D, true, G, XI, C16 == 4>(slice_ptr, col, col16, win_base, (c16_arg >> 30) & 1 ? 11 : 13, val, x, ld, s, lane, acc, (c16_arg >> 24) & 63);
     } else row_dot<T, D, G, XI>(slice_ptr, col, val, x, ld, s, lane, acc);
 }
 

@@ -303,7 +303,8 @@ __global__ void refill_diag(const int* __restrict__ diag_src, const int* __restr
 template <int NW>
 __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__ slice_ptr, const int* __restrict__ col, const int* __restrict__ a_ptr,
                                                      const int* __restrict__ new2old, const double* __restrict__ val, int n_slices, int test_fail,
-                                                     unsigned* __restrict__ col16, int* __restrict__ win_base, int* __restrict__ fail) {
+                                                     unsigned* __restrict__ col16, int* __restrict__ win_base, int* __restrict__ fail,
+                                                     int w_expected = -1, int* __restrict__ other_width = nullptr) {
     constexpr int kSpan = 65536 / NW;
     constexpr int kDbits = NW == 8 ? 13 : 11;
     static_assert(NW == 8 || NW == 32, "8 windows of 8192 or 32 windows of 2048");
@@ -312,6 +313,8 @@ __global__ __launch_bounds__(256) void compress_cols(const int64_t* __restrict__
     if (s >= n_slices) return;
     const int64_t p0 = slice_ptr[s];
     const int w = (int)((slice_ptr[s + 1] - p0) >> 6);
+    // (are all slices w_expected wide?  then the kernels need no slice pointers: DevSell::uniform_w.  Counted until the answer is no)
+    if (other_width && w != w_expected && lane == 0 && __hip_atomic_load(other_width, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) atomicAdd(other_width, 1);
     int len = 0;
     if (a_ptr) { const int old = new2old[s * 64 + lane]; len = old >= 0 ? a_ptr[old + 1] - a_ptr[old] - 1 : 0; }
     auto real = [&](int j) { return a_ptr ? j < len : val[p0 + (int64_t)j * 64 + lane] != 0.0; };

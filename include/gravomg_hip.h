@@ -131,6 +131,9 @@ typedef struct {
                               device (same sums, same arithmetic) and that launch returns at once when the iteration has stopped -- the ~6 us of host latency
                               between two cycles disappear, iterates and iteration counts are unchanged.  Stream launches, fp64, colour-major level 0, d <= 4,
                               one device; otherwise, and with 0, the host decides before anything of the next cycle is enqueued */
+    int uniform_slices;    /* 1 (default): a level-0 operator all of whose 64-row slices are equally wide (a regular mesh: every vertex has six neighbours) is
+                              read without its slice pointers -- a slice's place follows from its number, so a wave's first loads are the entries and not two
+                              pointers they would wait for.  Same entries in the same order.  0: always through the pointers */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -489,6 +489,50 @@ def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi
     assert np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
 
 
+@pytest.mark.parametrize("case,test_fail", [("torus", 0), ("torus", 9), ("torus", -3), ("smoothing-d3", 0), ("random-order", 0), ("pointcloud", 0)])
+def test_equally_wide_slices_are_read_without_their_pointers(cabi, case, test_fail):
+    """gmg_config::uniform_slices: when every 64-row slice of a level-0 operator is equally wide (a regular mesh: six neighbours everywhere; the
+    prolongation: three entries per row) the kernels compute a slice's place from its number instead of loading two slice pointers first
+    (kernels.hip.hpp::row_dot).  Found by gmgs::compress_cols; same entries in the same order, so every iterate is bit-identical -- with the codes
+    flagged slice by slice and with a 32-bit prefix too --; an operator with slices of several widths (a kNN graph) keeps its pointers."""
+    P = {"torus": lambda: problems.torus_problem(96, 80, "poisson", 30),
+         "random-order": lambda: problems.torus_problem(64, 60, "poisson", 40, order="random"),
+         "pointcloud": lambda: problems.pointcloud_problem(3000),
+         "smoothing-d3": lambda: problems.torus_problem(64, 60, "smoothing", 60)}[case]()
+
+    def run(uniform):
+        e = cabi.Engine(uniform_slices=uniform, block_fine=0)
+        if test_fail:
+            e.debug_set("col16_uncovered", test_fail)
+        e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
+        return e
+    a, b = run(True), run(False)
+    for key in ("col16_l0", "col16_R_l0", "col16_P_l0"):
+        assert b.timing(key + "_uniform_width") == 0.0
+    if case == "pointcloud":
+        assert a.timing("col16_l0_uniform_width") == 0.0                # 8 neighbours at least, more where the relation is not mutual
+    else:
+        assert a.timing("col16_l0_uniform_width") == 6.0                # a closed triangle mesh of a torus: valence six
+    for e in (a, b):
+        e.load_problem(P.rhs, P.rhs)
+    ha, hb = a.run_cycles(4, 2), b.run_cycles(4, 2)
+    assert np.array_equal(ha, hb) and np.array_equal(a.fetch_solution(), b.fetch_solution())
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(P.rhs.shape)
+    assert np.array_equal(a.residual(0, P.rhs, x), b.residual(0, P.rhs, x)) and np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
+    for t in (0, 1, 2, 3):
+        assert a.residual_norm(P.rhs, x, t) == b.residual_norm(P.rhs, x, t)
+    r = rng.standard_normal(P.rhs.shape)
+    assert np.array_equal(a.restrict(0, r), b.restrict(0, r))
+    e1 = rng.standard_normal((a.level_info(1)["n"], P.rhs.shape[1]))
+    assert np.array_equal(a.prolong_add(0, e1, x), b.prolong_add(0, e1, x))
+    lhs2 = P.lhs.copy(); lhs2.data = lhs2.data * (1.0 + 0.1 * rng.random(lhs2.nnz))
+    lhs2 = (lhs2 + lhs2.T) * 0.5
+    a.set_system(lhs2); b.set_system(lhs2)
+    assert a.timing("setup_values_only") == 1.0
+    assert np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
+
+
 @pytest.mark.parametrize("case", ["torus", "random-order", "pointcloud", "smoothing-d3-mixed"])
 def test_structure_prepared_at_hierarchy_time_gives_the_cold_set_ups_bits(cabi, case):
     """gmg_set_fine_graph / gmg_use_hierarchy hand the engine the hierarchy's point graph -- the sparsity pattern of the systems it is built
