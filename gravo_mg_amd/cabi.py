@@ -43,7 +43,7 @@ class GmgConfig(C.Structure):
         ("post_iters", C.c_int), ("coarse_mode", C.c_int), ("use_graph", C.c_int), ("sigma", C.c_int),
         ("row_align", C.c_int), ("block_rows", C.c_int), ("block_lanes", C.c_int), ("block_from_level", C.c_int),
         ("device_setup", C.c_int), ("device_rap", C.c_int), ("reorder_fine", C.c_int), ("inner_precision", C.c_int), ("block_csr", C.c_int), ("host_threads", C.c_int),
-        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("prepare_structure", C.c_int), ("fuse_restrict_sweep", C.c_int), ("speculate_head", C.c_int), ("uniform_slices", C.c_int),
+        ("verbose", C.c_int), ("gs_omega", C.c_double), ("restrict_sigma", C.c_int), ("block_ep", C.c_int), ("dist_shard_levels", C.c_int), ("block_fine", C.c_int), ("fine_col16", C.c_int), ("stream_gate", C.c_int), ("dist_exchange", C.c_int), ("prepare_structure", C.c_int), ("fuse_restrict_sweep", C.c_int), ("speculate_head", C.c_int), ("uniform_slices", C.c_int), ("color_ahead", C.c_int),
     ]
 
 
@@ -321,7 +321,7 @@ class Engine:
 
     def __init__(self, smoother=SMOOTHER_MULTICOLOR_GS, pre_iters=2, post_iters=2, jacobi_omega=0.67,
                  coarse_mode=COARSE_AUTO, use_graph=False, sigma=0, row_align=64, block_rows=64, block_from_level=1, block_lanes=0,
-                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None, fuse_restrict_sweep=None, speculate_head=None, uniform_slices=None):
+                 device_setup=True, device_rap=True, reorder_fine=2, inner_precision=0, block_csr=True, device=0, verbose=False, gs_omega=None, block_ep=None, restrict_sigma=None, dist_shard_levels=None, block_fine=None, fine_col16=None, stream_gate=None, prepare_structure=None, dist_exchange=None, fuse_restrict_sweep=None, speculate_head=None, uniform_slices=None, color_ahead=None):
         l = lib()
         cfg = GmgConfig()
         l.gmg_config_default(C.byref(cfg))
@@ -353,6 +353,8 @@ class Engine:
             cfg.speculate_head = int(bool(speculate_head))
         if uniform_slices is not None:
             cfg.uniform_slices = int(bool(uniform_slices))
+        if color_ahead is not None:
+            cfg.color_ahead = int(bool(color_ahead))
         if dist_exchange is not None:
             cfg.dist_exchange = int(dist_exchange)
         self._h = _vp()
@@ -815,6 +817,23 @@ def host_plan_level(A, mode: int = 0, block_rows: int = 256, sigma: int = 1024, 
     else:
         out["color_begin"] = color_begin[: n_colors + 1].copy()
     return out
+
+
+def host_plan_ahead(n, indptr, indices, row_align: int = 64, sigma: int = 1024) -> dict:
+    """gmg_host_plan_level mode 4: the colour-major ordering of a level from the colouring that a cold gmg_set_system starts AHEAD of its inspection,
+    on the arrays exactly as given (int32, no canonicalisation here: that is the point).  Raises GmgError(INVALID) for arrays that would take a
+    reader out of bounds.  `colored_ahead`: False when 64 colours were not enough and the general loop coloured instead."""
+    indptr = np.ascontiguousarray(indptr, np.int32); indices = np.ascontiguousarray(indices, np.int32)
+    vals = np.ones(max(len(indices), 1))
+    info = (C.c_int64 * 6)()
+    rc = lib().gmg_host_plan_level(int(n), _pi(indptr), _pi(indices), _pd(vals), 4, int(row_align), int(sigma), info, None, None, None, None)
+    if rc:
+        raise GmgError(rc, "gmg_host_plan_level")
+    new2old = np.empty(int(info[0]), np.int32); color_begin = np.zeros(int(info[1]) + 1, np.int32)
+    rc = lib().gmg_host_plan_level(int(n), _pi(indptr), _pi(indices), _pd(vals), 4, int(row_align), int(sigma), info, _pi(new2old), _pi(color_begin), None, None)
+    if rc:
+        raise GmgError(rc, "gmg_host_plan_level")
+    return {"n_pad": int(info[0]), "n_colors": int(info[1]), "colored_ahead": bool(info[5]), "new2old": new2old, "color_begin": color_begin}
 
 
 def host_fine_block_rule(A):

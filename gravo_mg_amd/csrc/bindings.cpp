@@ -329,6 +329,7 @@ public:
         else if (key == "fuse_restrict_sweep") c.fuse_restrict_sweep = (int)value;
         else if (key == "speculate_head") c.speculate_head = (int)value;
         else if (key == "uniform_slices") c.uniform_slices = (int)value;
+        else if (key == "color_ahead") c.color_ahead = (int)value;
         else if (key == "dist_exchange") c.dist_exchange = (int)value;
         else if (key == "inner_precision") c.inner_precision = (int)value;
         else throw std::invalid_argument("unknown engine option: " + key);

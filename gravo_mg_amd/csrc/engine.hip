@@ -183,6 +183,7 @@ int gmg_config_default(gmg_config* cfg) try {
     cfg->fuse_restrict_sweep = 1;
     cfg->speculate_head = 1;
     cfg->uniform_slices = 1;
+    cfg->color_ahead = 1;
     cfg->dist_exchange = 0;
     cfg->block_fine = 1;      // level 0 blocked too where it pays and is safe (long rows, Stieltjes matrix): see gmg_config
     cfg->restrict_sigma = 64;
@@ -554,11 +555,46 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     bool spec_done = false;
     // A handle WITHOUT a live system has nothing to refresh: the cold set-up's first device step -- A_0 in natural numbering, 250 MB at 3 M
     // vertices -- goes up beside the inspection instead of after it (into a matrix of its own: the levels are rebuilt further down)
+    // Colouring ahead of the layout decisions: when this call cannot be a values-only refresh (no live structure, or another entry count) and level 0
+    // will most likely be the colour-major one in the caller's order, the greedy colouring -- 10-13 ms on one core at 3 M vertices, what a cold
+    // set-up waits for longest -- starts as soon as the inspection of the caller's arrays has its verdict, while this thread is still busy sending
+    // A_0 to the device (host_plan.hpp::greedy_coloring_ahead: range-checked all the same).
+    // Used by the level-0 ordering task if the decisions below come out that way (canonical arrays, no renumbering, not blocked, no
+    // cached ordering); stopped and joined otherwise, and in any case before this function returns (it reads the caller's arrays).
+    struct AheadColoring {
+        std::atomic<int> stop{0};
+        PreColoring pre;
+        std::future<int> fut;
+        const int* ptr = nullptr;
+        void cancel() { stop.store(1); }
+        ~AheadColoring() { stop.store(1); if (fut.valid()) fut.wait(); }
+    } ahead;
+    bool want_ahead = false;
+    {
+        const bool live0 = h->system_ready || h->placeholder_ready;
+        const bool refresh_possible = live0 && h->live_key_valid && (int)h->lv.size() == L + 1 && h->lv[0].n == n && (int64_t)colptr[n] == h->lv[0].nnz;
+        if (!refresh_possible && !h->ord_cache_valid && h->cfg.smoother == GMG_SMOOTHER_MULTICOLOR_GS && n >= (1 << 17) && h->cfg.color_ahead &&
+            !(h->cfg.block_rows > 0 && h->cfg.block_from_level <= 0)) {
+            ahead.ptr = colptr;
+            const int64_t nnz_claimed = colptr[n];
+            want_ahead = true;
+            (void)nnz_claimed;
+        }
+    }
     DevCsr early_A0;
     bool early_upload = false;
     struct EarlyGuard { DevCsr& d; ~EarlyGuard() { free_csr(d); } } early_guard{early_A0};
     {
-        std::future<int> inspected = std::async(std::launch::async, [&] { return inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads); });
+        std::shared_future<int> inspected = std::async(std::launch::async, [&] { return inspect_pattern(n, n, colptr, rowidx, h->cfg.host_threads); }).share();
+        if (want_ahead) {
+            // (behind the inspection's verdict, which takes a millisecond or two -- not behind the upload this thread makes meanwhile: started at
+            // entry, beside the inspection's threads, the loop ran at half its speed)
+            const int64_t nnz_claimed = colptr[n];
+            ahead.fut = std::async(std::launch::async, [&ahead, inspected, n, colptr, rowidx, nnz_claimed] {
+                if (inspected.get() != 0) return -2;
+                return greedy_coloring_ahead(n, colptr, rowidx, nnz_claimed, ahead.pre.c8, ahead.stop);
+            });
+        }
         std::future<void> keyed;
         if ((h->system_ready || h->placeholder_ready) && h->live_key_valid && h->refill_ready && (int)h->lv.size() == L + 1 && h->lv[0].n == n && colptr[0] == 0 &&
             (int64_t)colptr[n] == h->lv[0].nnz && h->lv[0].dA.val) {
@@ -626,6 +662,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             canon = canonical_copy(n, n, colptr, rowidx, val, h->cfg.host_threads);
             colptr = canon.ptr.data(); rowidx = canon.idx.data(); val = canon.val.data();
             have_key = false;
+            ahead.cancel();                         // (coloured from rows that are not ascending: no result)
             if (early_upload) { free_csr(early_A0); early_upload = false; }      // (it went up in the caller's storage order)
             // (the values went up in the caller's storage order, the resident pattern is canonical: the live system is void, and this
             // matrix takes the full set-up from its canonical copy)
@@ -731,11 +768,13 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     const bool ord_hit = h->ord_cache_valid && (int)h->ord_cache.size() == L + 1 && pat_key[0] == h->ord_cache_key[0] && pat_key[1] == h->ord_cache_key[1] &&
                          h->ord_cache[0].blocked == blocked0;
     h->timing["setup_ordering_cached"] = ord_hit ? 1.0 : 0.0;
+    if (ord_hit || blocked0 || !mc || ahead.ptr != colptr) ahead.cancel();
     h->timing["setup_values_only"] = 0.0;
     h->ord_cache_valid = false;       // a hit moves the cached orderings into the levels; the next call moves them back
     std::shared_future<void> patches_done;      // hierarchies set level by level (gmg_set_prolongation): grown now, in the background
     if (!h->patches_ready && !ord_hit) patches_done = std::async(std::launch::async, [h] { build_patches(h); }).share();
     bool reorder0 = false, permuted0 = false;      // level-0 locality renumbering (decided below, before level 0 is spawned)
+    std::atomic<int> colored_ahead{0};             // the level-0 ordering took the colouring made ahead of the verdict (AheadColoring)
     std::function<void(int)> spawn_level_ops;
     auto spawn_level = [&](int k) {
         ord_done[k] = std::async(std::launch::async, [&, k] {
@@ -762,7 +801,15 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
                     parallel_ranges(c.n_pad, T, [&](int lo, int hi, int) { for (int r = lo; r < hi; ++r) if (c.new2old[r] >= 0) c.old2new[c.new2old[r]] = r; });
                     c.reordered = true;
                     lk.ord = std::move(c);
-                } else lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, reorder0 ? 1 : 0, base, /*idx_sorted=*/true);   // the caller's arrays (canonical: checked / canonicalised at entry)
+                } else {
+                    PreColoring* pre = nullptr;
+                    if (!reorder0 && !base && mc && ahead.fut.valid() && ahead.ptr == colptr && !ahead.stop.load()) {
+                        ahead.pre.n_colors = ahead.fut.get();
+                        if (ahead.pre.n_colors >= 0) pre = &ahead.pre;
+                    } else ahead.cancel();
+                    colored_ahead.store(pre ? 1 : 0);
+                    lk.ord = make_ordering(PatternView{n, colptr, rowidx}, mc, h->cfg.row_align, h->cfg.sigma, reorder0 ? 1 : 0, base, /*idx_sorted=*/true, pre);   // the caller's arrays (canonical: checked / canonicalised at entry)
+                }
             }
             else lk.ord = make_ordering(lk.A, mc, h->cfg.row_align, h->cfg.sigma);
             lk.n_pad = lk.ord.n_pad;
@@ -909,6 +956,9 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
         ms_factor = ms_since(t);
         return ok;
     });
+    int factor_state = -1;                          // (the future is read once: by the early inverse below, or at the end)
+    auto factor_result = [&]() -> bool { if (factor_state < 0) factor_state = factor_done.get() ? 1 : 0; return factor_state == 1; };
+    bool inverse_built = false;
     auto tl = clk::now();
     double ms_h2d = 0;
     int rc_all = GMG_OK;
@@ -965,6 +1015,20 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
             for (int k = 1; k < L && rc_all == GMG_OK; ++k) rc_all = device_layout_level(h, k, d_err.p, (k == 1 && shard1) ? d_mask1 : nullptr, nullptr);
             if (part && shard1 && rc_all == GMG_OK && !h->lv[1].use_ep) { rc_all = GMG_ERR_UNSUPPORTED; err_all = "level 1 cannot run the entry-parallel block sweep (a block is too large for its LDS buffers): create the handle with dist_shard_levels = 1"; }
             ms_layout += ms_since(tlay);
+            // The device has nothing to do until the ordering of level 0 arrives (a sequential colouring on the host): when the coarsest factor is
+            // there first, the dense inverse of the coarsest operator is built in that gap instead of at the end of the call
+            if (rc_all == GMG_OK && !part && !h->preparing_structure && want_coarse_device(h, h->lv[L].A.n_outer)) {
+                while (ord_done[0].wait_for(std::chrono::seconds(0)) != std::future_status::ready &&
+                       factor_done.valid() && factor_done.wait_for(std::chrono::microseconds(200)) != std::future_status::ready) {}
+                if (factor_state >= 0 || (factor_done.valid() && factor_done.wait_for(std::chrono::seconds(0)) == std::future_status::ready)) {
+                    if (factor_result()) {
+                        h->coarse_device = true;
+                        rc_all = build_coarse_inverse_device(h);
+                        inverse_built = rc_all == GMG_OK;
+                        mark("coarse_inverse_early");
+                    }
+                }
+            }
             if (rc_all == GMG_OK && !part) ordering_of(0);
             tlay = clk::now();
             if (rc_all == GMG_OK) rc_all = device_layout_level(h, 0, d_err.p, part ? d_mask0 : nullptr, (part && shard1) ? d_mask1 : nullptr);
@@ -1035,8 +1099,9 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     }
     join_tasks();
     h->timing["t_lhs_copied"] = ms_lhs_copied;
+    h->timing["setup_colored_ahead"] = colored_ahead.load();
     mark("tasks_joined");
-    const bool factor_ok = factor_done.get();
+    const bool factor_ok = factor_result();
     mark("factor_joined");
     (void)hipStreamSynchronize(h->stream);      // staged host arrays die at scope end
     if (rc_all != GMG_OK) return err_all.empty() ? rc_all : fail(h, rc_all, err_all);
@@ -1058,7 +1123,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     }
     h->coarse_device = want_coarse_device(h, h->lv[L].A.n_outer);
     h->timing["coarse_on_device"] = h->coarse_device ? 1.0 : 0.0;
-    if (h->coarse_device && !h->preparing_structure) {
+    if (h->coarse_device && !h->preparing_structure && !inverse_built) {
         int rc = build_coarse_inverse_device(h);
         if (rc) return rc;
     }
@@ -2254,9 +2319,24 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
 
 int gmg_host_plan_level(int n, const int* colptr, const int* rowidx, const double* val, int mode, int block_rows, int sigma, int64_t* info,
                         int* new2old, int* color_begin, int* blk_begin, unsigned char* row_color) try {
-    if (n <= 0 || !colptr || !rowidx || !val || mode < 0 || mode > 3) return GMG_ERR_INVALID;
+    if (n <= 0 || !colptr || !rowidx || !val || mode < 0 || mode > 4) return GMG_ERR_INVALID;
     if (mode == 1 && (block_rows <= 0 || block_rows > gmgk::kBlockRows || block_rows % 64)) return GMG_ERR_INVALID;
     if (sigma < 0 || sigma % 64) return GMG_ERR_INVALID;
+    if (mode == 4) {
+        // the colouring that a cold gmg_set_system starts ahead of its inspection, on the caller's arrays as they are (greedy_coloring_ahead): -2 is reported
+        // as GMG_ERR_INVALID (arrays that would take a reader out of bounds), a result goes through make_ordering like the one made after the inspection
+        PreColoring pre;
+        std::atomic<int> stop{0};
+        pre.n_colors = greedy_coloring_ahead(n, colptr, rowidx, (int64_t)colptr[n], pre.c8, stop);
+        if (pre.n_colors == -2) return GMG_ERR_INVALID;
+        if (info) info[5] = pre.n_colors >= 0 ? 1 : 0;
+        LevelOrdering o = make_ordering(PatternView{n, colptr, rowidx}, true, (block_rows > 0 && block_rows % 64 == 0) ? block_rows : 64, sigma, 0, nullptr, true, &pre);
+        if (o.n_colors > 256) return GMG_ERR_UNSUPPORTED;
+        if (info) { info[0] = o.n_pad; info[1] = o.n_colors; info[2] = 0; info[3] = 0; info[4] = 0; }
+        if (new2old) std::memcpy(new2old, o.new2old.data(), sizeof(int) * o.n_pad);
+        if (color_begin) std::memcpy(color_begin, o.color_begin.data(), sizeof(int) * (o.n_colors + 1));
+        return GMG_OK;
+    }
     Compressed A;
     A.assign(n, n, colptr, rowidx, val);
     // (mode 2: colour-major with the locality reordering forced -- the colouring then walks a visit ORDER; mode 3: colour-major, row indices declared ascending)

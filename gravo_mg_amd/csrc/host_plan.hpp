@@ -184,6 +184,39 @@ inline int greedy_coloring_bytes(const Mat& A, RawVec<unsigned char>& c8, const 
     return ncol;
 }
 
+// The same colouring (natural order, ascending rows) started BEFORE the caller's arrays have been inspected -- a cold gmg_set_system waits for this loop
+// longer than for anything else, and the inspection takes 6 of its first milliseconds at 3 M vertices (engine.hip: "colouring ahead of the verdict").
+// Every pointer and index is checked against [0, nnz] / [0, n), so arrays that will fail the inspection cannot take the loop out of bounds; a result
+// computed from rows that turn out not to be ascending is thrown away by the caller.  Returns the number of colours, -1 (64 colours are not enough:
+// the general loop decides) or -2 (inconsistent arrays, or `stop` raised: no result).
+inline int greedy_coloring_ahead(int n, const int* ptr, const int* idx, int64_t nnz, RawVec<unsigned char>& c8, const std::atomic<int>& stop) {
+    constexpr unsigned char kNone = 255;
+    c8.resize((size_t)std::max(n, 1));
+    std::memset(c8.data(), kNone, (size_t)n);
+    unsigned char* cc = c8.data();
+    int ncol = 0;
+    for (int i = 0; i < n; ++i) {
+        if ((i & 8191) == 0 && stop.load(std::memory_order_relaxed)) return -2;
+        const int64_t p0 = ptr[i], p1 = ptr[i + 1];
+        if (p0 < 0 || p1 < p0 || p1 > nnz) return -2;
+        uint64_t mask = 0;
+        for (int64_t p = p0; p < p1; ++p) {
+            const int j = idx[p];
+            if ((unsigned)j >= (unsigned)n) return -2;
+            if (j >= i) break;                             // (ascending indices: the rest of the row is not coloured yet)
+            const unsigned c = cc[j];
+            if (c < 64) mask |= (uint64_t)1 << c;
+        }
+        if (~mask == 0) return -1;
+        const int c = __builtin_ctzll(~mask);
+        cc[i] = (unsigned char)c;
+        if (c >= ncol) ncol = c + 1;
+    }
+    return ncol;
+}
+// a colouring made ahead of make_ordering (natural visit order): the bytes and the number of colours
+struct PreColoring { RawVec<unsigned char> c8; int n_colors = -1; };
+
 // (Round 6 built the same colouring as a dataflow over strips of the visit sequence on several threads -- a vertex waits for the bytes of the
 // neighbours visited before it -- and removed it again: on a mesh in a local order the colouring is a chain along every mesh row, each row two
 // columns behind the one above, so threads either hold consecutive strips of ONE chain (cyclic deal: no parallelism) or read colour bytes a peer
@@ -289,7 +322,8 @@ inline void neigh_pattern(const int* neigh, int n, int K, RawVec<int>& ptr, RawV
 }
 
 template <class Mat>
-inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma, int reorder = 0, const std::vector<int>* ext_base = nullptr, bool idx_sorted = false) {
+inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align, int sigma, int reorder = 0, const std::vector<int>* ext_base = nullptr, bool idx_sorted = false,
+                                   PreColoring* pre = nullptr) {
     LevelOrdering o;
     const int n = A.n_outer;
     o.n = n;
@@ -321,7 +355,11 @@ inline LevelOrdering make_ordering(const Mat& A, bool multicolor, int row_align,
     std::vector<int> color;
     RawVec<unsigned char> c8_own;
     const unsigned char* c8 = nullptr;
-    if (multicolor) {
+    if (multicolor && pre && pre->n_colors >= 0 && base.empty() && pre->c8.n >= (size_t)n) {      // coloured ahead (greedy_coloring_ahead): the same bytes
+        c8_own = std::move(pre->c8);
+        o.n_colors = pre->n_colors;
+        c8 = c8_own.data();
+    } else if (multicolor) {
         o.n_colors = greedy_coloring_bytes(A, c8_own, base, idx_sorted);
         if (o.n_colors < 0) { c8_own.resize(0); o.n_colors = greedy_coloring_general(A, color, base); }
         else c8 = c8_own.data();

@@ -134,6 +134,9 @@ typedef struct {
     int uniform_slices;    /* 1 (default): a level-0 operator all of whose 64-row slices are equally wide (a regular mesh: every vertex has six neighbours) is
                               read without its slice pointers -- a slice's place follows from its number, so a wave's first loads are the entries and not two
                               pointers they would wait for.  Same entries in the same order.  0: always through the pointers */
+    int color_ahead;       /* 1 (default): a gmg_set_system that cannot be a values-only refresh starts the greedy colouring of level 0 (one core, 10-13 ms at
+                              3 M vertices: the longest task of a cold set-up) at entry, beside the inspection of the caller's arrays, with every index checked;
+                              the result is used when the inspection and the layout decisions allow it -- the same colours, ~6 ms earlier.  0: after them */
 } gmg_config;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

@@ -32,7 +32,9 @@ int gmg_host_galerkin(int n, const int* a_colptr, const int* a_rowidx, const dou
 /* Host-only view of the device layout planner (colouring / block growing / SELL-64), for CPU tests of the
  * host logic.  mode 0: colour-major ordering (exact multicolour Gauss-Seidel), mode 1: block ordering
  * (block-hybrid Gauss-Seidel, `block_rows` rows per block), mode 2: mode 0 with the locality reordering forced (rows of a colour in breadth-first
- * patch order), mode 3: mode 0 for a matrix whose row indices are ascending (the short-cut of the colouring loop).  In modes 0 / 2 / 3 `block_rows` is the colour-class
+ * patch order), mode 3: mode 0 for a matrix whose row indices are ascending (the short-cut of the colouring loop), mode 4: mode 3 with the colouring that a cold
+ * gmg_set_system starts ahead of its inspection -- on the arrays as given, every index checked (GMG_ERR_INVALID for arrays that would take a reader out of bounds;
+ * info[5] = 1 when that colouring was used, 0 when it gave up at 64 colours; no SELL statistics).  In modes 0 / 2 / 3 / 4 `block_rows` is the colour-class
  * alignment (the config's row_align; 0 = 64).  info[0..5] = n_pad, n_colors, n_blocks,
  * stored SELL entries (off-diagonal), real off-diagonal entries, 0.  Output pointers may be NULL: call once
  * with NULL outputs for the sizes, then with new2old / row_color of n_pad entries, color_begin of

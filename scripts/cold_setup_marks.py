@@ -14,11 +14,12 @@ def run():
     eng.use_hierarchy(H); eng.set_mass(mass)
     t = time.perf_counter(); eng.set_system(lhs); ms = 1e3 * (time.perf_counter() - t)
     marks = {}
-    for m in ["pattern_key", "permuted_pattern", "upload_A0"] + [f"rap_l{k}" for k in range(1, 6)] + [f"ordering_ready_l{k}" for k in range(6)] + ["device_layout", "tasks_joined", "factor_joined", "mass_done"]:
+    for m in ["pattern_key", "permuted_pattern", "upload_A0"] + [f"rap_l{k}" for k in range(1, 6)] + [f"ordering_ready_l{k}" for k in range(6)] + ["coarse_inverse_early", "device_layout", "tasks_joined", "factor_joined", "mass_done"]:
         try:
             marks[m] = round(eng.timing("t_" + m), 2)
         except Exception:
             pass
+    marks["colored_ahead"] = eng.timing("setup_colored_ahead")
     return ms, sorted(marks.items(), key=lambda kv: kv[1])
 run()
 for _ in range(2):

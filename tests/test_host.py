@@ -392,3 +392,47 @@ def test_device_factor_layout_and_schedule_on_the_host(kind):
     chunks, levels, cols, diff, scale = int(m1.group(1)), int(m1.group(2)), int(m1.group(3)), float(m1.group(4)), float(m1.group(5))
     assert chunks >= A.shape[0] // 8 and 2 <= levels <= chunks and cols == 24
     assert diff <= 1e-11 * scale, (diff, scale)
+
+
+def test_colouring_ahead_of_the_inspection_gives_the_same_ordering_and_survives_bad_arrays(cabi):
+    """A cold gmg_set_system starts the greedy colouring of level 0 at entry, beside the inspection of the caller's arrays (gmg_config::color_ahead,
+    host_plan.hpp::greedy_coloring_ahead): the same first-fit colours as the loop that runs after the inspection, hence the same ordering; every
+    pointer and index is range-checked, so arrays the inspection would reject end the loop instead of taking it out of bounds; beyond 64 colours it
+    gives up and the general loop colours."""
+    import scipy.sparse as sp
+    from gravo_mg_amd import meshgen
+    V, F = meshgen.torus_mesh(150, 140)
+    S, _ = meshgen.cotan_laplacian(V, F)
+    rng = np.random.default_rng(3)
+    R = sp.random(4000, 4000, density=0.002, random_state=5, format="csr")
+    R = (R + R.T + sp.identity(4000)).tocsc()
+    for A in (S.tocsc(), R):
+        A.sort_indices()
+        n = A.shape[0]
+        ref = cabi.host_plan_level(A, mode=3)
+        got = cabi.host_plan_ahead(n, A.indptr, A.indices)
+        assert got["colored_ahead"] and got["n_colors"] == ref["n_colors"] and got["n_pad"] == ref["n_pad"]
+        assert np.array_equal(got["color_begin"], ref["color_begin"]) and np.array_equal(got["new2old"], ref["new2old"])
+    # a complete graph on 70 vertices needs 70 colours: the 64-bit mask runs out, the general loop takes over -- same ordering
+    K = sp.csc_matrix(np.ones((70, 70)))
+    K.sort_indices()
+    ref = cabi.host_plan_level(K, mode=3)
+    got = cabi.host_plan_ahead(70, K.indptr, K.indices)
+    assert not got["colored_ahead"] and got["n_colors"] == ref["n_colors"] == 70 and np.array_equal(got["new2old"], ref["new2old"])
+    # arrays that fail the inspection: an index out of range, a negative one, pointers that go backwards, pointers beyond the claimed entry count
+    A = S.tocsc(); A.sort_indices()
+    n = A.shape[0]
+    for spoil in ("index-high", "index-negative", "pointer-backwards", "pointer-beyond"):
+        ptr, idx = A.indptr.astype(np.int32).copy(), A.indices.astype(np.int32).copy()
+        if spoil == "index-high":
+            idx[ptr[n // 2]] = n + 5          # (first entry of a row: read before the `j >= i` stop)
+        elif spoil == "index-negative":
+            idx[ptr[n // 3]] = -7
+        elif spoil == "pointer-backwards":
+            ptr[n // 2] = ptr[n // 2 - 1] - 3
+        else:
+            ptr[n // 2 + 1] = ptr[n] + 1000
+            ptr[n // 2 + 2:] = np.maximum(ptr[n // 2 + 2:], ptr[n // 2 + 1])
+            ptr[n] = A.indptr[n]
+        with pytest.raises(cabi.GmgError):
+            cabi.host_plan_ahead(n, ptr, idx)
