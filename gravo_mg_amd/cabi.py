@@ -62,6 +62,7 @@ _vp = C.c_void_p
 # (tests/test_host.py::test_library_exports_every_declared_symbol checks this table against the header).
 SIGNATURES = {
     "gmg_config_default": (C.c_int, [C.POINTER(GmgConfig)]),
+    "gmg_config_size": (C.c_int, []),
     "gmg_create": (C.c_int, [C.POINTER(GmgConfig), C.POINTER(_vp)]),
     "gmg_destroy": (None, [_vp]),
     "gmg_last_error": (C.c_char_p, [_vp]),
@@ -191,6 +192,9 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.gmg_config_size() != C.sizeof(GmgConfig):
+            raise ImportError(f"{LIB_PATH} was built with a gmg_config of {l.gmg_config_size()} bytes, gravo_mg_amd/cabi.py mirrors one of {C.sizeof(GmgConfig)}: "
+                              "rebuild the library (gravo_mg_amd/csrc/build.sh) or update the mirror")
         _lib = l
     return _lib
 

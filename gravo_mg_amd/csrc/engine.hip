@@ -153,6 +153,8 @@ static bool ensure_rap_order(gmg_handle h) {
 
 extern "C" {
 
+int gmg_config_size(void) { return (int)sizeof(gmg_config); }
+
 int gmg_config_default(gmg_config* cfg) try {
     if (!cfg) return GMG_ERR_INVALID;
     std::memset(cfg, 0, sizeof(*cfg));

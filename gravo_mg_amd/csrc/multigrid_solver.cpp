@@ -86,7 +86,12 @@ std::pair<uint64_t, uint64_t> SparseMatrix::digest() const {
 // system ONCE, with 4-6 V-cycles, and the engine's default -- a dense inverse of the coarsest operator built per gmg_set_system, which pays off
 // from ~50 cycles per system on -- would cost it 2-7 ms per solve for 0.2-0.7 ms saved.  The coarsest solve therefore stays where
 // the reference has it, on the host; set_engine_option("coarse_mode", 2) selects the engine's default for callers that keep a system.
-static void dropInDefaults(gmg_config& c) { c.coarse_mode = GMG_COARSE_HOST_LDLT; }
+static void dropInDefaults(gmg_config& c) {
+    // (this file and libgravomg_hip.so are built separately: a library with another edition of gmg_config would misread every field)
+    if (gmg_config_size() != (int)sizeof(gmg_config))
+        throw std::runtime_error("libgravomg_hip.so was built with another gmg_config than this module (include/gravomg_hip.h changed): rebuild both (gravo_mg_amd/csrc/build.sh, build_bindings.sh)");
+    c.coarse_mode = GMG_COARSE_HOST_LDLT;
+}
 
 MultigridSolver::MultigridSolver(MatrixXd& V_, MatrixXi& neigh_, SparseMatrix& M_) : V(V_), neigh(neigh_), M(M_) {
     hierarchyTiming["n_vertices"] = V.rows();               // multigrid_solver.cpp:21

@@ -141,6 +141,10 @@ typedef struct {
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 int gmg_config_default(gmg_config* cfg);
+/* sizeof(gmg_config) as the LIBRARY was built: a binding compiled against another edition of this header (the struct grows at its end) compares it
+ * with its own before it hands a gmg_config over -- the pybind module and the ctypes mirror refuse to run on a mismatch instead of passing a
+ * misread configuration. */
+int gmg_config_size(void);
 /* Replaces the construction of the solver state the pybind shim owns
  * (gravomg_bindings/src/cpp/core.cpp:27,138). */
 int gmg_create(const gmg_config* cfg, gmg_handle* out);
