@@ -8,6 +8,9 @@ bash scripts/r06_prof.sh $T 3m 3m_smoothing_d3:--config:4s 722k:--config:2 point
 bash scripts/r06_pmc.sh $T 3m; bash scripts/r06_pmc.sh $T 3m_smoothing_d3 --config 4s; bash scripts/r06_pmc.sh $T 722k --config 2
 cd $R
 python scripts/coarse_inverse_timing.py 2>&1 | grep -v amdgpu > $O/coarse_inverse_timing.txt
+python scripts/head_ab.py 2>&1 | grep -v amdgpu > $O/head_of_next_cycle_ab.txt
+python scripts/uniform_ab.py 2>&1 | grep -v amdgpu > $O/uniform_slices_ab.txt
+(python scripts/cold_setup_marks.py natural; python scripts/cold_setup_marks.py random) 2>&1 | grep -v amdgpu > $O/cold_setup_marks.txt
 for W in 2 4 8; do timeout -s KILL 300 python scripts/p2p_hybrid_probe.py $W poisson-big 2 2>&1 | grep "exact\|hybrid"; done > $O/hybrid_smoother_ranks_on_one_gpu.txt
 timeout -s KILL 900 python bench.py --n1 2828 --n2 2828 --no-variants --cpu-cycles 0 > $O/bench_8m.json 2> $O/bench_8m.err; tail -c 150 $O/bench_8m.json; echo
 timeout -s KILL 1500 python bench.py --n1 4472 --n2 4472 --no-variants --cpu-cycles 0 > $O/bench_20m.json 2> $O/bench_20m.err; tail -c 150 $O/bench_20m.json; echo
