@@ -489,7 +489,7 @@ def test_16_bit_column_codes_of_the_fine_level_change_nothing_but_the_bytes(cabi
     assert np.array_equal(a.smooth(0, P.rhs, x, 2), b.smooth(0, P.rhs, x, 2))
 
 
-@pytest.mark.parametrize("case,test_fail", [("torus", 0), ("torus", 9), ("torus", -3), ("smoothing-d3", 0), ("random-order", 0), ("pointcloud", 0)])
+@pytest.mark.parametrize("case,test_fail", [("torus", 0), ("torus", 9), ("torus", -3), ("smoothing-d3", 0), ("random-order", 0), ("pointcloud", 0), ("torus-mixed", 0)])
 def test_equally_wide_slices_are_read_without_their_pointers(cabi, case, test_fail):
     """gmg_config::uniform_slices: when every 64-row slice of a level-0 operator is equally wide (a regular mesh: six neighbours everywhere; the
     prolongation: three entries per row) the kernels compute a slice's place from its number instead of loading two slice pointers first
@@ -498,10 +498,11 @@ def test_equally_wide_slices_are_read_without_their_pointers(cabi, case, test_fa
     P = {"torus": lambda: problems.torus_problem(96, 80, "poisson", 30),
          "random-order": lambda: problems.torus_problem(64, 60, "poisson", 40, order="random"),
          "pointcloud": lambda: problems.pointcloud_problem(3000),
+         "torus-mixed": lambda: problems.torus_problem(96, 80, "poisson", 30),          # the fp32 inner cycle reads the same layout through its fp32 twins
          "smoothing-d3": lambda: problems.torus_problem(64, 60, "smoothing", 60)}[case]()
 
     def run(uniform):
-        e = cabi.Engine(uniform_slices=uniform, block_fine=0)
+        e = cabi.Engine(uniform_slices=uniform, block_fine=0, **({"inner_precision": 1} if case.endswith("mixed") else {}))
         if test_fail:
             e.debug_set("col16_uncovered", test_fail)
         e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)
