@@ -558,7 +558,7 @@ def test_restriction_fused_with_the_first_pre_sweep_gives_the_same_bits(cabi, ki
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
-@pytest.mark.parametrize("kind,d", [("poisson", 1), ("smoothing", 3), ("poisson-host-coarse", 1), ("poisson-omega1", 1)])
+@pytest.mark.parametrize("kind,d", [("poisson", 1), ("smoothing", 3), ("poisson-host-coarse", 1), ("poisson-omega1", 1), ("poisson-d2", 2), ("poisson-d4", 4)])
 def test_head_of_the_next_cycle_is_enqueued_ahead_of_the_decision_and_changes_nothing(cabi, kind, d):
     """gmg_config::speculate_head: the solve loop (multigrid_solver.cpp:1408-1419) puts the first colour launch of the next cycle into the stream behind
     the residual check before the host has seen the norm; the check's reduction decides on the device whether the iteration goes on, and a stopped
@@ -566,7 +566,7 @@ def test_head_of_the_next_cycle_is_enqueued_ahead_of_the_decision_and_changes_no
     tolerance stops it, when max_iter stops it (no head behind the last allowed cycle), when the first cycle already meets the tolerance (the head
     is in the stream and must do nothing), and for a fixed number of cycles (gmg_run_cycles)."""
     from tests import problems
-    P = problems.torus_problem(300, 280, "smoothing" if kind.startswith("smoothing") else "poisson", 100)
+    P = problems.torus_problem(300, 280, "smoothing" if kind.startswith("smoothing") else "poisson", 100, d=(d if kind.endswith(("-d2", "-d4")) else 1))      # (more right-hand sides: the worst column decides)
     kw = {}
     if "host-coarse" in kind:
         kw["coarse_mode"] = cabi.COARSE_HOST_LDLT
@@ -581,6 +581,13 @@ def test_head_of_the_next_cycle_is_enqueued_ahead_of_the_decision_and_changes_no
                                      ("second solve", 1e-5, 100)):
             x, it, r, conv = eng.solve(P.rhs, tol=tol, max_iter=max_iter)
             res[name] = (x.copy(), it, r, conv[:, 1].copy())
+        # every norm type the loop can stop on (0: ||r|| / ||b||, 1 / 2: M^-1- / M-weighted, 3: absolute): the device decides with the host's arithmetic
+        for t in (0, 1, 2, 3):
+            eng.load_problem(P.rhs, P.rhs)
+            hist = eng.run_cycles(3, t)
+            x, it, r, conv = eng.solve(P.rhs, tol=float(hist[2]) * (1.0 + 1e-12), stop_type=t, max_iter=50)
+            res["norm type %d" % t] = (x.copy(), it, r, conv[:, 1].copy())
+            assert it <= 3 and r == hist[it - 1]
         if spec:
             assert eng.timing("heads_enqueued") >= res["to the tolerance"][1] + 2 and eng.timing("head_decision_differs") == 0.0
         else:
@@ -594,10 +601,10 @@ def test_head_of_the_next_cycle_is_enqueued_ahead_of_the_decision_and_changes_no
         res["then one cycle"] = (eng.run_cycles(1, -1), eng.fetch_solution().copy())
         out.append(res)
         eng.close()
-    assert P.rhs.shape[1] == d
+    assert (P.rhs.shape[1] if P.rhs.ndim == 2 else 1) == d
     a, b = out
     assert a["to the tolerance"][1] > 2 and a["max_iter"][1] == 3 and a["one cycle allowed"][1] == 1 and a["first cycle is enough"][1] == 1
-    for name in ("to the tolerance", "max_iter", "one cycle allowed", "first cycle is enough", "second solve"):
+    for name in ("to the tolerance", "max_iter", "one cycle allowed", "first cycle is enough", "second solve", "norm type 0", "norm type 1", "norm type 2", "norm type 3"):
         assert a[name][1] == b[name][1], name
         assert a[name][2] == b[name][2], name
         assert np.array_equal(a[name][3], b[name][3]), name
