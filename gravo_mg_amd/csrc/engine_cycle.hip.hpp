@@ -754,10 +754,20 @@ inline void launch_cvt(gmg_handle h, const float* src, double* dst, size_t n) {
 #ifndef GMG_SYMV_ROWS
 #define GMG_SYMV_ROWS 0
 #endif
+inline int symv_env(const char* name) { const char* v = std::getenv(name); return v ? std::atoi(v) : 0; }
 inline int symv_rows(int n, int d) {
+    static const int forced = symv_env("GMG_SYMV_ROWS");      // (measurement: scripts/symv_sweep.py)
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
     if (GMG_SYMV_ROWS > 0) return GMG_SYMV_ROWS;       // (A/B builds)
-    if (n >= 4096) return 4;
+    if (n >= 3500) return 4;                           // (profiles/r06/symv_rows_strides_sweep.txt: n_L = 4 046 at d = 3: 41 -> 34 us with four rows)
     return (n >= 2500 || d > 1) ? 2 : 1;
+}
+// strides of 64 columns a lane loads per trip (dense_symv's U)
+inline int symv_strides(int n, int d, int rows) {
+    static const int forced = symv_env("GMG_SYMV_STRIDES");
+    if (forced == 2 || forced == 4 || forced == 8) return forced;
+    (void)n; (void)d; (void)rows;
+    return 4;                                          // (2 / 4 / 8 measured: within the noise of each other except four rows x two strides at 4 046: +3 us)
 }
 
 // e = A_L^{-1} rc with the dense inverse (always applied in fp64; the fp32 cycle converts around it)
@@ -773,9 +783,14 @@ void enqueue_coarse_device(gmg_handle h, int d) {
         const int rows_per_wave = symv_rows(c.n, dc);
         const int per_block = gmgk::kWavesPerBlock * rows_per_wave;
         const dim3 grid((c.n + per_block - 1) / per_block);
-        if (rows_per_wave == 4) { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, 4>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
-        else if (rows_per_wave == 2) { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, 2>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
-        else { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, 1>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
+        const int strides = symv_strides(c.n, dc, rows_per_wave);
+#define GMG_SYMV_LAUNCH(R, U) DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, R, U>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad))
+#define GMG_SYMV_U(R) do { if (strides >= 8) { GMG_SYMV_LAUNCH(R, 8); } else if (strides >= 4) { GMG_SYMV_LAUNCH(R, 4); } else { GMG_SYMV_LAUNCH(R, 2); } } while (0)
+        if (rows_per_wave == 4) GMG_SYMV_U(4);
+        else if (rows_per_wave == 2) GMG_SYMV_U(2);
+        else GMG_SYMV_U(1);
+#undef GMG_SYMV_U
+#undef GMG_SYMV_LAUNCH
     }
     if (sizeof(T) == 4) launch_cvt(h, c.x, c.x32, cnt);
 }

@@ -1770,7 +1770,7 @@ __global__ void permute_mass(const double* __restrict__ mass, const int* __restr
 // application, streamed -- the vectors are a few KB and stay in the caches), wave reduction in a fixed order.  x/y leading dimension ldv.
 // R rows per wave: the R rows share every load of x (with d = 3 and one row per wave the vectors were read three times as often as the matrix -- from the
 // L2, whose bandwidth then bounded the product: 288 MB in 95 us at n = 6 005); a row's sum keeps its order (lane-strided, then the shuffle tree).
-template <int D, int R>
+template <int D, int R, int U>
 __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ Ainv, int n, const double* __restrict__ x,
                                                      double* __restrict__ y, int ldv) {
     const int row0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * R;
@@ -1784,7 +1784,8 @@ __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ 
     const double* a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) a[r] = Ainv + (int64_t)(row0 + r < n ? row0 + r : row0) * n;      // (rows beyond the last: recomputed, not stored)
-    constexpr int U = R >= 4 ? 2 : 4;               // matrix loads in flight per lane: R * U
+    // U strides of 64 columns per trip: R * U matrix loads in flight per lane (a lane adds its products in ascending column order whatever U is: the
+    // same bits) -- few rows mean few waves, which then have to keep more bytes in flight each to cover the memory latency
     int j = lane;
     for (; j + 64 * (U - 1) < n; j += 64 * U) {
         double v[R][U], xv[U][D];
