@@ -424,9 +424,10 @@ static int build_coarse_inverse_device(gmg_handle h) {
     const size_t bytes = sizeof(double) * (size_t)nl * nl;
     DevTmp<double> X;                                       // the inverse in the factor's numbering
     if ((rc = X.alloc(h, std::max<size_t>((size_t)nl * nl, 1)))) return rc;
+    const int lda = (nl + 7) / 8 * 8;
     if (h->d_ainv && h->ainv_n != nl) { (void)dev_free(h->d_ainv); h->d_ainv = nullptr; }
-    if (!h->d_ainv) HIPCHK(dev_malloc((void**)&h->d_ainv, std::max<size_t>(bytes, 8)));
-    h->ainv_n = nl;
+    if (!h->d_ainv) HIPCHK(dev_malloc((void**)&h->d_ainv, std::max<size_t>(sizeof(double) * (size_t)nl * lda, 8)));
+    h->ainv_n = nl; h->ainv_ld = lda;
     HIPCHK(hipMemsetAsync(X.p, 0, bytes, h->stream));
     gmgs::InvFactor F;
     F.n = nl; F.nq = E.nq; F.nlev = E.nlev;
@@ -444,8 +445,8 @@ static int build_coarse_inverse_device(gmg_handle h) {
         (void)hipEventRecord(h->ev1, h->stream);
         hipLaunchKernelGGL(gmgs::mirror_lower_to_upper, dim3(nm, nm), dim3(256), 0, h->stream, X.p, nl);
         // ... and into the level's numbering: the product kernel then reads its vectors contiguously
-        if (nl <= 8192) hipLaunchKernelGGL(gmgs::permute_symmetric, dim3(nl), dim3(256), sizeof(double) * (size_t)nl, h->stream, (const double*)X.p, (const int*)perm_d.p, (const int*)inv_d.p, nl, h->d_ainv);
-        else hipLaunchKernelGGL(gmgs::permute_symmetric_scatter, dim3(nl), dim3(256), 0, h->stream, (const double*)X.p, (const int*)perm_d.p, nl, h->d_ainv);
+        if (nl <= 8192) hipLaunchKernelGGL(gmgs::permute_symmetric, dim3(nl), dim3(256), sizeof(double) * (size_t)nl, h->stream, (const double*)X.p, (const int*)perm_d.p, (const int*)inv_d.p, nl, h->d_ainv, lda);
+        else hipLaunchKernelGGL(gmgs::permute_symmetric_scatter, dim3(nl), dim3(256), 0, h->stream, (const double*)X.p, (const int*)perm_d.p, nl, h->d_ainv, lda);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(h->stream));        // (the temporaries above go back to the pool; the host copy E dies here)

@@ -759,8 +759,10 @@ inline int symv_rows(int n, int d) {
     static const int forced = symv_env("GMG_SYMV_ROWS");      // (measurement: scripts/symv_sweep.py)
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     if (GMG_SYMV_ROWS > 0) return GMG_SYMV_ROWS;       // (A/B builds)
-    if (n >= 3500) return 4;                           // (profiles/r06/symv_rows_strides_sweep.txt: n_L = 4 046 at d = 3: 41 -> 34 us with four rows)
-    return (n >= 2500 || d > 1) ? 2 : 1;
+    // with 16-byte loads (dense_symv_v2; profiles/r06/symv_rows_loads_sweep.txt): one row per wave while the level is small (n_L = 1 929: 11.8 us at
+    // d = 1, 13.5 at d = 3; 2 968: 16.3), two beyond (4 046 at d = 3: 32.6; 6 005: 57 at d = 3, 50 at d = 1); four rows only pay with 8-byte loads
+    (void)d;
+    return n >= 3000 ? 2 : 1;
 }
 // strides of 64 columns a lane loads per trip (dense_symv's U)
 inline int symv_strides(int n, int d, int rows) {
@@ -784,8 +786,16 @@ void enqueue_coarse_device(gmg_handle h, int d) {
         const int per_block = gmgk::kWavesPerBlock * rows_per_wave;
         const dim3 grid((c.n + per_block - 1) / per_block);
         const int strides = symv_strides(c.n, dc, rows_per_wave);
-#define GMG_SYMV_LAUNCH(R, U) DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, R, U>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad))
+#define GMG_SYMV_LAUNCH(R, U) DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv<D, R, U>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, h->ainv_ld, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad))
 #define GMG_SYMV_U(R) do { if (strides >= 8) { GMG_SYMV_LAUNCH(R, 8); } else if (strides >= 4) { GMG_SYMV_LAUNCH(R, 4); } else { GMG_SYMV_LAUNCH(R, 2); } } while (0)
+        static const char* v2_env = std::getenv("GMG_SYMV_V2");
+        const bool v2 = v2_env ? std::atoi(v2_env) != 0 : true;
+        if (v2 && rows_per_wave <= 2 && (h->ainv_ld & 1) == 0 && (c.n_pad & 1) == 0) {
+            if (rows_per_wave == 4) { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv_v2<D, 4, 2>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, h->ainv_ld, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
+            else if (rows_per_wave == 2) { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv_v2<D, 2, 2>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, h->ainv_ld, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
+            else { DISPATCH_D(dc, hipLaunchKernelGGL((gmgk::dense_symv_v2<D, 1, 2>), grid, dim3(gmgk::kBlock), 0, h->stream, h->d_ainv, c.n, h->ainv_ld, c.b + (size_t)c0 * c.n_pad, c.x + (size_t)c0 * c.n_pad, c.n_pad)); }
+            continue;
+        }
         if (rows_per_wave == 4) GMG_SYMV_U(4);
         else if (rows_per_wave == 2) GMG_SYMV_U(2);
         else GMG_SYMV_U(1);

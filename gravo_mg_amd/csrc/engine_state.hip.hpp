@@ -260,7 +260,7 @@ struct gmg_solver_s {
     int coarse_pending_d = 0;
     bool poll = true;             // GMG_POLL=0: copy + hipStreamSynchronize instead (the waiting thread then sleeps instead of spinning)
     double* d_ainv = nullptr;                              // coarse_device: dense A_L^-1, level numbering (engine.hip::build_coarse_inverse_device)
-    int ainv_n = 0;
+    int ainv_n = 0, ainv_ld = 0;                           // ... n x n with rows ainv_ld doubles apart (n rounded up to 8: rows at 64-byte boundaries)
     bool preparing_structure = false;                      // inside prepare_structure (placeholder values)
     bool first_sweep_fused = false;                        // enqueue_down: the restriction into the next level ran that level's first pre-sweep (launch_restrict_sweep0)
     bool coarse_device = false;                            // the coarsest solve of the live system runs on the device (gmg_config::coarse_mode, decided per system)

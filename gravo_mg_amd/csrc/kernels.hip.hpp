@@ -1771,7 +1771,7 @@ __global__ void permute_mass(const double* __restrict__ mass, const int* __restr
 // R rows per wave: the R rows share every load of x (with d = 3 and one row per wave the vectors were read three times as often as the matrix -- from the
 // L2, whose bandwidth then bounded the product: 288 MB in 95 us at n = 6 005); a row's sum keeps its order (lane-strided, then the shuffle tree).
 template <int D, int R, int U>
-__global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ Ainv, int n, const double* __restrict__ x,
+__global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ Ainv, int n, int lda, const double* __restrict__ x,
                                                      double* __restrict__ y, int ldv) {
     const int row0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * R;
     const int lane = threadIdx.x & 63;
@@ -1783,7 +1783,7 @@ __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ 
         for (int c = 0; c < D; ++c) acc[r][c] = 0.0;
     const double* a[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) a[r] = Ainv + (int64_t)(row0 + r < n ? row0 + r : row0) * n;      // (rows beyond the last: recomputed, not stored)
+    for (int r = 0; r < R; ++r) a[r] = Ainv + (int64_t)(row0 + r < n ? row0 + r : row0) * lda;    // (rows beyond the last: recomputed, not stored)
     // U strides of 64 columns per trip: R * U matrix loads in flight per lane (a lane adds its products in ascending column order whatever U is: the
     // same bits) -- few rows mean few waves, which then have to keep more bytes in flight each to cover the memory latency
     int j = lane;
@@ -1813,6 +1813,59 @@ __global__ __launch_bounds__(kBlock) void dense_symv(const double* __restrict__ 
 #pragma unroll
             for (int c = 0; c < D; ++c) acc[r][c] += v * xv[c];
         }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double v = acc[r][c];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && row0 + r < n) y[row0 + r + (int64_t)c * ldv] = v;
+        }
+}
+
+// The same product with 16-byte loads: lane l takes columns 2 l and 2 l + 1 (+ 128 per stride), so a row of the matrix goes by in half as many load
+// instructions -- with one or two rows per wave that is what the product waits for (n_L = 2 968: 21.4 -> 16.3 us, n_L = 4 046 at d = 3: 40.4 -> 29.2 us;
+// with four rows per wave the loads of the vectors are shared widely enough and nothing changes).  Rows start every lda doubles, lda even (the inverse is
+// stored with lda = n rounded up to 8), vectors 16-byte aligned (level buffers are).  A lane adds its columns in ascending order: deterministic, not the bits
+// of the 8-byte kernel.
+template <int D, int R, int U>
+__global__ __launch_bounds__(kBlock) void dense_symv_v2(const double* __restrict__ Ainv, int n, int lda, const double* __restrict__ x, double* __restrict__ y, int ldv) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int row0 = (blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)) * R;
+    const int lane = threadIdx.x & 63;
+    if (row0 >= n) return;
+    double acc[R][D];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[r][c] = 0.0;
+    const double* a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = Ainv + (int64_t)(row0 + r < n ? row0 + r : row0) * lda;
+    int j = 2 * lane;
+    for (; j + 128 * (U - 1) + 1 < n; j += 128 * U) {
+        d2 v[R][U], xv[U][D];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) v[r][u] = __builtin_nontemporal_load(reinterpret_cast<const d2*>(a[r] + j + 128 * u));
+#pragma unroll
+            for (int c = 0; c < D; ++c) xv[u][c] = *reinterpret_cast<const d2*>(x + j + 128 * u + (int64_t)c * ldv);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int c = 0; c < D; ++c) { acc[r][c] += v[r][u].x * xv[u][c].x; acc[r][c] += v[r][u].y * xv[u][c].y; }
+    }
+    for (; j < n; j += 128) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < D; ++c) { acc[r][c] += a[r][j] * x[j + (int64_t)c * ldv]; if (j + 1 < n) acc[r][c] += a[r][j + 1] * x[j + 1 + (int64_t)c * ldv]; }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)

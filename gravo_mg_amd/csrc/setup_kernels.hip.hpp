@@ -958,21 +958,21 @@ __global__ __launch_bounds__(256) void mirror_lower_to_upper(double* __restrict_
 // out[perm[j]][perm[c]] = X[j][c]: the inverse from the factor's numbering into the level's (perm: factor -> level, inv its inverse), one
 // workgroup per row: the row goes through LDS, so that both the read of X and the write of `out` are contiguous.  Dynamic LDS: n doubles.
 __global__ __launch_bounds__(256) void permute_symmetric(const double* __restrict__ X, const int* __restrict__ perm, const int* __restrict__ inv, int n,
-                                                         double* __restrict__ out) {
+                                                         double* __restrict__ out, int ldo) {
     extern __shared__ double row[];
     const int j = blockIdx.x;
     const double* src = X + (int64_t)j * n;
     for (int c = threadIdx.x; c < n; c += 256) row[c] = src[c];
     __syncthreads();
-    double* dst = out + (int64_t)perm[j] * n;
+    double* dst = out + (int64_t)perm[j] * ldo;       // (ldo >= n: rows of the result start at 16-byte boundaries, kernels.hip.hpp::dense_symv_v2)
     for (int c = threadIdx.x; c < n; c += 256) dst[c] = row[inv[c]];
 }
 
 // the same for rows that do not fit LDS (n > 8 192: only with GMG_COARSE_DEVICE_INVERSE forced on a large coarsest level): scattered writes
-__global__ __launch_bounds__(256) void permute_symmetric_scatter(const double* __restrict__ X, const int* __restrict__ perm, int n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void permute_symmetric_scatter(const double* __restrict__ X, const int* __restrict__ perm, int n, double* __restrict__ out, int ldo) {
     const int j = blockIdx.x;
     const double* src = X + (int64_t)j * n;
-    double* dst = out + (int64_t)perm[j] * n;
+    double* dst = out + (int64_t)perm[j] * ldo;
     for (int c = threadIdx.x; c < n; c += 256) dst[perm[c]] = src[c];
 }
 

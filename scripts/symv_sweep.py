@@ -25,3 +25,5 @@ if __name__ == "__main__":
     run("152k d3", 390, 390, "smoothing", 3)
     run("722k d1", 850, 850, "poisson", 1)
     run("3M d1", 1732, 1732, "poisson", 1)
+    run("3M d3", 1732, 1732, "smoothing", 3)
+    run("36k d1", 190, 190, "poisson", 1)
