@@ -885,6 +885,7 @@ static int set_system_impl(gmg_handle h, int n, const int* colptr, const int* ro
     // hierarchy's cluster order at hand the LHS pattern is permuted on the device first, so that the (sequential) greedy
     // colouring runs on a locally ordered graph; that needs the LHS on the device before the ordering task starts.
     reorder0 = mc && !ord_hit && !blocked0 && wants_locality_reorder(PatternView{n, colptr, rowidx}, h->cfg.reorder_fine);
+    if (reorder0) ahead.cancel();                  // (the level is coloured along another visit order: the loop started on the caller's order is of no use)
     bool A0_uploaded = false;
     if (early_upload && device_setup && h->cfg.device_rap) { free_csr(h->lv[0].dA); h->lv[0].dA = early_A0; early_A0 = DevCsr(); A0_uploaded = true; }
     // (h->cluster_order is only read once the patches are ready: build_patches may still be writing it)
