@@ -518,41 +518,94 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
     o.row_color.assign(o.n_pad, 0);
     o.blk_ncolors.assign(nb_all, 0);
     std::vector<int> color(n, -1);
-    // visit order of a block's members for the first-fit colouring: breadth-first (the members' order), or SMALLEST-LAST (repeatedly remove a vertex
-    // of least remaining in-block degree; colour in reverse removal order) -- on the Galerkin levels' in-block graphs ~13 % fewer colours, i.e. fewer
-    // sequential steps of the block sweep's in-block solve (kernels.hip.hpp::ep_block_lower).  EnvSwitches::block_smallest_last.
-    const bool smallest_last = EnvSwitches::get().block_smallest_last;
-    std::vector<int> pos_in_block;                 // a vertex's place among its block's members (the local numbering of the in-block graphs)
+    // visit order of a block's members for the first-fit colouring: breadth-first (the members' order; default), or SMALLEST-LAST (repeatedly remove a
+    // vertex of least remaining in-block degree; colour in reverse removal order; GMG_BLOCK_COLOURING=sl) -- on the Galerkin levels' in-block graphs
+    // ~13 % fewer colours, i.e. fewer sequential steps of the block sweep's in-block solve (kernels.hip.hpp::ep_block_lower): 3 M d = 3 0.998 -> 0.984 ms
+    // per cycle, point cloud 0.563 -> 0.556, d = 1 -2.8 us, same cycle counts.  Not the default: the ordering of the 506 k-row level takes 1.8 x as long
+    // (the local graph of every block has to be formed first), which the other host tasks of a set-up feel -- cold gmg_set_system 27 -> 36 ms at 3 M,
+    // structure preparation at hierarchy time +19 ms (profiles/r06/block_colouring_order_ab.txt); it pays for a hierarchy that solves thousands of cycles.
+    const int max_members = [&] { int m = 0; for (int b = 0; b < nb; ++b) m = std::max(m, mem_begin[b + 1] - mem_begin[b]); return m; }();
+    const bool smallest_last = EnvSwitches::get().block_smallest_last && nb < (1 << 21) && max_members <= 1024;
+    // block and place among its block's members of every vertex in one word (one random access per neighbour instead of two): block << 10 | place
+    std::vector<unsigned> packed;
     if (smallest_last) {
-        pos_in_block.assign((size_t)n, 0);
-        parallel_ranges(nb, T, [&](int lo, int hi, int) { for (int b = lo; b < hi; ++b) for (int m = mem_begin[b]; m < mem_begin[b + 1]; ++m) pos_in_block[(size_t)members[m]] = m - mem_begin[b]; }, 64);
+        packed.assign((size_t)n, 0u);
+        parallel_ranges(nb, T, [&](int lo, int hi, int) { for (int b = lo; b < hi; ++b) for (int m = mem_begin[b]; m < mem_begin[b + 1]; ++m) packed[(size_t)members[m]] = ((unsigned)b << 10) | (unsigned)(m - mem_begin[b]); }, 64);
     }
     parallel_ranges(nb, T, [&](int lo, int hi, int) {
         std::vector<char> forbid;
-        std::vector<int> mem, visit, deg, lptr, lidx;
+        std::vector<int> mem, visit, deg, lptr, lidx, lcol;
+        std::vector<uint64_t> bucket;
         std::vector<char> gone;
+        // (the scratch arrays of a block are a few hundred bytes each and are rewritten thousands of times per millisecond: as small heap blocks the arrays
+        // of different threads came to lie in the same cache lines, and eight threads took longer than one -- every array gets its capacity for the
+        // largest block at once, far beyond a cache line)
+        if (smallest_last) {
+            visit.reserve(4096); deg.reserve(4096); lptr.reserve(4096); lidx.reserve(65536); lcol.reserve(4096); gone.reserve(16384);
+            bucket.reserve((size_t)1025 * 16);
+        }
         for (int b = lo; b < hi; ++b) {
             int ncol = 0;
             const int m0 = mem_begin[b], mcount = mem_begin[b + 1] - m0;
             visit.resize((size_t)mcount);
             for (int i = 0; i < mcount; ++i) visit[(size_t)i] = members[m0 + i];
-            if (smallest_last && mcount > 2 && mcount <= 1024) {
-                // local adjacency of the in-block subgraph
+            bool coloured = false;
+            if (smallest_last && mcount > 2) {
+                // local adjacency of the in-block subgraph (places among the block's members)
                 lptr.assign((size_t)mcount + 1, 0); lidx.clear(); deg.assign((size_t)mcount, 0); gone.assign((size_t)mcount, 0);
                 for (int i = 0; i < mcount; ++i) {
                     const int v = members[m0 + i];
-                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { const int w = A.idx[p]; if (w != v && block_of[w] == b) lidx.push_back(pos_in_block[(size_t)w]); }
+                    if (i + 6 < mcount) { const int vn = members[m0 + i + 6]; __builtin_prefetch(&A.idx[A.ptr[vn]]); __builtin_prefetch(&A.idx[A.ptr[vn]] + 16); }
+                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { const int w = A.idx[p]; const unsigned pk = packed[(size_t)w]; if (w != v && (int)(pk >> 10) == b) lidx.push_back((int)(pk & 1023u)); }
                     lptr[(size_t)i + 1] = (int)lidx.size();
                 }
-                for (int i = 0; i < mcount; ++i) deg[(size_t)i] = lptr[(size_t)i + 1] - lptr[(size_t)i];
+                // buckets by remaining degree as bit sets over the block's members: the vertex of least degree -- the earliest member among equals -- is
+                // the lowest bit of the first non-empty bucket, and the least degree drops by at most one per removal
+                const int W = (mcount + 63) / 64;
+                int dmax = 0;
+                for (int i = 0; i < mcount; ++i) { deg[(size_t)i] = lptr[(size_t)i + 1] - lptr[(size_t)i]; dmax = std::max(dmax, deg[(size_t)i]); }
+                bucket.assign((size_t)(dmax + 1) * W, 0);
+                for (int i = 0; i < mcount; ++i) bucket[(size_t)deg[(size_t)i] * W + (i >> 6)] |= (uint64_t)1 << (i & 63);
+                int dmin = 0;
                 for (int step = mcount - 1; step >= 0; --step) {
                     int best = -1;
-                    for (int i = 0; i < mcount; ++i) if (!gone[(size_t)i] && (best < 0 || deg[(size_t)i] < deg[(size_t)best])) best = i;      // (ties: the earlier member)
+                    for (dmin = std::max(dmin - 1, 0); dmin <= dmax && best < 0; ++dmin)
+                        for (int q = 0; q < W; ++q) { const uint64_t bits = bucket[(size_t)dmin * W + q]; if (bits) { best = q * 64 + __builtin_ctzll(bits); break; } }
+                    --dmin;                                                    // (the bucket the vertex came from)
                     gone[(size_t)best] = 1;
-                    visit[(size_t)step] = members[m0 + best];
-                    for (int p = lptr[(size_t)best]; p < lptr[(size_t)best + 1]; ++p) if (!gone[(size_t)lidx[(size_t)p]]) --deg[(size_t)lidx[(size_t)p]];
+                    bucket[(size_t)deg[(size_t)best] * W + (best >> 6)] &= ~((uint64_t)1 << (best & 63));
+                    visit[(size_t)step] = best;                                // (a place, not a vertex: the colouring below stays in the local graph)
+                    for (int p = lptr[(size_t)best]; p < lptr[(size_t)best + 1]; ++p) {
+                        const int w = lidx[(size_t)p];
+                        if (gone[(size_t)w]) continue;
+                        bucket[(size_t)deg[(size_t)w] * W + (w >> 6)] &= ~((uint64_t)1 << (w & 63));
+                        --deg[(size_t)w];
+                        bucket[(size_t)deg[(size_t)w] * W + (w >> 6)] |= (uint64_t)1 << (w & 63);
+                    }
                 }
+                // first fit in that order, on the local graph
+                lcol.assign((size_t)mcount, -1);
+                for (int m = 0; m < mcount; ++m) {
+                    const int i = visit[(size_t)m];
+                    uint64_t mask = 0;
+                    bool wide = false;
+                    for (int p = lptr[(size_t)i]; p < lptr[(size_t)i + 1]; ++p) { const int cw = lcol[(size_t)lidx[(size_t)p]]; if (cw >= 64) wide = true; else if (cw >= 0) mask |= (uint64_t)1 << cw; }
+                    int c;
+                    if (~mask != 0) c = __builtin_ctzll(~mask);
+                    else {
+                        (void)wide;
+                        forbid.assign((size_t)ncol + 1, 0);
+                        for (int p = lptr[(size_t)i]; p < lptr[(size_t)i + 1]; ++p) { const int cw = lcol[(size_t)lidx[(size_t)p]]; if (cw >= 0) forbid[(size_t)cw] = 1; }
+                        c = 64;
+                        while (c < ncol && forbid[(size_t)c]) ++c;
+                    }
+                    lcol[(size_t)i] = c;
+                    if (c >= ncol) ncol = c + 1;
+                }
+                for (int i = 0; i < mcount; ++i) color[(size_t)members[m0 + i]] = lcol[(size_t)i];
+                coloured = true;
             }
+            if (!coloured)
             for (int m = 0; m < mcount; ++m) {
                 const int v = visit[(size_t)m];
                 // the members come in breadth-first order, their rows from all over A: fetch the row a few members ahead
