@@ -518,12 +518,13 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
     o.row_color.assign(o.n_pad, 0);
     o.blk_ncolors.assign(nb_all, 0);
     std::vector<int> color(n, -1);
-    // visit order of a block's members for the first-fit colouring: breadth-first (the members' order; default), or SMALLEST-LAST (repeatedly remove a
-    // vertex of least remaining in-block degree; colour in reverse removal order; GMG_BLOCK_COLOURING=sl) -- on the Galerkin levels' in-block graphs
-    // ~13 % fewer colours, i.e. fewer sequential steps of the block sweep's in-block solve (kernels.hip.hpp::ep_block_lower): 3 M d = 3 0.998 -> 0.984 ms
-    // per cycle, point cloud 0.563 -> 0.556, d = 1 -2.8 us, same cycle counts.  Not the default: the ordering of the 506 k-row level takes 1.8 x as long
-    // (the local graph of every block has to be formed first), which the other host tasks of a set-up feel -- cold gmg_set_system 27 -> 36 ms at 3 M,
-    // structure preparation at hierarchy time +19 ms (profiles/r06/block_colouring_order_ab.txt); it pays for a hierarchy that solves thousands of cycles.
+    // visit order of a block's members for the first-fit colouring: SMALLEST-LAST (repeatedly remove a vertex of least remaining in-block degree; colour
+    // in reverse removal order; default since round 6) or breadth-first (the members' order; GMG_BLOCK_COLOURING=bfs) -- on the Galerkin levels' in-block
+    // graphs smallest-last needs ~13 % fewer colours, i.e. fewer sequential steps of the block sweep's in-block solve (kernels.hip.hpp::ep_block_lower):
+    // 3 M d = 3 0.998 -> 0.984 ms per cycle, point cloud 0.563 -> 0.556, d = 1 -2.8 us, same cycle counts.  A first version (local graphs as index
+    // lists, a scan per removal, then buckets) made the ordering of the 506 k-row level 1.8 x as slow and a cold gmg_set_system 9 ms longer; with a
+    // 64-row block's graph as 64 words and its degrees as 64 bytes the ordering tasks take 1-2 ms more than breadth-first and run beside each other
+    // (profiles/r06/block_colouring_order_ab.txt).
     const int max_members = [&] { int m = 0; for (int b = 0; b < nb; ++b) m = std::max(m, mem_begin[b + 1] - mem_begin[b]); return m; }();
     const bool smallest_last = EnvSwitches::get().block_smallest_last && nb < (1 << 21) && max_members <= 1024;
     // block and place among its block's members of every vertex in one word (one random access per neighbour instead of two): block << 10 | place
@@ -550,7 +551,45 @@ inline LevelOrdering make_block_ordering(const Mat& A, int block_rows, const Pat
             visit.resize((size_t)mcount);
             for (int i = 0; i < mcount; ++i) visit[(size_t)i] = members[m0 + i];
             bool coloured = false;
-            if (smallest_last && mcount > 2) {
+            if (smallest_last && mcount > 2 && mcount <= 64) {
+                // a block of one wavefront's rows: the in-block graph as one 64-bit word per member, remaining degrees as bytes (a removed member's
+                // degree becomes 255, so the least degree is a plain minimum over 64 bytes), first fit over the words -- ~1.5 us per block on top of the
+                // row scan every ordering of the block needs
+                uint64_t adj[64];
+                unsigned char dg[64];
+                for (int i = 0; i < 64; ++i) { adj[i] = 0; dg[i] = 255; }
+                for (int i = 0; i < mcount; ++i) {
+                    const int v = members[m0 + i];
+                    if (i + 6 < mcount) { const int vn = members[m0 + i + 6]; __builtin_prefetch(&A.idx[A.ptr[vn]]); __builtin_prefetch(&A.idx[A.ptr[vn]] + 16); }
+                    uint64_t a = 0;
+                    for (int p = A.ptr[v]; p < A.ptr[v + 1]; ++p) { const int w = A.idx[p]; const unsigned pk = packed[(size_t)w]; if (w != v && (int)(pk >> 10) == b) a |= (uint64_t)1 << (pk & 63u); }
+                    adj[i] = a;
+                    dg[i] = (unsigned char)__builtin_popcountll(a);
+                }
+                int order[64];
+                for (int step = mcount - 1; step >= 0; --step) {
+                    int best = 0;
+                    unsigned char bd = dg[0];
+                    for (int i = 1; i < 64; ++i) if (dg[i] < bd) { bd = dg[i]; best = i; }      // (the earliest member among equals)
+                    dg[best] = 255;
+                    order[step] = best;
+                    for (uint64_t nb_bits = adj[best]; nb_bits; nb_bits &= nb_bits - 1) { const int w = __builtin_ctzll(nb_bits); if (dg[w] != 255) --dg[w]; }
+                }
+                signed char lc8[64];
+                for (int i = 0; i < 64; ++i) lc8[i] = -1;
+                for (int m = 0; m < mcount; ++m) {
+                    const int i = order[m];
+                    uint64_t mask = 0;
+                    for (uint64_t nb_bits = adj[i]; nb_bits; nb_bits &= nb_bits - 1) { const int cw = lc8[__builtin_ctzll(nb_bits)]; if (cw >= 0) mask |= (uint64_t)1 << cw; }
+                    const int c = __builtin_ctzll(~mask);                    // (at most 63 neighbours: a colour below 64 is free)
+                    lc8[i] = (signed char)c;
+                    if (c >= ncol) ncol = c + 1;
+                }
+                for (int i = 0; i < mcount; ++i) color[(size_t)members[m0 + i]] = lc8[i];
+                coloured = true;
+            }
+            if (!coloured && smallest_last && mcount > 2) {
+                // (bigger blocks -- the 256-row blocks of the quad layout: the same order with buckets by remaining degree)
                 // local adjacency of the in-block subgraph (places among the block's members)
                 lptr.assign((size_t)mcount + 1, 0); lidx.clear(); deg.assign((size_t)mcount, 0); gone.assign((size_t)mcount, 0);
                 for (int i = 0; i < mcount; ++i) {

@@ -95,7 +95,7 @@ struct Compressed {
 struct EnvSwitches {
     int host_threads = 0, local_world = 0, ldlt_threads = 0;
     bool trace_setup = false, trace_ldlt = false, trace_ctor = false, poll = true, segv_backtrace = false;
-    bool block_smallest_last = false;      // GMG_BLOCK_COLOURING=sl: in-block colouring in smallest-last instead of breadth-first order (host_plan.hpp::make_block_ordering)
+    bool block_smallest_last = true;       // GMG_BLOCK_COLOURING=bfs: in-block colouring in breadth-first instead of smallest-last order (host_plan.hpp::make_block_ordering)
     double p2p_timeout_s = 0.0;
     bool p2p_fence_free = false, publish_fenced = false, p2p_shared_device = false;
     static const EnvSwitches& get() {
@@ -105,7 +105,7 @@ struct EnvSwitches {
             if (num("GMG_HOST_THREADS") > 0) e.host_threads = (int)num("GMG_HOST_THREADS");
             if (num("LOCAL_WORLD_SIZE") > 1) e.local_world = (int)num("LOCAL_WORLD_SIZE");
             if (num("GMG_LDLT_THREADS") > 0) e.ldlt_threads = (int)num("GMG_LDLT_THREADS");
-            if (const char* t = std::getenv("GMG_BLOCK_COLOURING")) e.block_smallest_last = std::string(t) == "sl";
+            if (const char* t = std::getenv("GMG_BLOCK_COLOURING")) e.block_smallest_last = std::string(t) != "bfs";
             if (const char* t = std::getenv("GMG_TRACE")) { const std::string s(t); e.trace_setup = s.find("setup") != std::string::npos; e.trace_ldlt = s.find("ldlt") != std::string::npos; e.trace_ctor = s.find("ctor") != std::string::npos; }
             e.poll = num("GMG_POLL") != 0.0;
             if (num("GMG_P2P_TIMEOUT_S") > 0) e.p2p_timeout_s = num("GMG_P2P_TIMEOUT_S");

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from gravo_mg_amd import cabi, meshgen
-tag = os.environ.get("GMG_BLOCK_COLOURING", "bfs")
+tag = os.environ.get("GMG_BLOCK_COLOURING", "sl")
 
 def run(name, H, mass, lhs, rhs, steps=100, tol=1e-4):
     eng = cabi.Engine()

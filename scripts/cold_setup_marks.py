@@ -20,6 +20,11 @@ def run():
         except Exception:
             pass
     marks["colored_ahead"] = eng.timing("setup_colored_ahead")
+    for k in range(5):
+        try:
+            marks[f"(ordering task of level {k}: ms)"] = round(eng.timing(f"setup_ordering_l{k}"), 2)
+        except Exception:
+            pass
     return ms, sorted(marks.items(), key=lambda kv: kv[1])
 run()
 for _ in range(2):
