@@ -196,7 +196,7 @@ def test_block_ordering_is_compact_and_properly_coloured(cabi, order):
     P = problems.torus_problem(72, 60, "poisson", 40, order=order)
     A = sp.csc_matrix(P.U[0].T @ P.lhs @ P.U[0])
     n = A.shape[0]
-    for rows in (128, 256):
+    for rows in (64, 128, 256):          # (64: a block is one word per member in the smallest-last colouring; beyond: its bucket form)
         plan = cabi.host_plan_level(A, mode=1, block_rows=rows)
         new2old, bb, rc = plan["new2old"], plan["blk_begin"], plan["row_color"]
         assert sorted(new2old[new2old >= 0]) == list(range(n))
@@ -213,6 +213,30 @@ def test_block_ordering_is_compact_and_properly_coloured(cabi, order):
         # colours ascend inside a block
         d_blk = np.diff(blk_dev[real]); d_col = np.diff(rc[real].astype(int))
         assert np.all((d_col >= 0) | (d_blk != 0))
+
+
+def test_smallest_last_in_block_colouring_needs_no_more_colours_and_does_not_depend_on_the_threads(cabi):
+    """The block sweeps walk a block's colours one after the other, so the in-block colouring visits a block's rows in smallest-last order (default;
+    GMG_BLOCK_COLOURING=bfs: breadth-first, rounds 2-5).  The switches are read once per process: child processes give the breadth-first colouring
+    and the one-thread result of the same level."""
+    import json, subprocess, sys, os
+    code = ("import sys, json, numpy as np, scipy.sparse as sp; sys.path.insert(0, %r); from gravo_mg_amd import cabi; from tests import problems; "
+            "P = problems.torus_problem(150, 140, 'poisson', 100); A = sp.csc_matrix(P.U[0].T @ P.lhs @ P.U[0]); out = {}\n"
+            "for rows in (64, 256):\n"
+            "    plan = cabi.host_plan_level(A, mode=1, block_rows=rows); bb = plan['blk_begin']; rc = plan['row_color']\n"
+            "    out[str(rows)] = {'colours': [int(rc[bb[b]:bb[b + 1]].max()) + 1 for b in range(len(bb) - 1)], 'sum': int(np.dot(plan['new2old'].astype(np.int64) + 2, np.arange(len(plan['new2old'])) %% 1000003))}\n"
+            "print(json.dumps(out))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(**env):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    sl, bfs, sl1 = run(), run(GMG_BLOCK_COLOURING="bfs"), run(GMG_HOST_THREADS="1")
+    for rows in ("64", "256"):
+        assert sl[rows] == sl1[rows]                                             # same ordering whatever the number of threads
+        a, b = np.array(sl[rows]["colours"]), np.array(bfs[rows]["colours"])
+        assert a.shape == b.shape and a.mean() <= b.mean() and a.max() <= b.max()
+    assert np.mean(sl["64"]["colours"]) <= 0.95 * np.mean(bfs["64"]["colours"])   # (Galerkin level of a mesh: ~13 % fewer)
 
 
 def test_missing_diagonal_is_a_numeric_error(cabi):
