@@ -202,3 +202,28 @@ def test_the_distributed_path_takes_a_blocked_level_0(cabi):
     three.dist_setup(1, 3)
     assert (three.level_info(0)["n_pad"] // 64) % 3 == 0
     _engine(cabi, P, row_align=128, block_fine=0).dist_setup(0, 2)
+
+
+def test_both_in_block_colouring_orders_solve_the_same_systems(cabi):
+    """The in-block colouring of the block sweeps follows a smallest-last order (default) or the breadth-first order of rounds 2-5
+    (GMG_BLOCK_COLOURING=bfs; the switch is read once per process, hence the child): two orderings of the same block Gauss-Seidel smoother -- both
+    converge to the same solution in (about) the same number of cycles, and the default needs no more colours on any level."""
+    import json, os, subprocess, sys
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); from gravo_mg_amd import cabi; from tests import problems; out = {}\n"
+            "for name, P in (('torus', problems.torus_problem(300, 280, 'poisson', 100)), ('cloud', problems.pointcloud_problem(9000, 8, 120))):\n"
+            "    e = cabi.Engine(); e.set_prolongations(P.U); e.set_mass(P.mass); e.set_system(P.lhs)\n"
+            "    x, it, res, conv = e.solve(P.rhs, tol=1e-6, max_iter=100)\n"
+            "    out[name] = {'it': int(it), 'res': float(res), 'x': np.asarray(x).ravel()[::97].tolist(), 'colours': [int(e.level_info(k).get('n_colors') or 0) for k in range(e.num_levels + 1)]}\n"
+            "print(json.dumps(out))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(**env):
+        e = dict(os.environ); e.update(env)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    sl, bfs = run(), run(GMG_BLOCK_COLOURING="bfs")
+    for name in ("torus", "cloud"):
+        a, b = sl[name], bfs[name]
+        assert a["res"] <= 1e-6 and b["res"] <= 1e-6 and abs(a["it"] - b["it"]) <= 1, (name, a["it"], b["it"])
+        xa, xb = np.array(a["x"]), np.array(b["x"])
+        assert np.linalg.norm(xa - xb) <= 1e-4 * np.linalg.norm(xb), name
+        assert all(ca <= cb for ca, cb in zip(a["colours"][1:], b["colours"][1:])), (name, a["colours"], b["colours"])
